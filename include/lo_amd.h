@@ -1,0 +1,178 @@
+/* lo_amd.h -- C ABI of liblo_amd.so: MI355X (gfx950) kernels for linear_operator's
+ * iterative solve / logdet hot path.
+ *
+ * The reference (cornellius-gp/linear_operator) is pure Python and has no FFI; the seams this
+ * library sits behind are the reference's own plug-in points:
+ *   - linear_operator.utils.linear_cg          (linear_operator/utils/linear_cg.py:98-109, looked up
+ *                                                at call time in operators/_linear_operator.py:796)
+ *   - LinearOperator._matmul                    (operators/_linear_operator.py:169-190)
+ *   - AddedDiagLinearOperator._preconditioner   (operators/added_diag_linear_operator.py:95-142)
+ *   - PivotedCholesky.forward                   (functions/_pivoted_cholesky.py:14-105)
+ *   - lanczos_tridiag / lanczos_tridiag_to_diag (utils/lanczos.py:9-189), StochasticLQ.to_dense
+ *                                                (utils/stochastic_lq.py:45-82)
+ * Each entry point below cites the reference interface it replaces.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all tensors are DEVICE pointers, fp32 (`float`), row-major contiguous, in the reference's
+ *     layouts: vectors [B, N, c] with the column index c innermost; matrices [B, rows, cols];
+ *     permutations int64 [B, N].  B is the flattened batch (product of the reference's *batch dims).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous
+ *     unless stated; the library never allocates device memory: the caller provides workspaces
+ *     whose sizes come from the matching *_workspace_bytes query (host side: torch.empty).
+ *   - return value: 0 = ok, <0 = LO_ERR_* (bad arguments, launch failure).  Numerical conditions
+ *     (NaN in a matvec, non-convergence) are reported through lo_cg_info, and are mapped by the
+ *     host shim to the reference's RuntimeError / NumericalWarning (linear_cg.py:199-200,337-347).
+ *   - pointers are borrowed for the duration of the call only (asynchronous calls: until the
+ *     stream has drained); inputs are never written (reference: linear_cg.py:182-190 allocates).
+ */
+#ifndef LO_AMD_H
+#define LO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LO_OK 0
+#define LO_ERR_BADARG (-1)
+#define LO_ERR_LAUNCH (-2)
+#define LO_ERR_WORKSPACE (-3)
+#define LO_ERR_UNSUPPORTED (-4)
+
+/* operator kinds: the `_matmul`s that feed CG */
+#define LO_OP_LOWRANK_DIAG 0 /* AddedDiag(Root/LowRankRoot(C), Diag(d)):  y = C (C^T v) + d o v       */
+#define LO_OP_DENSE_DIAG 1   /* AddedDiag(Dense(K), Diag(d)):             y = K v + d o v             */
+#define LO_OP_KRON_DIAG 2    /* AddedDiag(Kron(K1,K2), Diag(d)):          y = (K1 (x) K2) v + d o v   */
+#define LO_OP_CALLBACK 3     /* opaque closure (the reference's matmul_closure argument)              */
+
+/* diagonal storage */
+#define LO_DIAG_NONE 0  /* no diagonal term (plain Root / Dense / Kron operator)                    */
+#define LO_DIAG_FULL 1  /* DiagLinearOperator._diag [B, N]         (diag_linear_operator.py:25)      */
+#define LO_DIAG_CONST 2 /* ConstantDiagLinearOperator.diag_values [B] (diag_linear_operator.py:313)  */
+
+/* Operator descriptor ("op-tree lowering" of an AddedDiag/Sum tree). */
+typedef struct lo_op_desc {
+  int32_t kind;      /* LO_OP_*                                                                    */
+  int32_t diag_mode; /* LO_DIAG_*                                                                  */
+  int64_t B;         /* batch members                                                              */
+  int64_t N;         /* matrix size (rows == cols)                                                 */
+  int64_t R;         /* LOWRANK: root rank R (C is [B,N,R]);  KRON: n1;  DENSE: unused             */
+  int64_t n2;        /* KRON: n2 (N == n1*n2); others unused                                       */
+  const float* A0;   /* LOWRANK: C [B,N,R];  DENSE: K [B,N,N];  KRON: K1 [B,n1,n1]                 */
+  const float* A1;   /* KRON: K2 [B,n2,n2]; others NULL                                            */
+  const float* d;    /* diagonal, layout per diag_mode (NULL if LO_DIAG_NONE)                      */
+} lo_op_desc;
+
+/* Callbacks for LO_OP_CALLBACK and for a user preconditioner closure.
+ * v, y: device pointers [B, N, c] fp32 contiguous.  Must enqueue on `stream`.  Return 0 on success. */
+typedef int (*lo_matvec_cb)(void* user, const float* v, float* y, int64_t B, int64_t N, int64_t c, void* stream);
+
+/* Pivoted-Cholesky/QR Woodbury preconditioner  P = L L^T + D  (added_diag_linear_operator.py:95-184)
+ * in the form the reference caches it: z = r/d - Q (Q^T r)   (non-constant diag, :140)
+ *                                     z = (r - Q Q^T r)/sigma (constant diag, :137-139)          */
+typedef struct lo_precond_desc {
+  int32_t k;             /* rank of Q (<= 32)                                                     */
+  int32_t constant_diag; /* 1: `dinv` holds 1/sigma per member [B]; 0: `dinv` holds 1/d [B,N]      */
+  const float* Q;        /* [B, N, k]  (_q_cache)                                                  */
+  const float* dinv;     /* reciprocal noise                                                       */
+} lo_precond_desc;
+
+/* linear_cg arguments that are scalars in the reference signature (linear_cg.py:98-109). */
+typedef struct lo_cg_params {
+  int64_t c;                /* number of right-hand-side columns                                  */
+  int32_t n_tridiag;        /* tridiagonalise the first n_tridiag columns (0 = none)              */
+  int32_t max_iter;         /* n_iter (already min'ed with N if terminate_cg_by_size, :170)        */
+  int32_t max_tridiag_iter; /* n_tridiag_iter = min(max_tridiag_iter, N) (:171)                    */
+  int32_t reserved;
+  float tolerance;          /* settings.cg_tolerance (:150-151)                                    */
+  float eps;                /* 1e-10 (:104)                                                        */
+  float stop_updating_after;/* 1e-10 (:105)                                                        */
+  float pad;
+} lo_cg_params;
+
+/* What the reference reports through its warning text / exception (host-readable after the call). */
+typedef struct lo_cg_info {
+  int32_t iterations;        /* loop bodies executed (k+1 of linear_cg.py:343)                     */
+  int32_t matvecs;           /* operator applications actually executed                            */
+  int32_t tolerance_reached; /* linear_cg.py:307                                                   */
+  int32_t nan_detected;      /* linear_cg.py:199-200                                               */
+  int32_t skipped;           /* all columns converged before the first iteration (:207-208)        */
+  int32_t last_tridiag_iter; /* t_mat is valid on [0..last_tridiag_iter]^2 (:353)                  */
+  float mean_residual;       /* residual_norm.mean() at exit (:343)                                */
+  float reserved;
+} lo_cg_info;
+
+/* ---- library ------------------------------------------------------------------------------- */
+/* ABI version (bumped on any signature change) and the gfx arch string the code objects target. */
+int lo_abi_version(void);
+const char* lo_target_arch(void);
+
+/* ---- structured matvecs: LinearOperator._matmul for the hot-path operator classes ----------- */
+/* y[B,N,c] = A v.  Replaces AddedDiagLinearOperator._matmul (added_diag_linear_operator.py:72-76)
+ * over RootLinearOperator._matmul (root_linear_operator.py:68-72), DenseLinearOperator._matmul
+ * (dense_linear_operator.py:60-64), KroneckerProductLinearOperator._matmul
+ * (kronecker_product_linear_operator.py:272-284), Diag/ConstantDiag (diag_linear_operator.py:203-230). */
+size_t lo_matvec_workspace_bytes(const lo_op_desc* op, int64_t c);
+int lo_matvec_f32(const lo_op_desc* op, const float* v, float* y, int64_t c, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- linear_cg (linear_operator/utils/linear_cg.py:98-359) ----------------------------------- */
+/* Solves A X = rhs for all B members and c columns with the reference's modified preconditioned CG
+ * (column normalisation, masked alpha/beta, batch-global stopping rule, CG-coefficient tridiagonals).
+ *   op        structured operator, or kind LO_OP_CALLBACK with (matvec, matvec_user)
+ *   pre       NULL | Woodbury-QR preconditioner;  precond_cb non-NULL = opaque preconditioner closure
+ *   rhs       [B,N,c]      x0  [B,N,c] or NULL (zeros)        x  [B,N,c] out
+ *   t_mat     [n_tridiag, B, T, T] out, T = max_tridiag_iter, zero-filled by the call; the caller crops
+ *             to [: last_tridiag_iter+1]^2 (linear_cg.py:353-357)
+ * SYNCHRONOUS: polls the device stop flag between launch chunks and returns with `info` filled.  */
+size_t lo_cg_workspace_bytes(const lo_op_desc* op, const lo_precond_desc* pre, const lo_cg_params* prm);
+int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user, const lo_precond_desc* pre,
+                    lo_matvec_cb precond_cb, void* precond_user, const lo_cg_params* prm, const float* rhs,
+                    const float* x0, float* x, float* t_mat, void* ws, size_t ws_bytes, lo_cg_info* info,
+                    void* stream);
+
+/* ---- PivotedCholesky.forward (linear_operator/functions/_pivoted_cholesky.py:14-105) ---------- */
+/* Greedy partial pivoted Cholesky of the NON-diagonal part of `op` (op->d is ignored, as
+ * added_diag_linear_operator.py:125 calls self._linear_op.pivoted_cholesky).
+ *   L_rows  [B, max_rank, N] out (row m = column m of L; the host returns L_rows[:, :m].mT.contiguous())
+ *   perm    [B, N] int64 out (full permutation; first m entries are the pivots)
+ *   rank_out host int: number of pivots m taken (shared by the whole batch, :57)
+ * SYNCHRONOUS (reads m back).                                                                      */
+size_t lo_pivoted_cholesky_workspace_bytes(const lo_op_desc* op, int32_t max_rank);
+int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_tol, float* L_rows, int64_t* perm,
+                            int32_t* rank_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- AddedDiagLinearOperator._init_cache* (added_diag_linear_operator.py:144-184) ------------- */
+/* From L [B,N,k] and the diagonal builds Q [B,N,k] (the reference's _q_cache, up to the sign/rotation
+ * freedom of a thin QR, which Q Q^T is invariant to), dinv and logdet_p [B].
+ * Gram matrix + Cholesky + triangular solve in fp64, rounded once to fp32.            */
+size_t lo_precond_build_workspace_bytes(int64_t B, int64_t N, int32_t k);
+int lo_precond_build_f32(const float* L, const float* d, int32_t diag_mode, int64_t B, int64_t N, int32_t k, float* Q,
+                         float* dinv, float* logdet_p, void* ws, size_t ws_bytes, void* stream);
+/* z = P^{-1} r  (precondition_closure, added_diag_linear_operator.py:135-140) */
+size_t lo_precond_apply_workspace_bytes(int64_t B, int64_t N, int32_t k, int64_t c);
+int lo_precond_apply_f32(const lo_precond_desc* pre, const float* r, float* z, int64_t B, int64_t N, int64_t c, void* ws,
+                         size_t ws_bytes, void* stream);
+
+/* ---- lanczos_tridiag (linear_operator/utils/lanczos.py:9-164) --------------------------------- */
+/*   init_vecs [B,N,P];  q_mat [max_iter, B, N, P] out;  t_mat [max_iter, max_iter, B, P] out (reference
+ *   storage order, :69-77; the host permutes/crops as :151-161);  iters_out = k+1 (:151). SYNCHRONOUS. */
+size_t lo_lanczos_workspace_bytes(const lo_op_desc* op, int64_t P, int32_t max_iter);
+int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user, const float* init_vecs,
+                           int64_t P, int32_t max_iter, float tol, float* q_mat, float* t_mat, int32_t* iters_out,
+                           void* ws, size_t ws_bytes, void* stream);
+
+/* ---- lanczos_tridiag_to_diag + StochasticLQ.to_dense (lanczos.py:167-189, stochastic_lq.py:45-82) */
+/* t_mat [M, T, T] (M = P*B tridiagonals, only the three diagonals are read) ->
+ *   evals [M, T], evecs [M, T, T] (column j = eigenvector j; negative eigenvalues -> 1 and their
+ *   eigenvector columns zeroed, lanczos.py:185-187).  evecs may be NULL.
+ * If logdet != NULL (size B): logdet[b] = (n / P) * sum_p sum_i evecs[p,b,0,i]^2 log(evals[p,b,i]).   */
+int lo_tridiag_eigh_slq_f32(const float* t_mat, int64_t P, int64_t B, int32_t T, int64_t n, float* evals, float* evecs,
+                            float* logdet, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LO_AMD_H */

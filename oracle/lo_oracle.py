@@ -1,0 +1,545 @@
+"""CPU ORACLE -- test infrastructure only, never a product path.
+
+A numpy restatement of the reference's iterative solve / logdet hot path
+(cornellius-gp/linear_operator @ /root/reference).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module, and only as the *checker* -- the shipped package
+(``linear_operator_amd``) never imports it and has no CPU fallback.
+
+Parity is PINNED: ``tests/golden/make_golden.py`` runs the real reference (imported
+from /root/reference in the build container) on seeded inputs and commits its
+outputs as ``tests/golden/*.npz``; ``tests/test_oracle_vs_golden.py`` checks every
+function below against those vectors (pivots bit-exact, floats <= 1e-5 rel).
+
+Every function cites the reference file:line it restates.  Arithmetic is done in
+the dtype of the inputs (fp32 for the benchmark configs, fp64 for the reference's
+own unit-test recipes).  Where the order of floating point operations decides an
+*integer* result (pivot selection in pivoted Cholesky) the order is spelled out:
+sequential left-to-right sums, products rounded before summation, no FMA -- the
+HIP kernels use exactly the same order, so pivots and L agree bit for bit.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# ----------------------------------------------------------------------------------
+# structured matvecs  (the `_matmul`s that feed CG)
+# ----------------------------------------------------------------------------------
+
+
+def matvec_lowrank_diag(C, d, v):
+    """y = C (C^T v) + d o v.
+
+    reference: AddedDiagLinearOperator._matmul (operators/added_diag_linear_operator.py:72-76)
+    -> RootLinearOperator._matmul (operators/root_linear_operator.py:68-72)
+    -> DenseLinearOperator._t_matmul/_matmul (operators/dense_linear_operator.py:84-88, 60-64).
+    C [*B,N,R], d [*B,N], v [*B,N,c].
+    """
+    t = np.matmul(np.swapaxes(C, -1, -2), v)
+    return np.matmul(C, t) + d[..., None] * v
+
+
+def matvec_dense_diag(K, d, v):
+    """y = K v + d o v.  reference: added_diag_linear_operator.py:72-76 + dense_linear_operator.py:60-64."""
+    return np.matmul(K, v) + d[..., None] * v
+
+
+def matvec_kron(K1, K2, v):
+    """y = (K1 (x) K2) v  ==  vec(K1 V K2^T) with V = v.reshape(n1, n2, c).
+
+    reference: module-level _matmul in operators/kronecker_product_linear_operator.py:34-45
+    (per factor: view [n_i, -1], factor matmul, view/transpose(-3,-2)/reshape).
+    """
+    n1, n2 = K1.shape[-1], K2.shape[-1]
+    bshape = v.shape[:-2]
+    c = v.shape[-1]
+    V = v.reshape(*bshape, n1, n2 * c)
+    W = np.matmul(K1, V).reshape(*bshape, n1, n2, c)  # [i1, j2, c]
+    W = np.swapaxes(W, -3, -2).reshape(*bshape, n2, n1 * c)  # [j2, i1*c]
+    Y = np.matmul(K2, W).reshape(*bshape, n2, n1, c)  # [i2, i1, c]
+    return np.swapaxes(Y, -3, -2).reshape(*bshape, n1 * n2, c)
+
+
+def matvec_kron_diag(K1, K2, d, v):
+    """y = (K1 (x) K2) v + d o v (added_diag_linear_operator.py:72-76 over the Kron matvec)."""
+    return matvec_kron(K1, K2, v) + d[..., None] * v
+
+
+# ----------------------------------------------------------------------------------
+# linear_cg  (HOT LOOP A)
+# ----------------------------------------------------------------------------------
+
+
+class CGInfo:
+    """Side information the reference only exposes through its warning text."""
+
+    def __init__(self):
+        self.iterations = 0  # number of loop bodies executed (k+1 at exit)
+        self.matvecs = 0  # closure calls (1 + iterations, linear_cg.py:186,248)
+        self.tolerance_reached = False
+        self.mean_residual = float("nan")
+        self.skipped = False  # linear_cg.py:207-208
+        self.last_tridiag_iter = 0
+
+
+def linear_cg(
+    matmul_closure,
+    rhs,
+    n_tridiag=0,
+    tolerance=1.0,
+    eps=1e-10,
+    stop_updating_after=1e-10,
+    max_iter=1000,
+    max_tridiag_iter=20,
+    initial_guess=None,
+    preconditioner=None,
+    terminate_cg_by_size=False,
+):
+    """Batched modified preconditioned CG, restating linear_operator/utils/linear_cg.py:98-359.
+
+    Returns (x, t_mat_or_None, CGInfo).  Defaults are the reference's settings defaults
+    (settings.py: cg_tolerance=1, max_cg_iterations=1000, max_lanczos_quadrature_iterations=20).
+    """
+    info = CGInfo()
+    rhs = np.asarray(rhs)
+    is_vector = rhs.ndim == 1  # :134-136
+    if is_vector:
+        rhs = rhs[:, None]
+    dt = rhs.dtype
+    if initial_guess is None:  # :143-149
+        initial_guess = np.zeros_like(rhs)
+    else:
+        initial_guess = np.asarray(initial_guess, dtype=dt)
+        if initial_guess.ndim == 1:
+            is_vector = True
+            initial_guess = initial_guess[:, None]
+    precond = preconditioner is not None
+    if max_tridiag_iter > max_iter:  # :159-160
+        raise RuntimeError("Getting a tridiagonalization larger than the number of CG iterations run is not possible!")
+    if not callable(matmul_closure):  # :163-166
+        raise RuntimeError("matmul_closure must be a tensor, or a callable object!")
+
+    num_rows = rhs.shape[-2]
+    n_iter = min(max_iter, num_rows) if terminate_cg_by_size else max_iter  # :170
+    n_tridiag_iter = min(max_tridiag_iter, num_rows)  # :171
+    eps = dt.type(eps)  # :172
+    stop_after = dt.type(stop_updating_after)
+
+    def colnorm(a):
+        return np.sqrt(np.sum(a * a, axis=-2, keepdims=True, dtype=dt))
+
+    rhs_norm = colnorm(rhs)  # :177
+    rhs_is_zero = rhs_norm < eps
+    rhs_norm = np.where(rhs_is_zero, dt.type(1), rhs_norm)
+    rhs = rhs / rhs_norm  # :182
+    initial_guess = initial_guess / rhs_norm
+
+    residual = rhs - matmul_closure(initial_guess)  # :186
+    info.matvecs = 1
+    batch_shape = residual.shape[:-2]
+    ncols = rhs.shape[-1]
+    result = np.ascontiguousarray(np.broadcast_to(initial_guess, residual.shape)).copy()  # :190
+
+    if np.isnan(residual).any():  # :199-200
+        raise RuntimeError("NaNs encountered when trying to perform matrix-vector multiplication")
+
+    residual_norm = colnorm(residual)  # :204
+    has_converged = residual_norm < stop_after
+
+    if has_converged.all() and not n_tridiag:  # :207-208
+        n_iter = 0
+        info.skipped = True
+    else:
+        precond_residual = preconditioner(residual) if precond else residual.copy()  # :213
+        curr_conjugate_vec = precond_residual.copy()
+        residual_inner_prod = np.sum(precond_residual * residual, axis=-2, keepdims=True, dtype=dt)
+
+    if n_tridiag:  # :224-236
+        t_mat = np.zeros((n_tridiag_iter, n_tridiag_iter) + tuple(batch_shape) + (n_tridiag,), dtype=dt)
+        prev_alpha_reciprocal = np.empty(tuple(batch_shape) + (n_tridiag,), dtype=dt)
+        prev_beta = np.empty_like(prev_alpha_reciprocal)
+    update_tridiag = True
+    last_tridiag_iter = 0
+    tolerance_reached = False
+    k = -1
+    one = dt.type(1)
+    zero = dt.type(0)
+
+    for k in range(n_iter):  # :245
+        mvms = matmul_closure(curr_conjugate_vec)  # :248
+        info.matvecs += 1
+        alpha = np.sum(curr_conjugate_vec * mvms, axis=-2, keepdims=True, dtype=dt)  # :250-251 / :65-66
+        is_zero = alpha < eps  # :254 (negative curvature is zeroed too)
+        alpha = np.where(is_zero, one, alpha)
+        alpha = residual_inner_prod / alpha
+        alpha = np.where(is_zero, zero, alpha)
+        alpha = np.where(has_converged, zero, alpha)  # :260
+        residual = residual - alpha * mvms  # :264 / :78
+        precond_residual = preconditioner(residual) if precond else residual.copy()  # :268 / :82
+        result = result + alpha * curr_conjugate_vec  # :31
+        beta = residual_inner_prod.copy()  # :34
+        residual_inner_prod = np.sum(residual * precond_residual, axis=-2, keepdims=True, dtype=dt)  # :35-36
+        is_zero = beta < eps  # :39
+        beta = np.where(is_zero, one, beta)
+        beta = residual_inner_prod / beta
+        beta = np.where(is_zero, zero, beta)
+        curr_conjugate_vec = curr_conjugate_vec * beta + precond_residual  # :46
+
+        residual_norm = colnorm(residual)  # :298
+        residual_norm = np.where(rhs_is_zero, zero, residual_norm)  # :299
+        has_converged = residual_norm < stop_after  # :300
+
+        if (
+            k >= min(10, max_iter - 1)
+            and bool(residual_norm.mean(dtype=dt) < tolerance)
+            and not (n_tridiag and k < min(n_tridiag_iter, max_iter - 1))
+        ):  # :302-308
+            tolerance_reached = True
+            break
+
+        if n_tridiag and k < n_tridiag_iter and update_tridiag:  # :311-332
+            alpha_tridiag = alpha[..., 0, :n_tridiag]
+            beta_tridiag = beta[..., 0, :n_tridiag]
+            a_is_zero = alpha_tridiag == 0
+            alpha_reciprocal = one / np.where(a_is_zero, one, alpha_tridiag)
+            if k == 0:
+                t_mat[k, k] = alpha_reciprocal
+            else:
+                t_mat[k, k] = alpha_reciprocal + prev_beta * prev_alpha_reciprocal
+                off = np.sqrt(prev_beta) * prev_alpha_reciprocal
+                t_mat[k, k - 1] = off
+                t_mat[k - 1, k] = off
+                if t_mat[k - 1, k].max() < 1e-6:  # :326
+                    update_tridiag = False
+            last_tridiag_iter = k
+            prev_alpha_reciprocal = alpha_reciprocal.copy()
+            prev_beta = beta_tridiag.copy()
+
+    result = result * rhs_norm  # :335
+    info.iterations = k + 1 if n_iter > 0 else 0
+    info.tolerance_reached = tolerance_reached
+    info.mean_residual = float(residual_norm.mean(dtype=dt))
+    info.last_tridiag_iter = last_tridiag_iter
+    info.warned = (not tolerance_reached) and n_iter > 0  # :337
+    if is_vector:
+        result = result[..., 0]
+    if n_tridiag:
+        t_mat = t_mat[: last_tridiag_iter + 1, : last_tridiag_iter + 1]  # :353
+        nb = len(batch_shape)
+        perm = (t_mat.ndim - 1,) + tuple(range(2, 2 + nb)) + (0, 1)  # :354-357
+        return result, np.ascontiguousarray(np.transpose(t_mat, perm)), info
+    return result, None, info
+
+
+# ----------------------------------------------------------------------------------
+# pivoted Cholesky  (HOT LOOP B)
+# ----------------------------------------------------------------------------------
+
+
+def _seq_dot_rows(A, Bm):
+    """sum_r A[..., r] * B[..., r], sequential in r, product rounded first (no FMA)."""
+    R = A.shape[-1]
+    acc = A[..., 0] * Bm[..., 0]
+    for r in range(1, R):
+        acc = acc + A[..., r] * Bm[..., r]
+    return acc
+
+
+class LowRankRowSource:
+    """diag / row access for RootLinearOperator(C): root_linear_operator.py:22-28 (diag), :37-50 (rows)."""
+
+    def __init__(self, C):
+        self.C = C
+        self.n = C.shape[-2]
+        self.batch_shape = C.shape[:-2]
+        self.dtype = C.dtype
+
+    def diag(self):
+        return _seq_dot_rows(self.C, self.C)
+
+    def row(self, idx):  # idx [*B] -> [*B, N]
+        Cr = np.take_along_axis(self.C, idx[..., None, None], axis=-2)  # [*B,1,R]
+        return _seq_dot_rows(np.broadcast_to(Cr, self.C.shape), self.C)
+
+
+class DenseRowSource:
+    """dense_linear_operator.py:37-40 (diag), :47-50 (rows)."""
+
+    def __init__(self, K):
+        self.K = K
+        self.n = K.shape[-1]
+        self.batch_shape = K.shape[:-2]
+        self.dtype = K.dtype
+
+    def diag(self):
+        return np.diagonal(self.K, axis1=-2, axis2=-1).copy()
+
+    def row(self, idx):
+        return np.take_along_axis(self.K, idx[..., None, None], axis=-2)[..., 0, :]
+
+
+class KronRowSource:
+    """kronecker_product_linear_operator.py:20-27,188-191 (diag), :198-216 (rows)."""
+
+    def __init__(self, K1, K2):
+        self.K1, self.K2 = K1, K2
+        self.n1, self.n2 = K1.shape[-1], K2.shape[-1]
+        self.n = self.n1 * self.n2
+        self.batch_shape = K1.shape[:-2]
+        self.dtype = K1.dtype
+
+    def diag(self):
+        d1 = np.diagonal(self.K1, axis1=-2, axis2=-1)
+        d2 = np.diagonal(self.K2, axis1=-2, axis2=-1)
+        return (d1[..., :, None] * d2[..., None, :]).reshape(*self.batch_shape, self.n)
+
+    def row(self, idx):
+        i1 = idx // self.n2
+        i2 = idx % self.n2
+        r1 = np.take_along_axis(self.K1, i1[..., None, None], axis=-2)[..., 0, :]
+        r2 = np.take_along_axis(self.K2, i2[..., None, None], axis=-2)[..., 0, :]
+        return (r1[..., :, None] * r2[..., None, :]).reshape(*self.batch_shape, self.n)
+
+
+def pivoted_cholesky(src, rank, error_tol=1e-3):
+    """Greedy partial pivoted Cholesky, restating functions/_pivoted_cholesky.py:14-105.
+
+    src: a *RowSource (diag(), row(idx)).  Returns (L [*B,N,m], permutation [*B,N] int64).
+    Batch-global loop condition (:57), first-max tie-break (:61-63, torch.max on CPU returns the
+    first maximal index), sequential-in-j Schur update with products rounded before the sum (:83-89).
+    """
+    batch_shape = tuple(src.batch_shape)
+    N = src.n
+    dt = src.dtype
+    diag = src.diag().astype(dt).copy()  # :25-30
+    max_iter = min(rank, N)  # :33
+    L = np.zeros(batch_shape + (max_iter, N), dtype=dt)  # :36-42
+    orig_error = diag.max(axis=-1)  # :43
+    errors = np.abs(diag).sum(axis=-1, dtype=dt) / orig_error  # :44
+    perm = np.broadcast_to(np.arange(N, dtype=np.int64), batch_shape + (N,)).copy()  # :47-48
+    m = 0
+    while m == 0 or (m < max_iter and errors.max() > error_tol):  # :57
+        permuted_diags = np.take_along_axis(diag, perm[..., m:], axis=-1)  # :61
+        max_idx = permuted_diags.argmax(axis=-1)  # first max
+        max_val = np.take_along_axis(permuted_diags, max_idx[..., None], axis=-1)[..., 0]
+        max_idx = max_idx + m
+        old_pi_m = perm[..., m].copy()  # :67-70
+        new_pi_m = np.take_along_axis(perm, max_idx[..., None], axis=-1)[..., 0]
+        perm[..., m] = new_pi_m
+        np.put_along_axis(perm, max_idx[..., None], old_pi_m[..., None], axis=-1)
+        pi_m = perm[..., m]
+        L_m = L[..., m, :]
+        piv = np.sqrt(max_val).astype(dt)
+        np.put_along_axis(L_m, pi_m[..., None], piv[..., None], axis=-1)  # :73-74
+        if m + 1 < N:  # :77
+            row = src.row(pi_m)  # :79
+            pi_i = perm[..., m + 1 :]
+            L_m_new = np.take_along_axis(row, pi_i, axis=-1)  # :82
+            if m > 0:  # :83-89
+                acc = None
+                for j in range(m):
+                    Lj = L[..., j, :]
+                    upd = np.take_along_axis(Lj, pi_m[..., None], axis=-1)  # [*B,1]
+                    prev = np.take_along_axis(Lj, pi_i, axis=-1)
+                    term = upd * prev
+                    acc = term if acc is None else acc + term
+                L_m_new = L_m_new - acc
+            L_m_new = L_m_new / piv[..., None]  # :91
+            np.put_along_axis(L_m, pi_i, L_m_new, axis=-1)  # :92
+            cur = np.take_along_axis(diag, pi_i, axis=-1)  # :94-95
+            newd = cur - L_m_new * L_m_new
+            np.put_along_axis(diag, pi_i, newd, axis=-1)
+            errors = np.abs(newd).sum(axis=-1, dtype=dt) / orig_error  # :99
+        m += 1
+    return np.ascontiguousarray(np.swapaxes(L[..., :m, :], -1, -2)), perm  # :105
+
+
+# ----------------------------------------------------------------------------------
+# pivoted-Cholesky / QR Woodbury preconditioner
+# ----------------------------------------------------------------------------------
+
+
+class Preconditioner:
+    """P = L L^T + D, restating AddedDiagLinearOperator._preconditioner / _init_cache*
+    (operators/added_diag_linear_operator.py:95-184)."""
+
+    def __init__(self, L, d):
+        # L [*B,N,k], d [*B,N]
+        dt = L.dtype
+        N, k = L.shape[-2:]
+        noise = d[..., None]  # :146
+        self.constant_diag = bool(np.array_equal(noise, noise[..., :1, :] * np.ones_like(noise)))  # :149-150
+        eye = np.broadcast_to(np.eye(k, dtype=dt), L.shape[:-2] + (k, k))
+        if self.constant_diag:  # :161-172
+            noise = noise[..., :1, :]
+            Q, R = np.linalg.qr(np.concatenate([L, np.sqrt(noise) * eye], axis=-2))
+            self.Q = np.ascontiguousarray(Q[..., :N, :])
+            logdet = 2 * np.log(np.abs(np.diagonal(R, axis1=-2, axis2=-1))).sum(-1)
+            logdet = logdet + (N - k) * np.log(noise[..., 0, 0])
+        else:  # :174-184
+            sq = np.sqrt(noise)
+            Q, R = np.linalg.qr(np.concatenate([L / sq, eye], axis=-2))
+            self.Q = np.ascontiguousarray(Q[..., :N, :] / sq)
+            logdet = 2 * np.log(np.abs(np.diagonal(R, axis1=-2, axis2=-1))).sum(-1)
+            logdet = logdet - np.log(1.0 / noise).sum(axis=(-1, -2))
+        self.R = R
+        self.noise = noise.astype(dt)
+        self.logdet = logdet.astype(dt)
+        self.L = L
+        self.d = d
+
+    def apply(self, r):
+        """precondition_closure, added_diag_linear_operator.py:135-140."""
+        qqt = np.matmul(self.Q, np.matmul(np.swapaxes(self.Q, -1, -2), r))
+        if self.constant_diag:
+            return (1 / self.noise) * (r - qqt)
+        return r / self.noise - qqt
+
+
+# ----------------------------------------------------------------------------------
+# Lanczos (HOT LOOP C), tridiagonal eigensolve, SLQ
+# ----------------------------------------------------------------------------------
+
+
+def lanczos_tridiag(matmul_closure, max_iter, init_vecs, tol=1e-5):
+    """Lanczos with full re-orthogonalisation, restating utils/lanczos.py:9-164.
+
+    init_vecs [*B,N,P] must be supplied (the reference's randn default is not reproducible).
+    Returns (q_mat [P,*B,N,k'], t_mat [P,*B,k',k']) -- leading P squeezed iff P == 1 (:159-161).
+    """
+    init_vecs = np.asarray(init_vecs)
+    dt = init_vecs.dtype
+    batch_shape = init_vecs.shape[:-2]
+    N, P = init_vecs.shape[-2:]
+    num_iter = min(max_iter, N)  # :57
+    q_mat = np.zeros((num_iter,) + tuple(batch_shape) + (N, P), dtype=dt)  # :69-77
+    t_mat = np.zeros((num_iter, num_iter) + tuple(batch_shape) + (P,), dtype=dt)
+
+    def vnorm(a, keepdims=False):
+        return np.sqrt(np.sum(a * a, axis=-2, keepdims=keepdims, dtype=dt))
+
+    q0 = init_vecs / vnorm(init_vecs)[..., None, :]  # :81
+    q_mat[0] = q0
+    r_vec = matmul_closure(q0)  # :85
+    alpha0 = np.sum(q0 * r_vec, axis=-2, dtype=dt)
+    r_vec = r_vec - alpha0[..., None, :] * q0  # :89
+    beta0 = vnorm(r_vec)
+    t_mat[0, 0] = alpha0
+    if num_iter > 1:
+        t_mat[0, 1] = beta0
+        t_mat[1, 0] = beta0
+        q_mat[1] = r_vec / beta0[..., None, :]  # :98
+    k = 0
+    for k in range(1, num_iter):  # :101
+        q_prev = q_mat[k - 1]
+        q_curr = q_mat[k]
+        beta_prev = t_mat[k, k - 1][..., None, :]
+        r_vec = matmul_closure(q_curr) - q_prev * beta_prev  # :108
+        alpha_curr = np.sum(q_curr * r_vec, axis=-2, keepdims=True, dtype=dt)
+        t_mat[k, k] = alpha_curr[..., 0, :]
+        if k + 1 < num_iter:  # :114
+            r_vec = r_vec - alpha_curr * q_curr
+            Qk = q_mat[: k + 1]
+            corr = np.sum(r_vec[None] * Qk, axis=-2, keepdims=True, dtype=dt)  # :118
+            corr = np.sum(Qk * corr, axis=0, dtype=dt)
+            r_vec = r_vec - corr
+            r_norm = vnorm(r_vec, keepdims=True)
+            r_vec = r_vec / r_norm
+            beta_curr = r_norm[..., 0, :]
+            t_mat[k, k + 1] = beta_curr
+            t_mat[k + 1, k] = beta_curr
+            inner = np.sum(Qk * r_vec[None], axis=-2, dtype=dt)  # :131
+            could = False
+            for _ in range(10):  # :133-142 (signed compare)
+                if not np.sum(inner > tol):
+                    could = True
+                    break
+                corr = np.sum(r_vec[None] * Qk, axis=-2, keepdims=True, dtype=dt)
+                corr = np.sum(Qk * corr, axis=0, dtype=dt)
+                r_vec = r_vec - corr
+                r_norm = vnorm(r_vec, keepdims=True)
+                r_vec = r_vec / r_norm
+                inner = np.sum(Qk * r_vec[None], axis=-2, dtype=dt)
+            q_mat[k + 1] = r_vec  # :145
+            if np.sum(np.abs(beta_curr) > 1e-6) == 0 or not could:  # :147
+                break
+    num_iter = k + 1  # :151
+    nb = len(batch_shape)
+    qp = (q_mat.ndim - 1,) + tuple(range(1, 1 + nb)) + (q_mat.ndim - 2, 0)
+    q_out = np.ascontiguousarray(np.transpose(q_mat[:num_iter], qp))
+    tp = (t_mat.ndim - 1,) + tuple(range(2, 2 + nb)) + (0, 1)
+    t_out = np.ascontiguousarray(np.transpose(t_mat[:num_iter, :num_iter], tp))
+    if P == 1:  # squeeze_(0) only acts on a size-1 dim
+        q_out, t_out = q_out[0], t_out[0]
+    return q_out, t_out
+
+
+def lanczos_tridiag_to_diag(t_mat):
+    """eigh of each tridiagonal + clamp, restating utils/lanczos.py:167-189."""
+    evals, evecs = np.linalg.eigh(t_mat)
+    mask = evals >= 0
+    evecs = evecs * mask[..., None, :].astype(evecs.dtype)  # zero eigenvector COLUMNS (:186)
+    evals = np.where(mask, evals, evals.dtype.type(1))  # :187
+    return evals, evecs
+
+
+def slq_logdet(n, evals, evecs):
+    """StochasticLQ.to_dense with funcs=[log], restating utils/stochastic_lq.py:67-82.
+
+    evals [P,*B,k], evecs [P,*B,k,k] -> logdet [*B]  (scaled by n / P only, :80).
+    """
+    P = evals.shape[0]
+    dt = evals.dtype
+    res = np.zeros(evals.shape[1:-1], dtype=dt)
+    for j in range(P):
+        first = evecs[j][..., 0, :]
+        dots = np.sum(first * first * np.log(evals[j]), axis=-1, dtype=dt)
+        res = res + dt.type(n / float(P)) * dots
+    return res
+
+
+# ----------------------------------------------------------------------------------
+# orchestration: solve / inv_quad_logdet with the default preconditioner
+# ----------------------------------------------------------------------------------
+
+
+def solve(matmul_closure, row_src, d, rhs, tolerance=1.0, max_iter=1000, rank=15, min_precond_size=2000,
+          precond_tol=1e-3):
+    """`_solve` dispatch for N > max_cholesky_size, restating functions/_solve.py:19-22 +
+    LinearOperator._solve (operators/_linear_operator.py:781-803)."""
+    N = rhs.shape[-2]
+    pre = None
+    if rank > 0 and N >= min_precond_size:
+        L, _ = pivoted_cholesky(row_src, rank, precond_tol)
+        pre = Preconditioner(L, d)
+    x, _, info = linear_cg(matmul_closure, rhs, tolerance=tolerance, max_iter=max_iter,
+                           preconditioner=pre.apply if pre else None)
+    return x, info, pre
+
+
+def inv_quad_logdet(matmul_closure, row_src, d, inv_quad_rhs, probes, tolerance=1.0, max_iter=1000,
+                    max_tridiag_iter=20, rank=15, min_precond_size=2000, precond_tol=1e-3):
+    """InvQuadLogdet.forward with injected (already normalised) probe vectors, restating
+    functions/_inv_quad_logdet.py:112-153 and LinearOperator.inv_quad_logdet
+    (operators/_linear_operator.py:1773-1804).  probes [*B,N,P] unit columns."""
+    N = probes.shape[-2]
+    P = probes.shape[-1]
+    pre = None
+    logdet_p = 0.0
+    if rank > 0 and N >= min_precond_size:
+        L, _ = pivoted_cholesky(row_src, rank, precond_tol)
+        pre = Preconditioner(L, d)
+        logdet_p = pre.logdet
+    rhs = np.concatenate([probes, inv_quad_rhs], axis=-1) if inv_quad_rhs is not None else probes
+    solves, t_mat, info = linear_cg(matmul_closure, rhs, n_tridiag=P, tolerance=tolerance, max_iter=max_iter,
+                                    max_tridiag_iter=max_tridiag_iter,
+                                    preconditioner=pre.apply if pre else None)
+    if np.isnan(t_mat).any():  # :141-142
+        logdet = np.full(probes.shape[:-2], np.nan, dtype=probes.dtype)
+    else:
+        evals, evecs = lanczos_tridiag_to_diag(t_mat)
+        logdet = slq_logdet(N, evals, evecs)
+    inv_quad = None
+    if inv_quad_rhs is not None:
+        inv_quad = np.sum(solves[..., P:] * inv_quad_rhs, axis=-2)  # :151-153
+    return inv_quad, logdet + logdet_p, solves, t_mat, info, pre

@@ -1,0 +1,337 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/*.npz by running the REAL reference.
+
+Runs only in the build container (imports cornellius-gp/linear_operator from /root/reference;
+nothing of the reference travels to the GPU box -- only the .npz outputs committed next to this
+script).  Usage:  python tests/golden/make_golden.py
+
+Inputs come from tests/golden/cases.py (numpy PCG64, seeded); each file stores the reference's
+outputs, the iteration / matvec counts observed through a spy on `linear_operator.utils.linear_cg`
+(the seam the reference's own tests patch, linear_operator/test/linear_operator_test_case.py:555),
+and a checksum of the inputs.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+import numpy as np
+
+sys.path.insert(0, "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import torch  # noqa: E402
+
+import linear_operator  # noqa: E402
+from linear_operator import settings  # noqa: E402
+from linear_operator.operators import (  # noqa: E402
+    AddedDiagLinearOperator,
+    ConstantDiagLinearOperator,
+    DenseLinearOperator,
+    DiagLinearOperator,
+    KroneckerProductLinearOperator,
+    LowRankRootLinearOperator,
+)
+from linear_operator.utils import linear_cg as _ref_linear_cg  # noqa: E402
+from linear_operator.utils.lanczos import lanczos_tridiag, lanczos_tridiag_to_diag  # noqa: E402
+from linear_operator.utils.stochastic_lq import StochasticLQ  # noqa: E402
+from linear_operator.utils.warnings import NumericalWarning  # noqa: E402
+
+import cases  # noqa: E402
+
+torch.set_num_threads(8)
+T = torch.from_numpy
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+class Counter:
+    def __init__(self, fn):
+        self.fn = fn
+        self.calls = 0
+
+    def __call__(self, x):
+        self.calls += 1
+        return self.fn(x)
+
+
+def run_cg(closure, rhs, **kw):
+    cnt = Counter(closure)
+    with warnings.catch_warnings(record=True) as ws:
+        warnings.simplefilter("always")
+        out = _ref_linear_cg(cnt, rhs, **kw)
+    warned = any(issubclass(w.category, NumericalWarning) for w in ws)
+    return out, cnt.calls, warned
+
+
+# ------------------------------------------------------------------------------------------------
+def g1_linear_cg():
+    print("G1 linear_cg")
+    # test_linear_cg.py:27-64 recipe, fp64 N=100
+    M = cases.spd_test_matrix(101, 100)
+    b_vec = cases.randn(102, 100)
+    b_mat = cases.randn(103, 100, 50)
+    x0_vec = cases.randn(104, 100)
+    x0_mat = cases.randn(105, 100, 50)
+    Mt = T(M)
+    (x_vec), n1, w1 = run_cg(Mt.matmul, T(b_vec), max_iter=100)
+    (x_vec_i), n2, w2 = run_cg(Mt.matmul, T(b_vec), max_iter=100, initial_guess=T(x0_vec))
+    (x_mat), n3, w3 = run_cg(Mt.matmul, T(b_mat), max_iter=100)
+    (x_mat_i), n4, w4 = run_cg(Mt.matmul, T(b_mat), max_iter=100, initial_guess=T(x0_mat))
+    save("g1_cg_fp64_n100", x_vec=x_vec, x_vec_init=x_vec_i, x_mat=x_mat, x_mat_init=x_mat_i,
+         matvecs=np.array([n1, n2, n3, n4]), warned=np.array([w1, w2, w3, w4]),
+         checksum=cases.checksum(M, b_vec, b_mat, x0_vec, x0_mat))
+
+    # test_linear_cg.py:66-95 recipe, fp64 N=10, c=50, n_tridiag=5
+    M = cases.spd_test_matrix(111, 10)
+    b = cases.randn(112, 10, 50)
+    (x, t), n, w = run_cg(T(M).matmul, T(b), n_tridiag=5, max_tridiag_iter=10, max_iter=10, tolerance=0, eps=1e-15)
+    save("g1_cg_fp64_n10_tridiag", x=x, t_mat=t, matvecs=n, warned=w, checksum=cases.checksum(M, b))
+
+    # test_linear_cg.py:97-144 recipes, batch 5
+    M = cases.spd_test_matrix(121, 100, batch=(5,))
+    b = cases.randn(122, 5, 100, 50)
+    (x), n, w = run_cg(T(M).matmul, T(b), max_iter=100)
+    save("g1_cg_fp64_batch", x=x, matvecs=n, warned=w, checksum=cases.checksum(M, b))
+    M = cases.spd_test_matrix(131, 10, batch=(5,))
+    b = cases.randn(132, 5, 10, 10)
+    (x, t), n, w = run_cg(T(M).matmul, T(b), n_tridiag=8, max_iter=10, max_tridiag_iter=10, tolerance=0, eps=1e-30)
+    save("g1_cg_fp64_batch_tridiag", x=x, t_mat=t, matvecs=n, warned=w, checksum=cases.checksum(M, b))
+
+    # fp32 low-rank + diag, B=4, N=512, R=8, c=5, no preconditioner, n_tridiag=4, tolerances {1, 1e-4}
+    C, d, rhs = cases.lowrank_diag(141, 4, 512, 8, 5)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+    out = {}
+    for tag, tol in (("tol1", 1.0), ("tol1e4", 1e-4)):
+        (x), n, w = run_cg(A._matmul, T(rhs), tolerance=tol)
+        (x2, t2), n2, w2 = run_cg(A._matmul, T(rhs), tolerance=tol, n_tridiag=4)
+        out.update({f"x_{tag}": x, f"matvecs_{tag}": n, f"warned_{tag}": w,
+                    f"xt_{tag}": x2, f"t_mat_{tag}": t2, f"matvecs_t_{tag}": n2, f"warned_t_{tag}": w2})
+    # zero column + initial guess
+    rhs_z = rhs.copy()
+    rhs_z[1, :, 2] = 0.0
+    x0 = cases.randn(142, 4, 512, 5, dtype=np.float32) * 0.1
+    (xz), nz, wz = run_cg(A._matmul, T(rhs_z), tolerance=1e-4, initial_guess=T(x0))
+    out.update(x_zero_col=xz, matvecs_zero_col=nz)
+    save("g1_cg_fp32_lowrank", checksum=cases.checksum(C, d, rhs), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def g2_pivoted_cholesky():
+    print("G2 pivoted_cholesky")
+    m8 = cases.pivchol_dense8(201)
+    L, piv = linear_operator.pivoted_cholesky(T(m8), rank=3, return_pivots=True)
+    mb = cases.pivchol_dense8(202, batch=(2, 3))
+    Lb, pivb = linear_operator.pivoted_cholesky(T(mb), rank=3, return_pivots=True)
+    L8, piv8 = linear_operator.pivoted_cholesky(T(m8), rank=8, return_pivots=True)
+    save("g2_pivchol_dense8", L=L, piv=piv, Lb=Lb, pivb=pivb, L8=L8, piv8=piv8, checksum=cases.checksum(m8, mb))
+
+    out = {}
+    cs = []
+    for R in (8, 32):
+        C, d, _ = cases.lowrank_diag(210 + R, 3, 2048, R, 1)
+        op = LowRankRootLinearOperator(T(C))
+        Lr, pr = op.pivoted_cholesky(rank=15, return_pivots=True)
+        out[f"L_R{R}"] = Lr
+        out[f"piv_R{R}"] = pr
+        cs += [C]
+    save("g2_pivchol_lowrank", checksum=cases.checksum(*cs), **out)
+
+    K1, K2, _, _ = cases.kron_factors(221, 2, 16, 16, 1)
+    op = KroneckerProductLinearOperator(T(K1), T(K2))
+    Lk, pk = op.pivoted_cholesky(rank=15, return_pivots=True)
+    Kd, _, _ = cases.dense_diag(222, 2, 300, 1)
+    Ld, pd_ = DenseLinearOperator(T(Kd)).pivoted_cholesky(rank=15, return_pivots=True)
+    save("g2_pivchol_kron_dense", L_kron=Lk, piv_kron=pk, L_dense=Ld, piv_dense=pd_,
+         checksum=cases.checksum(K1, K2, Kd))
+
+
+# ------------------------------------------------------------------------------------------------
+def g3_preconditioner():
+    print("G3 preconditioner")
+    out = {}
+    C, d, rhs = cases.lowrank_diag(301, 3, 2048, 32, 4)
+    with settings.min_preconditioning_size(0):
+        # non-constant diag
+        A = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+        fn, plt, logdet_p = A._preconditioner()
+        out.update(z_nonconst=fn(T(rhs)), logdet_nonconst=logdet_p, L_nonconst=A._piv_chol_self,
+                   const_flag_nonconst=A._constant_diag)
+        # constant diag
+        sig = np.array([[0.3], [0.7], [1.1]], dtype=np.float32)
+        A2 = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), ConstantDiagLinearOperator(T(sig), 2048))
+        fn2, plt2, logdet_p2 = A2._preconditioner()
+        out.update(z_const=fn2(T(rhs)), logdet_const=logdet_p2, const_flag_const=A2._constant_diag,
+                   logdet_dense_const=np.linalg.slogdet(plt2.to_dense().numpy().astype(np.float64))[1].astype(np.float32))
+    save("g3_precond", checksum=cases.checksum(C, d, rhs), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+class _Spy:
+    """Wraps linear_operator.utils.linear_cg, recording matvec count and raw outputs."""
+
+    def __init__(self):
+        self.records = []
+
+    def __call__(self, matmul_closure, rhs, **kw):
+        cnt = Counter(matmul_closure)
+        out = _ref_linear_cg(cnt, rhs, **kw)
+        self.records.append(dict(matvecs=cnt.calls, out=out, kw=kw))
+        return out
+
+
+class _ProbedAddedDiag(AddedDiagLinearOperator):
+    _probes = None
+
+    def _probe_vectors_and_norms(self):  # hook: operators/_linear_operator.py:629-633
+        return self._probes
+
+
+def _with_spy(fn):
+    spy = _Spy()
+    old = linear_operator.utils.linear_cg
+    linear_operator.utils.linear_cg = spy
+    try:
+        with warnings.catch_warnings(record=True) as ws:
+            warnings.simplefilter("always")
+            res = fn()
+    finally:
+        linear_operator.utils.linear_cg = old
+    warned = any(issubclass(w.category, NumericalWarning) for w in ws)
+    return res, spy, warned
+
+
+def g4_solve_and_inv_quad_logdet():
+    print("G4 solve / inv_quad_logdet (operator API, default preconditioner)")
+    # ---- cfg2-shaped: AddedDiag(LowRankRoot, Diag).solve ----
+    C, d, rhs = cases.lowrank_diag(401, 4, 2048, 32, 1)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+    with settings.cg_tolerance(1e-4):
+        x, spy, w = _with_spy(lambda: A.solve(T(rhs)))
+    woodbury = (LowRankRootLinearOperator(T(C).double()) + DiagLinearOperator(T(d).double())).solve(T(rhs).double())
+    save("g4_solve_lowrank", x=x, matvecs=spy.records[0]["matvecs"], warned=w, x_exact=woodbury.float(),
+         checksum=cases.checksum(C, d, rhs))
+
+    # ---- cfg3-shaped: inv_quad_logdet with injected probes ----
+    C, d, rhs = cases.lowrank_diag(411, 3, 2048, 16, 1)
+    Z, Zn = cases.probes(412, 3, 2048, 8)
+    A = _ProbedAddedDiag(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+    A._probes = (T(Z), T(Zn))
+    with settings.cg_tolerance(1e-4):
+        (iq, ld), spy, w = _with_spy(lambda: A.inv_quad_logdet(T(rhs), logdet=True))
+    solves, t_mat = spy.records[0]["out"]
+    evals, evecs = lanczos_tridiag_to_diag(t_mat)
+    (pinvk_logdet,) = StochasticLQ().to_dense(A.matrix_shape, evals, evecs, [lambda x: x.log()])
+    _, _, logdet_p = A._preconditioner()
+    dense = (T(C).double() @ T(C).double().mT) + torch.diag_embed(T(d).double())
+    save("g4_iql_lowrank", inv_quad=iq, logdet=ld, solves=solves, t_mat=t_mat, evals=evals,
+         pinvk_logdet=pinvk_logdet, logdet_p=logdet_p, matvecs=spy.records[0]["matvecs"], warned=w,
+         logdet_exact=np.linalg.slogdet(dense.numpy())[1].astype(np.float32),
+         checksum=cases.checksum(C, d, rhs, Z))
+
+    # ---- cfg4-shaped: AddedDiag(Kron, ConstantDiag).solve, N = 48*48 = 2304 ----
+    K1, K2, sig, rhs = cases.kron_factors(421, 2, 48, 48, 1)
+    A = AddedDiagLinearOperator(KroneckerProductLinearOperator(T(K1), T(K2)), ConstantDiagLinearOperator(T(sig), 2304))
+    with settings.cg_tolerance(1e-3):
+        x, spy, w = _with_spy(lambda: A.solve(T(rhs)))
+    dense = torch.stack([torch.kron(T(K1)[i].double(), T(K2)[i].double()) for i in range(2)])
+    dense = dense + sig.astype(np.float64)[0, 0] * torch.eye(2304, dtype=torch.float64)
+    save("g4_solve_kron", x=x, matvecs=spy.records[0]["matvecs"], warned=w,
+         x_exact=np.linalg.solve(dense.numpy(), rhs.astype(np.float64)).astype(np.float32), checksum=cases.checksum(K1, K2, sig, rhs))
+
+    # ---- cfg5-shaped: Dense.add_diagonal(d) -> AddedDiag; inv_quad_logdet with probes, N = 2048 ----
+    K, d, rhs = cases.dense_diag(431, 2, 2048, 1)
+    Z, Zn = cases.probes(432, 2, 2048, 4)
+    base = DenseLinearOperator(T(K)).add_diagonal(T(d))
+    assert type(base) is AddedDiagLinearOperator
+    A = _ProbedAddedDiag(DenseLinearOperator(T(K)), DiagLinearOperator(T(d)))
+    A._probes = (T(Z), T(Zn))
+    with settings.cg_tolerance(1e-4):
+        (iq, ld), spy, w = _with_spy(lambda: A.inv_quad_logdet(T(rhs), logdet=True))
+    solves, t_mat = spy.records[0]["out"]
+    save("g4_iql_dense", inv_quad=iq, logdet=ld, solves=solves, t_mat=t_mat, matvecs=spy.records[0]["matvecs"],
+         warned=w, checksum=cases.checksum(K, d, rhs, Z))
+
+    # ---- cfg1: Dense 256x256, torch.linalg.solve -> Cholesky branch (functions/_solve.py:17-18) ----
+    M = cases.spd_test_matrix(441, 256, dtype=np.float32, jitter=1.0)
+    b = cases.randn(442, 256, 3, dtype=np.float32)
+    x, spy, w = _with_spy(lambda: torch.linalg.solve(DenseLinearOperator(T(M)), T(b)))
+    assert len(spy.records) == 0  # CG must NOT run
+    save("g4_cfg1_dense256", x=x, checksum=cases.checksum(M, b))
+
+
+# ------------------------------------------------------------------------------------------------
+def g5_lanczos():
+    print("G5 lanczos_tridiag")
+    out = {}
+    # test_lanczos.py:42-48 recipe (near exact), fp32 N=100, supplied init vec
+    M = cases.spd_test_matrix(501, 100, dtype=np.float32, jitter=1e-6)
+    v0 = cases.randn(502, 100, 1, dtype=np.float32)
+    q, t = lanczos_tridiag(T(M).matmul, max_iter=100, dtype=torch.float32, device=torch.device("cpu"),
+                           matrix_shape=M.shape, init_vecs=T(v0))
+    out.update(q_near=q, t_near=t)
+    # test_lanczos.py:50-57 recipe: orthogonal * diag(10^-i) * orthogonal^T, N=30
+    from scipy.stats import ortho_group
+
+    O = ortho_group.rvs(30, random_state=503).astype(np.float32)
+    Dg = np.diag(np.array([10.0 ** -i for i in range(30)], dtype=np.float32))
+    M2 = (O @ (Dg @ O.T)).astype(np.float32)
+    v2 = cases.randn(504, 30, 1, dtype=np.float32)
+    q2, t2 = lanczos_tridiag(T(M2).matmul, max_iter=30, dtype=torch.float32, device=torch.device("cpu"),
+                             matrix_shape=M2.shape, init_vecs=T(v2))
+    out.update(q_approx=q2, t_approx=t2, M_approx=M2)
+    # batched low-rank + diag, B=2, N=256, R=8, P=3 probes, 10 steps
+    C, d, _ = cases.lowrank_diag(511, 2, 256, 8, 1)
+    V = cases.randn(512, 2, 256, 3, dtype=np.float32)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+    q3, t3 = lanczos_tridiag(A._matmul, max_iter=10, dtype=torch.float32, device=torch.device("cpu"),
+                             matrix_shape=A.matrix_shape, batch_shape=A.batch_shape, init_vecs=T(V))
+    out.update(q_batch=q3, t_batch=t3)
+    save("g5_lanczos", checksum=cases.checksum(M, v0, v2, C, d, V), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def g6_matmuls():
+    print("G6 _matmul of the hot-path operators")
+    out = {}
+    C, d, v = cases.lowrank_diag(601, 3, 256, 8, 5)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+    out["y_lowrank_diag"] = A._matmul(T(v))
+    out["y_lowrank"] = LowRankRootLinearOperator(T(C))._matmul(T(v))
+    out["y_diag"] = DiagLinearOperator(T(d))._matmul(T(v))
+    sig = np.array([[0.25], [0.5], [2.0]], dtype=np.float32)
+    A2 = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), ConstantDiagLinearOperator(T(sig), 256))
+    out["y_lowrank_constdiag"] = A2._matmul(T(v))
+    # broadcast batch: unbatched operator times batched rhs
+    out["y_lowrank_diag_bcast"] = AddedDiagLinearOperator(
+        LowRankRootLinearOperator(T(C[0])), DiagLinearOperator(T(d[0])))._matmul(T(v))
+    K, dd, vv = cases.dense_diag(611, 2, 96, 3)
+    out["y_dense_diag"] = AddedDiagLinearOperator(DenseLinearOperator(T(K)), DiagLinearOperator(T(dd)))._matmul(T(vv))
+    out["y_dense"] = DenseLinearOperator(T(K))._matmul(T(vv))
+    K1, K2, s, vk = cases.kron_factors(621, 2, 12, 20, 3)
+    kp = KroneckerProductLinearOperator(T(K1), T(K2))
+    out["y_kron"] = kp._matmul(T(vk))
+    out["y_kron_diag"] = AddedDiagLinearOperator(kp, ConstantDiagLinearOperator(T(s), 240))._matmul(T(vk))
+    out["diag_kron"] = kp._diagonal()
+    save("g6_matmul", checksum=cases.checksum(C, d, v, K, dd, vv, K1, K2, vk), **out)
+
+
+if __name__ == "__main__":
+    g1_linear_cg()
+    g2_pivoted_cholesky()
+    g3_preconditioner()
+    g4_solve_and_inv_quad_logdet()
+    g5_lanczos()
+    g6_matmuls()
+    print("done")
