@@ -74,9 +74,13 @@ typedef int (*lo_matvec_cb)(void* user, const float* v, float* y, int64_t B, int
  * in the form the reference caches it: z = r/d - Q (Q^T r)   (non-constant diag, :140)
  *                                     z = (r - Q Q^T r)/sigma (constant diag, :137-139)          */
 typedef struct lo_precond_desc {
-  int32_t k;             /* rank of Q (<= 32)                                                     */
+  int32_t k;             /* rank of Q (<= 256)                                                    */
+  int32_t ldq;           /* row stride of Q in floats: k, or the zero-padded stride (4 * pow2) that   *
+                          * lo_precond_build_f32 emits (no staging copy in that case)               */
   int32_t constant_diag; /* 1: `dinv` holds 1/sigma per member [B]; 0: `dinv` holds 1/d [B,N]      */
-  const float* Q;        /* [B, N, k]  (_q_cache)                                                  */
+  int32_t reserved;
+  const float* Q;        /* [B, N, ldq]  (_q_cache; for constant diag it carries the 1/sqrt(sigma)  *
+                          * factor so that z = r*dinv - Q (Q^T r) in both cases)                    */
   const float* dinv;     /* reciprocal noise                                                       */
 } lo_precond_desc;
 
@@ -168,9 +172,12 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
 /* t_mat [M, T, T] (M = P*B tridiagonals, only the three diagonals are read) ->
  *   evals [M, T], evecs [M, T, T] (column j = eigenvector j; negative eigenvalues -> 1 and their
  *   eigenvector columns zeroed, lanczos.py:185-187).  evecs may be NULL.
- * If logdet != NULL (size B): logdet[b] = (n / P) * sum_p sum_i evecs[p,b,0,i]^2 log(evals[p,b,i]).   */
+ * If logdet != NULL (size B): logdet[b] = (n / P) * sum_p sum_i evecs[p,b,0,i]^2 log(evals[p,b,i]).
+ * One thread per tridiagonal, implicit-shift QL in fp64; T <= 32 (the reference itself switches algorithm
+ * at T >= 32, lanczos.py:179).                                                                      */
+size_t lo_tridiag_eigh_slq_workspace_bytes(int64_t P, int64_t B);
 int lo_tridiag_eigh_slq_f32(const float* t_mat, int64_t P, int64_t B, int32_t T, int64_t n, float* evals, float* evecs,
-                            float* logdet, void* stream);
+                            float* logdet, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,171 @@
+"""ctypes binding of liblo_amd.so (the C ABI declared in include/lo_amd.h).
+
+This is the ONLY compute backend of the package: there is no CPU or eager-PyTorch fallback.  If the
+shared library is missing or a tensor is not a contiguous fp32 HIP tensor the call raises.
+PyTorch is used for device memory (torch.empty workspaces through the caching allocator) and for the
+current HIP stream only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "liblo_amd.so")
+_lib = None
+
+LO_OP_LOWRANK_DIAG, LO_OP_DENSE_DIAG, LO_OP_KRON_DIAG, LO_OP_CALLBACK = 0, 1, 2, 3
+LO_DIAG_NONE, LO_DIAG_FULL, LO_DIAG_CONST = 0, 1, 2
+ABI_VERSION = 1
+
+_ERR = {-1: "bad argument", -2: "HIP launch/runtime failure", -3: "workspace too small", -4: "unsupported shape"}
+
+EXPORTS = [
+    "lo_abi_version", "lo_target_arch",
+    "lo_matvec_workspace_bytes", "lo_matvec_f32",
+    "lo_cg_workspace_bytes", "lo_cg_solve_f32",
+    "lo_pivoted_cholesky_workspace_bytes", "lo_pivoted_cholesky_f32",
+    "lo_precond_build_workspace_bytes", "lo_precond_build_f32",
+    "lo_precond_apply_workspace_bytes", "lo_precond_apply_f32",
+    "lo_lanczos_workspace_bytes", "lo_lanczos_tridiag_f32",
+    "lo_tridiag_eigh_slq_workspace_bytes", "lo_tridiag_eigh_slq_f32",
+]
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+class OpDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("diag_mode", C.c_int32), ("B", C.c_int64), ("N", C.c_int64), ("R", C.c_int64),
+                ("n2", C.c_int64), ("A0", C.c_void_p), ("A1", C.c_void_p), ("d", C.c_void_p)]
+
+
+class PrecondDesc(C.Structure):
+    _fields_ = [("k", C.c_int32), ("ldq", C.c_int32), ("constant_diag", C.c_int32), ("reserved", C.c_int32),
+                ("Q", C.c_void_p), ("dinv", C.c_void_p)]
+
+
+class CgParams(C.Structure):
+    _fields_ = [("c", C.c_int64), ("n_tridiag", C.c_int32), ("max_iter", C.c_int32), ("max_tridiag_iter", C.c_int32),
+                ("reserved", C.c_int32), ("tolerance", C.c_float), ("eps", C.c_float),
+                ("stop_updating_after", C.c_float), ("pad", C.c_float)]
+
+
+class CgInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("matvecs", C.c_int32), ("tolerance_reached", C.c_int32),
+                ("nan_detected", C.c_int32), ("skipped", C.c_int32), ("last_tridiag_iter", C.c_int32),
+                ("mean_residual", C.c_float), ("reserved", C.c_float)]
+
+
+MATVEC_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p)
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load liblo_amd.so (after torch, so that both share one HIP runtime).  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise HipExtensionError(
+            f"liblo_amd.so not found at {_LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C linear_operator_amd/csrc`). linear_operator_amd has no CPU fallback."
+        )
+    lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib.lo_abi_version.restype = C.c_int
+    lib.lo_target_arch.restype = C.c_char_p
+    if lib.lo_abi_version() != ABI_VERSION:
+        raise HipExtensionError(f"liblo_amd.so ABI {lib.lo_abi_version()} != binding {ABI_VERSION}; rebuild")
+    missing = [name for name in EXPORTS if not hasattr(lib, name)]
+    if missing:
+        raise HipExtensionError(f"liblo_amd.so does not export {missing}; rebuild it")
+    sz = C.c_size_t
+    P = C.POINTER
+    lib.lo_matvec_workspace_bytes.restype = sz
+    lib.lo_matvec_workspace_bytes.argtypes = [P(OpDesc), C.c_int64]
+    lib.lo_matvec_f32.restype = C.c_int
+    lib.lo_matvec_f32.argtypes = [P(OpDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, sz, C.c_void_p]
+    lib.lo_cg_workspace_bytes.restype = sz
+    lib.lo_cg_workspace_bytes.argtypes = [P(OpDesc), P(PrecondDesc), P(CgParams)]
+    lib.lo_cg_solve_f32.restype = C.c_int
+    lib.lo_cg_solve_f32.argtypes = [P(OpDesc), MATVEC_CB, C.c_void_p, P(PrecondDesc), MATVEC_CB, C.c_void_p,
+                                    P(CgParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz,
+                                    P(CgInfo), C.c_void_p]
+    lib.lo_pivoted_cholesky_workspace_bytes.restype = sz
+    lib.lo_pivoted_cholesky_workspace_bytes.argtypes = [P(OpDesc), C.c_int32]
+    lib.lo_pivoted_cholesky_f32.restype = C.c_int
+    lib.lo_pivoted_cholesky_f32.argtypes = [P(OpDesc), C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+                                            P(C.c_int32), C.c_void_p, sz, C.c_void_p]
+    lib.lo_precond_build_workspace_bytes.restype = sz
+    lib.lo_precond_build_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
+    lib.lo_precond_build_f32.restype = C.c_int
+    lib.lo_precond_build_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p]
+    lib.lo_precond_apply_workspace_bytes.restype = sz
+    lib.lo_precond_apply_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int64]
+    lib.lo_precond_apply_f32.restype = C.c_int
+    lib.lo_precond_apply_f32.argtypes = [P(PrecondDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                         C.c_void_p, sz, C.c_void_p]
+    lib.lo_lanczos_workspace_bytes.restype = sz
+    lib.lo_lanczos_workspace_bytes.argtypes = [P(OpDesc), C.c_int64, C.c_int32]
+    lib.lo_lanczos_tridiag_f32.restype = C.c_int
+    lib.lo_lanczos_tridiag_f32.argtypes = [P(OpDesc), MATVEC_CB, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                           C.c_float, C.c_void_p, C.c_void_p, P(C.c_int32), C.c_void_p, sz,
+                                           C.c_void_p]
+    lib.lo_tridiag_eigh_slq_f32.restype = C.c_int
+    lib.lo_tridiag_eigh_slq_workspace_bytes.restype = sz
+    lib.lo_tridiag_eigh_slq_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
+    lib.lo_tridiag_eigh_slq_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise HipExtensionError(f"liblo_amd {what} failed: {_ERR.get(rc, rc)}")
+
+
+def require_hip(*tensors: Optional[torch.Tensor]):
+    """Every tensor must be a HIP fp32 tensor; anything else is an error (no CPU path exists)."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HipExtensionError(
+                "linear_operator_amd's iterative solvers run only on MI355X device tensors (got a CPU tensor); "
+                "there is no CPU fallback -- move the operator / right-hand side to 'cuda'."
+            )
+        if t.dtype != torch.float32:
+            raise HipExtensionError(f"liblo_amd kernels are fp32; got {t.dtype}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+class DevArray:
+    """Borrowed device pointer exposed through __cuda_array_interface__ so that torch can view it
+    (used to hand the C engine's buffers to Python matvec closures without a copy)."""
+
+    def __init__(self, p: int, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(p), False),
+                                         "version": 2, "strides": None}
+
+
+def as_tensor(p: int, shape, device) -> torch.Tensor:
+    return torch.as_tensor(DevArray(p, shape), device=device)

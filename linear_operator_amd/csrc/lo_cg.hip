@@ -1,0 +1,528 @@
+// lo_cg.hip -- batched modified preconditioned conjugate gradients on the device.
+// Restates linear_operator/utils/linear_cg.py:98-359 (reference) as a launch sequence with NO host
+// synchronisation inside the iteration: every scalar decision of the reference (masked alpha/beta,
+// has_converged, the batch-global mean-residual stopping rule :302-308, the tridiagonal recurrence and
+// its batch-global freeze :311-332, the NaN check :199-200) is taken by a single-workgroup control
+// kernel that writes a sticky `stop` word; all later kernels of the solve read it and exit at once.
+// The host launches the iterations the reference is guaranteed to run (the 11 / n_tridiag floors) in
+// one go, then polls the control block every few iterations.
+//
+// per iteration k (vectors [B,N,c], partial sums [B,S,c] reduced in fixed order):
+//   update_p   p = z + beta p                                   (linear_cg.py:46; z == r if no precond)
+//   matvec     Ap = A p ;  pAp_part = sum_rows p o Ap           (:248, :250-251 fused into the matvec)
+//   update_xr  alpha (masked, :254-260) ; r -= alpha Ap (:264) ; x += alpha p (:31) ; rr_part = sum r^2
+//   precond    z = P^-1 r ; rz_part = sum r o z                 (:268, :35-36 fused)
+//   ctrl       beta (:34-42), residual norms (:298-300), stop rule (:302-308), tridiag (:311-332)
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "lo_device.h"
+#include "lo_internal.h"
+
+namespace lo {
+
+struct CgDev {
+  int64_t B, N;
+  int c, S, S_dot, S_rz;
+  int n_tridiag, max_iter, n_tridiag_iter, T;
+  float tol, eps, stop_after;
+  int check_nan_first;
+  // vectors
+  float *x, *r, *p, *z, *Ap;
+  // partials
+  float *pAp_part, *rr_part, *rz_part;
+  // per (b,col) scalars
+  float *rhs_norm, *rz, *alpha, *beta, *resid_norm, *prev_ar, *prev_beta;
+  int *rhs_is_zero, *has_conv;
+  float* t_mat;
+  CgCtrl* ctrl;
+};
+
+// ---- init ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_cg_init_scal(CgDev d, const float* __restrict__ part) {
+  const int64_t n = d.B * d.c;
+  for (int64_t i = threadIdx.x; i < n; i += kThreads) {
+    const int64_t b = i / d.c;
+    const int col = (int)(i % d.c);
+    float acc = 0.f;
+    for (int s = 0; s < d.S; ++s) acc += part[(b * d.S + s) * d.c + col];
+    float nrm = sqrtf(acc);                      // rhs.norm(2, dim=-2)            linear_cg.py:177
+    const int zero = nrm < d.eps;                // rhs_norm.lt(eps)               :178
+    d.rhs_is_zero[i] = zero;
+    d.rhs_norm[i] = zero ? 1.0f : nrm;           // masked_fill_(rhs_is_zero, 1)   :179
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_cg_init_vec(CgDev d, const float* __restrict__ rhs,
+                                                           const float* __restrict__ x0, int rows_per) {
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int c = d.c, N = (int)d.N;
+  const int nrs = kThreads / c;
+  const int col = threadIdx.x % c, slot = threadIdx.x / c;
+  if (slot >= nrs) return;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  const float nrm = d.rhs_norm[(size_t)b * c + col];
+  const size_t base = (size_t)b * N * c + col;
+  for (int row = r0 + slot; row < r1; row += nrs) {
+    const size_t i = base + (size_t)row * c;
+    d.r[i] = rhs[i] / nrm;                       // rhs.div(rhs_norm)              :182
+    d.x[i] = x0 ? x0[i] / nrm : 0.f;             // initial_guess.div(rhs_norm)    :183
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_cg_sub(float* __restrict__ r, const float* __restrict__ y, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) r[i] -= y[i];  // residual = rhs - A x0   :186
+}
+
+__global__ __launch_bounds__(kThreads) void k_cg_ctrl_init(CgDev d) {
+  __shared__ float red[kThreads];
+  const int64_t n = d.B * d.c;
+  float lnan = 0.f, lnotconv = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kThreads) {
+    const int64_t b = i / d.c;
+    const int col = (int)(i % d.c);
+    float rr = 0.f, rz = 0.f;
+    for (int s = 0; s < d.S; ++s) rr += d.rr_part[(b * d.S + s) * d.c + col];
+    for (int s = 0; s < d.S_rz; ++s) rz += d.rz_part[(b * d.S_rz + s) * d.c + col];
+    const float rn = sqrtf(rr);                  // residual.norm(2, dim=-2)       :204
+    const int conv = rn < d.stop_after;          // :205
+    d.resid_norm[i] = rn;
+    d.has_conv[i] = conv;
+    d.rz[i] = rz;                                // residual_inner_prod            :215
+    if (rr != rr || rz != rz) lnan = 1.f;
+    if (!conv) lnotconv = 1.f;
+  }
+  const float anynan = block_sum256(lnan, red);
+  const float notconv = block_sum256(lnotconv, red);
+  if (threadIdx.x == 0) {
+    if (anynan > 0.f) {                          // torch.equal(residual, residual) :199-200
+      d.ctrl->nan_detected = 1;
+      d.ctrl->stop = 1;
+    } else if (notconv == 0.f && d.n_tridiag == 0) {  // has_converged.all() and not n_tridiag :207-208
+      d.ctrl->skipped = 1;
+      d.ctrl->stop = 1;
+    }
+  }
+}
+
+// ---- iteration -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_cg_update_p(CgDev d, const float* __restrict__ z, int first,
+                                                           int rows_per) {
+  if (d.ctrl->stop) return;
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int c = d.c, N = (int)d.N;
+  const int nrs = kThreads / c;
+  const int col = threadIdx.x % c, slot = threadIdx.x / c;
+  if (slot >= nrs) return;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  const size_t base = (size_t)b * N * c + col;
+  if (first) {
+    for (int row = r0 + slot; row < r1; row += nrs) d.p[base + (size_t)row * c] = z[base + (size_t)row * c];  // :214
+  } else {
+    const float beta = d.beta[(size_t)b * c + col];
+    for (int row = r0 + slot; row < r1; row += nrs) {
+      const size_t i = base + (size_t)row * c;
+      d.p[i] = fmaf(d.p[i], beta, z[i]);         // curr_conjugate_vec.mul_(beta).add_(precond_residual) :46
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_cg_update_xr(CgDev d, int rows_per) {
+  if (d.ctrl->stop) return;
+  __shared__ float red[kThreads];
+  __shared__ float alpha_s[kMaxCols];
+  const int s = blockIdx.x, b = blockIdx.y, S = gridDim.x;
+  const int c = d.c, N = (int)d.N;
+  if (threadIdx.x < c) {
+    const int col = threadIdx.x;
+    float pAp = 0.f;
+    for (int ss = 0; ss < d.S_dot; ++ss) pAp += d.pAp_part[((size_t)b * d.S_dot + ss) * c + col];  // :250-251
+    const float rz = d.rz[(size_t)b * c + col];
+    float a = (pAp < d.eps) ? 0.f : rz / pAp;    // safe division :254-257 (negative curvature zeroed too)
+    if (d.has_conv[(size_t)b * c + col]) a = 0.f;  // alpha.masked_fill_(has_converged, 0) :260
+    alpha_s[col] = a;
+    if (s == 0) d.alpha[(size_t)b * c + col] = a;
+  }
+  __syncthreads();
+  const int nrs = kThreads / c;
+  const int col = threadIdx.x % c, slot = threadIdx.x / c;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  float acc = 0.f;
+  if (slot < nrs) {
+    const float a = alpha_s[col];
+    const size_t base = (size_t)b * N * c + col;
+    for (int row = r0 + slot; row < r1; row += nrs) {
+      const size_t i = base + (size_t)row * c;
+      const float rn = fmaf(-a, d.Ap[i], d.r[i]);  // residual - alpha * mvms  :264 / :78
+      d.r[i] = rn;
+      d.x[i] = fmaf(a, d.p[i], d.x[i]);            // result + alpha * p       :31
+      acc = fmaf(rn, rn, acc);
+    }
+  }
+  const float tot = block_colsum(slot < nrs ? acc : 0.f, c, nrs, red);
+  if (threadIdx.x < c) d.rr_part[((size_t)b * S + s) * c + col] = tot;
+}
+
+__global__ __launch_bounds__(kThreads) void k_cg_ctrl(CgDev d, int k) {
+  if (d.ctrl->stop) return;
+  __shared__ float red[kThreads];
+  const int64_t n = d.B * d.c;
+  float lsum = 0.f, lnan = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kThreads) {
+    const int64_t b = i / d.c;
+    const int col = (int)(i % d.c);
+    float rr = 0.f, rzn = 0.f;
+    for (int s = 0; s < d.S; ++s) rr += d.rr_part[(b * d.S + s) * d.c + col];
+    for (int s = 0; s < d.S_rz; ++s) rzn += d.rz_part[(b * d.S_rz + s) * d.c + col];
+    const float rzo = d.rz[i];                   // beta <- old residual_inner_prod   :34
+    const float beta = (rzo < d.eps) ? 0.f : rzn / rzo;  // :39-42
+    d.rz[i] = rzn;
+    d.beta[i] = beta;
+    float rn = sqrtf(rr);                        // vector_norm(residual)            :298
+    if (d.rhs_is_zero[i]) rn = 0.f;              // :299
+    d.resid_norm[i] = rn;
+    d.has_conv[i] = rn < d.stop_after;           // :300
+    lsum += rn;
+    if (rr != rr || rzn != rzn) lnan = 1.f;
+  }
+  const float mean = block_sum256(lsum, red) / (float)n;
+  const float anynan = block_sum256(lnan, red);
+  const int kfloor = min(10, d.max_iter - 1);
+  const bool stopnow = (k >= kfloor) && (mean < d.tol) &&
+                       !(d.n_tridiag && k < min(d.n_tridiag_iter, d.max_iter - 1));  // :302-306
+  if (threadIdx.x == 0) {
+    d.ctrl->iterations = k + 1;
+    d.ctrl->mean_resid = mean;
+    if (k == 0 && d.check_nan_first && anynan > 0.f) {  // NaN matvec detected on the first product
+      d.ctrl->nan_detected = 1;
+      d.ctrl->stop = 1;
+    }
+    if (stopnow) {
+      d.ctrl->tol_reached = 1;                   // :307
+      d.ctrl->stop = 1;
+    }
+  }
+  if (stopnow) return;                           // break happens BEFORE the tridiag update of iteration k
+  if (d.n_tridiag && k < d.n_tridiag_iter && !d.ctrl->tri_disabled) {  // :311
+    __syncthreads();                             // beta[] written above by other threads of this block
+    const int64_t nt = d.B * d.n_tridiag;
+    const int T = d.T;
+    float lmax = -INFINITY;
+    for (int64_t i = threadIdx.x; i < nt; i += kThreads) {
+      const int64_t b = i / d.n_tridiag;
+      const int col = (int)(i % d.n_tridiag);
+      const float alpha = d.alpha[b * d.c + col];
+      const float beta = d.beta[b * d.c + col];
+      const float ar = 1.0f / ((alpha == 0.f) ? 1.0f : alpha);  // :314-317
+      float* t = d.t_mat + ((size_t)col * d.B + b) * T * T;
+      if (k == 0) {
+        t[0] = ar;                               // :320
+      } else {
+        const float pb = d.prev_beta[i], par = d.prev_ar[i];
+        t[k * T + k] = fmaf(pb, par, ar);        // addcmul(alpha_reciprocal, prev_beta, prev_alpha_reciprocal) :322
+        const float off = sqrtf(pb) * par;       // :323
+        t[k * T + k - 1] = off;
+        t[(k - 1) * T + k] = off;                // :324
+        lmax = fmaxf(lmax, off);
+      }
+      d.prev_ar[i] = ar;                         // :331-332
+      d.prev_beta[i] = beta;
+    }
+    if (k > 0) {
+      const float m = block_max256(lmax, red);
+      if (threadIdx.x == 0 && m < 1e-6f) d.ctrl->tri_disabled = 1;  // :326-327
+    }
+    if (threadIdx.x == 0) d.ctrl->last_tridiag_iter = k;           // :329
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_cg_final(CgDev d, float* __restrict__ xout, int rows_per) {
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int c = d.c, N = (int)d.N;
+  const int nrs = kThreads / c;
+  const int col = threadIdx.x % c, slot = threadIdx.x / c;
+  if (slot >= nrs) return;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  const float nrm = d.rhs_norm[(size_t)b * c + col];
+  const size_t base = (size_t)b * N * c + col;
+  for (int row = r0 + slot; row < r1; row += nrs) {
+    const size_t i = base + (size_t)row * c;
+    xout[i] = d.x[i] * nrm;                      // result.mul(rhs_norm)  :335
+  }
+}
+
+// ---- host engine -----------------------------------------------------------------------------------
+struct CgLayout {
+  Split sp;
+  int S_dot;
+  bool precond;
+  int pre_R4;
+  bool pre_pad;
+};
+
+static int padded_rank_k(int k) {
+  int rq = (k + 3) / 4, p = 1;
+  while (p < rq) p <<= 1;
+  return 4 * p;
+}
+
+static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool pre_cb, const lo_cg_params* prm,
+                        void* ws, size_t ws_bytes, CgDev* d, MatvecPlan* pl, lo_matvec_cb mv_cb, void* mv_user,
+                        const float** Qpad, float** upart, hipStream_t st, int* rc_out, bool init) {
+  const int64_t B = op->B, N = op->N, c = prm->c;
+  Split sp = choose_split(B, N, 256);
+  Arena ar(ws, ws_bytes);
+  const size_t nv = (size_t)B * N * c;
+  const bool precond = pre != nullptr || pre_cb;
+  CgDev dd;
+  dd.B = B; dd.N = N; dd.c = (int)c; dd.S = sp.S;
+  dd.ctrl = ar.take<CgCtrl>(1);
+  dd.x = ar.take<float>(nv);
+  dd.r = ar.take<float>(nv);
+  dd.p = ar.take<float>(nv);
+  dd.Ap = ar.take<float>(nv);
+  dd.z = precond ? ar.take<float>(nv) : nullptr;
+  int S_dot = sp.S;
+  if (op->kind == LO_OP_DENSE_DIAG) {
+    const int rows = dense_rows_per_wg(B, N);
+    S_dot = (int)((N + rows - 1) / rows);
+  }
+  dd.S_dot = S_dot;
+  dd.pAp_part = ar.take<float>((size_t)B * std::max(S_dot, sp.S) * c);
+  dd.rr_part = ar.take<float>((size_t)B * sp.S * c);
+  dd.rz_part = precond ? ar.take<float>((size_t)B * sp.S * c) : dd.rr_part;
+  dd.S_rz = sp.S;
+  const size_t ns = (size_t)B * c;
+  dd.rhs_norm = ar.take<float>(ns);
+  dd.rz = ar.take<float>(ns);
+  dd.alpha = ar.take<float>(ns);
+  dd.beta = ar.take<float>(ns);
+  dd.resid_norm = ar.take<float>(ns);
+  dd.rhs_is_zero = ar.take<int>(ns);
+  dd.has_conv = ar.take<int>(ns);
+  const size_t nt = (size_t)B * std::max(1, (int)prm->n_tridiag);
+  dd.prev_ar = ar.take<float>(nt);
+  dd.prev_beta = ar.take<float>(nt);
+  // preconditioner staging
+  if (pre) {
+    const int R4 = padded_rank_k(pre->k);
+    float* up = ar.take<float>((size_t)B * sp.S * R4 * c);
+    if (upart) *upart = up;
+    if (pre->ldq != R4) {
+      float* qp = ar.take<float>((size_t)B * N * R4);
+      if (init && ar.ok && ws) {
+        if (pre->ldq != pre->k) { if (rc_out) *rc_out = LO_ERR_BADARG; }
+        else {
+          int rc = pad_rows(pre->Q, pre->k, qp, R4, B * N, st);
+          if (rc && rc_out) *rc_out = rc;
+        }
+      }
+      if (Qpad) *Qpad = qp;
+    } else if (Qpad) {
+      *Qpad = pre->Q;
+    }
+  }
+  // matvec plan
+  size_t before = ar.off;
+  (void)before;
+  if (init) {
+    int rc = matvec_plan_init(pl, op, mv_cb, mv_user, c, sp, &ar, st);
+    if (rc && rc_out) *rc_out = rc;
+  } else {
+    ar.off += matvec_plan_bytes(op, c, sp);
+  }
+  if (d) *d = dd;
+  if (init && !ar.ok && rc_out && *rc_out == LO_OK) *rc_out = LO_ERR_WORKSPACE;
+  return ar.off + 1024;
+}
+
+}  // namespace lo
+
+using namespace lo;
+
+extern "C" {
+
+size_t lo_cg_workspace_bytes(const lo_op_desc* op, const lo_precond_desc* pre, const lo_cg_params* prm) {
+  if (!op || !prm) return 0;
+  // worst case: assume an opaque preconditioner closure may be used as well (needs z)
+  lo_precond_desc dummy;
+  const lo_precond_desc* p = pre;
+  if (!p) {
+    dummy.k = 4; dummy.ldq = 4; dummy.constant_diag = 0; dummy.reserved = 0; dummy.Q = nullptr; dummy.dinv = nullptr;
+    p = &dummy;
+  }
+  return cg_layout(op, p, true, prm, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                   nullptr, false);
+}
+
+int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user, const lo_precond_desc* pre,
+                    lo_matvec_cb precond_cb, void* precond_user, const lo_cg_params* prm, const float* rhs,
+                    const float* x0, float* x, float* t_mat, void* ws, size_t ws_bytes, lo_cg_info* info,
+                    void* stream) {
+  if (!op || !prm || !rhs || !x || !ws || !info) return LO_ERR_BADARG;
+  if (prm->c < 1 || prm->c > kMaxCols) return LO_ERR_UNSUPPORTED;
+  if (prm->n_tridiag < 0 || prm->n_tridiag > prm->c) return LO_ERR_BADARG;
+  if (prm->n_tridiag && !t_mat) return LO_ERR_BADARG;
+  if (pre && precond_cb) return LO_ERR_BADARG;
+  if (pre && (pre->k < 1 || pre->k > kMaxRank || !pre->Q || !pre->dinv)) return LO_ERR_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t B = op->B, N = op->N;
+  const int c = (int)prm->c;
+
+  CgDev d;
+  MatvecPlan pl;
+  const float* Qp = nullptr;
+  float* upart = nullptr;
+  int rc = LO_OK;
+  cg_layout(op, pre, precond_cb != nullptr, prm, ws, ws_bytes, &d, &pl, matvec, matvec_user, &Qp, &upart, st, &rc, true);
+  if (rc) return rc;
+  const Split sp = pl.sp;
+  d.n_tridiag = prm->n_tridiag;
+  d.max_iter = prm->max_iter;
+  d.n_tridiag_iter = prm->max_tridiag_iter;
+  d.T = prm->max_tridiag_iter;
+  d.tol = prm->tolerance;
+  d.eps = prm->eps;
+  d.stop_after = prm->stop_updating_after;
+  d.check_nan_first = (x0 == nullptr);
+  d.t_mat = t_mat;
+  const bool precond = (pre != nullptr) || (precond_cb != nullptr);
+  const int preR4 = pre ? padded_rank_k(pre->k) : 0;
+  const int* stop = &d.ctrl->stop;
+  dim3 gridv(sp.S, (unsigned)B), block(kThreads);
+
+  LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, sizeof(CgCtrl), st));
+  if (prm->n_tridiag)
+    LO_HIP_CHECK(hipMemsetAsync(t_mat, 0, sizeof(float) * (size_t)prm->n_tridiag * B * d.T * d.T, st));
+
+  auto apply_precond = [&](const float* r, float* z, float* dotp) -> int {
+    if (pre) {
+      int e = skinny_tn(Qp, preR4, preR4, r, c, upart, B, N, sp, stop, st);
+      if (e) return e;
+      return skinny_nn(Qp, preR4, preR4, upart, pre->dinv, pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL, -1.0f, r,
+                       c, z, dotp, B, N, sp, stop, st);
+    }
+    int e = precond_cb(precond_user, r, z, B, N, c, (void*)st);
+    if (e) return LO_ERR_LAUNCH;
+    return vec_dot_part(r, z, c, dotp, B, N, sp, stop, st);
+  };
+
+  // ---- initialisation (linear_cg.py:177-215) ----
+  rc = vec_dot_part(rhs, rhs, c, d.pAp_part, B, N, sp, nullptr, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_cg_init_scal, dim3(1), block, 0, st, d, d.pAp_part);
+  hipLaunchKernelGGL(k_cg_init_vec, gridv, block, 0, st, d, rhs, x0, sp.rows);
+  LO_LAUNCH_CHECK();
+  int matvecs = 0;
+  if (x0) {
+    rc = matvec_run(&pl, d.x, d.Ap, nullptr, nullptr, st);
+    if (rc) return rc;
+    ++matvecs;
+    const size_t nv = (size_t)B * N * c;
+    hipLaunchKernelGGL(k_cg_sub, dim3((unsigned)std::min<size_t>((nv + 255) / 256, 8192)), block, 0, st, d.r, d.Ap, nv);
+    LO_LAUNCH_CHECK();
+  }
+  rc = vec_dot_part(d.r, d.r, c, d.rr_part, B, N, sp, nullptr, st);
+  if (rc) return rc;
+  if (precond) {
+    rc = apply_precond(d.r, d.z, d.rz_part);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_cg_ctrl_init, dim3(1), block, 0, st, d);
+  LO_LAUNCH_CHECK();
+
+  // ---- iterations ----
+  const float* zsrc = precond ? d.z : d.r;
+  const int kfloor = std::min(10, prm->max_iter - 1);
+  int first_poll = kfloor;
+  if (prm->n_tridiag) first_poll = std::max(first_poll, std::min(prm->max_tridiag_iter, prm->max_iter - 1));
+  const bool opaque = (op->kind == LO_OP_CALLBACK) || (precond_cb != nullptr);
+  const int chunk = opaque ? 1 : 4;
+  CgCtrl h;
+  memset(&h, 0, sizeof(h));
+  auto poll = [&]() -> int {
+    LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
+    LO_HIP_CHECK(hipStreamSynchronize(st));
+    return LO_OK;
+  };
+  if (opaque || prm->max_iter == 0) {  // closures cannot see the stop word: look before the first product
+    rc = poll();
+    if (rc) return rc;
+  }
+  int k = 0;
+  int launched = 0;
+  while (k < prm->max_iter && !h.stop) {
+    hipLaunchKernelGGL(k_cg_update_p, gridv, block, 0, st, d, zsrc, k == 0 ? 1 : 0, sp.rows);
+    LO_LAUNCH_CHECK();
+    rc = matvec_run(&pl, d.p, d.Ap, d.pAp_part, stop, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cg_update_xr, gridv, block, 0, st, d, sp.rows);
+    LO_LAUNCH_CHECK();
+    if (precond) {
+      rc = apply_precond(d.r, d.z, d.rz_part);
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_cg_ctrl, dim3(1), block, 0, st, d, k);
+    LO_LAUNCH_CHECK();
+    ++launched;
+    const bool at_poll = (k >= first_poll) && (((k - first_poll) % chunk) == 0);
+    if (at_poll || k == prm->max_iter - 1 || (opaque && k == 0)) {
+      rc = poll();
+      if (rc) return rc;
+    }
+    ++k;
+  }
+  if (launched == 0 || !h.stop) {
+    rc = poll();
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_cg_final, gridv, block, 0, st, d, x, sp.rows);
+  LO_LAUNCH_CHECK();
+  LO_HIP_CHECK(hipStreamSynchronize(st));
+
+  info->iterations = h.iterations;
+  info->matvecs = matvecs + h.iterations;
+  info->tolerance_reached = h.tol_reached;
+  info->nan_detected = h.nan_detected;
+  info->skipped = h.skipped;
+  info->last_tridiag_iter = h.last_tridiag_iter;
+  info->mean_residual = h.mean_resid;
+  info->reserved = 0.f;
+  return LO_OK;
+}
+
+// z = P^{-1} r as a standalone call (precondition_closure, added_diag_linear_operator.py:135-140)
+size_t lo_precond_apply_workspace_bytes(int64_t B, int64_t N, int32_t k, int64_t c) {
+  Split sp = choose_split(B, N, 256);
+  const int R4 = padded_rank_k(k);
+  return align_up((size_t)B * sp.S * R4 * c * sizeof(float), 256) + align_up((size_t)B * N * R4 * sizeof(float), 256) +
+         1024;
+}
+
+int lo_precond_apply_f32(const lo_precond_desc* pre, const float* r, float* z, int64_t B, int64_t N, int64_t c, void* ws,
+                         size_t ws_bytes, void* stream) {
+  if (!pre || !r || !z || !ws) return LO_ERR_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  Split sp = choose_split(B, N, 256);
+  const int R4 = padded_rank_k(pre->k);
+  Arena ar(ws, ws_bytes);
+  float* upart = ar.take<float>((size_t)B * sp.S * R4 * c);
+  const float* Qp = pre->Q;
+  if (pre->ldq != R4) {
+    if (pre->ldq != pre->k) return LO_ERR_BADARG;
+    float* qp = ar.take<float>((size_t)B * N * R4);
+    if (!ar.ok) return LO_ERR_WORKSPACE;
+    int rc = pad_rows(pre->Q, pre->k, qp, R4, B * N, st);
+    if (rc) return rc;
+    Qp = qp;
+  }
+  if (!ar.ok) return LO_ERR_WORKSPACE;
+  int rc = skinny_tn(Qp, R4, R4, r, c, upart, B, N, sp, nullptr, st);
+  if (rc) return rc;
+  return skinny_nn(Qp, R4, R4, upart, pre->dinv, pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL, -1.0f, r, c, z,
+                   nullptr, B, N, sp, nullptr, st);
+}
+
+}  // extern "C"

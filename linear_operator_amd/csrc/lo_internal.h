@@ -1,0 +1,109 @@
+// lo_internal.h -- shared declarations of liblo_amd's translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/lo_amd.h"
+
+namespace lo {
+
+constexpr int kThreads = 256;  // 4 wave64 per workgroup everywhere (vector / skinny kernels)
+constexpr int kMaxCols = 256;  // a workgroup's thread->column map needs c <= 256
+constexpr int kMaxRank = 256;  // padded root rank (floats per row) of a skinny operand
+
+#define LO_HIP_CHECK(expr)                                                                  \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      fprintf(stderr, "liblo_amd: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return LO_ERR_LAUNCH;                                                                 \
+    }                                                                                       \
+  } while (0)
+
+#define LO_LAUNCH_CHECK() LO_HIP_CHECK(hipGetLastError())
+
+// Row split of one batch member over S workgroups (rows multiple of 4 except the tail).
+struct Split {
+  int S;
+  int rows;
+};
+Split choose_split(int64_t B, int64_t N, int min_rows);
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over the caller's workspace.
+struct Arena {
+  char* base;
+  size_t cap, off;
+  bool ok;
+  Arena(void* p, size_t bytes) : base((char*)p), cap(bytes), off(0), ok(true) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = align_up(off, 256);
+    size_t bytes = n * sizeof(T);
+    T* r = (T*)(base ? base + off : nullptr);
+    off += bytes;
+    if (base && off > cap) ok = false;
+    return r;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// device control block of one CG solve (lives in the workspace; host polls it)
+struct CgCtrl {
+  int stop;               // sticky: every kernel of the solve exits at once when set
+  int iterations;         // loop bodies executed
+  int tol_reached;
+  int nan_detected;
+  int skipped;
+  int last_tridiag_iter;
+  int tri_disabled;       // update_tridiag == False (linear_cg.py:326-327)
+  float mean_resid;
+};
+
+// ---- skinny operand kernels (lo_skinny.hip): A [B,N,lda] with R4 = 4*RQ padded columns --------
+// tpart[B,S,R4,c] = A[rows_s]^T v[rows_s]
+int skinny_tn(const float* A, int lda, int R4, const float* v, int64_t c, float* tpart, int64_t B, int64_t N, Split sp,
+              const int* stop, hipStream_t st);
+// y = sgn * A (sum_s tpart) + dd o v ; optional dot_part[B,S,c] = sum_rows v o y
+int skinny_nn(const float* A, int lda, int R4, const float* tpart, const float* dd, int dd_mode, float sgn,
+              const float* v, int64_t c, float* y, float* dot_part, int64_t B, int64_t N, Split sp, const int* stop,
+              hipStream_t st);
+// copy rows [B,N,R] -> zero padded [B,N,R4]
+int pad_rows(const float* src, int R, float* dst, int R4, int64_t rows, hipStream_t st);
+
+// ---- vector kernels (lo_vec.hip): vectors [B,N,c] ------------------------------------------------
+int vec_dot_part(const float* a, const float* b, int64_t c, float* part, int64_t B, int64_t N, Split sp, const int* stop,
+                 hipStream_t st);
+// y = dd o v added onto y (dense / kron matvec epilogue): y += dd o v
+int vec_add_diag(const float* dd, int dd_mode, const float* v, float* y, int64_t c, int64_t B, int64_t N, Split sp,
+                 const int* stop, hipStream_t st);
+
+// ---- operator matvec dispatch (lo_matvec.hip) ---------------------------------------------------
+struct MatvecPlan {
+  lo_op_desc op;
+  int64_t c;
+  Split sp;           // row split used by the skinny kernels / dot partials
+  int S_dot;          // number of partials per (b,col) the plan writes into dot_part
+  const float* Apad;  // padded copy of C when R % 4 != 0 (else op.A0)
+  int lda, R4;
+  float* tpart;       // [B,S,R4,c]
+  float* kron_tmp;    // [B,N,c]
+  lo_matvec_cb cb;
+  void* cb_user;
+};
+size_t matvec_plan_bytes(const lo_op_desc* op, int64_t c, Split sp);
+int matvec_plan_init(MatvecPlan* pl, const lo_op_desc* op, lo_matvec_cb cb, void* cb_user, int64_t c, Split sp,
+                     Arena* ar, hipStream_t st);
+// y = A v (+ optional dot partials sum_rows v o y, S_dot per (b,col))
+int matvec_run(const MatvecPlan* pl, const float* v, float* y, float* dot_part, const int* stop, hipStream_t st);
+
+// dense / kron kernels
+int dense_matvec(const float* K, const float* d, int dd_mode, const float* v, float* y, float* dot_part, int64_t B,
+                 int64_t N, int64_t c, int rows_per_wg, const int* stop, hipStream_t st);
+int dense_rows_per_wg(int64_t B, int64_t N);
+int kron_matvec(const float* K1, const float* K2, const float* v, float* tmp, float* y, int64_t B, int n1, int n2,
+                int64_t c, const int* stop, hipStream_t st);
+
+}  // namespace lo

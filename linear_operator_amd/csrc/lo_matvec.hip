@@ -1,0 +1,136 @@
+// lo_matvec.hip -- operator descriptor -> kernel sequence ("op-tree lowering" target), and the public
+// lo_matvec_f32 entry point (LinearOperator._matmul of the hot-path classes, lo_amd.h).
+#include <algorithm>
+
+#include "lo_internal.h"
+
+namespace lo {
+
+static int padded_rank(int64_t R) {
+  int64_t rq = (R + 3) / 4;
+  int64_t p = 1;
+  while (p < rq) p <<= 1;
+  return (int)(4 * p);
+}
+
+size_t matvec_plan_bytes(const lo_op_desc* op, int64_t c, Split sp) {
+  Arena ar(nullptr, 0);
+  if (op->kind == LO_OP_LOWRANK_DIAG) {
+    const int R4 = padded_rank(op->R);
+    if (R4 != op->R) ar.take<float>((size_t)op->B * op->N * R4);
+    ar.take<float>((size_t)op->B * sp.S * R4 * c);
+  } else if (op->kind == LO_OP_KRON_DIAG) {
+    ar.take<float>((size_t)op->B * op->N * c);
+  }
+  return ar.off + 256;
+}
+
+int matvec_plan_init(MatvecPlan* pl, const lo_op_desc* op, lo_matvec_cb cb, void* cb_user, int64_t c, Split sp,
+                     Arena* ar, hipStream_t st) {
+  pl->op = *op;
+  pl->c = c;
+  pl->sp = sp;
+  pl->cb = cb;
+  pl->cb_user = cb_user;
+  pl->Apad = nullptr;
+  pl->tpart = nullptr;
+  pl->kron_tmp = nullptr;
+  pl->lda = pl->R4 = 0;
+  pl->S_dot = sp.S;
+  if (op->B < 1 || op->N < 1 || c < 1) return LO_ERR_BADARG;
+  if (op->diag_mode != LO_DIAG_NONE && !op->d) return LO_ERR_BADARG;
+  switch (op->kind) {
+    case LO_OP_LOWRANK_DIAG: {
+      if (!op->A0 || op->R < 1) return LO_ERR_BADARG;
+      const int R4 = padded_rank(op->R);
+      if (R4 > kMaxRank) return LO_ERR_UNSUPPORTED;
+      pl->R4 = R4;
+      pl->lda = R4;
+      if (R4 != op->R) {
+        float* p = ar->take<float>((size_t)op->B * op->N * R4);
+        if (!ar->ok) return LO_ERR_WORKSPACE;
+        int rc = pad_rows(op->A0, (int)op->R, p, R4, op->B * op->N, st);
+        if (rc) return rc;
+        pl->Apad = p;
+      } else {
+        pl->Apad = op->A0;
+      }
+      pl->tpart = ar->take<float>((size_t)op->B * sp.S * R4 * c);
+      break;
+    }
+    case LO_OP_DENSE_DIAG: {
+      if (!op->A0) return LO_ERR_BADARG;
+      const int rows = dense_rows_per_wg(op->B, op->N);
+      pl->S_dot = (int)((op->N + rows - 1) / rows);
+      break;
+    }
+    case LO_OP_KRON_DIAG: {
+      if (!op->A0 || !op->A1 || op->R * op->n2 != op->N) return LO_ERR_BADARG;
+      pl->kron_tmp = ar->take<float>((size_t)op->B * op->N * c);
+      break;
+    }
+    case LO_OP_CALLBACK:
+      if (!cb) return LO_ERR_BADARG;
+      break;
+    default:
+      return LO_ERR_BADARG;
+  }
+  return ar->ok ? LO_OK : LO_ERR_WORKSPACE;
+}
+
+int matvec_run(const MatvecPlan* pl, const float* v, float* y, float* dot_part, const int* stop, hipStream_t st) {
+  const lo_op_desc& op = pl->op;
+  int rc = LO_OK;
+  switch (op.kind) {
+    case LO_OP_LOWRANK_DIAG:
+      rc = skinny_tn(pl->Apad, pl->lda, pl->R4, v, pl->c, pl->tpart, op.B, op.N, pl->sp, stop, st);
+      if (rc) return rc;
+      return skinny_nn(pl->Apad, pl->lda, pl->R4, pl->tpart, op.d, op.diag_mode, 1.0f, v, pl->c, y, dot_part, op.B,
+                       op.N, pl->sp, stop, st);
+    case LO_OP_DENSE_DIAG:
+      return dense_matvec(op.A0, op.d, op.diag_mode, v, y, dot_part, op.B, op.N, pl->c,
+                          dense_rows_per_wg(op.B, op.N), stop, st);
+    case LO_OP_KRON_DIAG:
+      rc = kron_matvec(op.A0, op.A1, v, pl->kron_tmp, y, op.B, (int)op.R, (int)op.n2, pl->c, stop, st);
+      if (rc) return rc;
+      rc = vec_add_diag(op.d, op.diag_mode, v, y, pl->c, op.B, op.N, pl->sp, stop, st);
+      if (rc) return rc;
+      if (dot_part) rc = vec_dot_part(v, y, pl->c, dot_part, op.B, op.N, pl->sp, stop, st);
+      return rc;
+    case LO_OP_CALLBACK:
+      rc = pl->cb(pl->cb_user, v, y, op.B, op.N, pl->c, (void*)st);
+      if (rc) return LO_ERR_LAUNCH;
+      if (dot_part) rc = vec_dot_part(v, y, pl->c, dot_part, op.B, op.N, pl->sp, stop, st);
+      return rc;
+  }
+  return LO_ERR_BADARG;
+}
+
+}  // namespace lo
+
+using namespace lo;
+
+extern "C" {
+
+int lo_abi_version(void) { return 1; }
+const char* lo_target_arch(void) { return "gfx950"; }
+
+size_t lo_matvec_workspace_bytes(const lo_op_desc* op, int64_t c) {
+  if (!op) return 0;
+  Split sp = choose_split(op->B, op->N, 256);
+  return matvec_plan_bytes(op, c, sp);
+}
+
+int lo_matvec_f32(const lo_op_desc* op, const float* v, float* y, int64_t c, void* ws, size_t ws_bytes, void* stream) {
+  if (!op || !v || !y || op->kind == LO_OP_CALLBACK) return LO_ERR_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  Split sp = choose_split(op->B, op->N, 256);
+  Arena ar(ws, ws_bytes);
+  if (matvec_plan_bytes(op, c, sp) > 256 && !ws) return LO_ERR_WORKSPACE;
+  MatvecPlan pl;
+  int rc = matvec_plan_init(&pl, op, nullptr, nullptr, c, sp, &ar, st);
+  if (rc) return rc;
+  return matvec_run(&pl, v, y, nullptr, nullptr, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// lo_vec.hip -- elementwise / reduction kernels over vectors [B, N, c] (c innermost).
+// Thread map: a member's row range is a contiguous slab; thread t owns column t % c and row slot t / c
+// (threads >= c * (256 / c) idle), so consecutive lanes touch consecutive addresses and each thread
+// keeps ONE accumulator per reduction.  Partials are [B, S, c], summed in fixed order by the consumer.
+#include <algorithm>
+
+#include "lo_device.h"
+#include "lo_internal.h"
+
+namespace lo {
+
+Split choose_split(int64_t B, int64_t N, int min_rows) {
+  // aim for >= ~1024 workgroups (4 per CU) but keep >= min_rows rows per workgroup
+  int64_t S = (1024 + B - 1) / B;
+  int64_t maxS = std::max<int64_t>(1, N / std::max(min_rows, 4));
+  S = std::max<int64_t>(1, std::min<int64_t>(S, maxS));
+  S = std::min<int64_t>(S, 64);
+  int64_t rows = (N + S - 1) / S;
+  rows = (rows + 3) / 4 * 4;
+  S = (N + rows - 1) / rows;
+  Split sp;
+  sp.S = (int)S;
+  sp.rows = (int)rows;
+  return sp;
+}
+
+__global__ __launch_bounds__(kThreads) void k_dot_part(const float* __restrict__ a, const float* __restrict__ bvec,
+                                                        int c, float* __restrict__ part, int N, int rows_per,
+                                                        const int* __restrict__ stop) {
+  if (stop && *stop) return;
+  __shared__ float red[kThreads];
+  const int s = blockIdx.x, b = blockIdx.y, S = gridDim.x;
+  const int nrs = kThreads / c;
+  const int col = threadIdx.x % c, slot = threadIdx.x / c;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  float acc = 0.f;
+  if (slot < nrs) {
+    const size_t base = (size_t)b * N * c + col;
+    for (int row = r0 + slot; row < r1; row += nrs) acc = fmaf(a[base + (size_t)row * c], bvec[base + (size_t)row * c], acc);
+  }
+  const float tot = block_colsum(slot < nrs ? acc : 0.f, c, nrs, red);
+  if (threadIdx.x < c) part[((size_t)b * S + s) * c + col] = tot;
+}
+
+int vec_dot_part(const float* a, const float* b, int64_t c, float* part, int64_t B, int64_t N, Split sp, const int* stop,
+                 hipStream_t st) {
+  if (c < 1 || c > kMaxCols) return LO_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_dot_part, dim3(sp.S, (unsigned)B), dim3(kThreads), 0, st, a, b, (int)c, part, (int)N, sp.rows,
+                     stop);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+__global__ __launch_bounds__(kThreads) void k_add_diag(const float* __restrict__ dd, int dd_mode,
+                                                        const float* __restrict__ v, float* __restrict__ y, int c,
+                                                        int N, int rows_per, const int* __restrict__ stop) {
+  if (stop && *stop) return;
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int nrs = kThreads / c;
+  const int col = threadIdx.x % c, slot = threadIdx.x / c;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  if (slot >= nrs) return;
+  const size_t base = (size_t)b * N * c + col;
+  const float dc = (dd_mode == LO_DIAG_CONST) ? dd[b] : 0.f;
+  for (int row = r0 + slot; row < r1; row += nrs) {
+    const float dv = (dd_mode == LO_DIAG_FULL) ? dd[(size_t)b * N + row] : dc;
+    y[base + (size_t)row * c] = fmaf(dv, v[base + (size_t)row * c], y[base + (size_t)row * c]);
+  }
+}
+
+int vec_add_diag(const float* dd, int dd_mode, const float* v, float* y, int64_t c, int64_t B, int64_t N, Split sp,
+                 const int* stop, hipStream_t st) {
+  if (dd_mode == LO_DIAG_NONE) return LO_OK;
+  if (c < 1 || c > kMaxCols) return LO_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_add_diag, dim3(sp.S, (unsigned)B), dim3(kThreads), 0, st, dd, dd_mode, v, y, (int)c, (int)N,
+                     sp.rows, stop);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+}  // namespace lo

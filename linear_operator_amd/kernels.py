@@ -1,0 +1,365 @@
+"""Tensor-level wrappers over the C ABI (include/lo_amd.h): shape checks, batch flattening, workspaces.
+
+Everything here takes contiguous fp32 HIP tensors and launches hand-written gfx950 kernels on the
+current stream; there is no other implementation behind these functions.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+
+from . import _hip
+
+
+@dataclass
+class OperatorDescriptor:
+    """Lowered form of an operator tree (see operators/_lowering.py): what the kernels need."""
+
+    kind: int
+    B: int
+    N: int
+    A0: Optional[torch.Tensor] = None  # C [B,N,R] | K [B,N,N] | K1 [B,n1,n1]
+    A1: Optional[torch.Tensor] = None  # K2 [B,n2,n2]
+    d: Optional[torch.Tensor] = None  # [B,N] (FULL) or [B] (CONST)
+    diag_mode: int = _hip.LO_DIAG_NONE
+    R: int = 0
+    n2: int = 0
+    batch_shape: torch.Size = torch.Size()
+
+    @property
+    def device(self):
+        for t in (self.A0, self.A1, self.d):
+            if t is not None:
+                return t.device
+        raise ValueError("empty descriptor")
+
+    def c_struct(self) -> _hip.OpDesc:
+        s = _hip.OpDesc()
+        s.kind, s.diag_mode, s.B, s.N, s.R, s.n2 = self.kind, self.diag_mode, self.B, self.N, self.R, self.n2
+        s.A0 = None if self.A0 is None else self.A0.data_ptr()
+        s.A1 = None if self.A1 is None else self.A1.data_ptr()
+        s.d = None if self.d is None else self.d.data_ptr()
+        return s
+
+    def without_diag(self) -> "OperatorDescriptor":
+        return OperatorDescriptor(self.kind, self.B, self.N, self.A0, self.A1, None, _hip.LO_DIAG_NONE, self.R,
+                                  self.n2, self.batch_shape)
+
+
+def _flat(t: torch.Tensor, keep: int) -> torch.Tensor:
+    """[*batch, <keep trailing dims>] -> contiguous [B, ...]."""
+    t = t.contiguous()
+    return t.reshape(-1, *t.shape[t.dim() - keep:])
+
+
+def lowrank_diag_descriptor(Croot: torch.Tensor, d: Optional[torch.Tensor], const_diag: bool = False):
+    _hip.require_hip(Croot, d)
+    batch = Croot.shape[:-2]
+    N, R = Croot.shape[-2:]
+    C3 = _flat(Croot, 2)
+    return _with_diag(OperatorDescriptor(_hip.LO_OP_LOWRANK_DIAG, C3.shape[0], N, A0=C3, R=R, batch_shape=batch), d,
+                      const_diag)
+
+
+def dense_diag_descriptor(K: torch.Tensor, d: Optional[torch.Tensor], const_diag: bool = False):
+    _hip.require_hip(K, d)
+    batch = K.shape[:-2]
+    N = K.shape[-1]
+    K3 = _flat(K, 2)
+    return _with_diag(OperatorDescriptor(_hip.LO_OP_DENSE_DIAG, K3.shape[0], N, A0=K3, batch_shape=batch), d,
+                      const_diag)
+
+
+def kron_diag_descriptor(K1: torch.Tensor, K2: torch.Tensor, d: Optional[torch.Tensor], const_diag: bool = False):
+    _hip.require_hip(K1, K2, d)
+    batch = K1.shape[:-2]
+    n1, n2 = K1.shape[-1], K2.shape[-1]
+    A = _flat(K1, 2)
+    Bm = _flat(K2, 2)
+    return _with_diag(OperatorDescriptor(_hip.LO_OP_KRON_DIAG, A.shape[0], n1 * n2, A0=A, A1=Bm, R=n1, n2=n2,
+                                         batch_shape=batch), d, const_diag)
+
+
+def _with_diag(desc: OperatorDescriptor, d, const_diag):
+    if d is None:
+        return desc
+    if const_diag:
+        desc.d = d.contiguous().reshape(-1)
+        assert desc.d.numel() == desc.B, "constant diagonal must hold one value per batch member"
+        desc.diag_mode = _hip.LO_DIAG_CONST
+    else:
+        desc.d = _flat(d, 1)
+        assert desc.d.shape == (desc.B, desc.N)
+        desc.diag_mode = _hip.LO_DIAG_FULL
+    return desc
+
+
+# ------------------------------------------------------------------------------------------------
+def matvec(desc: OperatorDescriptor, v: torch.Tensor) -> torch.Tensor:
+    """y = A v for v [*batch, N, c] (LinearOperator._matmul of the lowered operator)."""
+    lib = _hip.load()
+    _hip.require_hip(v)
+    c = v.shape[-1]
+    v3 = _flat(v, 2)
+    if v3.shape[0] != desc.B or v3.shape[1] != desc.N:
+        raise RuntimeError(f"matvec: rhs of shape {tuple(v.shape)} does not match operator batch {desc.B} x N {desc.N}")
+    y = torch.empty_like(v3)
+    s = desc.c_struct()
+    ws_bytes = lib.lo_matvec_workspace_bytes(C.byref(s), c)
+    ws = _hip.workspace(ws_bytes, v.device)
+    _hip.check(lib.lo_matvec_f32(C.byref(s), _hip.ptr(v3), _hip.ptr(y), c, _hip.ptr(ws), ws.numel(),
+                                 _hip.stream_ptr(v.device)), "lo_matvec_f32")
+    return y.reshape(v.shape)
+
+
+@dataclass
+class WoodburyPreconditioner:
+    """Device form of the reference's cached (Q, noise) pair, added_diag_linear_operator.py:63-70."""
+
+    Q: torch.Tensor  # [B, N, ldq]
+    dinv: torch.Tensor  # [B, N] or [B]
+    k: int
+    constant_diag: bool
+    logdet: Optional[torch.Tensor] = None  # [B]
+
+    def c_struct(self) -> _hip.PrecondDesc:
+        s = _hip.PrecondDesc()
+        s.k, s.ldq, s.constant_diag, s.reserved = self.k, self.Q.shape[-1], int(self.constant_diag), 0
+        s.Q, s.dinv = self.Q.data_ptr(), self.dinv.data_ptr()
+        return s
+
+
+@dataclass
+class CGResult:
+    x: torch.Tensor
+    t_mat: Optional[torch.Tensor]
+    iterations: int
+    matvecs: int
+    tolerance_reached: bool
+    nan_detected: bool
+    skipped: bool
+    mean_residual: float
+
+
+def _wrap_closure(fn: Callable, device):
+    """Python closure (tensor -> tensor) as an lo_matvec_cb."""
+    err = []
+
+    def cb(user, v_ptr, y_ptr, B, N, c, stream):
+        try:
+            v = _hip.as_tensor(v_ptr, (B, N, c), device)
+            y = _hip.as_tensor(y_ptr, (B, N, c), device)
+            out = fn(v)
+            y.copy_(out.reshape(B, N, c))
+            return 0
+        except BaseException as e:  # noqa: BLE001 -- must not unwind through C
+            err.append(e)
+            return 1
+
+    return _hip.MATVEC_CB(cb), err
+
+
+def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optional[torch.Tensor] = None,
+             precond: Optional[WoodburyPreconditioner] = None, matvec_closure: Optional[Callable] = None,
+             precond_closure: Optional[Callable] = None, closure_batch_shape=None, n_tridiag: int = 0,
+             max_iter: int = 1000, max_tridiag_iter: int = 20, tolerance: float = 1.0, eps: float = 1e-10,
+             stop_updating_after: float = 1e-10) -> CGResult:
+    """lo_cg_solve_f32: the reference's linear_cg (utils/linear_cg.py:98-359) on the device.
+
+    rhs [*batch, N, c].  Either `desc` (structured operator, fully native loop) or `matvec_closure`
+    (opaque callable on [B,N,c] tensors).  `closure_batch_shape` reshapes [B,...] back for closures.
+    """
+    lib = _hip.load()
+    _hip.require_hip(rhs, x0)
+    N, c = rhs.shape[-2:]
+    rhs3 = _flat(rhs, 2)
+    B = rhs3.shape[0]
+    x03 = None if x0 is None else _flat(x0.expand_as(rhs), 2)
+    dev = rhs.device
+    keep = []
+    if desc is None:
+        if matvec_closure is None:
+            raise ValueError("need an operator descriptor or a matvec closure")
+        s = _hip.OpDesc()
+        s.kind, s.diag_mode, s.B, s.N, s.R, s.n2 = _hip.LO_OP_CALLBACK, _hip.LO_DIAG_NONE, B, N, 0, 0
+        bshape = tuple(closure_batch_shape) if closure_batch_shape is not None else tuple(rhs.shape[:-2])
+
+        def mv(v):
+            return matvec_closure(v.reshape(*bshape, N, c))
+
+        mv_cb, mv_err = _wrap_closure(mv, dev)
+    else:
+        if desc.B != B or desc.N != N:
+            raise RuntimeError(f"cg_solve: rhs {tuple(rhs.shape)} does not match operator batch {desc.B}, N {desc.N}")
+        s = desc.c_struct()
+        mv_cb, mv_err = _hip.MATVEC_CB(), []
+    if precond_closure is not None:
+        bshape_p = tuple(closure_batch_shape) if closure_batch_shape is not None else tuple(rhs.shape[:-2])
+
+        def pc(v):
+            return precond_closure(v.reshape(*bshape_p, N, c))
+
+        pc_cb, pc_err = _wrap_closure(pc, dev)
+    else:
+        pc_cb, pc_err = _hip.MATVEC_CB(), []
+    keep += [mv_cb, pc_cb]
+    pre_s = precond.c_struct() if precond is not None else None
+    prm = _hip.CgParams()
+    prm.c, prm.n_tridiag, prm.max_iter, prm.max_tridiag_iter = c, n_tridiag, max_iter, max_tridiag_iter
+    prm.tolerance, prm.eps, prm.stop_updating_after = tolerance, eps, stop_updating_after
+    ws_bytes = lib.lo_cg_workspace_bytes(C.byref(s), C.byref(pre_s) if pre_s is not None else None, C.byref(prm))
+    ws = _hip.workspace(ws_bytes, dev)
+    x = torch.empty_like(rhs3)
+    t_mat = None
+    if n_tridiag:
+        t_mat = torch.empty(n_tridiag, B, max_tridiag_iter, max_tridiag_iter, dtype=torch.float32, device=dev)
+    info = _hip.CgInfo()
+    rc = lib.lo_cg_solve_f32(C.byref(s), mv_cb, None, C.byref(pre_s) if pre_s is not None else None, pc_cb, None,
+                             C.byref(prm), _hip.ptr(rhs3), _hip.ptr(x03), _hip.ptr(x), _hip.ptr(t_mat), _hip.ptr(ws),
+                             ws.numel(), C.byref(info), _hip.stream_ptr(dev))
+    for e in (mv_err + pc_err):
+        raise e
+    _hip.check(rc, "lo_cg_solve_f32")
+    if t_mat is not None:
+        m = info.last_tridiag_iter + 1
+        t_mat = t_mat[:, :, :m, :m].contiguous()
+    return CGResult(x.reshape(rhs.shape), t_mat, info.iterations, info.matvecs, bool(info.tolerance_reached),
+                    bool(info.nan_detected), bool(info.skipped), float(info.mean_residual))
+
+
+def precond_apply(pre: WoodburyPreconditioner, r: torch.Tensor) -> torch.Tensor:
+    lib = _hip.load()
+    _hip.require_hip(r)
+    N, c = r.shape[-2:]
+    r3 = _flat(r, 2)
+    B = r3.shape[0]
+    z = torch.empty_like(r3)
+    s = pre.c_struct()
+    ws = _hip.workspace(lib.lo_precond_apply_workspace_bytes(B, N, pre.k, c), r.device)
+    _hip.check(lib.lo_precond_apply_f32(C.byref(s), _hip.ptr(r3), _hip.ptr(z), B, N, c, _hip.ptr(ws), ws.numel(),
+                                        _hip.stream_ptr(r.device)), "lo_precond_apply_f32")
+    return z.reshape(r.shape)
+
+
+# ------------------------------------------------------------------------------------------------
+def pivoted_cholesky(desc: OperatorDescriptor, rank: int, error_tol: float = 1e-3):
+    """lo_pivoted_cholesky_f32: PivotedCholesky.forward (functions/_pivoted_cholesky.py:14-105) of the
+    NON-diagonal part of `desc`.  Returns (L [*batch, N, m], permutation [*batch, N] int64)."""
+    lib = _hip.load()
+    dev = desc.device
+    B, N = desc.B, desc.N
+    max_rank = min(int(rank), N)
+    L_rows = torch.empty(B, max_rank, N, dtype=torch.float32, device=dev)
+    perm = torch.empty(B, N, dtype=torch.int64, device=dev)
+    s = desc.without_diag().c_struct()
+    ws = _hip.workspace(lib.lo_pivoted_cholesky_workspace_bytes(C.byref(s), max_rank), dev)
+    m = C.c_int32(0)
+    _hip.check(lib.lo_pivoted_cholesky_f32(C.byref(s), max_rank, float(error_tol), _hip.ptr(L_rows), _hip.ptr(perm),
+                                           C.byref(m), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)),
+               "lo_pivoted_cholesky_f32")
+    L = L_rows[:, : m.value, :].mT.contiguous()  # _pivoted_cholesky.py:105
+    bs = tuple(desc.batch_shape)
+    return L.reshape(*bs, N, m.value), perm.reshape(*bs, N)
+
+
+def padded_rank(k: int) -> int:
+    rq, p = (k + 3) // 4, 1
+    while p < rq:
+        p <<= 1
+    return 4 * p
+
+
+def precond_build(L: torch.Tensor, d: torch.Tensor, constant_diag: bool) -> WoodburyPreconditioner:
+    """lo_precond_build_f32: AddedDiagLinearOperator._init_cache* (added_diag_linear_operator.py:144-184).
+    L [*batch, N, k]; d [*batch, N] (or [*batch] when constant_diag)."""
+    lib = _hip.load()
+    _hip.require_hip(L, d)
+    N, k = L.shape[-2:]
+    L3 = _flat(L, 2)
+    B = L3.shape[0]
+    dev = L.device
+    ldq = padded_rank(k)
+    Q = torch.empty(B, N, ldq, dtype=torch.float32, device=dev)
+    if constant_diag:
+        d2 = d.contiguous().reshape(-1)
+        assert d2.numel() == B
+        dinv = torch.empty(B, dtype=torch.float32, device=dev)
+        mode = _hip.LO_DIAG_CONST
+    else:
+        d2 = _flat(d, 1)
+        assert d2.shape == (B, N)
+        dinv = torch.empty(B, N, dtype=torch.float32, device=dev)
+        mode = _hip.LO_DIAG_FULL
+    logdet = torch.empty(B, dtype=torch.float32, device=dev)
+    ws = _hip.workspace(lib.lo_precond_build_workspace_bytes(B, N, k), dev)
+    _hip.check(lib.lo_precond_build_f32(_hip.ptr(L3), _hip.ptr(d2), mode, B, N, k, _hip.ptr(Q), _hip.ptr(dinv),
+                                        _hip.ptr(logdet), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)),
+               "lo_precond_build_f32")
+    return WoodburyPreconditioner(Q, dinv, k, constant_diag, logdet.reshape(L.shape[:-2]))
+
+
+def tridiag_eigh_slq(t_mat: torch.Tensor, n: int, want_evecs: bool = False, want_logdet: bool = True):
+    """lo_tridiag_eigh_slq_f32 on t_mat [P, *batch, T, T] -> (evals [P,*batch,T], evecs or None, logdet [*batch])."""
+    lib = _hip.load()
+    _hip.require_hip(t_mat)
+    P = t_mat.shape[0]
+    T = t_mat.shape[-1]
+    batch = t_mat.shape[1:-2]
+    t3 = t_mat.contiguous().reshape(-1, T, T)
+    B = t3.shape[0] // P
+    dev = t_mat.device
+    evals = torch.empty(P * B, T, dtype=torch.float32, device=dev)
+    evecs = torch.empty(P * B, T, T, dtype=torch.float32, device=dev) if want_evecs else None
+    logdet = torch.empty(B, dtype=torch.float32, device=dev) if want_logdet else None
+    ws = _hip.workspace(lib.lo_tridiag_eigh_slq_workspace_bytes(P, B), dev)
+    _hip.check(lib.lo_tridiag_eigh_slq_f32(_hip.ptr(t3), P, B, T, int(n), _hip.ptr(evals), _hip.ptr(evecs),
+                                           _hip.ptr(logdet), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)),
+               "lo_tridiag_eigh_slq_f32")
+    return (evals.reshape(P, *batch, T), None if evecs is None else evecs.reshape(P, *batch, T, T),
+            None if logdet is None else logdet.reshape(batch))
+
+
+def lanczos_tridiag(desc: Optional[OperatorDescriptor], init_vecs: torch.Tensor, max_iter: int, tol: float = 1e-5,
+                    matvec_closure: Optional[Callable] = None):
+    """lo_lanczos_tridiag_f32: utils/lanczos.py:9-164.  init_vecs [*batch, N, P].
+    Returns (q_mat [P,*batch,N,k'], t_mat [P,*batch,k',k']) in the reference's output layout (:151-161)."""
+    lib = _hip.load()
+    _hip.require_hip(init_vecs)
+    N, P = init_vecs.shape[-2:]
+    batch = tuple(init_vecs.shape[:-2])
+    v3 = _flat(init_vecs, 2)
+    B = v3.shape[0]
+    dev = init_vecs.device
+    if desc is None:
+        s = _hip.OpDesc()
+        s.kind, s.diag_mode, s.B, s.N, s.R, s.n2 = _hip.LO_OP_CALLBACK, _hip.LO_DIAG_NONE, B, N, 0, 0
+
+        def mv(v):
+            return matvec_closure(v.reshape(*batch, N, P))
+
+        cb, err = _wrap_closure(mv, dev)
+    else:
+        s = desc.c_struct()
+        cb, err = _hip.MATVEC_CB(), []
+    max_iter = int(max_iter)
+    q = torch.empty(max_iter, B, N, P, dtype=torch.float32, device=dev)
+    t = torch.empty(max_iter, max_iter, B, P, dtype=torch.float32, device=dev)
+    ws = _hip.workspace(lib.lo_lanczos_workspace_bytes(C.byref(s), P, max_iter), dev)
+    iters = C.c_int32(0)
+    rc = lib.lo_lanczos_tridiag_f32(C.byref(s), cb, None, _hip.ptr(v3), P, max_iter, float(tol), _hip.ptr(q),
+                                    _hip.ptr(t), C.byref(iters), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev))
+    for e in err:
+        raise e
+    _hip.check(rc, "lo_lanczos_tridiag_f32")
+    k = iters.value
+    nb = len(batch)
+    q = q[:k].reshape(k, *batch, N, P)
+    t = t[:k, :k].reshape(k, k, *batch, P)
+    q_out = q.permute(-1, *range(1, 1 + nb), -2, 0).contiguous()  # lanczos.py:154
+    t_out = t.permute(-1, *range(2, 2 + nb), 0, 1).contiguous()  # :156
+    if P == 1:  # squeeze_(0) (:159-161) only acts on a size-1 leading dim
+        q_out, t_out = q_out[0], t_out[0]
+    return q_out, t_out

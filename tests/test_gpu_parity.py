@@ -1,0 +1,306 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, linear_operator_amd.kernels) against
+ (a) the CPU oracle on the same seeded inputs and (b) the golden vectors the real reference produced.
+Bars: integer results (pivots / permutations / iteration counts at the floors) bit-exact; fp32 solves
+within 1e-4 relative per column (north_star); logdet within 1e-4 rel + the documented eigensolver noise
+floor.  Run with `pytest -m gpu` on an MI355X.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from conftest import load_golden, max_rel_err_cols, rel_err
+from oracle import lo_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+from linear_operator_amd import kernels as K  # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------- matvecs
+@pytest.mark.parametrize("c", [1, 2, 5, 8, 17])
+@pytest.mark.parametrize("R", [8, 15, 32])
+def test_matvec_lowrank_diag(c, R):
+    C, d, v = cases.lowrank_diag(1000 + c + R, 3, 1000, R, c)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    y = host(K.matvec(desc, dev(v)))
+    ref = orc.matvec_lowrank_diag(C.astype(np.float64), d.astype(np.float64), v.astype(np.float64))
+    assert max_rel_err_cols(y, ref) < 2e-6
+    # constant diagonal + no diagonal
+    sig = np.array([0.25, 0.5, 2.0], dtype=np.float32)
+    y2 = host(K.matvec(K.lowrank_diag_descriptor(dev(C), dev(sig), const_diag=True), dev(v)))
+    ref2 = orc.matvec_lowrank_diag(C.astype(np.float64), np.broadcast_to(sig[:, None], d.shape).astype(np.float64),
+                                   v.astype(np.float64))
+    assert max_rel_err_cols(y2, ref2) < 2e-6
+    y3 = host(K.matvec(K.lowrank_diag_descriptor(dev(C), None), dev(v)))
+    assert max_rel_err_cols(y3, orc.matvec_lowrank_diag(C.astype(np.float64), 0 * d.astype(np.float64),
+                                                        v.astype(np.float64))) < 2e-6
+
+
+def test_matvec_golden_g6():
+    g = load_golden("g6_matmul")
+    C, d, v = cases.lowrank_diag(601, 3, 256, 8, 5)
+    Kd, dd, vv = cases.dense_diag(611, 2, 96, 3)
+    K1, K2, s, vk = cases.kron_factors(621, 2, 12, 20, 3)
+    tol = dict(rtol=1e-4, atol=1e-4)
+    assert np.allclose(host(K.matvec(K.lowrank_diag_descriptor(dev(C), dev(d)), dev(v))), g["y_lowrank_diag"], **tol)
+    assert np.allclose(host(K.matvec(K.lowrank_diag_descriptor(dev(C), None), dev(v))), g["y_lowrank"], **tol)
+    assert np.allclose(host(K.matvec(K.dense_diag_descriptor(dev(Kd), dev(dd)), dev(vv))), g["y_dense_diag"], **tol)
+    assert np.allclose(host(K.matvec(K.dense_diag_descriptor(dev(Kd), None), dev(vv))), g["y_dense"], **tol)
+    assert np.allclose(host(K.matvec(K.kron_diag_descriptor(dev(K1), dev(K2), None), dev(vk))), g["y_kron"], **tol)
+    assert np.allclose(host(K.matvec(K.kron_diag_descriptor(dev(K1), dev(K2), dev(s[:, 0]), const_diag=True), dev(vk))),
+                       g["y_kron_diag"], **tol)
+
+
+@pytest.mark.parametrize("c", [1, 3, 6])
+def test_matvec_dense_and_kron(c):
+    Kd, dd, vv = cases.dense_diag(1100 + c, 2, 520, c)
+    y = host(K.matvec(K.dense_diag_descriptor(dev(Kd), dev(dd)), dev(vv)))
+    ref = orc.matvec_dense_diag(Kd.astype(np.float64), dd.astype(np.float64), vv.astype(np.float64))
+    assert max_rel_err_cols(y, ref) < 5e-6
+    K1, K2, s, vk = cases.kron_factors(1200 + c, 3, 24, 40, c)
+    y = host(K.matvec(K.kron_diag_descriptor(dev(K1), dev(K2), dev(s[:, 0]), const_diag=True), dev(vk)))
+    dk = np.broadcast_to(s, (3, 960)).astype(np.float64)
+    ref = orc.matvec_kron_diag(K1.astype(np.float64), K2.astype(np.float64), dk, vk.astype(np.float64))
+    assert max_rel_err_cols(y, ref) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------- linear_cg
+def test_cg_lowrank_no_precond_vs_golden_and_oracle():
+    g = load_golden("g1_cg_fp32_lowrank")
+    C, d, rhs = cases.lowrank_diag(141, 4, 512, 8, 5)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    res = K.cg_solve(desc, dev(rhs), tolerance=1.0)
+    # 11-iteration floor; the reference spends one more product on A @ 0, we skip it
+    assert res.iterations == int(g["matvecs_tol1"]) - 1 == 11 and res.tolerance_reached
+    assert max_rel_err_cols(host(res.x), g["x_tol1"]) < 1e-4
+    res = K.cg_solve(desc, dev(rhs), tolerance=1.0, n_tridiag=4)
+    assert res.iterations == int(g["matvecs_t_tol1"]) - 1 == 21
+    assert res.t_mat.shape == g["t_mat_tol1"].shape
+    assert max_rel_err_cols(host(res.x), g["xt_tol1"]) < 1e-4
+    assert rel_err(host(res.t_mat)[..., :8, :8], g["t_mat_tol1"][..., :8, :8]) < 1e-3
+    res = K.cg_solve(desc, dev(rhs), tolerance=1e-4)
+    assert abs(res.iterations - (int(g["matvecs_tol1e4"]) - 1)) <= 1  # fp32 noise regime, see oracle test
+    assert max_rel_err_cols(host(res.x), g["x_tol1e4"]) < 1e-4
+    # zero column + initial guess: one CG step from x0 then frozen
+    rhs_z = rhs.copy()
+    rhs_z[1, :, 2] = 0.0
+    x0 = cases.randn(142, 4, 512, 5, dtype=np.float32) * 0.1
+    res = K.cg_solve(desc, dev(rhs_z), x0=dev(x0), tolerance=1e-4)
+    assert res.matvecs == int(g["matvecs_zero_col"]) or abs(res.matvecs - int(g["matvecs_zero_col"])) <= 1
+    assert np.allclose(host(res.x)[1, :, 2], g["x_zero_col"][1, :, 2], rtol=1e-4, atol=1e-6)
+    assert max_rel_err_cols(np.delete(host(res.x), 2, -1), np.delete(g["x_zero_col"], 2, -1)) < 1e-4
+    res = K.cg_solve(desc, dev(rhs_z), tolerance=1e-4)
+    assert np.all(host(res.x)[1, :, 2] == 0)
+
+
+def test_cg_fp32_reference_recipe_dense_callback_and_native():
+    """test_linear_cg.py:27-64 recipe in fp32 (kernels are fp32): CG vs direct solve, atol 1e-3 / rtol 1e-4."""
+    M = cases.spd_test_matrix(101, 100, dtype=np.float32)
+    b = cases.randn(103, 100, 50, dtype=np.float32)
+    actual = np.linalg.solve(M.astype(np.float64), b.astype(np.float64))
+    Mt = dev(M)
+    res = K.cg_solve(None, dev(b), matvec_closure=lambda v: Mt @ v, max_iter=100, tolerance=1e-6)
+    assert np.allclose(host(res.x), actual, atol=1e-3, rtol=1e-4)
+    desc = K.dense_diag_descriptor(dev(M[None]), None)
+    res2 = K.cg_solve(desc, dev(b[None]), max_iter=100, tolerance=1e-6)
+    assert np.allclose(host(res2.x)[0], actual, atol=1e-3, rtol=1e-4)
+    # same algorithm through both paths
+    assert res.iterations == res2.iterations or abs(res.iterations - res2.iterations) <= 2
+    xo, _, info = orc.linear_cg(lambda v: M @ v, b, max_iter=100, tolerance=1e-6)
+    assert abs(info.iterations - res2.iterations) <= 2
+
+
+def test_cg_tridiag_eigenvalues_small():
+    """test_linear_cg.py:66-95: tridiagonals of a 10x10 system reproduce its spectrum."""
+    M = cases.spd_test_matrix(111, 10, dtype=np.float32)
+    b = cases.randn(112, 10, 50, dtype=np.float32)
+    res = K.cg_solve(K.dense_diag_descriptor(dev(M[None]), None), dev(b[None]), n_tridiag=5, max_tridiag_iter=10,
+                     max_iter=10, tolerance=0.0, eps=1e-15)
+    assert not res.tolerance_reached and res.iterations == 10  # -> NumericalWarning in the shim
+    eigs = np.linalg.eigvalsh(M.astype(np.float64))
+    t = host(res.t_mat)
+    assert t.shape == (5, 1, 10, 10)
+    for i in range(5):
+        assert np.allclose(eigs, np.linalg.eigvalsh(t[i, 0].astype(np.float64)), atol=1e-3, rtol=1e-3)
+
+
+def test_cg_nan_detection_and_skip():
+    C, d, rhs = cases.lowrank_diag(77, 2, 300, 8, 2)
+    Cn = C.copy()
+    Cn[0, 5, 1] = np.nan
+    res = K.cg_solve(K.lowrank_diag_descriptor(dev(Cn), dev(d)), dev(rhs))
+    assert res.nan_detected
+    res = K.cg_solve(K.lowrank_diag_descriptor(dev(Cn), dev(d)), dev(rhs), x0=dev(rhs * 0.1))
+    assert res.nan_detected
+    res = K.cg_solve(K.lowrank_diag_descriptor(dev(C), dev(d)), dev(np.zeros_like(rhs)))
+    assert res.skipped and res.iterations == 0 and np.all(host(res.x) == 0)
+
+
+# ------------------------------------------------------------------------------------------- pivoted Cholesky
+def _check_pivchol(desc, src, rank, golden_L=None, golden_piv=None):
+    L, piv = K.pivoted_cholesky(desc, rank)
+    Lo, pivo = orc.pivoted_cholesky(src, rank)
+    assert np.array_equal(host(piv), pivo), "pivots / permutation must be bit-exact"
+    assert host(L).shape == Lo.shape
+    assert np.array_equal(host(L), Lo), "same operation order -> L must be bit-identical to the oracle"
+    if golden_piv is not None:
+        assert np.array_equal(host(piv), golden_piv)
+        assert np.allclose(host(L), golden_L, rtol=1e-4, atol=1e-5)
+
+
+def test_pivoted_cholesky_bit_exact():
+    g = load_golden("g2_pivchol_lowrank")
+    for R in (8, 32):
+        C = cases.lowrank_diag(210 + R, 3, 2048, R, 1)[0]
+        _check_pivchol(K.lowrank_diag_descriptor(dev(C), None), orc.LowRankRowSource(C), 15, g[f"L_R{R}"],
+                       g[f"piv_R{R}"])
+    g = load_golden("g2_pivchol_kron_dense")
+    K1, K2, _, _ = cases.kron_factors(221, 2, 16, 16, 1)
+    _check_pivchol(K.kron_diag_descriptor(dev(K1), dev(K2), None), orc.KronRowSource(K1, K2), 15, g["L_kron"],
+                   g["piv_kron"])
+    Kd = cases.dense_diag(222, 2, 300, 1)[0]
+    _check_pivchol(K.dense_diag_descriptor(dev(Kd), None), orc.DenseRowSource(Kd), 15, g["L_dense"], g["piv_dense"])
+    g = load_golden("g2_pivchol_dense8")
+    m8 = cases.pivchol_dense8(201)
+    _check_pivchol(K.dense_diag_descriptor(dev(m8[None]), None), orc.DenseRowSource(m8[None]), 3, g["L"][None],
+                   g["piv"][None])
+    mb = cases.pivchol_dense8(202, batch=(2, 3))
+    L, piv = K.pivoted_cholesky(K.dense_diag_descriptor(dev(mb), None), 3)
+    assert tuple(L.shape) == (2, 3, 8, 3) and np.array_equal(host(piv), g["pivb"])
+    assert np.allclose(host(L), g["Lb"], rtol=1e-5, atol=1e-6)
+    L8, piv8 = K.pivoted_cholesky(K.dense_diag_descriptor(dev(m8[None]), None), 8)  # rank == N edge
+    assert np.array_equal(host(piv8)[0], g["piv8"]) and tuple(L8.shape) == (1, 8, g["L8"].shape[-1])
+
+
+def test_pivoted_cholesky_bench_shape_bit_exact():
+    """cfg2-shaped (N=8192, R=32), more members: pivots and L bit-identical to the oracle."""
+    C = cases.lowrank_diag(2301, 6, 8192, 32, 1)[0]
+    _check_pivchol(K.lowrank_diag_descriptor(dev(C), None), orc.LowRankRowSource(C), 15)
+
+
+# ------------------------------------------------------------------------------------------- preconditioner
+def test_preconditioner_build_apply():
+    g = load_golden("g3_precond")
+    C, d, rhs = cases.lowrank_diag(301, 3, 2048, 32, 4)
+    L, _ = K.pivoted_cholesky(K.lowrank_diag_descriptor(dev(C), None), 15)
+    assert np.allclose(host(L), g["L_nonconst"], rtol=1e-4, atol=1e-5)
+    pre = K.precond_build(L, dev(d), constant_diag=False)
+    z = host(K.precond_apply(pre, dev(rhs)))
+    assert max_rel_err_cols(z, g["z_nonconst"]) < 1e-5
+    assert np.allclose(host(pre.logdet), g["logdet_nonconst"], rtol=1e-5)
+    sig = np.array([0.3, 0.7, 1.1], dtype=np.float32)
+    pre = K.precond_build(L, dev(sig), constant_diag=True)
+    z = host(K.precond_apply(pre, dev(rhs)))
+    assert max_rel_err_cols(z, g["z_const"]) < 1e-5
+    assert np.allclose(host(pre.logdet), g["logdet_const"], rtol=1e-5, atol=1e-2)
+    # against the oracle in fp64
+    po = orc.Preconditioner(host(L).astype(np.float64), np.broadcast_to(sig[:, None], (3, 2048)).astype(np.float64))
+    assert max_rel_err_cols(z, po.apply(rhs.astype(np.float64))) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- solve / inv_quad_logdet
+def _default_precond(desc, d_t, const):
+    L, _ = K.pivoted_cholesky(desc, 15)
+    return K.precond_build(L, d_t, constant_diag=const)
+
+
+def test_solve_lowrank_default_preconditioner():
+    g = load_golden("g4_solve_lowrank")
+    C, d, rhs = cases.lowrank_diag(401, 4, 2048, 32, 1)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    pre = _default_precond(desc, dev(d), False)
+    res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+    assert res.iterations == int(g["matvecs"]) - 1 == 11 and res.tolerance_reached
+    assert max_rel_err_cols(host(res.x), g["x"]) < 1e-4
+    assert max_rel_err_cols(host(res.x), g["x_exact"]) < 1e-4
+
+
+def test_inv_quad_logdet_lowrank_injected_probes():
+    g = load_golden("g4_iql_lowrank")
+    C, d, rhs = cases.lowrank_diag(411, 3, 2048, 16, 1)
+    Z, _ = cases.probes(412, 3, 2048, 8)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    pre = _default_precond(desc, dev(d), False)
+    full = np.concatenate([Z, rhs], axis=-1)
+    res = K.cg_solve(desc, dev(full), precond=pre, n_tridiag=8, tolerance=1e-4)
+    assert res.iterations == int(g["matvecs"]) - 1 == 21
+    assert max_rel_err_cols(host(res.x), g["solves"]) < 1e-4
+    assert abs(res.t_mat.shape[-1] - g["t_mat"].shape[-1]) <= 1
+    assert rel_err(host(res.t_mat)[..., :2, :2], g["t_mat"][..., :2, :2]) < 1e-4
+    _, _, pinvk = K.tridiag_eigh_slq(res.t_mat, 2048)
+    logdet = host(pinvk) + host(pre.logdet)
+    inv_quad = (host(res.x)[..., 8:] * rhs).sum(-2)[..., 0]
+    assert np.allclose(host(pre.logdet), g["logdet_p"], rtol=1e-5)
+    assert np.allclose(inv_quad, g["inv_quad"], rtol=1e-4)
+    floor = 2048 * 1.2e-7 * 137.0  # fp32 eigensolver noise floor of the REFERENCE
+    assert np.allclose(logdet, g["logdet"], rtol=1e-4, atol=floor)
+    # G7: eig + SLQ on the reference's own t_mat
+    evals, evecs, pk = K.tridiag_eigh_slq(dev(g["t_mat"]), 2048, want_evecs=True)
+    assert np.allclose(host(evals), g["evals"], rtol=1e-4, atol=1e-4)
+    assert np.allclose(host(pk), g["pinvk_logdet"], rtol=1e-4, atol=floor)
+    ev64, vec64 = np.linalg.eigh(g["t_mat"].astype(np.float64))
+    assert np.allclose(host(evals), ev64, rtol=1e-5, atol=1e-5)
+    slq64 = (2048 / 8.0) * (vec64[..., 0, :] ** 2 * np.log(ev64)).sum(-1).sum(0)
+    assert np.allclose(host(pk), slq64, rtol=1e-4, atol=1e-3)
+    rec = np.einsum("...ij,...j,...kj->...ik", host(evecs).astype(np.float64), host(evals).astype(np.float64),
+                    host(evecs).astype(np.float64))
+    assert np.allclose(rec, g["t_mat"], atol=1e-3)
+
+
+def test_solve_kron_constant_diag():
+    g = load_golden("g4_solve_kron")
+    K1, K2, sig, rhs = cases.kron_factors(421, 2, 48, 48, 1)
+    desc = K.kron_diag_descriptor(dev(K1), dev(K2), dev(sig[:, 0]), const_diag=True)
+    pre = _default_precond(desc, dev(sig[:, 0]), True)
+    res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-3)
+    assert abs(res.iterations - (int(g["matvecs"]) - 1)) <= 3
+    assert max_rel_err_cols(host(res.x), g["x"]) < 5e-3
+    assert max_rel_err_cols(host(res.x), g["x_exact"]) < 2e-2
+
+
+def test_inv_quad_logdet_dense_injected_probes():
+    g = load_golden("g4_iql_dense")
+    Kd, d, rhs = cases.dense_diag(431, 2, 2048, 1)
+    Z, _ = cases.probes(432, 2, 2048, 4)
+    desc = K.dense_diag_descriptor(dev(Kd), dev(d))
+    pre = _default_precond(desc, dev(d), False)
+    res = K.cg_solve(desc, dev(np.concatenate([Z, rhs], -1)), precond=pre, n_tridiag=4, tolerance=1e-4)
+    assert res.iterations == int(g["matvecs"]) - 1
+    assert max_rel_err_cols(host(res.x), g["solves"]) < 1e-4
+    _, _, pinvk = K.tridiag_eigh_slq(res.t_mat, 2048)
+    logdet = host(pinvk) + host(pre.logdet)
+    assert np.allclose((host(res.x)[..., 4:] * rhs).sum(-2)[..., 0], g["inv_quad"], rtol=1e-4)
+    assert np.allclose(logdet, g["logdet"], rtol=1e-4, atol=2048 * 1.2e-7 * 10.0)
+
+
+# ------------------------------------------------------------------------------------------- Lanczos
+def test_lanczos_against_reference():
+    g = load_golden("g5_lanczos")
+    M = cases.spd_test_matrix(501, 100, dtype=np.float32, jitter=1e-6)
+    v0 = cases.randn(502, 100, 1, dtype=np.float32)
+    q, t = K.lanczos_tridiag(K.dense_diag_descriptor(dev(M[None]), None), dev(v0[None]), 100)
+    q, t = host(q)[0], host(t)[0]
+    assert q.shape[0] == 100 and t.shape[0] == t.shape[1] == q.shape[1]
+    assert np.allclose(t[:10, :10], g["t_near"][:10, :10], rtol=1e-3, atol=1e-5)
+    assert np.allclose(q @ t @ q.T, M, atol=1e-4)  # test_lanczos.py:35-36
+    M2 = g["M_approx"]
+    v2 = cases.randn(504, 30, 1, dtype=np.float32)
+    Mt = dev(M2)
+    q2, t2 = K.lanczos_tridiag(None, dev(v2), 30, matvec_closure=lambda v: Mt @ v)  # closure path
+    q2, t2 = host(q2), host(t2)
+    assert np.allclose(q2 @ t2 @ q2.T, M2, atol=1e-4)
+    C, d, _ = cases.lowrank_diag(511, 2, 256, 8, 1)
+    V = cases.randn(512, 2, 256, 3, dtype=np.float32)
+    q3, t3 = K.lanczos_tridiag(K.lowrank_diag_descriptor(dev(C), dev(d)), dev(V), 10)
+    assert tuple(q3.shape) == g["q_batch"].shape and tuple(t3.shape) == g["t_batch"].shape
+    assert np.allclose(host(t3), g["t_batch"], rtol=1e-3, atol=1e-4)
+    assert np.allclose(host(q3), g["q_batch"], atol=2e-3)
