@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the batched preconditioned-CG hot path on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver
+launches it under torch.distributed.run, one rank per GPU.  Prints ONE JSON line on rank 0.
+
+Workload (config.workload): BASELINE.json north_star headline -- a batch of 512 operators
+A_b = C_b C_b^T + diag(d_b), C [512, 8192, 32], d [512, 8192] (AddedDiag(LowRankRoot, Diag)), one right-hand
+side column, solved by `linear_cg` with the reference's rank-15 pivoted-Cholesky preconditioner at
+cg_tolerance 1e-4 (stops at the 11-iteration floor).  A "step" is one full linear_cg call
+over the whole batch (init, 11 iterations, un-normalise; preconditioner already built, as the reference's
+`_solve` receives it).  Inputs are resident in HBM before the timed region.
+  metric  = member-matvecs per second inside CG = batch members x operator applications / CG wall time
+  value   = whole-job aggregate over all ranks (weak scaling: every rank owns 512 members; the solutions are
+            all-gathered over RCCL at the end of each step when N > 1, as north_star prescribes)
+Also reported: end-to-end solves/s (preconditioner build included), the roofline line of the dominant
+kernel (live HIP-event timing on the launch stream), and the CPU oracle timed on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+from linear_operator_amd import _hip  # noqa: E402
+from linear_operator_amd import kernels as K  # noqa: E402
+
+B_PER_GPU, N, R, C_COLS, RANK_K = 512, 8192, 32, 1, 15
+TOL = 1e-4
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+
+def make_problem(device, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    Cm = torch.randn(B_PER_GPU, N, R, generator=g, device=device, dtype=torch.float32) / (R ** 0.5)
+    d = torch.rand(B_PER_GPU, N, generator=g, device=device, dtype=torch.float32) + 0.5
+    rhs = torch.randn(B_PER_GPU, N, C_COLS, generator=g, device=device, dtype=torch.float32)
+    return Cm, d, rhs
+
+
+def build_precond(desc, d):
+    L, _ = K.pivoted_cholesky(desc, RANK_K)
+    return K.precond_build(L, d, constant_diag=False)
+
+
+def algorithmic_bytes(name, k_eff):
+    """Compulsory HBM bytes of one launch of a kernel class (DESIGN.md section 'kernels'), fp32."""
+    B, c = B_PER_GPU, C_COLS
+    if name.startswith("skinny_tn_R"):
+        r = R if name.endswith("R32") else k_eff
+        return 4 * B * (N * r + N * c)  # stream A once + the vector; partial outputs are KB
+    if name.startswith("skinny_nn_R"):
+        r = R if name.endswith("R32") else k_eff
+        return 4 * B * (N * r + N + 2 * N * c)  # stream A once + diagonal + vector in + vector out
+    if name == "cg_update_xr":
+        return 4 * B * N * c * 6  # r, Ap, x, p read; r, x written
+    if name == "cg_update_p":
+        return 4 * B * N * c * 3
+    if name == "vec_dot_part":
+        return 4 * B * N * c * 2
+    return 0
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """The numpy oracle (kind 'port') on a bounded sample of the same workload, host cores."""
+    import cases
+    from oracle import lo_oracle as orc
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:  # noqa: BLE001
+        threads = os.cpu_count() or 1
+    Bs = 8
+    Cs, ds, rs = cases.lowrank_diag(4242, Bs, N, R, C_COLS)
+    L, _ = orc.pivoted_cholesky(orc.LowRankRowSource(Cs), RANK_K)
+    pre = orc.Preconditioner(L, ds)
+    mm = lambda v: orc.matvec_lowrank_diag(Cs, ds, v)  # noqa: E731
+    orc.linear_cg(mm, rs, tolerance=TOL, preconditioner=pre.apply)  # warm up
+    t0 = time.perf_counter()
+    reps, mv = 0, 0
+    while time.perf_counter() - t0 < seconds_budget:
+        _, _, info = orc.linear_cg(mm, rs, tolerance=TOL, preconditioner=pre.apply)
+        mv += Bs * info.matvecs
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": mv / dt, "unit": "member-matvecs/s", "cores": int(threads), "kind": "port",
+            "sample": f"{reps} x oracle linear_cg on {Bs} of the {B_PER_GPU} members (same N={N}, R={R}, c={C_COLS}, "
+                      f"rank-{RANK_K} preconditioner, tol {TOL}); reference counts {11 + 1} products per solve"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: PLW0621
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    _hip.load()
+
+    Cm, d, rhs = make_problem(device, 1234 + rank)
+    desc = K.lowrank_diag_descriptor(Cm, d)
+    pre = build_precond(desc, d)
+    gather_buf = torch.empty(world * B_PER_GPU, N, C_COLS, device=device) if world > 1 else None
+
+    def step():
+        res = K.cg_solve(desc, rhs, precond=pre, tolerance=TOL)
+        if world > 1:
+            dist.all_gather_into_tensor(gather_buf, res.x)  # the single collective of the path (north_star)
+        return res
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    matvecs_per_solve = res.matvecs
+    total_members = world * B_PER_GPU
+    value = total_members * matvecs_per_solve * args.steps / elapsed
+
+    # ---- end-to-end solves/s (pivoted Cholesky + preconditioner build + CG), local rank ----
+    fence()
+    t1 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        p2 = build_precond(desc, d)
+        K.cg_solve(desc, rhs, precond=p2, tolerance=TOL)
+    fence()
+    e2e = (time.perf_counter() - t1) / reps
+    if world > 1:
+        t = torch.tensor([e2e], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e2e = float(t.item())
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: live HIP-event timing on the launch stream ----
+        _hip.prof_enable(True)
+        for _ in range(3):
+            K.cg_solve(desc, rhs, precond=pre, tolerance=TOL)
+        torch.cuda.synchronize(device)
+        prof = _hip.prof_report()
+        _hip.prof_enable(False)
+        dom = max(prof, key=lambda k: prof[k][1])
+        cnt, ms = prof[dom]
+        avg_s = ms / cnt * 1e-3
+        alg = algorithmic_bytes(dom, RANK_K)
+        achieved = alg / avg_s / 1e9
+        tn, nn = prof.get("skinny_tn_R32"), prof.get("skinny_nn_R32")
+        mv_alg = 4 * B_PER_GPU * (N * R + N + 2 * N * C_COLS)  # 1,146,880 B per member
+        mv_s = (tn[1] / tn[0] + nn[1] / nn[0]) * 1e-3
+        kernels = {k: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2),
+                       "alg_GBs": round(algorithmic_bytes(k, RANK_K) / (v[1] / v[0] * 1e-3) / 1e9, 1)}
+                   for k, v in sorted(prof.items())}
+        out = {
+            "metric": "cg_member_matvecs_per_sec",
+            "value": value,
+            "unit": "member-matvecs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "north_star headline (cfg3 operator, 1 rhs column): AddedDiag(LowRankRoot(C[512,8192,32]), "
+                            "Diag(d[512,8192])) per GPU, linear_cg with rank-15 pivoted-Cholesky preconditioner, "
+                            "cg_tolerance 1e-4 -> 11 iterations (floor)",
+                "batch_per_gpu": B_PER_GPU, "N": N, "R": R, "rhs_columns": C_COLS, "precond_rank": RANK_K,
+                "iterations": res.iterations, "matvecs_per_solve": matvecs_per_solve,
+                "sharding": f"batch x{world}, all_gather of solutions per step" if world > 1 else "single GPU",
+            },
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6, "launches_timed": cnt},
+            "matvec_roofline": {"algorithmic_bytes": mv_alg, "avg_us": mv_s * 1e6,
+                                "achieved_GBs": mv_alg / mv_s / 1e9, "frac_of_8TBs": mv_alg / mv_s / 1e9 / HBM_PEAK_GBS,
+                                "note": "C^T p + C t + d o p pair = one batched CG matvec (north_star 60% target)"},
+            "solves_per_sec_end_to_end": total_members / e2e,
+            "end_to_end_ms": e2e * 1e3,
+            "kernels": kernels,
+            "final_mean_residual": res.mean_residual,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -179,6 +179,13 @@ size_t lo_tridiag_eigh_slq_workspace_bytes(int64_t P, int64_t B);
 int lo_tridiag_eigh_slq_f32(const float* t_mat, int64_t P, int64_t B, int32_t T, int64_t n, float* evals, float* evecs,
                             float* logdet, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- measurement aid (no reference counterpart) ------------------------------------------------ */
+/* Opt-in HIP-event timing of every kernel launch of the library, recorded on the launch stream.
+ * lo_prof_report writes "name count total_ms" lines into buf (returns the byte count) and resets.
+ * bench.py uses it for the live per-kernel duration behind its roofline line.                     */
+int lo_prof_enable(int on);
+int lo_prof_report(char* buf, size_t buflen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,7 @@ EXPORTS = [
     "lo_precond_apply_workspace_bytes", "lo_precond_apply_f32",
     "lo_lanczos_workspace_bytes", "lo_lanczos_tridiag_f32",
     "lo_tridiag_eigh_slq_workspace_bytes", "lo_tridiag_eigh_slq_f32",
+    "lo_prof_enable", "lo_prof_report",
 ]
 
 
@@ -123,8 +124,27 @@ def load():
     lib.lo_tridiag_eigh_slq_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
     lib.lo_tridiag_eigh_slq_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p]
+    lib.lo_prof_enable.restype = C.c_int
+    lib.lo_prof_enable.argtypes = [C.c_int]
+    lib.lo_prof_report.restype = C.c_int
+    lib.lo_prof_report.argtypes = [C.c_char_p, sz]
     _lib = lib
     return lib
+
+
+def prof_enable(on: bool):
+    load().lo_prof_enable(1 if on else 0)
+
+
+def prof_report() -> dict:
+    """{kernel_class: (launch_count, total_ms)} since the last report (HIP events on the launch stream)."""
+    buf = C.create_string_buffer(1 << 16)
+    load().lo_prof_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split()
+        out[name] = (int(cnt), float(ms))
+    return out
 
 
 def check(rc: int, what: str):

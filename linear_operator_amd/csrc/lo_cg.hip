@@ -454,17 +454,23 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   int k = 0;
   int launched = 0;
   while (k < prm->max_iter && !h.stop) {
+    LO_PROF_BEGIN("cg_update_p", st);
     hipLaunchKernelGGL(k_cg_update_p, gridv, block, 0, st, d, zsrc, k == 0 ? 1 : 0, sp.rows);
+    LO_PROF_END(st);
     LO_LAUNCH_CHECK();
     rc = matvec_run(&pl, d.p, d.Ap, d.pAp_part, stop, st);
     if (rc) return rc;
+    LO_PROF_BEGIN("cg_update_xr", st);
     hipLaunchKernelGGL(k_cg_update_xr, gridv, block, 0, st, d, sp.rows);
+    LO_PROF_END(st);
     LO_LAUNCH_CHECK();
     if (precond) {
       rc = apply_precond(d.r, d.z, d.rz_part);
       if (rc) return rc;
     }
+    LO_PROF_BEGIN("cg_ctrl", st);
     hipLaunchKernelGGL(k_cg_ctrl, dim3(1), block, 0, st, d, k);
+    LO_PROF_END(st);
     LO_LAUNCH_CHECK();
     ++launched;
     const bool at_poll = (k >= first_poll) && (((k - first_poll) % chunk) == 0);

@@ -132,10 +132,12 @@ int dense_matvec(const float* K, const float* d, int dd_mode, const float* v, fl
 #define LO_DM(CT)                                                                                              \
   hipLaunchKernelGGL((k_dense_mv<CT>), grid, block, 0, st, K, d, dd_mode, vp, (int)c, cn, yp, dp, (int)c, (int)N, \
                      rows_per_wg, stop)
+    LO_PROF_BEGIN("dense_mv", st);
     if (cn == 1) LO_DM(1);
     else if (cn == 2) LO_DM(2);
     else LO_DM(4);
 #undef LO_DM
+    LO_PROF_END(st);
     LO_LAUNCH_CHECK();
   }
   return LO_OK;

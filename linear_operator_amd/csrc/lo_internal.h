@@ -23,6 +23,19 @@ constexpr int kMaxRank = 256;  // padded root rank (floats per row) of a skinny 
 
 #define LO_LAUNCH_CHECK() LO_HIP_CHECK(hipGetLastError())
 
+// opt-in event timing of a launch (lo_prof.hip)
+extern bool g_prof_on;
+void prof_start(const char* name, hipStream_t st);
+void prof_stop(hipStream_t st);
+#define LO_PROF_BEGIN(name, st) \
+  do {                          \
+    if (lo::g_prof_on) lo::prof_start(name, st); \
+  } while (0)
+#define LO_PROF_END(st)                 \
+  do {                                  \
+    if (lo::g_prof_on) lo::prof_stop(st); \
+  } while (0)
+
 // Row split of one batch member over S workgroups (rows multiple of 4 except the tail).
 struct Split {
   int S;

@@ -85,7 +85,9 @@ __global__ __launch_bounds__(kThreads) void k_gemm(GemmArgs g, const int* __rest
 
 static int launch_gemm(const GemmArgs& g, int nbatch, const int* stop, hipStream_t st) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, nbatch);
+  LO_PROF_BEGIN("kron_gemm", st);
   hipLaunchKernelGGL(k_gemm, grid, dim3(kThreads), 0, st, g, stop);
+  LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
 }

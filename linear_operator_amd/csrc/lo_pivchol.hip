@@ -280,9 +280,13 @@ int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_
   const size_t R = (op->kind == LO_OP_LOWRANK_DIAG) ? (size_t)op->R : 0;
   for (int m = 0; m < rank; ++m) {
     hipLaunchKernelGGL(k_pc_ctrl, dim3(1), block, 0, st, d, m);
+    LO_PROF_BEGIN("pc_argmax", st);
     hipLaunchKernelGGL(k_pc_argmax, dim3((unsigned)B), block, 0, st, d, m);
+    LO_PROF_END(st);
     if (m + 1 < N) {  // :77
+      LO_PROF_BEGIN("pc_update", st);
       hipLaunchKernelGGL(k_pc_update, grid, block, (m + R) * sizeof(float), st, d, m);
+      LO_PROF_END(st);
     }
     LO_LAUNCH_CHECK();
   }

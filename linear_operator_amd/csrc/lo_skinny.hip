@@ -232,6 +232,29 @@ int pad_rows(const float* src, int R, float* dst, int R4, int64_t rows, hipStrea
   return LO_OK;
 }
 
+static const char* tn_name(int R4) {
+  switch (R4) {
+    case 4: return "skinny_tn_R4";
+    case 8: return "skinny_tn_R8";
+    case 16: return "skinny_tn_R16";
+    case 32: return "skinny_tn_R32";
+    case 64: return "skinny_tn_R64";
+    case 128: return "skinny_tn_R128";
+    default: return "skinny_tn_R256";
+  }
+}
+static const char* nn_name(int R4) {
+  switch (R4) {
+    case 4: return "skinny_nn_R4";
+    case 8: return "skinny_nn_R8";
+    case 16: return "skinny_nn_R16";
+    case 32: return "skinny_nn_R32";
+    case 64: return "skinny_nn_R64";
+    case 128: return "skinny_nn_R128";
+    default: return "skinny_nn_R256";
+  }
+}
+
 // A wave's shuffle groups must not straddle row-validity: RQ | 64 guarantees the RQ lanes of one row
 // sit in one wave.
 static bool rq_ok(int R4) {
@@ -252,11 +275,13 @@ int skinny_tn(const float* A, int lda, int R4, const float* v, int64_t c, float*
     const float* vp = v + c0;
 #define LO_TN(CT) \
   hipLaunchKernelGGL((k_skinny_tn<CT>), grid, block, 0, st, A, lda, RQ, vp, (int)c, cn, tp, (int)N, sp.rows, stop)
+    LO_PROF_BEGIN(tn_name(R4), st);
     if (cn == 1) LO_TN(1);
     else if (cn == 2) LO_TN(2);
     else if (cn <= 4) LO_TN(4);
     else LO_TN(8);
 #undef LO_TN
+    LO_PROF_END(st);
     LO_LAUNCH_CHECK();
   }
   return LO_OK;
@@ -284,11 +309,13 @@ int skinny_nn(const float* A, int lda, int R4, const float* tpart, const float* 
       hipLaunchKernelGGL((k_skinny_nn<CT, false>), grid, block, shm, st, A, lda, RQ, tp, dd, dd_mode, sgn, vp,     \
                          (int)c, cn, yp, dp, (int)c, (int)N, sp.rows, stop);                                       \
   } while (0)
+    LO_PROF_BEGIN(nn_name(R4), st);
     if (cn == 1) LO_NN(1);
     else if (cn == 2) LO_NN(2);
     else if (cn <= 4) LO_NN(4);
     else LO_NN(8);
 #undef LO_NN
+    LO_PROF_END(st);
     LO_LAUNCH_CHECK();
   }
   return LO_OK;

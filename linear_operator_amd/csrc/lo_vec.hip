@@ -45,8 +45,10 @@ __global__ __launch_bounds__(kThreads) void k_dot_part(const float* __restrict__
 int vec_dot_part(const float* a, const float* b, int64_t c, float* part, int64_t B, int64_t N, Split sp, const int* stop,
                  hipStream_t st) {
   if (c < 1 || c > kMaxCols) return LO_ERR_UNSUPPORTED;
+  LO_PROF_BEGIN("vec_dot_part", st);
   hipLaunchKernelGGL(k_dot_part, dim3(sp.S, (unsigned)B), dim3(kThreads), 0, st, a, b, (int)c, part, (int)N, sp.rows,
                      stop);
+  LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
 }
@@ -72,8 +74,10 @@ int vec_add_diag(const float* dd, int dd_mode, const float* v, float* y, int64_t
                  const int* stop, hipStream_t st) {
   if (dd_mode == LO_DIAG_NONE) return LO_OK;
   if (c < 1 || c > kMaxCols) return LO_ERR_UNSUPPORTED;
+  LO_PROF_BEGIN("vec_add_diag", st);
   hipLaunchKernelGGL(k_add_diag, dim3(sp.S, (unsigned)B), dim3(kThreads), 0, st, dd, dd_mode, v, y, (int)c, (int)N,
                      sp.rows, stop);
+  LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
 }
