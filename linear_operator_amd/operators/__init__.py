@@ -1,0 +1,17 @@
+"""The operator classes that feed the iterative solve / logdet path."""
+from ._linear_operator import LinearOperator, to_dense
+from .added_diag_linear_operator import AddedDiagLinearOperator
+from .dense_linear_operator import DenseLinearOperator, to_linear_operator
+from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
+from .identity_linear_operator import IdentityLinearOperator
+from .kronecker_product_linear_operator import KroneckerProductLinearOperator
+from .linear_operator_representation_tree import LinearOperatorRepresentationTree
+from .root_linear_operator import LowRankRootLinearOperator, RootLinearOperator
+from .sum_linear_operator import PsdSumLinearOperator, SumLinearOperator
+
+__all__ = [
+    "LinearOperator", "to_dense", "to_linear_operator", "AddedDiagLinearOperator", "DenseLinearOperator",
+    "DiagLinearOperator", "ConstantDiagLinearOperator", "IdentityLinearOperator", "KroneckerProductLinearOperator",
+    "LinearOperatorRepresentationTree", "RootLinearOperator", "LowRankRootLinearOperator", "SumLinearOperator",
+    "PsdSumLinearOperator",
+]

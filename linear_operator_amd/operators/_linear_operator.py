@@ -1,0 +1,529 @@
+"""LinearOperator base class -- the part of the reference's API surface the solve / logdet path needs
+(reference: linear_operator/operators/_linear_operator.py, 3039 lines; SURVEY.md section 8(b) lists the kept
+signatures).  Operators stay thin Python objects holding tensors.  What is new: `_kernel_descriptor()` -- the
+lowering of an operator tree to the descriptor liblo_amd's kernels consume -- which lets `_solve`,
+`pivoted_cholesky`, `_matmul` ... hand whole loops to the device instead of calling closures per iteration.
+
+Kept seams: operator protocol (_matmul/_size/_transpose_nonbatch), `_solve` / `_preconditioner` /
+`_solve_preconditioner` / `_probe_vectors_and_norms` overrides, `__torch_function__` dispatch by method NAME
+(so subclass overrides win, :3006-3009), `utils.linear_cg` looked up at call time (:796).
+"""
+from __future__ import annotations
+
+import itertools
+import numbers
+from collections import OrderedDict
+from typing import Callable, Optional
+
+import torch
+from torch import Tensor
+
+from .. import settings, utils
+from ..utils.broadcasting import _matmul_broadcast_shape
+from .linear_operator_representation_tree import LinearOperatorRepresentationTree
+
+_HANDLED_FUNCTIONS = {}
+_HANDLED_SECOND_ARG_FUNCTIONS = {}
+
+
+def _implements(torch_function: Callable) -> Callable:
+    """Register `method` as the override of `torch_function` (stored by name, reference :61-74)."""
+
+    def decorator(func):
+        _HANDLED_FUNCTIONS[torch_function] = func.__name__
+        return func
+
+    return decorator
+
+
+def _implements_second_arg(torch_function: Callable) -> Callable:
+    """Override for torch functions whose SECOND argument is the operator (reference :77-95)."""
+
+    def decorator(func):
+        _HANDLED_SECOND_ARG_FUNCTIONS[torch_function] = func.__name__
+        return func
+
+    return decorator
+
+
+def _implements_symmetric(torch_function: Callable) -> Callable:
+    def decorator(func):
+        _HANDLED_FUNCTIONS[torch_function] = func.__name__
+        _HANDLED_SECOND_ARG_FUNCTIONS[torch_function] = func.__name__
+        return func
+
+    return decorator
+
+
+class LinearOperator(object):
+    """A (batch of) matrices of size (... x M x N) represented by its action `_matmul`."""
+
+    def _check_args(self, *args, **kwargs) -> Optional[str]:
+        return None
+
+    def __init__(self, *args, **kwargs):
+        if settings.debug.on():
+            err = self._check_args(*args, **kwargs)
+            if err is not None:
+                raise ValueError(err)
+        self._args = args
+        self._differentiable_kwargs = OrderedDict()
+        self._nondifferentiable_kwargs = dict()
+        for name, val in sorted(kwargs.items()):  # sorted: deterministic flattening (reference :160-166)
+            if torch.is_tensor(val) or isinstance(val, LinearOperator):
+                self._differentiable_kwargs[name] = val
+            else:
+                self._nondifferentiable_kwargs[name] = val
+
+    # ------------------------------------------------------------------ operator protocol (reference :169-221)
+    def _matmul(self, rhs: Tensor) -> Tensor:
+        raise NotImplementedError("The class {} requires a _matmul function!".format(self.__class__.__name__))
+
+    def _size(self) -> torch.Size:
+        raise NotImplementedError("The class {} requires a _size function!".format(self.__class__.__name__))
+
+    def _transpose_nonbatch(self) -> "LinearOperator":
+        raise NotImplementedError(
+            "The class {} requires a _transpose_nonbatch function!".format(self.__class__.__name__)
+        )
+
+    # ------------------------------------------------------------------ lowering hook (new)
+    def _kernel_descriptor(self, batch_shape=None):
+        """OperatorDescriptor for liblo_amd, or None if this tree has no native kernel (-> closure path).
+        `batch_shape`: batch the descriptor must be expanded to (defaults to the operator's own)."""
+        return None
+
+    # ------------------------------------------------------------------ optional overrides
+    def _diagonal(self) -> Tensor:
+        raise NotImplementedError(f"{self.__class__.__name__} does not define _diagonal")
+
+    def _approx_diagonal(self) -> Tensor:  # reference :483-497
+        return self._diagonal()
+
+    def _expand_batch(self, batch_shape) -> "LinearOperator":
+        raise NotImplementedError(f"{self.__class__.__name__} does not define _expand_batch")
+
+    def _t_matmul(self, rhs: Tensor) -> Tensor:
+        return self.mT._matmul(rhs)
+
+    def _preconditioner(self):  # reference :618-627
+        """(closure P^-1(.), LinearOperator P, log|P|) or (None, None, None)."""
+        return None, None, None
+
+    def _probe_vectors_and_norms(self):  # reference :629-633 -- hook for fixed probes
+        return None, None
+
+    def _solve_preconditioner(self):  # reference :805-846 (default_preconditioner beta feature: out of scope)
+        base_precond, _, _ = self._preconditioner()
+        return base_precond
+
+    def _solve(self, rhs: Tensor, preconditioner: Optional[Callable] = None, num_tridiag: Optional[int] = 0):
+        """reference :781-803.  `utils.linear_cg` is resolved through the module at call time (seam)."""
+        return utils.linear_cg(
+            self._matmul,
+            rhs,
+            n_tridiag=num_tridiag,
+            max_iter=settings.max_cg_iterations.value(),
+            max_tridiag_iter=settings.max_lanczos_quadrature_iterations.value(),
+            preconditioner=preconditioner,
+        )
+
+    def _cholesky_solve(self, rhs, upper: bool = False):
+        raise NotImplementedError(f"_cholesky_solve not implemented for {self.__class__.__name__}")
+
+    # ------------------------------------------------------------------ shape / dtype
+    @property
+    def shape(self) -> torch.Size:
+        return self._size()
+
+    def size(self, dim: Optional[int] = None):
+        s = self._size()
+        return s if dim is None else s[dim]
+
+    def dim(self) -> int:
+        return len(self.shape)
+
+    ndimension = dim
+
+    @property
+    def batch_shape(self) -> torch.Size:
+        return self.shape[:-2]
+
+    @property
+    def batch_dim(self) -> int:
+        return len(self.batch_shape)
+
+    @property
+    def matrix_shape(self) -> torch.Size:
+        return torch.Size(self.shape[-2:])
+
+    @property
+    def is_square(self) -> bool:
+        return self.matrix_shape[0] == self.matrix_shape[1]
+
+    def numel(self) -> int:
+        return self.shape.numel()
+
+    def _leaf_tensors(self):
+        for arg in itertools.chain(self._args, self._differentiable_kwargs.values()):
+            if torch.is_tensor(arg):
+                yield arg
+            elif isinstance(arg, LinearOperator):
+                yield from arg._leaf_tensors()
+
+    @property
+    def dtype(self) -> torch.dtype:
+        for t in self._leaf_tensors():
+            return t.dtype
+        return torch.get_default_dtype()
+
+    @property
+    def device(self) -> torch.device:
+        for t in self._leaf_tensors():
+            return t.device
+        return torch.device("cpu")
+
+    @property
+    def requires_grad(self) -> bool:
+        return any(t.requires_grad for t in self._leaf_tensors())
+
+    def detach(self) -> "LinearOperator":
+        def conv(a):
+            return a.detach() if hasattr(a, "detach") else a
+
+        return self.__class__(*[conv(a) for a in self._args],
+                              **{k: conv(v) for k, v in self._differentiable_kwargs.items()},
+                              **self._nondifferentiable_kwargs)
+
+    def to(self, *args, **kwargs) -> "LinearOperator":
+        def conv(a):
+            return a.to(*args, **kwargs) if hasattr(a, "to") else a
+
+        return self.__class__(*[conv(a) for a in self._args],
+                              **{k: conv(v) for k, v in self._differentiable_kwargs.items()},
+                              **self._nondifferentiable_kwargs)
+
+    def cuda(self, device_id=None) -> "LinearOperator":
+        return self.to(torch.device("cuda", device_id) if device_id is not None else "cuda")
+
+    def cpu(self) -> "LinearOperator":
+        return self.to("cpu")
+
+    # ------------------------------------------------------------------ representation (reference :2076-2101)
+    def representation(self):
+        rep = []
+        for arg in itertools.chain(self._args, self._differentiable_kwargs.values()):
+            if torch.is_tensor(arg):
+                rep.append(arg)
+            elif hasattr(arg, "representation") and callable(arg.representation):
+                rep += list(arg.representation())
+            else:
+                raise RuntimeError("Representation of a LinearOperator should consist only of Tensors")
+        return tuple(rep)
+
+    def representation_tree(self) -> LinearOperatorRepresentationTree:
+        return LinearOperatorRepresentationTree(self)
+
+    def evaluate_kernel(self) -> "LinearOperator":
+        return self
+
+    # ------------------------------------------------------------------ dense evaluation helpers
+    def to_dense(self) -> Tensor:
+        n = self.size(-1)
+        eye = torch.eye(n, dtype=self.dtype, device=self.device).expand(*self.batch_shape, n, n).contiguous()
+        return self._matmul(eye)
+
+    def diagonal(self, offset: int = 0, dim1: int = -2, dim2: int = -1) -> Tensor:
+        if not (offset == 0 and dim1 in (-2, self.dim() - 2) and dim2 in (-1, self.dim() - 1)):
+            raise NotImplementedError("LinearOperator.diagonal only computes the main diagonal of the last two dims")
+        if not self.is_square:
+            raise RuntimeError("LinearOperator#diagonal is only defined for square matrices")
+        return self._diagonal()
+
+    def cholesky(self, upper: bool = False):
+        """Dense Cholesky factor for the N <= max_cholesky_size branch (reference :1211-1225 -> _cholesky)."""
+        from .dense_linear_operator import DenseLinearOperator
+        from ..utils.cholesky import psd_safe_cholesky
+
+        L = psd_safe_cholesky(self.to_dense(), upper=upper)
+        return _TriangularFactor(L, upper=upper)
+
+    # ------------------------------------------------------------------ transpose
+    def transpose(self, dim1: int, dim2: int) -> "LinearOperator":
+        nd = self.dim()
+        dim1, dim2 = dim1 % nd, dim2 % nd
+        if {dim1, dim2} == {nd - 2, nd - 1}:
+            return self._transpose_nonbatch()
+        raise NotImplementedError("only the last two dimensions can be transposed on this path")
+
+    @property
+    def mT(self) -> "LinearOperator":
+        return self.transpose(-1, -2)
+
+    # ------------------------------------------------------------------ algebra
+    @_implements(torch.matmul)
+    def matmul(self, other):  # reference :1844-1866
+        from ..functions._matmul import Matmul
+
+        if isinstance(other, LinearOperator):
+            raise NotImplementedError("operator @ operator (MatmulLinearOperator) is outside the solve/logdet path")
+        _matmul_broadcast_shape(self.shape, other.shape)
+        return Matmul.apply(self.representation_tree(), other, *self.representation())
+
+    def __matmul__(self, other):
+        return self.matmul(other)
+
+    @_implements_second_arg(torch.matmul)
+    def rmatmul(self, other):
+        if other.ndim == 1:
+            return self.mT.matmul(other)
+        return self.mT.matmul(other.mT).mT
+
+    def __rmatmul__(self, other):
+        return self.rmatmul(other)
+
+    def add_diagonal(self, diag: Tensor) -> "LinearOperator":  # reference :953-1001
+        from .added_diag_linear_operator import AddedDiagLinearOperator
+        from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
+
+        if not self.is_square:
+            raise RuntimeError("add_diagonal only defined for square matrices")
+        diag_shape = diag.shape
+        if len(diag_shape) and diag_shape[-1] != 1:
+            try:
+                expanded = diag.expand(self.shape[:-1])
+            except RuntimeError:
+                raise RuntimeError(
+                    "add_diagonal for LinearOperator of size {} received invalid diagonal of size {}.".format(
+                        self.shape, diag_shape
+                    )
+                )
+            diag_op = DiagLinearOperator(expanded)
+        else:
+            try:
+                expanded = diag.expand(*self.batch_shape, 1)
+            except RuntimeError:
+                raise RuntimeError(
+                    "add_diagonal for LinearOperator of size {} received invalid diagonal of size {}.".format(
+                        self.shape, diag_shape
+                    )
+                )
+            diag_op = ConstantDiagLinearOperator(expanded, diag_shape=self.shape[-1])
+        return AddedDiagLinearOperator(self, diag_op)
+
+    def add_jitter(self, jitter_val: float = 1e-3) -> "LinearOperator":  # reference :1003-1017
+        return self.add_diagonal(torch.tensor(jitter_val, dtype=self.dtype, device=self.device))
+
+    @_implements_symmetric(torch.add)
+    def add(self, other, alpha=None):
+        return self + other if alpha is None else self + alpha * other
+
+    def __add__(self, other):  # reference :2801-2827
+        from .added_diag_linear_operator import AddedDiagLinearOperator
+        from .dense_linear_operator import to_linear_operator
+        from .diag_linear_operator import DiagLinearOperator
+        from .sum_linear_operator import SumLinearOperator
+
+        if isinstance(other, DiagLinearOperator):
+            return AddedDiagLinearOperator(self, other)
+        if isinstance(other, Tensor):
+            other = to_linear_operator(other)
+            shape = torch.broadcast_shapes(self.shape, other.shape)
+            new_self = self if self.shape[:-2] == shape[:-2] else self._expand_batch(shape[:-2])
+            new_other = other if other.shape[:-2] == shape[:-2] else other._expand_batch(shape[:-2])
+            return SumLinearOperator(new_self, new_other)
+        if isinstance(other, numbers.Number) and other == 0:
+            return self
+        return SumLinearOperator(self, other)
+
+    def __radd__(self, other):
+        return self + other
+
+    # ------------------------------------------------------------------ solves / quadratic forms / logdet
+    @_implements(torch.linalg.solve)
+    def solve(self, right_tensor: Tensor, left_tensor: Optional[Tensor] = None) -> Tensor:  # reference :2324-2379
+        from ..functions._solve import Solve
+
+        if not self.is_square:
+            raise RuntimeError(
+                "solve only operates on (batches of) square (positive semi-definite) LinearOperators. "
+                "Got a {} of size {}.".format(self.__class__.__name__, self.size())
+            )
+        if self.dim() == 2 and right_tensor.dim() == 1:
+            if self.shape[-1] != right_tensor.numel():
+                raise RuntimeError(
+                    "LinearOperator (size={}) cannot be multiplied with right-hand-side Tensor (size={}).".format(
+                        self.shape, right_tensor.shape
+                    )
+                )
+        if left_tensor is None:
+            return Solve.apply(self.representation_tree(), False, right_tensor, *self.representation())
+        return Solve.apply(self.representation_tree(), True, left_tensor, right_tensor, *self.representation())
+
+    def inv_quad(self, inv_quad_rhs: Tensor, reduce_inv_quad: bool = True) -> Tensor:  # reference :1637-1686
+        from ..functions._inv_quad import InvQuad
+
+        if not self.is_square:
+            raise RuntimeError(
+                "inv_quad only operates on (batches of) square (positive semi-definite) LinearOperators. "
+                "Got a {} of size {}.".format(self.__class__.__name__, self.size())
+            )
+        try:
+            result_shape = _matmul_broadcast_shape(self.shape, inv_quad_rhs.shape)
+        except RuntimeError:
+            raise RuntimeError(
+                "LinearOperator (size={}) cannot be multiplied with right-hand-side Tensor (size={}).".format(
+                    self.shape, inv_quad_rhs.shape
+                )
+            )
+        args = (inv_quad_rhs.expand(*result_shape[:-2], *inv_quad_rhs.shape[-2:]),) + self.representation()
+        term = InvQuad.apply(self.representation_tree(), *args)
+        return term.sum(-1) if reduce_inv_quad else term
+
+    def inv_quad_logdet(self, inv_quad_rhs: Optional[Tensor] = None, logdet: bool = False,
+                        reduce_inv_quad: bool = True):  # reference :1688-1804
+        from ..functions._inv_quad_logdet import InvQuadLogdet
+        from .identity_linear_operator import IdentityLinearOperator
+
+        if settings.fast_computations.log_prob.off() or (self.size(-1) <= settings.max_cholesky_size.value()):
+            return self.cholesky().inv_quad_logdet(inv_quad_rhs=inv_quad_rhs, logdet=logdet,
+                                                   reduce_inv_quad=reduce_inv_quad)
+        if not logdet:
+            if inv_quad_rhs is None:
+                raise RuntimeError("Either `inv_quad_rhs` or `logdet` must be specifed.")
+            return self.inv_quad(inv_quad_rhs, reduce_inv_quad=reduce_inv_quad), torch.zeros(
+                [], dtype=self.dtype, device=self.device
+            )
+        if not self.is_square:
+            raise RuntimeError(
+                "inv_quad_logdet only operates on (batches of) square (positive semi-definite) LinearOperators. "
+                "Got a {} of size {}.".format(self.__class__.__name__, self.size())
+            )
+        if inv_quad_rhs is not None:
+            if self.dim() == 2 and inv_quad_rhs.dim() == 1:
+                if self.shape[-1] != inv_quad_rhs.numel():
+                    raise RuntimeError(
+                        "LinearOperator (size={}) cannot be multiplied with right-hand-side Tensor (size={}).".format(
+                            self.shape, inv_quad_rhs.shape
+                        )
+                    )
+            elif self.dim() != inv_quad_rhs.dim():
+                raise RuntimeError(
+                    "LinearOperator (size={}) and right-hand-side Tensor (size={}) should have the same number "
+                    "of dimensions.".format(self.shape, inv_quad_rhs.shape)
+                )
+            elif self.batch_shape != inv_quad_rhs.shape[:-2] or self.shape[-1] != inv_quad_rhs.shape[-2]:
+                raise RuntimeError(
+                    "LinearOperator (size={}) cannot be multiplied with right-hand-side Tensor (size={}).".format(
+                        self.shape, inv_quad_rhs.shape
+                    )
+                )
+        args = self.representation()
+        if inv_quad_rhs is not None:
+            args = [inv_quad_rhs] + list(args)
+        preconditioner, precond_lt, logdet_p = self._preconditioner()
+        if precond_lt is None:
+            precond_lt = IdentityLinearOperator(diag_shape=self.size(-1), batch_shape=self.batch_shape,
+                                                dtype=self.dtype, device=self.device)
+            logdet_p = 0.0
+        precond_args = precond_lt.representation()
+        probe_vectors, probe_vector_norms = self._probe_vectors_and_norms()
+        inv_quad_term, pinvk_logdet = InvQuadLogdet.apply(
+            self.representation_tree(), precond_lt.representation_tree(), preconditioner, len(precond_args),
+            (inv_quad_rhs is not None), probe_vectors, probe_vector_norms, *(list(args) + list(precond_args)),
+        )
+        logdet_term = pinvk_logdet + logdet_p
+        if inv_quad_term.numel() and reduce_inv_quad:
+            inv_quad_term = inv_quad_term.sum(-1)
+        return inv_quad_term, logdet_term
+
+    @_implements(torch.logdet)
+    def logdet(self) -> Tensor:  # reference :1834-1842
+        _, res = self.inv_quad_logdet(inv_quad_rhs=None, logdet=True)
+        return res
+
+    def pivoted_cholesky(self, rank: int, error_tol: Optional[float] = None, return_pivots: bool = False):
+        """reference :1975-2008 -> functions/_pivoted_cholesky.py"""
+        from ..functions._pivoted_cholesky import PivotedCholesky
+
+        res, pivots = PivotedCholesky.apply(self.representation_tree(), rank, error_tol, *self.representation())
+        return (res, pivots) if return_pivots else res
+
+    def zero_mean_mvn_samples(self, num_samples: int) -> Tensor:  # reference :2746-2793 (root-based branch)
+        raise NotImplementedError(f"{self.__class__.__name__}.zero_mean_mvn_samples needs a root decomposition "
+                                  "(Lanczos consumers are SURVEY 8(f) 'next')")
+
+    # ------------------------------------------------------------------ torch dispatch (reference :2981-3009)
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if kwargs is None:
+            kwargs = {}
+
+        def unsupported():
+            name = func.__name__.replace("linalg_", "linalg.")
+            arg_classes = ", ".join(arg.__class__.__name__ for arg in args)
+            kwarg_classes = ", ".join(f"{key}={val.__class__.__name__}" for key, val in kwargs.items())
+            return NotImplementedError(f"torch.{name}({arg_classes}, {kwarg_classes}) is not implemented.")
+
+        ok_types = all(issubclass(t, (torch.Tensor, LinearOperator)) for t in types)
+        if not isinstance(args[0], cls):
+            if func not in _HANDLED_SECOND_ARG_FUNCTIONS or not ok_types:
+                raise unsupported()
+            method = getattr(cls, _HANDLED_SECOND_ARG_FUNCTIONS[func])  # by NAME: subclass overrides win
+            return method(args[1], args[0], *args[2:], **kwargs)
+        if func not in _HANDLED_FUNCTIONS or not ok_types:
+            raise unsupported()
+        method = getattr(cls, _HANDLED_FUNCTIONS[func])
+        return method(*args, **kwargs)
+
+    def __repr__(self):
+        return f"<{self.__class__.__name__} of size {tuple(self.shape)}>"
+
+
+class _TriangularFactor:
+    """Minimal stand-in for CholLinearOperator(TriangularLinearOperator(L)) on the N <= max_cholesky_size
+    branch (reference: chol_linear_operator.py:121, triangular_linear_operator.py:72-91): exact solves and
+    logdet through ATen.  Plumbing for cfg1, not part of the HIP hot path."""
+
+    def __init__(self, factor: Tensor, upper: bool = False):
+        self.factor = factor
+        self.upper = upper
+
+    def to_dense(self):
+        return self.factor
+
+    def _cholesky_solve(self, rhs, upper: bool = False):
+        is_vec = rhs.dim() == 1
+        if is_vec:
+            rhs = rhs.unsqueeze(-1)
+        res = torch.cholesky_solve(rhs, self.factor, upper=self.upper)
+        return res.squeeze(-1) if is_vec else res
+
+    def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
+        inv_quad_term, logdet_term = None, None
+        if inv_quad_rhs is not None:
+            is_vec = inv_quad_rhs.dim() == 1
+            r = inv_quad_rhs.unsqueeze(-1) if is_vec else inv_quad_rhs
+            L = self.factor.mT if self.upper else self.factor
+            half = torch.linalg.solve_triangular(L, r, upper=False)
+            inv_quad_term = (half ** 2).sum(-2)
+            if reduce_inv_quad:
+                inv_quad_term = inv_quad_term.sum(-1)
+        if logdet:
+            logdet_term = self.factor.diagonal(dim1=-1, dim2=-2).pow(2).log().sum(-1)
+        else:
+            logdet_term = torch.zeros([], dtype=self.factor.dtype, device=self.factor.device)
+        if inv_quad_term is None:
+            inv_quad_term = torch.zeros([], dtype=self.factor.dtype, device=self.factor.device)
+        return inv_quad_term, logdet_term
+
+
+def to_dense(obj):
+    if torch.is_tensor(obj):
+        return obj
+    if isinstance(obj, LinearOperator):
+        return obj.to_dense()
+    raise TypeError("object of class {} cannot be made into a Tensor".format(obj.__class__.__name__))
+
+
+__all__ = ["LinearOperator", "to_dense"]

@@ -1,0 +1,131 @@
+"""AddedDiagLinearOperator `A + D` with the pivoted-Cholesky / Woodbury preconditioner
+(reference: linear_operator/operators/added_diag_linear_operator.py:21-209).
+
+  _matmul          y = A v + d o v in ONE fused kernel (reference :72-76 is addcmul over A._matmul)
+  _preconditioner  (:95-142) pivoted Cholesky of the non-diagonal part on the device (csrc/lo_pivchol.hip), then the
+                   cached form (Q, 1/d, log|P|) from csrc/lo_precond.hip instead of torch.linalg.qr (:144-184);
+                   returns the same triple (closure, PsdSum(Root(L), D), logdet_p).  The closure object carries the
+                   device preconditioner so that linear_cg applies it natively inside the CG loop.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Callable, Optional
+
+import torch
+from torch import Tensor
+
+from .. import kernels as K
+from .. import settings
+from ..utils.warnings import NumericalWarning
+from ._linear_operator import LinearOperator
+from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
+from .root_linear_operator import RootLinearOperator
+from .sum_linear_operator import PsdSumLinearOperator, SumLinearOperator, _attach_diag
+
+
+class WoodburyPreconditionClosure:
+    """precondition_closure (reference :135-140): z = r / d - Q (Q^T r)  (or (r - Q Q^T r) / sigma)."""
+
+    def __init__(self, woodbury: K.WoodburyPreconditioner, batch_shape):
+        self.woodbury = woodbury
+        self.batch_shape = torch.Size(batch_shape)
+
+    def __call__(self, tensor: Tensor) -> Tensor:
+        is_vec = tensor.dim() == 1
+        t = tensor.unsqueeze(-1) if is_vec else tensor
+        t = t.expand(*self.batch_shape, *t.shape[-2:]) if t.shape[:-2] != self.batch_shape else t
+        z = K.precond_apply(self.woodbury, t)
+        return z.squeeze(-1) if is_vec else z
+
+
+class AddedDiagLinearOperator(SumLinearOperator):
+    def __init__(self, *linear_ops, preconditioner_override: Optional[Callable] = None):
+        linear_ops = list(linear_ops)
+        super().__init__(*linear_ops, preconditioner_override=preconditioner_override)
+        if len(linear_ops) > 2:
+            raise RuntimeError("An AddedDiagLinearOperator can only have two components")
+        a, b = self.linear_ops
+        if isinstance(a, DiagLinearOperator) and isinstance(b, DiagLinearOperator):
+            raise RuntimeError(
+                "Trying to lazily add two DiagLinearOperators. Create a single DiagLinearOperator instead."
+            )
+        elif isinstance(a, DiagLinearOperator):
+            self._diag_tensor, self._linear_op = a, b
+        elif isinstance(b, DiagLinearOperator):
+            self._diag_tensor, self._linear_op = b, a
+        else:
+            raise RuntimeError(
+                "One of the LinearOperators input to AddedDiagLinearOperator must be a DiagLinearOperator!"
+            )
+        self.preconditioner_override = preconditioner_override
+        # caches (reference :63-70); they live on the rebuilt, detached operator, not on the user's object
+        self._constant_diag = None
+        self._noise = None
+        self._piv_chol_self = None
+        self._precond_lt = None
+        self._precond_logdet_cache = None
+        self._q_cache = None
+        self._woodbury = None
+
+    def _kernel_descriptor(self, batch_shape=None):
+        return _attach_diag(self._linear_op, self._diag_tensor, torch.Size(batch_shape or self.batch_shape))
+
+    def _matmul(self, rhs: Tensor) -> Tensor:
+        if rhs.dim() >= 2 and rhs.is_cuda and rhs.dtype == torch.float32:
+            desc = self._kernel_descriptor(torch.broadcast_shapes(self.batch_shape, rhs.shape[:-2]))
+            if desc is not None:
+                return K.matvec(desc, rhs.expand(*desc.batch_shape, *rhs.shape[-2:]))
+        return torch.addcmul(self._linear_op._matmul(rhs), self._diag_tensor._diag.unsqueeze(-1), rhs)
+
+    def add_diagonal(self, diag: Tensor):
+        return self.__class__(self._linear_op, self._diag_tensor.add_diagonal(diag))
+
+    def __add__(self, other):
+        if isinstance(other, DiagLinearOperator):
+            return self.__class__(self._linear_op, self._diag_tensor + other)
+        return self.__class__(self._linear_op + other, self._diag_tensor)
+
+    # ------------------------------------------------------------------ preconditioner (reference :95-184)
+    def _preconditioner(self):
+        if self.preconditioner_override is not None:
+            return self.preconditioner_override(self)
+        if settings.max_preconditioner_size.value() == 0 or self.size(-1) < settings.min_preconditioning_size.value():
+            return None, None, None
+        if self._q_cache is None:
+            max_iter = settings.max_preconditioner_size.value()
+            self._piv_chol_self = self._linear_op.pivoted_cholesky(rank=max_iter)  # :125
+            if torch.any(torch.isnan(self._piv_chol_self)).item():  # :126-131
+                warnings.warn(
+                    "NaNs encountered in preconditioner computation. Attempting to continue without preconditioning.",
+                    NumericalWarning,
+                )
+                return None, None, None
+            self._init_cache()
+        closure = WoodburyPreconditionClosure(self._woodbury, self.batch_shape)
+        return closure, self._precond_lt, self._precond_logdet_cache
+
+    def _init_cache(self):
+        L = self._piv_chol_self
+        batch_shape = L.shape[:-2]
+        n = L.shape[-2]
+        noise = self._diag_tensor._diagonal().expand(*batch_shape, n)
+        # constant-diagonal test on VALUES, as the reference does (:146-150), not on the operator type
+        first = noise[..., :1]
+        self._constant_diag = bool(torch.equal(noise, first.expand_as(noise)))
+        self._noise = first if self._constant_diag else noise
+        if not (L.is_cuda and L.dtype == torch.float32):
+            raise K._hip.HipExtensionError("the preconditioner cache is built by liblo_amd: fp32 HIP tensors only")
+        d_arg = first[..., 0].contiguous() if self._constant_diag else noise.contiguous()
+        self._woodbury = K.precond_build(L, d_arg.to(torch.float32), self._constant_diag)
+        self._q_cache = self._woodbury.Q[..., : self._woodbury.k].reshape(*batch_shape, n, self._woodbury.k)
+        logdet = self._woodbury.logdet
+        self._precond_logdet_cache = logdet.view(*batch_shape) if len(batch_shape) else logdet.squeeze()  # :172,:184
+        self._precond_lt = PsdSumLinearOperator(RootLinearOperator(L), self._diag_tensor)  # :159
+
+    def evaluate_kernel(self):
+        rebuilt = self.representation_tree()(*self.representation())
+        return rebuilt._linear_op + rebuilt._diag_tensor
+
+
+__all__ = ["AddedDiagLinearOperator", "WoodburyPreconditionClosure"]

@@ -1,0 +1,112 @@
+"""DiagLinearOperator / ConstantDiagLinearOperator (reference: linear_operator/operators/diag_linear_operator.py:16-434).
+Inside CG the diagonal is never applied on its own: AddedDiag lowers `A + D` to one fused kernel
+(y = A v + d o v).  Stand-alone use is elementwise ATen, like the reference."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from ._linear_operator import LinearOperator
+
+
+class DiagLinearOperator(LinearOperator):
+    def __init__(self, diag: Tensor):
+        super().__init__(diag)
+        self._diag = diag
+
+    def __add__(self, other):  # reference :27-35
+        if isinstance(other, DiagLinearOperator):
+            return self.add_diagonal(other._diag)
+        from .added_diag_linear_operator import AddedDiagLinearOperator
+
+        return AddedDiagLinearOperator(other, self)
+
+    def add_diagonal(self, added_diag: Tensor) -> "DiagLinearOperator":
+        shape = torch.broadcast_shapes(self._diag.shape, added_diag.shape)
+        return DiagLinearOperator(self._diag.expand(shape) + added_diag.expand(shape))
+
+    def _diagonal(self) -> Tensor:
+        return self._diag
+
+    def _expand_batch(self, batch_shape):
+        return self.__class__(self._diag.expand(*batch_shape, self._diag.size(-1)))
+
+    def _get_indices(self, row_index, col_index, *batch_indices) -> Tensor:
+        res = self._diag[(*batch_indices, row_index)]
+        return res * torch.eq(row_index, col_index).to(device=res.device, dtype=res.dtype)
+
+    def _matmul(self, rhs: Tensor) -> Tensor:  # reference :203-230
+        if rhs.ndimension() == 1:
+            return self._diag * rhs
+        return self._diag.unsqueeze(-1) * rhs
+
+    def _t_matmul(self, rhs):
+        return self._matmul(rhs)
+
+    def _size(self) -> torch.Size:
+        return self._diag.shape + self._diag.shape[-1:]
+
+    def _transpose_nonbatch(self):
+        return self
+
+    def to_dense(self) -> Tensor:
+        if self._diag.dim() == 0:
+            return self._diag
+        return torch.diag_embed(self._diag)
+
+    def inverse(self):
+        return self.__class__(self._diag.reciprocal())
+
+    def logdet(self):
+        return self._diag.log().sum(-1)
+
+    def solve(self, right_tensor: Tensor, left_tensor=None) -> Tensor:
+        res = self.inverse()._matmul(right_tensor)
+        return left_tensor @ res if left_tensor is not None else res
+
+    def zero_mean_mvn_samples(self, num_samples: int) -> Tensor:  # reference :273-277
+        base = torch.randn(num_samples, *self._diag.shape, dtype=self.dtype, device=self.device)
+        return base * self._diag.sqrt()
+
+
+class ConstantDiagLinearOperator(DiagLinearOperator):
+    """sigma I with diag_values [*batch, 1] (reference :303-434)."""
+
+    def __init__(self, diag_values: Tensor, diag_shape: int):
+        if diag_values.dim() == 0 or diag_values.size(-1) != 1:
+            raise ValueError(
+                f"diag_values argument to ConstantDiagLinearOperator needs to have a final singleton dimension. "
+                f"Instead, got a value with shape {diag_values.shape}."
+            )
+        LinearOperator.__init__(self, diag_values, diag_shape=diag_shape)
+        self.diag_values = diag_values
+        self.diag_shape = diag_shape
+
+    @property
+    def _diag(self) -> Tensor:  # reference :346-350
+        return self.diag_values.expand(*self.diag_values.shape[:-1], self.diag_shape)
+
+    def __add__(self, other):
+        if isinstance(other, ConstantDiagLinearOperator):
+            if other.shape[-1] == self.shape[-1]:
+                return ConstantDiagLinearOperator(self.diag_values + other.diag_values, self.diag_shape)
+            raise RuntimeError(f"Trying to add constant diagonals of different sizes {self.shape} / {other.shape}")
+        return super().__add__(other)
+
+    def add_diagonal(self, added_diag: Tensor):
+        if added_diag.dim() == 0 or added_diag.size(-1) == 1:
+            d = added_diag if added_diag.dim() else added_diag.unsqueeze(-1)
+            return ConstantDiagLinearOperator(self.diag_values + d, self.diag_shape)
+        return DiagLinearOperator(self._diag + added_diag)
+
+    def _expand_batch(self, batch_shape):
+        return self.__class__(self.diag_values.expand(*batch_shape, 1), diag_shape=self.diag_shape)
+
+    def _size(self) -> torch.Size:
+        return torch.Size((*self.diag_values.shape[:-1], self.diag_shape, self.diag_shape))
+
+    def inverse(self):
+        return self.__class__(self.diag_values.reciprocal(), diag_shape=self.diag_shape)
+
+
+__all__ = ["DiagLinearOperator", "ConstantDiagLinearOperator"]

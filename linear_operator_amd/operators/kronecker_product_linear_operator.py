@@ -1,0 +1,126 @@
+"""KroneckerProductLinearOperator K1 (x) ... (x) KP -- `_matmul`, `_diagonal`, `_get_indices` only
+(reference: operators/kronecker_product_linear_operator.py:20-45, 62-96, 188-216, 272-284).  Two dense factors
+lower to the batched-GEMM kernel pair in csrc/lo_kron.hip; the closed-form eig solves of the reference's
+KroneckerProductAddedDiag subclass (:98-114 routing) are SURVEY 8(f) 'next', so `+ Diag` yields the plain
+AddedDiagLinearOperator, i.e. the CG path."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from .. import kernels as K
+from ..utils.broadcasting import _matmul_broadcast_shape
+from ._linear_operator import LinearOperator
+from .dense_linear_operator import DenseLinearOperator, to_linear_operator
+
+
+def _kron_diag(*ops) -> Tensor:
+    lead = ops[0]._diagonal()
+    if len(ops) == 1:
+        return lead
+    trail = _kron_diag(*ops[1:])
+    d = lead.unsqueeze(-2) * trail.unsqueeze(-1)
+    return d.mT.reshape(*d.shape[:-2], -1)
+
+
+def _kron_matmul(ops, kp_shape, rhs):
+    """Per factor: view [n_i, -1], multiply, transposing reshape (reference :34-45) -- ATen fallback path."""
+    out_shape = _matmul_broadcast_shape(kp_shape, rhs.shape)
+    batch = out_shape[:-2]
+    res = rhs.expand(*batch, *rhs.shape[-2:])
+    ncols = rhs.size(-1)
+    for op in ops:
+        res = res.reshape(*batch, op.size(-1), -1)
+        f = op._matmul(res)
+        res = f.view(*batch, op.size(-2), -1, ncols).transpose(-3, -2).reshape(*batch, -1, ncols)
+    return res
+
+
+class KroneckerProductLinearOperator(LinearOperator):
+    def __init__(self, *linear_ops):
+        try:
+            linear_ops = tuple(to_linear_operator(op) for op in linear_ops)
+        except TypeError:
+            raise RuntimeError("KroneckerProductLinearOperator is intended to wrap lazy tensors.")
+        try:
+            batch = torch.broadcast_shapes(*(op.batch_shape for op in linear_ops))
+        except RuntimeError:
+            raise RuntimeError(
+                "Batch shapes of LinearOperators "
+                f"({', '.join([str(tuple(op.shape)) for op in linear_ops])}) "
+                "are incompatible for a Kronecker product."
+            )
+        if len(batch):
+            linear_ops = tuple(op._expand_batch(batch) if op.batch_shape != batch else op for op in linear_ops)
+        super().__init__(*linear_ops)
+        self.linear_ops = linear_ops
+
+    def _kernel_descriptor(self, batch_shape=None):
+        if len(self.linear_ops) != 2 or not all(isinstance(op, DenseLinearOperator) for op in self.linear_ops):
+            return None
+        k1, k2 = (op.tensor for op in self.linear_ops)
+        if not all(t.is_cuda and t.dtype == torch.float32 and t.shape[-1] == t.shape[-2] for t in (k1, k2)):
+            return None
+        bs = torch.Size(batch_shape) if batch_shape is not None else self.batch_shape
+        k1 = k1.expand(*bs, *k1.shape[-2:])
+        k2 = k2.expand(*bs, *k2.shape[-2:])
+        return K.kron_diag_descriptor(k1, k2, None)
+
+    def _diagonal(self) -> Tensor:
+        return _kron_diag(*self.linear_ops)
+
+    def _expand_batch(self, batch_shape):
+        return self.__class__(*[op._expand_batch(batch_shape) for op in self.linear_ops])
+
+    def _get_indices(self, row_index, col_index, *batch_indices) -> Tensor:  # reference :198-216
+        row_factor, col_factor = self.size(-2), self.size(-1)
+        res = None
+        for op in self.linear_ops:
+            nr, nc = op.size(-2), op.size(-1)
+            row_factor //= nr
+            col_factor //= nc
+            sub = op._get_indices(
+                torch.div(row_index, row_factor, rounding_mode="floor").fmod(nr),
+                torch.div(col_index, col_factor, rounding_mode="floor").fmod(nc),
+                *batch_indices,
+            )
+            res = sub if res is None else (sub * res)
+        return res
+
+    def _matmul(self, rhs: Tensor) -> Tensor:  # reference :272-284
+        is_vec = rhs.ndimension() == 1
+        if is_vec:
+            rhs = rhs.unsqueeze(-1)
+        desc = None
+        if rhs.is_cuda and rhs.dtype == torch.float32:
+            desc = self._kernel_descriptor(torch.broadcast_shapes(self.batch_shape, rhs.shape[:-2]))
+        if desc is not None:
+            res = K.matvec(desc, rhs.expand(*desc.batch_shape, *rhs.shape[-2:]))
+        else:
+            res = _kron_matmul(self.linear_ops, self.shape, rhs.contiguous())
+        return res.squeeze(-1) if is_vec else res
+
+    def _t_matmul(self, rhs):
+        return self.mT._matmul(rhs)
+
+    def _size(self) -> torch.Size:
+        rows = 1
+        cols = 1
+        for op in self.linear_ops:
+            rows *= op.size(-2)
+            cols *= op.size(-1)
+        return torch.Size((*self.linear_ops[0].batch_shape, rows, cols))
+
+    def _transpose_nonbatch(self):
+        return self.__class__(*(op._transpose_nonbatch() for op in self.linear_ops))
+
+    def to_dense(self) -> Tensor:
+        res = self.linear_ops[0].to_dense()
+        for op in self.linear_ops[1:]:
+            nxt = op.to_dense()
+            res = (res.unsqueeze(-1).unsqueeze(-3) * nxt.unsqueeze(-2).unsqueeze(-4)).reshape(
+                *res.shape[:-2], res.shape[-2] * nxt.shape[-2], res.shape[-1] * nxt.shape[-1])
+        return res
+
+
+__all__ = ["KroneckerProductLinearOperator"]

@@ -1,0 +1,109 @@
+"""SumLinearOperator / PsdSumLinearOperator (reference: operators/sum_linear_operator.py:16-116,
+operators/psd_sum_linear_operator.py:10-18)."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from ._linear_operator import LinearOperator
+from .dense_linear_operator import to_linear_operator
+
+
+class SumLinearOperator(LinearOperator):
+    def __init__(self, *linear_ops, **kwargs):
+        try:
+            linear_ops = tuple(to_linear_operator(lt) for lt in linear_ops)
+        except TypeError:
+            raise TypeError("All arguments of a SumLinearOperator should be LinearOperators or Tensors")
+        batch_shape = torch.broadcast_shapes(*[lt.batch_shape for lt in linear_ops])
+        linear_ops = tuple(lt._expand_batch(batch_shape) if lt.batch_shape != batch_shape else lt for lt in linear_ops)
+        super().__init__(*linear_ops, **kwargs)
+        self.linear_ops = linear_ops
+
+    def _kernel_descriptor(self, batch_shape=None):
+        """`X + D` sums lower like AddedDiag (one structured term + one diagonal)."""
+        from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
+
+        diags = [op for op in self.linear_ops if isinstance(op, DiagLinearOperator)]
+        others = [op for op in self.linear_ops if not isinstance(op, DiagLinearOperator)]
+        if len(others) != 1 or len(diags) > 1:
+            return None
+        return _attach_diag(others[0], diags[0] if diags else None, batch_shape or self.batch_shape)
+
+    def _diagonal(self) -> Tensor:
+        return sum(op._diagonal() for op in self.linear_ops)
+
+    def _expand_batch(self, batch_shape):
+        return self.__class__(*[op._expand_batch(batch_shape) for op in self.linear_ops])
+
+    def _get_indices(self, row_index, col_index, *batch_indices) -> Tensor:
+        return sum(op._get_indices(row_index, col_index, *batch_indices) for op in self.linear_ops)
+
+    def _matmul(self, rhs: Tensor) -> Tensor:  # reference :47-51
+        if rhs.dim() >= 2 and rhs.is_cuda and rhs.dtype == torch.float32:
+            desc = self._kernel_descriptor(torch.broadcast_shapes(self.batch_shape, rhs.shape[:-2]))
+            if desc is not None:
+                from .. import kernels as K
+
+                return K.matvec(desc, rhs.expand(*desc.batch_shape, *rhs.shape[-2:]))
+        return sum(op._matmul(rhs) for op in self.linear_ops)
+
+    def _t_matmul(self, rhs):
+        return sum(op._t_matmul(rhs) for op in self.linear_ops)
+
+    def _size(self) -> torch.Size:
+        return torch.broadcast_shapes(*[op.shape for op in self.linear_ops])
+
+    def _transpose_nonbatch(self):
+        return self.__class__(*[op.mT for op in self.linear_ops])
+
+    def to_dense(self) -> Tensor:
+        return sum(op.to_dense() for op in self.linear_ops).contiguous()
+
+    def __add__(self, other):  # reference :88-116
+        from .added_diag_linear_operator import AddedDiagLinearOperator
+        from .diag_linear_operator import DiagLinearOperator
+
+        if isinstance(other, DiagLinearOperator):
+            return AddedDiagLinearOperator(self, other)
+        if isinstance(other, SumLinearOperator):
+            return SumLinearOperator(*(list(self.linear_ops) + list(other.linear_ops)))
+        if isinstance(other, LinearOperator):
+            return SumLinearOperator(*(list(self.linear_ops) + [other]))
+        if isinstance(other, Tensor):
+            shape = torch.broadcast_shapes(self.shape, other.shape)
+            new_self = self if shape == self.shape else self._expand_batch(shape[:-2])
+            return SumLinearOperator(*(list(new_self.linear_ops) + [to_linear_operator(other.expand(shape))]))
+        raise AttributeError("other must be a LinearOperator")
+
+
+class PsdSumLinearOperator(SumLinearOperator):
+    """A sum of positive semi-definite terms: samples add (reference psd_sum_linear_operator.py:15-18)."""
+
+    def zero_mean_mvn_samples(self, num_samples: int) -> Tensor:
+        return sum(op.zero_mean_mvn_samples(num_samples) for op in self.linear_ops)
+
+
+def _attach_diag(base_op, diag_op, batch_shape):
+    """Descriptor of `base_op (+ diag_op)` expanded to batch_shape, or None."""
+    from .diag_linear_operator import ConstantDiagLinearOperator
+
+    desc = base_op._kernel_descriptor(batch_shape)
+    if desc is None or desc.diag_mode != 0:
+        return None
+    if diag_op is None:
+        return desc
+    from .. import kernels as K
+
+    if isinstance(diag_op, ConstantDiagLinearOperator):
+        vals = diag_op.diag_values
+        if not (vals.is_cuda and vals.dtype == torch.float32):
+            return None
+        return K._with_diag(desc, vals.expand(*batch_shape, 1)[..., 0], True)
+    d = diag_op._diag
+    if not (d.is_cuda and d.dtype == torch.float32):
+        return None
+    return K._with_diag(desc, d.expand(*batch_shape, d.shape[-1]), False)
+
+
+__all__ = ["SumLinearOperator", "PsdSumLinearOperator"]

@@ -1,0 +1,126 @@
+"""linear_cg with the reference's signature and semantics (linear_operator/utils/linear_cg.py:98-359), executed
+by liblo_amd's device-side CG engine (csrc/lo_cg.hip).  This module attribute is THE solver seam of the
+reference: `LinearOperator._solve` resolves `utils.linear_cg` at call time (operators/_linear_operator.py:796), and
+the reference's tests wrap it with mock.patch -- both keep working here.
+
+How the closure is executed:
+  * `matmul_closure` is a torch.Tensor, or the bound `_matmul` of an operator whose tree lowers to a kernel
+    descriptor (AddedDiag(LowRankRoot|Dense|Kron, Diag) ...): the whole loop -- matvec included -- runs on the
+    device with no Python in it;
+  * any other callable: the engine calls back into Python for the product only (one launch group per
+    iteration, vector updates / inner products / stopping rule stay in the kernels);
+  * `preconditioner`: the Woodbury closure AddedDiagLinearOperator._preconditioner returns is recognised and
+    applied natively; any other callable is called back.
+There is no CPU implementation: tensors must be fp32 HIP tensors.
+"""
+from __future__ import annotations
+
+import warnings
+
+import torch
+
+from .. import settings
+from .. import kernels as K
+from .warnings import NumericalWarning
+
+
+def _default_preconditioner(x):
+    return x.clone()
+
+
+def _lower_matmul_closure(matmul_closure, batch_shape):
+    """Return an OperatorDescriptor for closures we can run natively, else None."""
+    if torch.is_tensor(matmul_closure):
+        M = matmul_closure
+        if M.dim() < 2 or M.shape[-1] != M.shape[-2]:
+            return None
+        return K.dense_diag_descriptor(M.expand(*batch_shape, *M.shape[-2:]), None)
+    owner = getattr(matmul_closure, "__self__", None)
+    if owner is not None and getattr(matmul_closure, "__name__", "") == "_matmul" and hasattr(owner, "_kernel_descriptor"):
+        if type(owner)._matmul is not getattr(matmul_closure, "__func__", None):
+            return None  # instance-level override / mock
+        return owner._kernel_descriptor(batch_shape)
+    return None
+
+
+def linear_cg(
+    matmul_closure,
+    rhs,
+    n_tridiag=0,
+    tolerance=None,
+    eps=1e-10,
+    stop_updating_after=1e-10,
+    max_iter=None,
+    max_tridiag_iter=None,
+    initial_guess=None,
+    preconditioner=None,
+):
+    """Solve `lhs result = rhs` for a (batch of) symmetric positive definite operators.
+
+    Returns `result`, or `(result, tridiags)` when n_tridiag > 0 (tridiags: [n_tridiag, *batch, T, T]).
+    """
+    is_vector = rhs.ndimension() == 1  # linear_cg.py:134-136
+    if is_vector:
+        rhs = rhs.unsqueeze(-1)
+    if max_iter is None:
+        max_iter = settings.max_cg_iterations.value()
+    if max_tridiag_iter is None:
+        max_tridiag_iter = settings.max_lanczos_quadrature_iterations.value()
+    if initial_guess is not None and initial_guess.ndimension() == 1:  # :147-149
+        is_vector = True
+        initial_guess = initial_guess.unsqueeze(-1)
+    if tolerance is None:
+        tolerance = settings.cg_tolerance.value()
+    if max_tridiag_iter > max_iter:  # :159-160 (raised even when n_tridiag == 0)
+        raise RuntimeError("Getting a tridiagonalization larger than the number of CG iterations run is not possible!")
+    if not torch.is_tensor(matmul_closure) and not callable(matmul_closure):  # :163-166
+        raise RuntimeError("matmul_closure must be a tensor, or a callable object!")
+
+    num_rows = rhs.size(-2)
+    n_iter = min(max_iter, num_rows) if settings.terminate_cg_by_size.on() else max_iter  # :170
+    n_tridiag_iter = min(max_tridiag_iter, num_rows)  # :171
+    batch_shape = rhs.shape[:-2]
+
+    if settings.verbose_linalg.on():
+        settings.verbose_linalg.logger.debug(
+            f"Running CG on a {rhs.shape} RHS for {n_iter} iterations (tol={tolerance}). Output: {rhs.shape}."
+        )
+
+    desc = _lower_matmul_closure(matmul_closure, batch_shape)
+    closure = None
+    if desc is None:
+        closure = matmul_closure.matmul if torch.is_tensor(matmul_closure) else matmul_closure
+    woodbury, precond_closure = None, None
+    if preconditioner is not None:
+        woodbury = getattr(preconditioner, "woodbury", None)
+        if woodbury is not None and tuple(woodbury.Q.shape[:-2]) != (max(1, batch_shape.numel()),):
+            woodbury = None
+        if woodbury is None:
+            precond_closure = preconditioner
+
+    res = K.cg_solve(
+        desc, rhs, x0=initial_guess, precond=woodbury, matvec_closure=closure, precond_closure=precond_closure,
+        n_tridiag=n_tridiag, max_iter=n_iter, max_tridiag_iter=n_tridiag_iter, tolerance=float(tolerance),
+        eps=float(eps), stop_updating_after=float(stop_updating_after),
+    )
+    if res.nan_detected:  # :199-200
+        raise RuntimeError("NaNs encountered when trying to perform matrix-vector multiplication")
+    if not res.tolerance_reached and res.iterations > 0:  # :337-347
+        warnings.warn(
+            "CG terminated in {} iterations with average residual norm {}"
+            " which is larger than the tolerance of {} specified by"
+            " linear_operator.settings.cg_tolerance."
+            " If performance is affected, consider raising the maximum number of CG iterations by running code in"
+            " a linear_operator.settings.max_cg_iterations(value) context.".format(
+                res.iterations, res.mean_residual, tolerance
+            ),
+            NumericalWarning,
+        )
+    result = res.x
+    if is_vector:
+        result = result.squeeze(-1)
+    if n_tridiag:
+        t = res.t_mat  # [n_tridiag, B, T', T']
+        t = t.reshape(n_tridiag, *batch_shape, t.shape[-2], t.shape[-1])
+        return result, t
+    return result

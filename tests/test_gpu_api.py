@@ -1,0 +1,152 @@
+"""GPU tests of the drop-in boundary: the reference's own operator API (torch.linalg.solve / A.solve /
+A.inv_quad_logdet / torch.logdet / pivoted_cholesky / linear_cg seam / preconditioner_override seam / probe
+seam) running on the HIP path, checked against the golden vectors the real reference produced."""
+import warnings
+from unittest import mock
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from conftest import load_golden, max_rel_err_cols, rel_err
+
+pytestmark = pytest.mark.gpu
+
+import linear_operator_amd as lo  # noqa: E402
+from linear_operator_amd import settings  # noqa: E402
+from linear_operator_amd.operators import (  # noqa: E402
+    AddedDiagLinearOperator, ConstantDiagLinearOperator, DenseLinearOperator, DiagLinearOperator,
+    KroneckerProductLinearOperator, LowRankRootLinearOperator,
+)
+from linear_operator_amd.utils.warnings import NumericalWarning  # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+class ProbedAddedDiag(AddedDiagLinearOperator):
+    _probes = None
+
+    def _probe_vectors_and_norms(self):  # hook: reference _linear_operator.py:629-633
+        return self._probes
+
+
+def test_solve_lowrank_operator_api_and_cg_seam():
+    g = load_golden("g4_solve_lowrank")
+    C, d, rhs = cases.lowrank_diag(401, 4, 2048, 32, 1)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C)), DiagLinearOperator(dev(d)))
+    spy = mock.MagicMock(wraps=lo.utils.linear_cg)
+    with settings.cg_tolerance(1e-4), mock.patch("linear_operator_amd.utils.linear_cg", new=spy):
+        x = torch.linalg.solve(A, dev(rhs))  # __torch_function__ -> solve -> Solve -> _solve -> utils.linear_cg
+    assert spy.called and spy.call_args.kwargs["preconditioner"] is not None  # CG ran, preconditioned
+    assert max_rel_err_cols(host(x), g["x"]) < 1e-4
+    assert max_rel_err_cols(host(x), g["x_exact"]) < 1e-4
+    # un-batched operator with a vector right-hand side (is_vector path, linear_cg.py:134-136,349-350)
+    A0 = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C[0])), DiagLinearOperator(dev(d[0])))
+    with settings.cg_tolerance(1e-4):
+        x0 = A0.solve(dev(rhs[0, :, 0]))
+    assert x0.shape == (2048,)
+    assert rel_err(host(x0), g["x_exact"][0, :, 0]) < 1e-4
+
+
+def test_inv_quad_logdet_probe_seam_and_logdet():
+    g = load_golden("g4_iql_lowrank")
+    C, d, rhs = cases.lowrank_diag(411, 3, 2048, 16, 1)
+    Z, Zn = cases.probes(412, 3, 2048, 8)
+    A = ProbedAddedDiag(LowRankRootLinearOperator(dev(C)), DiagLinearOperator(dev(d)))
+    A._probes = (dev(Z), dev(Zn))
+    with settings.cg_tolerance(1e-4):
+        iq, ld = A.inv_quad_logdet(dev(rhs), logdet=True)
+    floor = 2048 * 1.2e-7 * 137.0
+    assert np.allclose(host(iq), g["inv_quad"], rtol=1e-4)
+    assert np.allclose(host(ld), g["logdet"], rtol=1e-4, atol=floor)
+    # random probes (no hook): stochastic estimate, the reference's own acceptance is rtol 0.2 / atol 0.03 scale
+    A2 = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C)), DiagLinearOperator(dev(d)))
+    torch.manual_seed(0)
+    with settings.cg_tolerance(1e-4), settings.num_trace_samples(64):
+        ld2 = torch.logdet(A2)
+    assert np.allclose(host(ld2), g["logdet_exact"], rtol=0.1, atol=2.0)
+
+
+def test_kron_and_dense_operator_api():
+    g = load_golden("g4_solve_kron")
+    K1, K2, sig, rhs = cases.kron_factors(421, 2, 48, 48, 1)
+    A = AddedDiagLinearOperator(KroneckerProductLinearOperator(dev(K1), dev(K2)),
+                                ConstantDiagLinearOperator(dev(sig), 2304))
+    with settings.cg_tolerance(1e-3):
+        x = A.solve(dev(rhs))
+    assert max_rel_err_cols(host(x), g["x"]) < 5e-3
+    g = load_golden("g4_iql_dense")
+    Kd, d, rhs = cases.dense_diag(431, 2, 2048, 1)
+    Z, Zn = cases.probes(432, 2, 2048, 4)
+    base = DenseLinearOperator(dev(Kd)).add_diagonal(dev(d))
+    assert type(base) is AddedDiagLinearOperator
+    A = ProbedAddedDiag(DenseLinearOperator(dev(Kd)), DiagLinearOperator(dev(d)))
+    A._probes = (dev(Z), dev(Zn))
+    with settings.cg_tolerance(1e-4):
+        iq, ld = A.inv_quad_logdet(dev(rhs), logdet=True)
+    assert np.allclose(host(iq), g["inv_quad"], rtol=1e-4)
+    assert np.allclose(host(ld), g["logdet"], rtol=1e-4, atol=2048 * 1.2e-7 * 10.0)
+
+
+def test_pivoted_cholesky_api_and_preconditioner_override():
+    g = load_golden("g2_pivchol_lowrank")
+    C = cases.lowrank_diag(242, 3, 2048, 32, 1)[0]
+    L, piv = lo.pivoted_cholesky(LowRankRootLinearOperator(dev(C)), rank=15, return_pivots=True)
+    assert np.array_equal(host(piv), g["piv_R32"]) and np.allclose(host(L), g["L_R32"], rtol=1e-4, atol=1e-5)
+    m8 = cases.pivchol_dense8(201)
+    g8 = load_golden("g2_pivchol_dense8")
+    L8, p8 = lo.pivoted_cholesky(dev(m8), rank=3, return_pivots=True)  # plain tensor input
+    assert np.array_equal(host(p8), g8["piv"]) and np.allclose(host(L8), g8["L"], rtol=1e-5, atol=1e-6)
+    # preconditioner_override seam (reference added_diag_linear_operator.py:36-40,112-113)
+    Cc, d, rhs = cases.lowrank_diag(401, 4, 2048, 32, 1)
+    calls = []
+
+    def override(self):
+        calls.append(self)
+        return (lambda t: t / self._diag_tensor._diag.unsqueeze(-1)), None, None  # Jacobi, opaque closure
+
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(Cc)), DiagLinearOperator(dev(d)),
+                                preconditioner_override=override)
+    with settings.cg_tolerance(1e-4), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        x = A.solve(dev(rhs))
+    assert calls
+    ge = load_golden("g4_solve_lowrank")
+    assert max_rel_err_cols(host(x), ge["x_exact"]) < 5e-3  # weaker preconditioner, still a solve
+
+
+def test_linear_cg_signature_closures_warnings_errors():
+    M = cases.spd_test_matrix(111, 10, dtype=np.float32)
+    b = cases.randn(112, 10, 50, dtype=np.float32)
+    Mt = dev(M)
+    with warnings.catch_warnings(record=True) as ws:  # test_linear_cg.py:74-84: warning when tolerance unmet
+        warnings.simplefilter("always")
+        solves, t_mats = lo.utils.linear_cg(Mt.matmul, rhs=dev(b), n_tridiag=5, max_tridiag_iter=10, max_iter=10,
+                                            tolerance=0, eps=1e-15)
+    assert any(issubclass(w.category, NumericalWarning) for w in ws)
+    assert tuple(t_mats.shape) == (5, 10, 10)
+    actual = np.linalg.solve(M.astype(np.float64), b.astype(np.float64))
+    assert np.allclose(host(solves), actual, atol=1e-3, rtol=1e-3)
+    x_vec = lo.utils.linear_cg(lambda v: Mt @ v, dev(b[:, 0]), max_iter=10, max_tridiag_iter=5, tolerance=1e-6)
+    assert x_vec.shape == (10,)
+    Mn = M.copy()
+    Mn[0, 0] = np.nan
+    with pytest.raises(RuntimeError, match="NaNs encountered"):
+        lo.utils.linear_cg(dev(Mn).matmul, dev(b), max_iter=10, max_tridiag_iter=5)
+    # lanczos seam
+    from linear_operator_amd.utils.lanczos import lanczos_tridiag, lanczos_tridiag_to_diag
+
+    Ml = cases.spd_test_matrix(501, 100, dtype=np.float32, jitter=1e-6)
+    q, t = lanczos_tridiag(dev(Ml).matmul, max_iter=100, dtype=torch.float32, device=Mt.device,
+                           matrix_shape=Ml.shape, init_vecs=dev(cases.randn(502, 100, 1, dtype=np.float32)))
+    assert np.allclose(host(q @ t @ q.mT), Ml, atol=1e-4)
+    evals, evecs = lanczos_tridiag_to_diag(t[:20, :20].contiguous().unsqueeze(0))
+    ref = np.linalg.eigvalsh(host(t[:20, :20]).astype(np.float64))
+    assert np.allclose(host(evals)[0], np.where(ref >= 0, ref, 1.0), rtol=1e-4, atol=1e-5)

@@ -1,0 +1,169 @@
+"""CPU tests of the host-side mirror: settings, operator algebra / dispatch, representation tree, the
+Cholesky plumbing branch (cfg1), error conventions, the C-ABI library (loads + exports every declared symbol)
+and the 'no CPU fallback' rule.  No GPU compute here."""
+import ctypes
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from conftest import ROOT, load_golden
+
+import linear_operator_amd as lo
+from linear_operator_amd import _hip, settings
+from linear_operator_amd.operators import (
+    AddedDiagLinearOperator, ConstantDiagLinearOperator, DenseLinearOperator, DiagLinearOperator,
+    KroneckerProductLinearOperator, LinearOperator, LowRankRootLinearOperator, PsdSumLinearOperator,
+    RootLinearOperator, SumLinearOperator,
+)
+
+T = torch.from_numpy
+
+
+def test_settings_names_defaults_and_context_protocol():
+    # names and defaults GPyTorch relies on
+    assert settings.cg_tolerance.value() == 1
+    assert settings.max_cg_iterations.value() == 1000
+    assert settings.max_cholesky_size.value() == 800
+    assert settings.max_lanczos_quadrature_iterations.value() == 20
+    assert settings.max_preconditioner_size.value() == 15
+    assert settings.min_preconditioning_size.value() == 2000
+    assert settings.num_trace_samples.value() == 10
+    assert settings.preconditioner_tolerance.value() == 1e-3
+    assert settings.terminate_cg_by_size.off() and settings.skip_logdet_forward.off() and settings.verbose_linalg.off()
+    assert settings.fast_computations.solves.on() and settings.fast_computations.log_prob.on()
+    with settings.cg_tolerance(1e-4), settings.max_cholesky_size(0), settings.fast_computations(solves=False):
+        assert settings.cg_tolerance.value() == 1e-4 and settings.max_cholesky_size.value() == 0
+        assert settings.fast_computations.solves.off() and settings.fast_computations.log_prob.on()
+    assert settings.cg_tolerance.value() == 1 and settings.fast_computations.solves.on()
+    with settings.cholesky_jitter(float_value=1e-3):
+        assert settings.cholesky_jitter.value(torch.float) == 1e-3
+    assert settings.cholesky_jitter.value(torch.float) == 1e-6
+
+    class my_tol(settings.cg_tolerance):  # GPyTorch-style subclassing keeps working
+        pass
+
+    with my_tol(0.5):
+        assert my_tol.value() == 0.5
+
+
+def test_abi_library_loads_and_exports_every_declared_symbol():
+    lib = _hip.load()
+    assert lib.lo_abi_version() == _hip.ABI_VERSION and lib.lo_target_arch() == b"gfx950"
+    hdr = open(os.path.join(ROOT, "include", "lo_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(lo_[a-z0-9_]+)\s*\(", hdr)) - {"lo_matvec_cb"})
+    assert len(declared) >= 18
+    raw = ctypes.CDLL(_hip.lib_path())
+    for name in declared:
+        assert hasattr(raw, name), f"liblo_amd.so does not export {name} declared in include/lo_amd.h"
+    assert set(_hip.EXPORTS) == set(declared)
+
+
+def test_class_relationships_and_add_routing():
+    # isinstance relations are part of the contract
+    assert issubclass(AddedDiagLinearOperator, SumLinearOperator)
+    assert issubclass(LowRankRootLinearOperator, RootLinearOperator)
+    assert issubclass(ConstantDiagLinearOperator, DiagLinearOperator)
+    assert issubclass(PsdSumLinearOperator, SumLinearOperator)
+    C = torch.randn(3, 20, 4)
+    d = torch.rand(3, 20) + 0.5
+    A = RootLinearOperator(C) + DiagLinearOperator(d)
+    assert type(A) is AddedDiagLinearOperator and A._linear_op.__class__ is RootLinearOperator
+    A2 = DenseLinearOperator(torch.randn(3, 20, 20)).add_diagonal(d)
+    assert type(A2) is AddedDiagLinearOperator and isinstance(A2._diag_tensor, DiagLinearOperator)
+    A3 = DenseLinearOperator(torch.randn(20, 20)).add_jitter(1e-2)
+    assert isinstance(A3._diag_tensor, ConstantDiagLinearOperator)
+    assert type(A + DiagLinearOperator(d)) is AddedDiagLinearOperator
+    S = RootLinearOperator(C) + DenseLinearOperator(torch.randn(3, 20, 20))
+    assert type(S) is SumLinearOperator and type(S + DiagLinearOperator(d)) is AddedDiagLinearOperator
+    with pytest.raises(RuntimeError, match="only have two components"):
+        AddedDiagLinearOperator(RootLinearOperator(C), DiagLinearOperator(d), DiagLinearOperator(d))
+    with pytest.raises(RuntimeError, match="must be a DiagLinearOperator"):
+        AddedDiagLinearOperator(RootLinearOperator(C), RootLinearOperator(C))
+    with pytest.raises(ValueError, match="final singleton dimension"):
+        ConstantDiagLinearOperator(torch.rand(3, 20), 20)
+
+
+def test_matmul_to_dense_and_torch_function_dispatch_cpu():
+    g = load_golden("g6_matmul")
+    C, d, v = cases.lowrank_diag(601, 3, 256, 8, 5)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+    y = torch.matmul(A, T(v))  # __torch_function__ -> matmul -> Matmul Function -> _matmul (ATen on CPU)
+    assert np.allclose(y.numpy(), g["y_lowrank_diag"], rtol=1e-5, atol=1e-5)
+    assert np.allclose((A @ T(v)).numpy(), g["y_lowrank_diag"], rtol=1e-5, atol=1e-5)
+    assert np.allclose(A.to_dense().numpy(), (C @ np.swapaxes(C, -1, -2)) + np.stack([np.diag(x) for x in d]),
+                       rtol=1e-4, atol=1e-5)
+    K1, K2, s, vk = cases.kron_factors(621, 2, 12, 20, 3)
+    kp = KroneckerProductLinearOperator(T(K1), T(K2))
+    assert np.allclose(kp._matmul(T(vk)).numpy(), g["y_kron"], rtol=1e-4, atol=1e-4)
+    assert np.allclose(kp._diagonal().numpy(), g["diag_kron"], rtol=1e-6)
+    assert np.allclose(kp.to_dense().numpy(), np.stack([np.kron(K1[i], K2[i]) for i in range(2)]), rtol=1e-5)
+    Ak = AddedDiagLinearOperator(kp, ConstantDiagLinearOperator(T(s), 240))
+    assert np.allclose(Ak._matmul(T(vk)).numpy(), g["y_kron_diag"], rtol=1e-4, atol=1e-4)
+    with pytest.raises(NotImplementedError, match="is not implemented"):
+        torch.trace(A)
+    with pytest.raises(RuntimeError):
+        torch.matmul(A, torch.randn(3, 255, 2))
+
+
+def test_representation_tree_roundtrip():
+    C, d, _ = cases.lowrank_diag(5, 2, 30, 4, 1)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), ConstantDiagLinearOperator(torch.rand(2, 1), 30))
+    rep = A.representation()
+    assert len(rep) == 2 and all(torch.is_tensor(t) for t in rep)
+    B = A.representation_tree()(*rep)
+    assert type(B) is AddedDiagLinearOperator and type(B._linear_op) is LowRankRootLinearOperator
+    assert type(B._diag_tensor) is ConstantDiagLinearOperator and B._diag_tensor.diag_shape == 30
+    assert torch.equal(B.to_dense(), A.to_dense())
+
+
+def test_cfg1_dense256_cholesky_branch_matches_reference():
+    """BASELINE cfg1: torch.linalg.solve(DenseLinearOperator(K256), b) takes the Cholesky branch (no CG, no GPU)."""
+    g = load_golden("g4_cfg1_dense256")
+    M = cases.spd_test_matrix(441, 256, dtype=np.float32, jitter=1.0)
+    b = cases.randn(442, 256, 3, dtype=np.float32)
+    called = []
+    orig = lo.utils.linear_cg
+    lo.utils.linear_cg = lambda *a, **k: called.append(1) or orig(*a, **k)
+    try:
+        x = torch.linalg.solve(DenseLinearOperator(T(M)), T(b))
+    finally:
+        lo.utils.linear_cg = orig
+    assert not called
+    assert np.allclose(x.numpy(), g["x"], rtol=1e-4, atol=1e-5)
+    iq, ld = DenseLinearOperator(T(M)).inv_quad_logdet(T(b), logdet=True)
+    assert np.allclose(ld.item(), np.linalg.slogdet(M.astype(np.float64))[1], rtol=1e-4)
+    assert np.allclose(iq.item(), (b * np.linalg.solve(M.astype(np.float64), b)).sum(), rtol=1e-4)
+
+
+def test_no_cpu_fallback_for_the_iterative_path():
+    C, d, rhs = cases.lowrank_diag(6, 2, 64, 4, 1)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+    with settings.max_cholesky_size(0):
+        with pytest.raises(_hip.HipExtensionError, match="no CPU fallback"):
+            A.solve(T(rhs))
+        with pytest.raises(_hip.HipExtensionError):
+            A.inv_quad_logdet(T(rhs), logdet=True)
+    with pytest.raises(_hip.HipExtensionError):
+        lo.utils.linear_cg(T(np.eye(8, dtype=np.float32)).matmul, torch.randn(8, 1), max_iter=8, max_tridiag_iter=4)
+    assert A._kernel_descriptor() is None  # CPU tensors never lower to a kernel descriptor
+
+
+def test_linear_cg_argument_errors_match_reference():
+    M = torch.eye(10)
+    with pytest.raises(RuntimeError, match="larger than the number of CG iterations"):  # linear_cg.py:159-160
+        lo.utils.linear_cg(M.matmul, torch.randn(10), max_iter=5)
+    with pytest.raises(RuntimeError, match="must be a tensor, or a callable"):  # :163-166
+        lo.utils.linear_cg(3.0, torch.randn(10), max_iter=10, max_tridiag_iter=5)
+    A = DenseLinearOperator(torch.randn(3, 20, 21))
+    with pytest.raises(RuntimeError, match="square"):
+        A.solve(torch.randn(3, 21, 1))
+    sq = DenseLinearOperator(torch.eye(900))
+    with pytest.raises(RuntimeError, match="same number of dimensions"):
+        sq.inv_quad_logdet(torch.randn(2, 900, 1), logdet=True)
+    with pytest.raises(RuntimeError, match="must be specifed"):
+        sq.inv_quad_logdet(None, logdet=False)
