@@ -454,19 +454,34 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   int k = 0;
   int launched = 0;
   while (k < prm->max_iter && !h.stop) {
-    LO_PROF_BEGIN("cg_update_p", st);
-    hipLaunchKernelGGL(k_cg_update_p, gridv, block, 0, st, d, zsrc, k == 0 ? 1 : 0, sp.rows);
-    LO_PROF_END(st);
-    LO_LAUNCH_CHECK();
-    rc = matvec_run(&pl, d.p, d.Ap, d.pAp_part, stop, st);
-    if (rc) return rc;
-    LO_PROF_BEGIN("cg_update_xr", st);
-    hipLaunchKernelGGL(k_cg_update_xr, gridv, block, 0, st, d, sp.rows);
-    LO_PROF_END(st);
-    LO_LAUNCH_CHECK();
-    if (precond) {
-      rc = apply_precond(d.r, d.z, d.rz_part);
+    if (matvec_can_fuse_pupdate(&pl)) {
+      rc = matvec_run_pupdate(&pl, d.p, zsrc, d.beta, k == 0 ? 1 : 0, d.Ap, d.pAp_part, stop, st);
       if (rc) return rc;
+    } else {
+      LO_PROF_BEGIN("cg_update_p", st);
+      hipLaunchKernelGGL(k_cg_update_p, gridv, block, 0, st, d, zsrc, k == 0 ? 1 : 0, sp.rows);
+      LO_PROF_END(st);
+      LO_LAUNCH_CHECK();
+      rc = matvec_run(&pl, d.p, d.Ap, d.pAp_part, stop, st);
+      if (rc) return rc;
+    }
+    if (pre) {
+      // r-update, x-update and the residual norm ride on the first pass over Q
+      rc = skinny_tn_rupdate(Qp, preR4, preR4, d.r, d.Ap, d.p, d.x, d.pAp_part, d.S_dot, d.rz, d.has_conv, d.eps,
+                             d.alpha, d.rr_part, c, upart, B, N, sp, stop, st);
+      if (rc) return rc;
+      rc = skinny_nn(Qp, preR4, preR4, upart, pre->dinv, pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL, -1.0f, d.r,
+                     c, d.z, d.rz_part, B, N, sp, stop, st);
+      if (rc) return rc;
+    } else {
+      LO_PROF_BEGIN("cg_update_xr", st);
+      hipLaunchKernelGGL(k_cg_update_xr, gridv, block, 0, st, d, sp.rows);
+      LO_PROF_END(st);
+      LO_LAUNCH_CHECK();
+      if (precond) {
+        rc = apply_precond(d.r, d.z, d.rz_part);
+        if (rc) return rc;
+      }
     }
     LO_PROF_BEGIN("cg_ctrl", st);
     hipLaunchKernelGGL(k_cg_ctrl, dim3(1), block, 0, st, d, k);

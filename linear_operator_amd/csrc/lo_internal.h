@@ -83,6 +83,15 @@ int skinny_tn(const float* A, int lda, int R4, const float* v, int64_t c, float*
 int skinny_nn(const float* A, int lda, int R4, const float* tpart, const float* dd, int dd_mode, float sgn,
               const float* v, int64_t c, float* y, float* dot_part, int64_t B, int64_t N, Split sp, const int* stop,
               hipStream_t st);
+// fused CG variants of skinny_tn (see lo_skinny.hip): the input vector is built on the fly
+//   pupdate: p = z + beta p (first: p = z), written back, then tpart = A^T p
+//   rupdate: masked alpha from pAp partials; r -= alpha Ap (written back); x += alpha p; rr_part = sum r^2; tpart = A^T r
+int skinny_tn_pupdate(const float* A, int lda, int R4, float* p, const float* z, const float* beta, int first, int64_t c,
+                      float* tpart, int64_t B, int64_t N, Split sp, const int* stop, hipStream_t st);
+int skinny_tn_rupdate(const float* A, int lda, int R4, float* r, const float* Ap, const float* p, float* x,
+                      const float* pAp_part, int S_dot, const float* rz, const int* has_conv, float eps,
+                      float* alpha_out, float* rr_part, int64_t c, float* tpart, int64_t B, int64_t N, Split sp,
+                      const int* stop, hipStream_t st);
 // copy rows [B,N,R] -> zero padded [B,N,R4]
 int pad_rows(const float* src, int R, float* dst, int R4, int64_t rows, hipStream_t st);
 
@@ -111,6 +120,11 @@ int matvec_plan_init(MatvecPlan* pl, const lo_op_desc* op, lo_matvec_cb cb, void
                      Arena* ar, hipStream_t st);
 // y = A v (+ optional dot partials sum_rows v o y, S_dot per (b,col))
 int matvec_run(const MatvecPlan* pl, const float* v, float* y, float* dot_part, const int* stop, hipStream_t st);
+// true if the plan can fuse the CG search-direction update into its first pass (low-rank operators)
+bool matvec_can_fuse_pupdate(const MatvecPlan* pl);
+// p = z + beta p (first: p = z); y = A p; dot partials
+int matvec_run_pupdate(const MatvecPlan* pl, float* p, const float* z, const float* beta, int first, float* y,
+                       float* dot_part, const int* stop, hipStream_t st);
 
 // dense / kron kernels
 int dense_matvec(const float* K, const float* d, int dd_mode, const float* v, float* y, float* dot_part, int64_t B,

@@ -106,6 +106,19 @@ int matvec_run(const MatvecPlan* pl, const float* v, float* y, float* dot_part, 
   return LO_ERR_BADARG;
 }
 
+bool matvec_can_fuse_pupdate(const MatvecPlan* pl) { return pl->op.kind == LO_OP_LOWRANK_DIAG; }
+
+int matvec_run_pupdate(const MatvecPlan* pl, float* p, const float* z, const float* beta, int first, float* y,
+                       float* dot_part, const int* stop, hipStream_t st) {
+  const lo_op_desc& op = pl->op;
+  if (op.kind != LO_OP_LOWRANK_DIAG) return LO_ERR_BADARG;
+  int rc = skinny_tn_pupdate(pl->Apad, pl->lda, pl->R4, p, z, beta, first, pl->c, pl->tpart, op.B, op.N, pl->sp, stop,
+                             st);
+  if (rc) return rc;
+  return skinny_nn(pl->Apad, pl->lda, pl->R4, pl->tpart, op.d, op.diag_mode, 1.0f, p, pl->c, y, dot_part, op.B, op.N,
+                   pl->sp, stop, st);
+}
+
 }  // namespace lo
 
 using namespace lo;
