@@ -137,6 +137,11 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
                     const float* x0, float* x, float* t_mat, void* ws, size_t ws_bytes, lo_cg_info* info,
                     void* stream);
 
+/* Development / test switch: 0 forces the streaming (multi-kernel) engine, 1 (default) allows the operator-resident
+ * fast path (csrc/lo_cg_onchip.hip) for low-rank + Woodbury-preconditioned single-column solves.  Same results
+ * up to summation order. */
+int lo_cg_set_onchip(int enable);
+
 /* ---- PivotedCholesky.forward (linear_operator/functions/_pivoted_cholesky.py:14-105) ---------- */
 /* Greedy partial pivoted Cholesky of the NON-diagonal part of `op` (op->d is ignored, as
  * added_diag_linear_operator.py:125 calls self._linear_op.pivoted_cholesky).

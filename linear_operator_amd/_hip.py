@@ -25,7 +25,7 @@ _ERR = {-1: "bad argument", -2: "HIP launch/runtime failure", -3: "workspace too
 EXPORTS = [
     "lo_abi_version", "lo_target_arch",
     "lo_matvec_workspace_bytes", "lo_matvec_f32",
-    "lo_cg_workspace_bytes", "lo_cg_solve_f32",
+    "lo_cg_workspace_bytes", "lo_cg_solve_f32", "lo_cg_set_onchip",
     "lo_pivoted_cholesky_workspace_bytes", "lo_pivoted_cholesky_f32",
     "lo_precond_build_workspace_bytes", "lo_precond_build_f32",
     "lo_precond_apply_workspace_bytes", "lo_precond_apply_f32",
@@ -124,6 +124,8 @@ def load():
     lib.lo_tridiag_eigh_slq_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
     lib.lo_tridiag_eigh_slq_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p]
+    lib.lo_cg_set_onchip.restype = C.c_int
+    lib.lo_cg_set_onchip.argtypes = [C.c_int]
     lib.lo_prof_enable.restype = C.c_int
     lib.lo_prof_enable.argtypes = [C.c_int]
     lib.lo_prof_report.restype = C.c_int

@@ -19,8 +19,11 @@
 
 #include "lo_device.h"
 #include "lo_internal.h"
+#include "lo_cg_onchip.h"
 
 namespace lo {
+
+bool g_onchip_disabled = false;
 
 struct CgDev {
   int64_t B, N;
@@ -37,6 +40,10 @@ struct CgDev {
   int *rhs_is_zero, *has_conv;
   float* t_mat;
   CgCtrl* ctrl;
+  unsigned long long* oc_gbuf;
+  int* oc_err;
+  float* oc_resid;
+  int* oc_init_conv;
 };
 
 // ---- init ----------------------------------------------------------------------------------------
@@ -238,6 +245,40 @@ __global__ __launch_bounds__(kThreads) void k_cg_ctrl(CgDev d, int k) {
   }
 }
 
+// control step after the operator-resident kernel ran iterations 0 .. iters-1 (c == 1, n_tridiag == 0):
+// the stop rule of iteration k = iters-1 (>= the 10-iteration floor), NaN check, skip rule (:207-208)
+__global__ __launch_bounds__(kThreads) void k_cg_ctrl_onchip(CgDev d, const float* __restrict__ resid_rec,
+                                                              const int* __restrict__ init_conv, int iters) {
+  __shared__ float red[kThreads];
+  float lsum = 0.f, lnan = 0.f, lnotconv = 0.f;
+  for (int64_t b = threadIdx.x; b < d.B; b += kThreads) {
+    const float rn = resid_rec[(size_t)(iters - 1) * d.B + b];
+    const float r0 = resid_rec[b];
+    lsum += rn;
+    if (r0 != r0 || rn != rn) lnan = 1.f;
+    if (!init_conv[b]) lnotconv = 1.f;
+  }
+  const float mean = block_sum256(lsum, red) / (float)d.B;
+  const float anynan = block_sum256(lnan, red);
+  const float notconv = block_sum256(lnotconv, red);
+  if (threadIdx.x == 0) {
+    const int k = iters - 1;
+    d.ctrl->iterations = iters;
+    d.ctrl->mean_resid = mean;
+    if (anynan > 0.f) {
+      d.ctrl->nan_detected = 1;
+      d.ctrl->stop = 1;
+    } else if (notconv == 0.f) {  // every column converged before the first iteration: the reference skips the loop
+      d.ctrl->skipped = 1;
+      d.ctrl->iterations = 0;
+      d.ctrl->stop = 1;
+    } else if (k >= min(10, d.max_iter - 1) && mean < d.tol) {
+      d.ctrl->tol_reached = 1;
+      d.ctrl->stop = 1;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_cg_final(CgDev d, float* __restrict__ xout, int rows_per) {
   const int s = blockIdx.x, b = blockIdx.y;
   const int c = d.c, N = (int)d.N;
@@ -305,6 +346,11 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   const size_t nt = (size_t)B * std::max(1, (int)prm->n_tridiag);
   dd.prev_ar = ar.take<float>(nt);
   dd.prev_beta = ar.take<float>(nt);
+  // operator-resident fast path scratch (c == 1): granule buffer, error word, per-iteration residuals
+  dd.oc_gbuf = ar.take<unsigned long long>(onchip_gbuf_bytes(64) / sizeof(unsigned long long));
+  dd.oc_err = ar.take<int>(1);
+  dd.oc_resid = ar.take<float>((size_t)B * 16);
+  dd.oc_init_conv = ar.take<int>((size_t)B);
   // preconditioner staging
   if (pre) {
     const int R4 = padded_rank_k(pre->k);
@@ -409,13 +455,51 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     return vec_dot_part(r, z, c, dotp, B, N, sp, stop, st);
   };
 
+  // ---- operator-resident fast path for the guaranteed iterations (lo_cg_onchip.hip) ----
+  int k_start = 0;
+  CgCtrl h;
+  memset(&h, 0, sizeof(h));
+  const int kfloor0 = std::min(10, prm->max_iter - 1);
+  const int oc_nwg = onchip_num_workgroups();
+  const bool oc_ok = (op->kind == LO_OP_LOWRANK_DIAG) && pre && !precond_cb && !x0 && prm->n_tridiag == 0 && c == 1 &&
+                     prm->max_iter >= 11 && oc_nwg >= 64 && onchip_eligible(pl.R4, preR4, N, c) && !g_onchip_disabled;
+  if (oc_ok) {
+    OnchipArgs a;
+    a.C = pl.Apad; a.Q = Qp; a.d = op->d; a.dinv = pre->dinv;
+    a.d_mode = op->diag_mode; a.dinv_mode = pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL;
+    a.rhs = rhs; a.B = B; a.N = (int)N; a.RW = (int)((N + 7) / 8);
+    a.iters = kfloor0 + 1;
+    a.eps = prm->eps; a.stop_after = prm->stop_updating_after;
+    a.x = d.x; a.r = d.r; a.p = d.p; a.z = d.z;
+    a.rhs_norm = d.rhs_norm; a.rz = d.rz; a.alpha = d.alpha; a.beta = d.beta; a.resid_norm = d.resid_norm;
+    a.rhs_is_zero = d.rhs_is_zero; a.has_conv = d.has_conv;
+    a.resid_rec = d.oc_resid; a.init_conv = d.oc_init_conv; a.gbuf = d.oc_gbuf; a.err = d.oc_err;
+    LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(oc_nwg / 8), st));
+    LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 0, sizeof(int), st));
+    rc = onchip_launch(pl.R4, preR4, a, oc_nwg, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cg_ctrl_onchip, dim3(1), block, 0, st, d, d.oc_resid, d.oc_init_conv, a.iters);
+    LO_LAUNCH_CHECK();
+    int oc_err = 0;
+    LO_HIP_CHECK(hipMemcpyAsync(&oc_err, d.oc_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
+    LO_HIP_CHECK(hipStreamSynchronize(st));
+    if (oc_err == 0) {
+      k_start = a.iters;
+    } else {  // a group hand-off timed out: redo everything with the streaming engine
+      fprintf(stderr, "liblo_amd: operator-resident CG timed out, falling back to the streaming engine\n");
+      LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, sizeof(CgCtrl), st));
+      memset(&h, 0, sizeof(h));
+    }
+  }
+  int matvecs = 0;
+  if (k_start == 0) {
   // ---- initialisation (linear_cg.py:177-215) ----
   rc = vec_dot_part(rhs, rhs, c, d.pAp_part, B, N, sp, nullptr, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_cg_init_scal, dim3(1), block, 0, st, d, d.pAp_part);
   hipLaunchKernelGGL(k_cg_init_vec, gridv, block, 0, st, d, rhs, x0, sp.rows);
   LO_LAUNCH_CHECK();
-  int matvecs = 0;
   if (x0) {
     rc = matvec_run(&pl, d.x, d.Ap, nullptr, nullptr, st);
     if (rc) return rc;
@@ -432,6 +516,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   }
   hipLaunchKernelGGL(k_cg_ctrl_init, dim3(1), block, 0, st, d);
   LO_LAUNCH_CHECK();
+  }  // k_start == 0
 
   // ---- iterations ----
   const float* zsrc = precond ? d.z : d.r;
@@ -440,8 +525,6 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   if (prm->n_tridiag) first_poll = std::max(first_poll, std::min(prm->max_tridiag_iter, prm->max_iter - 1));
   const bool opaque = (op->kind == LO_OP_CALLBACK) || (precond_cb != nullptr);
   const int chunk = opaque ? 1 : 4;
-  CgCtrl h;
-  memset(&h, 0, sizeof(h));
   auto poll = [&]() -> int {
     LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
     LO_HIP_CHECK(hipStreamSynchronize(st));
@@ -451,8 +534,8 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     rc = poll();
     if (rc) return rc;
   }
-  int k = 0;
-  int launched = 0;
+  int k = k_start;
+  int launched = k_start;
   while (k < prm->max_iter && !h.stop) {
     if (matvec_can_fuse_pupdate(&pl)) {
       rc = matvec_run_pupdate(&pl, d.p, zsrc, d.beta, k == 0 ? 1 : 0, d.Ap, d.pAp_part, stop, st);
@@ -511,6 +594,12 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   info->last_tridiag_iter = h.last_tridiag_iter;
   info->mean_residual = h.mean_resid;
   info->reserved = 0.f;
+  return LO_OK;
+}
+
+// development / test switch: force the streaming engine (0) or allow the operator-resident fast path (1)
+int lo_cg_set_onchip(int enable) {
+  g_onchip_disabled = (enable == 0);
   return LO_OK;
 }
 

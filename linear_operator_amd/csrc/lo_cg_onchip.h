@@ -1,0 +1,32 @@
+// lo_cg_onchip.h -- argument block of the operator-resident CG kernel (lo_cg_onchip.hip)
+#pragma once
+#include <stdint.h>
+
+#include <hip/hip_runtime.h>
+
+namespace lo {
+
+struct OnchipArgs {
+  const float* C;     // [B, N, RC]   (padded rank RC)
+  const float* Q;     // [B, N, RK]
+  const float* d;     // [B, N] or [B]
+  const float* dinv;  // [B, N] or [B]
+  int d_mode, dinv_mode;
+  const float* rhs;   // [B, N]
+  int64_t B;
+  int N, RW;          // rows per workgroup
+  int iters;          // iterations to run (k = 0 .. iters-1)
+  float eps, stop_after;
+  // state out (streaming engine layout, c == 1)
+  float *x, *r, *p, *z;
+  float *rhs_norm, *rz, *alpha, *beta, *resid_norm;
+  int *rhs_is_zero, *has_conv;
+  float* resid_rec;   // [iters, B] residual norm after each iteration (for the stop rule / NaN check)
+  int* init_conv;     // [B] has_converged before the first iteration (linear_cg.py:205-208)
+  unsigned long long* gbuf;  // [ngroups][2][8][40] granules
+  int* err;
+};
+
+int onchip_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st);
+
+}  // namespace lo

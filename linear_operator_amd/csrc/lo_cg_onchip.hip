@@ -1,0 +1,384 @@
+// lo_cg_onchip.hip -- "operator-resident" preconditioned CG for the headline case:
+//   A = C C^T + diag(d)  (C [N, R<=32]),  Woodbury/QR preconditioner Q [N, k<=16],  one right-hand side.
+// The multi-kernel engine (lo_cg.hip) streams C and Q from HBM twice per iteration (2.9 MiB per member and
+// iteration) -- HBM-bound at ~390 us per iteration for 512 members.  Here a member's whole operator lives
+// ON CHIP for all iterations the reference is guaranteed to run (the 11-iteration floor, linear_cg.py:303):
+// 8 workgroups (one per CU, 1024 threads) form a group that owns one member; thread t of workgroup w keeps
+// row (w * RW + t) of C and of Q -- 48 floats -- plus its elements of x, r, p, z, d, 1/d in VGPRs.  C and Q
+// are read from HBM ONCE per solve instead of 22 times.
+//
+// Every inner product of CG (C^T p, p.Ap, Q^T r with ||r||^2, r.z -- four per iteration) becomes
+//   wave:       recursive-halving butterfly (a lane ends with the wave sum of ONE component)
+//   workgroup:  16 wave partials through LDS, summed in fixed order
+//   group:      each workgroup publishes its partial as 8-byte {value, tag} granules with agent-scope relaxed
+//               atomic stores (sc1), every workgroup polls the 8 x n granules with agent-scope loads until the
+//               tag equals the phase counter, then sums them in fixed order -> bitwise identical in all 8.
+//   A granule is one naturally aligned 8-byte store, so value and tag can never be seen torn and no fence or
+//   separate flag is needed (MI355X_MICROARCH.md "hand-off" rows); two slot sets alternate by phase parity so a
+//   fast workgroup cannot overwrite a granule a slow one still has to read.  Polls are bounded: on timeout an
+//   error word is set and the host falls back to the streaming engine.
+//
+// The arithmetic is the reference's (same masked alpha/beta, same update order, linear_cg.py:245-300); only the
+// summation order of the inner products differs.  After the last guaranteed iteration the state (x, r, p, z and
+// the per-member scalars) is written back in the streaming engine's layout; the batch-global stop rule is then
+// evaluated by lo_cg.hip's control kernel, which continues with the streaming loop in the (rare) case that the
+// tolerance is not yet met.
+#include <algorithm>
+
+#include "lo_device.h"
+#include "lo_internal.h"
+#include "lo_cg_onchip.h"
+
+namespace lo {
+
+constexpr int OC_TPB = 1024;
+constexpr int OC_GW = 8;          // workgroups per member
+constexpr int OC_WAVES = OC_TPB / 64;
+constexpr unsigned OC_MAXSPIN = 1u << 22;
+
+
+// Recursive-halving tail, fully compile-time indexed (runtime-indexed register arrays would go to scratch):
+// v holds CNT live values; step with lane mask M keeps the half selected by lane bit M and adds the partner's.
+template <int CNT, int M, int NV>
+__device__ __forceinline__ void halving_steps(float (&v)[NV], int lane) {
+  if constexpr (M >= 1) {
+    if constexpr (CNT > 1) {
+      const bool hi = (lane & M) != 0;
+      constexpr int half = CNT / 2;
+#pragma unroll
+      for (int j = 0; j < half; ++j) {
+        const float keep = hi ? v[j + half] : v[j];
+        const float send = hi ? v[j] : v[j + half];
+        v[j] = keep + __shfl_xor(send, M, 64);
+      }
+      halving_steps<half, M / 2, NV>(v, lane);
+    } else {
+      v[0] += __shfl_xor(v[0], M, 64);
+      halving_steps<1, M / 2, NV>(v, lane);
+    }
+  }
+}
+
+// Wave reduce-scatter of the products a[j] * s with the operand row in LDS (read as float4): on exit lane l holds
+// the sum over the 64 lanes of component (l >> (6 - log2 n)).  The first halving step forms the products on the
+// fly, so only n/2 temporaries are live.  Used for the C row, which lives in LDS so that its 32 floats do not
+// occupy a quarter of the 128-VGPR budget.
+template <int n>
+__device__ __forceinline__ float wave_reduce_scatter_prod_lds(const float* __restrict__ a, float s) {
+  const int lane = threadIdx.x & 63;
+  constexpr int h0 = n / 2;
+  float v[h0];
+  const bool hi = (lane & 32) != 0;
+#pragma unroll
+  for (int j = 0; j < h0; j += 4) {
+    const float4 lo4 = *reinterpret_cast<const float4*>(a + j);
+    const float4 hi4 = *reinterpret_cast<const float4*>(a + j + h0);
+    const float lo_p[4] = {lo4.x * s, lo4.y * s, lo4.z * s, lo4.w * s};
+    const float hi_p[4] = {hi4.x * s, hi4.y * s, hi4.z * s, hi4.w * s};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float keep = hi ? hi_p[e] : lo_p[e];
+      const float send = hi ? lo_p[e] : hi_p[e];
+      v[j + e] = keep + __shfl_xor(send, 32, 64);
+    }
+  }
+  halving_steps<h0, 16, h0>(v, lane);
+  return v[0];
+}
+
+// The same with the operand row in registers (Q row).
+template <int n>
+__device__ __forceinline__ float wave_reduce_scatter_prod(const float (&a)[n], float s) {
+  const int lane = threadIdx.x & 63;
+  constexpr int h0 = n / 2;
+  float v[h0];
+  const bool hi = (lane & 32) != 0;
+#pragma unroll
+  for (int j = 0; j < h0; ++j) {
+    const float lo_p = a[j] * s, hi_p = a[j + h0] * s;
+    const float keep = hi ? hi_p : lo_p;
+    const float send = hi ? lo_p : hi_p;
+    v[j] = keep + __shfl_xor(send, 32, 64);
+  }
+  halving_steps<h0, 16, h0>(v, lane);
+  return v[0];
+}
+
+constexpr int OC_CLD = 36;  // padded LDS row stride of C (floats): 144-B rows -> conflict-free ds_read_b128
+
+struct OcShared {
+  float red[OC_WAVES][40];
+  float part[40];
+  float gath[OC_GW][40];
+  float res[40];
+};
+
+// Group-wide sum of `cnt` (<= 40) workgroup partials sitting in sh.part[0..cnt); result in sh.res[0..cnt),
+// identical in all workgroups of the group.  Must be called by all 1024 threads.
+__device__ __forceinline__ void group_exchange(OcShared& sh, int cnt, unsigned long long* gslot_base, int wig,
+                                               unsigned tag, int* err) {
+  const int t = threadIdx.x;
+  unsigned long long* slot = gslot_base + (size_t)(tag & 1u) * OC_GW * 40;
+  if (t < cnt) {
+    const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(sh.part[t]);
+    __hip_atomic_store(slot + (size_t)wig * 40 + t, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (t < OC_GW * cnt) {
+    const int w = t / cnt, i = t % cnt;
+    const unsigned long long* src = slot + (size_t)w * 40 + i;
+    unsigned long long g = 0;
+    unsigned spin = 0;
+    for (;;) {
+      g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(g >> 32) == tag) break;
+      if (++spin > OC_MAXSPIN) {
+        atomicExch(err, 1);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    sh.gath[w][i] = __uint_as_float((unsigned)(g & 0xffffffffull));
+  }
+  __syncthreads();
+  if (t < cnt) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < OC_GW; ++w) s += sh.gath[w][t];
+    sh.res[t] = s;
+  }
+  __syncthreads();
+}
+
+// workgroup partial of n per-thread components + `ns` scalars -> sh.part[0 .. n+ns)
+template <int n>
+__device__ __forceinline__ void wg_partial(OcShared& sh, const float (&a)[n], float mult, const float* scal, int ns) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  constexpr int sh_bits = (n == 32) ? 1 : (n == 16) ? 2 : (n == 8) ? 3 : (n == 4) ? 4 : 5;
+  const float mine = wave_reduce_scatter_prod<n>(a, mult);
+  if ((lane & ((1 << sh_bits) - 1)) == 0) sh.red[wave][lane >> sh_bits] = mine;
+  for (int j = 0; j < ns; ++j) {
+    const float sv = wave_sum(scal[j]);
+    if (lane == 0) sh.red[wave][n + j] = sv;
+  }
+  __syncthreads();
+  if (t < n + ns) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < OC_WAVES; ++w) s += sh.red[w][t];
+    sh.part[t] = s;
+  }
+  __syncthreads();
+}
+
+template <int n>
+__device__ __forceinline__ void wg_partial_lds(OcShared& sh, const float* a, float mult, const float* scal, int ns) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  constexpr int sh_bits = (n == 32) ? 1 : (n == 16) ? 2 : (n == 8) ? 3 : (n == 4) ? 4 : 5;
+  const float mine = wave_reduce_scatter_prod_lds<n>(a, mult);
+  if ((lane & ((1 << sh_bits) - 1)) == 0) sh.red[wave][lane >> sh_bits] = mine;
+  for (int j = 0; j < ns; ++j) {
+    const float sv = wave_sum(scal[j]);
+    if (lane == 0) sh.red[wave][n + j] = sv;
+  }
+  __syncthreads();
+  if (t < n + ns) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < OC_WAVES; ++w) s += sh.red[w][t];
+    sh.part[t] = s;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void wg_partial_scalars(OcShared& sh, const float* scal, int ns) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int j = 0; j < ns; ++j) {
+    const float sv = wave_sum(scal[j]);
+    if (lane == 0) sh.red[wave][j] = sv;
+  }
+  __syncthreads();
+  if (t < ns) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < OC_WAVES; ++w) s += sh.red[w][t];
+    sh.part[t] = s;
+  }
+  __syncthreads();
+}
+
+template <int RC, int RK>
+__global__ __launch_bounds__(OC_TPB) void k_cg_onchip(OnchipArgs a) {
+  __shared__ OcShared sh;
+  __shared__ float c_s[OC_TPB * OC_CLD];  // this workgroup's rows of C (144 KiB of the CU's 160 KiB LDS); Q rows in VGPRs
+  const int wg = blockIdx.x;
+  // keep the 8 workgroups of a group on one XCD (block b runs on XCD b % 8; speed only)
+  const int xcd = wg % 8, j = wg / 8;
+  const int groups_per_xcd = (gridDim.x / 8) / OC_GW;
+  const int grp = xcd * groups_per_xcd + j / OC_GW;
+  const int wig = j % OC_GW;
+  const int ngroups = gridDim.x / OC_GW;
+  if (j / OC_GW >= groups_per_xcd) return;  // grid not a multiple of 64: spare workgroups idle
+  const int t = threadIdx.x;
+  unsigned long long* gslot = a.gbuf + (size_t)grp * 2 * OC_GW * 40;
+  unsigned tag = 0;
+
+  for (int64_t b = grp; b < a.B; b += ngroups) {
+    const int row = wig * a.RW + t;
+    const bool valid = (t < a.RW) && (row < a.N);
+    float Qr[RK];
+    float* crow = c_s + t * OC_CLD;
+    float dv = 0.f, dinvv = 0.f, rhsv = 0.f;
+    if (valid) {
+      const float4* cp = reinterpret_cast<const float4*>(a.C + ((size_t)b * a.N + row) * RC);
+#pragma unroll
+      for (int i = 0; i < RC / 4; ++i) *reinterpret_cast<float4*>(crow + 4 * i) = cp[i];
+      const float4* qp = reinterpret_cast<const float4*>(a.Q + ((size_t)b * a.N + row) * RK);
+#pragma unroll
+      for (int i = 0; i < RK / 4; ++i) {
+        const float4 q4 = qp[i];
+        Qr[4 * i] = q4.x; Qr[4 * i + 1] = q4.y; Qr[4 * i + 2] = q4.z; Qr[4 * i + 3] = q4.w;
+      }
+      dv = (a.d_mode == LO_DIAG_FULL) ? a.d[(size_t)b * a.N + row] : (a.d_mode == LO_DIAG_CONST ? a.d[b] : 0.f);
+      dinvv = (a.dinv_mode == LO_DIAG_FULL) ? a.dinv[(size_t)b * a.N + row] : a.dinv[b];
+      rhsv = a.rhs[(size_t)b * a.N + row];
+    } else {
+#pragma unroll
+      for (int i = 0; i < RC; ++i) crow[i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < RK; ++i) Qr[i] = 0.f;
+    }
+
+    // ---- initialisation (linear_cg.py:177-215) ----
+    float sc[2];
+    sc[0] = rhsv * rhsv;
+    wg_partial_scalars(sh, sc, 1);
+    group_exchange(sh, 1, gslot, wig, ++tag, a.err);
+    float nrm = sqrtf(sh.res[0]);                           // rhs.norm(2, dim=-2)          :177
+    const bool rhs_zero = nrm < a.eps;                      // :178
+    if (rhs_zero) nrm = 1.0f;                               // :179
+    float r = rhsv / nrm;                                   // :182 (x0 = 0 -> residual = rhs)
+    float x = 0.f;
+    sc[0] = r * r;
+    sc[1] = dinvv * r * r;
+    wg_partial<RK>(sh, Qr, r, sc, 2);
+    group_exchange(sh, RK + 2, gslot, wig, ++tag, a.err);
+    float rr = sh.res[RK];
+    bool conv = sqrtf(rr) < a.stop_after;                   // :204-205
+    if (wig == 0 && t == 0) a.init_conv[b] = conv ? 1 : 0;
+    float z = dinvv * r;                                    // precondition_closure :135-140
+    float uu = 0.f;
+#pragma unroll
+    for (int i = 0; i < RK; ++i) {
+      z = fmaf(-Qr[i], sh.res[i], z);
+      uu = fmaf(sh.res[i], sh.res[i], uu);
+    }
+    // r.z = sum r o (r/d - Q u) = sum r^2/d - ||Q^T r||^2 : both terms come out of the exchange above, which
+    // saves a group-wide reduction per iteration (same value up to rounding; residual_inner_prod :215 / :35-36)
+    float rz = sh.res[RK + 1] - uu;
+    float p = z, beta = 0.f, alpha = 0.f, rn = sqrtf(rr);
+
+    for (int k = 0; k < a.iters; ++k) {
+      if (k > 0) p = fmaf(p, beta, z);                      // p.mul_(beta).add_(z)  :46
+      sc[0] = dv * p * p;
+      wg_partial_lds<RC>(sh, crow, p, sc, 1);
+      group_exchange(sh, RC + 1, gslot, wig, ++tag, a.err);  // t = C^T p  and  sum d p^2
+      float y = dv * p;                                     // A p = C t + d o p     added_diag...py:72-76
+      float ct = 0.f, tt = 0.f;
+#pragma unroll
+      for (int i = 0; i < RC; i += 4) {
+        const float4 c4 = *reinterpret_cast<const float4*>(crow + i);
+        const float4 t4 = *reinterpret_cast<const float4*>(&sh.res[i]);
+        ct = fmaf(c4.x, t4.x, ct);
+        ct = fmaf(c4.y, t4.y, ct);
+        ct = fmaf(c4.z, t4.z, ct);
+        ct = fmaf(c4.w, t4.w, ct);
+        tt = fmaf(t4.x, t4.x, tt);
+        tt = fmaf(t4.y, t4.y, tt);
+        tt = fmaf(t4.z, t4.z, tt);
+        tt = fmaf(t4.w, t4.w, tt);
+      }
+      y += ct;
+      // p.Ap = p^T C C^T p + p^T D p = ||C^T p||^2 + sum d p^2   (:250-251; no extra group reduction)
+      const float pAp = tt + sh.res[RC];
+      alpha = (pAp < a.eps) ? 0.f : rz / pAp;               // :254-257
+      if (conv) alpha = 0.f;                                // :260
+      r = fmaf(-alpha, y, r);                               // :264
+      x = fmaf(alpha, p, x);                                // :31
+      sc[0] = r * r;
+      sc[1] = dinvv * r * r;
+      wg_partial<RK>(sh, Qr, r, sc, 2);
+      group_exchange(sh, RK + 2, gslot, wig, ++tag, a.err);  // Q^T r, ||r||^2, sum r^2/d
+      rr = sh.res[RK];
+      z = dinvv * r;
+      float uu2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < RK; ++i) {
+        z = fmaf(-Qr[i], sh.res[i], z);
+        uu2 = fmaf(sh.res[i], sh.res[i], uu2);
+      }
+      const float rzn = sh.res[RK + 1] - uu2;               // r.z    :35-36
+      beta = (rz < a.eps) ? 0.f : rzn / rz;                 // :39-42
+      rz = rzn;
+      rn = sqrtf(rr);                                       // :298
+      if (rhs_zero) rn = 0.f;                               // :299
+      conv = rn < a.stop_after;                             // :300
+      if (wig == 0 && t == 0) a.resid_rec[(size_t)k * a.B + b] = rn;
+    }
+
+    // ---- write the state back in the streaming engine's layout ----
+    if (valid) {
+      const size_t o = (size_t)b * a.N + row;
+      a.x[o] = x;
+      a.r[o] = r;
+      a.p[o] = p;
+      a.z[o] = z;
+    }
+    if (wig == 0 && t == 0) {
+      a.rhs_norm[b] = nrm;
+      a.rhs_is_zero[b] = rhs_zero ? 1 : 0;
+      a.rz[b] = rz;
+      a.alpha[b] = alpha;
+      a.beta[b] = beta;
+      a.resid_norm[b] = rn;
+      a.has_conv[b] = conv ? 1 : 0;
+    }
+  }
+}
+
+size_t onchip_gbuf_bytes(int ngroups) { return (size_t)ngroups * 2 * OC_GW * 40 * sizeof(unsigned long long); }
+
+bool onchip_eligible(int RC, int RK, int64_t N, int64_t c) {
+  const bool rc_ok = (RC == 8 || RC == 16 || RC == 32);
+  const bool rk_ok = (RK == 4 || RK == 8 || RK == 16);
+  return rc_ok && rk_ok && c == 1 && N <= (int64_t)OC_GW * OC_TPB && N >= 1024;
+}
+
+int onchip_num_workgroups() {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  int cus = prop.multiProcessorCount;
+  return (cus / 64) * 64;  // multiple of 8 XCDs x 8 workgroups per group
+}
+
+int onchip_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st) {
+  dim3 grid(nwg), block(OC_TPB);
+  LO_PROF_BEGIN("cg_onchip", st);
+#define LO_OC(C_, K_) hipLaunchKernelGGL((k_cg_onchip<C_, K_>), grid, block, 0, st, a)
+  if (RC == 32 && RK == 16) LO_OC(32, 16);
+  else if (RC == 32 && RK == 8) LO_OC(32, 8);
+  else if (RC == 32 && RK == 4) LO_OC(32, 4);
+  else if (RC == 16 && RK == 16) LO_OC(16, 16);
+  else if (RC == 16 && RK == 8) LO_OC(16, 8);
+  else if (RC == 16 && RK == 4) LO_OC(16, 4);
+  else if (RC == 8 && RK == 16) LO_OC(8, 16);
+  else if (RC == 8 && RK == 8) LO_OC(8, 8);
+  else if (RC == 8 && RK == 4) LO_OC(8, 4);
+  else return LO_ERR_UNSUPPORTED;
+#undef LO_OC
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+}  // namespace lo

@@ -133,4 +133,10 @@ int dense_rows_per_wg(int64_t B, int64_t N);
 int kron_matvec(const float* K1, const float* K2, const float* v, float* tmp, float* y, int64_t B, int n1, int n2,
                 int64_t c, const int* stop, hipStream_t st);
 
+// ---- operator-resident CG (lo_cg_onchip.hip) -----------------------------------------------------
+struct OnchipArgs;
+size_t onchip_gbuf_bytes(int ngroups);
+bool onchip_eligible(int RC, int RK, int64_t N, int64_t c);
+int onchip_num_workgroups();
+
 }  // namespace lo

@@ -363,3 +363,8 @@ def lanczos_tridiag(desc: Optional[OperatorDescriptor], init_vecs: torch.Tensor,
     if P == 1:  # squeeze_(0) (:159-161) only acts on a size-1 leading dim
         q_out, t_out = q_out[0], t_out[0]
     return q_out, t_out
+
+
+def set_onchip_cg(enable: bool):
+    """Allow (default) or forbid the operator-resident CG fast path (csrc/lo_cg_onchip.hip); test / A-B switch."""
+    _hip.load().lo_cg_set_onchip(1 if enable else 0)

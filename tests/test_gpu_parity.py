@@ -304,3 +304,41 @@ def test_lanczos_against_reference():
     assert tuple(q3.shape) == g["q_batch"].shape and tuple(t3.shape) == g["t_batch"].shape
     assert np.allclose(host(t3), g["t_batch"], rtol=1e-3, atol=1e-4)
     assert np.allclose(host(q3), g["q_batch"], atol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------- operator-resident CG
+@pytest.mark.parametrize("N,R", [(8192, 32), (4096, 16), (2048, 8), (5000, 32)])
+def test_onchip_cg_matches_streaming_engine_and_oracle(N, R):
+    """The operator-resident fast path (8 workgroups per member, C in LDS, Q in VGPRs, granule all-reduces) runs the
+    same arithmetic as the streaming engine: same iteration count, solutions equal to summation-order noise."""
+    B = 70  # more members than the 32 concurrent groups, not a multiple of it
+    C, d, rhs = cases.lowrank_diag(3100 + R, B, N, R, 1)
+    rhs[3] = 0.0  # one all-zero right-hand side
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    pre = _default_precond(desc, dev(d), False)
+    try:
+        K.set_onchip_cg(False)
+        ref = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+        K.set_onchip_cg(True)
+        _hip_prof = K._hip
+        _hip_prof.prof_enable(True)
+        res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+        torch.cuda.synchronize()
+        prof = _hip_prof.prof_report()
+        _hip_prof.prof_enable(False)
+    finally:
+        K.set_onchip_cg(True)
+    assert "cg_onchip" in prof, "fast path was not taken"
+    assert res.iterations == ref.iterations == 11 and res.tolerance_reached
+    assert np.all(host(res.x)[3] == 0)
+    keep = [i for i in range(B) if i != 3]
+    assert max_rel_err_cols(host(res.x)[keep], host(ref.x)[keep]) < 2e-5
+    sub = slice(0, 4)
+    pre_o = orc.Preconditioner(host(K.pivoted_cholesky(K.lowrank_diag_descriptor(dev(C[sub]), None), 15)[0]), d[sub])
+    xo, _, info = orc.linear_cg(lambda v: orc.matvec_lowrank_diag(C[sub], d[sub], v), rhs[sub], tolerance=1e-4,
+                                preconditioner=pre_o.apply)
+    assert info.iterations == res.iterations
+    assert max_rel_err_cols(host(res.x)[:3], xo[:3]) < 1e-4
+    # bitwise reproducible run to run (fixed summation order, no float atomics)
+    res2 = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+    assert torch.equal(res.x, res2.x)
