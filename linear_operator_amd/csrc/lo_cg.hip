@@ -15,6 +15,7 @@
 //   ctrl       beta (:34-42), residual norms (:298-300), stop rule (:302-308), tridiag (:311-332)
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "lo_device.h"
@@ -474,6 +475,9 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.rhs_norm = d.rhs_norm; a.rz = d.rz; a.alpha = d.alpha; a.beta = d.beta; a.resid_norm = d.resid_norm;
     a.rhs_is_zero = d.rhs_is_zero; a.has_conv = d.has_conv;
     a.resid_rec = d.oc_resid; a.init_conv = d.oc_init_conv; a.gbuf = d.oc_gbuf; a.err = d.oc_err;
+    a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
+    const bool oc_dbg = getenv("LO_OC_DEBUG") != nullptr && B >= 8;
+    a.dbg = oc_dbg ? reinterpret_cast<long long*>(d.oc_resid + (size_t)B * 12) : nullptr;
     LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(oc_nwg / 8), st));
     LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 0, sizeof(int), st));
     rc = onchip_launch(pl.R4, preR4, a, oc_nwg, st);
@@ -484,6 +488,12 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     LO_HIP_CHECK(hipMemcpyAsync(&oc_err, d.oc_err, sizeof(int), hipMemcpyDeviceToHost, st));
     LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
     LO_HIP_CHECK(hipStreamSynchronize(st));
+    if (oc_dbg) {
+      long long ts[5];
+      LO_HIP_CHECK(hipMemcpy(ts, a.dbg, sizeof(ts), hipMemcpyDeviceToHost));
+      fprintf(stderr, "onchip member0 (100 MHz ticks): load %lld init %lld iters %lld store %lld\n", ts[1] - ts[0],
+              ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3]);
+    }
     if (oc_err == 0) {
       k_start = a.iters;
     } else {  // a group hand-off timed out: redo everything with the streaming engine

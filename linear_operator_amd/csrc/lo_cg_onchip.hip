@@ -37,23 +37,49 @@ constexpr int OC_WAVES = OC_TPB / 64;
 constexpr unsigned OC_MAXSPIN = 1u << 22;
 
 
+// ---- wave64 reduce-scatter primitives -------------------------------------------------------------
+// One halving step over lane bit M: every lane holds `lo` (a component it keeps if its bit M is clear) and `hi`
+// (kept if the bit is set); returns own kept value + the partner lane's value of the same component.
+// gfx950 cross-lane hardware, no LDS crossbar (ds_bpermute) except for M == 4:
+//   M = 32 / 16 : v_permlane32_swap / v_permlane16_swap  (upper half-rows of `lo` swap with lower half-rows of `hi`;
+//                 afterwards lo' + hi' is exactly keep + partner's send in every lane)
+//   M = 8       : DPP row_ror:8     M = 2, 1 : DPP quad_perm     M = 4 : ds_swizzle SWAP,4
+template <int M>
+__device__ __forceinline__ float xor_lane(float v) {
+  if constexpr (M == 8) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+  else if constexpr (M == 4) return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101f));
+  else if constexpr (M == 2) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));
+  else return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false));
+}
+
+template <int M>
+__device__ __forceinline__ float halve_pair(float lo, float hi, int lane) {
+  if constexpr (M == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  } else if constexpr (M == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  } else {
+    const bool up = (lane & M) != 0;
+    const float keep = up ? hi : lo;
+    const float send = up ? lo : hi;
+    return keep + xor_lane<M>(send);
+  }
+}
+
 // Recursive-halving tail, fully compile-time indexed (runtime-indexed register arrays would go to scratch):
-// v holds CNT live values; step with lane mask M keeps the half selected by lane bit M and adds the partner's.
+// v holds CNT live values; the step over lane bit M keeps the half selected by that bit and adds the partner's.
 template <int CNT, int M, int NV>
 __device__ __forceinline__ void halving_steps(float (&v)[NV], int lane) {
   if constexpr (M >= 1) {
     if constexpr (CNT > 1) {
-      const bool hi = (lane & M) != 0;
       constexpr int half = CNT / 2;
 #pragma unroll
-      for (int j = 0; j < half; ++j) {
-        const float keep = hi ? v[j + half] : v[j];
-        const float send = hi ? v[j] : v[j + half];
-        v[j] = keep + __shfl_xor(send, M, 64);
-      }
+      for (int j = 0; j < half; ++j) v[j] = halve_pair<M>(v[j], v[j + half], lane);
       halving_steps<half, M / 2, NV>(v, lane);
     } else {
-      v[0] += __shfl_xor(v[0], M, 64);
+      v[0] = halve_pair<M>(v[0], v[0], lane) ;
       halving_steps<1, M / 2, NV>(v, lane);
     }
   }
@@ -68,19 +94,14 @@ __device__ __forceinline__ float wave_reduce_scatter_prod_lds(const float* __res
   const int lane = threadIdx.x & 63;
   constexpr int h0 = n / 2;
   float v[h0];
-  const bool hi = (lane & 32) != 0;
 #pragma unroll
   for (int j = 0; j < h0; j += 4) {
     const float4 lo4 = *reinterpret_cast<const float4*>(a + j);
     const float4 hi4 = *reinterpret_cast<const float4*>(a + j + h0);
-    const float lo_p[4] = {lo4.x * s, lo4.y * s, lo4.z * s, lo4.w * s};
-    const float hi_p[4] = {hi4.x * s, hi4.y * s, hi4.z * s, hi4.w * s};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float keep = hi ? hi_p[e] : lo_p[e];
-      const float send = hi ? lo_p[e] : hi_p[e];
-      v[j + e] = keep + __shfl_xor(send, 32, 64);
-    }
+    v[j + 0] = halve_pair<32>(lo4.x * s, hi4.x * s, lane);
+    v[j + 1] = halve_pair<32>(lo4.y * s, hi4.y * s, lane);
+    v[j + 2] = halve_pair<32>(lo4.z * s, hi4.z * s, lane);
+    v[j + 3] = halve_pair<32>(lo4.w * s, hi4.w * s, lane);
   }
   halving_steps<h0, 16, h0>(v, lane);
   return v[0];
@@ -92,14 +113,8 @@ __device__ __forceinline__ float wave_reduce_scatter_prod(const float (&a)[n], f
   const int lane = threadIdx.x & 63;
   constexpr int h0 = n / 2;
   float v[h0];
-  const bool hi = (lane & 32) != 0;
 #pragma unroll
-  for (int j = 0; j < h0; ++j) {
-    const float lo_p = a[j] * s, hi_p = a[j + h0] * s;
-    const float keep = hi ? hi_p : lo_p;
-    const float send = hi ? lo_p : hi_p;
-    v[j] = keep + __shfl_xor(send, 32, 64);
-  }
+  for (int j = 0; j < h0; ++j) v[j] = halve_pair<32>(a[j] * s, a[j + h0] * s, lane);
   halving_steps<h0, 16, h0>(v, lane);
   return v[0];
 }
@@ -115,13 +130,20 @@ struct OcShared {
 
 // Group-wide sum of `cnt` (<= 40) workgroup partials sitting in sh.part[0..cnt); result in sh.res[0..cnt),
 // identical in all workgroups of the group.  Must be called by all 1024 threads.
+// `same_xcd`: all 8 workgroups were VERIFIED (XCC_ID exchanged through the agent-scope path first) to run on one
+// XCD, i.e. behind one L2.  Then the granule may be published with a plain store (write-through L1 -> stays in
+// that L2) and is picked up by the pollers' L1-bypassing loads as an L2 hit instead of a fabric round trip.
+// Without the verification the agent-scope (sc1, write-through to the fabric) store is used: correct anywhere.
 __device__ __forceinline__ void group_exchange(OcShared& sh, int cnt, unsigned long long* gslot_base, int wig,
-                                               unsigned tag, int* err) {
+                                               unsigned tag, int* err, bool same_xcd = false) {
   const int t = threadIdx.x;
   unsigned long long* slot = gslot_base + (size_t)(tag & 1u) * OC_GW * 40;
   if (t < cnt) {
     const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(sh.part[t]);
-    __hip_atomic_store(slot + (size_t)wig * 40 + t, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (same_xcd)
+      __hip_atomic_store(slot + (size_t)wig * 40 + t, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+      __hip_atomic_store(slot + (size_t)wig * 40 + t, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (t < OC_GW * cnt) {
     const int w = t / cnt, i = t % cnt;
@@ -221,8 +243,44 @@ __global__ __launch_bounds__(OC_TPB) void k_cg_onchip(OnchipArgs a) {
   const int t = threadIdx.x;
   unsigned long long* gslot = a.gbuf + (size_t)grp * 2 * OC_GW * 40;
   unsigned tag = 0;
+  // placement check (speed only, never assumed): do the 8 workgroups of this group share an XCD / L2?
+  bool same_xcd = false;
+  {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
+    if (t == 0) sh.part[0] = (float)xcc;
+    __syncthreads();
+    // each workgroup publishes its id; gather WITHOUT summing: compare the 8 raw values
+    const unsigned tg = ++tag;
+    unsigned long long* slot = gslot + (size_t)(tg & 1u) * OC_GW * 40;
+    if (t == 0) {
+      const unsigned long long g = ((unsigned long long)tg << 32) | (unsigned long long)xcc;
+      __hip_atomic_store(slot + (size_t)wig * 40, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t < OC_GW) {
+      unsigned long long g = 0;
+      unsigned spin = 0;
+      for (;;) {
+        g = __hip_atomic_load(slot + (size_t)t * 40, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(g >> 32) == tg) break;
+        if (++spin > OC_MAXSPIN) {
+          atomicExch(a.err, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      sh.gath[t][0] = (float)(unsigned)(g & 0xffffffffull);
+    }
+    __syncthreads();
+    bool same = true;
+#pragma unroll
+    for (int w = 1; w < OC_GW; ++w) same = same && (sh.gath[w][0] == sh.gath[0][0]);
+    same_xcd = same && (a.allow_l2_handoff != 0);
+    __syncthreads();
+  }
 
   for (int64_t b = grp; b < a.B; b += ngroups) {
+    const bool stamp = a.dbg && b == 0 && wig == 0 && t == 0;
+    if (stamp) a.dbg[0] = wall_clock64();
     const int row = wig * a.RW + t;
     const bool valid = (t < a.RW) && (row < a.N);
     float Qr[RK];
@@ -248,11 +306,13 @@ __global__ __launch_bounds__(OC_TPB) void k_cg_onchip(OnchipArgs a) {
       for (int i = 0; i < RK; ++i) Qr[i] = 0.f;
     }
 
+    __syncthreads();
+    if (stamp) a.dbg[1] = wall_clock64();
     // ---- initialisation (linear_cg.py:177-215) ----
     float sc[2];
     sc[0] = rhsv * rhsv;
     wg_partial_scalars(sh, sc, 1);
-    group_exchange(sh, 1, gslot, wig, ++tag, a.err);
+    group_exchange(sh, 1, gslot, wig, ++tag, a.err, same_xcd);
     float nrm = sqrtf(sh.res[0]);                           // rhs.norm(2, dim=-2)          :177
     const bool rhs_zero = nrm < a.eps;                      // :178
     if (rhs_zero) nrm = 1.0f;                               // :179
@@ -261,7 +321,7 @@ __global__ __launch_bounds__(OC_TPB) void k_cg_onchip(OnchipArgs a) {
     sc[0] = r * r;
     sc[1] = dinvv * r * r;
     wg_partial<RK>(sh, Qr, r, sc, 2);
-    group_exchange(sh, RK + 2, gslot, wig, ++tag, a.err);
+    group_exchange(sh, RK + 2, gslot, wig, ++tag, a.err, same_xcd);
     float rr = sh.res[RK];
     bool conv = sqrtf(rr) < a.stop_after;                   // :204-205
     if (wig == 0 && t == 0) a.init_conv[b] = conv ? 1 : 0;
@@ -277,11 +337,12 @@ __global__ __launch_bounds__(OC_TPB) void k_cg_onchip(OnchipArgs a) {
     float rz = sh.res[RK + 1] - uu;
     float p = z, beta = 0.f, alpha = 0.f, rn = sqrtf(rr);
 
+    if (stamp) a.dbg[2] = wall_clock64();
     for (int k = 0; k < a.iters; ++k) {
       if (k > 0) p = fmaf(p, beta, z);                      // p.mul_(beta).add_(z)  :46
       sc[0] = dv * p * p;
       wg_partial_lds<RC>(sh, crow, p, sc, 1);
-      group_exchange(sh, RC + 1, gslot, wig, ++tag, a.err);  // t = C^T p  and  sum d p^2
+      group_exchange(sh, RC + 1, gslot, wig, ++tag, a.err, same_xcd);  // t = C^T p  and  sum d p^2
       float y = dv * p;                                     // A p = C t + d o p     added_diag...py:72-76
       float ct = 0.f, tt = 0.f;
 #pragma unroll
@@ -307,7 +368,7 @@ __global__ __launch_bounds__(OC_TPB) void k_cg_onchip(OnchipArgs a) {
       sc[0] = r * r;
       sc[1] = dinvv * r * r;
       wg_partial<RK>(sh, Qr, r, sc, 2);
-      group_exchange(sh, RK + 2, gslot, wig, ++tag, a.err);  // Q^T r, ||r||^2, sum r^2/d
+      group_exchange(sh, RK + 2, gslot, wig, ++tag, a.err, same_xcd);  // Q^T r, ||r||^2, sum r^2/d
       rr = sh.res[RK];
       z = dinvv * r;
       float uu2 = 0.f;
@@ -325,6 +386,7 @@ __global__ __launch_bounds__(OC_TPB) void k_cg_onchip(OnchipArgs a) {
       if (wig == 0 && t == 0) a.resid_rec[(size_t)k * a.B + b] = rn;
     }
 
+    if (stamp) a.dbg[3] = wall_clock64();
     // ---- write the state back in the streaming engine's layout ----
     if (valid) {
       const size_t o = (size_t)b * a.N + row;
@@ -342,6 +404,7 @@ __global__ __launch_bounds__(OC_TPB) void k_cg_onchip(OnchipArgs a) {
       a.resid_norm[b] = rn;
       a.has_conv[b] = conv ? 1 : 0;
     }
+    if (stamp) a.dbg[4] = wall_clock64();
   }
 }
 
