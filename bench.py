@@ -36,6 +36,7 @@ from linear_operator_amd import kernels as K  # noqa: E402
 
 B_PER_GPU, N, R, C_COLS, RANK_K = 512, 8192, 32, 1, 15
 TOL = 1e-4
+ITERS_FLOOR = 11  # linear_cg.py:303 -- the iterations the operator-resident kernel runs in one launch
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 
@@ -62,6 +63,10 @@ def algorithmic_bytes(name, k_eff):
     if name.startswith("skinny_nn_R"):
         r = R if name.endswith("R32") else k_eff
         return 4 * B * (N * r + N + 2 * N * c)  # stream A once + diagonal + vector in + vector out
+    if name == "cg_onchip":
+        # operator-resident CG: ONE launch runs all guaranteed iterations.  Algorithmic bytes per member and
+        # iteration as SURVEY 8(d): matvec 4(NR+N+2Nc) + CG state 4*8*N*c + rank-k preconditioner 4(N*k+2N*c)
+        return B * ITERS_FLOOR * (4 * (N * R + N + 2 * N * c) + 32 * N * c + 4 * (N * k_eff + 2 * N * c))
     if name == "cg_update_xr":
         return 4 * B * N * c * 6  # r, Ap, x, p read; r, x written
     if name == "cg_update_p":
@@ -187,10 +192,24 @@ def main():
         achieved = alg / avg_s / 1e9
         tn, nn = prof.get("skinny_tn_R32"), prof.get("skinny_nn_R32")
         mv_alg = 4 * B_PER_GPU * (N * R + N + 2 * N * C_COLS)  # 1,146,880 B per member
-        mv_s = (tn[1] / tn[0] + nn[1] / nn[0]) * 1e-3
+        if tn and nn:
+            mv_s = (tn[1] / tn[0] + nn[1] / nn[0]) * 1e-3
+            mv_note = "C^T p + C t + d o p kernel pair = one batched CG matvec (north_star 60% target)"
+        else:
+            # fused kernel: the matvec cannot be timed on its own; charge it the WHOLE iteration (upper bound)
+            mv_s = avg_s / ITERS_FLOOR
+            mv_note = ("operator-resident kernel: time of one full CG iteration (matvec + preconditioner + updates) "
+                       "charged to the matvec; north_star target is <= 122 us for the matvec alone")
         kernels = {k: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2),
                        "alg_GBs": round(algorithmic_bytes(k, RANK_K) / (v[1] / v[0] * 1e-3) / 1e9, 1)}
                    for k, v in sorted(prof.items())}
+        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (run separately; see profiles/*/README.md)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_onchip", "traffic.json")))
+            if dom == "cg_onchip" and tj["kernel"].startswith("k_cg_onchip"):
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            pass
         out = {
             "metric": "cg_member_matvecs_per_sec",
             "value": value,
@@ -213,11 +232,14 @@ def main():
                 "sharding": f"batch x{world}, all_gather of solutions per step" if world > 1 else "single GPU",
             },
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6, "launches_timed": cnt},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6, "launches_timed": cnt,
+                         "note": ("frac > 1 is possible for cg_onchip: the algorithmic figure charges C and Q once per "
+                                  "iteration, the kernel keeps them in LDS/VGPRs and reads them from HBM once per solve")
+                         if dom == "cg_onchip" else ""},
             "matvec_roofline": {"algorithmic_bytes": mv_alg, "avg_us": mv_s * 1e6,
                                 "achieved_GBs": mv_alg / mv_s / 1e9, "frac_of_8TBs": mv_alg / mv_s / 1e9 / HBM_PEAK_GBS,
-                                "note": "C^T p + C t + d o p pair = one batched CG matvec (north_star 60% target)"},
+                                "note": mv_note},
             "solves_per_sec_end_to_end": total_members / e2e,
             "end_to_end_ms": e2e * 1e3,
             "kernels": kernels,
