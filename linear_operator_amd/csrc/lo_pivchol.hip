@@ -45,6 +45,8 @@ struct PcDev {
   float* part_b;     // [B,S]
   float* orig;       // [B]
   float* errors;     // [B]
+  float* arg_v;      // [B,S] per-slice argmax partial (value)
+  int* arg_j;        // [B,S]                          (position)
   PcCtrl* ctrl;
 };
 
@@ -69,18 +71,100 @@ __device__ __forceinline__ float src_diag(const PcDev& d, int64_t b, int i) {
   }
 }
 
+// Stage the C rows of `np` positions (rows i = perm[j0 + t], or i = j0 + t when perm == nullptr) into LDS with row
+// stride R + 1 (conflict-free when every thread then walks its own row), coalesced: consecutive lanes read
+// consecutive floats (float4 when R % 4 == 0) of consecutive rows.
+__device__ __forceinline__ void stage_rows(const float* __restrict__ Cb, int R, const long long* __restrict__ perm,
+                                           int j0, int np, float* __restrict__ tile) {
+  const int ld = R + 1;
+  if ((R & 3) == 0) {
+    const int RQ = R >> 2;
+    for (int e = threadIdx.x; e < np * RQ; e += kThreads) {
+      const int pos = e / RQ, q = e % RQ;
+      const int i = perm ? (int)perm[j0 + pos] : j0 + pos;
+      const float4 v = *reinterpret_cast<const float4*>(Cb + (size_t)i * R + 4 * q);
+      float* t = tile + pos * ld + 4 * q;
+      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+  } else {
+    for (int e = threadIdx.x; e < np * R; e += kThreads) {
+      const int pos = e / R, r = e % R;
+      const int i = perm ? (int)perm[j0 + pos] : j0 + pos;
+      tile[pos * ld + r] = Cb[(size_t)i * R + r];
+    }
+  }
+}
+
+__device__ __forceinline__ int tile_positions(int R) {
+  // LDS budget ~48 KiB for the tile: 256 positions for R <= 47, fewer for fat roots
+  const int tp = 12288 / (R + 1);
+  return tp >= kThreads ? kThreads : (tp < 1 ? 1 : tp);
+}
+
+// per-slice argmax partial: best (value, position) with the FIRST maximal position winning
+__device__ __forceinline__ void slice_argmax(float bv, int bj, float* vbest, int* jbest, float* out_v, int* out_j) {
+  vbest[threadIdx.x] = bv;
+  jbest[threadIdx.x] = bj;
+  __syncthreads();
+  for (int h = kThreads / 2; h >= 1; h >>= 1) {
+    if (threadIdx.x < h) {
+      const float ov = vbest[threadIdx.x + h];
+      const int oj = jbest[threadIdx.x + h];
+      const float mv = vbest[threadIdx.x];
+      const int mj = jbest[threadIdx.x];
+      if (oj != 0x7fffffff && (mj == 0x7fffffff || ov > mv || (ov == mv && oj < mj))) {
+        vbest[threadIdx.x] = ov;
+        jbest[threadIdx.x] = oj;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *out_v = vbest[0];
+    *out_j = jbest[0];
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_pc_init(PcDev d) {
+  extern __shared__ float sh[];
   __shared__ float red[kThreads];
+  __shared__ float vbest[kThreads];
+  __shared__ int jbest[kThreads];
   const int s = blockIdx.x;
   const int64_t b = blockIdx.y;
-  const int j0 = s * d.rows, j1 = min((int)d.N, j0 + d.rows);
+  const int N = (int)d.N;
+  const int j0 = s * d.rows, j1 = min(N, j0 + d.rows);
+  const bool lowrank = d.op.kind == LO_OP_LOWRANK_DIAG;
+  const int R = lowrank ? (int)d.op.R : 0;
+  const int tp = lowrank ? tile_positions(R) : kThreads;
   float lmax = -INFINITY, lsum = 0.f;
-  for (int i = j0 + threadIdx.x; i < j1; i += kThreads) {
-    const float v = src_diag(d, b, i);
-    d.diag[(size_t)b * d.N + i] = v;
-    d.perm[(size_t)b * d.N + i] = i;
-    lmax = fmaxf(lmax, v);
-    lsum += fabsf(v);
+  float bv = -INFINITY;
+  int bj = 0x7fffffff;
+  for (int t0 = j0; t0 < j1; t0 += tp) {
+    const int np = min(tp, j1 - t0);
+    if (lowrank) {
+      __syncthreads();
+      stage_rows(d.op.A0 + (size_t)b * N * R, R, nullptr, t0, np, sh);
+      __syncthreads();
+    }
+    const int i = t0 + threadIdx.x;
+    if ((int)threadIdx.x < np) {
+      float v;
+      if (lowrank) {
+        const float* row = sh + threadIdx.x * (R + 1);
+        v = seq_dot(row, row, R);                      // (root ** 2).sum(-1), root_linear_operator.py:22-28
+      } else {
+        v = src_diag(d, b, i);
+      }
+      d.diag[(size_t)b * N + i] = v;
+      d.perm[(size_t)b * N + i] = i;
+      lmax = fmaxf(lmax, v);
+      lsum += fabsf(v);
+      if (v > bv || bj == 0x7fffffff) {  // positions increase with the loop: ties keep the earlier one
+        bv = v;
+        bj = i;
+      }
+    }
   }
   const float m = block_max256(lmax, red);
   const float t = block_sum256(lsum, red);
@@ -88,6 +172,7 @@ __global__ __launch_bounds__(kThreads) void k_pc_init(PcDev d) {
     d.part_a[b * d.S + s] = m;
     d.part_b[b * d.S + s] = t;
   }
+  slice_argmax(bv, bj, vbest, jbest, &d.arg_v[b * d.S + s], &d.arg_j[b * d.S + s]);
 }
 
 __global__ __launch_bounds__(kThreads) void k_pc_ctrl0(PcDev d) {
@@ -102,12 +187,15 @@ __global__ __launch_bounds__(kThreads) void k_pc_ctrl0(PcDev d) {
   }
 }
 
-// decides whether pivot m is taken (loop condition :57) from the errors of pivot m-1
+// Decides whether pivot m is taken (loop condition :57) from the errors of pivot m-1, then finishes the argmax over
+// the not-yet-pivoted positions from the per-slice partials (FIRST maximal position wins: torch.max on CPU, :61-63),
+// swaps the permutation entries (:67-70) and sets L[m, pi_m] = sqrt(max) (:73-74).
 __global__ __launch_bounds__(kThreads) void k_pc_ctrl(PcDev d, int m) {
   if (d.ctrl->stop) return;
   __shared__ float red[kThreads];
-  float lmax = -INFINITY, lnan = 0.f;
+  const int N = (int)d.N;
   if (m > 0) {
+    float lmax = -INFINITY, lnan = 0.f;
     for (int64_t b = threadIdx.x; b < d.B; b += kThreads) {
       float t = 0.f;
       for (int s = 0; s < d.S; ++s) t += d.part_b[b * d.S + s];
@@ -126,61 +214,36 @@ __global__ __launch_bounds__(kThreads) void k_pc_ctrl(PcDev d, int m) {
     }
   }
   if (threadIdx.x == 0) d.ctrl->m = m + 1;
-}
-
-// argmax over the not-yet-pivoted positions, FIRST maximal position wins (torch.max on CPU, :61-63);
-// swap permutation entries (:67-70); L[m, pi_m] = sqrt(max) (:73-74)
-__global__ __launch_bounds__(kThreads) void k_pc_argmax(PcDev d, int m) {
-  if (d.ctrl->stop) return;
-  __shared__ float vbest[kThreads];
-  __shared__ int jbest[kThreads];
-  const int64_t b = blockIdx.x;
-  const int N = (int)d.N;
-  long long* perm = d.perm + (size_t)b * N;
-  const float* diag = d.diag + (size_t)b * N;
-  float bv = -INFINITY;
-  int bj = 0x7fffffff;
-  for (int j = m + threadIdx.x; j < N; j += kThreads) {
-    const float v = diag[perm[j]];
-    if (v > bv || (v == bv && j < bj) || bj == 0x7fffffff) {
-      bv = v;
-      bj = j;
-    }
-  }
-  vbest[threadIdx.x] = bv;
-  jbest[threadIdx.x] = bj;
-  __syncthreads();
-  for (int h = kThreads / 2; h >= 1; h >>= 1) {
-    if (threadIdx.x < h) {
-      const float ov = vbest[threadIdx.x + h];
-      const int oj = jbest[threadIdx.x + h];
-      const float mv = vbest[threadIdx.x];
-      const int mj = jbest[threadIdx.x];
-      if (oj != 0x7fffffff && (mj == 0x7fffffff || ov > mv || (ov == mv && oj < mj))) {
-        vbest[threadIdx.x] = ov;
-        jbest[threadIdx.x] = oj;
+  for (int64_t b = threadIdx.x; b < d.B; b += kThreads) {
+    float bv = -INFINITY;
+    int bj = 0x7fffffff;
+    for (int s = 0; s < d.S; ++s) {
+      const float v = d.arg_v[b * d.S + s];
+      const int j = d.arg_j[b * d.S + s];
+      if (j != 0x7fffffff && (bj == 0x7fffffff || v > bv || (v == bv && j < bj))) {
+        bv = v;
+        bj = j;
       }
     }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const int j = jbest[0];
-    const float v = vbest[0];
+    long long* perm = d.perm + (size_t)b * N;
     const long long old = perm[m];
-    const long long piv = perm[j];
+    const long long piv = perm[bj];
     perm[m] = piv;
-    perm[j] = old;
+    perm[bj] = old;
     d.pim[b] = piv;
-    d.maxval[b] = v;
-    d.L[((size_t)b * d.max_rank + m) * N + piv] = sqrtf(v);
+    d.maxval[b] = bv;
+    d.L[((size_t)b * d.max_rank + m) * N + piv] = sqrtf(bv);
   }
 }
 
-// Schur update of row m (:77-99) over the positions j > m of this workgroup's slice
+// Schur update of row m (:77-99) over the positions j > m of this workgroup's slice, plus the slice's argmax
+// partial for pivot m + 1.
 __global__ __launch_bounds__(kThreads) void k_pc_update(PcDev d, int m) {
   if (d.ctrl->stop) return;
-  extern __shared__ float sh[];  // [m] L[j][pi_m] | [R] C[pi_m,:]
+  extern __shared__ float sh[];  // [max_rank] L[j][pi_m] | [R] C[pi_m,:] | row tile
   __shared__ float red[kThreads];
+  __shared__ float vbest[kThreads];
+  __shared__ int jbest[kThreads];
   const int s = blockIdx.x;
   const int64_t b = blockIdx.y;
   const int N = (int)d.N;
@@ -190,40 +253,59 @@ __global__ __launch_bounds__(kThreads) void k_pc_update(PcDev d, int m) {
   float* Lb = d.L + (size_t)b * d.max_rank * N;
   const int pim = (int)d.pim[b];
   const float piv = sqrtf(d.maxval[b]);
+  const bool lowrank = op.kind == LO_OP_LOWRANK_DIAG;
+  const int R = lowrank ? (int)op.R : 0;
   float* upd = sh;
-  float* crow = sh + m;
+  float* crow = sh + d.max_rank;
+  float* tile = crow + R;
   for (int j = threadIdx.x; j < m; j += kThreads) upd[j] = Lb[(size_t)j * N + pim];
-  const int R = (op.kind == LO_OP_LOWRANK_DIAG) ? (int)op.R : 0;
   for (int r = threadIdx.x; r < R; r += kThreads) crow[r] = op.A0[((size_t)b * N + pim) * R + r];
   __syncthreads();
   const int j0 = max(s * d.rows, m + 1), j1 = min(N, (s + 1) * d.rows);
+  const int tp = lowrank ? tile_positions(R) : kThreads;
   float lerr = 0.f;
+  float bv = -INFINITY;
+  int bj = 0x7fffffff;
   const int n1 = (int)op.R, n2 = (int)op.n2;
-  for (int j = j0 + threadIdx.x; j < j1; j += kThreads) {
-    const int i = (int)perm[j];
-    float rowv;
-    if (op.kind == LO_OP_LOWRANK_DIAG) {
-      rowv = seq_dot(crow, op.A0 + ((size_t)b * N + i) * R, R);
-    } else if (op.kind == LO_OP_DENSE_DIAG) {
-      rowv = op.A0[((size_t)b * N + pim) * N + i];
-    } else {
-      const int p1 = pim / n2, p2 = pim % n2, i1 = i / n2, i2 = i % n2;
-      rowv = op.A0[((size_t)b * n1 + p1) * n1 + i1] * op.A1[((size_t)b * n2 + p2) * n2 + i2];
+  for (int t0 = j0; t0 < j1; t0 += tp) {
+    const int np = min(tp, j1 - t0);
+    if (lowrank) {
+      __syncthreads();
+      stage_rows(op.A0 + (size_t)b * N * R, R, perm, t0, np, tile);
+      __syncthreads();
     }
-    float v = rowv;
-    if (m > 0) {
-      float acc = upd[0] * Lb[i];
-      for (int jj = 1; jj < m; ++jj) acc = acc + upd[jj] * Lb[(size_t)jj * N + i];  // :83-89
-      v = rowv - acc;
+    if ((int)threadIdx.x < np) {
+      const int j = t0 + threadIdx.x;
+      const int i = (int)perm[j];
+      float rowv;
+      if (lowrank) {
+        rowv = seq_dot(crow, tile + threadIdx.x * (R + 1), R);
+      } else if (op.kind == LO_OP_DENSE_DIAG) {
+        rowv = op.A0[((size_t)b * N + pim) * N + i];
+      } else {
+        const int p1 = pim / n2, p2 = pim % n2, i1 = i / n2, i2 = i % n2;
+        rowv = op.A0[((size_t)b * n1 + p1) * n1 + i1] * op.A1[((size_t)b * n2 + p2) * n2 + i2];
+      }
+      float v = rowv;
+      if (m > 0) {
+        float acc = upd[0] * Lb[i];
+        for (int jj = 1; jj < m; ++jj) acc = acc + upd[jj] * Lb[(size_t)jj * N + i];  // :83-89
+        v = rowv - acc;
+      }
+      v = v / piv;                                   // :91
+      Lb[(size_t)m * N + i] = v;                     // :92
+      const float dn = diag[i] - v * v;              // :94-95
+      diag[i] = dn;
+      lerr += fabsf(dn);
+      if (dn > bv || bj == 0x7fffffff) {
+        bv = dn;
+        bj = j;
+      }
     }
-    v = v / piv;                                   // :91
-    Lb[(size_t)m * N + i] = v;                               // :92
-    const float dn = diag[i] - v * v;    // :94-95
-    diag[i] = dn;
-    lerr += fabsf(dn);
   }
   const float t = block_sum256(lerr, red);
   if (threadIdx.x == 0) d.part_b[b * d.S + s] = t;
+  slice_argmax(bv, bj, vbest, jbest, &d.arg_v[b * d.S + s], &d.arg_j[b * d.S + s]);
 }
 
 static void pc_layout(const lo_op_desc* op, int max_rank, Arena& ar, PcDev* d) {
@@ -239,6 +321,8 @@ static void pc_layout(const lo_op_desc* op, int max_rank, Arena& ar, PcDev* d) {
   d->part_b = ar.take<float>((size_t)B * sp.S);
   d->orig = ar.take<float>(B);
   d->errors = ar.take<float>(B);
+  d->arg_v = ar.take<float>((size_t)B * sp.S);
+  d->arg_j = ar.take<int>((size_t)B * sp.S);
 }
 
 }  // namespace lo
@@ -274,18 +358,26 @@ int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_
   LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, sizeof(PcCtrl), st));
   LO_HIP_CHECK(hipMemsetAsync(L_rows, 0, sizeof(float) * (size_t)B * max_rank * N, st));  // L = zeros :36-42
   dim3 grid(d.S, (unsigned)B), block(kThreads);
-  hipLaunchKernelGGL(k_pc_init, grid, block, 0, st, d);
+  const size_t R = (op->kind == LO_OP_LOWRANK_DIAG) ? (size_t)op->R : 0;
+  size_t tile_floats = 0;
+  if (R) {
+    size_t tp = 12288 / (R + 1);
+    tp = tp >= (size_t)kThreads ? (size_t)kThreads : (tp < 1 ? 1 : tp);
+    tile_floats = tp * (R + 1);
+  }
+  if ((tile_floats + R + max_rank) * sizeof(float) > 60000) return LO_ERR_UNSUPPORTED;
+  LO_PROF_BEGIN("pc_init", st);
+  hipLaunchKernelGGL(k_pc_init, grid, block, tile_floats * sizeof(float), st, d);
+  LO_PROF_END(st);
   hipLaunchKernelGGL(k_pc_ctrl0, dim3(1), block, 0, st, d);
   LO_LAUNCH_CHECK();
-  const size_t R = (op->kind == LO_OP_LOWRANK_DIAG) ? (size_t)op->R : 0;
   for (int m = 0; m < rank; ++m) {
+    LO_PROF_BEGIN("pc_ctrl_argmax", st);
     hipLaunchKernelGGL(k_pc_ctrl, dim3(1), block, 0, st, d, m);
-    LO_PROF_BEGIN("pc_argmax", st);
-    hipLaunchKernelGGL(k_pc_argmax, dim3((unsigned)B), block, 0, st, d, m);
     LO_PROF_END(st);
     if (m + 1 < N) {  // :77
       LO_PROF_BEGIN("pc_update", st);
-      hipLaunchKernelGGL(k_pc_update, grid, block, (m + R) * sizeof(float), st, d, m);
+      hipLaunchKernelGGL(k_pc_update, grid, block, (max_rank + R + tile_floats) * sizeof(float), st, d, m);
       LO_PROF_END(st);
     }
     LO_LAUNCH_CHECK();

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(kThreads) void k_pb_gram(const float* __restrict__ 
                                                        int diag_mode, int N, int k, int rows_per,
                                                        double* __restrict__ gpart, double* __restrict__ logd_part) {
   __shared__ float w_s[kPbRows][kPbMaxK + 1];
+  __shared__ float sc_s[kPbRows];
   __shared__ double redd[4];
   const int s = blockIdx.x, S = gridDim.x;
   const int64_t b = blockIdx.y;
@@ -34,15 +35,19 @@ __global__ __launch_bounds__(kThreads) void k_pb_gram(const float* __restrict__ 
   for (int base = r0; base < r1; base += kPbRows) {
     const int nr = min(kPbRows, r1 - base);
     __syncthreads();
+    if ((int)threadIdx.x < nr) {  // one fp64 rsqrt / log per ROW, not per element
+      double sc = 1.0;
+      if (diag_mode == LO_DIAG_FULL) {
+        const double dv = (double)dd[(size_t)b * N + base + threadIdx.x];
+        sc = 1.0 / sqrt(dv);
+        lacc += log(dv);
+      }
+      sc_s[threadIdx.x] = (float)sc;
+    }
+    __syncthreads();
     for (int e = threadIdx.x; e < nr * k; e += kThreads) {
       const int rr = e / k, a = e % k;
-      const int row = base + rr;
-      float wv = L[((size_t)b * N + row) * k + a];
-      if (diag_mode == LO_DIAG_FULL) wv = (float)((double)wv / sqrt((double)dd[(size_t)b * N + row]));
-      w_s[rr][a] = wv;
-    }
-    if (diag_mode == LO_DIAG_FULL) {
-      for (int rr = threadIdx.x; rr < nr; rr += kThreads) lacc += log((double)dd[(size_t)b * N + base + rr]);
+      w_s[rr][a] = L[((size_t)b * N + base + rr) * k + a] * sc_s[rr];
     }
     __syncthreads();
 #pragma unroll
@@ -127,6 +132,7 @@ __global__ __launch_bounds__(64) void k_pb_chol(const double* __restrict__ gpart
 }
 
 // Q[row, j] = scale_row * sum_{a<=j} M[j][a] w[a]
+template <int KM>
 __global__ __launch_bounds__(kThreads) void k_pb_q(const float* __restrict__ L, const float* __restrict__ dd,
                                                     int diag_mode, int N, int k, int ldq, int rows_per,
                                                     const double* __restrict__ Minv, float* __restrict__ Q,
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(kThreads) void k_pb_q(const float* __restrict__ L, 
   const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
   const double inv_sqrt_sigma = (diag_mode == LO_DIAG_CONST) ? 1.0 / sqrt((double)dd[b]) : 1.0;
   for (int row = r0 + threadIdx.x; row < r1; row += kThreads) {
-    double w[kPbMaxK];
+    double w[KM];
     double sc = inv_sqrt_sigma;
     if (diag_mode == LO_DIAG_FULL) {
       const double dv = (double)dd[(size_t)b * N + row];
@@ -148,14 +154,14 @@ __global__ __launch_bounds__(kThreads) void k_pb_q(const float* __restrict__ L, 
     }
     const float* lr = L + ((size_t)b * N + row) * k;
 #pragma unroll
-    for (int a = 0; a < kPbMaxK; ++a) w[a] = (a < k) ? (double)lr[a] * ((diag_mode == LO_DIAG_FULL) ? sc : 1.0) : 0.0;
+    for (int a = 0; a < KM; ++a) w[a] = (a < k) ? (double)lr[a] * ((diag_mode == LO_DIAG_FULL) ? sc : 1.0) : 0.0;
     float* qr = Q + ((size_t)b * N + row) * ldq;
 #pragma unroll
-    for (int j = 0; j < kPbMaxK; ++j) {
+    for (int j = 0; j < KM; ++j) {
       if (j < k) {
         double t = 0.0;
 #pragma unroll
-        for (int a = 0; a < kPbMaxK; ++a)
+        for (int a = 0; a < KM; ++a)
           if (a <= j && a < k) t = fma(M[j][a], w[a], t);
         qr[j] = (float)(t * sc);
       }
@@ -200,10 +206,17 @@ int lo_precond_build_f32(const float* L, const float* d, int32_t diag_mode, int6
   if (!ar.ok) return LO_ERR_WORKSPACE;
   const int ldq = padded_k(k);
   dim3 grid(sp.S, (unsigned)B), block(kThreads);
+  LO_PROF_BEGIN("pb_gram", st);
   hipLaunchKernelGGL(k_pb_gram, grid, block, 0, st, L, d, diag_mode, (int)N, (int)k, sp.rows, gpart, logd);
+  LO_PROF_END(st);
   hipLaunchKernelGGL(k_pb_chol, dim3((unsigned)B), dim3(64), 0, st, gpart, logd, d, diag_mode, (int)N, (int)k, sp.S,
                      Minv, logdet_p, dinv);
-  hipLaunchKernelGGL(k_pb_q, grid, block, 0, st, L, d, diag_mode, (int)N, (int)k, ldq, sp.rows, Minv, Q, dinv);
+  LO_PROF_BEGIN("pb_q", st);
+  if (k <= 16)
+    hipLaunchKernelGGL((k_pb_q<16>), grid, block, 0, st, L, d, diag_mode, (int)N, (int)k, ldq, sp.rows, Minv, Q, dinv);
+  else
+    hipLaunchKernelGGL((k_pb_q<32>), grid, block, 0, st, L, d, diag_mode, (int)N, (int)k, ldq, sp.rows, Minv, Q, dinv);
+  LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
 }
