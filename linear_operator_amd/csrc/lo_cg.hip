@@ -41,6 +41,7 @@ struct CgDev {
   int *rhs_is_zero, *has_conv;
   float* t_mat;
   CgCtrl* ctrl;
+  float* ctrl_part;  // [3, kCtrlMaxG] per-workgroup partials of the control step
   unsigned long long* oc_gbuf;
   int* oc_err;
   float* oc_resid;
@@ -173,12 +174,25 @@ __global__ __launch_bounds__(kThreads) void k_cg_update_xr(CgDev d, int rows_per
   if (threadIdx.x < c) d.rr_part[((size_t)b * S + s) * c + col] = tot;
 }
 
-__global__ __launch_bounds__(kThreads) void k_cg_ctrl(CgDev d, int k) {
+// Control step of iteration k, split in two so that it scales with B * c:
+//  k_cg_scal (many workgroups): per (member, column) scalars -- beta (:34-42), residual norm (:298-299),
+//    has_converged (:300) -- the tridiagonal recurrence (:311-332) of that column, and per-workgroup partials of the
+//    residual-norm sum / NaN flag / max off-diagonal.
+//  k_cg_ctrl (one workgroup): reduces the partials in fixed order and takes the batch-global decisions: stop rule
+//    (:302-308), tridiag freeze (:326-327), last_tridiag_iter (:329).
+// The recurrence entries of iteration k are written before the stop decision is known; the reference breaks BEFORE
+// its tridiag update (:307-308), but a stop can only happen at k >= n_tridiag_iter (or the last iteration), where no
+// entry inside the returned [: last_tridiag_iter + 1]^2 block is touched.
+constexpr int kCtrlMaxG = 256;
+
+__global__ __launch_bounds__(kThreads) void k_cg_scal(CgDev d, int k) {
   if (d.ctrl->stop) return;
   __shared__ float red[kThreads];
   const int64_t n = d.B * d.c;
-  float lsum = 0.f, lnan = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += kThreads) {
+  const bool tri = d.n_tridiag && k < d.n_tridiag_iter && !d.ctrl->tri_disabled;
+  const int T = d.T;
+  float lsum = 0.f, lnan = 0.f, lmax = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
     const int64_t b = i / d.c;
     const int col = (int)(i % d.c);
     float rr = 0.f, rzn = 0.f;
@@ -194,13 +208,50 @@ __global__ __launch_bounds__(kThreads) void k_cg_ctrl(CgDev d, int k) {
     d.has_conv[i] = rn < d.stop_after;           // :300
     lsum += rn;
     if (rr != rr || rzn != rzn) lnan = 1.f;
+    if (tri && col < d.n_tridiag) {
+      const int64_t it = b * d.n_tridiag + col;
+      const float alpha = d.alpha[i];
+      const float ar = 1.0f / ((alpha == 0.f) ? 1.0f : alpha);  // :314-317
+      float* t = d.t_mat + ((size_t)col * d.B + b) * T * T;
+      if (k == 0) {
+        t[0] = ar;                               // :320
+      } else {
+        const float pb = d.prev_beta[it], par = d.prev_ar[it];
+        t[k * T + k] = fmaf(pb, par, ar);        // addcmul(alpha_reciprocal, prev_beta, prev_alpha_reciprocal) :322
+        const float off = sqrtf(pb) * par;       // :323
+        t[k * T + k - 1] = off;
+        t[(k - 1) * T + k] = off;                // :324
+        lmax = fmaxf(lmax, off);
+      }
+      d.prev_ar[it] = ar;                        // :331-332
+      d.prev_beta[it] = beta;
+    }
   }
-  const float mean = block_sum256(lsum, red) / (float)n;
-  const float anynan = block_sum256(lnan, red);
+  const float bs = block_sum256(lsum, red);
+  const float bn = block_sum256(lnan, red);
+  const float bm = block_max256(lmax, red);
+  if (threadIdx.x == 0) {
+    d.ctrl_part[blockIdx.x] = bs;
+    d.ctrl_part[kCtrlMaxG + blockIdx.x] = bn;
+    d.ctrl_part[2 * kCtrlMaxG + blockIdx.x] = bm;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_cg_ctrl(CgDev d, int k, int G) {
+  if (d.ctrl->stop) return;
+  __shared__ float red[kThreads];
+  const int t = threadIdx.x;
+  const float ls = (t < G) ? d.ctrl_part[t] : 0.f;
+  const float ln = (t < G) ? d.ctrl_part[kCtrlMaxG + t] : 0.f;
+  const float lm = (t < G) ? d.ctrl_part[2 * kCtrlMaxG + t] : -INFINITY;
+  const int64_t n = d.B * d.c;
+  const float mean = block_sum256(ls, red) / (float)n;
+  const float anynan = block_sum256(ln, red);
+  const float mx = block_max256(lm, red);
   const int kfloor = min(10, d.max_iter - 1);
   const bool stopnow = (k >= kfloor) && (mean < d.tol) &&
                        !(d.n_tridiag && k < min(d.n_tridiag_iter, d.max_iter - 1));  // :302-306
-  if (threadIdx.x == 0) {
+  if (t == 0) {
     d.ctrl->iterations = k + 1;
     d.ctrl->mean_resid = mean;
     if (k == 0 && d.check_nan_first && anynan > 0.f) {  // NaN matvec detected on the first product
@@ -210,39 +261,10 @@ __global__ __launch_bounds__(kThreads) void k_cg_ctrl(CgDev d, int k) {
     if (stopnow) {
       d.ctrl->tol_reached = 1;                   // :307
       d.ctrl->stop = 1;
+    } else if (d.n_tridiag && k < d.n_tridiag_iter && !d.ctrl->tri_disabled) {
+      if (k > 0 && mx < 1e-6f) d.ctrl->tri_disabled = 1;  // :326-327
+      d.ctrl->last_tridiag_iter = k;                       // :329
     }
-  }
-  if (stopnow) return;                           // break happens BEFORE the tridiag update of iteration k
-  if (d.n_tridiag && k < d.n_tridiag_iter && !d.ctrl->tri_disabled) {  // :311
-    __syncthreads();                             // beta[] written above by other threads of this block
-    const int64_t nt = d.B * d.n_tridiag;
-    const int T = d.T;
-    float lmax = -INFINITY;
-    for (int64_t i = threadIdx.x; i < nt; i += kThreads) {
-      const int64_t b = i / d.n_tridiag;
-      const int col = (int)(i % d.n_tridiag);
-      const float alpha = d.alpha[b * d.c + col];
-      const float beta = d.beta[b * d.c + col];
-      const float ar = 1.0f / ((alpha == 0.f) ? 1.0f : alpha);  // :314-317
-      float* t = d.t_mat + ((size_t)col * d.B + b) * T * T;
-      if (k == 0) {
-        t[0] = ar;                               // :320
-      } else {
-        const float pb = d.prev_beta[i], par = d.prev_ar[i];
-        t[k * T + k] = fmaf(pb, par, ar);        // addcmul(alpha_reciprocal, prev_beta, prev_alpha_reciprocal) :322
-        const float off = sqrtf(pb) * par;       // :323
-        t[k * T + k - 1] = off;
-        t[(k - 1) * T + k] = off;                // :324
-        lmax = fmaxf(lmax, off);
-      }
-      d.prev_ar[i] = ar;                         // :331-332
-      d.prev_beta[i] = beta;
-    }
-    if (k > 0) {
-      const float m = block_max256(lmax, red);
-      if (threadIdx.x == 0 && m < 1e-6f) d.ctrl->tri_disabled = 1;  // :326-327
-    }
-    if (threadIdx.x == 0) d.ctrl->last_tridiag_iter = k;           // :329
   }
 }
 
@@ -347,6 +369,7 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   const size_t nt = (size_t)B * std::max(1, (int)prm->n_tridiag);
   dd.prev_ar = ar.take<float>(nt);
   dd.prev_beta = ar.take<float>(nt);
+  dd.ctrl_part = ar.take<float>(3 * 256);
   // operator-resident fast path scratch (c == 1): granule buffer, error word, per-iteration residuals
   dd.oc_gbuf = ar.take<unsigned long long>(onchip_gbuf_bytes(64) / sizeof(unsigned long long));
   dd.oc_err = ar.take<int>(1);
@@ -544,6 +567,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     rc = poll();
     if (rc) return rc;
   }
+  const int ctrl_G = (int)std::min<int64_t>(kCtrlMaxG, ((int64_t)B * c + kThreads - 1) / kThreads);
   int k = k_start;
   int launched = k_start;
   while (k < prm->max_iter && !h.stop) {
@@ -577,7 +601,8 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       }
     }
     LO_PROF_BEGIN("cg_ctrl", st);
-    hipLaunchKernelGGL(k_cg_ctrl, dim3(1), block, 0, st, d, k);
+    hipLaunchKernelGGL(k_cg_scal, dim3(ctrl_G), block, 0, st, d, k);
+    hipLaunchKernelGGL(k_cg_ctrl, dim3(1), block, 0, st, d, k, ctrl_G);
     LO_PROF_END(st);
     LO_LAUNCH_CHECK();
     ++launched;

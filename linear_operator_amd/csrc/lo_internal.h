@@ -75,6 +75,33 @@ struct CgCtrl {
   float mean_resid;
 };
 
+// fused-update arguments of the skinny tn kernels (VMODE 1: p-update, VMODE 2: r/x-update; see lo_skinny.hip)
+struct TnFuse {
+  // VMODE 1
+  const float* z;
+  const float* beta;  // [B, ldv]
+  int first;
+  // VMODE 2
+  const float* Ap;
+  const float* p;
+  float* x;
+  const float* pAp_part;  // [B, S_dot, ldv]
+  int S_dot;
+  const float* rz;        // [B, ldv]
+  const int* has_conv;    // [B, ldv]
+  float eps;
+  float* alpha_out;       // [B, ldv]
+  float* rr_part;         // [B, S, ldv]
+};
+
+// matrix-core versions for 8 < c <= 32 (lo_skinny_mfma.hip); tpart layout [B,S,R4,c]
+bool skinny_mfma_ok(int R4, int64_t c);
+int skinny_tn_mfma(int vmode, const float* A, int R4, float* v, int64_t c, float* tpart, int64_t B, int64_t N, Split sp,
+                   const TnFuse& f, const int* stop, hipStream_t st);
+int skinny_nn_mfma(const float* A, int R4, const float* tpart, const float* dd, int dd_mode, float sgn, const float* v,
+                   int64_t c, float* y, float* dot_part, int64_t B, int64_t N, Split sp, const int* stop,
+                   hipStream_t st);
+
 // ---- skinny operand kernels (lo_skinny.hip): A [B,N,lda] with R4 = 4*RQ padded columns --------
 // tpart[B,S,R4,c] = A[rows_s]^T v[rows_s]
 int skinny_tn(const float* A, int lda, int R4, const float* v, int64_t c, float* tpart, int64_t B, int64_t N, Split sp,

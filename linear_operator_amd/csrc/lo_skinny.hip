@@ -26,23 +26,6 @@
 
 namespace lo {
 
-struct TnFuse {
-  // VMODE 1
-  const float* z;
-  const float* beta;  // [B, ldv]
-  int first;
-  // VMODE 2
-  const float* Ap;
-  const float* p;
-  float* x;
-  const float* pAp_part;  // [B, S_dot, ldv]
-  int S_dot;
-  const float* rz;        // [B, ldv]
-  const int* has_conv;    // [B, ldv]
-  float eps;
-  float* alpha_out;       // [B, ldv]
-  float* rr_part;         // [B, S, ldv]
-};
 
 template <int CT, int RQ, int VMODE>
 __global__ __launch_bounds__(kThreads) void k_skinny_tn(const float* __restrict__ A, float* __restrict__ v, int ldv,
@@ -362,6 +345,7 @@ template <int VMODE>
 static int skinny_tn_impl(const float* A, int lda, int R4, float* v, int64_t c, float* tpart, int64_t B, int64_t N,
                           Split sp, const TnFuse& f0, const int* stop, hipStream_t st) {
   if (!rq_ok(R4) || lda != R4 || c < 1) return LO_ERR_BADARG;
+  if (skinny_mfma_ok(R4, c)) return skinny_tn_mfma(VMODE, A, R4, v, c, tpart, B, N, sp, f0, stop, st);
   const int RQ = R4 / 4;
   dim3 grid(sp.S, (unsigned)B);
   for (int64_t c0 = 0; c0 < c; c0 += 8) {
@@ -445,6 +429,8 @@ int skinny_nn(const float* A, int lda, int R4, const float* tpart, const float* 
               const float* v, int64_t c, float* y, float* dot_part, int64_t B, int64_t N, Split sp, const int* stop,
               hipStream_t st) {
   if (!rq_ok(R4) || lda != R4 || c < 1) return LO_ERR_BADARG;
+  if (skinny_mfma_ok(R4, c))
+    return skinny_nn_mfma(A, R4, tpart, dd, dd_mode, sgn, v, c, y, dot_part, B, N, sp, stop, st);
   const int RQ = R4 / 4;
   dim3 grid(sp.S, (unsigned)B);
   for (int64_t c0 = 0; c0 < c; c0 += 8) {
