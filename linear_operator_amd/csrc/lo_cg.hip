@@ -350,8 +350,7 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   dd.z = precond ? ar.take<float>(nv) : nullptr;
   int S_dot = sp.S;
   if (op->kind == LO_OP_DENSE_DIAG) {
-    const int rows = dense_rows_per_wg(B, N);
-    S_dot = (int)((N + rows - 1) / rows);
+    S_dot = dense_S_dot(B, N, c);
   }
   dd.S_dot = S_dot;
   dd.pAp_part = ar.take<float>((size_t)B * std::max(S_dot, sp.S) * c);

@@ -119,9 +119,16 @@ int dense_rows_per_wg(int64_t B, int64_t N) {
   return (int)rows;
 }
 
+int dense_S_dot(int64_t B, int64_t N, int64_t c) {
+  if (dense_mfma_ok(N, c)) return dense_mfma_tiles(N);
+  const int rows = dense_rows_per_wg(B, N);
+  return (int)((N + rows - 1) / rows);
+}
+
 int dense_matvec(const float* K, const float* d, int dd_mode, const float* v, float* y, float* dot_part, int64_t B,
                  int64_t N, int64_t c, int rows_per_wg, const int* stop, hipStream_t st) {
   if (c < 1) return LO_ERR_BADARG;
+  if (dense_mfma_ok(N, c)) return dense_matvec_mfma(K, d, dd_mode, v, y, dot_part, B, N, c, stop, st);
   const int S = (int)((N + rows_per_wg - 1) / rows_per_wg);
   dim3 grid(S, (unsigned)B), block(kThreads);
   for (int64_t c0 = 0; c0 < c; c0 += 4) {

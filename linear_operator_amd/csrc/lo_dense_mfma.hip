@@ -1,0 +1,145 @@
+// lo_dense_mfma.hip -- y = K v + d o v for dense K [B,N,N] and MANY columns (4 < c <= 32) on the matrix cores
+// (reference: AddedDiagLinearOperator._matmul added_diag_linear_operator.py:72-76 over DenseLinearOperator._matmul
+// dense_linear_operator.py:60-64; BASELINE cfg5: dense 16384^2 with 16 probes + 1 rhs).
+// HBM-bound: K (N^2 floats per member) is streamed exactly ONCE for all columns -- the 4-column VALU kernel in
+// lo_dense.hip would stream it ceil(c/4) times.  8.5 flop/B at c = 17, far below the fp32-MFMA ridge.
+//
+// Workgroup = 128 rows x all N; loop over K in slabs of 64 columns:
+//   global -> registers (next slab, issued before the MFMAs of the current one) -> LDS:
+//     K slab [128 rows][64 k], row stride 68 floats: float4 stores stay aligned and the ds_read_b128 of the A
+//     operand (lane = row) is bank-conflict free (4 * row mod 64 distinct within a 16-lane group);
+//     v slab [64 k][32 cols] (columns >= c zero).
+//   wave w owns rows 32 w .. 32 w + 31: D[row][col] += sum_k K[row][k] v[k][col] with v_mfma_f32_32x32x2_f32, lane
+//   half h = lane >> 5 taking k in [32 h, 32 h + 32) of the slab.
+// Epilogue fused: + d o v, store, CG inner product partial sum_rows v o y (one per 128-row tile).
+#include <algorithm>
+
+#include "lo_device.h"
+#include "lo_internal.h"
+
+namespace lo {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int DM_ROWS = 128, DM_KB = 64, DM_LD = 68;
+
+__device__ __forceinline__ int dm_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+template <bool DOT>
+__global__ __launch_bounds__(kThreads) void k_dense_mv_mfma(const float* __restrict__ K, const float* __restrict__ dd,
+                                                             int dd_mode, const float* __restrict__ v, int ldv, int c,
+                                                             float* __restrict__ y, float* __restrict__ dot_part,
+                                                             int ldd, int N, const int* __restrict__ stop) {
+  if (stop && *stop) return;
+  __shared__ float k_s[DM_ROWS * DM_LD];
+  __shared__ float v_s[DM_KB * 32];
+  __shared__ float dot_s[4][32];
+  const int tile = blockIdx.x, b = blockIdx.y, S = gridDim.x;
+  const int row0 = tile * DM_ROWS;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, h = lane >> 5;
+  const float* Kb = K + (size_t)b * N * N;
+  const size_t vbase = (size_t)b * N * ldv;
+
+  // staging map: thread t loads float4 #(t + 256 u), u = 0..7 of the [128][64] slab: row = f / 16, quad = f % 16
+  float4 kreg[8];
+  float vreg[8];
+  auto load_slab = [&](int kb) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int f = threadIdx.x + kThreads * u;
+      const int r = f >> 4, q = f & 15;
+      const int grow = row0 + r, gk = kb + 4 * q;
+      if (grow < N && gk + 3 < N && (N & 3) == 0) {
+        kreg[u] = *reinterpret_cast<const float4*>(Kb + (size_t)grow * N + gk);
+      } else {
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = (grow < N && gk + e < N) ? Kb[(size_t)grow * N + gk + e] : 0.f;
+        kreg[u] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+      const int e = threadIdx.x + kThreads * u;  // [64 k][32 cols]
+      const int kk = e >> 5, col = e & 31;
+      vreg[u] = (col < c && kb + kk < N) ? v[vbase + (size_t)(kb + kk) * ldv + col] : 0.f;
+    }
+  };
+  auto store_slab = [&]() {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int f = threadIdx.x + kThreads * u;
+      const int r = f >> 4, q = f & 15;
+      *reinterpret_cast<float4*>(&k_s[r * DM_LD + 4 * q]) = kreg[u];
+      v_s[threadIdx.x + kThreads * u] = vreg[u];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+  load_slab(0);
+  for (int kb = 0; kb < N; kb += DM_KB) {
+    __syncthreads();  // previous slab fully consumed
+    store_slab();
+    __syncthreads();
+    if (kb + DM_KB < N) load_slab(kb + DM_KB);  // in flight during the MFMAs below
+    const float* arow = &k_s[(32 * wave + li) * DM_LD + 32 * h];
+    const float* bcol = &v_s[(32 * h) * 32 + li];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * q);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bcol[(4 * q + 0) * 32], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bcol[(4 * q + 1) * 32], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bcol[(4 * q + 2) * 32], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bcol[(4 * q + 3) * 32], acc, 0, 0, 0);
+    }
+  }
+
+  const float ddc = (dd_mode == LO_DIAG_CONST) ? dd[b] : 0.f;
+  float dacc = 0.f;
+  if (li < c) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = row0 + 32 * wave + dm_row(e, lane);
+      if (row < N) {
+        const float dv = (dd_mode == LO_DIAG_FULL) ? dd[(size_t)b * N + row] : ddc;
+        const size_t o = vbase + (size_t)row * ldv + li;
+        const float vin = v[o];
+        const float yv = fmaf(dv, vin, acc[e]);
+        y[o] = yv;
+        if (DOT) dacc = fmaf(vin, yv, dacc);
+      }
+    }
+  }
+  if (DOT) {
+    dacc += __shfl_xor(dacc, 32, 64);
+    if (h == 0) dot_s[wave][li] = dacc;
+    __syncthreads();
+    if (threadIdx.x < c)
+      dot_part[((size_t)b * S + tile) * ldd + threadIdx.x] =
+          (dot_s[0][threadIdx.x] + dot_s[1][threadIdx.x]) + (dot_s[2][threadIdx.x] + dot_s[3][threadIdx.x]);
+  }
+}
+
+bool dense_mfma_ok(int64_t N, int64_t c) { return c > 4 && N >= 256; }
+int dense_mfma_tiles(int64_t N) { return (int)((N + DM_ROWS - 1) / DM_ROWS); }
+
+int dense_matvec_mfma(const float* K, const float* d, int dd_mode, const float* v, float* y, float* dot_part, int64_t B,
+                      int64_t N, int64_t c, const int* stop, hipStream_t st) {
+  dim3 grid(dense_mfma_tiles(N), (unsigned)B), block(kThreads);
+  for (int64_t c0 = 0; c0 < c; c0 += 32) {  // column tiles of 32 (K is re-streamed per tile: only for c > 32)
+    const int cn = (int)std::min<int64_t>(32, c - c0);
+    LO_PROF_BEGIN("dense_mv_mfma", st);
+    if (dot_part)
+      hipLaunchKernelGGL((k_dense_mv_mfma<true>), grid, block, 0, st, K, d, dd_mode, v + c0, (int)c, cn, y + c0,
+                         dot_part + c0, (int)c, (int)N, stop);
+    else
+      hipLaunchKernelGGL((k_dense_mv_mfma<false>), grid, block, 0, st, K, d, dd_mode, v + c0, (int)c, cn, y + c0,
+                         dot_part, (int)c, (int)N, stop);
+    LO_PROF_END(st);
+    LO_LAUNCH_CHECK();
+  }
+  return LO_OK;
+}
+
+}  // namespace lo

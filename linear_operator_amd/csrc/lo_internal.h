@@ -157,6 +157,12 @@ int matvec_run_pupdate(const MatvecPlan* pl, float* p, const float* z, const flo
 int dense_matvec(const float* K, const float* d, int dd_mode, const float* v, float* y, float* dot_part, int64_t B,
                  int64_t N, int64_t c, int rows_per_wg, const int* stop, hipStream_t st);
 int dense_rows_per_wg(int64_t B, int64_t N);
+// number of dot partials per (member, column) the dense matvec writes for this shape (VALU vs MFMA tiling)
+int dense_S_dot(int64_t B, int64_t N, int64_t c);
+bool dense_mfma_ok(int64_t N, int64_t c);
+int dense_mfma_tiles(int64_t N);
+int dense_matvec_mfma(const float* K, const float* d, int dd_mode, const float* v, float* y, float* dot_part, int64_t B,
+                      int64_t N, int64_t c, const int* stop, hipStream_t st);
 int kron_matvec(const float* K1, const float* K2, const float* v, float* tmp, float* y, int64_t B, int n1, int n2,
                 int64_t c, const int* stop, hipStream_t st);
 

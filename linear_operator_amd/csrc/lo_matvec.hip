@@ -60,8 +60,7 @@ int matvec_plan_init(MatvecPlan* pl, const lo_op_desc* op, lo_matvec_cb cb, void
     }
     case LO_OP_DENSE_DIAG: {
       if (!op->A0) return LO_ERR_BADARG;
-      const int rows = dense_rows_per_wg(op->B, op->N);
-      pl->S_dot = (int)((op->N + rows - 1) / rows);
+      pl->S_dot = dense_S_dot(op->B, op->N, c);
       break;
     }
     case LO_OP_KRON_DIAG: {
