@@ -342,3 +342,48 @@ def test_onchip_cg_matches_streaming_engine_and_oracle(N, R):
     # bitwise reproducible run to run (fixed summation order, no float atomics)
     res2 = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
     assert torch.equal(res.x, res2.x)
+
+
+# ------------------------------------------------------------------------------------------- many columns (MFMA paths)
+def test_cg_many_columns_mfma_paths_vs_oracle():
+    """cfg3 / cfg5-shaped right-hand sides (16 probes + 1 rhs) go through the v_mfma_f32_32x32x2_f32 kernels
+    (lo_skinny_mfma.hip, lo_dense_mfma.hip): same iteration counts and solutions as the oracle."""
+    # low-rank + diag, preconditioned, tridiagonals of the 16 probe columns
+    C, d, rhs = cases.lowrank_diag(5101, 3, 2304, 32, 17)
+    rhs[..., :16] /= np.sqrt((rhs[..., :16] ** 2).sum(-2, keepdims=True))
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    pre = _default_precond(desc, dev(d), False)
+    res = K.cg_solve(desc, dev(rhs), precond=pre, n_tridiag=16, tolerance=1e-4)
+    Lo, _ = orc.pivoted_cholesky(orc.LowRankRowSource(C), 15)
+    po = orc.Preconditioner(Lo, d)
+    xo, to, info = orc.linear_cg(lambda v: orc.matvec_lowrank_diag(C, d, v), rhs, n_tridiag=16, tolerance=1e-4,
+                                 preconditioner=po.apply)
+    assert res.iterations == info.iterations == 21
+    assert max_rel_err_cols(host(res.x), xo) < 1e-4
+    assert rel_err(host(res.t_mat)[..., :2, :2], to[..., :2, :2]) < 1e-4
+    _, _, ld = K.tridiag_eigh_slq(res.t_mat, 2304)
+    ev, evec = orc.lanczos_tridiag_to_diag(to.astype(np.float64))
+    assert np.allclose(host(ld), orc.slq_logdet(2304, ev, evec), rtol=1e-4, atol=2304 * 1.2e-7 * 150)
+    # unpreconditioned, 12 columns, R = 16 (padded operand tile half empty)
+    C2, d2, rhs2 = cases.lowrank_diag(5102, 2, 1500, 16, 12)
+    r2 = K.cg_solve(K.lowrank_diag_descriptor(dev(C2), dev(d2)), dev(rhs2), tolerance=1.0)
+    x2, _, i2 = orc.linear_cg(lambda v: orc.matvec_lowrank_diag(C2, d2, v), rhs2, tolerance=1.0)
+    assert r2.iterations == i2.iterations == 11 and max_rel_err_cols(host(r2.x), x2) < 1e-4
+    # dense + diag, 17 columns, N not a multiple of the 128-row / 64-column tiles
+    Kd, dd, rhs3 = cases.dense_diag(5103, 2, 1100, 17)
+    desc3 = K.dense_diag_descriptor(dev(Kd), dev(dd))
+    y = host(K.matvec(desc3, dev(rhs3)))
+    assert max_rel_err_cols(y, orc.matvec_dense_diag(Kd.astype(np.float64), dd.astype(np.float64),
+                                                     rhs3.astype(np.float64))) < 5e-6
+    r3 = K.cg_solve(desc3, dev(rhs3), tolerance=1e-2, n_tridiag=4)
+    x3, t3, i3 = orc.linear_cg(lambda v: orc.matvec_dense_diag(Kd, dd, v), rhs3, tolerance=1e-2, n_tridiag=4)
+    assert abs(r3.iterations - i3.iterations) <= 1 and max_rel_err_cols(host(r3.x), x3) < 2e-3
+    # 40 columns: two MFMA column tiles for the dense kernel, VALU chunks for the skinny kernels
+    rhs4 = cases.randn(5104, 2, 1100, 40, dtype=np.float32)
+    y4 = host(K.matvec(desc3, dev(rhs4)))
+    assert max_rel_err_cols(y4, orc.matvec_dense_diag(Kd.astype(np.float64), dd.astype(np.float64),
+                                                      rhs4.astype(np.float64))) < 5e-6
+    C5, d5, rhs5 = cases.lowrank_diag(5105, 2, 900, 32, 40)
+    y5 = host(K.matvec(K.lowrank_diag_descriptor(dev(C5), dev(d5)), dev(rhs5)))
+    assert max_rel_err_cols(y5, orc.matvec_lowrank_diag(C5.astype(np.float64), d5.astype(np.float64),
+                                                        rhs5.astype(np.float64))) < 5e-6
