@@ -150,3 +150,34 @@ def test_linear_cg_signature_closures_warnings_errors():
     evals, evecs = lanczos_tridiag_to_diag(t[:20, :20].contiguous().unsqueeze(0))
     ref = np.linalg.eigvalsh(host(t[:20, :20]).astype(np.float64))
     assert np.allclose(host(evals)[0], np.where(ref >= 0, ref, 1.0), rtol=1e-4, atol=1e-5)
+
+
+def test_ragged_shapes_multibatch_and_wide_rhs():
+    """Odd sizes (N, R not multiples of the tiles), multi-dimensional batch, un-batched operator, 50 columns
+    (the reference's own test width, test_linear_cg.py:50), all through the operator API with max_cholesky_size(0)."""
+    from oracle import lo_oracle as orc
+
+    rng = np.random.default_rng(99)
+    # [2, 3] batch, N = 777, R = 7
+    C = (rng.standard_normal((2, 3, 777, 7)) / np.sqrt(7)).astype(np.float32)
+    d = (rng.random((2, 3, 777)) + 0.5).astype(np.float32)
+    rhs = rng.standard_normal((2, 3, 777, 3)).astype(np.float32)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C)), DiagLinearOperator(dev(d)))
+    with settings.max_cholesky_size(0), settings.cg_tolerance(1e-5), settings.min_preconditioning_size(100):
+        x = A.solve(dev(rhs))
+        L, piv = A._linear_op.pivoted_cholesky(rank=5, return_pivots=True)
+    dense = C.astype(np.float64) @ np.swapaxes(C.astype(np.float64), -1, -2)
+    dense = dense + np.eye(777) * d.astype(np.float64)[..., None]
+    exact = np.linalg.solve(dense, rhs.astype(np.float64))
+    assert x.shape == (2, 3, 777, 3) and max_rel_err_cols(host(x), exact) < 1e-4
+    Lo, pivo = orc.pivoted_cholesky(orc.LowRankRowSource(C), 5)
+    assert tuple(L.shape) == (2, 3, 777, 5) and np.array_equal(host(piv), pivo) and np.array_equal(host(L), Lo)
+    # un-batched operator, 50 columns, unpreconditioned (N < min_preconditioning_size)
+    M = cases.spd_test_matrix(7, 100, dtype=np.float32)
+    b = cases.randn(8, 100, 50, dtype=np.float32)
+    with settings.max_cholesky_size(0), settings.cg_tolerance(1e-6), settings.max_cg_iterations(100):
+        xs = DenseLinearOperator(dev(M)).solve(dev(b))
+    assert np.allclose(host(xs), np.linalg.solve(M.astype(np.float64), b.astype(np.float64)), atol=1e-3, rtol=1e-3)
+    # rhs broadcast over the operator batch is rejected with the reference's message
+    with settings.max_cholesky_size(0), pytest.raises(RuntimeError, match="same number of dimensions"):
+        A.inv_quad_logdet(dev(rhs[0]), logdet=True)
