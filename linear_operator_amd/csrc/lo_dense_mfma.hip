@@ -4,7 +4,8 @@
 // HBM-bound: K (N^2 floats per member) is streamed exactly ONCE for all columns -- the 4-column VALU kernel in
 // lo_dense.hip would stream it ceil(c/4) times.  8.5 flop/B at c = 17, far below the fp32-MFMA ridge.
 //
-// Workgroup = 128 rows x all N; loop over K in slabs of 64 columns:
+// Workgroup = 64 rows x all N; loop over K in slabs of 128 columns (512 contiguous bytes per row: DRAM locality);
+// waves = 2 row tiles x 2 k-halves, the k-halves are summed through LDS at the end:
 //   global -> registers (next slab, issued before the MFMAs of the current one) -> LDS:
 //     K slab [128 rows][64 k], row stride 68 floats: float4 stores stay aligned and the ds_read_b128 of the A
 //     operand (lane = row) is bank-conflict free (4 * row mod 64 distinct within a 16-lane group);
@@ -21,7 +22,7 @@ namespace lo {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int DM_ROWS = 128, DM_KB = 64, DM_LD = 68;
+constexpr int DM_ROWS = 64, DM_KB = 128, DM_LD = DM_KB + 4;  // 512 contiguous bytes per row and slab (DRAM locality)
 
 __device__ __forceinline__ int dm_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
@@ -38,27 +39,37 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma(const float* __restr
   const int row0 = tile * DM_ROWS;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int li = lane & 31, h = lane >> 5;
+  const int wr = wave & 1, wk = wave >> 1;  // row tile / k half of the slab this wave owns
   const float* Kb = K + (size_t)b * N * N;
   const size_t vbase = (size_t)b * N * ldv;
 
   // staging map: thread t loads float4 #(t + 256 u), u = 0..7 of the [128][64] slab: row = f / 16, quad = f % 16
   float4 kreg[8];
-  float vreg[8];
+  float vreg[16];
+  const bool full_rows = ((N & 3) == 0) && (row0 + DM_ROWS <= N);  // workgroup-uniform fast path condition
   auto load_slab = [&](int kb) {
+    if (full_rows && kb + DM_KB <= N) {  // unguarded 16-byte loads (keeps global_load_dwordx4 in the ISA)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int f = threadIdx.x + kThreads * u;
-      const int r = f >> 4, q = f & 15;
-      const int grow = row0 + r, gk = kb + 4 * q;
-      if (grow < N && gk + 3 < N && (N & 3) == 0) {
-        kreg[u] = *reinterpret_cast<const float4*>(Kb + (size_t)grow * N + gk);
-      } else {
+      for (int u = 0; u < 8; ++u) {
+        const int f = threadIdx.x + kThreads * u;
+        const int r = f >> 5, q = f & 31;
+        kreg[u] = *reinterpret_cast<const float4*>(Kb + (size_t)(row0 + r) * N + kb + 4 * q);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = threadIdx.x + kThreads * u;
+        const int r = f >> 5, q = f & 31;
+        const int grow = row0 + r, gk = kb + 4 * q;
         float t[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) t[e] = (grow < N && gk + e < N) ? Kb[(size_t)grow * N + gk + e] : 0.f;
         kreg[u] = make_float4(t[0], t[1], t[2], t[3]);
       }
-      const int e = threadIdx.x + kThreads * u;  // [64 k][32 cols]
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = threadIdx.x + kThreads * u;  // [128 k][32 cols]
       const int kk = e >> 5, col = e & 31;
       vreg[u] = (col < c && kb + kk < N) ? v[vbase + (size_t)(kb + kk) * ldv + col] : 0.f;
     }
@@ -67,8 +78,11 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma(const float* __restr
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int f = threadIdx.x + kThreads * u;
-      const int r = f >> 4, q = f & 15;
+      const int r = f >> 5, q = f & 31;
       *reinterpret_cast<float4*>(&k_s[r * DM_LD + 4 * q]) = kreg[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
       v_s[threadIdx.x + kThreads * u] = vreg[u];
     }
   };
@@ -83,8 +97,8 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma(const float* __restr
     store_slab();
     __syncthreads();
     if (kb + DM_KB < N) load_slab(kb + DM_KB);  // in flight during the MFMAs below
-    const float* arow = &k_s[(32 * wave + li) * DM_LD + 32 * h];
-    const float* bcol = &v_s[(32 * h) * 32 + li];
+    const float* arow = &k_s[(32 * wr + li) * DM_LD + 64 * wk + 32 * h];
+    const float* bcol = &v_s[(64 * wk + 32 * h) * 32 + li];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * q);
@@ -95,12 +109,24 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma(const float* __restr
     }
   }
 
+  // the two waves that share a row tile sum their k-halves through LDS (fixed order: half 0 + half 1)
+  __syncthreads();
+  float* red = k_s;  // reuse: [2 row tiles][16 regs][64 lanes]
+  if (wk == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(wr * 16 + e) * 64 + lane] = acc[e];
+  }
+  __syncthreads();
+  if (wk == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += red[(wr * 16 + e) * 64 + lane];
+  }
   const float ddc = (dd_mode == LO_DIAG_CONST) ? dd[b] : 0.f;
   float dacc = 0.f;
-  if (li < c) {
+  if (wk == 0 && li < c) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int row = row0 + 32 * wave + dm_row(e, lane);
+      const int row = row0 + 32 * wr + dm_row(e, lane);
       if (row < N) {
         const float dv = (dd_mode == LO_DIAG_FULL) ? dd[(size_t)b * N + row] : ddc;
         const size_t o = vbase + (size_t)row * ldv + li;
@@ -113,7 +139,7 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma(const float* __restr
   }
   if (DOT) {
     dacc += __shfl_xor(dacc, 32, 64);
-    if (h == 0) dot_s[wave][li] = dacc;
+    if (h == 0) dot_s[wave][li] = dacc;  // waves with wk == 1 contribute 0
     __syncthreads();
     if (threadIdx.x < c)
       dot_part[((size_t)b * S + tile) * ldd + threadIdx.x] =
