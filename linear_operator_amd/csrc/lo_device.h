@@ -20,6 +20,53 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- xor-butterfly partner fetch on the gfx950 cross-lane hardware (no LDS crossbar except M == 4) ----
+//   M = 32 / 16 : v_permlane32_swap / v_permlane16_swap     M = 8 : DPP row_ror:8
+//   M = 4       : ds_swizzle SWAP,4                         M = 2, 1 : DPP quad_perm
+template <int M>
+__device__ __forceinline__ int xor_lane_i(int v) {
+  if constexpr (M == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);
+  else if constexpr (M == 4) return __builtin_amdgcn_ds_swizzle(v, 0x101f);
+  else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false);
+  else return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false);
+}
+// {a, b} = {own value, value of lane ^ M} in an order that depends on the lane: combine them symmetrically.
+template <int M>
+__device__ __forceinline__ void bfly_i(int x, int& a, int& b) {
+  if constexpr (M == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    a = (int)r[0];
+    b = (int)r[1];
+  } else if constexpr (M == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+    a = (int)r[0];
+    b = (int)r[1];
+  } else {
+    a = x;
+    b = xor_lane_i<M>(x);
+  }
+}
+template <int M>
+__device__ __forceinline__ float bfly_add(float x) {
+  int a, b;
+  bfly_i<M>(__float_as_int(x), a, b);
+  return __int_as_float(a) + __int_as_float(b);
+}
+// butterfly sums over groups of 64 / 16 / 8 consecutive lanes: every lane of the group ends with the same bits
+__device__ __forceinline__ float wave_sum_fast(float v) {
+  v = bfly_add<1>(v); v = bfly_add<2>(v); v = bfly_add<4>(v); v = bfly_add<8>(v);
+  v = bfly_add<16>(v); v = bfly_add<32>(v);
+  return v;
+}
+__device__ __forceinline__ float lanes16_sum(float v) {
+  v = bfly_add<1>(v); v = bfly_add<2>(v); v = bfly_add<4>(v); v = bfly_add<8>(v);
+  return v;
+}
+__device__ __forceinline__ float lanes8_sum(float v) {
+  v = bfly_add<1>(v); v = bfly_add<2>(v); v = bfly_add<4>(v);
+  return v;
+}
+
 // Sum over all threads of a 256-thread block; result valid in every thread.  `red` >= 4 floats of LDS.
 // Fixed order (wave butterfly, then waves 0..3) -> bitwise reproducible.
 __device__ __forceinline__ float block_sum256(float v, float* red) {

@@ -336,7 +336,7 @@ size_t lo_pivoted_cholesky_workspace_bytes(const lo_op_desc* op, int32_t max_ran
   Arena ar(nullptr, 0);
   PcDev d;
   pc_layout(op, max_rank, ar, &d);
-  return ar.off + 1024;
+  return std::max(ar.off + 1024, pc_onchip_workspace_bytes(op->B, max_rank));
 }
 
 int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_tol, float* L_rows, int64_t* perm,
@@ -348,6 +348,11 @@ int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_
   hipStream_t st = (hipStream_t)stream;
   const int64_t B = op->B, N = op->N;
   const int rank = (int)std::min<int64_t>(max_rank, N);  // :33
+  if (pc_onchip_eligible(op, max_rank)) {  // operator-resident fast path (lo_pivchol_onchip.hip), same results
+    const int rc = pc_onchip_run(op, rank, max_rank, error_tol, L_rows, (long long*)perm, rank_out, ws, ws_bytes, st);
+    if (rc != LO_ERR_LAUNCH) return rc;
+    (void)hipGetLastError();  // exchange timed out (co-residency lost): redo with the streaming engine
+  }
   Arena ar(ws, ws_bytes);
   PcDev d;
   pc_layout(op, max_rank, ar, &d);

@@ -187,6 +187,43 @@ def test_pivoted_cholesky_bench_shape_bit_exact():
     _check_pivchol(K.lowrank_diag_descriptor(dev(C), None), orc.LowRankRowSource(C), 15)
 
 
+@pytest.mark.parametrize("N,R,B", [(8192, 32, 70), (4096, 16, 33), (1500, 8, 5), (5000, 32, 9)])
+def test_onchip_pivoted_cholesky_matches_streaming_engine_and_oracle(N, R, B):
+    """Operator-resident pivoted Cholesky (one 8-workgroup group per member, C rows in LDS, L rows in VGPRs, one
+    granule exchange per pivot): L, permutation and rank bit-identical to the streaming engine and to the oracle."""
+    C = cases.lowrank_diag(3300 + R, B, N, R, 1)[0]
+    desc = K.lowrank_diag_descriptor(dev(C), None)
+    try:
+        K.set_onchip_cg(False)
+        Ls, ps = K.pivoted_cholesky(desc, 15)
+        K.set_onchip_cg(True)
+        K._hip.prof_enable(True)
+        Lo, po = K.pivoted_cholesky(desc, 15)
+        torch.cuda.synchronize()
+        prof = K._hip.prof_report()
+        K._hip.prof_enable(False)
+    finally:
+        K.set_onchip_cg(True)
+    assert "pc_onchip" in prof, "fast path was not taken"
+    assert Lo.shape == Ls.shape
+    assert torch.equal(po, ps) and torch.equal(Lo, Ls)
+    sub = slice(0, 3)
+    Lr, pr = orc.pivoted_cholesky(orc.LowRankRowSource(C[sub]), 15)
+    assert np.array_equal(host(po)[sub], pr) and np.array_equal(host(Lo)[sub], Lr)
+    # early stop through the batch-global tolerance rule (_pivoted_cholesky.py:57): same m, same permutation
+    for tol in (0.5, 0.9):
+        try:
+            K.set_onchip_cg(False)
+            Ls, ps = K.pivoted_cholesky(desc, 15, error_tol=tol)
+        finally:
+            K.set_onchip_cg(True)
+        Lo, po = K.pivoted_cholesky(desc, 15, error_tol=tol)
+        assert Lo.shape == Ls.shape and torch.equal(po, ps) and torch.equal(Lo, Ls)
+    if R == 8:  # rank-deficient root: the error collapses after 8 pivots and the loop stops on its own
+        Lo, po = K.pivoted_cholesky(desc, 15, error_tol=1e-3)
+        assert Lo.shape[-1] < 15
+
+
 # ------------------------------------------------------------------------------------------- preconditioner
 def test_preconditioner_build_apply():
     g = load_golden("g3_precond")
