@@ -498,10 +498,14 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.rhs_is_zero = d.rhs_is_zero; a.has_conv = d.has_conv;
     a.resid_rec = d.oc_resid; a.init_conv = d.oc_init_conv; a.gbuf = d.oc_gbuf; a.err = d.oc_err;
     a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
+    a.prefetch = getenv("LO_OC_NO_PREFETCH") ? 0 : 1;
+    a.stagger = getenv("LO_OC_STAGGER") ? atoi(getenv("LO_OC_STAGGER")) : 0;
     const bool oc_dbg = getenv("LO_OC_DEBUG") != nullptr && B >= 8;
     a.dbg = oc_dbg ? reinterpret_cast<long long*>(d.oc_resid + (size_t)B * 12) : nullptr;
+    a.dbg_member = oc_dbg ? atoi(getenv("LO_OC_DEBUG")) : 0;  // LO_OC_DEBUG=<member index to time>
     LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(oc_nwg / 8), st));
     LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 0, sizeof(int), st));
+    if (oc_dbg) LO_HIP_CHECK(hipMemsetAsync(a.dbg, 0, 10 * sizeof(long long), st));
     rc = onchip_launch(pl.R4, preR4, a, oc_nwg, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_cg_ctrl_onchip, dim3(1), block, 0, st, d, d.oc_resid, d.oc_init_conv, a.iters);
@@ -511,7 +515,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
     LO_HIP_CHECK(hipStreamSynchronize(st));
     if (oc_dbg) {
-      long long ts[5];
+      long long ts[10];
       LO_HIP_CHECK(hipMemcpy(ts, a.dbg, sizeof(ts), hipMemcpyDeviceToHost));
       fprintf(stderr, "onchip member0 (100 MHz ticks): load %lld init %lld iters %lld store %lld\n", ts[1] - ts[0],
               ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3]);

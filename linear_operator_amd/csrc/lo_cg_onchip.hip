@@ -119,6 +119,7 @@ __device__ __forceinline__ float wave_reduce_scatter_prod(const float (&a)[n], f
   return v[0];
 }
 
+constexpr int PF_STRIDE = 64;  // bytes between L2 prefetch touches
 constexpr int OC_CLD = 36;  // padded LDS row stride of C (floats): 144-B rows -> conflict-free ds_read_b128
 
 struct OcShared {
@@ -179,7 +180,7 @@ __device__ __forceinline__ void wg_partial(OcShared& sh, const float (&a)[n], fl
   const float mine = wave_reduce_scatter_prod<n>(a, mult);
   if ((lane & ((1 << sh_bits) - 1)) == 0) sh.red[wave][lane >> sh_bits] = mine;
   for (int j = 0; j < ns; ++j) {
-    const float sv = wave_sum(scal[j]);
+    const float sv = wave_sum_fast(scal[j]);  // DPP/permlane butterfly: no LDS-crossbar latency chain
     if (lane == 0) sh.red[wave][n + j] = sv;
   }
   __syncthreads();
@@ -199,7 +200,7 @@ __device__ __forceinline__ void wg_partial_lds(OcShared& sh, const float* a, flo
   const float mine = wave_reduce_scatter_prod_lds<n>(a, mult);
   if ((lane & ((1 << sh_bits) - 1)) == 0) sh.red[wave][lane >> sh_bits] = mine;
   for (int j = 0; j < ns; ++j) {
-    const float sv = wave_sum(scal[j]);
+    const float sv = wave_sum_fast(scal[j]);  // DPP/permlane butterfly: no LDS-crossbar latency chain
     if (lane == 0) sh.red[wave][n + j] = sv;
   }
   __syncthreads();
@@ -215,7 +216,7 @@ __device__ __forceinline__ void wg_partial_lds(OcShared& sh, const float* a, flo
 __device__ __forceinline__ void wg_partial_scalars(OcShared& sh, const float* scal, int ns) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   for (int j = 0; j < ns; ++j) {
-    const float sv = wave_sum(scal[j]);
+    const float sv = wave_sum_fast(scal[j]);  // DPP/permlane butterfly: no LDS-crossbar latency chain
     if (lane == 0) sh.red[wave][j] = sv;
   }
   __syncthreads();
@@ -231,6 +232,7 @@ __device__ __forceinline__ void wg_partial_scalars(OcShared& sh, const float* sc
 template <int RC, int RK>
 __global__ __launch_bounds__(OC_TPB) void k_cg_onchip(OnchipArgs a) {
   __shared__ OcShared sh;
+  __shared__ float pf_sink[64];           // landing pad of the L2 prefetch loads (never read)
   __shared__ float c_s[OC_TPB * OC_CLD];  // this workgroup's rows of C (144 KiB of the CU's 160 KiB LDS); Q rows in VGPRs
   const int wg = blockIdx.x;
   // keep the 8 workgroups of a group on one XCD (block b runs on XCD b % 8; speed only)
@@ -278,32 +280,39 @@ __global__ __launch_bounds__(OC_TPB) void k_cg_onchip(OnchipArgs a) {
     __syncthreads();
   }
 
+  // de-synchronise the groups: otherwise all of them stream their operator rows from HBM at the same moment
+  // and then all leave HBM idle while they iterate
+  for (int i = 0; i < a.stagger * (j / OC_GW * 8 + xcd); ++i) __builtin_amdgcn_s_sleep(64);
   for (int64_t b = grp; b < a.B; b += ngroups) {
-    const bool stamp = a.dbg && b == 0 && wig == 0 && t == 0;
+    const bool stamp = a.dbg && b == a.dbg_member && wig == 0 && t == 0;
     if (stamp) a.dbg[0] = wall_clock64();
     const int row = wig * a.RW + t;
     const bool valid = (t < a.RW) && (row < a.N);
     float Qr[RK];
     float* crow = c_s + t * OC_CLD;
     float dv = 0.f, dinvv = 0.f, rhsv = 0.f;
-    if (valid) {
-      const float4* cp = reinterpret_cast<const float4*>(a.C + ((size_t)b * a.N + row) * RC);
-#pragma unroll
-      for (int i = 0; i < RC / 4; ++i) *reinterpret_cast<float4*>(crow + 4 * i) = cp[i];
-      const float4* qp = reinterpret_cast<const float4*>(a.Q + ((size_t)b * a.N + row) * RK);
+    {
+      // coalesced: both row blocks are in flight together; Q passes through the (still empty) C area of LDS
+      // on its way to the owning thread's registers
+      const int row0 = wig * a.RW;
+      const int nv = max(0, min(a.RW, a.N - row0));
+      float4 cq[RC / 4], qq[RK / 4];
+      rows_issue<RK, OC_TPB>(a.Q + ((size_t)b * a.N + row0) * RK, nv, qq);
+      rows_issue<RC, OC_TPB>(a.C + ((size_t)b * a.N + row0) * RC, nv, cq);
+      if (valid) {
+        dv = (a.d_mode == LO_DIAG_FULL) ? a.d[(size_t)b * a.N + row] : (a.d_mode == LO_DIAG_CONST ? a.d[b] : 0.f);
+        dinvv = (a.dinv_mode == LO_DIAG_FULL) ? a.dinv[(size_t)b * a.N + row] : a.dinv[b];
+        rhsv = a.rhs[(size_t)b * a.N + row];
+      }
+      rows_commit<RK, RK + 4, OC_TPB>(c_s, qq);
+      __syncthreads();
 #pragma unroll
       for (int i = 0; i < RK / 4; ++i) {
-        const float4 q4 = qp[i];
+        const float4 q4 = *reinterpret_cast<const float4*>(c_s + t * (RK + 4) + 4 * i);
         Qr[4 * i] = q4.x; Qr[4 * i + 1] = q4.y; Qr[4 * i + 2] = q4.z; Qr[4 * i + 3] = q4.w;
       }
-      dv = (a.d_mode == LO_DIAG_FULL) ? a.d[(size_t)b * a.N + row] : (a.d_mode == LO_DIAG_CONST ? a.d[b] : 0.f);
-      dinvv = (a.dinv_mode == LO_DIAG_FULL) ? a.dinv[(size_t)b * a.N + row] : a.dinv[b];
-      rhsv = a.rhs[(size_t)b * a.N + row];
-    } else {
-#pragma unroll
-      for (int i = 0; i < RC; ++i) crow[i] = 0.f;
-#pragma unroll
-      for (int i = 0; i < RK; ++i) Qr[i] = 0.f;
+      __syncthreads();
+      rows_commit<RC, OC_CLD, OC_TPB>(c_s, cq);
     }
 
     __syncthreads();
@@ -337,12 +346,57 @@ __global__ __launch_bounds__(OC_TPB) void k_cg_onchip(OnchipArgs a) {
     float rz = sh.res[RK + 1] - uu;
     float p = z, beta = 0.f, alpha = 0.f, rn = sqrtf(rr);
 
+    // L2 prefetch plan for the next member of this group (see the iteration loop)
+    int pf_lines = 0, pf_chunk = 0, pf_lc = 0, pf_lq = 0, pf_lv = 0;
+    const char *pf_c = nullptr, *pf_q = nullptr, *pf_v0 = nullptr, *pf_v1 = nullptr, *pf_v2 = nullptr;
+    if (a.prefetch && b + ngroups < a.B && a.iters > 0) {
+      const int64_t nb = b + ngroups;
+      const int row0 = wig * a.RW;
+      const int nv = max(0, min(a.RW, a.N - row0));
+      pf_lc = (nv * RC * 4) / PF_STRIDE;
+      pf_lq = (nv * RK * 4) / PF_STRIDE;
+      pf_lv = (nv * 4) / PF_STRIDE;
+      pf_c = reinterpret_cast<const char*>(a.C + ((size_t)nb * a.N + row0) * RC);
+      pf_q = reinterpret_cast<const char*>(a.Q + ((size_t)nb * a.N + row0) * RK);
+      pf_v0 = reinterpret_cast<const char*>(a.rhs + (size_t)nb * a.N + row0);
+      int nvec = 1;
+      if (a.d_mode == LO_DIAG_FULL) {
+        pf_v1 = reinterpret_cast<const char*>(a.d + (size_t)nb * a.N + row0);
+        nvec = 2;
+        if (a.dinv_mode == LO_DIAG_FULL) {
+          pf_v2 = reinterpret_cast<const char*>(a.dinv + (size_t)nb * a.N + row0);
+          nvec = 3;
+        }
+      } else if (a.dinv_mode == LO_DIAG_FULL) {
+        pf_v1 = reinterpret_cast<const char*>(a.dinv + (size_t)nb * a.N + row0);
+        nvec = 2;
+      }
+      pf_lines = pf_lc + pf_lq + nvec * pf_lv;
+      pf_chunk = min(OC_TPB, (pf_lines + a.iters - 1) / a.iters);
+    }
     if (stamp) a.dbg[2] = wall_clock64();
     for (int k = 0; k < a.iters; ++k) {
       if (k > 0) p = fmaf(p, beta, z);                      // p.mul_(beta).add_(z)  :46
       sc[0] = dv * p * p;
       wg_partial_lds<RC>(sh, crow, p, sc, 1);
       group_exchange(sh, RC + 1, gslot, wig, ++tag, a.err, same_xcd);  // t = C^T p  and  sum d p^2
+      if (pf_lines > 0) {
+        // L2 prefetch of this workgroup's rows of the NEXT member, one slice per iteration: one 4-byte
+        // global_load_lds per 128-byte line (no VGPR result, nothing waits on it); issued here so that the loads
+        // have landed before the next vector-memory wait (the poll of the second exchange)
+        const int line = k * pf_chunk + t;
+        if (t < pf_chunk && line < pf_lines) {
+          const char* src;
+          if (line < pf_lc) src = pf_c + (size_t)line * PF_STRIDE;
+          else if (line < pf_lc + pf_lq) src = pf_q + (size_t)(line - pf_lc) * PF_STRIDE;
+          else {
+            const int v = (line - pf_lc - pf_lq) / pf_lv, o = (line - pf_lc - pf_lq) % pf_lv;
+            src = (v == 0 ? pf_v0 : v == 1 ? pf_v1 : pf_v2) + (size_t)o * PF_STRIDE;
+          }
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)pf_sink, 4, 0, 0);
+        }
+      }
       float y = dv * p;                                     // A p = C t + d o p     added_diag...py:72-76
       float ct = 0.f, tt = 0.f;
 #pragma unroll

@@ -67,6 +67,29 @@ __device__ __forceinline__ float lanes8_sum(float v) {
   return v;
 }
 
+// ---- coalesced row-block staging for the operator-resident kernels ------------------------------------------
+// `nv` rows x W floats (W = 4, 8, 16 or 32; row-major, contiguous, 16-byte aligned) -> registers -> LDS rows of
+// stride LD floats; a workgroup of NT threads moves NT rows (rows >= nv are zero-filled).  Consecutive lanes read
+// consecutive 16-byte pieces (one wave instruction = 1 KiB contiguous) instead of each lane walking its own row.
+template <int W, int NT>
+__device__ __forceinline__ void rows_issue(const float* __restrict__ src, int nv, float4 (&reg)[W / 4]) {
+  constexpr int QW = W / 4;
+#pragma unroll
+  for (int i = 0; i < QW; ++i) {
+    const int f = i * NT + (int)threadIdx.x;
+    reg[i] = (f / QW < nv) ? reinterpret_cast<const float4*>(src)[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int W, int LD, int NT>
+__device__ __forceinline__ void rows_commit(float* __restrict__ lds, const float4 (&reg)[W / 4]) {
+  constexpr int QW = W / 4;
+#pragma unroll
+  for (int i = 0; i < QW; ++i) {
+    const int f = i * NT + (int)threadIdx.x;
+    *reinterpret_cast<float4*>(lds + (f / QW) * LD + 4 * (f % QW)) = reg[i];
+  }
+}
+
 // Sum over all threads of a 256-thread block; result valid in every thread.  `red` >= 4 floats of LDS.
 // Fixed order (wave butterfly, then waves 0..3) -> bitwise reproducible.
 __device__ __forceinline__ float block_sum256(float v, float* red) {

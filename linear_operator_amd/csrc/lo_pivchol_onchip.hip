@@ -289,15 +289,14 @@ __global__ __launch_bounds__(PO_TPB) void k_pc_onchip(PoArgs a) {
     const int row = wig * a.RW + t;
     const bool valid = (t < a.RW) && (row < a.N);
     float* crow = c_s + t * PO_CLD;
-    if (valid) {
-      const float4* cp = reinterpret_cast<const float4*>(a.C + ((size_t)b * a.N + row) * RC);
-#pragma unroll
-      for (int i = 0; i < RC / 4; ++i) *reinterpret_cast<float4*>(crow + 4 * i) = cp[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < RC; ++i) crow[i] = 0.f;
+    {
+      const int row0 = wig * a.RW;
+      const int nv = max(0, min(a.RW, a.N - row0));
+      float4 cq[RC / 4];
+      rows_issue<RC, PO_TPB>(a.C + ((size_t)b * a.N + row0) * RC, nv, cq);  // coalesced: 1 KiB per wave instruction
+      rows_commit<RC, PO_CLD, PO_TPB>(c_s, cq);
     }
-    // own-row LDS traffic only (each thread reads back what it wrote): no barrier needed here
+    __syncthreads();
     float dg = 0.f;
     {
       float acc = crow[0] * crow[0];  // (root ** 2).sum(-1), sequential in r
