@@ -50,7 +50,7 @@ def make_problem(device, seed):
 
 
 def build_precond(desc, d):
-    L, _ = K.pivoted_cholesky(desc, RANK_K)
+    L, _ = K.pivoted_cholesky(desc, RANK_K, contiguous=False)  # [B, m, N] rows read in place by the build
     return K.precond_build(L, d, constant_diag=False)
 
 
@@ -157,7 +157,7 @@ def other_configs(device):
     desc = K.kron_diag_descriptor(K1, K2, sig, const_diag=True)
 
     def kron():
-        L, _ = K.pivoted_cholesky(desc, RANK_K)
+        L, _ = K.pivoted_cholesky(desc, RANK_K, contiguous=False)  # [B, m, N] rows read in place by the build
         return K.cg_solve(desc, rhs, precond=K.precond_build(L, sig, True), tolerance=1e-3)
 
     t, r = _time(kron, 1)
@@ -173,7 +173,7 @@ def other_configs(device):
     desc = K.dense_diag_descriptor(Kd, d)
 
     def dense():
-        L, _ = K.pivoted_cholesky(desc, RANK_K)
+        L, _ = K.pivoted_cholesky(desc, RANK_K, contiguous=False)  # [B, m, N] rows read in place by the build
         return K.cg_solve(desc, full, precond=K.precond_build(L, d, False), n_tridiag=16, tolerance=TOL)
 
     t, r = _time(dense, 1)

@@ -160,6 +160,12 @@ int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_
 size_t lo_precond_build_workspace_bytes(int64_t B, int64_t N, int32_t k);
 int lo_precond_build_f32(const float* L, const float* d, int32_t diag_mode, int64_t B, int64_t N, int32_t k, float* Q,
                          float* dinv, float* logdet_p, void* ws, size_t ws_bytes, void* stream);
+/* Same with an explicit layout of L: element (member b, row i, column a) = L[b*ld_member + i*ld_row + a*ld_col].
+ * (N*k, k, 1) is the reference's [B,N,k]; (max_rank*N, 1, N) consumes the L_rows that
+ * lo_pivoted_cholesky_f32 writes without the transposed copy of _pivoted_cholesky.py:105.          */
+int lo_precond_build_strided_f32(const float* L, int64_t ld_member, int64_t ld_row, int64_t ld_col, const float* d,
+                                 int32_t diag_mode, int64_t B, int64_t N, int32_t k, float* Q, float* dinv,
+                                 float* logdet_p, void* ws, size_t ws_bytes, void* stream);
 /* z = P^{-1} r  (precondition_closure, added_diag_linear_operator.py:135-140) */
 size_t lo_precond_apply_workspace_bytes(int64_t B, int64_t N, int32_t k, int64_t c);
 int lo_precond_apply_f32(const lo_precond_desc* pre, const float* r, float* z, int64_t B, int64_t N, int64_t c, void* ws,

@@ -27,7 +27,7 @@ EXPORTS = [
     "lo_matvec_workspace_bytes", "lo_matvec_f32",
     "lo_cg_workspace_bytes", "lo_cg_solve_f32", "lo_cg_set_onchip",
     "lo_pivoted_cholesky_workspace_bytes", "lo_pivoted_cholesky_f32",
-    "lo_precond_build_workspace_bytes", "lo_precond_build_f32",
+    "lo_precond_build_workspace_bytes", "lo_precond_build_f32", "lo_precond_build_strided_f32",
     "lo_precond_apply_workspace_bytes", "lo_precond_apply_f32",
     "lo_lanczos_workspace_bytes", "lo_lanczos_tridiag_f32",
     "lo_tridiag_eigh_slq_workspace_bytes", "lo_tridiag_eigh_slq_f32",
@@ -108,6 +108,10 @@ def load():
     lib.lo_precond_build_f32.restype = C.c_int
     lib.lo_precond_build_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p]
+    lib.lo_precond_build_strided_f32.restype = C.c_int
+    lib.lo_precond_build_strided_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32,
+                                                 C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, sz, C.c_void_p]
     lib.lo_precond_apply_workspace_bytes.restype = sz
     lib.lo_precond_apply_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int64]
     lib.lo_precond_apply_f32.restype = C.c_int

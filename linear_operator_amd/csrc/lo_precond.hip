@@ -10,6 +10,7 @@
 // apply is z = r o dinv - Q (Q^T r) in both cases.
 // Output Q is written with the zero-padded row stride ldq = 4 * pow2 >= k that the skinny kernels read.
 #include <algorithm>
+#include <stdint.h>
 
 #include "lo_device.h"
 #include "lo_internal.h"
@@ -20,9 +21,16 @@ constexpr int kPbRows = 32;   // rows staged per step
 constexpr int kPbMaxK = 32;
 
 // partial Gram matrices: gpart[b,s,k,k] (fp64) = sum_{rows in slice} w w^T ; logd_part[b,s] = sum log d
-__global__ __launch_bounds__(kThreads) void k_pb_gram(const float* __restrict__ L, const float* __restrict__ dd,
-                                                       int diag_mode, int N, int k, int rows_per,
-                                                       double* __restrict__ gpart, double* __restrict__ logd_part) {
+// L element (member b, row i, column a) = L[b * ls.member + i * ls.row + a * ls.col]: [B,N,k] (reference layout)
+// or the [B, max_rank, N] rows the pivoted-Cholesky kernels write (no transposed copy needed)
+struct LStride {
+  int64_t member, row, col;
+};
+
+__global__ __launch_bounds__(kThreads) void k_pb_gram(const float* __restrict__ L, LStride ls,
+                                                       const float* __restrict__ dd, int diag_mode, int N, int k,
+                                                       int rows_per, double* __restrict__ gpart,
+                                                       double* __restrict__ logd_part) {
   __shared__ float w_s[kPbRows][kPbMaxK + 1];
   __shared__ float sc_s[kPbRows];
   __shared__ double redd[4];
@@ -45,9 +53,17 @@ __global__ __launch_bounds__(kThreads) void k_pb_gram(const float* __restrict__ 
       sc_s[threadIdx.x] = (float)sc;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < nr * k; e += kThreads) {
-      const int rr = e / k, a = e % k;
-      w_s[rr][a] = L[((size_t)b * N + base + rr) * k + a] * sc_s[rr];
+    const float* Lb = L + (size_t)b * ls.member;
+    if (ls.row == 1) {  // rows layout: consecutive threads take consecutive rows of one column
+      for (int e = threadIdx.x; e < kPbRows * k; e += kThreads) {
+        const int a = e / kPbRows, rr = e % kPbRows;
+        if (rr < nr) w_s[rr][a] = Lb[(size_t)a * ls.col + base + rr] * sc_s[rr];
+      }
+    } else {
+      for (int e = threadIdx.x; e < nr * k; e += kThreads) {
+        const int rr = e / k, a = e % k;
+        w_s[rr][a] = Lb[(size_t)(base + rr) * ls.row + (size_t)a * ls.col] * sc_s[rr];
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -133,8 +149,9 @@ __global__ __launch_bounds__(64) void k_pb_chol(const double* __restrict__ gpart
 
 // Q[row, j] = scale_row * sum_{a<=j} M[j][a] w[a]
 template <int KM>
-__global__ __launch_bounds__(kThreads) void k_pb_q(const float* __restrict__ L, const float* __restrict__ dd,
-                                                    int diag_mode, int N, int k, int ldq, int rows_per,
+__global__ __launch_bounds__(kThreads) void k_pb_q(const float* __restrict__ L, LStride ls,
+                                                    const float* __restrict__ dd, int diag_mode, int N, int k,
+                                                    int ldq, int rows_per,
                                                     const double* __restrict__ Minv, float* __restrict__ Q,
                                                     float* __restrict__ dinv) {
   __shared__ double M[kPbMaxK][kPbMaxK + 1];
@@ -152,9 +169,10 @@ __global__ __launch_bounds__(kThreads) void k_pb_q(const float* __restrict__ L, 
       sc = 1.0 / sqrt(dv);
       dinv[(size_t)b * N + row] = (float)(1.0 / dv);
     }
-    const float* lr = L + ((size_t)b * N + row) * k;
+    const float* lr = L + (size_t)b * ls.member + (size_t)row * ls.row;
 #pragma unroll
-    for (int a = 0; a < KM; ++a) w[a] = (a < k) ? (double)lr[a] * ((diag_mode == LO_DIAG_FULL) ? sc : 1.0) : 0.0;
+    for (int a = 0; a < KM; ++a)
+      w[a] = (a < k) ? (double)lr[(size_t)a * ls.col] * ((diag_mode == LO_DIAG_FULL) ? sc : 1.0) : 0.0;
     float* qr = Q + ((size_t)b * N + row) * ldq;
 #pragma unroll
     for (int j = 0; j < KM; ++j) {
@@ -167,6 +185,157 @@ __global__ __launch_bounds__(kThreads) void k_pb_q(const float* __restrict__ L, 
       }
     }
     for (int j = k; j < ldq; ++j) qr[j] = 0.f;
+  }
+}
+
+// ---- fp64 matrix-core versions for the rows layout (ls.row == 1) and k <= 16 -------------------------------
+// v_mfma_f64_16x16x4_f64 (layout probed on gfx950, tools/probe/mfma_f64_layout.hip): lane l supplies
+// A[i = l % 16][kk = l / 16] and B[kk = l / 16][j = l % 16]; result register r of lane l is D[4 r + l / 16][l % 16].
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// per-row quantities of the non-constant diagonal, once: sc = 1/sqrt(d) (fp64, rounded to fp32), dinv = 1/d,
+// logd_part[b,s] = sum log d (fp64)
+__global__ __launch_bounds__(kThreads) void k_pb_scale(const float* __restrict__ dd, int N, int rows_per,
+                                                        float* __restrict__ sc, float* __restrict__ dinv,
+                                                        double* __restrict__ logd_part) {
+  __shared__ double redd[4];
+  const int s = blockIdx.x, S = gridDim.x;
+  const int64_t b = blockIdx.y;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  double lacc = 0.0;
+  for (int row = r0 + threadIdx.x; row < r1; row += kThreads) {
+    const double dv = (double)dd[(size_t)b * N + row];
+    sc[(size_t)b * N + row] = (float)(1.0 / sqrt(dv));
+    dinv[(size_t)b * N + row] = (float)(1.0 / dv);
+    lacc += log(dv);
+  }
+  const double v = wave_sum_d(lacc);
+  if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) logd_part[b * S + s] = (redd[0] + redd[1]) + (redd[2] + redd[3]);
+}
+
+// G partial = W^T W over the slice, W = L o sc (fp32 product, as k_pb_gram), accumulated in fp64 on the matrix
+// cores: one MFMA consumes 4 rows, A and B operand of a lane are the SAME value w[row][a = l % 16].
+// A wave takes 32-row chunks: lane (a, kk) loads rows chunk + 8 kk .. + 7 of column a (two 16-byte loads).
+__global__ __launch_bounds__(kThreads) void k_pb_gram_mfma(const float* __restrict__ L, LStride ls,
+                                                            const float* __restrict__ sc, int N, int k, int rows_per,
+                                                            double* __restrict__ gpart) {
+  __shared__ double red[4][64][4];
+  const int s = blockIdx.x, S = gridDim.x;
+  const int64_t b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int a = l & 15, kk = l >> 4;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  const float* col = L + (size_t)b * ls.member + (size_t)a * ls.col;
+  const float* scb = sc ? sc + (size_t)b * N : nullptr;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int cb = r0 + 32 * wave; cb < r1; cb += 128) {
+    const int rb = cb + 8 * kk;
+    float w[8];
+    if (cb + 32 <= r1) {  // wave-uniform: whole chunk inside the slice (rows are multiples of 4 -> aligned)
+      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+      if (a < k) {
+        x0 = *reinterpret_cast<const float4*>(col + rb);
+        x1 = *reinterpret_cast<const float4*>(col + rb + 4);
+      }
+      float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0;
+      if (scb) {
+        s0 = *reinterpret_cast<const float4*>(scb + rb);
+        s1 = *reinterpret_cast<const float4*>(scb + rb + 4);
+      }
+      w[0] = x0.x * s0.x; w[1] = x0.y * s0.y; w[2] = x0.z * s0.z; w[3] = x0.w * s0.w;
+      w[4] = x1.x * s1.x; w[5] = x1.y * s1.y; w[6] = x1.z * s1.z; w[7] = x1.w * s1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = rb + e;
+        w[e] = (a < k && row < r1) ? col[row] * (scb ? scb[row] : 1.f) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)w[e], (double)w[e], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][l][r] = acc[r];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ga = 4 * r + kk, gc = a;  // D[4 r + l / 16][l % 16]
+      if (ga < k && gc < k)
+        gpart[((size_t)b * S + s) * k * k + ga * k + gc] = (red[0][l][r] + red[1][l][r]) + (red[2][l][r] + red[3][l][r]);
+    }
+  }
+}
+
+// Q tile = W M^T on the matrix cores: 64-row chunks per wave as 4 interleaved 16-row tiles (tile t holds the rows
+// chunk + 4 i + t, so that lane (i, kk) fetches its 4 tiles' operands of column a = 4 s + kk with ONE 16-byte load).
+__global__ __launch_bounds__(kThreads) void k_pb_q_mfma(const float* __restrict__ L, LStride ls,
+                                                         const float* __restrict__ sc, const float* __restrict__ dd,
+                                                         int diag_mode, int N, int k, int ldq, int rows_per,
+                                                         const double* __restrict__ Minv, float* __restrict__ Q) {
+  const int s = blockIdx.x;
+  const int64_t b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int i = l & 15, kk = l >> 4;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  double mb[4];  // B operand of step s: M^T[4 s + kk][j = i] = M[i][4 s + kk]
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int a = 4 * st + kk;
+    mb[st] = (i < k && a < k) ? Minv[(size_t)b * k * k + i * k + a] : 0.0;
+  }
+  const float* Lb = L + (size_t)b * ls.member;
+  const float* scb = sc ? sc + (size_t)b * N : nullptr;
+  const double cs = (diag_mode == LO_DIAG_CONST) ? 1.0 / sqrt((double)dd[b]) : 1.0;
+  float* Qb = Q + (size_t)b * N * ldq;
+  for (int cb = r0 + 64 * wave; cb < r1; cb += 256) {
+    const bool full = cb + 64 <= r1;
+    const int rb = cb + 4 * i;
+    float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (scb) {
+      if (full) sv = *reinterpret_cast<const float4*>(scb + rb);
+      else {
+        sv.x = rb < r1 ? scb[rb] : 0.f; sv.y = rb + 1 < r1 ? scb[rb + 1] : 0.f;
+        sv.z = rb + 2 < r1 ? scb[rb + 2] : 0.f; sv.w = rb + 3 < r1 ? scb[rb + 3] : 0.f;
+      }
+    }
+    f64x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int a = 4 * st + kk;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a < k) {
+        const float* cp = Lb + (size_t)a * ls.col + rb;
+        if (full) x = *reinterpret_cast<const float4*>(cp);
+        else {
+          x.x = rb < r1 ? cp[0] : 0.f; x.y = rb + 1 < r1 ? cp[1] : 0.f;
+          x.z = rb + 2 < r1 ? cp[2] : 0.f; x.w = rb + 3 < r1 ? cp[3] : 0.f;
+        }
+      }
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)(x.x * sv.x), mb[st], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)(x.y * sv.y), mb[st], acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)(x.z * sv.z), mb[st], acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)(x.w * sv.w), mb[st], acc[3], 0, 0, 0);
+    }
+    // acc[t][r] = Qtile_t[4 r + kk][j = i] -> row cb + 4 (4 r + kk) + t, column j
+    if (i < ldq) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rowb = cb + 16 * r + 4 * kk;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = rowb + t;
+          if (row < r1) {
+            const double rs = scb ? (double)scb[row] : cs;
+            Qb[(size_t)row * ldq + i] = (float)(acc[t][r] * rs);
+          }
+        }
+      }
+    }
   }
 }
 
@@ -188,12 +357,20 @@ size_t lo_precond_build_workspace_bytes(int64_t B, int64_t N, int32_t k) {
   ar.take<double>((size_t)B * sp.S * k * k);
   ar.take<double>((size_t)B * sp.S);
   ar.take<double>((size_t)B * k * k);
+  ar.take<float>((size_t)B * N);  // per-row 1/sqrt(d) of the matrix-core path
   return ar.off + 1024;
 }
 
 // Q must hold [B, N, ldq] floats with ldq = 4 * pow2ceil(ceil(k/4)); dinv [B,N] (FULL) or [B] (CONST).
 int lo_precond_build_f32(const float* L, const float* d, int32_t diag_mode, int64_t B, int64_t N, int32_t k, float* Q,
                          float* dinv, float* logdet_p, void* ws, size_t ws_bytes, void* stream) {
+  return lo_precond_build_strided_f32(L, N * k, k, 1, d, diag_mode, B, N, k, Q, dinv, logdet_p, ws, ws_bytes, stream);
+}
+
+int lo_precond_build_strided_f32(const float* L, int64_t ld_member, int64_t ld_row, int64_t ld_col, const float* d,
+                                 int32_t diag_mode, int64_t B, int64_t N, int32_t k, float* Q, float* dinv,
+                                 float* logdet_p, void* ws, size_t ws_bytes, void* stream) {
+  const LStride ls{ld_member, ld_row, ld_col};
   if (!L || !d || !Q || !dinv || !logdet_p || !ws) return LO_ERR_BADARG;
   if (diag_mode != LO_DIAG_FULL && diag_mode != LO_DIAG_CONST) return LO_ERR_BADARG;
   if (k < 1 || k > kPbMaxK) return LO_ERR_UNSUPPORTED;
@@ -203,19 +380,42 @@ int lo_precond_build_f32(const float* L, const float* d, int32_t diag_mode, int6
   double* gpart = ar.take<double>((size_t)B * sp.S * k * k);
   double* logd = ar.take<double>((size_t)B * sp.S);
   double* Minv = ar.take<double>((size_t)B * k * k);
+  float* scale = ar.take<float>((size_t)B * N);
   if (!ar.ok) return LO_ERR_WORKSPACE;
   const int ldq = padded_k(k);
   dim3 grid(sp.S, (unsigned)B), block(kThreads);
+  // rows layout ([B, m, N] as the pivoted-Cholesky kernels write it), k <= 16: fp64 matrix cores, 16-byte loads
+  const bool mfma = ld_row == 1 && k <= 16 && (N % 4) == 0 && (ld_col % 4) == 0 && (ld_member % 4) == 0 &&
+                    ((uintptr_t)L % 16) == 0 && ((uintptr_t)scale % 16) == 0;
+  if (mfma) {
+    const float* sc = nullptr;
+    if (diag_mode == LO_DIAG_FULL) {
+      LO_PROF_BEGIN("pb_scale", st);
+      hipLaunchKernelGGL(k_pb_scale, grid, block, 0, st, d, (int)N, sp.rows, scale, dinv, logd);
+      LO_PROF_END(st);
+      sc = scale;
+    }
+    LO_PROF_BEGIN("pb_gram_mfma", st);
+    hipLaunchKernelGGL(k_pb_gram_mfma, grid, block, 0, st, L, ls, sc, (int)N, (int)k, sp.rows, gpart);
+    LO_PROF_END(st);
+    hipLaunchKernelGGL(k_pb_chol, dim3((unsigned)B), dim3(64), 0, st, gpart, logd, d, diag_mode, (int)N, (int)k, sp.S,
+                       Minv, logdet_p, dinv);
+    LO_PROF_BEGIN("pb_q_mfma", st);
+    hipLaunchKernelGGL(k_pb_q_mfma, grid, block, 0, st, L, ls, sc, d, diag_mode, (int)N, (int)k, ldq, sp.rows, Minv, Q);
+    LO_PROF_END(st);
+    LO_LAUNCH_CHECK();
+    return LO_OK;
+  }
   LO_PROF_BEGIN("pb_gram", st);
-  hipLaunchKernelGGL(k_pb_gram, grid, block, 0, st, L, d, diag_mode, (int)N, (int)k, sp.rows, gpart, logd);
+  hipLaunchKernelGGL(k_pb_gram, grid, block, 0, st, L, ls, d, diag_mode, (int)N, (int)k, sp.rows, gpart, logd);
   LO_PROF_END(st);
   hipLaunchKernelGGL(k_pb_chol, dim3((unsigned)B), dim3(64), 0, st, gpart, logd, d, diag_mode, (int)N, (int)k, sp.S,
                      Minv, logdet_p, dinv);
   LO_PROF_BEGIN("pb_q", st);
   if (k <= 16)
-    hipLaunchKernelGGL((k_pb_q<16>), grid, block, 0, st, L, d, diag_mode, (int)N, (int)k, ldq, sp.rows, Minv, Q, dinv);
+    hipLaunchKernelGGL((k_pb_q<16>), grid, block, 0, st, L, ls, d, diag_mode, (int)N, (int)k, ldq, sp.rows, Minv, Q, dinv);
   else
-    hipLaunchKernelGGL((k_pb_q<32>), grid, block, 0, st, L, d, diag_mode, (int)N, (int)k, ldq, sp.rows, Minv, Q, dinv);
+    hipLaunchKernelGGL((k_pb_q<32>), grid, block, 0, st, L, ls, d, diag_mode, (int)N, (int)k, ldq, sp.rows, Minv, Q, dinv);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;

@@ -245,9 +245,11 @@ def precond_apply(pre: WoodburyPreconditioner, r: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
-def pivoted_cholesky(desc: OperatorDescriptor, rank: int, error_tol: float = 1e-3):
+def pivoted_cholesky(desc: OperatorDescriptor, rank: int, error_tol: float = 1e-3, contiguous: bool = True):
     """lo_pivoted_cholesky_f32: PivotedCholesky.forward (functions/_pivoted_cholesky.py:14-105) of the
-    NON-diagonal part of `desc`.  Returns (L [*batch, N, m], permutation [*batch, N] int64)."""
+    NON-diagonal part of `desc`.  Returns (L [*batch, N, m], permutation [*batch, N] int64).
+    contiguous=False skips the transposed copy of :105 and returns L as a strided view of the [B, m, N] rows the
+    kernels write (what precond_build consumes directly)."""
     lib = _hip.load()
     dev = desc.device
     B, N = desc.B, desc.N
@@ -260,7 +262,9 @@ def pivoted_cholesky(desc: OperatorDescriptor, rank: int, error_tol: float = 1e-
     _hip.check(lib.lo_pivoted_cholesky_f32(C.byref(s), max_rank, float(error_tol), _hip.ptr(L_rows), _hip.ptr(perm),
                                            C.byref(m), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)),
                "lo_pivoted_cholesky_f32")
-    L = L_rows[:, : m.value, :].mT.contiguous()  # _pivoted_cholesky.py:105
+    L = L_rows[:, : m.value, :].mT  # _pivoted_cholesky.py:105
+    if contiguous:
+        L = L.contiguous()
     bs = tuple(desc.batch_shape)
     return L.reshape(*bs, N, m.value), perm.reshape(*bs, N)
 
@@ -278,7 +282,9 @@ def precond_build(L: torch.Tensor, d: torch.Tensor, constant_diag: bool) -> Wood
     lib = _hip.load()
     _hip.require_hip(L, d)
     N, k = L.shape[-2:]
-    L3 = _flat(L, 2)
+    L3 = L.reshape(-1, N, k)  # stays a view for the strided rows layout pivoted_cholesky(contiguous=False) returns
+    if min(L3.stride()) < 0 or L3.dtype != torch.float32:
+        L3 = L3.contiguous()
     B = L3.shape[0]
     dev = L.device
     ldq = padded_rank(k)
@@ -295,9 +301,13 @@ def precond_build(L: torch.Tensor, d: torch.Tensor, constant_diag: bool) -> Wood
         mode = _hip.LO_DIAG_FULL
     logdet = torch.empty(B, dtype=torch.float32, device=dev)
     ws = _hip.workspace(lib.lo_precond_build_workspace_bytes(B, N, k), dev)
-    _hip.check(lib.lo_precond_build_f32(_hip.ptr(L3), _hip.ptr(d2), mode, B, N, k, _hip.ptr(Q), _hip.ptr(dinv),
-                                        _hip.ptr(logdet), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)),
-               "lo_precond_build_f32")
+    sm, sr, sc = L3.stride()
+    if B == 1:
+        sm = 0
+    _hip.check(lib.lo_precond_build_strided_f32(_hip.ptr(L3), sm, sr, sc, _hip.ptr(d2), mode, B, N, k, _hip.ptr(Q),
+                                                _hip.ptr(dinv), _hip.ptr(logdet), _hip.ptr(ws), ws.numel(),
+                                                _hip.stream_ptr(dev)),
+               "lo_precond_build_strided_f32")
     return WoodburyPreconditioner(Q, dinv, k, constant_diag, logdet.reshape(L.shape[:-2]))
 
 

@@ -94,7 +94,7 @@ class AddedDiagLinearOperator(SumLinearOperator):
             return None, None, None
         if self._q_cache is None:
             max_iter = settings.max_preconditioner_size.value()
-            self._piv_chol_self = self._linear_op.pivoted_cholesky(rank=max_iter)  # :125
+            self._piv_chol_self = self._pivoted_cholesky_factor(max_iter)  # :125
             if torch.any(torch.isnan(self._piv_chol_self)).item():  # :126-131
                 warnings.warn(
                     "NaNs encountered in preconditioner computation. Attempting to continue without preconditioning.",
@@ -104,6 +104,17 @@ class AddedDiagLinearOperator(SumLinearOperator):
             self._init_cache()
         closure = WoodburyPreconditionClosure(self._woodbury, self.batch_shape)
         return closure, self._precond_lt, self._precond_logdet_cache
+
+    def _pivoted_cholesky_factor(self, max_iter):
+        """self._linear_op.pivoted_cholesky(rank=max_iter) (:125); when the operator lowers to a kernel descriptor
+        the factor stays in the [B, m, N] row layout the HIP kernels write (a strided [.., N, m] view): the
+        preconditioner build reads it in place and the transposed copy of _pivoted_cholesky.py:105 is skipped."""
+        desc = self._linear_op._kernel_descriptor()
+        if desc is None or desc.diag_mode != 0 or self.device.type != "cuda" or self.dtype != torch.float32:
+            return self._linear_op.pivoted_cholesky(rank=max_iter)
+        tol = settings.preconditioner_tolerance.value()
+        L, _ = K.pivoted_cholesky(desc, min(max_iter, self.size(-1)), float(tol), contiguous=False)
+        return L
 
     def _init_cache(self):
         L = self._piv_chol_self

@@ -250,6 +250,37 @@ def _default_precond(desc, d_t, const):
     return K.precond_build(L, d_t, constant_diag=const)
 
 
+@pytest.mark.parametrize("N,R,B", [(2048, 32, 3), (8192, 32, 4), (1500, 8, 5), (4100, 16, 2)])
+def test_preconditioner_build_rows_layout_matrix_core_path(N, R, B):
+    """lo_precond_build_strided_f32 on the [B, m, N] rows the pivoted-Cholesky kernels write (fp64 MFMA Gram and
+    Q kernels, no transposed copy) against the [B, N, k] streaming kernels and the golden reference values."""
+    C, d, rhs = cases.lowrank_diag(301 if (N, R) == (2048, 32) else 5200 + R, B, N, R, 4)
+    desc = K.lowrank_diag_descriptor(dev(C), None)
+    Lc, _ = K.pivoted_cholesky(desc, 15)
+    Lv, _ = K.pivoted_cholesky(desc, 15, contiguous=False)
+    assert not Lv.is_contiguous() and torch.equal(Lc, Lv)
+    sig = np.linspace(0.3, 1.1, B).astype(np.float32)
+    for dd, const in ((dev(d), False), (dev(sig), True)):
+        K._hip.prof_enable(True)
+        pv = K.precond_build(Lv, dd, constant_diag=const)
+        torch.cuda.synchronize()
+        prof = K._hip.prof_report()
+        K._hip.prof_enable(False)
+        assert "pb_q_mfma" in prof and "pb_gram_mfma" in prof, "matrix-core path was not taken"
+        pc = K.precond_build(Lc, dd, constant_diag=const)
+        assert pv.k == pc.k and pv.Q.shape == pc.Q.shape
+        assert np.allclose(host(pv.logdet), host(pc.logdet), rtol=1e-6)
+        assert np.allclose(host(pv.dinv), host(pc.dinv), rtol=1e-7)
+        # Q is fixed by the Cholesky factor of the SAME fp64 Gram matrix: equal up to fp64 summation order
+        assert np.allclose(host(pv.Q), host(pc.Q), rtol=1e-5, atol=1e-6)
+        zv, zc = host(K.precond_apply(pv, dev(rhs))), host(K.precond_apply(pc, dev(rhs)))
+        assert max_rel_err_cols(zv, zc) < 2e-6
+        if (N, R) == (2048, 32) and not const:
+            g = load_golden("g3_precond")
+            assert max_rel_err_cols(zv, g["z_nonconst"]) < 1e-5
+            assert np.allclose(host(pv.logdet), g["logdet_nonconst"], rtol=1e-5)
+
+
 def test_solve_lowrank_default_preconditioner():
     g = load_golden("g4_solve_lowrank")
     C, d, rhs = cases.lowrank_diag(401, 4, 2048, 32, 1)
