@@ -485,12 +485,18 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   const int kfloor0 = std::min(10, prm->max_iter - 1);
   const int oc_nwg = onchip_num_workgroups();
   const bool oc_ok = (op->kind == LO_OP_LOWRANK_DIAG) && pre && !precond_cb && !x0 && prm->n_tridiag == 0 && c == 1 &&
-                     prm->max_iter >= 11 && oc_nwg >= 64 && onchip_eligible(pl.R4, preR4, N, c) && !g_onchip_disabled;
+                     prm->max_iter >= 11 && oc_nwg >= 64 && !g_onchip_disabled &&
+                     (onchip_eligible(pl.R4, preR4, N, c) || onchip4_eligible(pl.R4, preR4, N, c));
+  // second generation (4 rows per thread, lo_cg_onchip4.hip) unless LO_OC_GEN1 asks for the first one
+  const bool oc_gen2 = oc_ok && onchip4_eligible(pl.R4, preR4, N, c) &&
+                       !(getenv("LO_OC_GEN1") && onchip_eligible(pl.R4, preR4, N, c));
   if (oc_ok) {
     OnchipArgs a;
     a.C = pl.Apad; a.Q = Qp; a.d = op->d; a.dinv = pre->dinv;
     a.d_mode = op->diag_mode; a.dinv_mode = pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL;
-    a.rhs = rhs; a.B = B; a.N = (int)N; a.RW = (int)((N + 7) / 8);
+    a.rhs = rhs; a.B = B; a.N = (int)N;
+    a.GW = oc_gen2 ? onchip4_group_size(N) : 8;
+    a.RW = (int)((N + a.GW - 1) / a.GW);
     a.iters = kfloor0 + 1;
     a.eps = prm->eps; a.stop_after = prm->stop_updating_after;
     a.x = d.x; a.r = d.r; a.p = d.p; a.z = d.z;
@@ -503,10 +509,16 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     const bool oc_dbg = getenv("LO_OC_DEBUG") != nullptr && B >= 8;
     a.dbg = oc_dbg ? reinterpret_cast<long long*>(d.oc_resid + (size_t)B * 12) : nullptr;
     a.dbg_member = oc_dbg ? atoi(getenv("LO_OC_DEBUG")) : 0;  // LO_OC_DEBUG=<member index to time>
-    LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(oc_nwg / 8), st));
+    LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(64), st));  // whole allocation (either generation)
     LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 0, sizeof(int), st));
     if (oc_dbg) LO_HIP_CHECK(hipMemsetAsync(a.dbg, 0, 10 * sizeof(long long), st));
-    rc = onchip_launch(pl.R4, preR4, a, oc_nwg, st);
+    rc = LO_ERR_UNSUPPORTED;
+    if (oc_gen2) rc = onchip4_launch(pl.R4, preR4, a, oc_nwg, st);
+    if (rc == LO_ERR_UNSUPPORTED && onchip_eligible(pl.R4, preR4, N, c)) {
+      a.GW = 8;
+      a.RW = (int)((N + 7) / 8);
+      rc = onchip_launch(pl.R4, preR4, a, oc_nwg, st);
+    }
     if (rc) return rc;
     hipLaunchKernelGGL(k_cg_ctrl_onchip, dim3(1), block, 0, st, d, d.oc_resid, d.oc_init_conv, a.iters);
     LO_LAUNCH_CHECK();

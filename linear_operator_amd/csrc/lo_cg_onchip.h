@@ -15,6 +15,7 @@ struct OnchipArgs {
   const float* rhs;   // [B, N]
   int64_t B;
   int N, RW;          // rows per workgroup
+  int GW;             // workgroups per member (group size): 8 (first generation), 4 or 8 (second)
   int iters;          // iterations to run (k = 0 .. iters-1)
   float eps, stop_after;
   // state out (streaming engine layout, c == 1)
@@ -33,5 +34,6 @@ struct OnchipArgs {
 };
 
 int onchip_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st);
+int onchip4_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st);
 
 }  // namespace lo

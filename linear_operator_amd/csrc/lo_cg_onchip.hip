@@ -37,54 +37,6 @@ constexpr int OC_WAVES = OC_TPB / 64;
 constexpr unsigned OC_MAXSPIN = 1u << 22;
 
 
-// ---- wave64 reduce-scatter primitives -------------------------------------------------------------
-// One halving step over lane bit M: every lane holds `lo` (a component it keeps if its bit M is clear) and `hi`
-// (kept if the bit is set); returns own kept value + the partner lane's value of the same component.
-// gfx950 cross-lane hardware, no LDS crossbar (ds_bpermute) except for M == 4:
-//   M = 32 / 16 : v_permlane32_swap / v_permlane16_swap  (upper half-rows of `lo` swap with lower half-rows of `hi`;
-//                 afterwards lo' + hi' is exactly keep + partner's send in every lane)
-//   M = 8       : DPP row_ror:8     M = 2, 1 : DPP quad_perm     M = 4 : ds_swizzle SWAP,4
-template <int M>
-__device__ __forceinline__ float xor_lane(float v) {
-  if constexpr (M == 8) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
-  else if constexpr (M == 4) return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101f));
-  else if constexpr (M == 2) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));
-  else return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false));
-}
-
-template <int M>
-__device__ __forceinline__ float halve_pair(float lo, float hi, int lane) {
-  if constexpr (M == 32) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  } else if constexpr (M == 16) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  } else {
-    const bool up = (lane & M) != 0;
-    const float keep = up ? hi : lo;
-    const float send = up ? lo : hi;
-    return keep + xor_lane<M>(send);
-  }
-}
-
-// Recursive-halving tail, fully compile-time indexed (runtime-indexed register arrays would go to scratch):
-// v holds CNT live values; the step over lane bit M keeps the half selected by that bit and adds the partner's.
-template <int CNT, int M, int NV>
-__device__ __forceinline__ void halving_steps(float (&v)[NV], int lane) {
-  if constexpr (M >= 1) {
-    if constexpr (CNT > 1) {
-      constexpr int half = CNT / 2;
-#pragma unroll
-      for (int j = 0; j < half; ++j) v[j] = halve_pair<M>(v[j], v[j + half], lane);
-      halving_steps<half, M / 2, NV>(v, lane);
-    } else {
-      v[0] = halve_pair<M>(v[0], v[0], lane) ;
-      halving_steps<1, M / 2, NV>(v, lane);
-    }
-  }
-}
-
 // Wave reduce-scatter of the products a[j] * s with the operand row in LDS (read as float4): on exit lane l holds
 // the sum over the 64 lanes of component (l >> (6 - log2 n)).  The first halving step forms the products on the
 // fly, so only n/2 temporaries are live.  Used for the C row, which lives in LDS so that its 32 floats do not

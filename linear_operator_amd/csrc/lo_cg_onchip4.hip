@@ -1,0 +1,470 @@
+// lo_cg_onchip4.hip -- second generation of the operator-resident preconditioned CG (see lo_cg_onchip.hip for the
+// algorithm, the granule hand-off and the reference citations; the arithmetic is identical).
+//
+// What limits the first generation is not HBM and not the hand-off latency but VALU issue: with one operator row
+// per thread, the per-thread overhead of every inner product (wave reduce-scatter, scalar butterflies, ~250
+// instructions) is paid once per ROW, a member occupies 8 CUs, and while a group waits for a hand-off (two per
+// iteration, ~1 us each) its CUs idle.  Here a thread owns FOUR rows and TWO workgroups share a CU:
+//   * workgroup = 256 threads x 4 rows = 1024 rows; a member of N <= 8192 rows is a group of 8 workgroups but only
+//     4 CUs' worth of resources, so 64 members are in flight instead of 32 (groups of 4 / 16 for N <= 4096 /
+//     16384); the two workgroups resident on a CU belong to different members, so one computes while the other
+//     waits for its hand-off;
+//   * the 4 C rows of a thread live in VGPRs (4 x 32 floats -- the register file of a CU is 512 KiB, four times
+//     its LDS), the 4 Q rows in LDS (1024 x 16 floats = 64 KiB per workgroup, 16-byte slots XOR-swizzled so that
+//     the ds_read_b128 of 16 consecutive rows is bank-conflict free without padding);
+//   * the products of the 4 rows are summed in registers BEFORE the wave reduce-scatter, so the reduction cost
+//     per row drops 4x;
+//   * one all-reduce = wave reduce-scatter -> LDS -> barrier -> the first wave sums the 4 wave partials, publishes
+//     the granules, polls the whole group's granules and sums them -> LDS -> barrier (2 barriers instead of 4).
+// Requires 2 resident workgroups per CU (256 VGPRs per lane, 66 KiB LDS each): checked on the host with the
+// occupancy API, otherwise the first generation runs.
+#include <algorithm>
+#include <stdlib.h>
+
+#include "lo_device.h"
+#include "lo_internal.h"
+#include "lo_cg_onchip.h"
+
+namespace lo {
+
+constexpr int R4_TPB = 256;
+constexpr int R4_NR = 4;                 // rows per thread
+constexpr int R4_WAVES = R4_TPB / 64;    // 4
+constexpr int R4_ROWS = R4_TPB * R4_NR;  // rows per workgroup
+constexpr int R4_MAXGW = 16;
+constexpr int R4_SLOT = 40;
+constexpr unsigned R4_MAXSPIN = 1u << 22;
+constexpr int R4_PF = 64;  // bytes between L2 prefetch touches
+
+struct alignas(16) R4Shared {
+  float red[R4_WAVES][R4_SLOT];
+  float res[R4_SLOT];
+};
+
+// physical 16-byte slot of logical slot q of Q row r (NQ slots per row)
+template <int NQ>
+__device__ __forceinline__ int q_slot(int r, int q) {
+  if constexpr (NQ == 4) return r * 4 + (q ^ ((r >> 2) & 3));
+  else if constexpr (NQ == 2) return r * 2 + (q ^ ((r >> 3) & 1));
+  else return r;
+}
+
+// wave reduce-scatter of n register values (destroyed): lane l ends with the wave sum of component l >> (6 - log2 n)
+// The components come from a generator so that only n/2 temporaries are ever live (component j and j + n/2 are
+// formed right before their first halving step).
+template <int n, class Gen>
+__device__ __forceinline__ float r4_wave_rs(Gen gen) {
+  const int lane = threadIdx.x & 63;
+  constexpr int h0 = n / 2;
+  float w[h0];
+#pragma unroll
+  for (int j = 0; j < h0; ++j) w[j] = halve_pair<32>(gen(j), gen(j + h0), lane);
+  halving_steps<h0, 16, h0>(w, lane);
+  return w[0];
+}
+
+struct R4Group {
+  unsigned long long* gslot;  // [2][GW][R4_SLOT] granules of this group
+  int wig;
+  unsigned tag;
+  int* err;
+  bool same_xcd;
+};
+
+// Second half of an all-reduce: sh.red[w][0..cnt) hold the wave partials.  Thread t < cnt sums them (fixed
+// order), publishes the granule, polls the same component of every workgroup of the group and sums those in fixed
+// order -> sh.res[t], bitwise identical in all workgroups.  Ends with a barrier.
+template <int GW>
+__device__ __forceinline__ void r4_group_sum(R4Shared& sh, int cnt, R4Group& g) {
+  const int t = threadIdx.x;
+  const unsigned tag = ++g.tag;
+  __syncthreads();
+  if (t < cnt) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < R4_WAVES; ++w) s += sh.red[w][t];
+    unsigned long long* slot = g.gslot + (size_t)(tag & 1u) * GW * R4_SLOT;
+    const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(s);
+    if (g.same_xcd)
+      __hip_atomic_store(slot + (size_t)g.wig * R4_SLOT + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+      __hip_atomic_store(slot + (size_t)g.wig * R4_SLOT + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float vals[GW];
+    unsigned spin = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int w = 0; w < GW; ++w) {
+        const unsigned long long x =
+            __hip_atomic_load(slot + (size_t)w * R4_SLOT + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = ok && ((unsigned)(x >> 32) == tag);
+        vals[w] = __uint_as_float((unsigned)(x & 0xffffffffull));
+      }
+      if (ok) break;
+      if (++spin > R4_MAXSPIN) {
+        atomicExch(g.err, 1);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < GW; ++w) tot += vals[w];
+    sh.res[t] = tot;
+  }
+  __syncthreads();
+}
+
+// all-reduce of n generated components + ns scalars over the whole group -> sh.res[0 .. n + ns)
+template <int GW, int n, class Gen>
+__device__ __forceinline__ void r4_allreduce(R4Shared& sh, Gen gen, const float* scal, int ns, R4Group& g) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  constexpr int sh_bits = (n == 32) ? 1 : (n == 16) ? 2 : (n == 8) ? 3 : 4;
+  const float mine = r4_wave_rs<n>(gen);
+  if ((lane & ((1 << sh_bits) - 1)) == 0) sh.red[wave][lane >> sh_bits] = mine;
+  for (int j = 0; j < ns; ++j) {
+    const float sv = wave_sum_fast(scal[j]);
+    if (lane == 0) sh.red[wave][n + j] = sv;
+  }
+  r4_group_sum<GW>(sh, n + ns, g);
+}
+
+template <int GW>
+__device__ __forceinline__ void r4_allreduce_scalars(R4Shared& sh, const float* scal, int ns, R4Group& g) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int j = 0; j < ns; ++j) {
+    const float sv = wave_sum_fast(scal[j]);
+    if (lane == 0) sh.red[wave][j] = sv;
+  }
+  r4_group_sum<GW>(sh, ns, g);
+}
+
+template <int RC, int RK, int GW>
+__global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
+  constexpr int NQ = RK / 4;
+  __shared__ R4Shared sh;
+  __shared__ float pf_sink[64];
+  __shared__ float4 q_s[R4_ROWS * NQ];  // Q rows of this workgroup, swizzled 16-byte slots
+  __shared__ float x_s[R4_ROWS], d_s[R4_ROWS], dinv_s[R4_ROWS];  // per-row x, d, 1/d (VGPR budget: 256 with 2 WGs per CU)
+  constexpr int gw = GW;
+  const int wg = blockIdx.x;
+  const int xcd = wg % 8, jx = wg / 8;  // block b runs on XCD b % 8: keep a group behind one L2 (speed only)
+  const int groups_per_xcd = (gridDim.x / 8) / gw;
+  const int grp = xcd * groups_per_xcd + jx / gw;
+  const int wig = jx % gw;
+  const int ngroups = groups_per_xcd * 8;
+  if (jx / gw >= groups_per_xcd) return;
+  const int t = threadIdx.x;
+  R4Group g;
+  g.gslot = a.gbuf + (size_t)grp * 2 * gw * R4_SLOT;
+  g.wig = wig;
+  g.tag = 0;
+  g.err = a.err;
+  g.same_xcd = false;
+  {  // placement check through the agent-scope path: plain-store hand-off only when the whole group shares an XCD;
+     // sum and sum of squares of the XCC ids agree with gw * id and gw * id^2 only if all ids are equal
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
+    if (t < 64) {
+      sh.red[0][0] = (float)xcc;
+      sh.red[0][1] = (float)(xcc * xcc);
+    }
+    if (t < 2 * (R4_WAVES - 1)) sh.red[1 + t / 2][t % 2] = 0.f;
+    r4_group_sum<GW>(sh, 2, g);
+    const float fx = (float)xcc;
+    g.same_xcd = (sh.res[0] == gw * fx) && (sh.res[1] == gw * fx * fx) && (a.allow_l2_handoff != 0);
+    __syncthreads();
+  }
+
+  const int row0 = wig * a.RW;
+  const int nv = max(0, min(a.RW, a.N - row0));  // rows of this workgroup
+  for (int64_t b = grp; b < a.B; b += ngroups) {
+    const bool stamp = a.dbg && b == a.dbg_member && wig == 0 && t == 0;
+    if (stamp) a.dbg[0] = wall_clock64();
+    // ---- load: C rows -> VGPRs (each thread walks its own 4 rows; the rows were pulled into L2 by the previous
+    // member's prefetch), Q rows -> LDS (coalesced, swizzled), x / d / 1/d -> LDS ----
+    float Cr[R4_NR][RC];
+    float rhsv[R4_NR];
+    bool valid[R4_NR];
+    // thread index the optimiser cannot see through: keeps the address arithmetic of the load phase from being
+    // hoisted out of the member loop (it would stay live in VGPRs during the iterations and force spills)
+    int tl = t;
+    asm volatile("" : "+v"(tl));
+#pragma unroll
+    for (int q = 0; q < R4_NR; ++q) {
+      const int lr = tl + R4_TPB * q;
+      valid[q] = lr < nv;
+      const size_t grow = (size_t)b * a.N + row0 + lr;
+      float dq = 0.f, diq = 0.f;
+      rhsv[q] = 0.f;
+      if (valid[q]) {
+        const float4* cp = reinterpret_cast<const float4*>(a.C + grow * RC);
+#pragma unroll
+        for (int i = 0; i < RC / 4; ++i) {
+          const float4 c4 = cp[i];
+          Cr[q][4 * i] = c4.x; Cr[q][4 * i + 1] = c4.y; Cr[q][4 * i + 2] = c4.z; Cr[q][4 * i + 3] = c4.w;
+        }
+        dq = (a.d_mode == LO_DIAG_FULL) ? a.d[grow] : (a.d_mode == LO_DIAG_CONST ? a.d[b] : 0.f);
+        diq = (a.dinv_mode == LO_DIAG_FULL) ? a.dinv[grow] : a.dinv[b];
+        rhsv[q] = a.rhs[grow];
+      } else {
+#pragma unroll
+        for (int i = 0; i < RC; ++i) Cr[q][i] = 0.f;
+      }
+      d_s[lr] = dq;
+      dinv_s[lr] = diq;
+      x_s[lr] = 0.f;
+    }
+    {  // Q rows -> LDS, coalesced and swizzled, one row-slot group (R4_NR float4 per thread) at a time: the loads
+       // in flight stay within the VGPR budget next to the 128 registers of C
+      const float4* qsrc = reinterpret_cast<const float4*>(a.Q + ((size_t)b * a.N + row0) * RK);
+#pragma unroll
+      for (int i0 = 0; i0 < R4_NR * NQ; i0 += R4_NR) {
+        float4 v[R4_NR];
+#pragma unroll
+        for (int i = 0; i < R4_NR; ++i) {
+          const int f = (i0 + i) * R4_TPB + tl;
+          v[i] = (f / NQ < nv) ? qsrc[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < R4_NR; ++i) {
+          const int f = (i0 + i) * R4_TPB + tl;
+          q_s[q_slot<NQ>(f / NQ, f % NQ)] = v[i];
+        }
+      }
+    }
+    __syncthreads();
+    if (stamp) a.dbg[1] = wall_clock64();
+
+    // ---- initialisation (linear_cg.py:177-215) ----
+    float sc[2];
+    sc[0] = 0.f;
+#pragma unroll
+    for (int q = 0; q < R4_NR; ++q) sc[0] = fmaf(rhsv[q], rhsv[q], sc[0]);
+    r4_allreduce_scalars<GW>(sh, sc, 1, g);
+    float nrm = sqrtf(sh.res[0]);                           // rhs.norm(2, dim=-2)          :177
+    const bool rhs_zero = nrm < a.eps;                      // :178
+    if (rhs_zero) nrm = 1.0f;                               // :179
+    float r[R4_NR], p[R4_NR], z[R4_NR];
+#pragma unroll
+    for (int q = 0; q < R4_NR; ++q) {
+      r[q] = rhsv[q] / nrm;                                 // :182 (x0 = 0 -> residual = rhs)
+    }
+    // Q^T r, ||r||^2, sum r^2/d; z = r/d - Q (Q^T r)  (precondition_closure :135-140)
+    float rr, rz, rn;
+    bool conv;
+    auto precond = [&](float& rz_out) {
+      float u[RK];
+#pragma unroll
+      for (int j = 0; j < RK; ++j) u[j] = 0.f;
+      float s2[2] = {0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < R4_NR; ++q) {
+        const int lr = t + R4_TPB * q;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          const float4 q4 = q_s[q_slot<NQ>(lr, i)];
+          u[4 * i] = fmaf(q4.x, r[q], u[4 * i]);
+          u[4 * i + 1] = fmaf(q4.y, r[q], u[4 * i + 1]);
+          u[4 * i + 2] = fmaf(q4.z, r[q], u[4 * i + 2]);
+          u[4 * i + 3] = fmaf(q4.w, r[q], u[4 * i + 3]);
+        }
+        s2[0] = fmaf(r[q], r[q], s2[0]);
+        s2[1] = fmaf(dinv_s[lr] * r[q], r[q], s2[1]);
+      }
+      r4_allreduce<GW, RK>(sh, [&](int j) { return u[j]; }, s2, 2, g);
+      rr = sh.res[RK];
+      float uu = 0.f;
+#pragma unroll
+      for (int j = 0; j < RK; ++j) uu = fmaf(sh.res[j], sh.res[j], uu);
+#pragma unroll
+      for (int q = 0; q < R4_NR; ++q) {
+        const int lr = t + R4_TPB * q;
+        float zq = dinv_s[lr] * r[q];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          const float4 q4 = q_s[q_slot<NQ>(lr, i)];
+          const float4 u4 = *reinterpret_cast<const float4*>(&sh.res[4 * i]);
+          zq = fmaf(-q4.x, u4.x, zq);
+          zq = fmaf(-q4.y, u4.y, zq);
+          zq = fmaf(-q4.z, u4.z, zq);
+          zq = fmaf(-q4.w, u4.w, zq);
+        }
+        z[q] = zq;
+      }
+      // r.z = sum r o (r/d - Q u) = sum r^2/d - ||Q^T r||^2   (residual_inner_prod :215 / :35-36)
+      rz_out = sh.res[RK + 1] - uu;
+    };
+    precond(rz);
+    conv = sqrtf(rr) < a.stop_after;                        // :204-205
+    if (wig == 0 && t == 0) a.init_conv[b] = conv ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < R4_NR; ++q) p[q] = z[q];
+    float beta = 0.f, alpha = 0.f;
+    rn = sqrtf(rr);
+
+    // L2 prefetch plan for the next member of this group (one slice per iteration, see lo_cg_onchip.hip)
+    int pf_lines = 0, pf_chunk = 0, pf_lc = 0, pf_lq = 0, pf_lv = 0;
+    const char *pf_c = nullptr, *pf_q = nullptr, *pf_v0 = nullptr, *pf_v1 = nullptr, *pf_v2 = nullptr;
+    if (a.prefetch && b + ngroups < a.B && a.iters > 0) {
+      const int64_t nb = b + ngroups;
+      pf_lc = (nv * RC * 4) / R4_PF;
+      pf_lq = (nv * RK * 4) / R4_PF;
+      pf_lv = (nv * 4) / R4_PF;
+      pf_c = reinterpret_cast<const char*>(a.C + ((size_t)nb * a.N + row0) * RC);
+      pf_q = reinterpret_cast<const char*>(a.Q + ((size_t)nb * a.N + row0) * RK);
+      pf_v0 = reinterpret_cast<const char*>(a.rhs + (size_t)nb * a.N + row0);
+      int nvec = 1;
+      if (a.d_mode == LO_DIAG_FULL) {
+        pf_v1 = reinterpret_cast<const char*>(a.d + (size_t)nb * a.N + row0);
+        nvec = 2;
+        if (a.dinv_mode == LO_DIAG_FULL) {
+          pf_v2 = reinterpret_cast<const char*>(a.dinv + (size_t)nb * a.N + row0);
+          nvec = 3;
+        }
+      } else if (a.dinv_mode == LO_DIAG_FULL) {
+        pf_v1 = reinterpret_cast<const char*>(a.dinv + (size_t)nb * a.N + row0);
+        nvec = 2;
+      }
+      pf_lines = pf_lc + pf_lq + nvec * pf_lv;
+      pf_chunk = (pf_lines + a.iters - 1) / a.iters;
+    }
+
+    if (stamp) a.dbg[2] = wall_clock64();
+    for (int k = 0; k < a.iters; ++k) {
+      if (k > 0) {
+#pragma unroll
+        for (int q = 0; q < R4_NR; ++q) p[q] = fmaf(p[q], beta, z[q]);  // p.mul_(beta).add_(z)  :46
+      }
+      {  // t = C^T p and sum d p^2
+        sc[0] = 0.f;
+#pragma unroll
+        for (int q = 0; q < R4_NR; ++q) sc[0] = fmaf(d_s[t + R4_TPB * q] * p[q], p[q], sc[0]);
+        r4_allreduce<GW, RC>(
+            sh,
+            [&](int c) {
+              float v = Cr[0][c] * p[0];
+#pragma unroll
+              for (int q = 1; q < R4_NR; ++q) v = fmaf(Cr[q][c], p[q], v);
+              return v;
+            },
+            sc, 1, g);
+      }
+      if (pf_lines > 0) {
+        const int hi = min(pf_lines, (k + 1) * pf_chunk);
+        for (int line = k * pf_chunk + t; line < hi; line += R4_TPB) {
+          const char* src;
+          if (line < pf_lc) src = pf_c + (size_t)line * R4_PF;
+          else if (line < pf_lc + pf_lq) src = pf_q + (size_t)(line - pf_lc) * R4_PF;
+          else {
+            const int vv = (line - pf_lc - pf_lq) / pf_lv, o = (line - pf_lc - pf_lq) % pf_lv;
+            src = (vv == 0 ? pf_v0 : vv == 1 ? pf_v1 : pf_v2) + (size_t)o * R4_PF;
+          }
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)pf_sink, 4, 0, 0);
+        }
+      }
+      // A p = C t + d o p (added_diag_linear_operator.py:72-76); p.Ap = ||C^T p||^2 + sum d p^2 (:250-251)
+      float y[R4_NR];
+#pragma unroll
+      for (int q = 0; q < R4_NR; ++q) y[q] = d_s[t + R4_TPB * q] * p[q];
+      float tt = 0.f;
+#pragma unroll
+      for (int i = 0; i < RC; i += 4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(&sh.res[i]);
+        tt = fmaf(t4.x, t4.x, tt);
+        tt = fmaf(t4.y, t4.y, tt);
+        tt = fmaf(t4.z, t4.z, tt);
+        tt = fmaf(t4.w, t4.w, tt);
+#pragma unroll
+        for (int q = 0; q < R4_NR; ++q) {
+          y[q] = fmaf(Cr[q][i], t4.x, y[q]);
+          y[q] = fmaf(Cr[q][i + 1], t4.y, y[q]);
+          y[q] = fmaf(Cr[q][i + 2], t4.z, y[q]);
+          y[q] = fmaf(Cr[q][i + 3], t4.w, y[q]);
+        }
+      }
+      const float pAp = tt + sh.res[RC];
+      alpha = (pAp < a.eps) ? 0.f : rz / pAp;               // :254-257
+      if (conv) alpha = 0.f;                                // :260
+#pragma unroll
+      for (int q = 0; q < R4_NR; ++q) {
+        r[q] = fmaf(-alpha, y[q], r[q]);                    // :264
+        x_s[t + R4_TPB * q] = fmaf(alpha, p[q], x_s[t + R4_TPB * q]);  // :31
+      }
+      float rzn;
+      precond(rzn);                                         // z = P^{-1} r, ||r||^2, r.z
+      beta = (rz < a.eps) ? 0.f : rzn / rz;                 // :39-42
+      rz = rzn;
+      rn = sqrtf(rr);                                       // :298
+      if (rhs_zero) rn = 0.f;                               // :299
+      conv = rn < a.stop_after;                             // :300
+      if (wig == 0 && t == 0) a.resid_rec[(size_t)k * a.B + b] = rn;
+    }
+
+    if (stamp) a.dbg[3] = wall_clock64();
+    // ---- write the state back in the streaming engine's layout ----
+#pragma unroll
+    for (int q = 0; q < R4_NR; ++q) {
+      if (valid[q]) {
+        const size_t o = (size_t)b * a.N + row0 + t + R4_TPB * q;
+        a.x[o] = x_s[t + R4_TPB * q];
+        a.r[o] = r[q];
+        a.p[o] = p[q];
+        a.z[o] = z[q];
+      }
+    }
+    if (wig == 0 && t == 0) {
+      a.rhs_norm[b] = nrm;
+      a.rhs_is_zero[b] = rhs_zero ? 1 : 0;
+      a.rz[b] = rz;
+      a.alpha[b] = alpha;
+      a.beta[b] = beta;
+      a.resid_norm[b] = rn;
+      a.has_conv[b] = conv ? 1 : 0;
+    }
+    __syncthreads();  // q_s / sh reuse by the next member
+    if (stamp) a.dbg[4] = wall_clock64();
+  }
+}
+
+bool onchip4_eligible(int RC, int RK, int64_t N, int64_t c) {
+  const bool rc_ok = (RC == 8 || RC == 16 || RC == 32);
+  const bool rk_ok = (RK == 4 || RK == 8 || RK == 16);
+  return rc_ok && rk_ok && c == 1 && N >= 1024 && N <= (int64_t)R4_MAXGW * R4_ROWS;
+}
+
+int onchip4_group_size(int64_t N) { return N <= 8 * (int64_t)R4_ROWS ? 8 : 16; }
+
+template <int RC, int RK, int GW>
+static int onchip4_go(const OnchipArgs& a, int nwg, hipStream_t st) {
+  // the spin-waiting groups need ALL workgroups resident: two per CU
+  int per_cu = 0;
+  const bool half = getenv("LO_OC_HALF") != nullptr;  // debugging: one workgroup per CU
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_onchip4<RC, RK, GW>, R4_TPB, 0) != hipSuccess ||
+      per_cu < (half ? 1 : 2))
+    return LO_ERR_UNSUPPORTED;
+  LO_PROF_BEGIN("cg_onchip", st);
+  hipLaunchKernelGGL((k_cg_onchip4<RC, RK, GW>), dim3(half ? nwg : 2 * nwg), dim3(R4_TPB), 0, st, a);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+// nwg = number of CUs used (multiple of 64); 2 * nwg workgroups are launched.  LO_ERR_UNSUPPORTED when two
+// workgroups do not fit on a CU (the caller then runs the first generation).
+int onchip4_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st) {
+#define LO_OC(C_, K_) return a.GW == 8 ? onchip4_go<C_, K_, 8>(a, nwg, st) : onchip4_go<C_, K_, 16>(a, nwg, st)
+  if (RC == 32 && RK == 16) LO_OC(32, 16);
+  else if (RC == 32 && RK == 8) LO_OC(32, 8);
+  else if (RC == 32 && RK == 4) LO_OC(32, 4);
+  else if (RC == 16 && RK == 16) LO_OC(16, 16);
+  else if (RC == 16 && RK == 8) LO_OC(16, 8);
+  else if (RC == 16 && RK == 4) LO_OC(16, 4);
+  else if (RC == 8 && RK == 16) LO_OC(8, 16);
+  else if (RC == 8 && RK == 8) LO_OC(8, 8);
+  else if (RC == 8 && RK == 4) LO_OC(8, 4);
+#undef LO_OC
+  return LO_ERR_UNSUPPORTED;
+}
+
+}  // namespace lo

@@ -171,6 +171,8 @@ struct OnchipArgs;
 size_t onchip_gbuf_bytes(int ngroups);
 bool onchip_eligible(int RC, int RK, int64_t N, int64_t c);
 int onchip_num_workgroups();
+bool onchip4_eligible(int RC, int RK, int64_t N, int64_t c);  // lo_cg_onchip4.hip
+int onchip4_group_size(int64_t N);
 extern bool g_onchip_disabled;  // lo_cg_set_onchip(0): streaming engines only (tests compare the two)
 
 // ---- operator-resident pivoted Cholesky (lo_pivchol_onchip.hip) ----------------------------------
