@@ -529,8 +529,8 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     if (oc_dbg) {
       long long ts[10];
       LO_HIP_CHECK(hipMemcpy(ts, a.dbg, sizeof(ts), hipMemcpyDeviceToHost));
-      fprintf(stderr, "onchip member0 (100 MHz ticks): load %lld init %lld iters %lld store %lld\n", ts[1] - ts[0],
-              ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3]);
+      fprintf(stderr, "onchip member0 (100 MHz ticks): load %lld init %lld iters %lld store %lld | wg-wait %lld publish %lld poll %lld\n",
+              ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5], ts[6], ts[7]);
     }
     if (oc_err == 0) {
       k_start = a.iters;

@@ -66,6 +66,7 @@ __device__ __forceinline__ float r4_wave_rs(Gen gen) {
 struct R4Group {
   unsigned long long* gslot;  // [2][GW][R4_SLOT] granules of this group
   int wig;
+  long long* dbg;  // phase timers of the stamped member (or nullptr)
   unsigned tag;
   int* err;
   bool same_xcd;
@@ -78,7 +79,11 @@ template <int GW>
 __device__ __forceinline__ void r4_group_sum(R4Shared& sh, int cnt, R4Group& g) {
   const int t = threadIdx.x;
   const unsigned tag = ++g.tag;
+  long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  const bool stamp = g.dbg && t == 0;
+  if (stamp) c0 = wall_clock64();
   __syncthreads();
+  if (stamp) c1 = wall_clock64();
   if (t < cnt) {
     float s = 0.f;
 #pragma unroll
@@ -89,6 +94,7 @@ __device__ __forceinline__ void r4_group_sum(R4Shared& sh, int cnt, R4Group& g) 
       __hip_atomic_store(slot + (size_t)g.wig * R4_SLOT + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else
       __hip_atomic_store(slot + (size_t)g.wig * R4_SLOT + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (stamp) c2 = wall_clock64();
     float vals[GW];
     unsigned spin = 0;
     for (;;) {
@@ -111,6 +117,12 @@ __device__ __forceinline__ void r4_group_sum(R4Shared& sh, int cnt, R4Group& g) 
 #pragma unroll
     for (int w = 0; w < GW; ++w) tot += vals[w];
     sh.res[t] = tot;
+    if (stamp) {
+      c3 = wall_clock64();
+      g.dbg[5] += c1 - c0;  // waiting for the slowest wave of this workgroup
+      g.dbg[6] += c2 - c1;  // wave-partial sum + publish
+      g.dbg[7] += c3 - c2;  // poll + sum
+    }
   }
   __syncthreads();
 }
@@ -158,6 +170,7 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
   R4Group g;
   g.gslot = a.gbuf + (size_t)grp * 2 * gw * R4_SLOT;
   g.wig = wig;
+  g.dbg = nullptr;
   g.tag = 0;
   g.err = a.err;
   g.same_xcd = false;
@@ -329,7 +342,10 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
       pf_chunk = (pf_lines + a.iters - 1) / a.iters;
     }
 
-    if (stamp) a.dbg[2] = wall_clock64();
+    if (stamp) {
+      a.dbg[2] = wall_clock64();
+      g.dbg = a.dbg;
+    }
     for (int k = 0; k < a.iters; ++k) {
       if (k > 0) {
 #pragma unroll
@@ -402,6 +418,7 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
     }
 
     if (stamp) a.dbg[3] = wall_clock64();
+    g.dbg = nullptr;
     // ---- write the state back in the streaming engine's layout ----
 #pragma unroll
     for (int q = 0; q < R4_NR; ++q) {

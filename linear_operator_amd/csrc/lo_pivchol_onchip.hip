@@ -325,6 +325,274 @@ __global__ __launch_bounds__(PO_TPB) void k_pc_onchip(PoArgs a) {
   }
 }
 
+// ---- second generation: 4 rows per thread, two workgroups per CU (same idea as lo_cg_onchip4.hip) -------------
+// Workgroup = 256 threads x 4 rows; the 4 C rows of a thread live in VGPRs, the L rows of the workgroup in LDS
+// (1024 x 16 floats, 16-byte slots XOR-swizzled), so the pivot index is a run-time value and the pivot loop is a
+// plain loop.  A member is a group of GW = 8 (N <= 8192) or 16 (N <= 16384) workgroups; two workgroups of
+// different members share a CU, one updates its rows while the other waits for its exchange.  Arithmetic and
+// operation order per row are those of the first generation, hence bit-identical results.
+constexpr int P4_TPB = 256;
+constexpr int P4_NR = 4;
+constexpr int P4_WAVES = P4_TPB / 64;
+constexpr int P4_ROWS = P4_TPB * P4_NR;
+
+template <int GW>
+struct alignas(16) P4Shared {
+  float wv[P4_WAVES];
+  int wj[P4_WAVES];
+  float we[P4_WAVES];
+  int pad[4];
+  unsigned part[PO_SLOT];
+  unsigned gath[GW][PO_SLOT];
+};
+
+__device__ __forceinline__ int l_slot(int r, int q) { return r * 4 + (q ^ ((r >> 2) & 3)); }
+
+// thread t < cnt publishes sh.part[t] and fetches component t of every workgroup of the group into sh.gath
+template <int GW>
+__device__ __forceinline__ void p4_gather(P4Shared<GW>& sh, int cnt, unsigned long long* gslot_base, int wig,
+                                          unsigned tag, int* err, bool same_xcd) {
+  const int t = threadIdx.x;
+  __syncthreads();  // sh.part complete
+  if (t < cnt) {
+    unsigned long long* slot = gslot_base + (size_t)(tag & 1u) * GW * PO_SLOT;
+    const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned long long)sh.part[t];
+    if (same_xcd)
+      __hip_atomic_store(slot + (size_t)wig * PO_SLOT + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+      __hip_atomic_store(slot + (size_t)wig * PO_SLOT + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned vals[GW];
+    unsigned spin = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int w = 0; w < GW; ++w) {
+        const unsigned long long x =
+            __hip_atomic_load(slot + (size_t)w * PO_SLOT + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = ok && ((unsigned)(x >> 32) == tag);
+        vals[w] = (unsigned)(x & 0xffffffffull);
+      }
+      if (ok) break;
+      if (++spin > PO_MAXSPIN) {
+        atomicExch(err, 1);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int w = 0; w < GW; ++w) sh.gath[w][t] = vals[w];
+  }
+  __syncthreads();
+}
+
+template <int RC, int GW>
+__global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
+  __shared__ P4Shared<GW> sh;
+  __shared__ float4 l_s[P4_ROWS * 4];  // L rows (16 floats) of this workgroup, swizzled 16-byte slots
+  const int wg = blockIdx.x;
+  const int xcd = wg % 8, jx = wg / 8;
+  const int groups_per_xcd = (gridDim.x / 8) / GW;
+  const int grp = xcd * groups_per_xcd + jx / GW;
+  const int wig = jx % GW;
+  const int ngroups = groups_per_xcd * 8;
+  if (jx / GW >= groups_per_xcd) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned long long* gslot = a.gbuf + (size_t)grp * 2 * GW * PO_SLOT;
+  unsigned tag = 0;
+  bool same_xcd = false;
+  {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
+    if (t == 0) sh.part[0] = xcc;
+    p4_gather<GW>(sh, 1, gslot, wig, ++tag, a.err, false);
+    bool same = true;
+#pragma unroll
+    for (int w = 1; w < GW; ++w) same = same && (sh.gath[w][0] == sh.gath[0][0]);
+    same_xcd = same && (a.allow_l2_handoff != 0);
+    __syncthreads();
+  }
+  const int row0 = wig * a.RW;
+  const int nv = max(0, min(a.RW, a.N - row0));
+
+  for (int64_t b = grp; b < a.B; b += ngroups) {
+    int tl = t;
+    asm volatile("" : "+v"(tl));  // keeps the load-phase address arithmetic inside the member loop (VGPR budget)
+    float Cr[P4_NR][RC];
+    float dg[P4_NR];
+    int pos[P4_NR];
+#pragma unroll
+    for (int q = 0; q < P4_NR; ++q) {
+      const int lr = tl + P4_TPB * q;
+      const bool valid = lr < nv;
+      if (valid) {
+        const float4* cp = reinterpret_cast<const float4*>(a.C + ((size_t)b * a.N + row0 + lr) * RC);
+#pragma unroll
+        for (int i = 0; i < RC / 4; ++i) {
+          const float4 c4 = cp[i];
+          Cr[q][4 * i] = c4.x; Cr[q][4 * i + 1] = c4.y; Cr[q][4 * i + 2] = c4.z; Cr[q][4 * i + 3] = c4.w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < RC; ++i) Cr[q][i] = 0.f;
+      }
+      float acc = Cr[q][0] * Cr[q][0];  // (root ** 2).sum(-1), sequential in r
+#pragma unroll
+      for (int r = 1; r < RC; ++r) acc = acc + Cr[q][r] * Cr[q][r];
+      dg[q] = valid ? acc : 0.f;
+      pos[q] = valid ? row0 + lr : PO_INVALID;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) l_s[l_slot(lr, i)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    for (int m = 0; m < a.rank; ++m) {
+      // ---- workgroup candidate: argmax of the running diagonal over the positions >= m, error 1-norm partial ----
+      float bv = -INFINITY, es = 0.f;
+      int bj = PO_INVALID;
+#pragma unroll
+      for (int q = 0; q < P4_NR; ++q) {
+        const bool cand = pos[q] != PO_INVALID && pos[q] >= m;
+        if (cand) {
+          es += fabsf(dg[q]);
+          if (po_better(dg[q], pos[q], bv, bj)) {
+            bv = dg[q];
+            bj = pos[q];
+          }
+        }
+      }
+      po_amax_step<1>(bv, bj); po_amax_step<2>(bv, bj); po_amax_step<4>(bv, bj);
+      po_amax_step<8>(bv, bj); po_amax_step<16>(bv, bj); po_amax_step<32>(bv, bj);
+      es = wave_sum_fast(es);
+      if (lane == 0) {
+        sh.wv[wave] = bv;
+        sh.wj[wave] = bj;
+        sh.we[wave] = es;
+      }
+      __syncthreads();
+      float gv = sh.wv[lane & 3];
+      int gj = sh.wj[lane & 3];
+      float ge = sh.we[lane & 3];
+      ge = bfly_add<1>(ge); ge = bfly_add<2>(ge);
+      po_amax_step<1>(gv, gj); po_amax_step<2>(gv, gj);
+      gv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gv)));
+      gj = __builtin_amdgcn_readfirstlane(gj);
+      ge = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ge)));
+      // the owner of the candidate publishes it: header, its C row, its L entries 0..m-1
+#pragma unroll
+      for (int q = 0; q < P4_NR; ++q) {
+        if (pos[q] != PO_INVALID && pos[q] >= m && pos[q] == gj) {
+          sh.part[0] = __float_as_uint(gv);
+          sh.part[1] = (unsigned)gj;
+#pragma unroll
+          for (int r = 0; r < RC; ++r) sh.part[PO_HDR + r] = __float_as_uint(Cr[q][r]);
+          const int lr = t + P4_TPB * q;
+          for (int j4 = 0; 4 * j4 < m; ++j4) {
+            const float4 l4 = l_s[l_slot(lr, j4)];
+            sh.part[PO_HDR + RC + 4 * j4] = __float_as_uint(l4.x);
+            sh.part[PO_HDR + RC + 4 * j4 + 1] = __float_as_uint(l4.y);
+            sh.part[PO_HDR + RC + 4 * j4 + 2] = __float_as_uint(l4.z);
+            sh.part[PO_HDR + RC + 4 * j4 + 3] = __float_as_uint(l4.w);
+          }
+        }
+      }
+      if (t == 0) {
+        if (gj == PO_INVALID) {
+          sh.part[0] = __float_as_uint(-INFINITY);
+          sh.part[1] = (unsigned)PO_INVALID;
+        }
+        sh.part[3] = __float_as_uint(ge);
+      }
+      p4_gather<GW>(sh, PO_HDR + RC + m, gslot, wig, ++tag, a.err, same_xcd);
+
+      // ---- group winner (identical in all workgroups): lane l holds candidate l % GW ----
+      float vb = __uint_as_float(sh.gath[lane % GW][0]);
+      const int myj = (int)sh.gath[lane % GW][1];
+      int jb = myj;
+      float etot = __uint_as_float(sh.gath[lane % GW][3]);
+      etot = bfly_add<1>(etot); etot = bfly_add<2>(etot); etot = bfly_add<4>(etot);
+      po_amax_step<1>(vb, jb); po_amax_step<2>(vb, jb); po_amax_step<4>(vb, jb);
+      if constexpr (GW == 16) {
+        etot = bfly_add<8>(etot);
+        po_amax_step<8>(vb, jb);
+      }
+      vb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vb)));
+      jb = __builtin_amdgcn_readfirstlane(jb);
+      etot = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(etot)));
+      const unsigned long long wbal = __ballot(lane < GW && myj == jb);
+      const int wb = wbal ? __ffsll((long long)wbal) - 1 : 0;
+      if (wig == 0 && t == 0) {
+        a.err_rec[(size_t)m * a.B + b] = etot;
+        if (m == 0) a.orig[b] = vb;
+        a.swaps[(size_t)b * a.max_rank + m] = jb;
+      }
+      const float piv = sqrtf(vb);  // :73-74
+      const float* g = reinterpret_cast<const float*>(sh.gath[wb]) + PO_HDR;
+      // pivot row of C and its L entries, shared by the 4 rows of this thread
+      float gc[RC];
+#pragma unroll
+      for (int i = 0; i < RC / 4; ++i) {
+        const float4 g4 = *reinterpret_cast<const float4*>(g + 4 * i);
+        gc[4 * i] = g4.x; gc[4 * i + 1] = g4.y; gc[4 * i + 2] = g4.z; gc[4 * i + 3] = g4.w;
+      }
+#pragma unroll
+      for (int q = 0; q < P4_NR; ++q) {
+        if (pos[q] == PO_INVALID) continue;
+        // permutation swap of positions m and jb (:67-70), tracked per row
+        if (pos[q] == jb) pos[q] = m;
+        else if (pos[q] == m) pos[q] = jb;
+        const int lr = t + P4_TPB * q;
+        const int ms = m >> 2, me = m & 3;
+        if (pos[q] == m) {
+          float4 l4 = l_s[l_slot(lr, ms)];
+          if (me == 0) l4.x = piv; else if (me == 1) l4.y = piv; else if (me == 2) l4.z = piv; else l4.w = piv;
+          l_s[l_slot(lr, ms)] = l4;
+        } else if (pos[q] > m) {  // Schur update of row m at the not yet pivoted rows (:77-95)
+          float rowv = gc[0] * Cr[q][0];
+#pragma unroll
+          for (int r = 1; r < RC; ++r) rowv = rowv + gc[r] * Cr[q][r];
+          float v = rowv;
+          if (m > 0) {
+            float acc = 0.f;
+            for (int j4 = 0; 4 * j4 < m; ++j4) {
+              const float4 u4 = *reinterpret_cast<const float4*>(g + RC + 4 * j4);
+              const float4 l4 = l_s[l_slot(lr, j4)];
+              const int j = 4 * j4;
+              acc = (j == 0) ? u4.x * l4.x : acc + u4.x * l4.x;
+              if (j + 1 < m) acc = acc + u4.y * l4.y;
+              if (j + 2 < m) acc = acc + u4.z * l4.z;
+              if (j + 3 < m) acc = acc + u4.w * l4.w;
+            }
+            v = rowv - acc;
+          }
+          v = v / piv;
+          float4 l4 = l_s[l_slot(lr, ms)];
+          if (me == 0) l4.x = v; else if (me == 1) l4.y = v; else if (me == 2) l4.z = v; else l4.w = v;
+          l_s[l_slot(lr, ms)] = l4;
+          dg[q] = dg[q] - v * v;
+        }
+      }
+      // sh.gath / sh.part are next written after the barrier that follows the candidate reduction
+    }
+
+    // ---- L rows -> global, [max_rank, N] layout, consecutive threads = consecutive rows ----
+#pragma unroll
+    for (int q = 0; q < P4_NR; ++q) {
+      const int lr = t + P4_TPB * q;
+      if (lr < nv) {
+        float* Lb = a.L + (size_t)b * a.max_rank * a.N + row0 + lr;
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const float4 l4 = l_s[l_slot(lr, j4)];
+          const int m0 = 4 * j4;
+          if (m0 < a.max_rank) Lb[(size_t)m0 * a.N] = (m0 < a.rank) ? l4.x : 0.f;
+          if (m0 + 1 < a.max_rank) Lb[(size_t)(m0 + 1) * a.N] = (m0 + 1 < a.rank) ? l4.y : 0.f;
+          if (m0 + 2 < a.max_rank) Lb[(size_t)(m0 + 2) * a.N] = (m0 + 2 < a.rank) ? l4.z : 0.f;
+          if (m0 + 3 < a.max_rank) Lb[(size_t)(m0 + 3) * a.N] = (m0 + 3 < a.rank) ? l4.w : 0.f;
+        }
+      }
+    }
+    __syncthreads();  // l_s / sh reuse by the next member
+  }
+}
+
 // m* = number of pivots the reference takes: pivot 0 always, pivot m >= 1 while max_b error_{m-1} > tol (:57, :99)
 __global__ __launch_bounds__(kThreads) void k_po_rank(PoArgs a, float tol, int* m_out) {
   __shared__ float red[kThreads];
@@ -370,7 +638,7 @@ bool pc_onchip_eligible(const lo_op_desc* op, int max_rank) {
   if (g_onchip_disabled || op->kind != LO_OP_LOWRANK_DIAG) return false;
   const int64_t R = op->R;
   return (R == 8 || R == 16 || R == 32) && max_rank <= PO_MAXR && op->N >= 1024 &&
-         op->N <= (int64_t)PO_GW * PO_TPB && onchip_num_workgroups() >= 64;
+         op->N <= (int64_t)16 * P4_ROWS && onchip_num_workgroups() >= 64;
 }
 
 struct PoLayout {
@@ -407,12 +675,29 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   po_layout(op->B, max_rank, ar, &l);
   if (!ar.ok) return LO_ERR_WORKSPACE;
   const int nwg = onchip_num_workgroups();
-  const int ngroups = nwg / PO_GW;
+  // second generation (4 rows per thread, two workgroups per CU) when two workgroups fit on a CU
+  const int gw2 = op->N <= (int64_t)8 * P4_ROWS ? 8 : 16;
+  bool gen2 = !(getenv("LO_OC_GEN1") && op->N <= (int64_t)PO_GW * PO_TPB);
+  if (gen2) {
+    int per_cu = 0;
+    hipError_t e = hipErrorUnknown;
+#define LO_OCC(R_, G_) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pc_onchip4<R_, G_>, P4_TPB, 0)
+    if (op->R == 32 && gw2 == 8) LO_OCC(32, 8);
+    else if (op->R == 32) LO_OCC(32, 16);
+    else if (op->R == 16 && gw2 == 8) LO_OCC(16, 8);
+    else if (op->R == 16) LO_OCC(16, 16);
+    else if (gw2 == 8) LO_OCC(8, 8);
+    else LO_OCC(8, 16);
+#undef LO_OCC
+    gen2 = (e == hipSuccess) && per_cu >= 2;
+  }
+  if (!gen2 && op->N > (int64_t)PO_GW * PO_TPB) return LO_ERR_LAUNCH;  // caller runs the streaming engine
+  const int gw = gen2 ? gw2 : PO_GW;
   PoArgs a;
   a.C = op->A0;
   a.B = op->B;
   a.N = (int)op->N;
-  a.RW = (int)((op->N + PO_GW - 1) / PO_GW);
+  a.RW = (int)((op->N + gw - 1) / gw);
   a.rank = rank;
   a.max_rank = max_rank;
   a.L = L_rows;
@@ -426,10 +711,20 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   a.dbg = debug ? l.dbg : nullptr;
   if (debug) LO_HIP_CHECK(hipMemsetAsync(l.dbg, 0, 8 * sizeof(long long), st));
   LO_HIP_CHECK(hipMemsetAsync(l.err, 0, 4 * sizeof(int), st));
-  LO_HIP_CHECK(hipMemsetAsync(l.gbuf, 0, sizeof(unsigned long long) * (size_t)ngroups * 2 * PO_GW * PO_SLOT, st));
+  LO_HIP_CHECK(hipMemsetAsync(l.gbuf, 0, sizeof(unsigned long long) * (size_t)64 * 2 * PO_GW * PO_SLOT, st));
   dim3 grid(nwg), block(PO_TPB);
   LO_PROF_BEGIN("pc_onchip", st);
-  if (op->R == 32) hipLaunchKernelGGL((k_pc_onchip<32>), grid, block, 0, st, a);
+  if (gen2) {
+    dim3 grid2(2 * nwg), block2(P4_TPB);
+#define LO_GO(R_, G_) hipLaunchKernelGGL((k_pc_onchip4<R_, G_>), grid2, block2, 0, st, a)
+    if (op->R == 32 && gw == 8) LO_GO(32, 8);
+    else if (op->R == 32) LO_GO(32, 16);
+    else if (op->R == 16 && gw == 8) LO_GO(16, 8);
+    else if (op->R == 16) LO_GO(16, 16);
+    else if (gw == 8) LO_GO(8, 8);
+    else LO_GO(8, 16);
+#undef LO_GO
+  } else if (op->R == 32) hipLaunchKernelGGL((k_pc_onchip<32>), grid, block, 0, st, a);
   else if (op->R == 16) hipLaunchKernelGGL((k_pc_onchip<16>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((k_pc_onchip<8>), grid, block, 0, st, a);
   LO_PROF_END(st);

@@ -187,7 +187,7 @@ def test_pivoted_cholesky_bench_shape_bit_exact():
     _check_pivchol(K.lowrank_diag_descriptor(dev(C), None), orc.LowRankRowSource(C), 15)
 
 
-@pytest.mark.parametrize("N,R,B", [(8192, 32, 70), (4096, 16, 33), (1500, 8, 5), (5000, 32, 9)])
+@pytest.mark.parametrize("N,R,B", [(8192, 32, 70), (4096, 16, 33), (1500, 8, 5), (5000, 32, 9), (12000, 16, 3)])
 def test_onchip_pivoted_cholesky_matches_streaming_engine_and_oracle(N, R, B):
     """Operator-resident pivoted Cholesky (one 8-workgroup group per member, C rows in LDS, L rows in VGPRs, one
     granule exchange per pivot): L, permutation and rank bit-identical to the streaming engine and to the oracle."""
