@@ -293,7 +293,7 @@ def main():
                    for k, v in sorted(prof.items())}
         traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (run separately; see profiles/*/README.md)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_onchip", "traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_gen2", "traffic.json")))
             if dom == "cg_onchip" and tj["kernel"].startswith("k_cg_onchip"):
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:  # noqa: BLE001

@@ -34,7 +34,6 @@ constexpr int R4_ROWS = R4_TPB * R4_NR;  // rows per workgroup
 constexpr int R4_MAXGW = 16;
 constexpr int R4_SLOT = 40;
 constexpr unsigned R4_MAXSPIN = 1u << 22;
-constexpr int R4_PF = 64;  // bytes between L2 prefetch touches
 
 struct alignas(16) R4Shared {
   float red[R4_WAVES][R4_SLOT];
@@ -155,7 +154,6 @@ template <int RC, int RK, int GW>
 __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
   constexpr int NQ = RK / 4;
   __shared__ R4Shared sh;
-  __shared__ float pf_sink[64];
   __shared__ float4 q_s[R4_ROWS * NQ];  // Q rows of this workgroup, swizzled 16-byte slots
   __shared__ float x_s[R4_ROWS], d_s[R4_ROWS], dinv_s[R4_ROWS];  // per-row x, d, 1/d (VGPR budget: 256 with 2 WGs per CU)
   constexpr int gw = GW;
@@ -315,33 +313,6 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
     float beta = 0.f, alpha = 0.f;
     rn = sqrtf(rr);
 
-    // L2 prefetch plan for the next member of this group (one slice per iteration, see lo_cg_onchip.hip)
-    int pf_lines = 0, pf_chunk = 0, pf_lc = 0, pf_lq = 0, pf_lv = 0;
-    const char *pf_c = nullptr, *pf_q = nullptr, *pf_v0 = nullptr, *pf_v1 = nullptr, *pf_v2 = nullptr;
-    if (a.prefetch && b + ngroups < a.B && a.iters > 0) {
-      const int64_t nb = b + ngroups;
-      pf_lc = (nv * RC * 4) / R4_PF;
-      pf_lq = (nv * RK * 4) / R4_PF;
-      pf_lv = (nv * 4) / R4_PF;
-      pf_c = reinterpret_cast<const char*>(a.C + ((size_t)nb * a.N + row0) * RC);
-      pf_q = reinterpret_cast<const char*>(a.Q + ((size_t)nb * a.N + row0) * RK);
-      pf_v0 = reinterpret_cast<const char*>(a.rhs + (size_t)nb * a.N + row0);
-      int nvec = 1;
-      if (a.d_mode == LO_DIAG_FULL) {
-        pf_v1 = reinterpret_cast<const char*>(a.d + (size_t)nb * a.N + row0);
-        nvec = 2;
-        if (a.dinv_mode == LO_DIAG_FULL) {
-          pf_v2 = reinterpret_cast<const char*>(a.dinv + (size_t)nb * a.N + row0);
-          nvec = 3;
-        }
-      } else if (a.dinv_mode == LO_DIAG_FULL) {
-        pf_v1 = reinterpret_cast<const char*>(a.dinv + (size_t)nb * a.N + row0);
-        nvec = 2;
-      }
-      pf_lines = pf_lc + pf_lq + nvec * pf_lv;
-      pf_chunk = (pf_lines + a.iters - 1) / a.iters;
-    }
-
     if (stamp) {
       a.dbg[2] = wall_clock64();
       g.dbg = a.dbg;
@@ -364,20 +335,6 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
               return v;
             },
             sc, 1, g);
-      }
-      if (pf_lines > 0) {
-        const int hi = min(pf_lines, (k + 1) * pf_chunk);
-        for (int line = k * pf_chunk + t; line < hi; line += R4_TPB) {
-          const char* src;
-          if (line < pf_lc) src = pf_c + (size_t)line * R4_PF;
-          else if (line < pf_lc + pf_lq) src = pf_q + (size_t)(line - pf_lc) * R4_PF;
-          else {
-            const int vv = (line - pf_lc - pf_lq) / pf_lv, o = (line - pf_lc - pf_lq) % pf_lv;
-            src = (vv == 0 ? pf_v0 : vv == 1 ? pf_v1 : pf_v2) + (size_t)o * R4_PF;
-          }
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)pf_sink, 4, 0, 0);
-        }
       }
       // A p = C t + d o p (added_diag_linear_operator.py:72-76); p.Ap = ||C^T p||^2 + sum d p^2 (:250-251)
       float y[R4_NR];
