@@ -291,6 +291,11 @@ def main():
         kernels = {k: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2),
                        "alg_GBs": round(algorithmic_bytes(k, RANK_K) / (v[1] / v[0] * 1e-3) / 1e9, 1)}
                    for k, v in sorted(prof.items())}
+        triad_gbs = None  # measured HBM ceiling of this box (report beside the spec peak)
+        try:
+            triad_gbs = round(_hip.hbm_triad_gbs(device), 1)
+        except Exception:  # noqa: BLE001
+            pass
         traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (run separately; see profiles/*/README.md)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_gen2", "traffic.json")))
@@ -321,6 +326,7 @@ def main():
             },
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "achievable_peak_triad": triad_gbs,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6, "launches_timed": cnt,
                          "note": ("frac > 1 is possible for cg_onchip: the algorithmic figure charges C and Q once per "
                                   "iteration, the kernel keeps them in LDS/VGPRs and reads them from HBM once per solve")

@@ -196,6 +196,9 @@ int lo_tridiag_eigh_slq_f32(const float* t_mat, int64_t P, int64_t B, int32_t T,
  * bench.py uses it for the live per-kernel duration behind its roofline line.                     */
 int lo_prof_enable(int on);
 int lo_prof_report(char* buf, size_t buflen);
+/* a = b + s c over n floats (n % 4 == 0): the achievable HBM rate of the box (3 x 4 n bytes per launch), reported by
+ * bench.py beside the 8 TB/s spec peak.                                                             */
+int lo_hbm_triad_f32(float* a, const float* b, const float* c, float s, size_t n, void* stream);
 
 #ifdef __cplusplus
 }

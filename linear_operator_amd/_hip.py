@@ -31,7 +31,7 @@ EXPORTS = [
     "lo_precond_apply_workspace_bytes", "lo_precond_apply_f32",
     "lo_lanczos_workspace_bytes", "lo_lanczos_tridiag_f32",
     "lo_tridiag_eigh_slq_workspace_bytes", "lo_tridiag_eigh_slq_f32",
-    "lo_prof_enable", "lo_prof_report",
+    "lo_prof_enable", "lo_prof_report", "lo_hbm_triad_f32",
 ]
 
 
@@ -134,6 +134,8 @@ def load():
     lib.lo_prof_enable.argtypes = [C.c_int]
     lib.lo_prof_report.restype = C.c_int
     lib.lo_prof_report.argtypes = [C.c_char_p, sz]
+    lib.lo_hbm_triad_f32.restype = C.c_int
+    lib.lo_hbm_triad_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, sz, C.c_void_p]
     _lib = lib
     return lib
 
@@ -151,6 +153,24 @@ def prof_report() -> dict:
         name, cnt, ms = line.split()
         out[name] = (int(cnt), float(ms))
     return out
+
+
+def hbm_triad_gbs(device, n_floats: int = 1 << 28, reps: int = 10) -> float:
+    """Achievable HBM rate of this box: a = b + s c over three n-float arrays (1 GiB each by default), GB/s."""
+    import torch
+    lib = load()
+    a, b, c = (torch.empty(n_floats, dtype=torch.float32, device=device) for _ in range(3))
+    b.fill_(1.0)
+    c.fill_(2.0)
+    st = stream_ptr(device)
+    check(lib.lo_hbm_triad_f32(ptr(a), ptr(b), ptr(c), 0.5, n_floats, st), "lo_hbm_triad_f32")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        lib.lo_hbm_triad_f32(ptr(a), ptr(b), ptr(c), 0.5, n_floats, st)
+    e1.record()
+    torch.cuda.synchronize(device)
+    return 3 * 4 * n_floats * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def check(rc: int, what: str):
