@@ -1,0 +1,186 @@
+"""Parity at BASELINE.json's FULL sizes through size-independent properties (the oracle cannot run these shapes in
+seconds): exact closed forms evaluated independently in fp64 with torch (Woodbury identity for low-rank + diagonal,
+per-factor eigendecomposition for the Kronecker product), residuals against an independent fp64 product, linearity of
+the solve, permutation / Schur-complement properties of the pivoted Cholesky, P^{-1} P v = v for the preconditioner,
+and bitwise run-to-run reproducibility.  Synthetic inputs follow SURVEY 8(d) (generated on the device, seed 1234)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from linear_operator_amd import kernels as K  # noqa: E402
+from linear_operator_amd import settings  # noqa: E402
+from linear_operator_amd.operators import (  # noqa: E402
+    AddedDiagLinearOperator, ConstantDiagLinearOperator, DenseLinearOperator, DiagLinearOperator,
+    KroneckerProductLinearOperator, LowRankRootLinearOperator,
+)
+
+DEV = "cuda"
+
+
+def _gen(seed=1234):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(seed)
+    return g
+
+
+def _colrel(x, ref):
+    """max over (member, column) of ||x - ref|| / ||ref|| (norms over the N axis)"""
+    num = (x.double() - ref.double()).norm(dim=-2)
+    return float((num / ref.double().norm(dim=-2)).max())
+
+
+def _woodbury_solve_logdet(C, d, rhs):
+    """fp64 closed form for A = C C^T + diag(d): x = D^-1 b - D^-1 C (I + C^T D^-1 C)^-1 C^T D^-1 b,
+    logdet A = sum log d + logdet(I + C^T D^-1 C)."""
+    C, d, rhs = C.double(), d.double(), rhs.double()
+    Dib = rhs / d.unsqueeze(-1)
+    CtDi = (C / d.unsqueeze(-1)).mT
+    M = torch.eye(C.shape[-1], dtype=torch.float64, device=C.device) + CtDi @ C
+    Lm = torch.linalg.cholesky(M)
+    x = Dib - CtDi.mT @ torch.cholesky_solve(CtDi @ rhs, Lm)
+    logdet = d.log().sum(-1) + 2 * Lm.diagonal(dim1=-2, dim2=-1).log().sum(-1)
+    return x, logdet
+
+
+class ProbedAddedDiag(AddedDiagLinearOperator):
+    _probes = None
+
+    def _probe_vectors_and_norms(self):  # hook: reference _linear_operator.py:629-633
+        return self._probes
+
+
+def test_cfg3_headline_size_solve_and_pivoted_cholesky_properties():
+    B, N, R = 512, 8192, 32
+    g = _gen()
+    C = torch.randn(B, N, R, generator=g, device=DEV) / R ** 0.5
+    d = torch.rand(B, N, generator=g, device=DEV) + 0.5
+    b1 = torch.randn(B, N, 1, generator=g, device=DEV)
+    b2 = torch.randn(B, N, 1, generator=g, device=DEV)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(C), DiagLinearOperator(d))
+    with settings.cg_tolerance(1e-4):
+        x1 = A.solve(b1)
+        x2 = A.solve(b2)
+        x12 = A.solve(0.75 * b1 - 1.5 * b2)
+        x1_again = A.solve(b1)
+    xe, _ = _woodbury_solve_logdet(C, d, b1)
+    assert _colrel(x1, xe) < 1e-4                                    # north_star: fp32 solves within 1e-4 rel
+    assert _colrel(x12, 0.75 * x1 - 1.5 * x2) < 1e-4                 # linearity of the solve
+    assert torch.equal(x1, x1_again)                                 # fixed summation order, no float atomics
+    res = (C.double() @ (C.double().mT @ x1.double()) + d.double().unsqueeze(-1) * x1.double()) - b1.double()
+    assert float((res.norm(dim=-2) / b1.double().norm(dim=-2)).max()) < 1e-4
+    # product through the HIP matvec against the same fp64 product
+    y = A @ b1
+    ye = C.double() @ (C.double().mT @ b1.double()) + d.double().unsqueeze(-1) * b1.double()
+    assert _colrel(y, ye) < 1e-5
+
+    # pivoted Cholesky of C C^T at full size: permutation property, pivot order, exactness of the pivoted block
+    desc = K.lowrank_diag_descriptor(C, None)
+    L, perm = K.pivoted_cholesky(desc, 15)
+    assert L.shape == (B, N, 15) and perm.dtype == torch.int64
+    assert torch.equal(perm.sort(dim=-1).values, torch.arange(N, device=DEV).expand(B, N))
+    piv = perm[:, :15]
+    # L L^T reproduces the pivot rows/columns of A exactly (property of a partial Cholesky): check the 15 x 15 block
+    Lp = torch.gather(L, 1, piv.unsqueeze(-1).expand(B, 15, 15)).double()
+    Cp = torch.gather(C, 1, piv.unsqueeze(-1).expand(B, 15, R)).double()
+    blk = Cp @ Cp.mT
+    assert float(((Lp @ Lp.mT - blk).abs().amax(dim=(-2, -1)) / blk.abs().amax(dim=(-2, -1))).max()) < 1e-5
+    # pivoted rows of L form a lower-triangular factor with a positive, non-increasing diagonal (greedy pivot order)
+    assert float(Lp.triu(1).abs().max()) == 0.0
+    dl = Lp.diagonal(dim1=-2, dim2=-1)
+    assert bool((dl > 0).all()) and bool((dl[:, 1:] <= dl[:, :-1] * (1 + 1e-6)).all())
+    # Schur complement stays PSD up to rounding: diag(A) - sum L^2 >= -eps
+    schur = (C.double() ** 2).sum(-1) - (L.double() ** 2).sum(-1)
+    assert float(schur.min()) > -1e-4
+
+    # preconditioner P = L L^T + D: z = P^-1 (P v) returns v; logdet P against the fp64 closed form
+    pre = K.precond_build(L, d, False)
+    v = torch.randn(B, N, 2, generator=g, device=DEV)
+    Pv = (L.double() @ (L.double().mT @ v.double()) + d.double().unsqueeze(-1) * v.double()).float()
+    assert _colrel(K.precond_apply(pre, Pv), v) < 2e-5
+    _, ldp = _woodbury_solve_logdet(L, d, v)
+    assert float(((pre.logdet.double() - ldp).abs() / ldp.abs()).max()) < 1e-6
+
+
+def test_cfg3_full_size_inv_quad_logdet_with_injected_probes():
+    B, N, R, P = 512, 8192, 32, 16
+    g = _gen(4321)
+    C = torch.randn(B, N, R, generator=g, device=DEV) / R ** 0.5
+    d = torch.rand(B, N, generator=g, device=DEV) + 0.5
+    rhs = torch.randn(B, N, 1, generator=g, device=DEV)
+    # probes ~ N(0, P) with P = L L^T + D the preconditioner, as _inv_quad_logdet.py:95-110 draws them through
+    # precond_lt.zero_mean_mvn_samples (only then is the preconditioned SLQ estimate unbiased); injected through the
+    # hook so that both calls below see the same probes
+    L, _ = K.pivoted_cholesky(K.lowrank_diag_descriptor(C, None), 15)
+    Z = L @ torch.randn(B, 15, P, generator=g, device=DEV) + d.sqrt().unsqueeze(-1) * torch.randn(
+        B, N, P, generator=g, device=DEV)
+    nrm = Z.norm(dim=-2, keepdim=True)
+    A = ProbedAddedDiag(LowRankRootLinearOperator(C), DiagLinearOperator(d))
+    A._probes = (Z / nrm, nrm)
+    with settings.cg_tolerance(1e-4), settings.num_trace_samples(P):
+        iq, ld = A.inv_quad_logdet(rhs, logdet=True)
+        iq2, ld2 = A.inv_quad_logdet(rhs, logdet=True)
+    xe, lde = _woodbury_solve_logdet(C, d, rhs)
+    iqe = (xe * rhs.double()).sum(dim=(-2, -1))
+    assert float(((iq.double() - iqe).abs() / iqe.abs()).max()) < 1e-4      # inv_quad = b^T A^-1 b, exact
+    # SLQ with 16 probes is a stochastic estimate of a sum of N = 8192 log-eigenvalues: unbiased over the 512
+    # members (errors of both signs, standard deviation ~1e-3 * N per member); the same probes give the same bits
+    err = ld.double() - lde
+    assert float(err.abs().max()) < 1e-2 * N
+    assert abs(float(err.mean())) < 2.0 and float(err.std()) < 3e-3 * N
+    assert torch.equal(iq, iq2) and torch.equal(ld, ld2)
+
+
+def test_cfg4_shard_size_kronecker_solve_against_eigendecomposition():
+    B, n = 128, 256  # one GPU's shard of the 1024-member batch
+    g = _gen(77)
+    X1 = torch.randn(B, n, n, generator=g, device=DEV) / 16
+    X2 = torch.randn(B, n, n, generator=g, device=DEV) / 16
+    K1 = X1 @ X1.mT + 0.1 * torch.eye(n, device=DEV)
+    K2 = X2 @ X2.mT + 0.1 * torch.eye(n, device=DEV)
+    sig = 1e-2
+    rhs = torch.randn(B, n * n, 1, generator=g, device=DEV)
+    A = AddedDiagLinearOperator(KroneckerProductLinearOperator(DenseLinearOperator(K1), DenseLinearOperator(K2)),
+                                ConstantDiagLinearOperator(torch.full((B, 1), sig, device=DEV), n * n))
+    with settings.cg_tolerance(1e-3), settings.max_cg_iterations(2000):
+        x = A.solve(rhs)
+    # exact: (K1 (x) K2 + s I)^-1 b = (Q1 (x) Q2) diag(1 / (l1 l2 + s)) (Q1 (x) Q2)^T b, fp64
+    l1, Q1 = torch.linalg.eigh(K1.double())
+    l2, Q2 = torch.linalg.eigh(K2.double())
+    Bm = rhs.double().reshape(B, n, n)
+    T = Q1.mT @ Bm @ Q2
+    T = T / (l1.unsqueeze(-1) * l2.unsqueeze(-2) + sig)
+    xe = (Q1 @ T @ Q2.mT).reshape(B, n * n, 1)
+    # the reference's stopping rule bounds the MEAN residual of the normalised systems by the tolerance (linear_cg.py:304)
+    Ax = (K1.double() @ x.double().reshape(B, n, n) @ K2.double().mT).reshape(B, n * n, 1) + sig * x.double()
+    resid = (Ax - rhs.double()).norm(dim=-2) / rhs.double().norm(dim=-2)
+    assert float(resid.mean()) < 1e-3
+    # forward error is bounded by cond(A) * residual; with this spectrum the solves agree to a few 1e-3
+    assert _colrel(x, xe) < 5e-2
+    y = A @ rhs
+    ye = (K1.double() @ Bm @ K2.double().mT).reshape(B, n * n, 1) + sig * rhs.double()
+    assert _colrel(y, ye) < 1e-5
+
+
+def test_cfg5_shard_size_dense_matvec_and_solve_residual():
+    B, N = 2, 16384  # members of the 32 a GPU owns in the 8-GPU split (1 GiB each)
+    g = _gen(5)
+    X = torch.randn(B, N, N, generator=g, device=DEV) / 128
+    Kd = X @ X.mT
+    del X
+    d = torch.rand(B, N, generator=g, device=DEV) + 0.5
+    rhs = torch.randn(B, N, 17, generator=g, device=DEV)
+    A = AddedDiagLinearOperator(DenseLinearOperator(Kd), DiagLinearOperator(d))
+    y = A @ rhs
+    ye = torch.empty(B, N, 17, dtype=torch.float64, device=DEV)
+    for b in range(B):  # fp64 product one member at a time (2 GiB of fp64 operator per member)
+        ye[b] = Kd[b].double() @ rhs[b].double() + d[b].double().unsqueeze(-1) * rhs[b].double()
+    assert _colrel(y, ye) < 1e-5
+    with settings.cg_tolerance(1e-4):
+        x = A.solve(rhs)
+    res = torch.empty(B, 17, dtype=torch.float64, device=DEV)
+    for b in range(B):
+        r = Kd[b].double() @ x[b].double() + d[b].double().unsqueeze(-1) * x[b].double() - rhs[b].double()
+        res[b] = r.norm(dim=-2) / rhs[b].double().norm(dim=-2)
+    assert float(res.mean()) < 1e-4 and float(res.max()) < 1e-3
