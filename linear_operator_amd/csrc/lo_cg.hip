@@ -505,12 +505,12 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.resid_rec = d.oc_resid; a.init_conv = d.oc_init_conv; a.gbuf = d.oc_gbuf; a.err = d.oc_err;
     a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
     a.prefetch = getenv("LO_OC_NO_PREFETCH") ? 0 : 1;
-    a.stagger = getenv("LO_OC_STAGGER") ? atoi(getenv("LO_OC_STAGGER")) : 0;
     const bool oc_dbg = getenv("LO_OC_DEBUG") != nullptr && B >= 8;
     a.dbg = oc_dbg ? reinterpret_cast<long long*>(d.oc_resid + (size_t)B * 12) : nullptr;
     a.dbg_member = oc_dbg ? atoi(getenv("LO_OC_DEBUG")) : 0;  // LO_OC_DEBUG=<member index to time>
     LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(64), st));  // whole allocation (either generation)
-    LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 0, sizeof(int), st));
+    // LO_OC_TEST_FALLBACK: start with the error word set, as if a hand-off had timed out (exercises the host fallback)
+    LO_HIP_CHECK(hipMemsetAsync(d.oc_err, getenv("LO_OC_TEST_FALLBACK") ? 1 : 0, sizeof(int), st));
     if (oc_dbg) LO_HIP_CHECK(hipMemsetAsync(a.dbg, 0, 10 * sizeof(long long), st));
     rc = LO_ERR_UNSUPPORTED;
     if (oc_gen2) rc = onchip4_launch(pl.R4, preR4, a, oc_nwg, st);

@@ -26,8 +26,7 @@ struct OnchipArgs {
   int* init_conv;     // [B] has_converged before the first iteration (linear_cg.py:205-208)
   unsigned long long* gbuf;  // [ngroups][2][8][40] granules
   int* err;
-  int prefetch;          // 1: pull the next member's rows into L2 while iterating on the current one
-  int stagger;           // start delay per group index in units of s_sleep(64) (spreads the load phases over time)
+  int prefetch;          // first generation only: pull the next member's rows into L2 while iterating
   int allow_l2_handoff;  // 1: use the verified same-XCD L2 hand-off when the placement check passes
   long long* dbg;  // optional timestamps (wall_clock64) of member dbg_member / its workgroup 0, or nullptr
   int dbg_member;

@@ -34,7 +34,7 @@ namespace lo {
 constexpr int OC_TPB = 1024;
 constexpr int OC_GW = 8;          // workgroups per member
 constexpr int OC_WAVES = OC_TPB / 64;
-constexpr unsigned OC_MAXSPIN = 1u << 22;
+constexpr unsigned OC_MAXSPIN = 1u << 20;  // ~0.5 s of polling: co-residency was lost (never seen on a dedicated GPU)
 
 
 // Wave reduce-scatter of the products a[j] * s with the operand row in LDS (read as float4): on exit lane l holds
@@ -106,8 +106,9 @@ __device__ __forceinline__ void group_exchange(OcShared& sh, int cnt, unsigned l
     for (;;) {
       g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((unsigned)(g >> 32) == tag) break;
-      if (++spin > OC_MAXSPIN) {
-        atomicExch(err, 1);
+      if (++spin > OC_MAXSPIN ||
+          ((spin & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        atomicExch(err, 1);  // timed out, or another workgroup already did: give up at once
         break;
       }
       __builtin_amdgcn_s_sleep(1);
@@ -216,8 +217,9 @@ __global__ __launch_bounds__(OC_TPB) void k_cg_onchip(OnchipArgs a) {
       for (;;) {
         g = __hip_atomic_load(slot + (size_t)t * 40, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(g >> 32) == tg) break;
-        if (++spin > OC_MAXSPIN) {
-          atomicExch(a.err, 1);
+        if (++spin > OC_MAXSPIN ||
+            ((spin & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          atomicExch(a.err, 1);  // timed out, or another workgroup already did: give up at once
           break;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -232,9 +234,6 @@ __global__ __launch_bounds__(OC_TPB) void k_cg_onchip(OnchipArgs a) {
     __syncthreads();
   }
 
-  // de-synchronise the groups: otherwise all of them stream their operator rows from HBM at the same moment
-  // and then all leave HBM idle while they iterate
-  for (int i = 0; i < a.stagger * (j / OC_GW * 8 + xcd); ++i) __builtin_amdgcn_s_sleep(64);
   for (int64_t b = grp; b < a.B; b += ngroups) {
     const bool stamp = a.dbg && b == a.dbg_member && wig == 0 && t == 0;
     if (stamp) a.dbg[0] = wall_clock64();

@@ -33,7 +33,7 @@ constexpr int R4_WAVES = R4_TPB / 64;    // 4
 constexpr int R4_ROWS = R4_TPB * R4_NR;  // rows per workgroup
 constexpr int R4_MAXGW = 16;
 constexpr int R4_SLOT = 40;
-constexpr unsigned R4_MAXSPIN = 1u << 22;
+constexpr unsigned R4_MAXSPIN = 1u << 20;  // ~0.5 s of polling: co-residency was lost (never seen on a dedicated GPU)
 
 struct alignas(16) R4Shared {
   float red[R4_WAVES][R4_SLOT];
@@ -106,8 +106,9 @@ __device__ __forceinline__ void r4_group_sum(R4Shared& sh, int cnt, R4Group& g) 
         vals[w] = __uint_as_float((unsigned)(x & 0xffffffffull));
       }
       if (ok) break;
-      if (++spin > R4_MAXSPIN) {
-        atomicExch(g.err, 1);
+      if (++spin > R4_MAXSPIN ||
+          ((spin & 1023u) == 0 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        atomicExch(g.err, 1);  // timed out, or another workgroup already did: give up at once
         break;
       }
       __builtin_amdgcn_s_sleep(1);

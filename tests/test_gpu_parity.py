@@ -413,6 +413,27 @@ def test_onchip_cg_matches_streaming_engine_and_oracle(N, R):
 
 
 # ------------------------------------------------------------------------------------------- many columns (MFMA paths)
+def test_onchip_timeout_falls_back_to_streaming_engines(monkeypatch):
+    """A timed-out group hand-off (error word set) makes the host redo the work with the streaming engines: same
+    pivots / L bit for bit, same iteration count, solutions equal to summation-order noise."""
+    C, d, rhs = cases.lowrank_diag(3900, 9, 4096, 32, 1)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    L0, p0 = K.pivoted_cholesky(desc, 15)
+    pre = K.precond_build(L0, dev(d), False)
+    ref = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+    monkeypatch.setenv("LO_OC_TEST_FALLBACK", "1")
+    K._hip.prof_enable(True)
+    L1, p1 = K.pivoted_cholesky(desc, 15)
+    res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+    torch.cuda.synchronize()
+    prof = K._hip.prof_report()
+    K._hip.prof_enable(False)
+    assert "pc_update" in prof and any(k.startswith("skinny_tn") for k in prof), "streaming engines did not run"
+    assert torch.equal(L0, L1) and torch.equal(p0, p1)
+    assert res.iterations == ref.iterations and res.tolerance_reached
+    assert max_rel_err_cols(host(res.x), host(ref.x)) < 2e-5
+
+
 def test_cg_many_columns_mfma_paths_vs_oracle():
     """cfg3 / cfg5-shaped right-hand sides (16 probes + 1 rhs) go through the v_mfma_f32_32x32x2_f32 kernels
     (lo_skinny_mfma.hip, lo_dense_mfma.hip): same iteration counts and solutions as the oracle."""
