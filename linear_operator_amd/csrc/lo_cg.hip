@@ -351,6 +351,8 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   int S_dot = sp.S;
   if (op->kind == LO_OP_DENSE_DIAG) {
     S_dot = dense_S_dot(B, N, c);
+  } else if (op->kind == LO_OP_KRON_DIAG) {
+    S_dot = kron_S_dot((int)op->R, (int)op->n2, c, sp.S);
   }
   dd.S_dot = S_dot;
   dd.pAp_part = ar.take<float>((size_t)B * std::max(S_dot, sp.S) * c);

@@ -165,6 +165,11 @@ int dense_matvec_mfma(const float* K, const float* d, int dd_mode, const float* 
                       int64_t N, int64_t c, const int* stop, hipStream_t st);
 int kron_matvec(const float* K1, const float* K2, const float* v, float* tmp, float* y, int64_t B, int n1, int n2,
                 int64_t c, const int* stop, hipStream_t st);
+// matrix-core engine (c == 1, factors multiples of 128): diagonal term and CG dot partials fused in the epilogue
+bool kron_mfma_ok(int n1, int n2, int64_t c);
+int kron_S_dot(int n1, int n2, int64_t c, int S_default);
+int kron_matvec_mfma(const float* K1, const float* K2, const float* diag, int diag_mode, const float* v, float* tmp,
+                     float* y, float* dot_part, int64_t B, int n1, int n2, const int* stop, hipStream_t st);
 
 // ---- operator-resident CG (lo_cg_onchip.hip) -----------------------------------------------------
 struct OnchipArgs;

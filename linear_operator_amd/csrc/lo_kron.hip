@@ -4,9 +4,14 @@
 //  transposing copies:
 //    W[i1,(j2,col)]  = sum_j1 K1[i1,j1] V[j1,(j2,col)]                (M=n1, K=n1, N=n2*c)
 //    Y[i1,i2,col]    = sum_j2 W[i1,j2,col] K2[i2,j2]   per (b,col)    (M=n1, K=n2, N=n2)
-// fp32 LDS-tiled GEMM, 64x64 tile, BK=16, 4x4 register micro-tile (round 1: VALU; the MFMA
-// v_mfma_f32_32x32x2_f32 version is the next step for this compute-bound operator).
+// Two engines: a generic strided VALU GEMM (any n1, n2, c: 64x64 tile, BK=16, 4x4 register micro-tile) and, for one
+// right-hand-side column and factors that are multiples of 128, an MFMA engine (v_mfma_f32_32x32x2_f32): both
+// products in the "NT" form D = A B^T with k-contiguous operands,
+//    Tt[j2, i1] = sum_i2 K2[j2, i2] V[i1, i2]          (the intermediate is produced transposed, coalesced)
+//    Y[j1, j2]  = sum_i1 K1[j1, i1] Tt[j2, i1]  + d o v, with the CG inner product sum v o y fused in the epilogue
+// (~64 flop/B, the one matrix-core-bound operator of the path).
 #include <algorithm>
+#include <stdlib.h>
 
 #include "lo_device.h"
 #include "lo_internal.h"
@@ -87,6 +92,170 @@ static int launch_gemm(const GemmArgs& g, int nbatch, const int* stop, hipStream
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, nbatch);
   LO_PROF_BEGIN("kron_gemm", st);
   hipLaunchKernelGGL(k_gemm, grid, dim3(kThreads), 0, st, g, stop);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+// ---- MFMA engine --------------------------------------------------------------------------------------------
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int KM_BM = 128, KM_BN = 128, KM_BK = 64, KM_LD = KM_BK + 4;
+
+struct KmArgs {
+  const float* A;   // [z][M][K]
+  const float* Bm;  // [z][N][K]
+  float* D;         // [z][M][N]
+  int M, N, K, B;
+  // epilogue (EPI): y = D + diag o v, dot partial sum v o y per workgroup tile
+  const float* diag;
+  int diag_mode;
+  const float* v;   // [z][M][N]
+  float* dot_part;  // [z][tiles] or nullptr
+};
+
+__device__ __forceinline__ int km_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// D = A B^T for one 128 x 128 tile, K in slabs of 64 through LDS (row stride 68 floats: conflict-free ds_read_b128
+// of the MFMA operands), next slab fetched into registers while the current one is multiplied.  4 waves, each a
+// 64 x 64 quadrant = 2 x 2 MFMA tiles of 32 x 32.
+template <bool EPI>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_kron_nt_mfma(
+    KmArgs g, const int* __restrict__ stop) {
+  if (stop && *stop) return;
+  __shared__ float a_s[KM_BM * KM_LD];
+  __shared__ float b_s[KM_BN * KM_LD];
+  __shared__ float dot_s[4];
+  // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs, so all tiles of a member get ids
+  // of the same residue mod 8 -> one XCD, one L2: the member's operands are fetched from HBM once, not once per XCD
+  const int tiles_n = g.N / KM_BN, tiles = tiles_n * (g.M / KM_BM);
+  const int id = blockIdx.x, xcd = id & 7, rest = id >> 3;
+  const int tile = rest % tiles, z = (rest / tiles) * 8 + xcd;
+  if (z >= g.B) return;
+  const int m0 = (tile / tiles_n) * KM_BM, n0 = (tile % tiles_n) * KM_BN;
+  const float* A = g.A + (size_t)z * g.M * g.K + (size_t)m0 * g.K;
+  const float* Bm = g.Bm + (size_t)z * g.N * g.K + (size_t)n0 * g.K;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  const int wr = wave & 1, wc = wave >> 1;  // wave quadrant: rows 64 wr .. +63, columns 64 wc .. +63
+  // staging map: thread t moves float4 #(t + 256 u): row = f / 16, quad = f % 16 of the [128][64] slabs.  Sixteen
+  // NAMED registers, not arrays: the compiler demoted loop-carried float4 arrays to LDS (promote-alloca), which put a
+  // wait right behind the loads and serialised fetch and MFMA; the loads are UNCONDITIONAL (the last iteration
+  // re-fetches its own slab) for the same reason.
+  const int sr = threadIdx.x >> 4, sq = threadIdx.x & 15;  // + 16 rows per u
+  const float* ag = A + (size_t)sr * g.K + 4 * sq;
+  const float* bg = Bm + (size_t)sr * g.K + 4 * sq;
+  const size_t rs = (size_t)16 * g.K;
+  float* al = &a_s[sr * KM_LD + 4 * sq];
+  float* bl = &b_s[sr * KM_LD + 4 * sq];
+  float4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
+#define KM_LD4(p_) (*reinterpret_cast<const float4*>(p_))
+#define KM_LOAD(k0_)                                                                                         \
+  ra0 = KM_LD4(ag + (k0_)); ra1 = KM_LD4(ag + rs + (k0_)); ra2 = KM_LD4(ag + 2 * rs + (k0_));               \
+  ra3 = KM_LD4(ag + 3 * rs + (k0_)); ra4 = KM_LD4(ag + 4 * rs + (k0_)); ra5 = KM_LD4(ag + 5 * rs + (k0_));   \
+  ra6 = KM_LD4(ag + 6 * rs + (k0_)); ra7 = KM_LD4(ag + 7 * rs + (k0_));                                      \
+  rb0 = KM_LD4(bg + (k0_)); rb1 = KM_LD4(bg + rs + (k0_)); rb2 = KM_LD4(bg + 2 * rs + (k0_));               \
+  rb3 = KM_LD4(bg + 3 * rs + (k0_)); rb4 = KM_LD4(bg + 4 * rs + (k0_)); rb5 = KM_LD4(bg + 5 * rs + (k0_));   \
+  rb6 = KM_LD4(bg + 6 * rs + (k0_)); rb7 = KM_LD4(bg + 7 * rs + (k0_));
+#define KM_ST4(p_, v_) (*reinterpret_cast<float4*>(p_) = (v_))
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    acc00[e] = 0.f;
+    acc01[e] = 0.f;
+    acc10[e] = 0.f;
+    acc11[e] = 0.f;
+  }
+  KM_LOAD(0)
+  for (int k0 = 0; k0 < g.K; k0 += KM_BK) {
+    __syncthreads();
+    KM_ST4(al, ra0); KM_ST4(al + 16 * KM_LD, ra1); KM_ST4(al + 32 * KM_LD, ra2); KM_ST4(al + 48 * KM_LD, ra3);
+    KM_ST4(al + 64 * KM_LD, ra4); KM_ST4(al + 80 * KM_LD, ra5); KM_ST4(al + 96 * KM_LD, ra6);
+    KM_ST4(al + 112 * KM_LD, ra7);
+    KM_ST4(bl, rb0); KM_ST4(bl + 16 * KM_LD, rb1); KM_ST4(bl + 32 * KM_LD, rb2); KM_ST4(bl + 48 * KM_LD, rb3);
+    KM_ST4(bl + 64 * KM_LD, rb4); KM_ST4(bl + 80 * KM_LD, rb5); KM_ST4(bl + 96 * KM_LD, rb6);
+    KM_ST4(bl + 112 * KM_LD, rb7);
+    __syncthreads();
+    {
+      const int kn = min(k0 + KM_BK, g.K - KM_BK);
+      KM_LOAD(kn)
+      __builtin_amdgcn_sched_barrier(0);  // the scheduler would otherwise sink the loads below the MFMAs
+    }
+    // lane half h takes k in [32 h, 32 h + 32) of the slab: a float4 feeds 4 consecutive MFMA steps
+    const float* a0 = &a_s[(64 * wr + li) * KM_LD + 32 * h];
+    const float* a1 = a0 + 32 * KM_LD;
+    const float* b0 = &b_s[(64 * wc + li) * KM_LD + 32 * h];
+    const float* b1 = b0 + 32 * KM_LD;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 p4 = *reinterpret_cast<const float4*>(a0 + 4 * q);
+      const float4 r4 = *reinterpret_cast<const float4*>(a1 + 4 * q);
+      const float4 x4 = *reinterpret_cast<const float4*>(b0 + 4 * q);
+      const float4 y4 = *reinterpret_cast<const float4*>(b1 + 4 * q);
+#define KM_STEP(c_)                                                                  \
+  acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.c_, x4.c_, acc00, 0, 0, 0);        \
+  acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.c_, y4.c_, acc01, 0, 0, 0);        \
+  acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(r4.c_, x4.c_, acc10, 0, 0, 0);        \
+  acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(r4.c_, y4.c_, acc11, 0, 0, 0);
+      KM_STEP(x) KM_STEP(y) KM_STEP(z) KM_STEP(w)
+#undef KM_STEP
+    }
+  }
+#undef KM_LOAD
+#undef KM_LD4
+#undef KM_ST4
+  float* D = g.D + (size_t)z * g.M * g.N;
+  const float dconst = (EPI && g.diag_mode == LO_DIAG_CONST) ? g.diag[z] : 0.f;
+  float dacc = 0.f;
+  auto epilogue = [&](const f32x16& acc, int rt, int ct) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + 64 * wr + 32 * rt + km_row(e, lane);
+      const size_t o = (size_t)row * g.N + n0 + 64 * wc + 32 * ct + li;
+      float yv = acc[e];
+      if (EPI) {
+        const float vin = g.v[(size_t)z * g.M * g.N + o];
+        const float dv = (g.diag_mode == LO_DIAG_FULL) ? g.diag[(size_t)z * g.M * g.N + o] : dconst;
+        yv = fmaf(dv, vin, yv);
+        dacc = fmaf(vin, yv, dacc);
+      }
+      D[o] = yv;
+    }
+  };
+  epilogue(acc00, 0, 0);
+  epilogue(acc01, 0, 1);
+  epilogue(acc10, 1, 0);
+  epilogue(acc11, 1, 1);
+  if (EPI && g.dot_part) {
+    dacc = wave_sum(dacc);
+    if (lane == 0) dot_s[wave] = dacc;
+    __syncthreads();
+    if (threadIdx.x == 0) g.dot_part[(size_t)z * tiles + tile] = (dot_s[0] + dot_s[1]) + (dot_s[2] + dot_s[3]);
+  }
+}
+
+bool kron_mfma_ok(int n1, int n2, int64_t c) {
+  return c == 1 && n1 % 128 == 0 && n2 % 128 == 0 && n1 >= 128 && n2 >= 128;
+}
+int kron_S_dot(int n1, int n2, int64_t c, int S_default) {
+  return kron_mfma_ok(n1, n2, c) ? (n1 / KM_BM) * (n2 / KM_BN) : S_default;
+}
+
+// y = (K1 (x) K2) v + diag o v and (optionally) the dot partials sum v o y, c == 1, matrix cores
+int kron_matvec_mfma(const float* K1, const float* K2, const float* diag, int diag_mode, const float* v, float* tmp,
+                     float* y, float* dot_part, int64_t B, int n1, int n2, const int* stop, hipStream_t st) {
+  KmArgs g;
+  g.B = (int)B;
+  g.A = K2; g.Bm = v; g.D = tmp;  // Tt [n2, n1]
+  g.M = n2; g.N = n1; g.K = n2;
+  g.diag = nullptr; g.diag_mode = LO_DIAG_NONE; g.v = nullptr; g.dot_part = nullptr;
+  LO_PROF_BEGIN("kron_gemm_mfma", st);
+  hipLaunchKernelGGL((k_kron_nt_mfma<false>), dim3((unsigned)(((B + 7) / 8) * 8 * (g.M / KM_BM) * (g.N / KM_BN))), dim3(kThreads), 0, st, g, stop);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  g.A = K1; g.Bm = tmp; g.D = y;  // Y [n1, n2]
+  g.M = n1; g.N = n2; g.K = n1;
+  g.diag = diag; g.diag_mode = diag ? diag_mode : LO_DIAG_NONE; g.v = v; g.dot_part = dot_part;
+  LO_PROF_BEGIN("kron_gemm_mfma", st);
+  hipLaunchKernelGGL((k_kron_nt_mfma<true>), dim3((unsigned)(((B + 7) / 8) * 8 * (g.M / KM_BM) * (g.N / KM_BN))), dim3(kThreads), 0, st, g, stop);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;

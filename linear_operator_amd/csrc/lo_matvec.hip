@@ -66,6 +66,7 @@ int matvec_plan_init(MatvecPlan* pl, const lo_op_desc* op, lo_matvec_cb cb, void
     case LO_OP_KRON_DIAG: {
       if (!op->A0 || !op->A1 || op->R * op->n2 != op->N) return LO_ERR_BADARG;
       pl->kron_tmp = ar->take<float>((size_t)op->B * op->N * c);
+      pl->S_dot = kron_S_dot((int)op->R, (int)op->n2, c, sp.S);
       break;
     }
     case LO_OP_CALLBACK:
@@ -90,6 +91,9 @@ int matvec_run(const MatvecPlan* pl, const float* v, float* y, float* dot_part, 
       return dense_matvec(op.A0, op.d, op.diag_mode, v, y, dot_part, op.B, op.N, pl->c,
                           dense_rows_per_wg(op.B, op.N), stop, st);
     case LO_OP_KRON_DIAG:
+      if (kron_mfma_ok((int)op.R, (int)op.n2, pl->c))
+        return kron_matvec_mfma(op.A0, op.A1, op.d, op.diag_mode, v, pl->kron_tmp, y, dot_part, op.B, (int)op.R,
+                                (int)op.n2, stop, st);
       rc = kron_matvec(op.A0, op.A1, v, pl->kron_tmp, y, op.B, (int)op.R, (int)op.n2, pl->c, stop, st);
       if (rc) return rc;
       rc = vec_add_diag(op.d, op.diag_mode, v, y, pl->c, op.B, op.N, pl->sp, stop, st);

@@ -73,6 +73,35 @@ def test_matvec_dense_and_kron(c):
     assert max_rel_err_cols(y, ref) < 5e-6
 
 
+@pytest.mark.parametrize("n1,n2", [(128, 256), (256, 128)])
+def test_matvec_and_cg_kron_matrix_core_engine(n1, n2):
+    """c == 1 and factors that are multiples of 128 take the MFMA engine (intermediate produced transposed, diagonal
+    term and CG dot partials fused in the epilogue): product against the fp64 oracle, CG against the VALU engine
+    (3 identical columns force it) and the oracle."""
+    K1, K2, s, vk = cases.kron_factors(1300 + n1, 3, n1, n2, 1)
+    N = n1 * n2
+    dfull = cases.randn(1301, 3, N, 1, dtype=np.float32)[..., 0] ** 2 + 0.5
+    for desc, dk in ((K.kron_diag_descriptor(dev(K1), dev(K2), dev(s[:, 0]), const_diag=True),
+                      np.broadcast_to(s, (3, N)).astype(np.float64)),
+                     (K.kron_diag_descriptor(dev(K1), dev(K2), dev(dfull)), dfull.astype(np.float64))):
+        K._hip.prof_enable(True)
+        y = host(K.matvec(desc, dev(vk)))
+        torch.cuda.synchronize()
+        assert "kron_gemm_mfma" in K._hip.prof_report()
+        K._hip.prof_enable(False)
+        ref = orc.matvec_kron_diag(K1.astype(np.float64), K2.astype(np.float64), dk, vk.astype(np.float64))
+        assert max_rel_err_cols(y, ref) < 5e-6
+    desc = K.kron_diag_descriptor(dev(K1), dev(K2), dev(s[:, 0]), const_diag=True)
+    res = K.cg_solve(desc, dev(vk), tolerance=1e-3, max_iter=400)
+    res3 = K.cg_solve(desc, dev(np.repeat(vk, 3, axis=-1)), tolerance=1e-3, max_iter=400)  # VALU engine (c = 3)
+    assert abs(res.iterations - res3.iterations) <= 1 and res.tolerance_reached
+    assert max_rel_err_cols(host(res.x), host(res3.x)[..., :1]) < 2e-3
+    dk = np.broadcast_to(s, (3, N)).astype(np.float32)
+    xo, _, info = orc.linear_cg(lambda v: orc.matvec_kron_diag(K1, K2, dk, v), vk, tolerance=1e-3, max_iter=400)
+    assert abs(info.iterations - res.iterations) <= 1
+    assert max_rel_err_cols(host(res.x), xo) < 2e-3
+
+
 # ------------------------------------------------------------------------------------------- linear_cg
 def test_cg_lowrank_no_precond_vs_golden_and_oracle():
     g = load_golden("g1_cg_fp32_lowrank")
