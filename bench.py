@@ -145,7 +145,11 @@ def other_configs(device):
     res["cfg3_B512_inv_quad_logdet"] = {"ms": t * 1e3, "member_solve_logdets_per_s": B_PER_GPU / t,
                                         "iterations": r.iterations,
                                         "member_matvec_columns_per_s": B_PER_GPU * 17 * r.matvecs / t}
-    del Cm, d, full, desc
+    # explicit Lanczos on the same operator: 16 probe vectors, 20 steps, full re-orthogonalisation
+    V = torch.randn(B_PER_GPU, N, 16, generator=g, device=device)
+    t, (q_mat, _) = _time(lambda: K.lanczos_tridiag(desc, V, 20), 1)
+    res["cfg3_B512_lanczos_P16_k20"] = {"ms": t * 1e3, "member_probe_steps_per_s": B_PER_GPU * 16 * q_mat.shape[-1] / t}
+    del Cm, d, full, desc, V, q_mat
     # cfg4 shard: 128 of 1024 Kronecker members (256 (x) 256 + 1e-2 I), CG to tolerance 1e-3
     n = 256
     X1 = torch.randn(128, n, n, generator=g, device=device) / 16

@@ -178,6 +178,10 @@ size_t lo_lanczos_workspace_bytes(const lo_op_desc* op, int64_t P, int32_t max_i
 int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user, const float* init_vecs,
                            int64_t P, int32_t max_iter, float tol, float* q_mat, float* t_mat, int32_t* iters_out,
                            void* ws, size_t ws_bytes, void* stream);
+/* q_mat [k, B, N, P] (first k of the stored vectors, working order) -> [P, B, N, k], the layout lanczos.py:154
+ * returns (permute(-1, batch, -2, 0).contiguous()).  LO_ERR_UNSUPPORTED when k * 32 * (P + 1) floats exceed 64 KiB
+ * of LDS (the host then permutes with torch).                                                       */
+int lo_lanczos_permute_f32(const float* q_in, int32_t k, int64_t B, int64_t N, int64_t P, float* q_out, void* stream);
 
 /* ---- lanczos_tridiag_to_diag + StochasticLQ.to_dense (lanczos.py:167-189, stochastic_lq.py:45-82) */
 /* t_mat [M, T, T] (M = P*B tridiagonals, only the three diagonals are read) ->

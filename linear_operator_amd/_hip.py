@@ -20,6 +20,7 @@ LO_OP_LOWRANK_DIAG, LO_OP_DENSE_DIAG, LO_OP_KRON_DIAG, LO_OP_CALLBACK = 0, 1, 2,
 LO_DIAG_NONE, LO_DIAG_FULL, LO_DIAG_CONST = 0, 1, 2
 ABI_VERSION = 1
 
+LO_ERR_UNSUPPORTED = -4
 _ERR = {-1: "bad argument", -2: "HIP launch/runtime failure", -3: "workspace too small", -4: "unsupported shape"}
 
 EXPORTS = [
@@ -29,7 +30,7 @@ EXPORTS = [
     "lo_pivoted_cholesky_workspace_bytes", "lo_pivoted_cholesky_f32",
     "lo_precond_build_workspace_bytes", "lo_precond_build_f32", "lo_precond_build_strided_f32",
     "lo_precond_apply_workspace_bytes", "lo_precond_apply_f32",
-    "lo_lanczos_workspace_bytes", "lo_lanczos_tridiag_f32",
+    "lo_lanczos_workspace_bytes", "lo_lanczos_tridiag_f32", "lo_lanczos_permute_f32",
     "lo_tridiag_eigh_slq_workspace_bytes", "lo_tridiag_eigh_slq_f32",
     "lo_prof_enable", "lo_prof_report", "lo_hbm_triad_f32",
 ]
@@ -117,6 +118,8 @@ def load():
     lib.lo_precond_apply_f32.restype = C.c_int
     lib.lo_precond_apply_f32.argtypes = [P(PrecondDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                          C.c_void_p, sz, C.c_void_p]
+    lib.lo_lanczos_permute_f32.restype = C.c_int
+    lib.lo_lanczos_permute_f32.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     lib.lo_lanczos_workspace_bytes.restype = sz
     lib.lo_lanczos_workspace_bytes.argtypes = [P(OpDesc), C.c_int64, C.c_int32]
     lib.lo_lanczos_tridiag_f32.restype = C.c_int

@@ -10,6 +10,7 @@
 // device and the host reads one word per decision (the reference does the same through bool(tensor)).
 #include <algorithm>
 #include <cstring>
+#include <stdint.h>
 
 #include "lo_device.h"
 #include "lo_internal.h"
@@ -58,8 +59,160 @@ __global__ __launch_bounds__(kThreads) void k_lz_dot(LzDev d, const float* __res
   if (threadIdx.x < c) d.part[(((size_t)b * d.S + s) * (d.max_iter + 1)) * c + col] = tot;
 }
 
-// part[b,s,j,p] = sum_rows r o q_j  for j = 0..nq-1
+// part[b,s,j,p] = sum_rows r o q_j  for j = 0..nq-1 in ONE pass over the rows: a thread keeps one accumulator per
+// previous vector (compile-time bound MAXQ so that the accumulators stay in registers), r is read once.
+constexpr int kLzMaxQ = 24;
+
+template <int MAXQ>
 __global__ __launch_bounds__(kThreads) void k_lz_multidot(LzDev d, int nq) {
+  __shared__ float red[kThreads];
+  const int s = blockIdx.x;
+  const int64_t b = blockIdx.y;
+  const int c = d.P, N = (int)d.N;
+  const int nrs = kThreads / c;
+  const int col = threadIdx.x % c, slot = threadIdx.x / c;
+  const int r0 = s * d.rows, r1 = min(N, r0 + d.rows);
+  const size_t base = (size_t)b * N * c + col;
+  const size_t qs = (size_t)d.B * d.N * d.P;
+  float acc[MAXQ];
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) acc[j] = 0.f;
+  if (slot < nrs) {
+    for (int row = r0 + slot; row < r1; row += nrs) {
+      const size_t i = base + (size_t)row * c;
+      const float rv = d.r[i];
+#pragma unroll
+      for (int j = 0; j < MAXQ; ++j)
+        if (j < nq) acc[j] = fmaf(rv, d.q[(size_t)j * qs + i], acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) {
+    if (j < nq) {  // nq is uniform: no divergent barrier
+      const float tot = block_colsum(slot < nrs ? acc[j] : 0.f, c, nrs, red);
+      if (threadIdx.x < c) d.part[(((size_t)b * d.S + s) * (d.max_iter + 1) + j) * c + col] = tot;
+    }
+  }
+}
+
+// float4 variants for P % 4 == 0 (P <= 64): a thread owns 4 consecutive probe columns, so a wave instruction moves
+// 1 KiB contiguous instead of 256 B.  Thread t: column quad t % (P/4), row slot t / (P/4).  The sums over the row
+// slots of a wave are butterflies over the lane bits above log2(P/4) (DPP / permlane, no LDS, no barrier); the 4
+// wave partials meet in LDS once.
+template <int MAXQ>
+__global__ __launch_bounds__(kThreads) void k_lz_multidot4(LzDev d, int nq) {
+  __shared__ float red[4][MAXQ * 64];
+  const int s = blockIdx.x;
+  const int64_t b = blockIdx.y;
+  const int c = d.P, c4 = c >> 2, N = (int)d.N;
+  const int nrs = kThreads / c4;  // power-of-two P/4 only: 1, 2, 4, 8, 16
+  const int cq = threadIdx.x % c4, slot = threadIdx.x / c4;
+  const int r0 = s * d.rows, r1 = min(N, r0 + d.rows);
+  const size_t base = (size_t)b * N * c + 4 * cq;
+  const size_t qs = (size_t)d.B * d.N * d.P;
+  float4 acc[MAXQ];
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int row = r0 + slot; row < r1; row += nrs) {
+    const size_t i = base + (size_t)row * c;
+    const float4 rv = *reinterpret_cast<const float4*>(d.r + i);
+#pragma unroll
+    for (int j = 0; j < MAXQ; ++j) {
+      if (j < nq) {
+        const float4 qv = *reinterpret_cast<const float4*>(d.q + (size_t)j * qs + i);
+        acc[j].x = fmaf(rv.x, qv.x, acc[j].x);
+        acc[j].y = fmaf(rv.y, qv.y, acc[j].y);
+        acc[j].z = fmaf(rv.z, qv.z, acc[j].z);
+        acc[j].w = fmaf(rv.w, qv.w, acc[j].w);
+      }
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) {
+    if (j < nq) {
+      float v[4] = {acc[j].x, acc[j].y, acc[j].z, acc[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = v[e];
+        if (c4 <= 1) x = bfly_add<1>(x);
+        if (c4 <= 2) x = bfly_add<2>(x);
+        if (c4 <= 4) x = bfly_add<4>(x);
+        if (c4 <= 8) x = bfly_add<8>(x);
+        if (c4 <= 16) x = bfly_add<16>(x);
+        x = bfly_add<32>(x);
+        if (lane < c4) red[wave][j * 64 + 4 * lane + e] = x;  // lane < c4: column quad = lane
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nq * c; i += kThreads) {
+    const int j = i / c, p = i % c;
+    const float tot = (red[0][j * 64 + p] + red[1][j * 64 + p]) + (red[2][j * 64 + p] + red[3][j * 64 + p]);
+    d.part[(((size_t)b * d.S + s) * (d.max_iter + 1) + j) * c + p] = tot;
+  }
+}
+
+template <int MAXQ>
+__global__ __launch_bounds__(kThreads) void k_lz_correct4(LzDev d, int nq) {
+  __shared__ float red[4][64];
+  const int s = blockIdx.x;
+  const int64_t b = blockIdx.y;
+  const int c = d.P, c4 = c >> 2, N = (int)d.N;
+  const int nrs = kThreads / c4;
+  const int cq = threadIdx.x % c4, slot = threadIdx.x / c4;
+  const int r0 = s * d.rows, r1 = min(N, r0 + d.rows);
+  const size_t base = (size_t)b * N * c + 4 * cq;
+  const size_t qs = (size_t)d.B * d.N * d.P;
+  float4 cf[MAXQ];
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j)
+    cf[j] = (j < nq) ? *reinterpret_cast<const float4*>(d.coef + ((size_t)b * (d.max_iter + 1) + j) * c + 4 * cq)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int row = r0 + slot; row < r1; row += nrs) {
+    const size_t i = base + (size_t)row * c;
+    float4 corr = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < MAXQ; ++j) {
+      if (j < nq) {
+        const float4 qv = *reinterpret_cast<const float4*>(d.q + (size_t)j * qs + i);
+        corr.x = fmaf(qv.x, cf[j].x, corr.x);
+        corr.y = fmaf(qv.y, cf[j].y, corr.y);
+        corr.z = fmaf(qv.z, cf[j].z, corr.z);
+        corr.w = fmaf(qv.w, cf[j].w, corr.w);
+      }
+    }
+    float4 rv = *reinterpret_cast<const float4*>(d.r + i);
+    rv.x -= corr.x; rv.y -= corr.y; rv.z -= corr.z; rv.w -= corr.w;
+    *reinterpret_cast<float4*>(d.r + i) = rv;
+    rr.x = fmaf(rv.x, rv.x, rr.x);
+    rr.y = fmaf(rv.y, rv.y, rr.y);
+    rr.z = fmaf(rv.z, rv.z, rr.z);
+    rr.w = fmaf(rv.w, rv.w, rr.w);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float v[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float x = v[e];
+    if (c4 <= 1) x = bfly_add<1>(x);
+    if (c4 <= 2) x = bfly_add<2>(x);
+    if (c4 <= 4) x = bfly_add<4>(x);
+    if (c4 <= 8) x = bfly_add<8>(x);
+    if (c4 <= 16) x = bfly_add<16>(x);
+    x = bfly_add<32>(x);
+    if (lane < c4) red[wave][4 * lane + e] = x;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < c) {
+    const int p = threadIdx.x;
+    d.part[(((size_t)b * d.S + s) * (d.max_iter + 1)) * c + p] = (red[0][p] + red[1][p]) + (red[2][p] + red[3][p]);
+  }
+}
+
+// the same, any number of previous vectors (one pass per vector)
+__global__ __launch_bounds__(kThreads) void k_lz_multidot_any(LzDev d, int nq) {
   __shared__ float red[kThreads];
   const int s = blockIdx.x;
   const int64_t b = blockIdx.y;
@@ -79,15 +232,14 @@ __global__ __launch_bounds__(kThreads) void k_lz_multidot(LzDev d, int nq) {
   }
 }
 
-// coef[b,j,p] = sum_s part[b,s,j,p]; mode 1: also flag any coef > tol (signed, :134)
+// coef[b,j,p] = sum_s part[b,s,j,p]; check: also flag any coef > tol (signed, :134).  One workgroup per member;
+// the flag word is cleared by the host-side memset before the launch.
 __global__ __launch_bounds__(kThreads) void k_lz_reduce(LzDev d, int nq, int check) {
   __shared__ float red[kThreads];
-  const int64_t n = d.B * nq * d.P;
+  const int64_t b = blockIdx.x;
   float flag = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += kThreads) {
-    const int p = (int)(i % d.P);
-    const int j = (int)((i / d.P) % nq);
-    const int64_t b = i / ((int64_t)d.P * nq);
+  for (int i = threadIdx.x; i < nq * d.P; i += kThreads) {
+    const int p = i % d.P, j = i / d.P;
     float acc = 0.f;
     for (int s = 0; s < d.S; ++s) acc += d.part[(((size_t)b * d.S + s) * (d.max_iter + 1) + j) * d.P + p];
     d.coef[((size_t)b * (d.max_iter + 1) + j) * d.P + p] = acc;
@@ -95,27 +247,67 @@ __global__ __launch_bounds__(kThreads) void k_lz_reduce(LzDev d, int nq, int che
   }
   if (check) {
     const float any = block_sum256(flag, red);
-    if (threadIdx.x == 0) d.ctrl->need_reorth = any > 0.f ? 1 : 0;
+    if (threadIdx.x == 0 && any > 0.f) atomicExch(&d.ctrl->need_reorth, 1);
   }
 }
 
-// r -= sum_j coef[b,j,p] * q_j   (:119-120)
+// r -= sum_j coef[b,j,p] * q_j   (:119-120), and the partial of ||r||^2 of the corrected r (slot 0 of `part`,
+// what the normalisation that follows needs: saves a pass).  Coefficients of the thread's column in registers.
+template <int MAXQ>
 __global__ __launch_bounds__(kThreads) void k_lz_correct(LzDev d, int nq) {
+  __shared__ float red[kThreads];
   const int s = blockIdx.x;
   const int64_t b = blockIdx.y;
   const int c = d.P, N = (int)d.N;
   const int nrs = kThreads / c;
   const int col = threadIdx.x % c, slot = threadIdx.x / c;
-  if (slot >= nrs) return;
   const int r0 = s * d.rows, r1 = min(N, r0 + d.rows);
   const size_t base = (size_t)b * N * c + col;
-  for (int row = r0 + slot; row < r1; row += nrs) {
-    const size_t i = base + (size_t)row * c;
-    float corr = 0.f;
-    for (int j = 0; j < nq; ++j)
-      corr = fmaf(d.q[qoff(d, j) + i], d.coef[((size_t)b * (d.max_iter + 1) + j) * c + col], corr);
-    d.r[i] -= corr;
+  const size_t qs = (size_t)d.B * d.N * d.P;
+  float cf[MAXQ];
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j)
+    cf[j] = (j < nq && slot < nrs) ? d.coef[((size_t)b * (d.max_iter + 1) + j) * c + col] : 0.f;
+  float rr = 0.f;
+  if (slot < nrs) {
+    for (int row = r0 + slot; row < r1; row += nrs) {
+      const size_t i = base + (size_t)row * c;
+      float corr = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXQ; ++j)
+        if (j < nq) corr = fmaf(d.q[(size_t)j * qs + i], cf[j], corr);
+      const float rn = d.r[i] - corr;
+      d.r[i] = rn;
+      rr = fmaf(rn, rn, rr);
+    }
   }
+  const float tot = block_colsum(slot < nrs ? rr : 0.f, c, nrs, red);
+  if (threadIdx.x < c) d.part[(((size_t)b * d.S + s) * (d.max_iter + 1)) * c + col] = tot;
+}
+
+__global__ __launch_bounds__(kThreads) void k_lz_correct_any(LzDev d, int nq) {
+  __shared__ float red[kThreads];
+  const int s = blockIdx.x;
+  const int64_t b = blockIdx.y;
+  const int c = d.P, N = (int)d.N;
+  const int nrs = kThreads / c;
+  const int col = threadIdx.x % c, slot = threadIdx.x / c;
+  const int r0 = s * d.rows, r1 = min(N, r0 + d.rows);
+  const size_t base = (size_t)b * N * c + col;
+  float rr = 0.f;
+  if (slot < nrs) {
+    for (int row = r0 + slot; row < r1; row += nrs) {
+      const size_t i = base + (size_t)row * c;
+      float corr = 0.f;
+      for (int j = 0; j < nq; ++j)
+        corr = fmaf(d.q[qoff(d, j) + i], d.coef[((size_t)b * (d.max_iter + 1) + j) * c + col], corr);
+      const float rn = d.r[i] - corr;
+      d.r[i] = rn;
+      rr = fmaf(rn, rn, rr);
+    }
+  }
+  const float tot = block_colsum(slot < nrs ? rr : 0.f, c, nrs, red);
+  if (threadIdx.x < c) d.part[(((size_t)b * d.S + s) * (d.max_iter + 1)) * c + col] = tot;
 }
 
 // elementwise helpers on [B,N,P] with per-(b,p) scalars
@@ -182,6 +374,27 @@ __global__ __launch_bounds__(kThreads) void k_lz_sub_prev(LzDev d, int k) {
   }
 }
 
+// q_mat [kstore, B, N, P] (working order, :69-76) -> [P, B, N, k] (returned order, lanczos.py:154): LDS-tiled
+// transpose, reads contiguous along P (and rows), writes contiguous along (row, k).  One workgroup = 32 rows of a member.
+constexpr int kLzTr = 32;
+
+__global__ __launch_bounds__(kThreads) void k_lz_permute(const float* __restrict__ qin, float* __restrict__ qout,
+                                                          int k, int64_t B, int N, int P) {
+  extern __shared__ float tile[];  // [k][kLzTr][P + 1]
+  const int64_t b = blockIdx.y;
+  const int n0 = blockIdx.x * kLzTr, nr = min(kLzTr, N - n0);
+  const int ld = P + 1;
+  for (int e = threadIdx.x; e < k * nr * P; e += kThreads) {
+    const int j = e / (nr * P), rem = e % (nr * P);  // rem = row * P + p: contiguous in qin
+    tile[(j * kLzTr + rem / P) * ld + rem % P] = qin[(((size_t)j * B + b) * N + n0) * P + rem];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < P * nr * k; e += kThreads) {
+    const int p = e / (nr * k), rem = e % (nr * k);  // rem = row * k + j: contiguous in qout
+    qout[(((size_t)p * B + b) * N + n0) * k + rem] = tile[((rem % k) * kLzTr + rem / k) * ld + p];
+  }
+}
+
 }  // namespace lo
 
 using namespace lo;
@@ -206,6 +419,19 @@ size_t lo_lanczos_workspace_bytes(const lo_op_desc* op, int64_t P, int32_t max_i
   Split sp;
   lz_layout(op, P, max_iter, ar, &d, &sp);
   return ar.off + matvec_plan_bytes(op, P, sp) + 1024;
+}
+
+int lo_lanczos_permute_f32(const float* q_in, int32_t k, int64_t B, int64_t N, int64_t P, float* q_out, void* stream) {
+  if (!q_in || !q_out || k < 1 || B < 1 || N < 1 || P < 1 || B > 65535) return LO_ERR_BADARG;
+  const size_t lds = sizeof(float) * (size_t)k * kLzTr * (P + 1);
+  if (lds > 64 * 1024) return LO_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((N + kLzTr - 1) / kLzTr), (unsigned)B);
+  LO_PROF_BEGIN("lz_permute", st);
+  hipLaunchKernelGGL(k_lz_permute, grid, dim3(kThreads), lds, st, q_in, q_out, (int)k, B, (int)N, (int)P);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
 }
 
 int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user, const float* init_vecs,
@@ -233,45 +459,97 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
   LO_HIP_CHECK(hipMemsetAsync(t_mat, 0, sizeof(float) * (size_t)max_iter * max_iter * B * P, st));
   LzCtrl h;
   auto q = [&](int k) { return q_mat + (size_t)k * nv; };
+  // float4 kernels: P a power of two in 4 .. 64 (column quads per row 1 .. 16), 16-byte aligned rows
+  const bool vec4 = (P == 4 || P == 8 || P == 16 || P == 32 || P == 64) && ((uintptr_t)q_mat % 16) == 0 &&
+                    ((uintptr_t)d.r % 16) == 0 && ((uintptr_t)d.coef % 16) == 0;
+  auto multidot = [&](int nq) {
+    LO_PROF_BEGIN("lz_multidot", st);
+    if (nq <= kLzMaxQ && vec4) hipLaunchKernelGGL((k_lz_multidot4<kLzMaxQ>), grid, block, 0, st, d, nq);
+    else if (nq <= kLzMaxQ) hipLaunchKernelGGL((k_lz_multidot<kLzMaxQ>), grid, block, 0, st, d, nq);
+    else hipLaunchKernelGGL(k_lz_multidot_any, grid, block, 0, st, d, nq);
+    LO_PROF_END(st);
+  };
+  auto correct = [&](int nq) {  // also leaves the partials of ||r||^2 in slot 0 of `part`
+    LO_PROF_BEGIN("lz_correct", st);
+    if (nq <= kLzMaxQ && vec4) hipLaunchKernelGGL((k_lz_correct4<kLzMaxQ>), grid, block, 0, st, d, nq);
+    else if (nq <= kLzMaxQ) hipLaunchKernelGGL((k_lz_correct<kLzMaxQ>), grid, block, 0, st, d, nq);
+    else hipLaunchKernelGGL(k_lz_correct_any, grid, block, 0, st, d, nq);
+    LO_PROF_END(st);
+  };
+  auto reduce = [&](int nq, int check) {
+    if (check) (void)hipMemsetAsync(&d.ctrl->need_reorth, 0, sizeof(int), st);
+    LO_PROF_BEGIN("lz_reduce", st);
+    hipLaunchKernelGGL(k_lz_reduce, dim3((unsigned)B), block, 0, st, d, nq, check);
+    LO_PROF_END(st);
+  };
 
   // q_0 = init / ||init||  (:81-82)
+  LO_PROF_BEGIN("lz_dot", st);
   hipLaunchKernelGGL(k_lz_dot, grid, block, 0, st, d, init_vecs, init_vecs);
+  LO_PROF_END(st);
+  LO_PROF_BEGIN("lz_scal", st);
   hipLaunchKernelGGL(k_lz_scal, one, block, 0, st, d, 0, -1, -1, 0, 0);
+  LO_PROF_END(st);
+  LO_PROF_BEGIN("lz_axpy", st);
   hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 0, init_vecs, q(0), d.scal);
+  LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   // r = A q_0 ; alpha_0 ; r -= alpha_0 q_0 ; beta_0 = ||r||  (:85-95)
   rc = matvec_run(&pl, q(0), d.r, nullptr, nullptr, st);
   if (rc) return rc;
+  LO_PROF_BEGIN("lz_dot", st);
   hipLaunchKernelGGL(k_lz_dot, grid, block, 0, st, d, q(0), d.r);
+  LO_PROF_END(st);
+  LO_PROF_BEGIN("lz_scal", st);
   hipLaunchKernelGGL(k_lz_scal, one, block, 0, st, d, 1, 0, 0, 0, 0);
+  LO_PROF_END(st);
+  LO_PROF_BEGIN("lz_axpy", st);
   hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 1, q(0), d.r, d.scal);
+  LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   int k = 0;
   if (num_iter > 1) {
+    LO_PROF_BEGIN("lz_dot", st);
     hipLaunchKernelGGL(k_lz_dot, grid, block, 0, st, d, d.r, d.r);
+    LO_PROF_END(st);
+    LO_PROF_BEGIN("lz_scal", st);
     hipLaunchKernelGGL(k_lz_scal, one, block, 0, st, d, 0, 0, 1, 1, 0);
+    LO_PROF_END(st);
+    LO_PROF_BEGIN("lz_axpy", st);
     hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 0, d.r, q(1), d.scal);  // q_1 = r / beta_0  (:98)
+    LO_PROF_END(st);
     LO_LAUNCH_CHECK();
     for (k = 1; k < num_iter; ++k) {
       rc = matvec_run(&pl, q(k), d.r, nullptr, nullptr, st);  // :108
       if (rc) return rc;
+      LO_PROF_BEGIN("lz_sub_prev", st);
       hipLaunchKernelGGL(k_lz_sub_prev, grid, block, 0, st, d, k);
+      LO_PROF_END(st);
+      LO_PROF_BEGIN("lz_dot", st);
       hipLaunchKernelGGL(k_lz_dot, grid, block, 0, st, d, q(k), d.r);
+      LO_PROF_END(st);
+      LO_PROF_BEGIN("lz_scal", st);
       hipLaunchKernelGGL(k_lz_scal, one, block, 0, st, d, 1, k, k, 0, 0);  // alpha_k -> t[k,k]  (:109-111)
+      LO_PROF_END(st);
       LO_LAUNCH_CHECK();
       if (k + 1 < num_iter) {  // :114
+        LO_PROF_BEGIN("lz_axpy", st);
         hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 1, q(k), d.r, d.scal);  // r -= alpha q_k  (:116)
+        LO_PROF_END(st);
         // full re-orthogonalisation (:118-120)
-        hipLaunchKernelGGL(k_lz_multidot, grid, block, 0, st, d, k + 1);
-        hipLaunchKernelGGL(k_lz_reduce, one, block, 0, st, d, k + 1, 0);
-        hipLaunchKernelGGL(k_lz_correct, grid, block, 0, st, d, k + 1);
-        // normalise; beta_k -> t[k,k+1], t[k+1,k]  (:121-128)
-        hipLaunchKernelGGL(k_lz_dot, grid, block, 0, st, d, d.r, d.r);
+        multidot(k + 1);
+        reduce(k + 1, 0);
+        correct(k + 1);
+        // normalise (||r||^2 partials come out of the correction kernel); beta_k -> t[k,k+1], t[k+1,k]  (:121-128)
+        LO_PROF_BEGIN("lz_scal", st);
         hipLaunchKernelGGL(k_lz_scal, one, block, 0, st, d, 0, k, k + 1, 1, 1);
+        LO_PROF_END(st);
+        LO_PROF_BEGIN("lz_axpy", st);
         hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 0, d.r, d.r, d.scal);
+        LO_PROF_END(st);
         // inner products with the normalised r (:131)
-        hipLaunchKernelGGL(k_lz_multidot, grid, block, 0, st, d, k + 1);
-        hipLaunchKernelGGL(k_lz_reduce, one, block, 0, st, d, k + 1, 1);
+        multidot(k + 1);
+        reduce(k + 1, 1);
         LO_LAUNCH_CHECK();
         LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(LzCtrl), hipMemcpyDeviceToHost, st));
         LO_HIP_CHECK(hipStreamSynchronize(st));
@@ -282,12 +560,15 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
             could = true;
             break;
           }
-          hipLaunchKernelGGL(k_lz_correct, grid, block, 0, st, d, k + 1);  // uses the coefficients just computed
-          hipLaunchKernelGGL(k_lz_dot, grid, block, 0, st, d, d.r, d.r);
+          correct(k + 1);  // uses the coefficients just computed
+          LO_PROF_BEGIN("lz_scal", st);
           hipLaunchKernelGGL(k_lz_scal, one, block, 0, st, d, 0, -1, -1, 0, 0);
+          LO_PROF_END(st);
+          LO_PROF_BEGIN("lz_axpy", st);
           hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 0, d.r, d.r, d.scal);
-          hipLaunchKernelGGL(k_lz_multidot, grid, block, 0, st, d, k + 1);
-          hipLaunchKernelGGL(k_lz_reduce, one, block, 0, st, d, k + 1, 1);
+          LO_PROF_END(st);
+          multidot(k + 1);
+          reduce(k + 1, 1);
           LO_LAUNCH_CHECK();
           LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(LzCtrl), hipMemcpyDeviceToHost, st));
           LO_HIP_CHECK(hipStreamSynchronize(st));

@@ -366,9 +366,13 @@ def lanczos_tridiag(desc: Optional[OperatorDescriptor], init_vecs: torch.Tensor,
     _hip.check(rc, "lo_lanczos_tridiag_f32")
     k = iters.value
     nb = len(batch)
-    q = q[:k].reshape(k, *batch, N, P)
     t = t[:k, :k].reshape(k, k, *batch, P)
-    q_out = q.permute(-1, *range(1, 1 + nb), -2, 0).contiguous()  # lanczos.py:154
+    q_out = torch.empty(P, *batch, N, k, dtype=torch.float32, device=dev)
+    rc = lib.lo_lanczos_permute_f32(_hip.ptr(q), k, B, N, P, _hip.ptr(q_out), _hip.stream_ptr(dev))  # lanczos.py:154
+    if rc == _hip.LO_ERR_UNSUPPORTED:
+        q_out = q[:k].reshape(k, *batch, N, P).permute(-1, *range(1, 1 + nb), -2, 0).contiguous()
+    else:
+        _hip.check(rc, "lo_lanczos_permute_f32")
     t_out = t.permute(-1, *range(2, 2 + nb), 0, 1).contiguous()  # :156
     if P == 1:  # squeeze_(0) (:159-161) only acts on a size-1 leading dim
         q_out, t_out = q_out[0], t_out[0]
