@@ -6,10 +6,12 @@ from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
 from .identity_linear_operator import IdentityLinearOperator
 from .kronecker_product_linear_operator import KroneckerProductLinearOperator
 from .linear_operator_representation_tree import LinearOperatorRepresentationTree
+from .low_rank_root_added_diag_linear_operator import LowRankRootAddedDiagLinearOperator
 from .root_linear_operator import LowRankRootLinearOperator, RootLinearOperator
 from .sum_linear_operator import PsdSumLinearOperator, SumLinearOperator
 
 __all__ = [
+    "LowRankRootAddedDiagLinearOperator",
     "LinearOperator", "to_dense", "to_linear_operator", "AddedDiagLinearOperator", "DenseLinearOperator",
     "DiagLinearOperator", "ConstantDiagLinearOperator", "IdentityLinearOperator", "KroneckerProductLinearOperator",
     "LinearOperatorRepresentationTree", "RootLinearOperator", "LowRankRootLinearOperator", "SumLinearOperator",

@@ -543,3 +543,38 @@ def inv_quad_logdet(matmul_closure, row_src, d, inv_quad_rhs, probes, tolerance=
     if inv_quad_rhs is not None:
         inv_quad = np.sum(solves[..., P:] * inv_quad_rhs, axis=-2)  # :151-153
     return inv_quad, logdet + logdet_p, solves, t_mat, info, pre
+
+
+# ----------------------------------------------------------------------------------
+# LowRankRootAddedDiagLinearOperator closed forms
+# ----------------------------------------------------------------------------------
+
+
+def woodbury_chol_cap_mat(C, d):
+    """Cholesky factor of the capacitance matrix I_R + C^T D^-1 C, restating
+    LowRankRootAddedDiagLinearOperator.chol_cap_mat (operators/low_rank_root_added_diag_linear_operator.py:36-47).
+    C [*B,N,R], d [*B,N]."""
+    V = np.swapaxes(C, -1, -2)
+    cap = np.eye(C.shape[-1], dtype=C.dtype) + V @ (C / d[..., None])
+    return np.linalg.cholesky(cap)
+
+
+def woodbury_solve(C, d, rhs):
+    """(C C^T + D)^-1 rhs = D^-1 rhs - D^-1 C cap^-1 C^T D^-1 rhs, restating `_solve`
+    (low_rank_root_added_diag_linear_operator.py:62-89): two triangular solves with chol_cap_mat."""
+    from scipy.linalg import solve_triangular
+
+    chol = woodbury_chol_cap_mat(C, d)
+    Dir = rhs / d[..., None]
+    res = np.swapaxes(C, -1, -2) @ Dir
+    out = np.empty_like(res)
+    for idx in np.ndindex(res.shape[:-2]):
+        y = solve_triangular(chol[idx], res[idx], lower=True)
+        out[idx] = solve_triangular(chol[idx].T, y, lower=False)
+    return Dir - (C @ out) / d[..., None]
+
+
+def woodbury_logdet(C, d):
+    """logdet(C C^T + D) = 2 sum log diag(chol_cap_mat) + sum log d, restating `_logdet` (:97-103)."""
+    chol = woodbury_chol_cap_mat(C, d)
+    return 2.0 * np.log(np.diagonal(chol, axis1=-2, axis2=-1)).sum(-1) + np.log(d).sum(-1)

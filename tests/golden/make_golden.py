@@ -327,11 +327,36 @@ def g6_matmuls():
     save("g6_matmul", checksum=cases.checksum(C, d, v, K, dd, vv, K1, K2, vk), **out)
 
 
+def g7_low_rank_root_added_diag():
+    """`LowRankRoot + Diag` routes to LowRankRootAddedDiagLinearOperator, whose solve / logdet are
+    the Woodbury closed forms (low_rank_root_added_diag_linear_operator.py:36-101), no CG."""
+    from linear_operator.operators import LowRankRootAddedDiagLinearOperator
+
+    C, d, rhs = cases.lowrank_diag(701, 3, 1024, 16, 3)
+    A = LowRankRootLinearOperator(T(C)) + DiagLinearOperator(T(d))
+    assert isinstance(A, LowRankRootAddedDiagLinearOperator)
+    out = {"x": A.solve(T(rhs)), "logdet": A.logdet(), "chol_cap_mat": A.chol_cap_mat}
+    iq, ld = A.inv_quad_logdet(T(rhs), logdet=True)
+    out["inv_quad"], out["iq_logdet"] = iq, ld
+    iqn, _ = A.inv_quad_logdet(T(rhs), logdet=False, reduce_inv_quad=False)
+    out["inv_quad_noreduce"] = iqn
+    sig = np.array([[0.3], [0.7], [1.1]], dtype=np.float32)
+    Ac = LowRankRootLinearOperator(T(C)).add_diagonal(T(sig))
+    assert isinstance(Ac, LowRankRootAddedDiagLinearOperator)
+    out["x_const"], out["logdet_const"] = Ac.solve(T(rhs)), Ac.logdet()
+    # fp64 reference values of the same closed form
+    C64, d64, r64 = C.astype(np.float64), d.astype(np.float64), rhs.astype(np.float64)
+    dense = C64 @ np.swapaxes(C64, -1, -2) + np.stack([np.diag(x) for x in d64])
+    out["x_exact"] = np.linalg.solve(dense, r64)
+    out["logdet_exact"] = np.linalg.slogdet(dense)[1]
+    save("g7_lowrank_added_diag", checksum=cases.checksum(C, d, rhs, sig), **out)
+
+
 if __name__ == "__main__":
-    g1_linear_cg()
-    g2_pivoted_cholesky()
-    g3_preconditioner()
-    g4_solve_and_inv_quad_logdet()
-    g5_lanczos()
-    g6_matmuls()
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
+                     ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
+                     ("g7", g7_low_rank_root_added_diag)):
+        if name in todo:
+            fn()
     print("done")

@@ -181,3 +181,40 @@ def test_ragged_shapes_multibatch_and_wide_rhs():
     # rhs broadcast over the operator batch is rejected with the reference's message
     with settings.max_cholesky_size(0), pytest.raises(RuntimeError, match="same number of dimensions"):
         A.inv_quad_logdet(dev(rhs[0]), logdet=True)
+
+
+def test_low_rank_root_added_diag_woodbury_closed_form():
+    """`LowRankRoot + Diag` / `.add_diagonal` build LowRankRootAddedDiagLinearOperator (reference default routing);
+    solve / logdet / inv_quad_logdet run the Woodbury closed form on the device (no CG) and match the reference."""
+    from linear_operator_amd.operators import LowRankRootAddedDiagLinearOperator
+
+    g = load_golden("g7_lowrank_added_diag")
+    C, d, rhs = cases.lowrank_diag(701, 3, 1024, 16, 3)
+    A = LowRankRootLinearOperator(dev(C)) + DiagLinearOperator(dev(d))
+    assert isinstance(A, LowRankRootAddedDiagLinearOperator)
+    spy = mock.MagicMock(wraps=lo.utils.linear_cg)
+    with mock.patch("linear_operator_amd.utils.linear_cg", new=spy), settings.max_cholesky_size(0):
+        x = A.solve(dev(rhs))
+        ld = A.logdet()
+        iq, ld2 = A.inv_quad_logdet(dev(rhs), logdet=True)
+        iqn, none = A.inv_quad_logdet(dev(rhs), logdet=False, reduce_inv_quad=False)
+    assert not spy.called and none is None
+    assert max_rel_err_cols(host(x), g["x"]) < 1e-4 and max_rel_err_cols(host(x), g["x_exact"]) < 1e-5
+    assert np.allclose(host(ld), g["logdet_exact"], rtol=1e-6) and np.allclose(host(ld2), g["logdet"], rtol=1e-5)
+    assert np.allclose(host(iq), g["inv_quad"], rtol=1e-4) and np.allclose(host(iqn), g["inv_quad_noreduce"], rtol=1e-4)
+    assert np.allclose(host(A.chol_cap_mat), g["chol_cap_mat"], rtol=1e-4, atol=1e-5)
+    sig = np.array([[0.3], [0.7], [1.1]], dtype=np.float32)
+    Ac = LowRankRootLinearOperator(dev(C)).add_diagonal(dev(sig))
+    assert isinstance(Ac, LowRankRootAddedDiagLinearOperator)
+    with settings.max_cholesky_size(0):
+        assert max_rel_err_cols(host(Ac.solve(dev(rhs))), g["x_const"]) < 1e-4
+        assert np.allclose(host(Ac.logdet()), g["logdet_const"], rtol=1e-5)
+    # adding another diagonal keeps the class; anything else falls back to the CG operator (reference :105-115)
+    assert isinstance(A + DiagLinearOperator(dev(d)), LowRankRootAddedDiagLinearOperator)
+    assert type(A + DenseLinearOperator(torch.eye(1024, device="cuda"))) is AddedDiagLinearOperator
+    # cfg3-sized batch: against the CG path of the explicit AddedDiagLinearOperator
+    Cb, db, rb = cases.lowrank_diag(702, 8, 8192, 32, 1)
+    Aw = LowRankRootLinearOperator(dev(Cb)) + DiagLinearOperator(dev(db))
+    Acg = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(Cb)), DiagLinearOperator(dev(db)))
+    with settings.cg_tolerance(1e-4):
+        assert max_rel_err_cols(host(Aw.solve(dev(rb))), host(Acg.solve(dev(rb)))) < 1e-4

@@ -287,3 +287,24 @@ def test_matmuls():
     dk = np.broadcast_to(s, (2, 240))
     assert np.allclose(orc.matvec_kron_diag(K1, K2, dk, vk), g["y_kron_diag"], rtol=1e-4, atol=1e-4)
     assert np.allclose(orc.KronRowSource(K1, K2).diag(), g["diag_kron"], rtol=1e-6)
+
+
+def test_g7_low_rank_root_added_diag_closed_forms():
+    """the Woodbury closed forms of LowRankRootAddedDiagLinearOperator (fp32 reference outputs
+    and the fp64 dense values stored next to them)."""
+    g = load_golden("g7_lowrank_added_diag")
+    C, d, rhs = cases.lowrank_diag(701, 3, 1024, 16, 3)
+    assert cases.checksum(C, d, rhs, np.array([[0.3], [0.7], [1.1]], dtype=np.float32)) == g["checksum"]
+    x = orc.woodbury_solve(C.astype(np.float64), d.astype(np.float64), rhs.astype(np.float64))
+    assert max_rel_err_cols(x, g["x_exact"]) < 1e-10
+    assert max_rel_err_cols(x, g["x"]) < 1e-4  # the reference's fp32 result
+    ld = orc.woodbury_logdet(C.astype(np.float64), d.astype(np.float64))
+    assert np.allclose(ld, g["logdet_exact"], rtol=1e-12)
+    assert np.allclose(ld, g["logdet"], rtol=1e-5) and np.allclose(ld, g["iq_logdet"], rtol=1e-5)
+    assert np.allclose(orc.woodbury_chol_cap_mat(C, d), g["chol_cap_mat"], rtol=1e-4, atol=1e-5)
+    iq = np.sum(x * rhs, axis=-2)
+    assert np.allclose(iq, g["inv_quad_noreduce"], rtol=1e-4) and np.allclose(iq.sum(-1), g["inv_quad"], rtol=1e-4)
+    sig = np.array([0.3, 0.7, 1.1])
+    dc = np.broadcast_to(sig[:, None], (3, 1024))
+    assert max_rel_err_cols(orc.woodbury_solve(C.astype(np.float64), dc, rhs.astype(np.float64)), g["x_const"]) < 1e-4
+    assert np.allclose(orc.woodbury_logdet(C.astype(np.float64), dc), g["logdet_const"], rtol=1e-5)
