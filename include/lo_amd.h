@@ -182,6 +182,11 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
  * returns (permute(-1, batch, -2, 0).contiguous()).  LO_ERR_UNSUPPORTED when k * 32 * (P + 1) floats exceed 64 KiB
  * of LDS (the host then permutes with torch).                                                       */
 int lo_lanczos_permute_f32(const float* q_in, int32_t k, int64_t B, int64_t N, int64_t P, float* q_out, void* stream);
+/* Epilogue of RootDecomposition.forward (functions/_root_decomposition.py:73-85) for PB = probes x batch members:
+ * qv = q evecs, root = qv o sqrt(evals), inverse = qv / sqrt(evals); q, qv, root, inverse [PB, N, k], evecs
+ * [PB, k, k], evals [PB, k]; any of the three outputs may be NULL.  k <= 32, else LO_ERR_UNSUPPORTED.      */
+int lo_root_from_lanczos_f32(const float* q, const float* evecs, const float* evals, int64_t PB, int64_t N, int32_t k,
+                             float* qv, float* root, float* inverse, void* stream);
 
 /* ---- lanczos_tridiag_to_diag + StochasticLQ.to_dense (lanczos.py:167-189, stochastic_lq.py:45-82) */
 /* t_mat [M, T, T] (M = P*B tridiagonals, only the three diagonals are read) ->

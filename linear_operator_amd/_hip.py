@@ -31,6 +31,7 @@ EXPORTS = [
     "lo_precond_build_workspace_bytes", "lo_precond_build_f32", "lo_precond_build_strided_f32",
     "lo_precond_apply_workspace_bytes", "lo_precond_apply_f32",
     "lo_lanczos_workspace_bytes", "lo_lanczos_tridiag_f32", "lo_lanczos_permute_f32",
+    "lo_root_from_lanczos_f32",
     "lo_tridiag_eigh_slq_workspace_bytes", "lo_tridiag_eigh_slq_f32",
     "lo_prof_enable", "lo_prof_report", "lo_hbm_triad_f32",
 ]
@@ -118,6 +119,9 @@ def load():
     lib.lo_precond_apply_f32.restype = C.c_int
     lib.lo_precond_apply_f32.argtypes = [P(PrecondDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                          C.c_void_p, sz, C.c_void_p]
+    lib.lo_root_from_lanczos_f32.restype = C.c_int
+    lib.lo_root_from_lanczos_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.lo_lanczos_permute_f32.restype = C.c_int
     lib.lo_lanczos_permute_f32.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     lib.lo_lanczos_workspace_bytes.restype = sz

@@ -395,6 +395,37 @@ __global__ __launch_bounds__(kThreads) void k_lz_permute(const float* __restrict
   }
 }
 
+// Epilogue of RootDecomposition.forward (functions/_root_decomposition.py:73-85): QV = Q V, root = QV o sqrt(lambda),
+// inverse = QV / sqrt(lambda) for a batch of tall Q [N, k] and small V [k, k] (k <= 32): one thread per row, the row
+// of Q in registers, V and sqrt(lambda) in LDS.  HBM-bound: 4 N k (1 + outputs) bytes per member.
+template <int KM>
+__global__ __launch_bounds__(kThreads) void k_lz_root(const float* __restrict__ q, const float* __restrict__ evecs,
+                                                       const float* __restrict__ evals, int N, int k,
+                                                       float* __restrict__ qv, float* __restrict__ root,
+                                                       float* __restrict__ inverse) {
+  __shared__ float v_s[KM * KM];
+  __shared__ float s_s[KM];
+  const int64_t b = blockIdx.y;
+  for (int e = threadIdx.x; e < k * k; e += kThreads) v_s[e] = evecs[(size_t)b * k * k + e];
+  for (int e = threadIdx.x; e < k; e += kThreads) s_s[e] = sqrtf(evals[(size_t)b * k + e]);
+  __syncthreads();
+  const int row = blockIdx.x * kThreads + threadIdx.x;
+  if (row >= N) return;
+  const size_t o = ((size_t)b * N + row) * k;
+  float x[KM];
+#pragma unroll
+  for (int a = 0; a < KM; ++a) x[a] = (a < k) ? q[o + a] : 0.f;
+  for (int j = 0; j < k; ++j) {
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < KM; ++a)
+      if (a < k) acc = fmaf(x[a], v_s[a * k + j], acc);
+    if (qv) qv[o + j] = acc;
+    if (root) root[o + j] = acc * s_s[j];
+    if (inverse) inverse[o + j] = acc / s_s[j];
+  }
+}
+
 }  // namespace lo
 
 using namespace lo;
@@ -419,6 +450,20 @@ size_t lo_lanczos_workspace_bytes(const lo_op_desc* op, int64_t P, int32_t max_i
   Split sp;
   lz_layout(op, P, max_iter, ar, &d, &sp);
   return ar.off + matvec_plan_bytes(op, P, sp) + 1024;
+}
+
+int lo_root_from_lanczos_f32(const float* q, const float* evecs, const float* evals, int64_t PB, int64_t N, int32_t k,
+                             float* qv, float* root, float* inverse, void* stream) {
+  if (!q || !evecs || !evals || PB < 1 || N < 1 || k < 1 || PB > 65535) return LO_ERR_BADARG;
+  if (k > 32) return LO_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((N + kThreads - 1) / kThreads), (unsigned)PB);
+  LO_PROF_BEGIN("lz_root", st);
+  if (k <= 16) hipLaunchKernelGGL((k_lz_root<16>), grid, dim3(kThreads), 0, st, q, evecs, evals, (int)N, (int)k, qv, root, inverse);
+  else hipLaunchKernelGGL((k_lz_root<32>), grid, dim3(kThreads), 0, st, q, evecs, evals, (int)N, (int)k, qv, root, inverse);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
 }
 
 int lo_lanczos_permute_f32(const float* q_in, int32_t k, int64_t B, int64_t N, int64_t P, float* q_out, void* stream) {

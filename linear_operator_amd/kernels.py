@@ -379,6 +379,34 @@ def lanczos_tridiag(desc: Optional[OperatorDescriptor], init_vecs: torch.Tensor,
     return q_out, t_out
 
 
+def root_from_lanczos(q_mat: torch.Tensor, evecs: torch.Tensor, evals: torch.Tensor, want_root: bool = True,
+                      want_inverse: bool = False):
+    """lo_root_from_lanczos_f32: the epilogue of RootDecomposition.forward (functions/_root_decomposition.py:73-85).
+    q_mat [*lead, N, k], evecs [*lead, k, k], evals [*lead, k] -> (q V, q V o sqrt(evals) or None, q V / sqrt(evals)
+    or None).  k > 32: the same three expressions with torch (as the reference)."""
+    lib = _hip.load()
+    lead = q_mat.shape[:-2]
+    N, k = q_mat.shape[-2:]
+    if k > 32 or not (q_mat.is_cuda and q_mat.dtype == torch.float32):
+        qv = q_mat.matmul(evecs)
+        s = evals.sqrt().unsqueeze(-2)
+        return qv, (qv * s if want_root else None), (qv / s if want_inverse else None)
+    _hip.require_hip(q_mat, evecs, evals)
+    q3 = q_mat.contiguous().reshape(-1, N, k)
+    PB = q3.shape[0]
+    v3 = evecs.contiguous().reshape(PB, k, k)
+    e3 = evals.contiguous().reshape(PB, k)
+    dev = q_mat.device
+    qv = torch.empty_like(q3)
+    root = torch.empty_like(q3) if want_root else None
+    inv = torch.empty_like(q3) if want_inverse else None
+    _hip.check(lib.lo_root_from_lanczos_f32(_hip.ptr(q3), _hip.ptr(v3), _hip.ptr(e3), PB, N, k, _hip.ptr(qv),
+                                            _hip.ptr(root), _hip.ptr(inv), _hip.stream_ptr(dev)),
+               "lo_root_from_lanczos_f32")
+    shp = (*lead, N, k)
+    return qv.reshape(shp), (None if root is None else root.reshape(shp)), (None if inv is None else inv.reshape(shp))
+
+
 def set_onchip_cg(enable: bool):
     """Allow (default) or forbid the operator-resident CG fast path (csrc/lo_cg_onchip.hip); test / A-B switch."""
     _hip.load().lo_cg_set_onchip(1 if enable else 0)

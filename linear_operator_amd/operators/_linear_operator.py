@@ -449,9 +449,110 @@ class LinearOperator(object):
         res, pivots = PivotedCholesky.apply(self.representation_tree(), rank, error_tol, *self.representation())
         return (res, pivots) if return_pivots else res
 
+    # ------------------------------------------------------------------ root decompositions
+    def _root_decomposition_size(self) -> int:  # reference :715-721
+        return settings.max_root_decomposition_size.value()
+
+    def _choose_root_method(self) -> str:  # reference :543-561 (no eig caches on this path)
+        if self.size(-1) <= settings.max_cholesky_size.value() or settings.fast_computations.covar_root_decomposition.off():
+            return "cholesky"
+        return "lanczos"
+
+    def _root_decomposition(self):  # reference :689-713
+        from ..functions._root_decomposition import RootDecomposition
+
+        res, _ = RootDecomposition.apply(self.representation_tree(), self._root_decomposition_size(), self.dtype,
+                                         self.device, self.batch_shape, self.matrix_shape, True, False, None,
+                                         *self.representation())
+        return res
+
+    def _root_inv_decomposition(self, initial_vectors=None, test_vectors=None):  # reference :723-763
+        from ..functions._root_decomposition import RootDecomposition
+
+        roots, inv_roots = RootDecomposition.apply(self.representation_tree(), self._root_decomposition_size(),
+                                                   self.dtype, self.device, self.batch_shape, self.matrix_shape, True,
+                                                   True, initial_vectors, *self.representation())
+        if initial_vectors is not None and initial_vectors.size(-1) > 1:
+            self._root_decomposition_cache = roots[0]
+        else:
+            self._root_decomposition_cache = roots
+        return inv_roots
+
+    def root_decomposition(self, method: Optional[str] = None):
+        """R with R R^T ~= A (reference :2158-2218).  Methods on this path: "lanczos" (device Lanczos + tridiagonal
+        eigh), "cholesky" (dense factor, N <= max_cholesky_size), "pivoted_cholesky"."""
+        from .root_linear_operator import RootLinearOperator
+
+        if not self.is_square:
+            raise RuntimeError(
+                "root_decomposition only operates on (batches of) square (symmetric) LinearOperators. "
+                "Got a {} of size {}.".format(self.__class__.__name__, self.size())
+            )
+        if self.shape[-2:].numel() == 1:
+            return RootLinearOperator(self.to_dense().sqrt())
+        if method is None:
+            method = self._choose_root_method()
+        if method == "cholesky":
+            return RootLinearOperator(self.cholesky().to_dense())
+        if method == "pivoted_cholesky":
+            return RootLinearOperator(self.pivoted_cholesky(rank=self._root_decomposition_size()))
+        if method == "lanczos":
+            return RootLinearOperator(self._root_decomposition())
+        raise RuntimeError(f"Unknown root decomposition method '{method}'")
+
+    def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method: Optional[str] = None):
+        """R with R R^T ~= A^-1 (reference :2220-2312); "lanczos" and "cholesky" on this path."""
+        from .root_linear_operator import RootLinearOperator
+
+        if not self.is_square:
+            raise RuntimeError(
+                "root_inv_decomposition only operates on (batches of) square (symmetric) LinearOperators. "
+                "Got a {} of size {}.".format(self.__class__.__name__, self.size())
+            )
+        if self.shape[-2:].numel() == 1:
+            return RootLinearOperator(1 / self.to_dense().sqrt())
+        if method is None:
+            method = self._choose_root_method()
+        if method == "cholesky":
+            L = self.cholesky().to_dense()
+            eye = torch.eye(L.shape[-2], device=L.device, dtype=L.dtype)
+            return RootLinearOperator(torch.linalg.solve_triangular(L, eye, upper=False).mT)
+        if method == "lanczos":
+            if initial_vectors is not None:
+                if self.dim() == 2 and initial_vectors.dim() == 1:
+                    if self.shape[-1] != initial_vectors.numel():
+                        raise RuntimeError(
+                            "LinearOperator (size={}) cannot be multiplied with initial_vectors (size={}).".format(
+                                self.shape, initial_vectors.shape
+                            )
+                        )
+                elif self.dim() != initial_vectors.dim():
+                    raise RuntimeError(
+                        "LinearOperator (size={}) and initial_vectors (size={}) should have the same number "
+                        "of dimensions.".format(self.shape, initial_vectors.shape)
+                    )
+                elif self.batch_shape != initial_vectors.shape[:-2] or self.shape[-1] != initial_vectors.shape[-2]:
+                    raise RuntimeError(
+                        "LinearOperator (size={}) cannot be multiplied with initial_vectors (size={}).".format(
+                            self.shape, initial_vectors.shape
+                        )
+                    )
+            inv_root = self._root_inv_decomposition(initial_vectors)
+            if initial_vectors is not None and initial_vectors.size(-1) > 1:
+                from ..utils.lanczos import _postprocess_lanczos_root_inv_decomp
+
+                inv_root = _postprocess_lanczos_root_inv_decomp(self, inv_root, initial_vectors, test_vectors)
+            return RootLinearOperator(inv_root)
+        raise RuntimeError(f"Unknown root inv decomposition method '{method}'")
+
     def zero_mean_mvn_samples(self, num_samples: int) -> Tensor:  # reference :2746-2793 (root-based branch)
-        raise NotImplementedError(f"{self.__class__.__name__}.zero_mean_mvn_samples needs a root decomposition "
-                                  "(Lanczos consumers are SURVEY 8(f) 'next')")
+        if self.size()[-2:] == torch.Size([1, 1]):
+            covar_root = self.to_dense().sqrt()
+        else:
+            covar_root = self.root_decomposition().root
+        base_samples = torch.randn(*self.batch_shape, covar_root.size(-1), num_samples, dtype=self.dtype,
+                                   device=self.device)
+        return covar_root.matmul(base_samples).permute(-1, *range(self.dim() - 1)).contiguous()
 
     # ------------------------------------------------------------------ torch dispatch (reference :2981-3009)
     @classmethod
@@ -527,3 +628,4 @@ def to_dense(obj):
 
 
 __all__ = ["LinearOperator", "to_dense"]
+

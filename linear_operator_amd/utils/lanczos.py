@@ -65,3 +65,21 @@ def lanczos_tridiag_to_diag(t_mat):
     evecs = evecs * mask.type_as(evecs).unsqueeze(-2)
     evals = evals.masked_fill_(~mask, 1)
     return evals, evecs
+
+
+def _postprocess_lanczos_root_inv_decomp(linear_op, inv_roots, initial_vectors, test_vectors):
+    """Pick, among the inverse roots obtained from each initial vector (inv_roots [P, *batch, N, k]), the one whose
+    implied solve R R^T t reproduces the test vectors best under the operator: argmin_p sum || A R_p R_p^T t - t ||_2
+    (reference utils/lanczos.py:192-223)."""
+    n_cand = initial_vectors.size(-1)
+    t = test_vectors.unsqueeze(0)
+    cand_solves = inv_roots.matmul(inv_roots.mT.matmul(t))  # [P, *batch, N, T]
+    nd = linear_op.dim()
+    stacked = cand_solves.permute(*range(1, nd + 1), 0).contiguous()
+    stacked = stacked.view(*linear_op.batch_shape, linear_op.matrix_shape[-1], -1)
+    back = linear_op.matmul(stacked)
+    back = back.view(*linear_op.batch_shape, linear_op.matrix_shape[-1], -1, n_cand).permute(-1, *range(0, nd))
+    err = (back - t).norm(2, dim=-2)
+    err = err.view(err.size(0), -1).sum(-1)
+    best = err.min(0)[1]
+    return inv_roots[best].squeeze(0)

@@ -578,3 +578,29 @@ def woodbury_logdet(C, d):
     """logdet(C C^T + D) = 2 sum log diag(chol_cap_mat) + sum log d, restating `_logdet` (:97-103)."""
     chol = woodbury_chol_cap_mat(C, d)
     return 2.0 * np.log(np.diagonal(chol, axis1=-2, axis2=-1)).sum(-1) + np.log(d).sum(-1)
+
+
+# ----------------------------------------------------------------------------------
+# RootDecomposition.forward (SURVEY 8(f) rank 2)
+# ----------------------------------------------------------------------------------
+
+
+def root_decomposition(matmul_closure, init_vecs, max_iter, tridiagonal_jitter=1e-3):
+    """Lanczos root / inverse root, restating RootDecomposition.forward (functions/_root_decomposition.py:49-85):
+    Q, T <- Lanczos; T += jitter * min(diag T) * I (:67-70); (lambda, V) <- eigh with the negative-eigenvalue clamp;
+    Q <- Q V; root = Q o sqrt(lambda); inverse = Q / sqrt(lambda).
+    init_vecs [*B,N,P] -> (root, inverse) [P,*B,N,k] (leading P squeezed iff P == 1)."""
+    q_mat, t_mat = lanczos_tridiag(matmul_closure, max_iter, init_vecs)
+    single = t_mat.ndim == init_vecs.ndim  # one probe vector: no leading P (:62-64)
+    if single:
+        q_mat, t_mat = q_mat[None], t_mat[None]
+    k = t_mat.shape[-1]
+    mins = np.diagonal(t_mat, axis1=-2, axis2=-1).min(axis=-1)[..., None, None]
+    jit = (t_mat.dtype.type(tridiagonal_jitter) * mins) * np.eye(k, dtype=t_mat.dtype)
+    evals, evecs = lanczos_tridiag_to_diag(t_mat + jit)
+    q_mat = q_mat @ evecs
+    s = np.sqrt(evals)[..., None, :]
+    root, inverse = q_mat * s, q_mat / s
+    if single:
+        root, inverse = root[0], inverse[0]
+    return root, inverse

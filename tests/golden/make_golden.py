@@ -352,11 +352,38 @@ def g7_low_rank_root_added_diag():
     save("g7_lowrank_added_diag", checksum=cases.checksum(C, d, rhs, sig), **out)
 
 
+def g8_root_decomposition():
+    """RootDecomposition.forward (Lanczos consumers) with SUPPLIED initial vectors (the default
+    randn start is not reproducible), root_inv_decomposition's choice among several initial vectors, and the dense
+    Cholesky-method root for a small operator."""
+    from linear_operator.functions._root_decomposition import RootDecomposition
+
+    C, d, _ = cases.lowrank_diag(801, 2, 512, 8, 1)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+    v1 = cases.randn(802, 2, 512, 1, dtype=np.float32)
+    v3 = cases.randn(803, 2, 512, 3, dtype=np.float32)
+    tv = cases.randn(804, 2, 512, 2, dtype=np.float32)
+    out = {}
+    for name, iv in (("p1", v1), ("p3", v3)):
+        root, inv = RootDecomposition.apply(A.representation_tree(), 12, A.dtype, A.device, A.batch_shape,
+                                            A.matrix_shape, True, True, T(iv), *A.representation())
+        out[f"root_{name}"], out[f"inv_{name}"] = root, inv
+        out[f"rrt_tv_{name}"] = root @ (root.mT @ T(tv))      # R R^T t   (sign-invariant)
+        out[f"iit_tv_{name}"] = inv @ (inv.mT @ T(tv))
+    with settings.max_cholesky_size(0):
+        Rinv = A.root_inv_decomposition(initial_vectors=T(v3), test_vectors=T(tv))
+    out["best_iit_tv"] = Rinv.root.to_dense() @ (Rinv.root.to_dense().mT @ T(tv))
+    dense = (T(C) @ T(C).mT + torch.diag_embed(T(d)))
+    out["A_tv"] = dense @ T(tv)
+    out["Ainv_tv"] = np.linalg.solve(dense.double().numpy(), tv.astype(np.float64))  # (torch fp64 solve hangs here)
+    save("g8_root_decomposition", checksum=cases.checksum(C, d, v1, v3, tv), **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
-                     ("g7", g7_low_rank_root_added_diag)):
+                     ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition)):
         if name in todo:
             fn()
     print("done")

@@ -218,3 +218,43 @@ def test_low_rank_root_added_diag_woodbury_closed_form():
     Acg = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(Cb)), DiagLinearOperator(dev(db)))
     with settings.cg_tolerance(1e-4):
         assert max_rel_err_cols(host(Aw.solve(dev(rb))), host(Acg.solve(dev(rb)))) < 1e-4
+
+
+def test_root_decomposition_lanczos_consumers():
+    """RootDecomposition.forward / root_decomposition / root_inv_decomposition /
+    zero_mean_mvn_samples on the device (Lanczos + tridiagonal eigh + lo_root_from_lanczos_f32) against the golden
+    outputs of the reference (sign-invariant products) and the oracle."""
+    from linear_operator_amd.functions._root_decomposition import RootDecomposition
+    from oracle import lo_oracle as orc
+
+    g = load_golden("g8_root_decomposition")
+    C, d, _ = cases.lowrank_diag(801, 2, 512, 8, 1)
+    v1 = cases.randn(802, 2, 512, 1, dtype=np.float32)
+    v3 = cases.randn(803, 2, 512, 3, dtype=np.float32)
+    tv = cases.randn(804, 2, 512, 2, dtype=np.float32)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C)), DiagLinearOperator(dev(d)))
+    for name, iv in (("p1", v1), ("p3", v3)):
+        root, inv = RootDecomposition.apply(A.representation_tree(), 12, A.dtype, A.device, A.batch_shape,
+                                            A.matrix_shape, True, True, dev(iv), *A.representation())
+        assert tuple(root.shape) == g[f"root_{name}"].shape and tuple(inv.shape) == g[f"inv_{name}"].shape
+        rrt = host(root @ (root.mT @ dev(tv)))
+        iit = host(inv @ (inv.mT @ dev(tv)))
+        assert max_rel_err_cols(rrt, g[f"rrt_tv_{name}"]) < 2e-3
+        assert max_rel_err_cols(iit, g[f"iit_tv_{name}"]) < 1e-2
+        ro, io = orc.root_decomposition(lambda v: orc.matvec_lowrank_diag(C, d, v), iv, 12)
+        assert max_rel_err_cols(rrt, ro @ (np.swapaxes(ro, -1, -2) @ tv)) < 2e-3
+    with settings.max_cholesky_size(0):
+        Rinv = A.root_inv_decomposition(initial_vectors=dev(v3), test_vectors=dev(tv))
+        R = A.root_decomposition()  # random start vector: only the quality of the approximation can be checked
+        samples = A.zero_mean_mvn_samples(7)
+    ri = Rinv.root.to_dense()
+    assert max_rel_err_cols(host(ri @ (ri.mT @ dev(tv))), g["best_iit_tv"]) < 1e-2
+    assert R.root.to_dense().shape[-2] == 512 and tuple(samples.shape) == (7, 2, 512)
+    # Lanczos property (A q_0 in span(q_0, q_1)): R R^T reproduces A on the start vector up to the tridiagonal jitter
+    root1, _ = RootDecomposition.apply(A.representation_tree(), 12, A.dtype, A.device, A.batch_shape, A.matrix_shape,
+                                       True, False, dev(v1), *A.representation())
+    assert max_rel_err_cols(host(root1 @ (root1.mT @ dev(v1))), host(A @ dev(v1))) < 5e-3
+    # small operators take the dense Cholesky root (reference _choose_root_method)
+    As = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C[:, :64])), DiagLinearOperator(dev(d[:, :64])))
+    Rs = As.root_decomposition().to_dense()
+    assert np.allclose(host(Rs), host(As.to_dense()), rtol=1e-4, atol=1e-5)

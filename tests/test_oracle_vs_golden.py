@@ -308,3 +308,27 @@ def test_g7_low_rank_root_added_diag_closed_forms():
     dc = np.broadcast_to(sig[:, None], (3, 1024))
     assert max_rel_err_cols(orc.woodbury_solve(C.astype(np.float64), dc, rhs.astype(np.float64)), g["x_const"]) < 1e-4
     assert np.allclose(orc.woodbury_logdet(C.astype(np.float64), dc), g["logdet_const"], rtol=1e-5)
+
+
+def test_g8_root_decomposition_forward():
+    """RootDecomposition.forward with supplied initial vectors.  Eigenvector signs are free, so
+    roots are compared through R R^T t and R^-T R^-1 t; the 12-step Lanczos basis is only approximately the
+    reference's in fp32 (re-orthogonalisation noise), hence the 1e-3 level of agreement on the products."""
+    g = load_golden("g8_root_decomposition")
+    C, d, _ = cases.lowrank_diag(801, 2, 512, 8, 1)
+    v1 = cases.randn(802, 2, 512, 1, dtype=np.float32)
+    v3 = cases.randn(803, 2, 512, 3, dtype=np.float32)
+    tv = cases.randn(804, 2, 512, 2, dtype=np.float32)
+    assert cases.checksum(C, d, v1, v3, tv) == g["checksum"]
+    mv = lambda v: orc.matvec_lowrank_diag(C, d, v)  # noqa: E731
+    for name, iv in (("p1", v1), ("p3", v3)):
+        root, inv = orc.root_decomposition(mv, iv, 12)
+        assert root.shape == g[f"root_{name}"].shape and inv.shape == g[f"inv_{name}"].shape
+        rrt = root @ (np.swapaxes(root, -1, -2) @ tv)
+        iit = inv @ (np.swapaxes(inv, -1, -2) @ tv)
+        assert max_rel_err_cols(rrt, g[f"rrt_tv_{name}"]) < 2e-3
+        assert max_rel_err_cols(iit, g[f"iit_tv_{name}"]) < 1e-2  # 1/lambda amplifies the noise of the small Ritz values
+    # Lanczos property: A q_0 lies in span(q_0, q_1), so R R^T = Q (T + jitter) Q^T reproduces A on the start vector
+    # up to the tridiagonal jitter (1e-3 * min diag T)
+    root, inv = orc.root_decomposition(mv, v1, 12)
+    assert max_rel_err_cols(root @ (np.swapaxes(root, -1, -2) @ v1), mv(v1)) < 5e-3
