@@ -199,6 +199,21 @@ size_t lo_tridiag_eigh_slq_workspace_bytes(int64_t P, int64_t B);
 int lo_tridiag_eigh_slq_f32(const float* t_mat, int64_t P, int64_t B, int32_t T, int64_t n, float* evals, float* evecs,
                             float* logdet, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- backward passes: `_bilinear_derivative` contractions -------------------------------- */
+/* U = left_vecs [B,N,D], V = right_vecs [B,N,D] (fp32, contiguous); derivative of sum_d u_d^T K v_d w.r.t. the
+ * tensor representing K.
+ *   dense: out [B,N,N] = U V^T                               (dense_linear_operator.py:69-71)
+ *   diag : out [B,N] = sum_d U o V; constant != 0: out [B] = sum_{n,d} U o V (ws: B*N floats)
+ *                                                            (diag_linear_operator.py:37-45, :337-344)
+ *   root : out [B,N,R] = U (V^T C) + V (U^T C) for K = C C^T, C [B,N,R]
+ *          (autograd of root._matmul(root._t_matmul(v)), _linear_operator.py:336-393, root_linear_operator.py:68-72) */
+int lo_bilinear_dense_f32(const float* U, const float* V, int64_t B, int64_t N, int64_t D, float* out, void* stream);
+int lo_bilinear_diag_f32(const float* U, const float* V, int64_t B, int64_t N, int64_t D, int32_t constant, float* out,
+                         void* ws, size_t ws_bytes, void* stream);
+size_t lo_bilinear_root_workspace_bytes(int64_t B, int64_t N, int64_t R, int64_t D);
+int lo_bilinear_root_f32(const float* C, const float* U, const float* V, int64_t B, int64_t N, int64_t R, int64_t D,
+                         float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- measurement aid (no reference counterpart) ------------------------------------------------ */
 /* Opt-in HIP-event timing of every kernel launch of the library, recorded on the launch stream.
  * lo_prof_report writes "name count total_ms" lines into buf (returns the byte count) and resets.

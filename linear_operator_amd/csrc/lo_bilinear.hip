@@ -1,0 +1,247 @@
+// lo_bilinear.hip -- `_bilinear_derivative` contractions of the backward passes: given
+// U = left_vecs [B,N,D] and V = right_vecs [B,N,D], the derivative of sum_d u_d^T K v_d with respect to the tensors
+// that represent K:
+//   Dense  K            : U V^T                         (operators/dense_linear_operator.py:69-71)
+//   Diag   diag(k)      : sum_d U o V   [B,N]           (operators/diag_linear_operator.py:37-45)
+//   ConstantDiag s I    : sum_{n,d} U o V   [B,1]       (operators/diag_linear_operator.py:337-344)
+//   Root   C C^T        : U (V^T C) + V (U^T C)  [B,N,R]  (autograd of root._matmul(root._t_matmul(v)),
+//                          operators/_linear_operator.py:336-393 + root_linear_operator.py:68-72)
+// All HBM-bound streaming kernels: the dense one writes N^2 outputs per member, the others read the skinny operands
+// once or twice.  fp32, fixed summation order (partials over row slices are summed in order by the consumer).
+#include <algorithm>
+
+#include "lo_device.h"
+#include "lo_internal.h"
+
+namespace lo {
+
+constexpr int kBdTile = 64;   // output tile of the dense outer product
+constexpr int kBdMaxD = 64;   // columns of U / V staged per pass
+
+// out[b, i, j] (+)= sum_d U[b,i,d] V[b,j,d]
+__global__ __launch_bounds__(kThreads) void k_bil_dense(const float* __restrict__ U, const float* __restrict__ V,
+                                                         int N, int D, int d0, int dn, float* __restrict__ out) {
+  __shared__ float u_s[kBdTile][kBdMaxD + 1];
+  __shared__ float v_s[kBdTile][kBdMaxD + 1];
+  const int64_t b = blockIdx.z;
+  const int i0 = blockIdx.y * kBdTile, j0 = blockIdx.x * kBdTile;
+  for (int e = threadIdx.x; e < kBdTile * dn; e += kThreads) {
+    const int r = e / dn, d = e % dn;
+    u_s[r][d] = (i0 + r < N) ? U[((size_t)b * N + i0 + r) * D + d0 + d] : 0.f;
+    v_s[r][d] = (j0 + r < N) ? V[((size_t)b * N + j0 + r) * D + d0 + d] : 0.f;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;  // 16 x 16 threads, 4 x 4 outputs each
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
+  for (int d = 0; d < dn; ++d) {
+    float uu[4], vv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      uu[a] = u_s[ty + 16 * a][d];
+      vv[a] = v_s[tx + 16 * a][d];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[a][c] = fmaf(uu[a], vv[c], acc[a][c]);
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = i0 + ty + 16 * a;
+    if (i >= N) continue;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = j0 + tx + 16 * c;  // consecutive threads -> consecutive columns
+      if (j < N) {
+        float* o = out + ((size_t)b * N + i) * N + j;
+        *o = (d0 == 0) ? acc[a][c] : *o + acc[a][c];
+      }
+    }
+  }
+}
+
+// out[b, n] = sum_d U o V
+__global__ __launch_bounds__(kThreads) void k_bil_diag(const float* __restrict__ U, const float* __restrict__ V,
+                                                        int64_t rows, int D, float* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (r >= rows) return;
+  const float* u = U + (size_t)r * D;
+  const float* v = V + (size_t)r * D;
+  float acc = 0.f;
+  for (int d = 0; d < D; ++d) acc = fmaf(u[d], v[d], acc);
+  out[r] = acc;
+}
+
+// out[b] = sum_n rowdot[b, n]  (fixed order: thread-strided partials, then the block tree)
+__global__ __launch_bounds__(kThreads) void k_bil_sum_rows(const float* __restrict__ rowdot, int N,
+                                                            float* __restrict__ out) {
+  __shared__ float red[kThreads];
+  const int64_t b = blockIdx.x;
+  float acc = 0.f;
+  for (int n = threadIdx.x; n < N; n += kThreads) acc += rowdot[(size_t)b * N + n];
+  const float tot = block_sum256(acc, red);
+  if (threadIdx.x == 0) out[b] = tot;
+}
+
+// Root, phase A: partial T1 = V^T C and T2 = U^T C over a slice of rows: tpart[b, s, 2, D, R]
+constexpr int kBrRows = 32;
+
+__global__ __launch_bounds__(kThreads) void k_bil_root_t(const float* __restrict__ C, const float* __restrict__ U,
+                                                          const float* __restrict__ V, int N, int R, int D,
+                                                          int rows_per, float* __restrict__ tpart) {
+  extern __shared__ float sh[];  // c_s [kBrRows][R] | u_s [kBrRows][D] | v_s [kBrRows][D]
+  float* c_s = sh;
+  float* u_s = c_s + kBrRows * R;
+  float* v_s = u_s + kBrRows * D;
+  const int s = blockIdx.x, S = gridDim.x;
+  const int64_t b = blockIdx.y;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  const int npair = D * R;
+  // thread t owns the pairs t, t + 256, ... (at most 8 per matrix: D * R <= 2048)
+  float a1[8], a2[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a1[u] = a2[u] = 0.f;
+  for (int base = r0; base < r1; base += kBrRows) {
+    const int nr = min(kBrRows, r1 - base);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nr * R; e += kThreads) c_s[e] = C[((size_t)b * N + base) * R + e];
+    for (int e = threadIdx.x; e < nr * D; e += kThreads) {
+      u_s[e] = U[((size_t)b * N + base) * D + e];
+      v_s[e] = V[((size_t)b * N + base) * D + e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int pr = threadIdx.x + kThreads * u;
+      if (pr < npair) {
+        const int d = pr / R, rho = pr % R;
+        float x1 = a1[u], x2 = a2[u];
+        for (int rr = 0; rr < nr; ++rr) {
+          const float cv = c_s[rr * R + rho];
+          x1 = fmaf(v_s[rr * D + d], cv, x1);
+          x2 = fmaf(u_s[rr * D + d], cv, x2);
+        }
+        a1[u] = x1;
+        a2[u] = x2;
+      }
+    }
+  }
+  float* tp = tpart + ((size_t)b * S + s) * 2 * npair;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int pr = threadIdx.x + kThreads * u;
+    if (pr < npair) {
+      tp[pr] = a1[u];
+      tp[npair + pr] = a2[u];
+    }
+  }
+}
+
+// Root, phase B: out[b, n, rho] = sum_d U[n,d] T1[d,rho] + V[n,d] T2[d,rho], T = sum_s tpart (fixed order)
+__global__ __launch_bounds__(kThreads) void k_bil_root_out(const float* __restrict__ U, const float* __restrict__ V,
+                                                            const float* __restrict__ tpart, int S, int N, int R,
+                                                            int D, float* __restrict__ out) {
+  extern __shared__ float sh[];  // t1 [D][R] | t2 [D][R]
+  const int64_t b = blockIdx.y;
+  const int npair = D * R;
+  for (int e = threadIdx.x; e < 2 * npair; e += kThreads) {
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += tpart[((size_t)b * S + s) * 2 * npair + e];
+    sh[e] = acc;
+  }
+  __syncthreads();
+  // thread = (row, group of 4 columns): consecutive threads write consecutive 16-byte pieces
+  const int R4 = (R + 3) / 4;
+  const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const int row = (int)(idx / R4), g = (int)(idx % R4);
+  if (row >= N) return;
+  const float* u = U + ((size_t)b * N + row) * D;
+  const float* v = V + ((size_t)b * N + row) * D;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int d = 0; d < D; ++d) {
+    const float ud = u[d], vd = v[d];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int rho = 4 * g + e;
+      if (rho < R) acc[e] = fmaf(ud, sh[d * R + rho], fmaf(vd, sh[npair + d * R + rho], acc[e]));
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int rho = 4 * g + e;
+    if (rho < R) out[((size_t)b * N + row) * R + rho] = acc[e];
+  }
+}
+
+}  // namespace lo
+
+using namespace lo;
+
+extern "C" {
+
+int lo_bilinear_dense_f32(const float* U, const float* V, int64_t B, int64_t N, int64_t D, float* out, void* stream) {
+  if (!U || !V || !out || B < 1 || N < 1 || D < 1 || B > 65535) return LO_ERR_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((N + kBdTile - 1) / kBdTile), (unsigned)((N + kBdTile - 1) / kBdTile), (unsigned)B);
+  for (int64_t d0 = 0; d0 < D; d0 += kBdMaxD) {  // more than 64 columns: accumulate passes
+    const int dn = (int)std::min<int64_t>(kBdMaxD, D - d0);
+    LO_PROF_BEGIN("bil_dense", st);
+    hipLaunchKernelGGL(k_bil_dense, grid, dim3(kThreads), 0, st, U, V, (int)N, (int)D, (int)d0, dn, out);
+    LO_PROF_END(st);
+    LO_LAUNCH_CHECK();
+  }
+  return LO_OK;
+}
+
+int lo_bilinear_diag_f32(const float* U, const float* V, int64_t B, int64_t N, int64_t D, int32_t constant,
+                         float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!U || !V || !out || B < 1 || N < 1 || D < 1) return LO_ERR_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = B * N;
+  float* rowdot = out;
+  if (constant) {
+    if (!ws || ws_bytes < sizeof(float) * (size_t)rows) return LO_ERR_WORKSPACE;
+    rowdot = (float*)ws;
+  }
+  LO_PROF_BEGIN("bil_diag", st);
+  hipLaunchKernelGGL(k_bil_diag, dim3((unsigned)((rows + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, U, V, rows,
+                     (int)D, rowdot);
+  LO_PROF_END(st);
+  if (constant) hipLaunchKernelGGL(k_bil_sum_rows, dim3((unsigned)B), dim3(kThreads), 0, st, rowdot, (int)N, out);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+size_t lo_bilinear_root_workspace_bytes(int64_t B, int64_t N, int64_t R, int64_t D) {
+  Split sp = choose_split(B, N, 256);
+  return sizeof(float) * (size_t)B * sp.S * 2 * D * R + 256;
+}
+
+int lo_bilinear_root_f32(const float* C, const float* U, const float* V, int64_t B, int64_t N, int64_t R, int64_t D,
+                         float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!C || !U || !V || !out || !ws || B < 1 || N < 1 || R < 1 || D < 1 || B > 65535) return LO_ERR_BADARG;
+  if (D * R > 8 * kThreads) return LO_ERR_UNSUPPORTED;
+  const size_t lds_a = sizeof(float) * (size_t)kBrRows * (R + 2 * D), lds_b = sizeof(float) * (size_t)2 * D * R;
+  if (lds_a > 64 * 1024 || lds_b > 64 * 1024) return LO_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  Split sp = choose_split(B, N, 256);
+  if (ws_bytes < sizeof(float) * (size_t)B * sp.S * 2 * D * R) return LO_ERR_WORKSPACE;
+  float* tpart = (float*)ws;
+  LO_PROF_BEGIN("bil_root_t", st);
+  hipLaunchKernelGGL(k_bil_root_t, dim3(sp.S, (unsigned)B), dim3(kThreads), lds_a, st, C, U, V, (int)N, (int)R, (int)D,
+                     sp.rows, tpart);
+  LO_PROF_END(st);
+  const int64_t items = N * ((R + 3) / 4);
+  LO_PROF_BEGIN("bil_root_out", st);
+  hipLaunchKernelGGL(k_bil_root_out, dim3((unsigned)((items + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads),
+                     lds_b, st, U, V, tpart, sp.S, (int)N, (int)R, (int)D, out);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+}  // extern "C"

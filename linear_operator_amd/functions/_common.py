@@ -1,6 +1,6 @@
-"""Forward-only autograd wrappers: the reference's Functions save tensors for a backward pass built from more
-solves and `_bilinear_derivative` (SURVEY 8(b) 'Autograd', 8(f) rank 1 -- 'next').  The wrappers are kept so
-that backward can be added behind the same call sites; until then asking for gradients fails loudly."""
+"""Autograd wrappers.  Matmul, Solve, InvQuad and InvQuadLogdet have forward and backward (more solves plus the
+`_bilinear_derivative` contractions of csrc/lo_bilinear.hip); PivotedCholesky and RootDecomposition
+are forward-only: asking them for gradients fails loudly."""
 from __future__ import annotations
 
 

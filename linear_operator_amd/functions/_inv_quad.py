@@ -5,7 +5,6 @@ import torch
 from torch.autograd import Function
 
 from .. import settings
-from ._common import not_yet
 
 
 def _solve(linear_op, rhs):
@@ -20,13 +19,28 @@ class InvQuad(Function):
     @staticmethod
     def forward(ctx, representation_tree, *args):
         inv_quad_rhs, *matrix_args = args
+        ctx.representation_tree = representation_tree
         linear_op = representation_tree(*matrix_args)
-        is_vector = inv_quad_rhs.ndimension() == 1
-        if is_vector:
+        ctx.is_vector = inv_quad_rhs.ndimension() == 1
+        if ctx.is_vector:
             inv_quad_rhs = inv_quad_rhs.unsqueeze(-1)
         solves = _solve(linear_op, inv_quad_rhs)
+        ctx.save_for_backward(*matrix_args, solves)
         return (solves * inv_quad_rhs).sum(-2)
 
     @staticmethod
-    def backward(ctx, grad_output):
-        not_yet("InvQuad")
+    def backward(ctx, inv_quad_grad_output):  # reference :63-93
+        *matrix_args, inv_quad_solves = ctx.saved_tensors
+        linear_op = ctx.representation_tree(*matrix_args)
+        inv_quad_grad_output = inv_quad_grad_output.unsqueeze(-2)
+        neg_solves_times_grad = inv_quad_solves.mul(inv_quad_grad_output).mul(-1)
+        matrix_arg_grads = [None] * len(matrix_args)
+        if any(ctx.needs_input_grad[2:]):
+            matrix_arg_grads = linear_op._bilinear_derivative(neg_solves_times_grad, inv_quad_solves)
+        if ctx.needs_input_grad[1]:
+            inv_quad_rhs_grad = neg_solves_times_grad.mul(-2)
+        else:
+            inv_quad_rhs_grad = torch.zeros_like(inv_quad_solves)
+        if ctx.is_vector:
+            inv_quad_rhs_grad = inv_quad_rhs_grad.squeeze(-1)
+        return tuple([None] + [inv_quad_rhs_grad] + list(matrix_arg_grads))

@@ -12,7 +12,6 @@ from .. import kernels as K
 from .. import settings
 from ..utils.lanczos import lanczos_tridiag_to_diag
 from ..utils.stochastic_lq import StochasticLQ
-from ._common import not_yet
 
 
 class InvQuadLogdet(Function):
@@ -26,6 +25,11 @@ class InvQuadLogdet(Function):
             matrix_args, precond_args = args[:-num_precond_args], args[-num_precond_args:]
         else:
             matrix_args, precond_args = args, tuple()
+        ctx.representation_tree = representation_tree
+        ctx.precond_representation_tree = precond_representation_tree
+        ctx.preconditioner = preconditioner
+        ctx.inv_quad = inv_quad
+        ctx.num_precond_args = num_precond_args
         linear_op = representation_tree(*matrix_args)
         precond_lt = precond_representation_tree(*precond_args)
         dtype, device = linear_op.dtype, linear_op.device
@@ -43,9 +47,11 @@ class InvQuadLogdet(Function):
         rhs_list = [probe_vectors]
         num_random_probes = probe_vectors.size(-1)
         num_inv_quad_solves = 0
+        ctx.is_vector = False
         if inv_quad:
             if inv_quad_rhs.ndimension() == 1:
                 inv_quad_rhs = inv_quad_rhs.unsqueeze(-1)
+                ctx.is_vector = True
             rhs_list.append(inv_quad_rhs)
             num_inv_quad_solves = inv_quad_rhs.size(-1)
         rhs = torch.cat(rhs_list, -1)
@@ -65,8 +71,65 @@ class InvQuadLogdet(Function):
         if inv_quad:  # reference :151-153
             inv_quad_solves = solves.narrow(-1, num_random_probes, num_inv_quad_solves)
             inv_quad_term = (inv_quad_solves * inv_quad_rhs).sum(-2)
+        ctx.probe_vectors = probe_vectors
+        ctx.probe_vector_norms = probe_vector_norms
+        ctx.num_random_probes = num_random_probes
+        ctx.num_inv_quad_solves = num_inv_quad_solves
+        ctx.save_for_backward(*precond_args, *matrix_args, solves)  # reference :155-159
         return inv_quad_term, logdet_term
 
     @staticmethod
-    def backward(ctx, inv_quad_grad_output, logdet_grad_output):
-        not_yet("InvQuadLogdet")
+    def backward(ctx, inv_quad_grad_output, logdet_grad_output):  # reference :163-226
+        if ctx.num_precond_args:
+            precond_args = ctx.saved_tensors[: ctx.num_precond_args]
+            matrix_args = ctx.saved_tensors[ctx.num_precond_args: -1]
+        else:
+            precond_args = []
+            matrix_args = ctx.saved_tensors[:-1]
+        solves = ctx.saved_tensors[-1]
+        linear_op = ctx.representation_tree(*matrix_args)
+        precond_lt = ctx.precond_representation_tree(*precond_args)
+
+        if ctx.inv_quad:
+            inv_quad_grad_output = inv_quad_grad_output.unsqueeze(-2)
+        logdet_grad_output = logdet_grad_output.unsqueeze(-1).unsqueeze(-1)
+
+        # un-normalise the probe-vector solves (:183-186)
+        coef = 1.0 / ctx.probe_vectors.size(-1)
+        probe_vector_solves = solves.narrow(-1, 0, ctx.num_random_probes).mul(coef)
+        probe_vector_solves = probe_vector_solves.mul(ctx.probe_vector_norms).mul(logdet_grad_output)
+
+        # probes were drawn from N(0, P); P^-1 probes are draws from N(0, P^-1)  (:188-193)
+        if ctx.preconditioner is not None:
+            precond_probe_vectors = ctx.preconditioner((ctx.probe_vectors * ctx.probe_vector_norms).contiguous())
+        else:
+            precond_probe_vectors = ctx.probe_vectors * ctx.probe_vector_norms
+
+        left_factors_list = [probe_vector_solves]
+        right_factors_list = [precond_probe_vectors]
+        neg_inv_quad_solves_times_grad_out = None
+        if ctx.inv_quad:
+            inv_quad_solves = solves.narrow(-1, ctx.num_random_probes, ctx.num_inv_quad_solves)
+            neg_inv_quad_solves_times_grad_out = inv_quad_solves.mul(inv_quad_grad_output).mul(-1)
+            left_factors_list.append(neg_inv_quad_solves_times_grad_out)
+            right_factors_list.append(inv_quad_solves)
+        left_factors = torch.cat(left_factors_list, -1)
+        right_factors = torch.cat(right_factors_list, -1)
+        matrix_arg_grads = linear_op._bilinear_derivative(left_factors, right_factors)
+
+        # preconditioner gradient (:211-213): only computed when one of its tensors asks for it
+        if any(t.requires_grad for t in precond_args):
+            precond_arg_grads = precond_lt._bilinear_derivative(
+                -precond_probe_vectors * coef, precond_probe_vectors * logdet_grad_output
+            )
+        else:
+            precond_arg_grads = [None] * len(precond_args)
+
+        if ctx.inv_quad:
+            inv_quad_rhs_grad = neg_inv_quad_solves_times_grad_out.mul(-2)
+            if ctx.is_vector:
+                inv_quad_rhs_grad = inv_quad_rhs_grad.squeeze(-1)
+            res = [inv_quad_rhs_grad] + list(matrix_arg_grads) + list(precond_arg_grads)
+        else:
+            res = list(matrix_arg_grads) + list(precond_arg_grads)
+        return tuple([None] * 7 + res)

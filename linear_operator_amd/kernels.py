@@ -407,6 +407,60 @@ def root_from_lanczos(q_mat: torch.Tensor, evecs: torch.Tensor, evals: torch.Ten
     return qv.reshape(shp), (None if root is None else root.reshape(shp)), (None if inv is None else inv.reshape(shp))
 
 
+def _uv(left_vecs: torch.Tensor, right_vecs: torch.Tensor, batch_shape):
+    """Broadcast left / right vectors [*b, N, D] to the operator's batch and flatten it."""
+    if left_vecs.dim() == 1:
+        left_vecs, right_vecs = left_vecs.unsqueeze(-1), right_vecs.unsqueeze(-1)
+    bs = torch.broadcast_shapes(tuple(batch_shape), left_vecs.shape[:-2], right_vecs.shape[:-2])
+    N, D = left_vecs.shape[-2:]
+    U = left_vecs.expand(*bs, N, D).contiguous().reshape(-1, N, D)
+    V = right_vecs.expand(*bs, N, D).contiguous().reshape(-1, N, D)
+    _hip.require_hip(U, V)
+    return U, V, bs
+
+
+def bilinear_dense(left_vecs: torch.Tensor, right_vecs: torch.Tensor, batch_shape=()):
+    """lo_bilinear_dense_f32: U V^T [*batch, N, N] (dense_linear_operator.py:69-71)."""
+    lib = _hip.load()
+    U, V, bs = _uv(left_vecs, right_vecs, batch_shape)
+    B, N, D = U.shape
+    out = torch.empty(B, N, N, dtype=torch.float32, device=U.device)
+    _hip.check(lib.lo_bilinear_dense_f32(_hip.ptr(U), _hip.ptr(V), B, N, D, _hip.ptr(out), _hip.stream_ptr(U.device)),
+               "lo_bilinear_dense_f32")
+    return out.reshape(*bs, N, N)
+
+
+def bilinear_diag(left_vecs: torch.Tensor, right_vecs: torch.Tensor, batch_shape=(), constant: bool = False):
+    """lo_bilinear_diag_f32: sum_d U o V [*batch, N], or its sum over N as [*batch, 1] for a constant diagonal
+    (diag_linear_operator.py:37-45, :337-344)."""
+    lib = _hip.load()
+    U, V, bs = _uv(left_vecs, right_vecs, batch_shape)
+    B, N, D = U.shape
+    dev = U.device
+    out = torch.empty(B if constant else B * N, dtype=torch.float32, device=dev)
+    ws = _hip.workspace(4 * B * N + 256, dev) if constant else None
+    _hip.check(lib.lo_bilinear_diag_f32(_hip.ptr(U), _hip.ptr(V), B, N, D, 1 if constant else 0, _hip.ptr(out),
+                                        _hip.ptr(ws), 0 if ws is None else ws.numel(), _hip.stream_ptr(dev)),
+               "lo_bilinear_diag_f32")
+    return out.reshape(*bs, 1) if constant else out.reshape(*bs, N)
+
+
+def bilinear_root(root: torch.Tensor, left_vecs: torch.Tensor, right_vecs: torch.Tensor):
+    """lo_bilinear_root_f32: U (V^T C) + V (U^T C) [*batch, N, R] for K = C C^T (autograd of the two-GEMM matvec)."""
+    lib = _hip.load()
+    U, V, bs = _uv(left_vecs, right_vecs, root.shape[:-2])
+    B, N, D = U.shape
+    R = root.shape[-1]
+    Cm = root.expand(*bs, N, R).contiguous().reshape(B, N, R)
+    _hip.require_hip(Cm)
+    dev = U.device
+    out = torch.empty(B, N, R, dtype=torch.float32, device=dev)
+    ws = _hip.workspace(lib.lo_bilinear_root_workspace_bytes(B, N, R, D), dev)
+    _hip.check(lib.lo_bilinear_root_f32(_hip.ptr(Cm), _hip.ptr(U), _hip.ptr(V), B, N, R, D, _hip.ptr(out), _hip.ptr(ws),
+                                        ws.numel(), _hip.stream_ptr(dev)), "lo_bilinear_root_f32")
+    return out.reshape(*bs, N, R)
+
+
 def set_onchip_cg(enable: bool):
     """Allow (default) or forbid the operator-resident CG fast path (csrc/lo_cg_onchip.hip); test / A-B switch."""
     _hip.load().lo_cg_set_onchip(1 if enable else 0)

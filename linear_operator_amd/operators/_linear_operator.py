@@ -210,6 +210,15 @@ class LinearOperator(object):
         return self.to("cpu")
 
     # ------------------------------------------------------------------ representation (reference :2076-2101)
+    def _bilinear_derivative(self, left_vecs: Tensor, right_vecs: Tensor):
+        """d/d(theta) sum_d u_d^T K(theta) v_d for the tensors theta that represent this operator (reference
+        :336-393).  The reference's generic version differentiates `_matmul` with autograd; the matvecs here are HIP
+        kernels, so every operator class on the path supplies the closed form (csrc/lo_bilinear.hip)."""
+        raise NotImplementedError(
+            f"{self.__class__.__name__}._bilinear_derivative is not implemented in linear_operator_amd: gradients flow "
+            "through Dense, Diag, ConstantDiag, Root / LowRankRoot and Sum / AddedDiag operators (SURVEY 8(f) rank 1)"
+        )
+
     def representation(self):
         rep = []
         for arg in itertools.chain(self._args, self._differentiable_kwargs.values()):

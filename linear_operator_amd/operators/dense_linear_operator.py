@@ -38,6 +38,10 @@ class DenseLinearOperator(LinearOperator):
     def _cholesky_solve(self, rhs, upper: bool = False):
         return torch.cholesky_solve(rhs, self.to_dense(), upper=upper)
 
+    def _bilinear_derivative(self, left_vecs: Tensor, right_vecs: Tensor):  # reference :69-71
+        res = K.bilinear_dense(left_vecs, right_vecs, self.batch_shape)
+        return (_sum_to(res, self.tensor.shape),)
+
     def _diagonal(self) -> Tensor:
         return self.tensor.diagonal(dim1=-1, dim2=-2)
 
@@ -85,3 +89,8 @@ def to_linear_operator(obj):
 
 
 __all__ = ["DenseLinearOperator", "to_linear_operator", "to_dense"]
+
+
+def _sum_to(grad: Tensor, shape) -> Tensor:
+    """Sum a derivative computed at the broadcast batch shape down to the shape of the tensor it belongs to."""
+    return grad if tuple(grad.shape) == tuple(shape) else grad.sum_to_size(*shape)

@@ -6,6 +6,7 @@ from __future__ import annotations
 import torch
 from torch import Tensor
 
+from .. import kernels as K
 from ._linear_operator import LinearOperator
 
 
@@ -34,6 +35,12 @@ class DiagLinearOperator(LinearOperator):
     def _get_indices(self, row_index, col_index, *batch_indices) -> Tensor:
         res = self._diag[(*batch_indices, row_index)]
         return res * torch.eq(row_index, col_index).to(device=res.device, dtype=res.dtype)
+
+    def _bilinear_derivative(self, left_vecs: Tensor, right_vecs: Tensor):  # reference :37-45
+        if not self._diag.requires_grad:
+            return (None,)
+        res = K.bilinear_diag(left_vecs, right_vecs, self.batch_shape)
+        return (res if tuple(res.shape) == tuple(self._diag.shape) else res.sum_to_size(*self._diag.shape),)
 
     def _matmul(self, rhs: Tensor) -> Tensor:  # reference :203-230
         if rhs.ndimension() == 1:
@@ -85,6 +92,13 @@ class ConstantDiagLinearOperator(DiagLinearOperator):
     @property
     def _diag(self) -> Tensor:  # reference :346-350
         return self.diag_values.expand(*self.diag_values.shape[:-1], self.diag_shape)
+
+    def _bilinear_derivative(self, left_vecs: Tensor, right_vecs: Tensor):  # reference :337-344
+        if not self.diag_values.requires_grad:
+            return (None,)
+        res = K.bilinear_diag(left_vecs, right_vecs, self.batch_shape, constant=True)
+        shape = self.diag_values.shape
+        return (res if tuple(res.shape) == tuple(shape) else res.sum_to_size(*shape),)
 
     def __add__(self, other):
         if isinstance(other, ConstantDiagLinearOperator):

@@ -28,6 +28,18 @@ class RootLinearOperator(LinearOperator):
             r = r.expand(*batch_shape, *r.shape[-2:])
         return K.lowrank_diag_descriptor(r, None)
 
+    def _bilinear_derivative(self, left_vecs: Tensor, right_vecs: Tensor):
+        """Derivative w.r.t. the root tensor of sum_d u_d^T R R^T v_d = U (V^T R) + V (U^T R): what the reference's
+        generic autograd version (_linear_operator.py:336-393) yields for `_matmul` = root._matmul(root._t_matmul(v))
+        (:68-72)."""
+        r = self._dense_root()
+        if r is None:
+            return super()._bilinear_derivative(left_vecs, right_vecs)
+        if not r.requires_grad:
+            return (None,)
+        res = K.bilinear_root(r, left_vecs, right_vecs)
+        return (res if tuple(res.shape) == tuple(r.shape) else res.sum_to_size(*r.shape),)
+
     def _diagonal(self) -> Tensor:  # reference :22-28
         r = self._dense_root()
         if r is not None:

@@ -48,6 +48,9 @@ class SumLinearOperator(LinearOperator):
                 return K.matvec(desc, rhs.expand(*desc.batch_shape, *rhs.shape[-2:]))
         return sum(op._matmul(rhs) for op in self.linear_ops)
 
+    def _bilinear_derivative(self, left_vecs: Tensor, right_vecs: Tensor):  # reference :59-62
+        return tuple(var for op in self.linear_ops for var in op._bilinear_derivative(left_vecs, right_vecs))
+
     def _t_matmul(self, rhs):
         return sum(op._t_matmul(rhs) for op in self.linear_ops)
 

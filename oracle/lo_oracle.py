@@ -604,3 +604,57 @@ def root_decomposition(matmul_closure, init_vecs, max_iter, tridiagonal_jitter=1
     if single:
         root, inverse = root[0], inverse[0]
     return root, inverse
+
+
+# ----------------------------------------------------------------------------------
+# Backward passes
+# ----------------------------------------------------------------------------------
+
+
+def bilinear_derivative_dense(U, V):
+    """d/dK sum_d u_d^T K v_d = U V^T  (operators/dense_linear_operator.py:69-71)."""
+    return U @ np.swapaxes(V, -1, -2)
+
+
+def bilinear_derivative_diag(U, V, constant=False):
+    """Diag: sum_d U o V (operators/diag_linear_operator.py:37-45); ConstantDiag: its sum over N, [*B,1] (:337-344)."""
+    res = (U * V).sum(-1)
+    return res.sum(-1, keepdims=True) if constant else res
+
+
+def bilinear_derivative_root(C, U, V):
+    """K = C C^T: d/dC sum_d u_d^T C C^T v_d = U (V^T C) + V (U^T C) -- what the generic autograd version
+    (operators/_linear_operator.py:336-393) yields for RootLinearOperator._matmul (root_linear_operator.py:68-72)."""
+    return U @ (np.swapaxes(V, -1, -2) @ C) + V @ (np.swapaxes(U, -1, -2) @ C)
+
+
+def solve_backward(solve_fn, right_solves, grad_output):
+    """Solve.backward without a left tensor (functions/_solve.py:70-115): returns (rhs_grad, U, V) where
+    (U, V) = ([L | R], -[R | L] / 2) are the factors handed to `_bilinear_derivative`, L = A^-1 grad_output."""
+    left_solves = solve_fn(grad_output)
+    U = np.concatenate([left_solves, right_solves], axis=-1)
+    V = np.concatenate([right_solves, left_solves], axis=-1) * right_solves.dtype.type(-0.5)
+    return left_solves, U, V
+
+
+def inv_quad_backward(inv_quad_solves, grad_output):
+    """InvQuad.backward (functions/_inv_quad.py:63-93): (rhs_grad, U, V)."""
+    neg = -inv_quad_solves * grad_output[..., None, :]
+    return -2.0 * neg, neg, inv_quad_solves
+
+
+def inv_quad_logdet_backward(solves, probe_vectors, probe_vector_norms, num_probes, inv_quad_grad, logdet_grad,
+                             precond_apply=None):
+    """InvQuadLogdet.backward (functions/_inv_quad_logdet.py:163-226) without the preconditioner-tensor gradients:
+    (rhs_grad, U, V) with U = [probe solves * norms * g / P | -iq_solves * g_iq], V = [P^-1 (probes * norms) | iq_solves]."""
+    coef = 1.0 / probe_vectors.shape[-1]
+    ld = logdet_grad[..., None, None]
+    pvs = solves[..., :num_probes] * coef * probe_vector_norms * ld
+    ppv = probe_vectors * probe_vector_norms
+    if precond_apply is not None:
+        ppv = precond_apply(ppv)
+    iqs = solves[..., num_probes:]
+    neg = -iqs * inv_quad_grad[..., None, :]
+    U = np.concatenate([pvs, neg], axis=-1)
+    V = np.concatenate([ppv, iqs], axis=-1)
+    return -2.0 * neg, U, V

@@ -379,11 +379,64 @@ def g8_root_decomposition():
     save("g8_root_decomposition", checksum=cases.checksum(C, d, v1, v3, tv), **out)
 
 
+def g9_backward():
+    """gradients of Matmul / Solve / InvQuad / InvQuadLogdet through the reference's autograd
+    Functions (`_bilinear_derivative` of Dense, Diag, ConstantDiag, Root, Sum).  N = 1024 < min_preconditioning_size, so
+    CG runs unpreconditioned and the stochastic logdet gradient has no preconditioner terms; probes are injected."""
+    out = {}
+    C, d, rhs = cases.lowrank_diag(901, 2, 1024, 8, 3)
+    W = cases.randn(902, 2, 1024, 3, dtype=np.float32)
+    Z = cases.randn(903, 2, 1024, 6, dtype=np.float32)
+
+    class Probed(AddedDiagLinearOperator):
+        def _probe_vectors_and_norms(self):
+            z = T(Z)
+            n = z.norm(dim=-2, keepdim=True)
+            return z / n, n
+
+    def leaves():
+        return [T(x).clone().requires_grad_(True) for x in (C, d, rhs)]
+
+    with settings.max_cholesky_size(0), settings.cg_tolerance(1e-5), settings.max_cg_iterations(200):
+        Ct, dt, rt = leaves()
+        A = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+        ((A @ rt) * T(W)).sum().backward()
+        out["mm_dC"], out["mm_dd"], out["mm_drhs"] = Ct.grad, dt.grad, rt.grad
+        Ct, dt, rt = leaves()
+        A = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+        x = A.solve(rt)
+        (x * T(W)).sum().backward()
+        out["solve_x"], out["solve_dC"], out["solve_dd"], out["solve_drhs"] = x, Ct.grad, dt.grad, rt.grad
+        Ct, dt, rt = leaves()
+        A = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+        iq = A.inv_quad(rt)
+        iq.sum().backward()
+        out["iq"], out["iq_dC"], out["iq_dd"], out["iq_drhs"] = iq, Ct.grad, dt.grad, rt.grad
+        Ct, dt, rt = leaves()
+        A = Probed(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+        with settings.num_trace_samples(6):
+            iq, ld = A.inv_quad_logdet(rt, logdet=True)
+        (iq.sum() + ld.sum()).backward()
+        out["iql_iq"], out["iql_ld"] = iq, ld
+        out["iql_dC"], out["iql_dd"], out["iql_drhs"] = Ct.grad, dt.grad, rt.grad
+        # dense + constant diagonal
+        Kd, _, rd = cases.dense_diag(904, 2, 300, 2)
+        sig = np.array([[0.4], [0.9]], dtype=np.float32)
+        Wd = cases.randn(905, 2, 300, 2, dtype=np.float32)
+        Kt, st, rdt = [T(x).clone().requires_grad_(True) for x in (Kd, sig, rd)]
+        Ad = AddedDiagLinearOperator(DenseLinearOperator(Kt), ConstantDiagLinearOperator(st, 300))
+        xd = Ad.solve(rdt)
+        (xd * T(Wd)).sum().backward()
+        out["dense_x"], out["dense_dK"], out["dense_dsig"], out["dense_drhs"] = xd, Kt.grad, st.grad, rdt.grad
+    save("g9_backward", checksum=cases.checksum(C, d, rhs, W, Z, Kd, sig, rd, Wd), **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
-                     ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition)):
+                     ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
+                     ("g9", g9_backward)):
         if name in todo:
             fn()
     print("done")

@@ -258,3 +258,70 @@ def test_root_decomposition_lanczos_consumers():
     As = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C[:, :64])), DiagLinearOperator(dev(d[:, :64])))
     Rs = As.root_decomposition().to_dense()
     assert np.allclose(host(Rs), host(As.to_dense()), rtol=1e-4, atol=1e-5)
+
+
+def test_backward_passes_against_reference_autograd():
+    """gradients through Matmul / Solve / InvQuad / InvQuadLogdet on the HIP path (forward solves,
+    the extra backward solve and the `_bilinear_derivative` contractions of csrc/lo_bilinear.hip) against the
+    gradients the reference's autograd produced (golden g9; gradients are quadratic in CG solves stopped at 1e-5,
+    hence max-norm comparisons at a few 1e-3)."""
+    g = load_golden("g9_backward")
+    C, d, rhs = cases.lowrank_diag(901, 2, 1024, 8, 3)
+    W = cases.randn(902, 2, 1024, 3, dtype=np.float32)
+    Z = cases.randn(903, 2, 1024, 6, dtype=np.float32)
+
+    def close(a, b, rel=3e-3):
+        a, b = host(a), np.asarray(b)
+        return a.shape == b.shape and np.abs(a - b).max() <= rel * np.abs(b).max()
+
+    def leaves(*arrs):
+        return [dev(x).clone().requires_grad_(True) for x in arrs]
+
+    with settings.max_cholesky_size(0), settings.cg_tolerance(1e-5), settings.max_cg_iterations(200):
+        Ct, dt, rt = leaves(C, d, rhs)
+        A = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+        ((A @ rt) * dev(W)).sum().backward()
+        assert close(Ct.grad, g["mm_dC"], 1e-5) and close(dt.grad, g["mm_dd"], 1e-5) and close(rt.grad, g["mm_drhs"], 1e-5)
+
+        Ct, dt, rt = leaves(C, d, rhs)
+        A = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+        x = A.solve(rt)
+        (x * dev(W)).sum().backward()
+        assert max_rel_err_cols(host(x), g["solve_x"]) < 1e-4
+        assert close(Ct.grad, g["solve_dC"]) and close(dt.grad, g["solve_dd"]) and close(rt.grad, g["solve_drhs"])
+
+        Ct, dt, rt = leaves(C, d, rhs)
+        A = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+        iq = A.inv_quad(rt)
+        iq.sum().backward()
+        assert np.allclose(host(iq), g["iq"], rtol=1e-4)
+        assert close(Ct.grad, g["iq_dC"]) and close(dt.grad, g["iq_dd"]) and close(rt.grad, g["iq_drhs"])
+
+        Ct, dt, rt = leaves(C, d, rhs)
+        A = ProbedAddedDiag(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+        z = dev(Z)
+        nrm = z.norm(dim=-2, keepdim=True)
+        A._probes = (z / nrm, nrm)
+        with settings.num_trace_samples(6):
+            iq, ld = A.inv_quad_logdet(rt, logdet=True)
+        (iq.sum() + ld.sum()).backward()
+        assert np.allclose(host(iq), g["iql_iq"], rtol=1e-4) and np.allclose(host(ld), g["iql_ld"], rtol=1e-3, atol=1e-2)
+        assert close(Ct.grad, g["iql_dC"]) and close(dt.grad, g["iql_dd"]) and close(rt.grad, g["iql_drhs"])
+
+        Kd, _, rd = cases.dense_diag(904, 2, 300, 2)
+        sig = np.array([[0.4], [0.9]], dtype=np.float32)
+        Wd = cases.randn(905, 2, 300, 2, dtype=np.float32)
+        Kt, st, rdt = leaves(Kd, sig, rd)
+        Ad = AddedDiagLinearOperator(DenseLinearOperator(Kt), ConstantDiagLinearOperator(st, 300))
+        xd = Ad.solve(rdt)
+        (xd * dev(Wd)).sum().backward()
+        assert max_rel_err_cols(host(xd), g["dense_x"]) < 1e-3
+        assert close(Kt.grad, g["dense_dK"], 5e-3) and close(st.grad, g["dense_dsig"], 5e-3)
+        assert close(rdt.grad, g["dense_drhs"], 5e-3)
+
+    # operators without a closed-form derivative on this path say so
+    K1, K2, s, vk = cases.kron_factors(906, 2, 8, 8, 1)
+    k1 = dev(K1).requires_grad_(True)
+    Ak = KroneckerProductLinearOperator(DenseLinearOperator(k1), DenseLinearOperator(dev(K2)))
+    with pytest.raises(NotImplementedError, match="_bilinear_derivative"):
+        (Ak @ dev(vk)).sum().backward()

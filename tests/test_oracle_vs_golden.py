@@ -332,3 +332,60 @@ def test_g8_root_decomposition_forward():
     # up to the tridiagonal jitter (1e-3 * min diag T)
     root, inv = orc.root_decomposition(mv, v1, 12)
     assert max_rel_err_cols(root @ (np.swapaxes(root, -1, -2) @ v1), mv(v1)) < 5e-3
+
+
+def test_g9_backward_passes():
+    """gradients the reference's autograd Functions produce for Matmul / Solve / InvQuad /
+    InvQuadLogdet, restated with the oracle's CG and the closed-form `_bilinear_derivative` contractions."""
+    g = load_golden("g9_backward")
+    C, d, rhs = cases.lowrank_diag(901, 2, 1024, 8, 3)
+    W = cases.randn(902, 2, 1024, 3, dtype=np.float32)
+    Z = cases.randn(903, 2, 1024, 6, dtype=np.float32)
+    Kd, _, rd = cases.dense_diag(904, 2, 300, 2)
+    sig = np.array([[0.4], [0.9]], dtype=np.float32)
+    Wd = cases.randn(905, 2, 300, 2, dtype=np.float32)
+    assert cases.checksum(C, d, rhs, W, Z, Kd, sig, rd, Wd) == g["checksum"]
+    mv = lambda v: orc.matvec_lowrank_diag(C, d, v)  # noqa: E731
+    cg = lambda b: orc.linear_cg(mv, b, tolerance=1e-5, max_iter=200)[0]  # noqa: E731
+    def close(a, b, rel=3e-3):  # gradients are quadratic in fp32 CG solves stopped at 1e-5: compare in max norm
+        return np.abs(a - b).max() <= rel * np.abs(b).max()
+
+    # Matmul: d/dK sum W o (K rhs) -> U = W, V = rhs; d/drhs = K^T W
+    assert close(orc.bilinear_derivative_root(C, W, rhs), g["mm_dC"])
+    assert close(orc.bilinear_derivative_diag(W, rhs), g["mm_dd"])
+    assert close(mv(W), g["mm_drhs"])
+    # Solve
+    x = cg(rhs)
+    assert max_rel_err_cols(x, g["solve_x"]) < 1e-4
+    drhs, U, V = orc.solve_backward(cg, x, W)
+    assert max_rel_err_cols(drhs, g["solve_drhs"]) < 1e-3
+    assert close(orc.bilinear_derivative_root(C, U, V), g["solve_dC"])
+    assert close(orc.bilinear_derivative_diag(U, V), g["solve_dd"])
+    # InvQuad
+    drhs, U, V = orc.inv_quad_backward(x, np.ones((2, 3), dtype=np.float32))
+    assert np.allclose((x * rhs).sum(-2).sum(-1), g["iq"], rtol=1e-4)  # reduce_inv_quad=True
+    assert max_rel_err_cols(drhs, g["iq_drhs"]) < 1e-3
+    assert close(orc.bilinear_derivative_root(C, U, V), g["iq_dC"])
+    assert close(orc.bilinear_derivative_diag(U, V), g["iq_dd"])
+    # InvQuadLogdet with injected probes, no preconditioner
+    nrm = np.linalg.norm(Z, axis=-2, keepdims=True)
+    probes = Z / nrm
+    full = np.concatenate([probes, rhs], axis=-1)
+    solves = orc.linear_cg(mv, full, n_tridiag=6, tolerance=1e-5, max_iter=200)[0]
+    drhs, U, V = orc.inv_quad_logdet_backward(solves, probes, nrm, 6, np.ones((2, 3), dtype=np.float32),
+                                              np.ones(2, dtype=np.float32))
+    assert max_rel_err_cols(drhs, g["iql_drhs"]) < 1e-3
+    assert close(orc.bilinear_derivative_root(C, U, V), g["iql_dC"])
+    assert close(orc.bilinear_derivative_diag(U, V), g["iql_dd"])
+    # dense + constant diagonal
+    dd = np.broadcast_to(sig, (2, 300)).astype(np.float32)
+    mvd = lambda v: orc.matvec_dense_diag(Kd, dd, v)  # noqa: E731
+    cgd = lambda b: orc.linear_cg(mvd, b, tolerance=1e-5, max_iter=200)[0]  # noqa: E731
+    xd = cgd(rd)
+    assert max_rel_err_cols(xd, g["dense_x"]) < 1e-3
+    drhs, U, V = orc.solve_backward(cgd, xd, Wd)
+    assert max_rel_err_cols(drhs, g["dense_drhs"]) < 5e-3
+    gk = g["dense_dK"]
+    assert np.abs(orc.bilinear_derivative_dense(U, V) - gk).max() < 5e-3 * np.abs(gk).max()
+    gs = g["dense_dsig"]
+    assert np.allclose(orc.bilinear_derivative_diag(U, V, constant=True), gs, rtol=5e-3)
