@@ -595,25 +595,34 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
   }
 }
 
-// m* = number of pivots the reference takes: pivot 0 always, pivot m >= 1 while max_b error_{m-1} > tol (:57, :99)
+// m* = number of pivots the reference takes: pivot 0 always, pivot m >= 1 while max_b error_{m-1} > tol (:57, :99).
+// Wave w evaluates the pivots m = w + 1, w + 5, ... (max over the members with wave butterflies, no barriers inside);
+// thread 0 then takes the first failing m.
 __global__ __launch_bounds__(kThreads) void k_po_rank(PoArgs a, float tol, int* m_out) {
-  __shared__ float red[kThreads];
-  int mstar = a.rank;
-  for (int m = 1; m < a.rank; ++m) {
+  __shared__ int cont_s[PO_MAXR + 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int m = 1 + wave; m < a.rank; m += kThreads / 64) {
     float lmax = -INFINITY, lnan = 0.f;
-    for (int64_t b = threadIdx.x; b < a.B; b += kThreads) {
+    for (int64_t b = lane; b < a.B; b += 64) {
       const float e = a.err_rec[(size_t)m * a.B + b] / a.orig[b];
       if (e != e) lnan = 1.f;
       lmax = fmaxf(lmax, e);
     }
-    const float mx = block_max256(lmax, red);
-    const float anynan = block_sum256(lnan, red);
-    if (!((anynan == 0.f) && (mx > tol))) {  // torch.max propagates NaN and (NaN > tol) is False
-      mstar = m;
-      break;
-    }
+    const float mx = wave_max(lmax);
+    const float anynan = wave_sum(lnan);
+    // torch.max propagates NaN and (NaN > tol) is False -> the reference stops
+    if (lane == 0) cont_s[m] = ((anynan == 0.f) && (mx > tol)) ? 1 : 0;
   }
-  if (threadIdx.x == 0) *m_out = mstar;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int mstar = a.rank;
+    for (int m = 1; m < a.rank; ++m)
+      if (!cont_s[m]) {
+        mstar = m;
+        break;
+      }
+    *m_out = mstar;
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void k_po_perm(PoArgs a, const int* __restrict__ m_in, long long* __restrict__ perm) {
