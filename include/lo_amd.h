@@ -214,6 +214,12 @@ size_t lo_bilinear_root_workspace_bytes(int64_t B, int64_t N, int64_t R, int64_t
 int lo_bilinear_root_f32(const float* C, const float* U, const float* V, int64_t B, int64_t N, int64_t R, int64_t D,
                          float* out, void* ws, size_t ws_bytes, void* stream);
 
+/*   kron : dK1 [B,n1,n1] = sum_d U_d K2 V_d^T, dK2 [B,n2,n2] = sum_d U_d^T K1 V_d with U_d, V_d the [n1,n2] views of
+ *          the columns (autograd of the Kronecker matvec, kronecker_product_linear_operator.py:34-45)            */
+size_t lo_bilinear_kron_workspace_bytes(int64_t B, int64_t n1, int64_t n2, int64_t D);
+int lo_bilinear_kron_f32(const float* K1, const float* K2, const float* U, const float* V, int64_t B, int64_t n1,
+                         int64_t n2, int64_t D, float* dK1, float* dK2, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- measurement aid (no reference counterpart) ------------------------------------------------ */
 /* Opt-in HIP-event timing of every kernel launch of the library, recorded on the launch stream.
  * lo_prof_report writes "name count total_ms" lines into buf (returns the byte count) and resets.

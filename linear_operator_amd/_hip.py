@@ -34,6 +34,7 @@ EXPORTS = [
     "lo_root_from_lanczos_f32",
     "lo_tridiag_eigh_slq_workspace_bytes", "lo_tridiag_eigh_slq_f32",
     "lo_bilinear_dense_f32", "lo_bilinear_diag_f32", "lo_bilinear_root_workspace_bytes", "lo_bilinear_root_f32",
+    "lo_bilinear_kron_workspace_bytes", "lo_bilinear_kron_f32",
     "lo_prof_enable", "lo_prof_report", "lo_hbm_triad_f32",
 ]
 
@@ -152,6 +153,11 @@ def load():
     lib.lo_bilinear_root_f32.restype = C.c_int
     lib.lo_bilinear_root_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                          C.c_void_p, C.c_void_p, sz, C.c_void_p]
+    lib.lo_bilinear_kron_workspace_bytes.restype = sz
+    lib.lo_bilinear_kron_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64]
+    lib.lo_bilinear_kron_f32.restype = C.c_int
+    lib.lo_bilinear_kron_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p]
     lib.lo_hbm_triad_f32.restype = C.c_int
     lib.lo_hbm_triad_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, sz, C.c_void_p]
     _lib = lib

@@ -244,4 +244,15 @@ int lo_bilinear_root_f32(const float* C, const float* U, const float* V, int64_t
   return LO_OK;
 }
 
+size_t lo_bilinear_kron_workspace_bytes(int64_t B, int64_t n1, int64_t n2, int64_t D) {
+  return sizeof(float) * (size_t)B * n1 * n2 * D + 256;
+}
+
+int lo_bilinear_kron_f32(const float* K1, const float* K2, const float* U, const float* V, int64_t B, int64_t n1,
+                         int64_t n2, int64_t D, float* dK1, float* dK2, void* ws, size_t ws_bytes, void* stream) {
+  if (!K1 || !K2 || !U || !V || !dK1 || !dK2 || !ws || B < 1 || n1 < 1 || n2 < 1 || D < 1) return LO_ERR_BADARG;
+  if (ws_bytes < sizeof(float) * (size_t)B * n1 * n2 * D) return LO_ERR_WORKSPACE;
+  return kron_bilinear(K1, K2, U, V, (float*)ws, dK1, dK2, B, (int)n1, (int)n2, D, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -166,6 +166,8 @@ int dense_matvec_mfma(const float* K, const float* d, int dd_mode, const float* 
 int kron_matvec(const float* K1, const float* K2, const float* v, float* tmp, float* y, int64_t B, int n1, int n2,
                 int64_t c, const int* stop, hipStream_t st);
 // matrix-core engine (c == 1, factors multiples of 128): diagonal term and CG dot partials fused in the epilogue
+int kron_bilinear(const float* K1, const float* K2, const float* U, const float* V, float* tmp, float* dK1, float* dK2,
+                  int64_t B, int n1, int n2, int64_t D, hipStream_t st);
 bool kron_mfma_ok(int n1, int n2, int64_t c);
 int kron_S_dot(int n1, int n2, int64_t c, int S_default);
 int kron_matvec_mfma(const float* K1, const float* K2, const float* diag, int diag_mode, const float* v, float* tmp,

@@ -27,6 +27,7 @@ struct GemmArgs {
   // batch z = zo * inner + zi
   int inner;
   int64_t a_zo, a_zi, b_zo, b_zi, c_zo, c_zi;
+  int accumulate;  // C += A B instead of C = A B
 };
 
 constexpr int BM = 64, BN = 64, BK = 16;
@@ -83,7 +84,10 @@ __global__ __launch_bounds__(kThreads) void k_gemm(GemmArgs g, const int* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int gn = n0 + 4 * tx + j;
-      if (gn < g.N) C[gm * g.sc_r + gn * g.sc_c] = acc[i][j];
+      if (gn < g.N) {
+        float* o = C + gm * g.sc_r + gn * g.sc_c;
+        *o = g.accumulate ? *o + acc[i][j] : acc[i][j];
+      }
     }
   }
 }
@@ -269,6 +273,7 @@ int kron_matvec(const float* K1, const float* K2, const float* v, float* tmp, fl
   g1.M = n1; g1.K = n1; g1.N = (int)(n2 * c);
   g1.sa_r = n1; g1.sa_c = 1; g1.sb_r = n2 * c; g1.sb_c = 1; g1.sc_r = n2 * c; g1.sc_c = 1;
   g1.inner = 1;
+  g1.accumulate = 0;
   g1.a_zo = (int64_t)n1 * n1; g1.a_zi = 0; g1.b_zo = N * c; g1.b_zi = 0; g1.c_zo = N * c; g1.c_zi = 0;
   int rc = launch_gemm(g1, (int)B, stop, st);
   if (rc) return rc;
@@ -277,9 +282,59 @@ int kron_matvec(const float* K1, const float* K2, const float* v, float* tmp, fl
   g2.M = n1; g2.K = n2; g2.N = n2;
   g2.sa_r = n2 * c; g2.sa_c = c; g2.sb_r = 1; g2.sb_c = n2; g2.sc_r = n2 * c; g2.sc_c = c;
   g2.inner = (int)c;
+  g2.accumulate = 0;
   g2.a_zo = N * c; g2.a_zi = 1; g2.b_zo = (int64_t)n2 * n2; g2.b_zi = 0; g2.c_zo = N * c; g2.c_zi = 1;
   if (B * c > 65535) return LO_ERR_UNSUPPORTED;
   return launch_gemm(g2, (int)(B * c), stop, st);
+}
+
+// d/dK1, d/dK2 of sum_d u_d^T (K1 (x) K2) v_d (generic autograd of the Kronecker matvec, reference
+// operators/_linear_operator.py:336-393 over kronecker_product_linear_operator.py:34-45): with U_d, V_d the [n1, n2]
+// views of the vectors,  dK1 = sum_d U_d K2 V_d^T,  dK2 = sum_d U_d^T K1 V_d.  Four strided GEMM stages:
+//   T[i1,j2,d] = sum_i2 V[i1,i2,d] K2[j2,i2]            S[i1,(j2,d)] = sum_j1 K1[i1,j1] V[j1,(j2,d)]
+//   dK1[j1,i1] = sum_(j2,d) U[j1,(j2,d)] T[i1,(j2,d)]   dK2[a,b] += sum_j1 U[j1,a,d] S[j1,b,d]   for every d
+int kron_bilinear(const float* K1, const float* K2, const float* U, const float* V, float* tmp, float* dK1, float* dK2,
+                  int64_t B, int n1, int n2, int64_t D, hipStream_t st) {
+  const int64_t N = (int64_t)n1 * n2;
+  if (B * D > 65535) return LO_ERR_UNSUPPORTED;
+  GemmArgs g;
+  g.accumulate = 0;
+  // T = (I (x) K2) V  -> tmp, batches (b, d)
+  g.A = V; g.Bm = K2; g.C = tmp;
+  g.M = n1; g.K = n2; g.N = n2;
+  g.sa_r = n2 * D; g.sa_c = D; g.sb_r = 1; g.sb_c = n2; g.sc_r = n2 * D; g.sc_c = D;
+  g.inner = (int)D;
+  g.a_zo = N * D; g.a_zi = 1; g.b_zo = (int64_t)n2 * n2; g.b_zi = 0; g.c_zo = N * D; g.c_zi = 1;
+  int rc = launch_gemm(g, (int)(B * D), nullptr, st);
+  if (rc) return rc;
+  // dK1 = U T^T over k = (j2, d)
+  g.A = U; g.Bm = tmp; g.C = dK1;
+  g.M = n1; g.K = (int)(n2 * D); g.N = n1;
+  g.sa_r = n2 * D; g.sa_c = 1; g.sb_r = 1; g.sb_c = n2 * D; g.sc_r = n1; g.sc_c = 1;
+  g.inner = 1;
+  g.a_zo = N * D; g.a_zi = 0; g.b_zo = N * D; g.b_zi = 0; g.c_zo = (int64_t)n1 * n1; g.c_zi = 0;
+  rc = launch_gemm(g, (int)B, nullptr, st);
+  if (rc) return rc;
+  // S = (K1 (x) I) V -> tmp
+  g.A = K1; g.Bm = V; g.C = tmp;
+  g.M = n1; g.K = n1; g.N = (int)(n2 * D);
+  g.sa_r = n1; g.sa_c = 1; g.sb_r = n2 * D; g.sb_c = 1; g.sc_r = n2 * D; g.sc_c = 1;
+  g.inner = 1;
+  g.a_zo = (int64_t)n1 * n1; g.a_zi = 0; g.b_zo = N * D; g.b_zi = 0; g.c_zo = N * D; g.c_zi = 0;
+  rc = launch_gemm(g, (int)B, nullptr, st);
+  if (rc) return rc;
+  // dK2[a, b] (+)= sum_j1 U[j1, a, d] S[j1, b, d], one accumulating GEMM per d
+  for (int64_t d = 0; d < D; ++d) {
+    g.A = U + d; g.Bm = tmp + d; g.C = dK2;
+    g.M = n2; g.K = n1; g.N = n2;
+    g.sa_r = D; g.sa_c = n2 * D; g.sb_r = n2 * D; g.sb_c = D; g.sc_r = n2; g.sc_c = 1;
+    g.inner = 1;
+    g.a_zo = N * D; g.a_zi = 0; g.b_zo = N * D; g.b_zi = 0; g.c_zo = (int64_t)n2 * n2; g.c_zi = 0;
+    g.accumulate = d > 0;
+    rc = launch_gemm(g, (int)B, nullptr, st);
+    if (rc) return rc;
+  }
+  return LO_OK;
 }
 
 }  // namespace lo

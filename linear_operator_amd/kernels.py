@@ -461,6 +461,27 @@ def bilinear_root(root: torch.Tensor, left_vecs: torch.Tensor, right_vecs: torch
     return out.reshape(*bs, N, R)
 
 
+def bilinear_kron(K1: torch.Tensor, K2: torch.Tensor, left_vecs: torch.Tensor, right_vecs: torch.Tensor):
+    """lo_bilinear_kron_f32: (dK1, dK2) of sum_d u_d^T (K1 (x) K2) v_d (autograd of the Kronecker matvec)."""
+    lib = _hip.load()
+    bs0 = torch.broadcast_shapes(K1.shape[:-2], K2.shape[:-2])
+    U, V, bs = _uv(left_vecs, right_vecs, bs0)
+    B, N, D = U.shape
+    n1, n2 = K1.shape[-1], K2.shape[-1]
+    assert n1 * n2 == N
+    A1 = K1.expand(*bs, n1, n1).contiguous().reshape(B, n1, n1)
+    A2 = K2.expand(*bs, n2, n2).contiguous().reshape(B, n2, n2)
+    _hip.require_hip(A1, A2)
+    dev = U.device
+    d1 = torch.empty(B, n1, n1, dtype=torch.float32, device=dev)
+    d2 = torch.empty(B, n2, n2, dtype=torch.float32, device=dev)
+    ws = _hip.workspace(lib.lo_bilinear_kron_workspace_bytes(B, n1, n2, D), dev)
+    _hip.check(lib.lo_bilinear_kron_f32(_hip.ptr(A1), _hip.ptr(A2), _hip.ptr(U), _hip.ptr(V), B, n1, n2, D, _hip.ptr(d1),
+                                        _hip.ptr(d2), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)),
+               "lo_bilinear_kron_f32")
+    return d1.reshape(*bs, n1, n1), d2.reshape(*bs, n2, n2)
+
+
 def set_onchip_cg(enable: bool):
     """Allow (default) or forbid the operator-resident CG fast path (csrc/lo_cg_onchip.hip); test / A-B switch."""
     _hip.load().lo_cg_set_onchip(1 if enable else 0)

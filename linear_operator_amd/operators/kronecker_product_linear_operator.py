@@ -66,6 +66,17 @@ class KroneckerProductLinearOperator(LinearOperator):
         k2 = k2.expand(*bs, *k2.shape[-2:])
         return K.kron_diag_descriptor(k1, k2, None)
 
+    def _bilinear_derivative(self, left_vecs: Tensor, right_vecs: Tensor):
+        """(dK1, dK2) = (sum_d U_d K2 V_d^T, sum_d U_d^T K1 V_d): the reference's generic autograd version
+        (_linear_operator.py:336-393) applied to the Kronecker matvec (:34-45); two dense factors on this path."""
+        if len(self.linear_ops) != 2 or not all(isinstance(op, DenseLinearOperator) for op in self.linear_ops):
+            return super()._bilinear_derivative(left_vecs, right_vecs)
+        k1, k2 = (op.tensor for op in self.linear_ops)
+        d1, d2 = K.bilinear_kron(k1, k2, left_vecs, right_vecs)
+        d1 = d1 if tuple(d1.shape) == tuple(k1.shape) else d1.sum_to_size(*k1.shape)
+        d2 = d2 if tuple(d2.shape) == tuple(k2.shape) else d2.sum_to_size(*k2.shape)
+        return (d1, d2)
+
     def _diagonal(self) -> Tensor:
         return _kron_diag(*self.linear_ops)
 

@@ -658,3 +658,17 @@ def inv_quad_logdet_backward(solves, probe_vectors, probe_vector_norms, num_prob
     U = np.concatenate([pvs, neg], axis=-1)
     V = np.concatenate([ppv, iqs], axis=-1)
     return -2.0 * neg, U, V
+
+
+def bilinear_derivative_kron(K1, K2, U, V):
+    """K = K1 (x) K2: (dK1, dK2) = (sum_d U_d K2 V_d^T, sum_d U_d^T K1 V_d) with U_d, V_d the [n1, n2] views of the
+    columns -- the generic autograd `_bilinear_derivative` (operators/_linear_operator.py:336-393) applied to the
+    Kronecker matvec (operators/kronecker_product_linear_operator.py:34-45)."""
+    n1, n2 = K1.shape[-1], K2.shape[-1]
+    bs = U.shape[:-2]
+    D = U.shape[-1]
+    Ud = np.moveaxis(U.reshape(*bs, n1, n2, D), -1, -3)  # [*B, D, n1, n2]
+    Vd = np.moveaxis(V.reshape(*bs, n1, n2, D), -1, -3)
+    dK1 = (Ud @ K2[..., None, :, :] @ np.swapaxes(Vd, -1, -2)).sum(-3)
+    dK2 = (np.swapaxes(Ud, -1, -2) @ K1[..., None, :, :] @ Vd).sum(-3)
+    return dK1, dK2

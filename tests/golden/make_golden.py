@@ -428,7 +428,23 @@ def g9_backward():
         xd = Ad.solve(rdt)
         (xd * T(Wd)).sum().backward()
         out["dense_x"], out["dense_dK"], out["dense_dsig"], out["dense_drhs"] = xd, Kt.grad, st.grad, rdt.grad
-    save("g9_backward", checksum=cases.checksum(C, d, rhs, W, Z, Kd, sig, rd, Wd), **out)
+    # Kronecker product + constant diagonal (explicit AddedDiagLinearOperator = the CG path), 12 (x) 20
+    K1, K2, sk, rk = cases.kron_factors(907, 2, 12, 20, 2)
+    Wk = cases.randn(908, 2, 240, 2, dtype=np.float32)
+    with settings.max_cholesky_size(0), settings.cg_tolerance(1e-5), settings.max_cg_iterations(400):
+        k1t, k2t, skt, rkt = [T(x).clone().requires_grad_(True) for x in (K1, K2, sk, rk)]
+        Ak = AddedDiagLinearOperator(KroneckerProductLinearOperator(DenseLinearOperator(k1t), DenseLinearOperator(k2t)),
+                                     ConstantDiagLinearOperator(skt, 240))
+        ((Ak @ rkt) * T(Wk)).sum().backward()
+        out["kron_mm_dK1"], out["kron_mm_dK2"], out["kron_mm_dsig"] = k1t.grad, k2t.grad, skt.grad
+        k1t, k2t, skt, rkt = [T(x).clone().requires_grad_(True) for x in (K1, K2, sk, rk)]
+        Ak = AddedDiagLinearOperator(KroneckerProductLinearOperator(DenseLinearOperator(k1t), DenseLinearOperator(k2t)),
+                                     ConstantDiagLinearOperator(skt, 240))
+        xk = Ak.solve(rkt)
+        (xk * T(Wk)).sum().backward()
+        out["kron_x"], out["kron_dK1"], out["kron_dK2"] = xk, k1t.grad, k2t.grad
+        out["kron_dsig"], out["kron_drhs"] = skt.grad, rkt.grad
+    save("g9_backward", checksum=cases.checksum(C, d, rhs, W, Z, Kd, sig, rd, Wd, K1, K2, sk, rk, Wk), **out)
 
 
 if __name__ == "__main__":

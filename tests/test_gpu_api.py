@@ -319,9 +319,31 @@ def test_backward_passes_against_reference_autograd():
         assert close(Kt.grad, g["dense_dK"], 5e-3) and close(st.grad, g["dense_dsig"], 5e-3)
         assert close(rdt.grad, g["dense_drhs"], 5e-3)
 
-    # operators without a closed-form derivative on this path say so
-    K1, K2, s, vk = cases.kron_factors(906, 2, 8, 8, 1)
+        # Kronecker product + constant diagonal
+        K1, K2, sk, rk = cases.kron_factors(907, 2, 12, 20, 2)
+        Wk = cases.randn(908, 2, 240, 2, dtype=np.float32)
+        with settings.max_cg_iterations(400):
+            k1t, k2t, skt, rkt = leaves(K1, K2, sk, rk)
+            Ak = AddedDiagLinearOperator(
+                KroneckerProductLinearOperator(DenseLinearOperator(k1t), DenseLinearOperator(k2t)),
+                ConstantDiagLinearOperator(skt, 240))
+            ((Ak @ rkt) * dev(Wk)).sum().backward()
+            assert close(k1t.grad, g["kron_mm_dK1"], 1e-5) and close(k2t.grad, g["kron_mm_dK2"], 1e-5)
+            assert close(skt.grad, g["kron_mm_dsig"], 1e-4)
+            k1t, k2t, skt, rkt = leaves(K1, K2, sk, rk)
+            Ak = AddedDiagLinearOperator(
+                KroneckerProductLinearOperator(DenseLinearOperator(k1t), DenseLinearOperator(k2t)),
+                ConstantDiagLinearOperator(skt, 240))
+            xk = Ak.solve(rkt)
+            (xk * dev(Wk)).sum().backward()
+            assert max_rel_err_cols(host(xk), g["kron_x"]) < 1e-3
+            assert close(k1t.grad, g["kron_dK1"], 5e-3) and close(k2t.grad, g["kron_dK2"], 5e-3)
+            assert close(skt.grad, g["kron_dsig"], 5e-3) and close(rkt.grad, g["kron_drhs"], 5e-3)
+
+    # operators without a closed-form derivative on this path say so (three Kronecker factors)
+    K1, K2, s, vk = cases.kron_factors(906, 2, 4, 4, 1)
     k1 = dev(K1).requires_grad_(True)
-    Ak = KroneckerProductLinearOperator(DenseLinearOperator(k1), DenseLinearOperator(dev(K2)))
+    Ak3 = KroneckerProductLinearOperator(DenseLinearOperator(k1), DenseLinearOperator(dev(K2)),
+                                         DenseLinearOperator(dev(K2)))
     with pytest.raises(NotImplementedError, match="_bilinear_derivative"):
-        (Ak @ dev(vk)).sum().backward()
+        (Ak3 @ dev(cases.randn(909, 2, 64, 1, dtype=np.float32))).sum().backward()

@@ -344,7 +344,9 @@ def test_g9_backward_passes():
     Kd, _, rd = cases.dense_diag(904, 2, 300, 2)
     sig = np.array([[0.4], [0.9]], dtype=np.float32)
     Wd = cases.randn(905, 2, 300, 2, dtype=np.float32)
-    assert cases.checksum(C, d, rhs, W, Z, Kd, sig, rd, Wd) == g["checksum"]
+    K1, K2, sk, rk = cases.kron_factors(907, 2, 12, 20, 2)
+    Wk = cases.randn(908, 2, 240, 2, dtype=np.float32)
+    assert cases.checksum(C, d, rhs, W, Z, Kd, sig, rd, Wd, K1, K2, sk, rk, Wk) == g["checksum"]
     mv = lambda v: orc.matvec_lowrank_diag(C, d, v)  # noqa: E731
     cg = lambda b: orc.linear_cg(mv, b, tolerance=1e-5, max_iter=200)[0]  # noqa: E731
     def close(a, b, rel=3e-3):  # gradients are quadratic in fp32 CG solves stopped at 1e-5: compare in max norm
@@ -389,3 +391,17 @@ def test_g9_backward_passes():
     assert np.abs(orc.bilinear_derivative_dense(U, V) - gk).max() < 5e-3 * np.abs(gk).max()
     gs = g["dense_dsig"]
     assert np.allclose(orc.bilinear_derivative_diag(U, V, constant=True), gs, rtol=5e-3)
+    # Kronecker product + constant diagonal
+    dk = np.broadcast_to(sk, (2, 240)).astype(np.float32)
+    d1, d2 = orc.bilinear_derivative_kron(K1, K2, Wk, rk)
+    assert close(d1, g["kron_mm_dK1"], 1e-5) and close(d2, g["kron_mm_dK2"], 1e-5)
+    assert np.allclose(orc.bilinear_derivative_diag(Wk, rk, constant=True), g["kron_mm_dsig"], rtol=1e-4)
+    mvk = lambda v: orc.matvec_kron_diag(K1, K2, dk, v)  # noqa: E731
+    cgk = lambda b: orc.linear_cg(mvk, b, tolerance=1e-5, max_iter=400)[0]  # noqa: E731
+    xk = cgk(rk)
+    assert max_rel_err_cols(xk, g["kron_x"]) < 1e-3
+    drhs, U, V = orc.solve_backward(cgk, xk, Wk)
+    assert max_rel_err_cols(drhs, g["kron_drhs"]) < 5e-3
+    d1, d2 = orc.bilinear_derivative_kron(K1, K2, U, V)
+    assert close(d1, g["kron_dK1"], 5e-3) and close(d2, g["kron_dK2"], 5e-3)
+    assert np.allclose(orc.bilinear_derivative_diag(U, V, constant=True), g["kron_dsig"], rtol=5e-3)
