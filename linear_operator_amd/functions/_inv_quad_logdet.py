@@ -14,6 +14,58 @@ from ..utils.lanczos import lanczos_tridiag_to_diag
 from ..utils.stochastic_lq import StochasticLQ
 
 
+def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, ppv, coef, logdet_grad):
+    """d/d(theta) of  logdet P  -  (1/P) sum_p (P^-1 z_p)^T P (P^-1 z_p)  for the pivoted-Cholesky preconditioner
+    P = L L^T + D of an AddedDiagLinearOperator, chained to the operator's own tensors (what the reference obtains
+    through autograd: `precond_arg_grads` :211-213 plus the graph of logdet_p, added_diag_linear_operator.py:159-184):
+        wrt L :  2 g P^-1 L  +  U (V^T L) + V (U^T L),   U = -ppv / P, V = ppv g      (then through the pivoted Cholesky)
+        wrt d :  g diag(P^-1)   (the probes' term sum_p U o V already reaches d: the diagonal's tensor is itself one of
+                                 the preconditioner arguments of the Function and receives `precond_arg_grads`)
+    Skipped (the estimator stays unbiased without it) when the preconditioner is not the Woodbury closure of an
+    AddedDiagLinearOperator over a dense-root or dense operator."""
+    from ..operators.added_diag_linear_operator import AddedDiagLinearOperator, WoodburyPreconditionClosure
+    from ..operators.diag_linear_operator import ConstantDiagLinearOperator
+    from ._pivoted_cholesky import pivoted_cholesky_vjp
+
+    pre = ctx.preconditioner
+    if not isinstance(pre, WoodburyPreconditionClosure) or not isinstance(linear_op, AddedDiagLinearOperator):
+        return matrix_arg_grads
+    L, perm = getattr(pre, "piv_chol", None), getattr(pre, "piv_perm", None)
+    if L is None or perm is None or not any(t.requires_grad for t in matrix_args):
+        return matrix_arg_grads
+    wb = pre.woodbury
+    g = logdet_grad  # [*batch, 1, 1]
+    U, V = -ppv * coef, ppv * g
+    # position of the two components inside the representation
+    first_is_diag = linear_op.linear_ops[0] is linear_op._diag_tensor
+    n_first = len(linear_op.linear_ops[0].representation())
+    op_slice = slice(n_first, None) if first_is_diag else slice(0, len(linear_op._linear_op.representation()))
+    diag_idx = 0 if first_is_diag else len(linear_op._linear_op.representation())
+    # ---- diagonal part
+    diag_leaf = matrix_args[diag_idx]
+    if diag_leaf.requires_grad:
+        const = isinstance(linear_op._diag_tensor, ConstantDiagLinearOperator)
+        q = wb.Q[..., : wb.k]
+        dinv = wb.dinv.unsqueeze(-1) if wb.constant_diag else wb.dinv
+        pinv_diag = (dinv - (q * q).sum(-1)).reshape(*linear_op.batch_shape, -1)  # diag(P^-1) = 1/d - rowsum(Q^2)
+        gd = pinv_diag * g.squeeze(-1)
+        if const:
+            gd = gd.sum(-1, keepdim=True)
+        gd = gd if tuple(gd.shape) == tuple(diag_leaf.shape) else gd.sum_to_size(*diag_leaf.shape)
+        matrix_arg_grads[diag_idx] = gd if matrix_arg_grads[diag_idx] is None else matrix_arg_grads[diag_idx] + gd
+    # ---- low-rank part, through the pivoted Cholesky
+    if any(t.requires_grad for t in matrix_args[op_slice]):
+        Lc = L.contiguous()
+        GL = 2.0 * g * pre(Lc) + K.bilinear_root(Lc, U, V)
+        extra = pivoted_cholesky_vjp(linear_op._linear_op, perm, GL)
+        if extra is not None:
+            idxs = range(*op_slice.indices(len(matrix_arg_grads)))
+            for i, e in zip(idxs, extra):
+                if e is not None:
+                    matrix_arg_grads[i] = e if matrix_arg_grads[i] is None else matrix_arg_grads[i] + e
+    return matrix_arg_grads
+
+
 class InvQuadLogdet(Function):
     @staticmethod
     def forward(ctx, representation_tree, precond_representation_tree, preconditioner, num_precond_args, inv_quad,
@@ -117,13 +169,19 @@ class InvQuadLogdet(Function):
         right_factors = torch.cat(right_factors_list, -1)
         matrix_arg_grads = linear_op._bilinear_derivative(left_factors, right_factors)
 
-        # preconditioner gradient (:211-213): only computed when one of its tensors asks for it
+        # preconditioner gradient (:211-213).  In the reference the preconditioner tensors (L, d) carry an autograd
+        # graph back to the operator's tensors (PivotedCholesky.backward, the QR of _init_cache) and logdet P is added
+        # outside with its own graph; here the preconditioner is built by kernels outside autograd, so both
+        # contributions are chained by hand into the gradients of the operator's tensors.
         if any(t.requires_grad for t in precond_args):
             precond_arg_grads = precond_lt._bilinear_derivative(
                 -precond_probe_vectors * coef, precond_probe_vectors * logdet_grad_output
             )
         else:
             precond_arg_grads = [None] * len(precond_args)
+        matrix_arg_grads = _add_preconditioner_terms(
+            ctx, linear_op, list(matrix_arg_grads), matrix_args, precond_probe_vectors, coef, logdet_grad_output
+        )
 
         if ctx.inv_quad:
             inv_quad_rhs_grad = neg_inv_quad_solves_times_grad_out.mul(-2)

@@ -35,3 +35,44 @@ class PivotedCholesky(Function):
     @staticmethod
     def backward(ctx, grad_output, _):
         not_yet("PivotedCholesky")
+
+
+def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L):
+    """Vector-Jacobian product of the pivoted-Cholesky factor L [*batch, N, m] with respect to the tensors that
+    represent `linear_op`, the way PivotedCholesky.backward does it (reference :107-147): re-express the factor of
+    the SAME pivots as  Pi^T [chol(K_pp); (chol(K_pp)^-1 K_pr)^T]  with differentiable ATen ops on the m pivot rows
+    (m x N data, k x k Cholesky: plumbing, like the reference) and back-propagate grad_L through it.
+    Returns one gradient (or None) per tensor of linear_op.representation()."""
+    from ..operators.dense_linear_operator import DenseLinearOperator
+    from ..operators.root_linear_operator import RootLinearOperator
+    from ..utils.cholesky import psd_safe_cholesky
+    from ..utils.permutation import inverse_permutation
+
+    m = grad_L.size(-1)
+    perm = full_permutation
+    inv_perm = inverse_permutation(perm)
+    leaves = []
+    for t in linear_op.representation():
+        leaves.append(t.detach().requires_grad_(True) if t.dtype.is_floating_point else t.detach())
+    with torch.enable_grad():
+        op = linear_op.representation_tree()(*leaves)
+        if isinstance(op, RootLinearOperator) and op._dense_root() is not None:
+            r = op._dense_root()
+            rp = torch.gather(r, -2, perm.unsqueeze(-1).expand(*perm.shape, r.size(-1)))  # rows in pivot order
+            krows = rp @ rp[..., :m, :].mT  # K[perm][:, pivots]  [*batch, N, m]
+        elif isinstance(op, DenseLinearOperator):
+            kd = op.tensor
+            rows = torch.gather(kd, -2, perm.unsqueeze(-1).expand(*perm.shape, kd.size(-1)))
+            krows = torch.gather(rows, -1, perm[..., :m].unsqueeze(-2).expand(*perm.shape[:-1], perm.size(-1), m))
+        else:
+            return None
+        l11 = psd_safe_cholesky(krows[..., :m, :])
+        rest = torch.linalg.solve_triangular(l11, krows[..., m:, :].mT, upper=False).mT
+        res_pivoted = torch.cat([l11, rest], dim=-2)
+        res = torch.gather(res_pivoted, -2, inv_perm.unsqueeze(-1).expand(*inv_perm.shape, m))
+        need = [t for t in leaves if t.requires_grad]
+        grads = list(torch.autograd.grad(res, need, grad_outputs=grad_L.contiguous(), allow_unused=True))
+    out = []
+    for t in leaves:
+        out.append(grads.pop(0) if t.requires_grad else None)
+    return out

@@ -63,6 +63,7 @@ class AddedDiagLinearOperator(SumLinearOperator):
         self._constant_diag = None
         self._noise = None
         self._piv_chol_self = None
+        self._piv_chol_perm = None
         self._precond_lt = None
         self._precond_logdet_cache = None
         self._q_cache = None
@@ -103,6 +104,7 @@ class AddedDiagLinearOperator(SumLinearOperator):
                 return None, None, None
             self._init_cache()
         closure = WoodburyPreconditionClosure(self._woodbury, self.batch_shape)
+        closure.piv_chol, closure.piv_perm = self._piv_chol_self, getattr(self, "_piv_chol_perm", None)
         return closure, self._precond_lt, self._precond_logdet_cache
 
     def _pivoted_cholesky_factor(self, max_iter):
@@ -113,7 +115,8 @@ class AddedDiagLinearOperator(SumLinearOperator):
         if desc is None or desc.diag_mode != 0 or self.device.type != "cuda" or self.dtype != torch.float32:
             return self._linear_op.pivoted_cholesky(rank=max_iter)
         tol = settings.preconditioner_tolerance.value()
-        L, _ = K.pivoted_cholesky(desc, min(max_iter, self.size(-1)), float(tol), contiguous=False)
+        L, perm = K.pivoted_cholesky(desc, min(max_iter, self.size(-1)), float(tol), contiguous=False)
+        self._piv_chol_perm = perm  # needed by the backward pass of the preconditioner terms
         return L
 
     def _init_cache(self):

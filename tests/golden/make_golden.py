@@ -447,12 +447,54 @@ def g9_backward():
     save("g9_backward", checksum=cases.checksum(C, d, rhs, W, Z, Kd, sig, rd, Wd, K1, K2, sk, rk, Wk), **out)
 
 
+def g10_backward_preconditioned():
+    """InvQuadLogdet gradients WITH the pivoted-Cholesky preconditioner (N = 2048 >= min_preconditioning_size): the
+    reference back-propagates through the preconditioner (PivotedCholesky.backward, the QR of _init_cache) and through
+    logdet P.  R = 8 < 15: the factorisation stops at m = 8 pivots.  Probes injected."""
+    C, d, rhs = cases.lowrank_diag(1001, 2, 2048, 8, 1)
+    Z = cases.randn(1002, 2, 2048, 6, dtype=np.float32)
+
+    class Probed(AddedDiagLinearOperator):
+        def _probe_vectors_and_norms(self):
+            z = T(Z)
+            n = z.norm(dim=-2, keepdim=True)
+            return z / n, n
+
+    out = {}
+    with settings.cg_tolerance(1e-5), settings.max_cg_iterations(200), settings.num_trace_samples(6):
+        Ct, dt, rt = [T(x).clone().requires_grad_(True) for x in (C, d, rhs)]
+        A = Probed(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+        iq, ld = A.inv_quad_logdet(rt, logdet=True)
+        (iq.sum() + ld.sum()).backward()
+        out["iq"], out["ld"], out["dC"], out["dd"], out["drhs"] = iq, ld, Ct.grad, dt.grad, rt.grad
+        Ct, dt, rt = [T(x).clone().requires_grad_(True) for x in (C, d, rhs)]
+        A = Probed(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+        ld = A.logdet()
+        (ld * T(np.array([1.5, -0.5], dtype=np.float32))).sum().backward()
+        out["ld_only"], out["ld_dC"], out["ld_dd"] = ld, Ct.grad, dt.grad
+    # constant diagonal: sigma [2, 1]
+    sig = np.array([[0.6], [1.3]], dtype=np.float32)
+    with settings.cg_tolerance(1e-5), settings.max_cg_iterations(200), settings.num_trace_samples(6):
+        Ct, st, rt = [T(x).clone().requires_grad_(True) for x in (C, sig, rhs)]
+        A = Probed(LowRankRootLinearOperator(Ct), ConstantDiagLinearOperator(st, 2048))
+        iq, ld = A.inv_quad_logdet(rt, logdet=True)
+        (iq.sum() + ld.sum()).backward()
+        out["c_iq"], out["c_ld"], out["c_dC"], out["c_dsig"], out["c_drhs"] = iq, ld, Ct.grad, st.grad, rt.grad
+    # exact gradient of logdet(C C^T + D): d/dd = diag(A^-1), d/dC = 2 A^-1 C   (fp64)
+    C64, d64 = C.astype(np.float64), d.astype(np.float64)
+    dense = C64 @ np.swapaxes(C64, -1, -2) + np.stack([np.diag(x) for x in d64])
+    Ainv = np.linalg.inv(dense)
+    out["exact_dlogdet_dd"] = np.diagonal(Ainv, axis1=-2, axis2=-1)
+    out["exact_dlogdet_dC"] = 2.0 * (Ainv @ C64)
+    save("g10_backward_precond", checksum=cases.checksum(C, d, rhs, Z, sig), **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
-                     ("g9", g9_backward)):
+                     ("g9", g9_backward), ("g10", g10_backward_preconditioned)):
         if name in todo:
             fn()
     print("done")

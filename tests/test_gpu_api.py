@@ -347,3 +347,46 @@ def test_backward_passes_against_reference_autograd():
                                          DenseLinearOperator(dev(K2)))
     with pytest.raises(NotImplementedError, match="_bilinear_derivative"):
         (Ak3 @ dev(cases.randn(909, 2, 64, 1, dtype=np.float32))).sum().backward()
+
+
+def test_backward_inv_quad_logdet_with_preconditioner_terms():
+    """With the pivoted-Cholesky preconditioner the reference's gradient contains d logdet P and the probes' estimate of
+    the same quantity, chained through PivotedCholesky.backward; here both are chained by hand
+    (functions/_inv_quad_logdet._add_preconditioner_terms): same gradients for the same probes (golden g10)."""
+    g = load_golden("g10_backward_precond")
+    C, d, rhs = cases.lowrank_diag(1001, 2, 2048, 8, 1)
+    Z = cases.randn(1002, 2, 2048, 6, dtype=np.float32)
+
+    def close(a, b, rel=5e-3):
+        a, b = host(a), np.asarray(b)
+        return a.shape == b.shape and np.abs(a - b).max() <= rel * np.abs(b).max()
+
+    z = dev(Z)
+    nrm = z.norm(dim=-2, keepdim=True)
+    with settings.cg_tolerance(1e-5), settings.max_cg_iterations(200), settings.num_trace_samples(6):
+        Ct, dt, rt = [dev(x).clone().requires_grad_(True) for x in (C, d, rhs)]
+        A = ProbedAddedDiag(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+        A._probes = (z / nrm, nrm)
+        iq, ld = A.inv_quad_logdet(rt, logdet=True)
+        (iq.sum() + ld.sum()).backward()
+        assert np.allclose(host(iq), g["iq"], rtol=1e-4) and np.allclose(host(ld), g["ld"], rtol=1e-3, atol=2e-2)
+        assert close(rt.grad, g["drhs"]) and close(dt.grad, g["dd"]) and close(Ct.grad, g["dC"])
+        Ct, dt, rt = [dev(x).clone().requires_grad_(True) for x in (C, d, rhs)]
+        A = ProbedAddedDiag(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+        A._probes = (z / nrm, nrm)
+        ld = A.logdet()
+        (ld * dev(np.array([1.5, -0.5], dtype=np.float32))).sum().backward()
+        assert close(dt.grad, g["ld_dd"]) and close(Ct.grad, g["ld_dC"])
+    # constant diagonal
+    sig = np.array([[0.6], [1.3]], dtype=np.float32)
+    with settings.cg_tolerance(1e-5), settings.max_cg_iterations(200), settings.num_trace_samples(6):
+        Ct2, st, rt2 = [dev(x).clone().requires_grad_(True) for x in (C, sig, rhs)]
+        A = ProbedAddedDiag(LowRankRootLinearOperator(Ct2), ConstantDiagLinearOperator(st, 2048))
+        A._probes = (z / nrm, nrm)
+        iq, ld = A.inv_quad_logdet(rt2, logdet=True)
+        (iq.sum() + ld.sum()).backward()
+        assert np.allclose(host(iq), g["c_iq"], rtol=1e-4) and np.allclose(host(ld), g["c_ld"], rtol=1e-3, atol=2e-2)
+        assert close(rt2.grad, g["c_drhs"]) and close(st.grad, g["c_dsig"]) and close(Ct2.grad, g["c_dC"])
+    # and the stochastic gradient is close to the exact one (6 probes, preconditioned: a few percent)
+    w = np.array([1.5, -0.5])[:, None]
+    assert np.abs(host(dt.grad) - w * g["exact_dlogdet_dd"]).max() < 0.2 * np.abs(g["exact_dlogdet_dd"]).max()
