@@ -1,6 +1,6 @@
 """Autograd wrappers.  Matmul, Solve, InvQuad and InvQuadLogdet have forward and backward (more solves plus the
-`_bilinear_derivative` contractions of csrc/lo_bilinear.hip); PivotedCholesky and RootDecomposition
-are forward-only: asking them for gradients fails loudly."""
+`_bilinear_derivative` contractions of csrc/lo_bilinear.hip), PivotedCholesky has the reference's
+backward for dense and dense-root operators; RootDecomposition is forward-only: asking it for gradients fails loudly."""
 from __future__ import annotations
 
 

@@ -30,11 +30,18 @@ class PivotedCholesky(Function):
             desc = K.dense_diag_descriptor(dense, None)
         L, perm = K.pivoted_cholesky(desc, max_iter, float(error_tol))
         ctx.mark_non_differentiable(perm)
+        ctx.representation_tree = representation_tree
+        ctx.save_for_backward(perm, *matrix_args)
         return L, perm
 
     @staticmethod
-    def backward(ctx, grad_output, _):
-        not_yet("PivotedCholesky")
+    def backward(ctx, grad_output, _):  # reference :107-147
+        perm, *matrix_args = ctx.saved_tensors
+        linear_op = ctx.representation_tree(*matrix_args)
+        grads = pivoted_cholesky_vjp(linear_op, perm, grad_output)
+        if grads is None:
+            not_yet("PivotedCholesky (operators other than dense / dense-root)")
+        return tuple([None, None, None] + list(grads))
 
 
 def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L):

@@ -472,6 +472,12 @@ def g10_backward_preconditioned():
         ld = A.logdet()
         (ld * T(np.array([1.5, -0.5], dtype=np.float32))).sum().backward()
         out["ld_only"], out["ld_dC"], out["ld_dd"] = ld, Ct.grad, dt.grad
+    # PivotedCholesky.backward on its own: loss = sum(L o G)
+    Gl = cases.randn(1003, 2, 2048, 8, dtype=np.float32)
+    Ct = T(C).clone().requires_grad_(True)
+    Lpc = LowRankRootLinearOperator(Ct).pivoted_cholesky(rank=15)
+    (Lpc * T(Gl)).sum().backward()
+    out["pc_L"], out["pc_dC"] = Lpc, Ct.grad
     # constant diagonal: sigma [2, 1]
     sig = np.array([[0.6], [1.3]], dtype=np.float32)
     with settings.cg_tolerance(1e-5), settings.max_cg_iterations(200), settings.num_trace_samples(6):
@@ -486,7 +492,7 @@ def g10_backward_preconditioned():
     Ainv = np.linalg.inv(dense)
     out["exact_dlogdet_dd"] = np.diagonal(Ainv, axis1=-2, axis2=-1)
     out["exact_dlogdet_dC"] = 2.0 * (Ainv @ C64)
-    save("g10_backward_precond", checksum=cases.checksum(C, d, rhs, Z, sig), **out)
+    save("g10_backward_precond", checksum=cases.checksum(C, d, rhs, Z, sig, Gl), **out)
 
 
 if __name__ == "__main__":

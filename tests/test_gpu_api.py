@@ -377,6 +377,12 @@ def test_backward_inv_quad_logdet_with_preconditioner_terms():
         ld = A.logdet()
         (ld * dev(np.array([1.5, -0.5], dtype=np.float32))).sum().backward()
         assert close(dt.grad, g["ld_dd"]) and close(Ct.grad, g["ld_dC"])
+    # PivotedCholesky.backward through the public method
+    Gl = cases.randn(1003, 2, 2048, 8, dtype=np.float32)
+    Ct3 = dev(C).clone().requires_grad_(True)
+    Lpc = LowRankRootLinearOperator(Ct3).pivoted_cholesky(rank=15)
+    (Lpc * dev(Gl)).sum().backward()
+    assert np.allclose(host(Lpc), g["pc_L"], rtol=1e-4, atol=1e-5) and close(Ct3.grad, g["pc_dC"], 1e-3)
     # constant diagonal
     sig = np.array([[0.6], [1.3]], dtype=np.float32)
     with settings.cg_tolerance(1e-5), settings.max_cg_iterations(200), settings.num_trace_samples(6):
