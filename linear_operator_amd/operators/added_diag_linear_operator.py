@@ -39,6 +39,19 @@ class WoodburyPreconditionClosure:
         return z.squeeze(-1) if is_vec else z
 
 
+# Memo of the last preconditioners, keyed on the operator's tensors (address, version counter, layout) and the settings
+# that shape the factorisation.  The reference caches the preconditioner on the operator OBJECT, but its autograd
+# Functions rebuild the operator from its tensors (functions/_solve.py:40), so a solve followed by a logdet, or the
+# solve inside Solve.backward, each factorise again; here those calls hit the memo.  The entry keeps the tensors alive
+# (so an address cannot be reused by other data) and any in-place update bumps the version counter.
+PRECONDITIONER_MEMO_SIZE = 2
+_precond_memo: "list[tuple]" = []
+
+
+def _memo_key(tensors, extra):
+    return tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype) for t in tensors) + extra
+
+
 class AddedDiagLinearOperator(SumLinearOperator):
     def __init__(self, *linear_ops, preconditioner_override: Optional[Callable] = None):
         linear_ops = list(linear_ops)
@@ -95,6 +108,16 @@ class AddedDiagLinearOperator(SumLinearOperator):
             return None, None, None
         if self._q_cache is None:
             max_iter = settings.max_preconditioner_size.value()
+            tensors = self.representation()
+            key = _memo_key(tensors, (max_iter, settings.preconditioner_tolerance.value(), type(self._linear_op),
+                                      type(self._diag_tensor)))
+            for entry in _precond_memo:
+                if entry[0] == key:
+                    (self._piv_chol_self, self._piv_chol_perm, self._woodbury, self._q_cache,
+                     self._precond_logdet_cache, self._constant_diag, self._noise) = entry[2]
+                    self._precond_lt = PsdSumLinearOperator(RootLinearOperator(self._piv_chol_self), self._diag_tensor)
+                    break
+        if self._q_cache is None:
             self._piv_chol_self = self._pivoted_cholesky_factor(max_iter)  # :125
             if torch.any(torch.isnan(self._piv_chol_self)).item():  # :126-131
                 warnings.warn(
@@ -103,6 +126,11 @@ class AddedDiagLinearOperator(SumLinearOperator):
                 )
                 return None, None, None
             self._init_cache()
+            if PRECONDITIONER_MEMO_SIZE > 0:
+                _precond_memo.insert(0, (key, tensors, (self._piv_chol_self, self._piv_chol_perm, self._woodbury,
+                                                        self._q_cache, self._precond_logdet_cache, self._constant_diag,
+                                                        self._noise)))
+                del _precond_memo[PRECONDITIONER_MEMO_SIZE:]
         closure = WoodburyPreconditionClosure(self._woodbury, self.batch_shape)
         closure.piv_chol, closure.piv_perm = self._piv_chol_self, getattr(self, "_piv_chol_perm", None)
         return closure, self._precond_lt, self._precond_logdet_cache

@@ -396,3 +396,32 @@ def test_backward_inv_quad_logdet_with_preconditioner_terms():
     # and the stochastic gradient is close to the exact one (6 probes, preconditioned: a few percent)
     w = np.array([1.5, -0.5])[:, None]
     assert np.abs(host(dt.grad) - w * g["exact_dlogdet_dd"]).max() < 0.2 * np.abs(g["exact_dlogdet_dd"]).max()
+
+
+def test_preconditioner_memo_hits_and_invalidates():
+    """The preconditioner memo (operators/added_diag_linear_operator.py) serves rebuilt operators over the SAME tensors
+    and is invalidated by in-place updates (tensor version counter) and by new tensors."""
+    from linear_operator_amd import kernels as K
+    from linear_operator_amd.operators import added_diag_linear_operator as adl
+
+    C, d, rhs = cases.lowrank_diag(1101, 2, 2048, 8, 1)
+    Ct, dt = dev(C), dev(d)
+    K._hip.prof_enable(True)
+    with settings.cg_tolerance(1e-4):
+        x1 = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt)).solve(dev(rhs))
+        torch.cuda.synchronize()
+        first = K._hip.prof_report()
+        x2 = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt)).solve(dev(rhs))
+        torch.cuda.synchronize()
+        second = K._hip.prof_report()
+        dt.mul_(2.0)  # in place: same address, new version
+        x3 = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt)).solve(dev(rhs))
+        torch.cuda.synchronize()
+        third = K._hip.prof_report()
+    K._hip.prof_enable(False)
+    built = lambda p: any(k.startswith("pc_") for k in p)  # noqa: E731
+    assert built(first) and not built(second) and built(third)
+    assert torch.equal(x1, x2)
+    A3 = C.astype(np.float64) @ np.swapaxes(C.astype(np.float64), -1, -2) + np.stack([np.diag(2.0 * v) for v in d.astype(np.float64)])
+    assert max_rel_err_cols(host(x3), np.linalg.solve(A3, rhs.astype(np.float64))) < 1e-4
+    assert len(adl._precond_memo) <= adl.PRECONDITIONER_MEMO_SIZE
