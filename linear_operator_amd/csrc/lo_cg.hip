@@ -373,7 +373,7 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   dd.ctrl_part = ar.take<float>(3 * 256);
   // operator-resident fast path scratch (c == 1): granule buffer, error word, per-iteration residuals
   dd.oc_gbuf = ar.take<unsigned long long>(onchip_gbuf_bytes(64) / sizeof(unsigned long long));
-  dd.oc_err = ar.take<int>(1);
+  dd.oc_err = ar.take<int>(4);  // [0] error word, [1] member counter of the dynamic hand-out
   dd.oc_resid = ar.take<float>((size_t)B * 16);
   dd.oc_init_conv = ar.take<int>((size_t)B);
   // preconditioner staging
@@ -490,7 +490,8 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
                      prm->max_iter >= 11 && oc_nwg >= 64 && !g_onchip_disabled &&
                      (onchip_eligible(pl.R4, preR4, N, c) || onchip4_eligible(pl.R4, preR4, N, c));
   // second generation (4 rows per thread, lo_cg_onchip4.hip) unless LO_OC_GEN1 asks for the first one
-  const bool oc_gen2 = oc_ok && onchip4_eligible(pl.R4, preR4, N, c) &&
+  // (the dynamic member hand-out passes indices through fp32 granules: exact below 2^24)
+  const bool oc_gen2 = oc_ok && onchip4_eligible(pl.R4, preR4, N, c) && B < (1 << 24) - 1024 &&
                        !(getenv("LO_OC_GEN1") && onchip_eligible(pl.R4, preR4, N, c));
   if (oc_ok) {
     OnchipArgs a;
@@ -504,7 +505,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.x = d.x; a.r = d.r; a.p = d.p; a.z = d.z;
     a.rhs_norm = d.rhs_norm; a.rz = d.rz; a.alpha = d.alpha; a.beta = d.beta; a.resid_norm = d.resid_norm;
     a.rhs_is_zero = d.rhs_is_zero; a.has_conv = d.has_conv;
-    a.resid_rec = d.oc_resid; a.init_conv = d.oc_init_conv; a.gbuf = d.oc_gbuf; a.err = d.oc_err;
+    a.resid_rec = d.oc_resid; a.init_conv = d.oc_init_conv; a.gbuf = d.oc_gbuf; a.err = d.oc_err; a.next_member = d.oc_err + 1;
     a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
     a.prefetch = getenv("LO_OC_NO_PREFETCH") ? 0 : 1;
     const bool oc_dbg = getenv("LO_OC_DEBUG") != nullptr && B >= 8;
@@ -512,7 +513,8 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.dbg_member = oc_dbg ? atoi(getenv("LO_OC_DEBUG")) : 0;  // LO_OC_DEBUG=<member index to time>
     LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(64), st));  // whole allocation (either generation)
     // LO_OC_TEST_FALLBACK: start with the error word set, as if a hand-off had timed out (exercises the host fallback)
-    LO_HIP_CHECK(hipMemsetAsync(d.oc_err, getenv("LO_OC_TEST_FALLBACK") ? 1 : 0, sizeof(int), st));
+    LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 0, 4 * sizeof(int), st));
+    if (getenv("LO_OC_TEST_FALLBACK")) LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 1, 1, st));
     if (oc_dbg) LO_HIP_CHECK(hipMemsetAsync(a.dbg, 0, 10 * sizeof(long long), st));
     rc = LO_ERR_UNSUPPORTED;
     if (oc_gen2) rc = onchip4_launch(pl.R4, preR4, a, oc_nwg, st);

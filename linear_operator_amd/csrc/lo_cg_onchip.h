@@ -26,6 +26,7 @@ struct OnchipArgs {
   int* init_conv;     // [B] has_converged before the first iteration (linear_cg.py:205-208)
   unsigned long long* gbuf;  // [ngroups][2][8][40] granules
   int* err;
+  int* next_member;   // second generation: shared counter of the dynamic member hand-out (zeroed by the host)
   int prefetch;          // first generation only: pull the next member's rows into L2 while iterating
   int allow_l2_handoff;  // 1: use the verified same-XCD L2 hand-off when the placement check passes
   long long* dbg;  // optional timestamps (wall_clock64) of member dbg_member / its workgroup 0, or nullptr

@@ -189,7 +189,11 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
 
   const int row0 = wig * a.RW;
   const int nv = max(0, min(a.RW, a.N - row0));  // rows of this workgroup
-  for (int64_t b = grp; b < a.B; b += ngroups) {
+  // Members are handed out dynamically: a group takes member `grp` first and then draws the next index from a
+  // shared counter.  Groups that start late (their workgroups waited for a CU that another kernel -- e.g. the RCCL
+  // all-gather of the previous solve -- was using) simply take fewer members instead of delaying the whole launch.
+  int64_t b = grp;
+  while (b < a.B) {
     const bool stamp = a.dbg && b == a.dbg_member && wig == 0 && t == 0;
     if (stamp) a.dbg[0] = wall_clock64();
     // ---- load: C rows -> VGPRs (each thread walks its own 4 rows; the rows were pulled into L2 by the previous
@@ -399,6 +403,14 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
     }
     __syncthreads();  // q_s / sh reuse by the next member
     if (stamp) a.dbg[4] = wall_clock64();
+    // next member: drawn by the group's first workgroup, handed to the others through the all-reduce path
+    // (one contributor, the rest add zeros: exact for indices < 2^24)
+    if (t < R4_WAVES) sh.red[t][0] = 0.f;
+    __syncthreads();
+    if (wig == 0 && t == 0) sh.red[0][0] = (float)(ngroups + atomicAdd(a.next_member, 1));
+    r4_group_sum<GW>(sh, 1, g);
+    b = (int64_t)sh.res[0];
+    __syncthreads();
   }
 }
 
