@@ -416,6 +416,9 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
   const int nv = max(0, min(a.RW, a.N - row0));
 
   for (int64_t b = grp; b < a.B; b += ngroups) {
+    const bool stamp = a.dbg && b == 64 && wig == 0 && t == 0;  // a member of the second round
+    long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if (stamp) a.dbg[0] = wall_clock64();
     int tl = t;
     asm volatile("" : "+v"(tl));  // keeps the load-phase address arithmetic inside the member loop (VGPR budget)
     float Cr[P4_NR][RC];
@@ -445,7 +448,9 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
       for (int i = 0; i < 4; ++i) l_s[l_slot(lr, i)] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
+    if (stamp) a.dbg[1] = wall_clock64();
     for (int m = 0; m < a.rank; ++m) {
+      if (stamp) c0 = wall_clock64();
       // ---- workgroup candidate: argmax of the running diagonal over the positions >= m, error 1-norm partial ----
       float bv = -INFINITY, es = 0.f;
       int bj = PO_INVALID;
@@ -502,7 +507,9 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
         }
         sh.part[3] = __float_as_uint(ge);
       }
+      if (stamp) c1 = wall_clock64();
       p4_gather<GW>(sh, PO_HDR + RC + m, gslot, wig, ++tag, a.err, same_xcd);
+      if (stamp) c2 = wall_clock64();
 
       // ---- group winner (identical in all workgroups): lane l holds candidate l % GW ----
       float vb = __uint_as_float(sh.gath[lane % GW][0]);
@@ -534,45 +541,65 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
         const float4 g4 = *reinterpret_cast<const float4*>(g + 4 * i);
         gc[4 * i] = g4.x; gc[4 * i + 1] = g4.y; gc[4 * i + 2] = g4.z; gc[4 * i + 3] = g4.w;
       }
+      // Schur update of row m for the 4 rows of this thread IN LOCKSTEP: the products and sums of a row are a
+      // dependent chain in the mandated order, the 4 rows give the instruction-level parallelism (computed for every
+      // row, applied below only where the reference writes)
+      float rowv[P4_NR], accs[P4_NR];
+#pragma unroll
+      for (int q = 0; q < P4_NR; ++q) rowv[q] = gc[0] * Cr[q][0];
+#pragma unroll
+      for (int r = 1; r < RC; ++r)
+#pragma unroll
+        for (int q = 0; q < P4_NR; ++q) rowv[q] = rowv[q] + gc[r] * Cr[q][r];
+#pragma unroll
+      for (int q = 0; q < P4_NR; ++q) accs[q] = 0.f;
+      for (int j4 = 0; 4 * j4 < m; ++j4) {  // :83-89, sequential in j
+        const float4 u4 = *reinterpret_cast<const float4*>(g + RC + 4 * j4);
+        const int j = 4 * j4;
+        float4 l4[P4_NR];
+#pragma unroll
+        for (int q = 0; q < P4_NR; ++q) l4[q] = l_s[l_slot(t + P4_TPB * q, j4)];
+#pragma unroll
+        for (int q = 0; q < P4_NR; ++q) accs[q] = (j == 0) ? u4.x * l4[q].x : accs[q] + u4.x * l4[q].x;
+        if (j + 1 < m) {
+#pragma unroll
+          for (int q = 0; q < P4_NR; ++q) accs[q] = accs[q] + u4.y * l4[q].y;
+        }
+        if (j + 2 < m) {
+#pragma unroll
+          for (int q = 0; q < P4_NR; ++q) accs[q] = accs[q] + u4.z * l4[q].z;
+        }
+        if (j + 3 < m) {
+#pragma unroll
+          for (int q = 0; q < P4_NR; ++q) accs[q] = accs[q] + u4.w * l4[q].w;
+        }
+      }
+      const int ms = m >> 2, me = m & 3;
 #pragma unroll
       for (int q = 0; q < P4_NR; ++q) {
         if (pos[q] == PO_INVALID) continue;
         // permutation swap of positions m and jb (:67-70), tracked per row
         if (pos[q] == jb) pos[q] = m;
         else if (pos[q] == m) pos[q] = jb;
+        if (pos[q] < m) continue;  // already pivoted rows keep L[m] = 0
         const int lr = t + P4_TPB * q;
-        const int ms = m >> 2, me = m & 3;
-        if (pos[q] == m) {
-          float4 l4 = l_s[l_slot(lr, ms)];
-          if (me == 0) l4.x = piv; else if (me == 1) l4.y = piv; else if (me == 2) l4.z = piv; else l4.w = piv;
-          l_s[l_slot(lr, ms)] = l4;
-        } else if (pos[q] > m) {  // Schur update of row m at the not yet pivoted rows (:77-95)
-          float rowv = gc[0] * Cr[q][0];
-#pragma unroll
-          for (int r = 1; r < RC; ++r) rowv = rowv + gc[r] * Cr[q][r];
-          float v = rowv;
-          if (m > 0) {
-            float acc = 0.f;
-            for (int j4 = 0; 4 * j4 < m; ++j4) {
-              const float4 u4 = *reinterpret_cast<const float4*>(g + RC + 4 * j4);
-              const float4 l4 = l_s[l_slot(lr, j4)];
-              const int j = 4 * j4;
-              acc = (j == 0) ? u4.x * l4.x : acc + u4.x * l4.x;
-              if (j + 1 < m) acc = acc + u4.y * l4.y;
-              if (j + 2 < m) acc = acc + u4.z * l4.z;
-              if (j + 3 < m) acc = acc + u4.w * l4.w;
-            }
-            v = rowv - acc;
-          }
-          v = v / piv;
-          float4 l4 = l_s[l_slot(lr, ms)];
-          if (me == 0) l4.x = v; else if (me == 1) l4.y = v; else if (me == 2) l4.z = v; else l4.w = v;
-          l_s[l_slot(lr, ms)] = l4;
-          dg[q] = dg[q] - v * v;
-        }
+        float v = (m > 0) ? rowv[q] - accs[q] : rowv[q];
+        v = v / piv;                                   // :91
+        const float val = (pos[q] == m) ? piv : v;     // the pivot row gets sqrt(max) (:73-74)
+        float4 l4 = l_s[l_slot(lr, ms)];
+        if (me == 0) l4.x = val; else if (me == 1) l4.y = val; else if (me == 2) l4.z = val; else l4.w = val;
+        l_s[l_slot(lr, ms)] = l4;
+        if (pos[q] > m) dg[q] = dg[q] - v * v;         // :94-95
       }
       // sh.gath / sh.part are next written after the barrier that follows the candidate reduction
+      if (stamp) {
+        c3 = wall_clock64();
+        a.dbg[4] += c1 - c0;
+        a.dbg[5] += c2 - c1;
+        a.dbg[6] += c3 - c2;
+      }
     }
+    if (stamp) a.dbg[2] = wall_clock64();
 
     // ---- L rows -> global, [max_rank, N] layout, consecutive threads = consecutive rows ----
 #pragma unroll
@@ -592,6 +619,7 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
       }
     }
     __syncthreads();  // l_s / sh reuse by the next member
+    if (stamp) a.dbg[3] = wall_clock64();
   }
 }
 
