@@ -442,6 +442,35 @@ def test_onchip_cg_matches_streaming_engine_and_oracle(N, R):
 
 
 # ------------------------------------------------------------------------------------------- many columns (MFMA paths)
+def test_onchip_cg_hands_over_to_streaming_loop_beyond_the_floor():
+    """When the tolerance is not met after the 11 guaranteed iterations the resident kernel's state (x, r, p, z and the
+    per-member scalars) continues in the streaming loop: same iteration count and solution as the streaming engine
+    alone, for a weak preconditioner (rank 2) and a tight tolerance."""
+    C, d, rhs = cases.lowrank_diag(3950, 20, 4096, 32, 1)
+    d = (10.0 ** (3.0 * (d - 0.5) - 2.0)).astype(np.float32)  # diagonal spread over 1e-2 .. 1e1: slow convergence
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    L, _ = K.pivoted_cholesky(K.lowrank_diag_descriptor(dev(C), None), 2)
+    pre = K.precond_build(L, dev(d), False)
+    try:
+        K.set_onchip_cg(False)
+        ref = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-5, max_iter=400)
+    finally:
+        K.set_onchip_cg(True)
+    K._hip.prof_enable(True)
+    res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-5, max_iter=400)
+    torch.cuda.synchronize()
+    prof = K._hip.prof_report()
+    K._hip.prof_enable(False)
+    assert "cg_onchip" in prof and any(k.startswith("skinny_") for k in prof), "both engines must have run"
+    # (ill-conditioned on purpose, cond ~ 1e5: the fp32 convergence histories of the two summation orders differ by a
+    # couple of iterations; both meet the tolerance)
+    assert ref.iterations > 11 and res.iterations > 11 and abs(res.iterations - ref.iterations) <= 4
+    assert res.tolerance_reached == ref.tolerance_reached
+    assert max_rel_err_cols(host(res.x), host(ref.x)) < 1e-3  # ill-conditioned on purpose: cond ~ 1e5
+    xo = orc.woodbury_solve(C.astype(np.float64), d.astype(np.float64), rhs.astype(np.float64))  # exact, fp64
+    assert max_rel_err_cols(host(res.x), xo) < 5e-2
+
+
 def test_onchip_timeout_falls_back_to_streaming_engines(monkeypatch):
     """A timed-out group hand-off (error word set) makes the host redo the work with the streaming engines: same
     pivots / L bit for bit, same iteration count, solutions equal to summation-order noise."""
