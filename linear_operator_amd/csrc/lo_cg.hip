@@ -46,6 +46,8 @@ struct CgDev {
   int* oc_err;
   float* oc_resid;
   int* oc_init_conv;
+  float* oc_zero_q;  // unpreconditioned resident path: an all-zero Q [B,N,4] and 1/d = 1 make z = r
+  float* oc_ones;
 };
 
 // ---- init ----------------------------------------------------------------------------------------
@@ -376,6 +378,12 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   dd.oc_err = ar.take<int>(4);  // [0] error word, [1] member counter of the dynamic hand-out
   dd.oc_resid = ar.take<float>((size_t)B * 16);
   dd.oc_init_conv = ar.take<int>((size_t)B);
+  dd.oc_zero_q = nullptr;
+  dd.oc_ones = nullptr;
+  if (!pre && !precond && c == 1 && op->kind == LO_OP_LOWRANK_DIAG && N >= 1024 && N <= 16384) {
+    dd.oc_zero_q = ar.take<float>((size_t)B * N * 4);
+    dd.oc_ones = ar.take<float>((size_t)B);
+  }
   // preconditioner staging
   if (pre) {
     const int R4 = padded_rank_k(pre->k);
@@ -424,8 +432,12 @@ size_t lo_cg_workspace_bytes(const lo_op_desc* op, const lo_precond_desc* pre, c
     dummy.k = 4; dummy.ldq = 4; dummy.constant_diag = 0; dummy.reserved = 0; dummy.Q = nullptr; dummy.dinv = nullptr;
     p = &dummy;
   }
-  return cg_layout(op, p, true, prm, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                   nullptr, false);
+  size_t need = cg_layout(op, p, true, prm, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, false);
+  if (!pre)  // the unpreconditioned resident path stages an all-zero Q instead of z
+    need = std::max(need, cg_layout(op, nullptr, false, prm, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, false));
+  return need;
 }
 
 int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user, const lo_precond_desc* pre,
@@ -486,17 +498,29 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   memset(&h, 0, sizeof(h));
   const int kfloor0 = std::min(10, prm->max_iter - 1);
   const int oc_nwg = onchip_num_workgroups();
-  const bool oc_ok = (op->kind == LO_OP_LOWRANK_DIAG) && pre && !precond_cb && !x0 && prm->n_tridiag == 0 && c == 1 &&
-                     prm->max_iter >= 11 && oc_nwg >= 64 && !g_onchip_disabled &&
-                     (onchip_eligible(pl.R4, preR4, N, c) || onchip4_eligible(pl.R4, preR4, N, c));
+  // no preconditioner (N < min_preconditioning_size in the host API): the resident kernel runs with Q = 0 and
+  // 1/d = 1, i.e. z = r and r.z = ||r||^2, which is the reference's unpreconditioned update (linear_cg.py:49-95)
+  const bool oc_nopre = !pre && !precond_cb && d.oc_zero_q != nullptr;
+  const int ocR4 = oc_nopre ? 4 : preR4;
+  const bool oc_ok = (op->kind == LO_OP_LOWRANK_DIAG) && (pre || oc_nopre) && !precond_cb && !x0 &&
+                     prm->n_tridiag == 0 && c == 1 && prm->max_iter >= 11 && oc_nwg >= 64 && !g_onchip_disabled &&
+                     (oc_nopre ? onchip4_eligible(pl.R4, 4, N, c)
+                               : (onchip_eligible(pl.R4, preR4, N, c) || onchip4_eligible(pl.R4, preR4, N, c)));
   // second generation (4 rows per thread, lo_cg_onchip4.hip) unless LO_OC_GEN1 asks for the first one
   // (the dynamic member hand-out passes indices through fp32 granules: exact below 2^24)
-  const bool oc_gen2 = oc_ok && onchip4_eligible(pl.R4, preR4, N, c) && B < (1 << 24) - 1024 &&
-                       !(getenv("LO_OC_GEN1") && onchip_eligible(pl.R4, preR4, N, c));
+  const bool oc_gen2 = oc_ok && onchip4_eligible(pl.R4, ocR4, N, c) && B < (1 << 24) - 1024 &&
+                       (oc_nopre || !(getenv("LO_OC_GEN1") && onchip_eligible(pl.R4, preR4, N, c)));
   if (oc_ok) {
     OnchipArgs a;
-    a.C = pl.Apad; a.Q = Qp; a.d = op->d; a.dinv = pre->dinv;
-    a.d_mode = op->diag_mode; a.dinv_mode = pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL;
+    a.C = pl.Apad; a.d = op->d;
+    a.d_mode = op->diag_mode;
+    if (oc_nopre) {
+      LO_HIP_CHECK(hipMemsetAsync(d.oc_zero_q, 0, sizeof(float) * (size_t)B * N * 4, st));
+      LO_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)d.oc_ones, 0x3f800000, (size_t)B, st));  // 1.0f
+      a.Q = d.oc_zero_q; a.dinv = d.oc_ones; a.dinv_mode = LO_DIAG_CONST;
+    } else {
+      a.Q = Qp; a.dinv = pre->dinv; a.dinv_mode = pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL;
+    }
     a.rhs = rhs; a.B = B; a.N = (int)N;
     a.GW = oc_gen2 ? onchip4_group_size(N) : 8;
     a.RW = (int)((N + a.GW - 1) / a.GW);
@@ -517,13 +541,14 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     if (getenv("LO_OC_TEST_FALLBACK")) LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 1, 1, st));
     if (oc_dbg) LO_HIP_CHECK(hipMemsetAsync(a.dbg, 0, 10 * sizeof(long long), st));
     rc = LO_ERR_UNSUPPORTED;
-    if (oc_gen2) rc = onchip4_launch(pl.R4, preR4, a, oc_nwg, st);
-    if (rc == LO_ERR_UNSUPPORTED && onchip_eligible(pl.R4, preR4, N, c)) {
+    if (oc_gen2) rc = onchip4_launch(pl.R4, ocR4, a, oc_nwg, st);
+    if (rc == LO_ERR_UNSUPPORTED && !oc_nopre && onchip_eligible(pl.R4, preR4, N, c)) {
       a.GW = 8;
       a.RW = (int)((N + 7) / 8);
       rc = onchip_launch(pl.R4, preR4, a, oc_nwg, st);
     }
-    if (rc) return rc;
+    if (rc && rc != LO_ERR_UNSUPPORTED) return rc;
+    if (rc == LO_OK) {  // (LO_ERR_UNSUPPORTED: no resident kernel fits this device / shape -> streaming engine)
     hipLaunchKernelGGL(k_cg_ctrl_onchip, dim3(1), block, 0, st, d, d.oc_resid, d.oc_init_conv, a.iters);
     LO_LAUNCH_CHECK();
     int oc_err = 0;
@@ -542,6 +567,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       fprintf(stderr, "liblo_amd: operator-resident CG timed out, falling back to the streaming engine\n");
       LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, sizeof(CgCtrl), st));
       memset(&h, 0, sizeof(h));
+    }
     }
   }
   int matvecs = 0;

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
         a.x[o] = x_s[t + R4_TPB * q];
         a.r[o] = r[q];
         a.p[o] = p[q];
-        a.z[o] = z[q];
+        if (a.z) a.z[o] = z[q];  // no z buffer in the unpreconditioned engine (z = r)
       }
     }
     if (wig == 0 && t == 0) {

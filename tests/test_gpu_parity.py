@@ -442,6 +442,38 @@ def test_onchip_cg_matches_streaming_engine_and_oracle(N, R):
 
 
 # ------------------------------------------------------------------------------------------- many columns (MFMA paths)
+@pytest.mark.parametrize("N,R", [(1500, 16), (4096, 32)])
+def test_onchip_cg_without_preconditioner(N, R):
+    """N < min_preconditioning_size in the host API means linear_cg gets no preconditioner: the resident kernel then
+    runs with Q = 0, 1/d = 1 (z = r), the reference's unpreconditioned update (linear_cg.py:49-95): same iterations and
+    solutions as the streaming engine and the oracle, including the hand-over when 11 iterations are not enough."""
+    B = 37
+    C, d, rhs = cases.lowrank_diag(3980 + R, B, N, R, 1)
+    rhs[5] = 0.0
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    for tol in (1e-1, 1e-4):
+        try:
+            K.set_onchip_cg(False)
+            ref = K.cg_solve(desc, dev(rhs), tolerance=tol, max_iter=300)
+        finally:
+            K.set_onchip_cg(True)
+        K._hip.prof_enable(True)
+        res = K.cg_solve(desc, dev(rhs), tolerance=tol, max_iter=300)
+        torch.cuda.synchronize()
+        prof = K._hip.prof_report()
+        K._hip.prof_enable(False)
+        assert "cg_onchip" in prof, "resident kernel was not used"
+        assert abs(res.iterations - ref.iterations) <= 1 and res.tolerance_reached == ref.tolerance_reached
+        keep = [i for i in range(B) if i != 5]
+        assert np.all(host(res.x)[5] == 0)
+        assert max_rel_err_cols(host(res.x)[keep], host(ref.x)[keep]) < 5e-5
+    sub = slice(0, 3)
+    xo, _, info = orc.linear_cg(lambda v: orc.matvec_lowrank_diag(C[sub], d[sub], v), rhs[sub], tolerance=1e-4,
+                                max_iter=300)
+    assert abs(info.iterations - res.iterations) <= 1
+    assert max_rel_err_cols(host(res.x)[sub], xo) < 1e-4
+
+
 def test_onchip_cg_hands_over_to_streaming_loop_beyond_the_floor():
     """When the tolerance is not met after the 11 guaranteed iterations the resident kernel's state (x, r, p, z and the
     per-member scalars) continues in the streaming loop: same iteration count and solution as the streaming engine
