@@ -339,6 +339,146 @@ __global__ __launch_bounds__(kThreads) void k_pb_q_mfma(const float* __restrict_
   }
 }
 
+// ---- the same for the reference layout L [B, N, k] (k contiguous), k <= 32: NA = number of 16-column halves --------
+// Gram: lane (a, kk) feeds w[row = chunk + 4 e + kk][a] (and [a + 16]) to MFMA e: a wave instruction reads 4 rows x
+// 64 contiguous bytes.  Blocks G00, G01, G11 are accumulated, G10 = G01^T is written on the way out.
+template <int NA>
+__global__ __launch_bounds__(kThreads) void k_pb_gram_mfma_nk(const float* __restrict__ L, LStride ls,
+                                                               const float* __restrict__ sc, int N, int k,
+                                                               int rows_per, double* __restrict__ gpart) {
+  constexpr int NB = (NA == 2) ? 3 : 1;
+  __shared__ double red[4][64][4 * NB];
+  const int s = blockIdx.x, S = gridDim.x;
+  const int64_t b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int a = l & 15, kk = l >> 4;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  const float* Lb = L + (size_t)b * ls.member;
+  const float* scb = sc ? sc + (size_t)b * N : nullptr;
+  f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc01 = acc00, acc11 = acc00;
+  for (int cb = r0 + 32 * wave; cb < r1; cb += 128) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = cb + 4 * e + kk;
+      float w0 = 0.f, w1 = 0.f;
+      if (row < r1) {
+        const float sv = scb ? scb[row] : 1.f;
+        const float* lr = Lb + (size_t)row * ls.row;
+        if (a < k) w0 = lr[a] * sv;
+        if (NA == 2 && a + 16 < k) w1 = lr[a + 16] * sv;
+      }
+      acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)w0, (double)w0, acc00, 0, 0, 0);
+      if (NA == 2) {
+        acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)w0, (double)w1, acc01, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)w1, (double)w1, acc11, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    red[wave][l][r] = acc00[r];
+    if (NA == 2) {
+      red[wave][l][4 + r] = acc01[r];
+      red[wave][l][8 + r] = acc11[r];
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double* gp = gpart + ((size_t)b * S + s) * k * k;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = 4 * r + kk, gj = a;  // D[4 r + l / 16][l % 16]
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) {
+        const double v = (red[0][l][4 * blk + r] + red[1][l][4 * blk + r]) + (red[2][l][4 * blk + r] + red[3][l][4 * blk + r]);
+        const int i = gi + (blk == 2 ? 16 : 0), j = gj + (blk >= 1 ? 16 : 0);
+        if (i < k && j < k) {
+          gp[i * k + j] = v;
+          if (blk == 1) gp[j * k + i] = v;  // G10 = G01^T
+        }
+      }
+    }
+  }
+}
+
+// Q = (W M^T) o scale: lane (i, kk) holds w[row][a = KA kk + st] (KA = 4 NA consecutive columns: 16-byte loads) and
+// B operand M[j][a]; 64-row chunks per wave as 4 tiles of 16 consecutive rows.
+template <int NA>
+__global__ __launch_bounds__(kThreads) void k_pb_q_mfma_nk(const float* __restrict__ L, LStride ls,
+                                                            const float* __restrict__ sc, const float* __restrict__ dd,
+                                                            int diag_mode, int N, int k, int ldq, int rows_per,
+                                                            const double* __restrict__ Minv, float* __restrict__ Q) {
+  constexpr int KA = 4 * NA;
+  const int s = blockIdx.x;
+  const int64_t b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int i = l & 15, kk = l >> 4;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  double mb[KA][NA];
+#pragma unroll
+  for (int st = 0; st < KA; ++st)
+#pragma unroll
+    for (int hj = 0; hj < NA; ++hj) {
+      const int a = KA * kk + st, j = i + 16 * hj;
+      mb[st][hj] = (j < k && a < k) ? Minv[(size_t)b * k * k + j * k + a] : 0.0;
+    }
+  const float* Lb = L + (size_t)b * ls.member;
+  const float* scb = sc ? sc + (size_t)b * N : nullptr;
+  const double cs = (diag_mode == LO_DIAG_CONST) ? 1.0 / sqrt((double)dd[b]) : 1.0;
+  float* Qb = Q + (size_t)b * N * ldq;
+  const bool vec_ok = (ls.row % 4) == 0 && (ls.member % 4) == 0 && ((uintptr_t)L % 16) == 0 && k >= KA * 4;  // 16-byte rows
+  for (int cb = r0 + 64 * wave; cb < r1; cb += 256) {
+    f64x4 acc[4][NA];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int hj = 0; hj < NA; ++hj) acc[t][hj] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = cb + 16 * t + i;
+      float x[KA];
+#pragma unroll
+      for (int st = 0; st < KA; ++st) x[st] = 0.f;
+      float sv = 0.f;
+      if (row < r1) {
+        sv = scb ? scb[row] : 1.f;
+        const float* lr = Lb + (size_t)row * ls.row + KA * kk;
+        if (vec_ok) {
+#pragma unroll
+          for (int q = 0; q < NA; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(lr + 4 * q);
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int st = 0; st < KA; ++st)
+            if (KA * kk + st < k) x[st] = lr[st];
+        }
+      }
+#pragma unroll
+      for (int st = 0; st < KA; ++st)
+#pragma unroll
+        for (int hj = 0; hj < NA; ++hj)
+          acc[t][hj] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)(x[st] * sv), mb[st][hj], acc[t][hj], 0, 0, 0);
+    }
+    // acc[t][hj][r] = Qtile_t[4 r + kk][j = i + 16 hj]
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = cb + 16 * t + 4 * r + kk;
+        if (row < r1) {
+          const double rs = scb ? (double)scb[row] : cs;
+#pragma unroll
+          for (int hj = 0; hj < NA; ++hj) {
+            const int j = i + 16 * hj;
+            if (j < ldq) Qb[(size_t)row * ldq + j] = (float)(acc[t][hj][r] * rs);
+          }
+        }
+      }
+  }
+}
+
 static int padded_k(int k) {
   int rq = (k + 3) / 4, p = 1;
   while (p < rq) p <<= 1;
@@ -387,7 +527,9 @@ int lo_precond_build_strided_f32(const float* L, int64_t ld_member, int64_t ld_r
   // rows layout ([B, m, N] as the pivoted-Cholesky kernels write it), k <= 16: fp64 matrix cores, 16-byte loads
   const bool mfma = ld_row == 1 && k <= 16 && (N % 4) == 0 && (ld_col % 4) == 0 && (ld_member % 4) == 0 &&
                     ((uintptr_t)L % 16) == 0 && ((uintptr_t)scale % 16) == 0;
-  if (mfma) {
+  // reference layout [B, N, k] (ld_col == 1), k <= 32: matrix-core kernels with per-row loads
+  const bool mfma_nk = !mfma && ld_col == 1 && k <= 32;
+  if (mfma || mfma_nk) {
     const float* sc = nullptr;
     if (diag_mode == LO_DIAG_FULL) {
       LO_PROF_BEGIN("pb_scale", st);
@@ -396,12 +538,21 @@ int lo_precond_build_strided_f32(const float* L, int64_t ld_member, int64_t ld_r
       sc = scale;
     }
     LO_PROF_BEGIN("pb_gram_mfma", st);
-    hipLaunchKernelGGL(k_pb_gram_mfma, grid, block, 0, st, L, ls, sc, (int)N, (int)k, sp.rows, gpart);
+    if (mfma) hipLaunchKernelGGL(k_pb_gram_mfma, grid, block, 0, st, L, ls, sc, (int)N, (int)k, sp.rows, gpart);
+    else if (k <= 16) hipLaunchKernelGGL((k_pb_gram_mfma_nk<1>), grid, block, 0, st, L, ls, sc, (int)N, (int)k, sp.rows, gpart);
+    else hipLaunchKernelGGL((k_pb_gram_mfma_nk<2>), grid, block, 0, st, L, ls, sc, (int)N, (int)k, sp.rows, gpart);
     LO_PROF_END(st);
     hipLaunchKernelGGL(k_pb_chol, dim3((unsigned)B), dim3(64), 0, st, gpart, logd, d, diag_mode, (int)N, (int)k, sp.S,
                        Minv, logdet_p, dinv);
     LO_PROF_BEGIN("pb_q_mfma", st);
-    hipLaunchKernelGGL(k_pb_q_mfma, grid, block, 0, st, L, ls, sc, d, diag_mode, (int)N, (int)k, ldq, sp.rows, Minv, Q);
+    if (mfma)
+      hipLaunchKernelGGL(k_pb_q_mfma, grid, block, 0, st, L, ls, sc, d, diag_mode, (int)N, (int)k, ldq, sp.rows, Minv, Q);
+    else if (k <= 16)
+      hipLaunchKernelGGL((k_pb_q_mfma_nk<1>), grid, block, 0, st, L, ls, sc, d, diag_mode, (int)N, (int)k, ldq, sp.rows,
+                         Minv, Q);
+    else
+      hipLaunchKernelGGL((k_pb_q_mfma_nk<2>), grid, block, 0, st, L, ls, sc, d, diag_mode, (int)N, (int)k, ldq, sp.rows,
+                         Minv, Q);
     LO_PROF_END(st);
     LO_LAUNCH_CHECK();
     return LO_OK;

@@ -310,6 +310,35 @@ def test_preconditioner_build_rows_layout_matrix_core_path(N, R, B):
             assert np.allclose(host(pv.logdet), g["logdet_nonconst"], rtol=1e-5)
 
 
+@pytest.mark.parametrize("k", [3, 15, 16, 20, 32])
+@pytest.mark.parametrize("const", [False, True])
+def test_preconditioner_build_reference_layout_any_rank(k, const):
+    """[B, N, k] factors (the Woodbury route hands its root over in this layout, k up to 32 on the fp64 matrix
+    cores) against the oracle's fp64 QR construction."""
+    B, N = 3, 3001
+    rng = np.random.default_rng(7700 + k)
+    L = (rng.standard_normal((B, N, k)) / np.sqrt(k)).astype(np.float32)
+    d = (0.2 + rng.random((B, N))).astype(np.float32)
+    sig = np.array([0.3, 0.7, 1.1], dtype=np.float32)
+    rhs = rng.standard_normal((B, N, 4)).astype(np.float32)
+    dd = np.broadcast_to(sig[:, None], (B, N)) if const else d
+    K._hip.prof_enable(True)
+    pre = K.precond_build(dev(L), dev(sig) if const else dev(d), constant_diag=const)
+    torch.cuda.synchronize()
+    prof = K._hip.prof_report()
+    K._hip.prof_enable(False)
+    assert "pb_q_mfma" in prof and "pb_gram_mfma" in prof
+    po = orc.Preconditioner(L.astype(np.float64), dd.astype(np.float64))
+    z = host(K.precond_apply(pre, dev(rhs)))
+    assert max_rel_err_cols(z, po.apply(rhs.astype(np.float64))) < 1e-5
+    assert np.allclose(host(pre.logdet), po.logdet, rtol=1e-5, atol=1e-3)
+    # Q Q^T is unique (Q itself only up to an orthogonal factor)
+    Q = host(pre.Q)[..., :k].astype(np.float64)
+    if const:  # the device Q carries the 1/sqrt(sigma^2) of P^-1 = (I - Q Q^T) / sigma^2
+        Q = Q * np.sqrt(sig.astype(np.float64))[:, None, None]
+    assert np.allclose(Q @ np.swapaxes(Q, -1, -2) [:, :, :200], (po.Q @ np.swapaxes(po.Q, -1, -2))[:, :, :200], atol=2e-6)
+
+
 def test_solve_lowrank_default_preconditioner():
     g = load_golden("g4_solve_lowrank")
     C, d, rhs = cases.lowrank_diag(401, 4, 2048, 32, 1)
