@@ -48,6 +48,9 @@ struct CgDev {
   int* oc_init_conv;
   float* oc_zero_q;  // unpreconditioned resident path: an all-zero Q [B,N,4] and 1/d = 1 make z = r
   float* oc_ones;
+  float* oc_ab;      // [iters, B, c, 2] alpha / beta record of the resident kernel (n_tridiag > 0)
+  int* oc_maxoff;    // [T + 1] per-iteration max off-diagonal (fp32 bit patterns, non-negative values)
+  long long* oc_dbg;
 };
 
 // ---- init ----------------------------------------------------------------------------------------
@@ -270,34 +273,90 @@ __global__ __launch_bounds__(kThreads) void k_cg_ctrl(CgDev d, int k, int G) {
   }
 }
 
-// control step after the operator-resident kernel ran iterations 0 .. iters-1 (c == 1, n_tridiag == 0):
-// the stop rule of iteration k = iters-1 (>= the 10-iteration floor), NaN check, skip rule (:207-208)
+// ---- after the operator-resident kernel ran iterations 0 .. iters-1 for every column ----
+// The tridiagonal recurrence (:311-332) is replayed from the recorded (masked) alpha / beta of each iteration:
+//  k_oc_maxoff: per-iteration maximum off-diagonal over the whole batch (the freeze rule :326-327 is batch-global)
+//  k_cg_ctrl_onchip: stop rule of iteration k = iters-1, NaN check, skip rule (:207-208), freeze iteration
+//  k_oc_tridiag: writes the entries of the iterations that ran before the freeze
+__device__ __forceinline__ float oc_recip(float alpha) { return 1.0f / ((alpha == 0.f) ? 1.0f : alpha); }  // :314-317
+
+__global__ __launch_bounds__(kThreads) void k_oc_maxoff(CgDev d, const float* __restrict__ ab, int ktri) {
+  const int64_t n = d.B * d.n_tridiag;
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const int64_t b = i / d.n_tridiag;
+  const int col = (int)(i % d.n_tridiag);
+  const size_t bc = (size_t)b * d.c + col, stride = (size_t)d.B * d.c;
+  for (int k = 1; k < ktri; ++k) {
+    const float pa = ab[2 * ((size_t)(k - 1) * stride + bc)], pb = ab[2 * ((size_t)(k - 1) * stride + bc) + 1];
+    const float off = sqrtf(pb) * oc_recip(pa);  // :323
+    if (off > 0.f) atomicMax(d.oc_maxoff + k, __float_as_int(off));
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_oc_tridiag(CgDev d, const float* __restrict__ ab, int ktri) {
+  const int64_t n = d.B * d.n_tridiag;
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const int64_t b = i / d.n_tridiag;
+  const int col = (int)(i % d.n_tridiag);
+  const size_t bc = (size_t)b * d.c + col, stride = (size_t)d.B * d.c;
+  const int T = d.T;
+  const int klast = min(ktri - 1, d.ctrl->last_tridiag_iter);
+  float* t = d.t_mat + ((size_t)col * d.B + b) * T * T;
+  float par = 0.f, pb = 0.f;
+  for (int k = 0; k <= klast; ++k) {
+    const float ar = oc_recip(ab[2 * ((size_t)k * stride + bc)]);
+    if (k == 0) {
+      t[0] = ar;                                 // :320
+    } else {
+      t[k * T + k] = fmaf(pb, par, ar);          // :322
+      const float off = sqrtf(pb) * par;         // :323
+      t[k * T + k - 1] = off;
+      t[(k - 1) * T + k] = off;                  // :324
+    }
+    par = ar;                                    // :331-332
+    pb = ab[2 * ((size_t)k * stride + bc) + 1];
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_cg_ctrl_onchip(CgDev d, const float* __restrict__ resid_rec,
-                                                              const int* __restrict__ init_conv, int iters) {
+                                                              const int* __restrict__ init_conv, int iters, int ktri) {
   __shared__ float red[kThreads];
   float lsum = 0.f, lnan = 0.f, lnotconv = 0.f;
-  for (int64_t b = threadIdx.x; b < d.B; b += kThreads) {
-    const float rn = resid_rec[(size_t)(iters - 1) * d.B + b];
-    const float r0 = resid_rec[b];
+  const int64_t n = d.B * d.c;
+  for (int64_t i = threadIdx.x; i < n; i += kThreads) {
+    const float rn = resid_rec[(size_t)(iters - 1) * n + i];
+    const float r0 = resid_rec[i];
     lsum += rn;
     if (r0 != r0 || rn != rn) lnan = 1.f;
-    if (!init_conv[b]) lnotconv = 1.f;
+    if (!init_conv[i]) lnotconv = 1.f;
   }
-  const float mean = block_sum256(lsum, red) / (float)d.B;
+  const float mean = block_sum256(lsum, red) / (float)n;
   const float anynan = block_sum256(lnan, red);
   const float notconv = block_sum256(lnotconv, red);
   if (threadIdx.x == 0) {
     const int k = iters - 1;
     d.ctrl->iterations = iters;
     d.ctrl->mean_resid = mean;
+    if (ktri > 0) {  // freeze rule: the first k > 0 whose largest off-diagonal is below 1e-6 is the last one recorded
+      int last = ktri - 1;
+      for (int kk = 1; kk < ktri; ++kk)
+        if (__int_as_float(d.oc_maxoff[kk]) < 1e-6f) {
+          last = kk;
+          d.ctrl->tri_disabled = 1;
+          break;
+        }
+      d.ctrl->last_tridiag_iter = last;          // :329
+    }
     if (anynan > 0.f) {
       d.ctrl->nan_detected = 1;
       d.ctrl->stop = 1;
-    } else if (notconv == 0.f) {  // every column converged before the first iteration: the reference skips the loop
+    } else if (notconv == 0.f && d.n_tridiag == 0) {  // every column converged before the first iteration (:207-208)
       d.ctrl->skipped = 1;
       d.ctrl->iterations = 0;
       d.ctrl->stop = 1;
-    } else if (k >= min(10, d.max_iter - 1) && mean < d.tol) {
+    } else if (k >= min(10, d.max_iter - 1) && mean < d.tol) {  // (k >= min(n_tridiag_iter, max_iter-1) by construction)
       d.ctrl->tol_reached = 1;
       d.ctrl->stop = 1;
     }
@@ -376,11 +435,19 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   // operator-resident fast path scratch (c == 1): granule buffer, error word, per-iteration residuals
   dd.oc_gbuf = ar.take<unsigned long long>(onchip_gbuf_bytes(64) / sizeof(unsigned long long));
   dd.oc_err = ar.take<int>(4);  // [0] error word, [1] member counter of the dynamic hand-out
-  dd.oc_resid = ar.take<float>((size_t)B * 16);
-  dd.oc_init_conv = ar.take<int>((size_t)B);
+  int oc_iters = std::min(10, prm->max_iter - 1);
+  if (prm->n_tridiag) oc_iters = std::max(oc_iters, std::min(prm->max_tridiag_iter, prm->max_iter - 1));
+  oc_iters = std::max(1, oc_iters + 1);
+  const bool oc_shape = op->kind == LO_OP_LOWRANK_DIAG && c <= 64 && N >= 1024 && N <= 16384;
+  const size_t oc_n = oc_shape ? (size_t)B * c : 1;
+  dd.oc_resid = ar.take<float>(oc_n * oc_iters);
+  dd.oc_init_conv = ar.take<int>(oc_n);
+  dd.oc_ab = (oc_shape && prm->n_tridiag) ? ar.take<float>(2 * oc_n * oc_iters) : nullptr;
+  dd.oc_maxoff = ar.take<int>((size_t)std::max(1, (int)prm->max_tridiag_iter) + 1);
+  dd.oc_dbg = ar.take<long long>(16);
   dd.oc_zero_q = nullptr;
   dd.oc_ones = nullptr;
-  if (!pre && !precond && c == 1 && op->kind == LO_OP_LOWRANK_DIAG && N >= 1024 && N <= 16384) {
+  if (!pre && !precond && oc_shape) {
     dd.oc_zero_q = ar.take<float>((size_t)B * N * 4);
     dd.oc_ones = ar.take<float>((size_t)B);
   }
@@ -496,20 +563,23 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   int k_start = 0;
   CgCtrl h;
   memset(&h, 0, sizeof(h));
-  const int kfloor0 = std::min(10, prm->max_iter - 1);
+  int kfloor0 = std::min(10, prm->max_iter - 1);
+  if (prm->n_tridiag) kfloor0 = std::max(kfloor0, std::min(prm->max_tridiag_iter, prm->max_iter - 1));  // first stop
   const int oc_nwg = onchip_num_workgroups();
   // no preconditioner (N < min_preconditioning_size in the host API): the resident kernel runs with Q = 0 and
   // 1/d = 1, i.e. z = r and r.z = ||r||^2, which is the reference's unpreconditioned update (linear_cg.py:49-95)
   const bool oc_nopre = !pre && !precond_cb && d.oc_zero_q != nullptr;
   const int ocR4 = oc_nopre ? 4 : preR4;
+  // (the first generation handles one column without tridiagonals; the second loops over the columns)
+  const bool oc_gen1_ok = !oc_nopre && prm->n_tridiag == 0 && c == 1 && onchip_eligible(pl.R4, preR4, N, c);
   const bool oc_ok = (op->kind == LO_OP_LOWRANK_DIAG) && (pre || oc_nopre) && !precond_cb && !x0 &&
-                     prm->n_tridiag == 0 && c == 1 && prm->max_iter >= 11 && oc_nwg >= 64 && !g_onchip_disabled &&
-                     (oc_nopre ? onchip4_eligible(pl.R4, 4, N, c)
-                               : (onchip_eligible(pl.R4, preR4, N, c) || onchip4_eligible(pl.R4, preR4, N, c)));
+                     prm->max_iter >= 11 && prm->max_iter > kfloor0 && oc_nwg >= 64 && !g_onchip_disabled &&
+                     (prm->n_tridiag == 0 || d.oc_ab != nullptr) &&
+                     (oc_gen1_ok || onchip4_eligible(pl.R4, ocR4, N, c));
   // second generation (4 rows per thread, lo_cg_onchip4.hip) unless LO_OC_GEN1 asks for the first one
   // (the dynamic member hand-out passes indices through fp32 granules: exact below 2^24)
   const bool oc_gen2 = oc_ok && onchip4_eligible(pl.R4, ocR4, N, c) && B < (1 << 24) - 1024 &&
-                       (oc_nopre || !(getenv("LO_OC_GEN1") && onchip_eligible(pl.R4, preR4, N, c)));
+                       !(getenv("LO_OC_GEN1") && oc_gen1_ok);
   if (oc_ok) {
     OnchipArgs a;
     a.C = pl.Apad; a.d = op->d;
@@ -522,6 +592,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       a.Q = Qp; a.dinv = pre->dinv; a.dinv_mode = pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL;
     }
     a.rhs = rhs; a.B = B; a.N = (int)N;
+    a.c = c; a.ab_rec = prm->n_tridiag ? d.oc_ab : nullptr;
     a.GW = oc_gen2 ? onchip4_group_size(N) : 8;
     a.RW = (int)((N + a.GW - 1) / a.GW);
     a.iters = kfloor0 + 1;
@@ -533,7 +604,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
     a.prefetch = getenv("LO_OC_NO_PREFETCH") ? 0 : 1;
     const bool oc_dbg = getenv("LO_OC_DEBUG") != nullptr && B >= 8;
-    a.dbg = oc_dbg ? reinterpret_cast<long long*>(d.oc_resid + (size_t)B * 12) : nullptr;
+    a.dbg = oc_dbg ? d.oc_dbg : nullptr;
     a.dbg_member = oc_dbg ? atoi(getenv("LO_OC_DEBUG")) : 0;  // LO_OC_DEBUG=<member index to time>
     LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(64), st));  // whole allocation (either generation)
     // LO_OC_TEST_FALLBACK: start with the error word set, as if a hand-off had timed out (exercises the host fallback)
@@ -542,14 +613,21 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     if (oc_dbg) LO_HIP_CHECK(hipMemsetAsync(a.dbg, 0, 10 * sizeof(long long), st));
     rc = LO_ERR_UNSUPPORTED;
     if (oc_gen2) rc = onchip4_launch(pl.R4, ocR4, a, oc_nwg, st);
-    if (rc == LO_ERR_UNSUPPORTED && !oc_nopre && onchip_eligible(pl.R4, preR4, N, c)) {
+    if (rc == LO_ERR_UNSUPPORTED && oc_gen1_ok) {
       a.GW = 8;
       a.RW = (int)((N + 7) / 8);
       rc = onchip_launch(pl.R4, preR4, a, oc_nwg, st);
     }
     if (rc && rc != LO_ERR_UNSUPPORTED) return rc;
     if (rc == LO_OK) {  // (LO_ERR_UNSUPPORTED: no resident kernel fits this device / shape -> streaming engine)
-    hipLaunchKernelGGL(k_cg_ctrl_onchip, dim3(1), block, 0, st, d, d.oc_resid, d.oc_init_conv, a.iters);
+    const int ktri = prm->n_tridiag ? std::min(a.iters, (int)prm->max_tridiag_iter) : 0;
+    const unsigned tri_grid = (unsigned)(((size_t)B * std::max(1, (int)prm->n_tridiag) + kThreads - 1) / kThreads);
+    if (ktri) {
+      LO_HIP_CHECK(hipMemsetAsync(d.oc_maxoff, 0, sizeof(int) * (prm->max_tridiag_iter + 1), st));
+      hipLaunchKernelGGL(k_oc_maxoff, dim3(tri_grid), block, 0, st, d, d.oc_ab, ktri);
+    }
+    hipLaunchKernelGGL(k_cg_ctrl_onchip, dim3(1), block, 0, st, d, d.oc_resid, d.oc_init_conv, a.iters, ktri);
+    if (ktri) hipLaunchKernelGGL(k_oc_tridiag, dim3(tri_grid), block, 0, st, d, d.oc_ab, ktri);
     LO_LAUNCH_CHECK();
     int oc_err = 0;
     LO_HIP_CHECK(hipMemcpyAsync(&oc_err, d.oc_err, sizeof(int), hipMemcpyDeviceToHost, st));

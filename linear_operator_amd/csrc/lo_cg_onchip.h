@@ -12,7 +12,9 @@ struct OnchipArgs {
   const float* d;     // [B, N] or [B]
   const float* dinv;  // [B, N] or [B]
   int d_mode, dinv_mode;
-  const float* rhs;   // [B, N]
+  const float* rhs;   // [B, N, c]
+  int c;              // right-hand-side columns (first generation: 1)
+  float* ab_rec;      // [iters, B, c, 2] masked alpha / beta per iteration (second generation, n_tridiag > 0) or nullptr
   int64_t B;
   int N, RW;          // rows per workgroup
   int GW;             // workgroups per member (group size): 8 (first generation), 4 or 8 (second)
@@ -22,8 +24,8 @@ struct OnchipArgs {
   float *x, *r, *p, *z;
   float *rhs_norm, *rz, *alpha, *beta, *resid_norm;
   int *rhs_is_zero, *has_conv;
-  float* resid_rec;   // [iters, B] residual norm after each iteration (for the stop rule / NaN check)
-  int* init_conv;     // [B] has_converged before the first iteration (linear_cg.py:205-208)
+  float* resid_rec;   // [iters, B, c] residual norm after each iteration (for the stop rule / NaN check)
+  int* init_conv;     // [B, c] has_converged before the first iteration (linear_cg.py:205-208)
   unsigned long long* gbuf;  // [ngroups][2][8][40] granules
   int* err;
   int* next_member;   // second generation: shared counter of the dynamic member hand-out (zeroed by the host)

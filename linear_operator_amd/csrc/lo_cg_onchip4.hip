@@ -151,7 +151,9 @@ __device__ __forceinline__ void r4_allreduce_scalars(R4Shared& sh, const float* 
   r4_group_sum<GW>(sh, ns, g);
 }
 
-template <int RC, int RK, int GW>
+// MC: several right-hand-side columns and / or recorded alpha, beta (the single-column instantiation keeps the
+// column count a compile-time 1)
+template <int RC, int RK, int GW, bool MC>
 __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
   constexpr int NQ = RK / 4;
   __shared__ R4Shared sh;
@@ -199,7 +201,6 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
     // ---- load: C rows -> VGPRs (each thread walks its own 4 rows; the rows were pulled into L2 by the previous
     // member's prefetch), Q rows -> LDS (coalesced, swizzled), x / d / 1/d -> LDS ----
     float Cr[R4_NR][RC];
-    float rhsv[R4_NR];
     bool valid[R4_NR];
     // thread index the optimiser cannot see through: keeps the address arithmetic of the load phase from being
     // hoisted out of the member loop (it would stay live in VGPRs during the iterations and force spills)
@@ -211,7 +212,6 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
       valid[q] = lr < nv;
       const size_t grow = (size_t)b * a.N + row0 + lr;
       float dq = 0.f, diq = 0.f;
-      rhsv[q] = 0.f;
       if (valid[q]) {
         const float4* cp = reinterpret_cast<const float4*>(a.C + grow * RC);
 #pragma unroll
@@ -221,14 +221,12 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
         }
         dq = (a.d_mode == LO_DIAG_FULL) ? a.d[grow] : (a.d_mode == LO_DIAG_CONST ? a.d[b] : 0.f);
         diq = (a.dinv_mode == LO_DIAG_FULL) ? a.dinv[grow] : a.dinv[b];
-        rhsv[q] = a.rhs[grow];
       } else {
 #pragma unroll
         for (int i = 0; i < RC; ++i) Cr[q][i] = 0.f;
       }
       d_s[lr] = dq;
       dinv_s[lr] = diq;
-      x_s[lr] = 0.f;
     }
     {  // Q rows -> LDS, coalesced and swizzled, one row-slot group (R4_NR float4 per thread) at a time: the loads
        // in flight stay within the VGPR budget next to the 128 registers of C
@@ -251,20 +249,30 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
     __syncthreads();
     if (stamp) a.dbg[1] = wall_clock64();
 
+    // The right-hand-side columns are solved one after the other against the resident rows (each column is an
+    // independent recurrence in the reference: every scalar of linear_cg.py carries a trailing column dimension).
+    const int nc = MC ? a.c : 1;
+    for (int col = 0; col < nc; ++col) {
+    const size_t bc = (size_t)b * nc + col;
     // ---- initialisation (linear_cg.py:177-215) ----
     float sc[2];
+    float r[R4_NR], p[R4_NR], z[R4_NR];
     sc[0] = 0.f;
+    int tc = t;  // (opaque, like tl: the addresses of the column's loads must not live across the iterations)
+    asm volatile("" : "+v"(tc));
 #pragma unroll
-    for (int q = 0; q < R4_NR; ++q) sc[0] = fmaf(rhsv[q], rhsv[q], sc[0]);
+    for (int q = 0; q < R4_NR; ++q) {
+      const int lr = tc + R4_TPB * q;
+      r[q] = (lr < nv) ? a.rhs[((size_t)b * a.N + row0 + lr) * nc + col] : 0.f;
+      x_s[lr] = 0.f;
+      sc[0] = fmaf(r[q], r[q], sc[0]);
+    }
     r4_allreduce_scalars<GW>(sh, sc, 1, g);
     float nrm = sqrtf(sh.res[0]);                           // rhs.norm(2, dim=-2)          :177
     const bool rhs_zero = nrm < a.eps;                      // :178
     if (rhs_zero) nrm = 1.0f;                               // :179
-    float r[R4_NR], p[R4_NR], z[R4_NR];
 #pragma unroll
-    for (int q = 0; q < R4_NR; ++q) {
-      r[q] = rhsv[q] / nrm;                                 // :182 (x0 = 0 -> residual = rhs)
-    }
+    for (int q = 0; q < R4_NR; ++q) r[q] = r[q] / nrm;      // :182 (x0 = 0 -> residual = rhs)
     // Q^T r, ||r||^2, sum r^2/d; z = r/d - Q (Q^T r)  (precondition_closure :135-140)
     float rr, rz, rn;
     bool conv;
@@ -312,13 +320,13 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
     };
     precond(rz);
     conv = sqrtf(rr) < a.stop_after;                        // :204-205
-    if (wig == 0 && t == 0) a.init_conv[b] = conv ? 1 : 0;
+    if (wig == 0 && t == 0) a.init_conv[bc] = conv ? 1 : 0;
 #pragma unroll
     for (int q = 0; q < R4_NR; ++q) p[q] = z[q];
     float beta = 0.f, alpha = 0.f;
     rn = sqrtf(rr);
 
-    if (stamp) {
+    if (stamp && col == 0) {
       a.dbg[2] = wall_clock64();
       g.dbg = a.dbg;
     }
@@ -376,16 +384,24 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
       rn = sqrtf(rr);                                       // :298
       if (rhs_zero) rn = 0.f;                               // :299
       conv = rn < a.stop_after;                             // :300
-      if (wig == 0 && t == 0) a.resid_rec[(size_t)k * a.B + b] = rn;
+      if (wig == 0 && t == 0) {
+        a.resid_rec[(size_t)k * a.B * nc + bc] = rn;
+        if (MC && a.ab_rec) {  // masked alpha and beta of this iteration: the tridiagonal recurrence is replayed afterwards
+          a.ab_rec[2 * ((size_t)k * a.B * nc + bc)] = alpha;
+          a.ab_rec[2 * ((size_t)k * a.B * nc + bc) + 1] = beta;
+        }
+      }
     }
 
-    if (stamp) a.dbg[3] = wall_clock64();
+    if (stamp && col == 0) a.dbg[3] = wall_clock64();
     g.dbg = nullptr;
     // ---- write the state back in the streaming engine's layout ----
+    int tw = t;
+    asm volatile("" : "+v"(tw));
 #pragma unroll
     for (int q = 0; q < R4_NR; ++q) {
-      if (valid[q]) {
-        const size_t o = (size_t)b * a.N + row0 + t + R4_TPB * q;
+      if (tw + R4_TPB * q < nv) {
+        const size_t o = ((size_t)b * a.N + row0 + tw + R4_TPB * q) * nc + col;
         a.x[o] = x_s[t + R4_TPB * q];
         a.r[o] = r[q];
         a.p[o] = p[q];
@@ -393,14 +409,15 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
       }
     }
     if (wig == 0 && t == 0) {
-      a.rhs_norm[b] = nrm;
-      a.rhs_is_zero[b] = rhs_zero ? 1 : 0;
-      a.rz[b] = rz;
-      a.alpha[b] = alpha;
-      a.beta[b] = beta;
-      a.resid_norm[b] = rn;
-      a.has_conv[b] = conv ? 1 : 0;
+      a.rhs_norm[bc] = nrm;
+      a.rhs_is_zero[bc] = rhs_zero ? 1 : 0;
+      a.rz[bc] = rz;
+      a.alpha[bc] = alpha;
+      a.beta[bc] = beta;
+      a.resid_norm[bc] = rn;
+      a.has_conv[bc] = conv ? 1 : 0;
     }
+    }  // columns
     __syncthreads();  // q_s / sh reuse by the next member
     if (stamp) a.dbg[4] = wall_clock64();
     // next member: drawn by the group's first workgroup, handed to the others through the all-reduce path
@@ -417,21 +434,21 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
 bool onchip4_eligible(int RC, int RK, int64_t N, int64_t c) {
   const bool rc_ok = (RC == 8 || RC == 16 || RC == 32);
   const bool rk_ok = (RK == 4 || RK == 8 || RK == 16);
-  return rc_ok && rk_ok && c == 1 && N >= 1024 && N <= (int64_t)R4_MAXGW * R4_ROWS;
+  return rc_ok && rk_ok && c >= 1 && c <= 64 && N >= 1024 && N <= (int64_t)R4_MAXGW * R4_ROWS;
 }
 
 int onchip4_group_size(int64_t N) { return N <= 8 * (int64_t)R4_ROWS ? 8 : 16; }
 
-template <int RC, int RK, int GW>
+template <int RC, int RK, int GW, bool MC>
 static int onchip4_go(const OnchipArgs& a, int nwg, hipStream_t st) {
   // the spin-waiting groups need ALL workgroups resident: two per CU
   int per_cu = 0;
   const bool half = getenv("LO_OC_HALF") != nullptr;  // debugging: one workgroup per CU
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_onchip4<RC, RK, GW>, R4_TPB, 0) != hipSuccess ||
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_onchip4<RC, RK, GW, MC>, R4_TPB, 0) != hipSuccess ||
       per_cu < (half ? 1 : 2))
     return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("cg_onchip", st);
-  hipLaunchKernelGGL((k_cg_onchip4<RC, RK, GW>), dim3(half ? nwg : 2 * nwg), dim3(R4_TPB), 0, st, a);
+  hipLaunchKernelGGL((k_cg_onchip4<RC, RK, GW, MC>), dim3(half ? nwg : 2 * nwg), dim3(R4_TPB), 0, st, a);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
@@ -440,7 +457,10 @@ static int onchip4_go(const OnchipArgs& a, int nwg, hipStream_t st) {
 // nwg = number of CUs used (multiple of 64); 2 * nwg workgroups are launched.  LO_ERR_UNSUPPORTED when two
 // workgroups do not fit on a CU (the caller then runs the first generation).
 int onchip4_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st) {
-#define LO_OC(C_, K_) return a.GW == 8 ? onchip4_go<C_, K_, 8>(a, nwg, st) : onchip4_go<C_, K_, 16>(a, nwg, st)
+  const bool mc = a.c > 1 || a.ab_rec != nullptr;
+#define LO_OC(C_, K_)                                                                                         \
+  return a.GW == 8 ? (mc ? onchip4_go<C_, K_, 8, true>(a, nwg, st) : onchip4_go<C_, K_, 8, false>(a, nwg, st)) \
+                   : (mc ? onchip4_go<C_, K_, 16, true>(a, nwg, st) : onchip4_go<C_, K_, 16, false>(a, nwg, st))
   if (RC == 32 && RK == 16) LO_OC(32, 16);
   else if (RC == 32 && RK == 8) LO_OC(32, 8);
   else if (RC == 32 && RK == 4) LO_OC(32, 4);

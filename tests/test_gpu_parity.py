@@ -470,6 +470,95 @@ def test_onchip_cg_matches_streaming_engine_and_oracle(N, R):
     assert torch.equal(res.x, res2.x)
 
 
+def _assert_tridiag_close(t_a, t_b, N, lead=2, same_size=True):
+    """Two fp32 runs of the same recurrence: the leading block agrees entry by entry; once a column sits at its fp32
+    noise floor alpha = r.z / p.Ap is a ratio of rounding noise, so the tail is compared through what it is used for --
+    the SLQ log-determinant estimate (per-member, relative to N)."""
+    a, b = host(t_a), host(t_b)
+    # (a freeze one iteration apart -- an off-diagonal of 1e-6 +- rounding -- only appends noise-floor rows)
+    assert a.shape[:-2] == b.shape[:-2] and abs(a.shape[-1] - b.shape[-1]) <= (0 if same_size else 1)
+    m = min(lead, a.shape[-1], b.shape[-1])
+    assert np.allclose(a[..., :m, :m], b[..., :m, :m], rtol=2e-3, atol=1e-4)
+    _, _, ld_a = K.tridiag_eigh_slq(t_a.contiguous(), N)
+    _, _, ld_b = K.tridiag_eigh_slq(t_b.contiguous(), N)
+    assert np.abs(host(ld_a) - host(ld_b)).max() / N < 1e-4
+
+
+@pytest.mark.parametrize("N,R,c,nt", [(4096, 32, 5, 0), (8192, 32, 7, 6), (2048, 16, 3, 3), (5000, 8, 17, 16)])
+def test_onchip_cg_many_columns_and_tridiagonals(N, R, c, nt):
+    """Several right-hand-side columns (the inv_quad_logdet call: probes + rhs) run one after the other against the
+    resident rows; the Lanczos tridiagonals are replayed from the recorded alpha / beta.  Same iteration count,
+    solutions, tridiagonal blocks and last_tridiag_iter as the streaming engine, and the oracle on a sub-batch."""
+    B = 41
+    C, d, rhs = cases.lowrank_diag(4400 + c, B, N, R, c)
+    rhs[2, :, 1] = 0.0  # an all-zero column
+    if nt:
+        rhs[..., :nt] /= np.maximum(np.linalg.norm(rhs[..., :nt], axis=-2, keepdims=True), 1e-30)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    pre = _default_precond(desc, dev(d), False)
+    kw = dict(precond=pre, tolerance=1e-4, n_tridiag=nt)
+    try:
+        K.set_onchip_cg(False)
+        ref = K.cg_solve(desc, dev(rhs), **kw)
+    finally:
+        K.set_onchip_cg(True)
+    K._hip.prof_enable(True)
+    res = K.cg_solve(desc, dev(rhs), **kw)
+    torch.cuda.synchronize()
+    prof = K._hip.prof_report()
+    K._hip.prof_enable(False)
+    assert "cg_onchip" in prof and not any(k.startswith("skinny_") for k in prof), "resident kernel alone expected"
+    assert res.iterations == ref.iterations == (21 if nt else 11) and res.tolerance_reached
+    assert np.all(host(res.x)[2, :, 1] == 0)
+    x, xr = host(res.x), host(ref.x)
+    mask = np.ones((B, c), bool)
+    mask[2, 1] = False
+    err = np.linalg.norm(x - xr, axis=-2) / np.maximum(np.linalg.norm(xr, axis=-2), 1e-30)
+    assert err[mask].max() < 2e-5
+    if nt:
+        assert res.t_mat.shape == ref.t_mat.shape  # (same last_tridiag_iter)
+        _assert_tridiag_close(res.t_mat, ref.t_mat, N)
+    sub = slice(0, 3)
+    pre_o = orc.Preconditioner(host(K.pivoted_cholesky(K.lowrank_diag_descriptor(dev(C[sub]), None), 15)[0]), d[sub])
+    xo, to, info = orc.linear_cg(lambda v: orc.matvec_lowrank_diag(C[sub], d[sub], v), rhs[sub], tolerance=1e-4,
+                                 preconditioner=pre_o.apply, n_tridiag=nt)
+    erro = np.linalg.norm(x[sub] - xo, axis=-2) / np.maximum(np.linalg.norm(xo, axis=-2), 1e-30)
+    assert erro[mask[sub]].max() < 1e-4
+    if nt:  # (the freeze rule :326-327 is batch-global: the oracle's sub-batch needs its own device run)
+        pre_s = _default_precond(K.lowrank_diag_descriptor(dev(C[sub]), dev(d[sub])), dev(d[sub]), False)
+        rs = K.cg_solve(K.lowrank_diag_descriptor(dev(C[sub]), dev(d[sub])), dev(rhs[sub]), precond=pre_s,
+                        tolerance=1e-4, n_tridiag=nt)
+        _assert_tridiag_close(rs.t_mat, torch.from_numpy(to.astype(np.float32)).cuda(), N, same_size=False)
+    res2 = K.cg_solve(desc, dev(rhs), **kw)
+    assert torch.equal(res.x, res2.x) and (not nt or torch.equal(res.t_mat, res2.t_mat))
+
+
+def test_onchip_cg_many_columns_hand_over():
+    """Columns + tridiagonals + a tolerance the guaranteed iterations do not reach: the streaming loop continues from
+    the resident kernel's per-column state."""
+    C, d, rhs = cases.lowrank_diag(4490, 12, 4096, 32, 4)
+    d = (10.0 ** (3.0 * (d - 0.5) - 2.0)).astype(np.float32)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    L, _ = K.pivoted_cholesky(K.lowrank_diag_descriptor(dev(C), None), 2)
+    pre = K.precond_build(L, dev(d), False)
+    kw = dict(precond=pre, tolerance=1e-5, max_iter=400, n_tridiag=3, max_tridiag_iter=8)  # 11 guaranteed iterations
+    try:
+        K.set_onchip_cg(False)
+        ref = K.cg_solve(desc, dev(rhs), **kw)
+    finally:
+        K.set_onchip_cg(True)
+    K._hip.prof_enable(True)
+    res = K.cg_solve(desc, dev(rhs), **kw)
+    torch.cuda.synchronize()
+    prof = K._hip.prof_report()
+    K._hip.prof_enable(False)
+    assert "cg_onchip" in prof and any(k.startswith("skinny_") for k in prof), "both engines must have run"
+    assert ref.iterations > 11 and res.iterations > 11 and abs(res.iterations - ref.iterations) <= 4
+    assert res.tolerance_reached == ref.tolerance_reached and res.t_mat.shape == ref.t_mat.shape
+    assert max_rel_err_cols(host(res.x), host(ref.x)) < 1e-3
+    _assert_tridiag_close(res.t_mat, ref.t_mat, 4096, lead=4)
+
+
 # ------------------------------------------------------------------------------------------- many columns (MFMA paths)
 @pytest.mark.parametrize("N,R", [(1500, 16), (4096, 32)])
 def test_onchip_cg_without_preconditioner(N, R):
