@@ -22,5 +22,7 @@ with settings.cg_tolerance(1e-4), settings.num_trace_samples(16):
         torch.cuda.synchronize(); print(f"{name}: forward + backward {B} x {N}: {(time.perf_counter()-t0)/3*1e3:.2f} ms")
         _hip.prof_enable(True); fn(); torch.cuda.synchronize()
         p = _hip.prof_report(); _hip.prof_enable(False)
-        for k, (c, ms) in sorted(p.items()):
-            if k.startswith("bil_"): print(f"    {k:16s} {c:3d} x {ms / c * 1e3:9.1f} us")
+        tot = sum(ms for _, ms in p.values())
+        print(f"    (liblo_amd kernels: {tot:.2f} ms; the rest is ATen plumbing + host)")
+        for k, (c, ms) in sorted(p.items(), key=lambda kv: -kv[1][1])[:12]:
+            print(f"    {k:20s} {c:3d} x {ms / c * 1e3:9.1f} us  = {ms:7.2f} ms")
