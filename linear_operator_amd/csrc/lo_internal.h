@@ -184,7 +184,7 @@ extern bool g_onchip_disabled;  // lo_cg_set_onchip(0): streaming engines only (
 
 // ---- operator-resident pivoted Cholesky (lo_pivchol_onchip.hip) ----------------------------------
 bool pc_onchip_eligible(const lo_op_desc* op, int max_rank);
-size_t pc_onchip_workspace_bytes(int64_t B, int max_rank);
+size_t pc_onchip_workspace_bytes(const lo_op_desc* op, int max_rank);
 // returns LO_ERR_LAUNCH when the group exchange timed out (caller falls back to the streaming engine)
 int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float* L_rows, long long* perm,
                   int32_t* rank_out, void* ws, size_t ws_bytes, hipStream_t st);

@@ -336,7 +336,7 @@ size_t lo_pivoted_cholesky_workspace_bytes(const lo_op_desc* op, int32_t max_ran
   Arena ar(nullptr, 0);
   PcDev d;
   pc_layout(op, max_rank, ar, &d);
-  return std::max(ar.off + 1024, pc_onchip_workspace_bytes(op->B, max_rank));
+  return std::max(ar.off + 1024, (pc_onchip_eligible(op, max_rank) ? pc_onchip_workspace_bytes(op, max_rank) : (size_t)0));
 }
 
 int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_tol, float* L_rows, int64_t* perm,

@@ -675,12 +675,15 @@ __global__ __launch_bounds__(kThreads) void k_po_perm(PoArgs a, const int* __res
 
 bool pc_onchip_eligible(const lo_op_desc* op, int max_rank) {
   if (g_onchip_disabled || op->kind != LO_OP_LOWRANK_DIAG) return false;
-  const int64_t R = op->R;
-  return (R == 8 || R == 16 || R == 32) && max_rank <= PO_MAXR && op->N >= 1024 &&
+  const int64_t R = op->R;  // (any rank up to 32: zero-padded to 8 / 16 / 32 columns in the workspace)
+  return R >= 1 && R <= 32 && max_rank <= PO_MAXR && op->N >= 1024 &&
          op->N <= (int64_t)16 * P4_ROWS && onchip_num_workgroups() >= 64;
 }
 
+static int po_padded_rank(int64_t R) { return R <= 8 ? 8 : (R <= 16 ? 16 : 32); }
+
 struct PoLayout {
+  float* cpad;  // [B, N, RP] zero-padded copy of C when R is not 8 / 16 / 32
   float* err_rec;
   float* orig;
   int* swaps;
@@ -690,7 +693,10 @@ struct PoLayout {
   long long* dbg;
 };
 
-static void po_layout(int64_t B, int max_rank, Arena& ar, PoLayout* l) {
+static void po_layout(const lo_op_desc* op, int max_rank, Arena& ar, PoLayout* l) {
+  const int64_t B = op->B;
+  const int RP = po_padded_rank(op->R);
+  l->cpad = (RP != op->R) ? ar.take<float>((size_t)B * op->N * RP) : nullptr;
   l->err = ar.take<int>(4);
   l->m_out = l->err + 1;
   l->err_rec = ar.take<float>((size_t)max_rank * B);
@@ -700,10 +706,10 @@ static void po_layout(int64_t B, int max_rank, Arena& ar, PoLayout* l) {
   l->dbg = ar.take<long long>(8);
 }
 
-size_t pc_onchip_workspace_bytes(int64_t B, int max_rank) {
+size_t pc_onchip_workspace_bytes(const lo_op_desc* op, int max_rank) {
   Arena ar(nullptr, 0);
   PoLayout l;
-  po_layout(B, max_rank, ar, &l);
+  po_layout(op, max_rank, ar, &l);
   return ar.off + 1024;
 }
 
@@ -711,8 +717,15 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
                   int32_t* rank_out, void* ws, size_t ws_bytes, hipStream_t st) {
   Arena ar(ws, ws_bytes);
   PoLayout l;
-  po_layout(op->B, max_rank, ar, &l);
+  po_layout(op, max_rank, ar, &l);
   if (!ar.ok) return LO_ERR_WORKSPACE;
+  const int RP = po_padded_rank(op->R);
+  const float* Csrc = op->A0;
+  if (RP != op->R) {
+    const int rc = pad_rows(op->A0, (int)op->R, l.cpad, RP, op->B * op->N, st);
+    if (rc) return rc;
+    Csrc = l.cpad;
+  }
   const int nwg = onchip_num_workgroups();
   // second generation (4 rows per thread, two workgroups per CU) when two workgroups fit on a CU
   const int gw2 = op->N <= (int64_t)8 * P4_ROWS ? 8 : 16;
@@ -721,10 +734,10 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
     int per_cu = 0;
     hipError_t e = hipErrorUnknown;
 #define LO_OCC(R_, G_) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pc_onchip4<R_, G_>, P4_TPB, 0)
-    if (op->R == 32 && gw2 == 8) LO_OCC(32, 8);
-    else if (op->R == 32) LO_OCC(32, 16);
-    else if (op->R == 16 && gw2 == 8) LO_OCC(16, 8);
-    else if (op->R == 16) LO_OCC(16, 16);
+    if (RP == 32 && gw2 == 8) LO_OCC(32, 8);
+    else if (RP == 32) LO_OCC(32, 16);
+    else if (RP == 16 && gw2 == 8) LO_OCC(16, 8);
+    else if (RP == 16) LO_OCC(16, 16);
     else if (gw2 == 8) LO_OCC(8, 8);
     else LO_OCC(8, 16);
 #undef LO_OCC
@@ -733,7 +746,7 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   if (!gen2 && op->N > (int64_t)PO_GW * PO_TPB) return LO_ERR_LAUNCH;  // caller runs the streaming engine
   const int gw = gen2 ? gw2 : PO_GW;
   PoArgs a;
-  a.C = op->A0;
+  a.C = Csrc;
   a.B = op->B;
   a.N = (int)op->N;
   a.RW = (int)((op->N + gw - 1) / gw);
@@ -757,15 +770,15 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   if (gen2) {
     dim3 grid2(2 * nwg), block2(P4_TPB);
 #define LO_GO(R_, G_) hipLaunchKernelGGL((k_pc_onchip4<R_, G_>), grid2, block2, 0, st, a)
-    if (op->R == 32 && gw == 8) LO_GO(32, 8);
-    else if (op->R == 32) LO_GO(32, 16);
-    else if (op->R == 16 && gw == 8) LO_GO(16, 8);
-    else if (op->R == 16) LO_GO(16, 16);
+    if (RP == 32 && gw == 8) LO_GO(32, 8);
+    else if (RP == 32) LO_GO(32, 16);
+    else if (RP == 16 && gw == 8) LO_GO(16, 8);
+    else if (RP == 16) LO_GO(16, 16);
     else if (gw == 8) LO_GO(8, 8);
     else LO_GO(8, 16);
 #undef LO_GO
-  } else if (op->R == 32) hipLaunchKernelGGL((k_pc_onchip<32>), grid, block, 0, st, a);
-  else if (op->R == 16) hipLaunchKernelGGL((k_pc_onchip<16>), grid, block, 0, st, a);
+  } else if (RP == 32) hipLaunchKernelGGL((k_pc_onchip<32>), grid, block, 0, st, a);
+  else if (RP == 16) hipLaunchKernelGGL((k_pc_onchip<16>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((k_pc_onchip<8>), grid, block, 0, st, a);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
