@@ -148,8 +148,10 @@ class InvQuadLogdet(Function):
 
         # un-normalise the probe-vector solves (:183-186)
         coef = 1.0 / ctx.probe_vectors.size(-1)
-        probe_vector_solves = solves.narrow(-1, 0, ctx.num_random_probes).mul(coef)
-        probe_vector_solves = probe_vector_solves.mul(ctx.probe_vector_norms).mul(logdet_grad_output)
+        # (the three per-probe / per-member factors are combined first: one pass over the [*, N, P] solves)
+        probe_vector_solves = solves.narrow(-1, 0, ctx.num_random_probes).mul(
+            ctx.probe_vector_norms.mul(logdet_grad_output).mul(coef)
+        )
 
         # probes were drawn from N(0, P); P^-1 probes are draws from N(0, P^-1)  (:188-193)
         if ctx.preconditioner is not None:

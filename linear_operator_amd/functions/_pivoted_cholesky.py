@@ -44,12 +44,43 @@ class PivotedCholesky(Function):
         return tuple([None, None, None] + list(grads))
 
 
-def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L):
+def _dense_root_vjp(r, perm, inv_perm, grad_L, m):
+    """The same pull-back for K = R R^T written out by hand (a dozen passes over [*, N, m] / [*, N, R] data instead of
+    the autograd tape of the generic re-expression); only the m x m Cholesky goes through autograd, so the
+    triangular / symmetric conventions of its backward are the ones the generic path (and the reference) get.
+      Lp = [L11; K21 L11^-T],  K11 = chol^-1 ...:  with G = grad_L in pivot order, G = [G11; G2], Rest = K21 L11^-T:
+      bar L11 = G11 - L11^-T (G2^T Rest),  bar K21 = G2 L11^-1,  bar K11 = chol_backward(bar L11),
+      bar Rp = bar Krows Rm,  bar Rm += bar Krows^T Rp   (Krows = Rp Rm^T, Rm = the m pivot rows)."""
+    from ..utils.cholesky import psd_safe_cholesky
+
+    R = r.size(-1)
+    idx = perm.unsqueeze(-1)
+    rp = torch.gather(r, -2, idx.expand(*perm.shape, R))  # rows in pivot order
+    gp = torch.gather(grad_L.contiguous(), -2, idx.expand(*perm.shape, m))
+    rm = rp[..., :m, :]
+    krows = rp @ rm.mT  # K[perm][:, pivots]  [*, N, m]
+    k11 = krows[..., :m, :].detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        l11 = psd_safe_cholesky(k11)
+    l11d = l11.detach()
+    rest = torch.linalg.solve_triangular(l11d, krows[..., m:, :].mT, upper=False).mT  # K21 L11^-T
+    g2 = gp[..., m:, :]
+    lbar = gp[..., :m, :] - torch.linalg.solve_triangular(l11d.mT, g2.mT @ rest, upper=True)
+    (k11bar,) = torch.autograd.grad(l11, k11, grad_outputs=lbar)
+    k21bar = torch.linalg.solve_triangular(l11d, g2, upper=False, left=False)  # G2 L11^-1
+    kbar = torch.cat([k11bar, k21bar], dim=-2)
+    rp_bar = kbar @ rm
+    rp_bar[..., :m, :] += kbar.mT @ rp
+    return torch.gather(rp_bar, -2, inv_perm.unsqueeze(-1).expand(*inv_perm.shape, R))
+
+
+def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False):
     """Vector-Jacobian product of the pivoted-Cholesky factor L [*batch, N, m] with respect to the tensors that
     represent `linear_op`, the way PivotedCholesky.backward does it (reference :107-147): re-express the factor of
     the SAME pivots as  Pi^T [chol(K_pp); (chol(K_pp)^-1 K_pr)^T]  with differentiable ATen ops on the m pivot rows
     (m x N data, k x k Cholesky: plumbing, like the reference) and back-propagate grad_L through it.
-    Returns one gradient (or None) per tensor of linear_op.representation()."""
+    Returns one gradient (or None) per tensor of linear_op.representation().  Dense roots take the hand-written
+    pull-back (_dense_root_vjp) unless `generic` asks for the autograd tape (tests compare the two)."""
     from ..operators.dense_linear_operator import DenseLinearOperator
     from ..operators.root_linear_operator import RootLinearOperator
     from ..utils.cholesky import psd_safe_cholesky
@@ -58,6 +89,9 @@ def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L):
     m = grad_L.size(-1)
     perm = full_permutation
     inv_perm = inverse_permutation(perm)
+    reps = linear_op.representation()
+    if not generic and isinstance(linear_op, RootLinearOperator) and len(reps) == 1 and linear_op._dense_root() is reps[0]:
+        return [_dense_root_vjp(reps[0].detach(), perm, inv_perm, grad_L, m)]
     leaves = []
     for t in linear_op.representation():
         leaves.append(t.detach().requires_grad_(True) if t.dtype.is_floating_point else t.detach())

@@ -349,6 +349,21 @@ def test_backward_passes_against_reference_autograd():
         (Ak3 @ dev(cases.randn(909, 2, 64, 1, dtype=np.float32))).sum().backward()
 
 
+def test_pivoted_cholesky_vjp_hand_written_matches_autograd_tape():
+    """The hand-written pull-back of the pivoted-Cholesky factor of a dense root (K = C C^T, R > m) against the
+    generic differentiable re-expression (the reference's PivotedCholesky.backward construction)."""
+    from linear_operator_amd import kernels as K
+    from linear_operator_amd.functions._pivoted_cholesky import pivoted_cholesky_vjp
+    C = cases.lowrank_diag(1101, 3, 2048, 32, 1)[0]
+    G = cases.randn(1102, 3, 2048, 15, dtype=np.float32)
+    op = LowRankRootLinearOperator(dev(C))
+    L, perm = K.pivoted_cholesky(op._kernel_descriptor(), 15)
+    (g_hand,) = pivoted_cholesky_vjp(op, perm, dev(G))
+    (g_tape,) = pivoted_cholesky_vjp(op, perm, dev(G), generic=True)
+    assert g_hand.shape == g_tape.shape == (3, 2048, 32)
+    assert (g_hand - g_tape).abs().max().item() <= 2e-4 * g_tape.abs().max().item()
+
+
 def test_backward_inv_quad_logdet_with_preconditioner_terms():
     """With the pivoted-Cholesky preconditioner the reference's gradient contains d logdet P and the probes' estimate of
     the same quantity, chained through PivotedCholesky.backward; here both are chained by hand
