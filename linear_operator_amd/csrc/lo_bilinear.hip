@@ -141,6 +141,78 @@ __global__ __launch_bounds__(kThreads) void k_bil_root_t(const float* __restrict
   }
 }
 
+// Root, phase A on the matrix cores (R <= 32, D <= 64): D-matrix[i = rho][j = d] += C^T[rho][row] * W[row][d] with
+// v_mfma_f32_32x32x2_f32, two rows per instruction; lane l loads C[row + (l >> 5)][l & 31] and W[row + (l >> 5)][32 t +
+// (l & 31)] -- one wave load = two consecutive rows, contiguous -- for W = V (-> T1) and W = U (-> T2).  C, U, V are
+// streamed exactly once.  Same tpart layout as k_bil_root_t.
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <int NTD>
+__global__ __launch_bounds__(kThreads) void k_bil_root_t_mfma(const float* __restrict__ C, const float* __restrict__ U,
+                                                               const float* __restrict__ V, int N, int R, int D,
+                                                               int rows_per, float* __restrict__ tpart) {
+  __shared__ float red[4][32][33];
+  const int s = blockIdx.x, S = gridDim.x;
+  const int64_t b = blockIdx.y;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, kk = lane >> 5;
+  const float* Cb = C + (size_t)b * N * R;
+  const float* Ub = U + (size_t)b * N * D;
+  const float* Vb = V + (size_t)b * N * D;
+  f32x16 acc[2][NTD];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < NTD; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][t][e] = 0.f;
+  constexpr int UNR = 4;  // row pairs in flight per wave
+  const int npairs = (r1 - r0 + 1) / 2;
+  for (int pr0 = wave; pr0 < npairs; pr0 += 4 * UNR) {
+    float cv[UNR], uv[UNR][NTD], vv[UNR][NTD];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int pr = pr0 + 4 * u;
+      const int row = r0 + 2 * pr + kk;
+      const bool ok = (pr < npairs) && (row < r1);
+      cv[u] = (ok && li < R) ? Cb[(size_t)row * R + li] : 0.f;
+#pragma unroll
+      for (int t = 0; t < NTD; ++t) {
+        const int d = 32 * t + li;
+        const bool okd = ok && d < D;
+        uv[u][t] = okd ? Ub[(size_t)row * D + d] : 0.f;
+        vv[u][t] = okd ? Vb[(size_t)row * D + d] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int t = 0; t < NTD; ++t) {
+        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cv[u], vv[u][t], acc[0][t], 0, 0, 0);  // T1 = V^T C
+        acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cv[u], uv[u][t], acc[1][t], 0, 0, 0);  // T2 = U^T C
+      }
+  }
+  // cross-wave sum in fixed order; D-matrix element (i = rho, j = d - 32 t) -> tp[m][d][rho]
+  const int npair = D * R;
+  float* tp = tpart + ((size_t)b * S + s) * 2 * npair;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < NTD; ++t) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) red[wave][(e & 3) + 8 * (e >> 2) + 4 * kk][li] = acc[m][t][e];
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < 32 * 32; idx += kThreads) {
+        const int j = idx >> 5, i = idx & 31;  // consecutive threads -> consecutive rho
+        const int d = 32 * t + j;
+        if (i < R && d < D)
+          tp[(size_t)m * npair + (size_t)d * R + i] = (red[0][i][j] + red[1][i][j]) + (red[2][i][j] + red[3][i][j]);
+      }
+    }
+}
+
 // Root, phase B: out[b, n, rho] = sum_d U[n,d] T1[d,rho] + V[n,d] T2[d,rho], T = sum_s tpart (fixed order)
 __global__ __launch_bounds__(kThreads) void k_bil_root_out(const float* __restrict__ U, const float* __restrict__ V,
                                                             const float* __restrict__ tpart, int S, int N, int R,
@@ -232,8 +304,15 @@ int lo_bilinear_root_f32(const float* C, const float* U, const float* V, int64_t
   if (ws_bytes < sizeof(float) * (size_t)B * sp.S * 2 * D * R) return LO_ERR_WORKSPACE;
   float* tpart = (float*)ws;
   LO_PROF_BEGIN("bil_root_t", st);
-  hipLaunchKernelGGL(k_bil_root_t, dim3(sp.S, (unsigned)B), dim3(kThreads), lds_a, st, C, U, V, (int)N, (int)R, (int)D,
-                     sp.rows, tpart);
+  if (R <= 32 && D <= 32)
+    hipLaunchKernelGGL(k_bil_root_t_mfma<1>, dim3(sp.S, (unsigned)B), dim3(kThreads), 0, st, C, U, V, (int)N, (int)R,
+                       (int)D, sp.rows, tpart);
+  else if (R <= 32 && D <= 64)
+    hipLaunchKernelGGL(k_bil_root_t_mfma<2>, dim3(sp.S, (unsigned)B), dim3(kThreads), 0, st, C, U, V, (int)N, (int)R,
+                       (int)D, sp.rows, tpart);
+  else
+    hipLaunchKernelGGL(k_bil_root_t, dim3(sp.S, (unsigned)B), dim3(kThreads), lds_a, st, C, U, V, (int)N, (int)R,
+                       (int)D, sp.rows, tpart);
   LO_PROF_END(st);
   const int64_t items = N * ((R + 3) / 4);
   LO_PROF_BEGIN("bil_root_out", st);

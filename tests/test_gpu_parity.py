@@ -685,3 +685,20 @@ def test_cg_many_columns_mfma_paths_vs_oracle():
     y5 = host(K.matvec(K.lowrank_diag_descriptor(dev(C5), dev(d5)), dev(rhs5)))
     assert max_rel_err_cols(y5, orc.matvec_lowrank_diag(C5.astype(np.float64), d5.astype(np.float64),
                                                         rhs5.astype(np.float64))) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------- bilinear derivative (root)
+@pytest.mark.parametrize("N,R,D", [(1001, 32, 2), (2048, 32, 34), (777, 5, 17), (1500, 20, 64), (900, 8, 70),
+                                    (600, 40, 6)])
+def test_bilinear_derivative_root_all_engines(N, R, D):
+    """lo_bilinear_root_f32 = U (V^T C) + V (U^T C): matrix-core first phase for R <= 32, D <= 64 (one or two column
+    tiles), VALU kernel beyond, against the oracle in fp64."""
+    B = 3
+    rng = np.random.default_rng(8800 + D)
+    C = rng.standard_normal((B, N, R)).astype(np.float32)
+    U = rng.standard_normal((B, N, D)).astype(np.float32)
+    V = rng.standard_normal((B, N, D)).astype(np.float32)
+    out = host(K.bilinear_root(dev(C), dev(U), dev(V)))
+    ref = orc.bilinear_derivative_root(C.astype(np.float64), U.astype(np.float64), V.astype(np.float64))
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 2e-5 * np.abs(ref).max()
