@@ -6,7 +6,7 @@ The compute backend is liblo_amd.so (hand-written gfx950 kernels, C ABI in inclu
 CPU fallback for the iterative path.  See DESIGN.md / INTEGRATION.md.
 """
 from . import operators, settings, utils
-from .functions import (add_diagonal, add_jitter, diagonal, inv_quad, inv_quad_logdet, logdet, matmul,
+from .functions import (add_diagonal, add_jitter, diagonal, diagonalization, inv_quad, inv_quad_logdet, logdet, matmul,
                         pivoted_cholesky, solve)
 from .operators import LinearOperator, to_dense, to_linear_operator
 
@@ -14,6 +14,6 @@ __version__ = "0.1.0"
 
 __all__ = [
     "LinearOperator", "to_dense", "to_linear_operator", "operators", "settings", "utils",
-    "add_diagonal", "add_jitter", "diagonal", "inv_quad", "inv_quad_logdet", "logdet", "matmul", "pivoted_cholesky",
+    "add_diagonal", "add_jitter", "diagonal", "diagonalization", "inv_quad", "inv_quad_logdet", "logdet", "matmul", "pivoted_cholesky",
     "solve",
 ]

@@ -16,6 +16,8 @@
 //     per row drops 4x;
 //   * one all-reduce = wave reduce-scatter -> LDS -> barrier -> the first wave sums the 4 wave partials, publishes
 //     the granules, polls the whole group's granules and sums them -> LDS -> barrier (2 barriers instead of 4).
+// (512 threads x 2 rows per thread -- 4 waves per SIMD to hide the reduction latency -- was measured 10 % slower:
+// the per-thread reduction overhead doubles and the 128-VGPR budget spills.)
 // Requires 2 resident workgroups per CU (256 VGPRs per lane, 66 KiB LDS each): checked on the host with the
 // occupancy API, otherwise the first generation runs.
 #include <algorithm>
@@ -154,7 +156,7 @@ __device__ __forceinline__ void r4_allreduce_scalars(R4Shared& sh, const float* 
 // MC: several right-hand-side columns and / or recorded alpha, beta (the single-column instantiation keeps the
 // column count a compile-time 1)
 template <int RC, int RK, int GW, bool MC>
-__global__ __launch_bounds__(R4_TPB, 2) void k_cg_onchip4(OnchipArgs a) {
+__global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip4(OnchipArgs a) {
   constexpr int NQ = RK / 4;
   __shared__ R4Shared sh;
   __shared__ float4 q_s[R4_ROWS * NQ];  // Q rows of this workgroup, swizzled 16-byte slots

@@ -22,6 +22,10 @@ def diagonal(input):
     return _op(input).diagonal()
 
 
+def diagonalization(input, method=None):
+    return _op(input).diagonalization(method=method)
+
+
 def inv_quad(input, inv_quad_rhs, reduce_inv_quad: bool = True):
     return _op(input).inv_quad(inv_quad_rhs, reduce_inv_quad=reduce_inv_quad)
 
@@ -46,5 +50,5 @@ def solve(input, rhs, lhs=None):
     return _op(input).solve(right_tensor=rhs, left_tensor=lhs)
 
 
-__all__ = ["add_diagonal", "add_jitter", "diagonal", "inv_quad", "inv_quad_logdet", "logdet", "matmul",
+__all__ = ["add_diagonal", "add_jitter", "diagonal", "diagonalization", "inv_quad", "inv_quad_logdet", "logdet", "matmul",
            "pivoted_cholesky", "solve"]

@@ -487,6 +487,40 @@ class LinearOperator(object):
             self._root_decomposition_cache = roots
         return inv_roots
 
+    def _symeig(self, eigenvectors: bool = False, return_evals_as_lazy: bool = False):
+        """Dense symmetric eigendecomposition in `settings._linalg_dtype_symeig` (ATen plumbing; reference :878-901)."""
+        from .dense_linear_operator import DenseLinearOperator
+
+        if settings.verbose_linalg.on():
+            settings.verbose_linalg.logger.debug(f"Running symeig on a matrix of size {self.shape}.")
+        dtype = self.dtype
+        evals, evecs = torch.linalg.eigh(self.to_dense().to(dtype=settings._linalg_dtype_symeig.value()))
+        evals = evals.clamp_min(0.0).to(dtype=dtype)
+        return evals, (DenseLinearOperator(evecs.to(dtype=dtype)) if eigenvectors else None)
+
+    def diagonalization(self, method: Optional[str] = None):
+        """(evals, evecs) of a (usually partial) diagonalization Q diag(lambda) Q^T ~= A (reference :1439-1482):
+        "lanczos" (device Lanczos, functions/_diagonalization.py) or "symeig"."""
+        from ..functions._diagonalization import Diagonalization
+        from . import to_linear_operator
+
+        if not self.is_square:
+            raise RuntimeError(
+                "diagonalization only operates on (batches of) square (symmetric) LinearOperators. "
+                "Got a {} of size {}.".format(self.__class__.__name__, self.size())
+            )
+        if method is None:
+            method = "symeig" if self.size(-1) <= settings.max_cholesky_size.value() else "lanczos"
+        if method == "lanczos":
+            evals, evecs = Diagonalization.apply(
+                self.representation_tree(), self.device, self.dtype, self.matrix_shape,
+                self._root_decomposition_size(), self.batch_shape, *self.representation(),
+            )
+            return evals, to_linear_operator(evecs)
+        if method == "symeig":
+            return self._symeig(eigenvectors=True)
+        raise RuntimeError(f"Unknown diagonalization method '{method}'")
+
     def root_decomposition(self, method: Optional[str] = None):
         """R with R R^T ~= A (reference :2158-2218).  Methods on this path: "lanczos" (device Lanczos + tridiagonal
         eigh), "cholesky" (dense factor, N <= max_cholesky_size), "pivoted_cholesky"."""

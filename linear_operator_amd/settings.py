@@ -228,6 +228,31 @@ class tridiagonal_jitter(_value_context):
     _global_value = 1e-6
 
 
+class _linalg_dtype_symeig(_value_context):
+    _global_value = torch.double
+
+
+class _linalg_dtype_cholesky(_value_context):
+    _global_value = torch.double
+
+
+class linalg_dtypes:
+    """Precision of the dense symeig / Cholesky plumbing calls (settings.py:356-380); default torch.double."""
+
+    def __init__(self, default=torch.double, symeig=None, cholesky=None):
+        self.symeig = _linalg_dtype_symeig(default if symeig is None else symeig)
+        self.cholesky = _linalg_dtype_cholesky(default if cholesky is None else cholesky)
+
+    def __enter__(self):
+        self.symeig.__enter__()
+        self.cholesky.__enter__()
+
+    def __exit__(self, *args):
+        self.symeig.__exit__()
+        self.cholesky.__exit__()
+        return False
+
+
 class verbose_linalg(_feature_flag):
     """Debug logging of every linear-algebra call (settings.py:587-605)."""
 
@@ -241,7 +266,7 @@ class verbose_linalg(_feature_flag):
 
 
 __all__ = [
-    "fast_computations", "cholesky_jitter", "cholesky_max_tries", "cg_tolerance", "debug", "deterministic_probes",
+    "fast_computations", "linalg_dtypes", "cholesky_jitter", "cholesky_max_tries", "cg_tolerance", "debug", "deterministic_probes",
     "max_cg_iterations", "max_cholesky_size", "max_lanczos_quadrature_iterations", "max_preconditioner_size",
     "max_root_decomposition_size", "memory_efficient", "min_preconditioning_size", "num_trace_samples",
     "preconditioner_tolerance", "skip_logdet_forward", "terminate_cg_by_size", "trace_mode", "tridiagonal_jitter",

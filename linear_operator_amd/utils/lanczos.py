@@ -49,13 +49,14 @@ def lanczos_tridiag(
     return K.lanczos_tridiag(desc, init_vecs.contiguous(), num_iter, tol=tol, matvec_closure=closure)
 
 
-def lanczos_tridiag_to_diag(t_mat):
+def lanczos_tridiag_to_diag(t_mat, tridiagonal=True):
     """t_mat [P, *batch, k, k] -> (evals [P,*batch,k], evecs [P,*batch,k,k]); negative eigenvalues -> 1 with their
     eigenvector columns zeroed (lanczos.py:185-187).  On device for k <= 32 (the reference moves the matrices to
-    the CPU in that case, :179-180); larger k uses torch.linalg.eigh on the device like the reference (:182)."""
+    the CPU in that case, :179-180); larger k uses torch.linalg.eigh on the device like the reference (:182).
+    `tridiagonal=False`: the matrices are full symmetric (Diagonalization's jitter), dense eigensolver."""
     if settings.verbose_linalg.on():
         settings.verbose_linalg.logger.debug(f"Running symeig on a matrix of size {t_mat.shape}.")
-    if t_mat.size(-1) <= 32 and t_mat.is_cuda and t_mat.dtype == torch.float32:
+    if tridiagonal and t_mat.size(-1) <= 32 and t_mat.is_cuda and t_mat.dtype == torch.float32:
         lead = t_mat.shape[:-2]
         t3 = t_mat.reshape(1, -1, *t_mat.shape[-2:])
         evals, evecs, _ = K.tridiag_eigh_slq(t3, 1, want_evecs=True, want_logdet=False)

@@ -585,7 +585,7 @@ def woodbury_logdet(C, d):
 # ----------------------------------------------------------------------------------
 
 
-def root_decomposition(matmul_closure, init_vecs, max_iter, tridiagonal_jitter=1e-3):
+def root_decomposition(matmul_closure, init_vecs, max_iter, tridiagonal_jitter=1e-6):
     """Lanczos root / inverse root, restating RootDecomposition.forward (functions/_root_decomposition.py:49-85):
     Q, T <- Lanczos; T += jitter * min(diag T) * I (:67-70); (lambda, V) <- eigh with the negative-eigenvalue clamp;
     Q <- Q V; root = Q o sqrt(lambda); inverse = Q / sqrt(lambda).
@@ -604,6 +604,20 @@ def root_decomposition(matmul_closure, init_vecs, max_iter, tridiagonal_jitter=1
     if single:
         root, inverse = root[0], inverse[0]
     return root, inverse
+
+
+def diagonalization(matmul_closure, init_vecs, max_iter, tridiagonal_jitter=1e-6):
+    """Partial eigendecomposition A ~= Q diag(lambda) Q^T, restating Diagonalization.forward
+    (functions/_diagonalization.py:30-58): Q, T <- Lanczos; T += jitter_mat where jitter_mat is
+    `diag_embed(jitter * min(diag T))` -- a [...,1,1] tensor -- EXPANDED to T's shape, i.e. the constant is added to
+    EVERY entry of T, not only its diagonal (:48-50; reproduced as written); (lambda, V) <- eigh of that full
+    symmetric matrix with the negative-eigenvalue clamp (lanczos_tridiag_to_diag); Q <- Q V.
+    init_vecs [*B,N,1] -> (evals [*B,k], Q [*B,N,k])."""
+    q_mat, t_mat = lanczos_tridiag(matmul_closure, max_iter, init_vecs)
+    mins = np.diagonal(t_mat, axis1=-2, axis2=-1).min(axis=-1)[..., None, None]
+    jit = np.broadcast_to(t_mat.dtype.type(tridiagonal_jitter) * mins, t_mat.shape)
+    evals, evecs = lanczos_tridiag_to_diag(t_mat + jit)
+    return evals, q_mat @ evecs
 
 
 # ----------------------------------------------------------------------------------

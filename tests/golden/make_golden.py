@@ -495,12 +495,51 @@ def g10_backward_preconditioned():
     save("g10_backward_precond", checksum=cases.checksum(C, d, rhs, Z, sig, Gl), **out)
 
 
+def g11_diagonalization():
+    """SURVEY 8(f) rank 2, second half: Diagonalization.forward through the public `diagonalization(method="lanczos")`.
+    The Function draws its Lanczos start vector with torch.randn (utils/lanczos.py:31-33) and offers no way to pass
+    one, so the draw is replaced by a seeded vector for the duration of the call (stored with the outputs)."""
+    from unittest import mock
+
+    out = {}
+    C, d, _ = cases.lowrank_diag(1201, 2, 384, 8, 1)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+    v0 = cases.randn(1202, 384, 1, dtype=np.float32)
+    tv = cases.randn(1203, 2, 384, 3, dtype=np.float32)
+
+    def fake_randn(*size, dtype=None, device=None, **kw):
+        assert tuple(size) == (384, 1), size
+        return T(v0).to(dtype=dtype, device=device)
+
+    with mock.patch("linear_operator.utils.lanczos.torch.randn", side_effect=fake_randn), \
+            settings.max_root_decomposition_size(20):
+        evals, evecs = A.diagonalization(method="lanczos")
+    Q = evecs.to_dense()
+    out["evals"], out["evecs"] = evals, Q
+    out["recon_tv"] = Q @ (evals.unsqueeze(-1) * (Q.mT @ T(tv)))  # Q diag(lambda) Q^T t  (sign-invariant)
+    # complete diagonalization of a small non-batch dense matrix (any start vector gives the same spectrum)
+    Kd, dd, _ = cases.dense_diag(1204, 1, 40, 1)
+    M = T(Kd[0]) + torch.diag_embed(T(dd[0]))
+    v1 = cases.randn(1205, 40, 1, dtype=np.float32)
+
+    def fake_randn1(*size, dtype=None, device=None, **kw):
+        return T(v1).to(dtype=dtype, device=device)
+
+    with mock.patch("linear_operator.utils.lanczos.torch.randn", side_effect=fake_randn1):
+        e2, q2 = DenseLinearOperator(M).diagonalization(method="lanczos")
+    out["dense_evals"], out["dense_evecs"] = e2, q2.to_dense()
+    out["dense_M"] = M
+    e3, q3 = DenseLinearOperator(M).diagonalization(method="symeig")
+    out["symeig_evals"] = e3
+    save("g11_diagonalization", checksum=cases.checksum(C, d, v0, tv, Kd, dd, v1), v0=v0, v1=v1, **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
-                     ("g9", g9_backward), ("g10", g10_backward_preconditioned)):
+                     ("g9", g9_backward), ("g10", g10_backward_preconditioned), ("g11", g11_diagonalization)):
         if name in todo:
             fn()
     print("done")

@@ -260,6 +260,50 @@ def test_root_decomposition_lanczos_consumers():
     assert np.allclose(host(Rs), host(As.to_dense()), rtol=1e-4, atol=1e-5)
 
 
+def test_diagonalization_lanczos_and_symeig():
+    """SURVEY 8(f) rank 2, second half: `diagonalization(method="lanczos")` = Diagonalization.forward on the device
+    Lanczos (start vector injected where the Function draws it) against golden g11 (sign-invariant quantities) and the
+    oracle; complete 40 x 40 case and the symeig method against the true spectrum."""
+    import linear_operator_amd as lo_pkg
+    from oracle import lo_oracle as orc
+
+    g = load_golden("g11_diagonalization")
+    C, d, _ = cases.lowrank_diag(1201, 2, 384, 8, 1)
+    tv = cases.randn(1203, 2, 384, 3, dtype=np.float32)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C)), DiagLinearOperator(dev(d)))
+
+    def fake_randn(v):
+        def f(*size, dtype=None, device=None, **kw):
+            assert tuple(size) == v.shape
+            return dev(v).to(dtype=dtype)
+        return f
+
+    with mock.patch("linear_operator_amd.utils.lanczos.torch.randn", side_effect=fake_randn(g["v0"])), \
+            settings.max_root_decomposition_size(20):
+        evals, evecs = A.diagonalization(method="lanczos")
+    Q = evecs.to_dense()
+    assert tuple(evals.shape) == g["evals"].shape and tuple(Q.shape) == g["evecs"].shape
+    assert np.allclose(np.sort(host(evals), -1)[..., -8:], np.sort(g["evals"], -1)[..., -8:], rtol=2e-3)
+    recon = host(Q @ (evals.unsqueeze(-1) * (Q.mT @ dev(tv))))
+    assert max_rel_err_cols(recon, g["recon_tv"]) < 5e-3
+    eo, qo = orc.diagonalization(lambda v: orc.matvec_lowrank_diag(C, d, v), np.broadcast_to(g["v0"], (2, 384, 1)).copy(), 20)
+    assert max_rel_err_cols(recon, qo @ (eo[..., None] * (np.swapaxes(qo, -1, -2) @ tv))) < 5e-3
+    # orthonormal columns
+    assert np.abs(host(Q.mT @ Q) - np.eye(20, dtype=np.float32)).max() < 1e-3
+    M = dev(g["dense_M"])
+    with mock.patch("linear_operator_amd.utils.lanczos.torch.randn", side_effect=fake_randn(g["v1"])):
+        e2, q2 = lo_pkg.diagonalization(M, method="lanczos")
+    q2 = q2.to_dense()
+    assert np.allclose(np.sort(host(e2)), np.sort(g["symeig_evals"]), rtol=1e-3, atol=1e-4)
+    assert np.abs(host((q2 * e2) @ q2.mT) - g["dense_M"]).max() < 2e-3 * np.abs(g["dense_M"]).max()
+    e3, q3 = lo_pkg.diagonalization(M)  # N <= max_cholesky_size -> symeig
+    assert np.allclose(host(e3), g["symeig_evals"], rtol=1e-4, atol=1e-5)
+    q3 = q3.to_dense()
+    assert np.abs(host((q3 * e3) @ q3.mT) - g["dense_M"]).max() < 1e-4 * np.abs(g["dense_M"]).max()
+    with pytest.raises(RuntimeError, match="Unknown diagonalization method"):
+        A.diagonalization(method="qr")
+
+
 def test_backward_passes_against_reference_autograd():
     """gradients through Matmul / Solve / InvQuad / InvQuadLogdet on the HIP path (forward solves,
     the extra backward solve and the `_bilinear_derivative` contractions of csrc/lo_bilinear.hip) against the

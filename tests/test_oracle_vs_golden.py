@@ -329,9 +329,35 @@ def test_g8_root_decomposition_forward():
         assert max_rel_err_cols(rrt, g[f"rrt_tv_{name}"]) < 2e-3
         assert max_rel_err_cols(iit, g[f"iit_tv_{name}"]) < 1e-2  # 1/lambda amplifies the noise of the small Ritz values
     # Lanczos property: A q_0 lies in span(q_0, q_1), so R R^T = Q (T + jitter) Q^T reproduces A on the start vector
-    # up to the tridiagonal jitter (1e-3 * min diag T)
+    # up to the tridiagonal jitter (settings.tridiagonal_jitter = 1e-6 times min diag T) and fp32 noise
     root, inv = orc.root_decomposition(mv, v1, 12)
     assert max_rel_err_cols(root @ (np.swapaxes(root, -1, -2) @ v1), mv(v1)) < 5e-3
+
+
+def test_g11_diagonalization_forward():
+    """Diagonalization.forward (20-step Lanczos from the stored start vector, the jitter added to
+    every entry of T as the reference writes it, dense eigh, Q V).  Eigenvector signs are free: compared through the
+    eigenvalues and Q diag(lambda) Q^T t; the complete 40 x 40 case reproduces the spectrum and the matrix."""
+    g = load_golden("g11_diagonalization")
+    C, d, _ = cases.lowrank_diag(1201, 2, 384, 8, 1)
+    v0 = cases.randn(1202, 384, 1, dtype=np.float32)
+    tv = cases.randn(1203, 2, 384, 3, dtype=np.float32)
+    Kd, dd, _ = cases.dense_diag(1204, 1, 40, 1)
+    v1 = cases.randn(1205, 40, 1, dtype=np.float32)
+    assert cases.checksum(C, d, v0, tv, Kd, dd, v1) == g["checksum"]
+    mv = lambda v: orc.matvec_lowrank_diag(C, d, v)  # noqa: E731
+    evals, Q = orc.diagonalization(mv, np.broadcast_to(v0, (2, 384, 1)).copy(), 20)
+    assert evals.shape == g["evals"].shape and Q.shape == g["evecs"].shape
+    # the 8 dominant Ritz values (rank of the root) are converged; the cluster inside the diagonal's range is fp32 noise
+    assert np.allclose(np.sort(evals, -1)[..., -8:], np.sort(g["evals"], -1)[..., -8:], rtol=2e-3)
+    recon = Q @ (evals[..., None] * (np.swapaxes(Q, -1, -2) @ tv))
+    assert max_rel_err_cols(recon, g["recon_tv"]) < 5e-3
+    M = g["dense_M"]
+    e2, q2 = orc.diagonalization(lambda v: M @ v, v1, 100)
+    assert e2.shape == g["dense_evals"].shape == (40,) and q2.shape == (40, 40)
+    assert np.allclose(np.sort(e2), np.sort(g["dense_evals"]), rtol=1e-3, atol=1e-4)
+    assert np.allclose(np.sort(e2), np.sort(g["symeig_evals"]), rtol=1e-3, atol=1e-4)
+    assert np.abs((q2 * e2) @ q2.T - M).max() < 2e-3 * np.abs(M).max()
 
 
 def test_g9_backward_passes():
