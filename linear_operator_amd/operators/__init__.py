@@ -5,13 +5,14 @@ from .dense_linear_operator import DenseLinearOperator, to_linear_operator
 from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
 from .identity_linear_operator import IdentityLinearOperator
 from .kronecker_product_linear_operator import KroneckerProductLinearOperator
+from .kronecker_product_added_diag_linear_operator import KroneckerProductAddedDiagLinearOperator
 from .linear_operator_representation_tree import LinearOperatorRepresentationTree
 from .low_rank_root_added_diag_linear_operator import LowRankRootAddedDiagLinearOperator
 from .root_linear_operator import LowRankRootLinearOperator, RootLinearOperator
 from .sum_linear_operator import PsdSumLinearOperator, SumLinearOperator
 
 __all__ = [
-    "LowRankRootAddedDiagLinearOperator",
+    "LowRankRootAddedDiagLinearOperator", "KroneckerProductAddedDiagLinearOperator",
     "LinearOperator", "to_dense", "to_linear_operator", "AddedDiagLinearOperator", "DenseLinearOperator",
     "DiagLinearOperator", "ConstantDiagLinearOperator", "IdentityLinearOperator", "KroneckerProductLinearOperator",
     "LinearOperatorRepresentationTree", "RootLinearOperator", "LowRankRootLinearOperator", "SumLinearOperator",

@@ -1,14 +1,15 @@
 """KroneckerProductLinearOperator K1 (x) ... (x) KP -- `_matmul`, `_diagonal`, `_get_indices` only
 (reference: operators/kronecker_product_linear_operator.py:20-45, 62-96, 188-216, 272-284).  Two dense factors
-lower to the batched-GEMM kernel pair in csrc/lo_kron.hip; the closed-form eig solves of the reference's
-KroneckerProductAddedDiag subclass (:98-114 routing) are SURVEY 8(f) 'next', so `+ Diag` yields the plain
-AddedDiagLinearOperator, i.e. the CG path."""
+lower to the batched-GEMM kernel pair in csrc/lo_kron.hip.  `+ Diag` / `add_diagonal` build the
+KroneckerProductAddedDiagLinearOperator like the reference (:98-145): eigendecomposition closed forms for a
+constant diagonal, the CG path otherwise (an explicit AddedDiagLinearOperator(kron, diag) is always the CG path)."""
 from __future__ import annotations
 
 import torch
 from torch import Tensor
 
 from .. import kernels as K
+from .. import settings
 from ..utils.broadcasting import _matmul_broadcast_shape
 from ._linear_operator import LinearOperator
 from .dense_linear_operator import DenseLinearOperator, to_linear_operator
@@ -76,6 +77,58 @@ class KroneckerProductLinearOperator(LinearOperator):
         d1 = d1 if tuple(d1.shape) == tuple(k1.shape) else d1.sum_to_size(*k1.shape)
         d2 = d2 if tuple(d2.shape) == tuple(k2.shape) else d2.sum_to_size(*k2.shape)
         return (d1, d2)
+
+    def __add__(self, other):  # reference :98-114
+        from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
+        from .kronecker_product_added_diag_linear_operator import KroneckerProductAddedDiagLinearOperator
+
+        if isinstance(other, ConstantDiagLinearOperator):
+            return KroneckerProductAddedDiagLinearOperator(self, other)
+        if isinstance(other, DiagLinearOperator):
+            return self.add_diagonal(other._diagonal())
+        return super().__add__(other)
+
+    def add_diagonal(self, diag: Tensor):  # reference :116-145
+        from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
+        from .kronecker_product_added_diag_linear_operator import KroneckerProductAddedDiagLinearOperator
+
+        if not self.is_square:
+            raise RuntimeError("add_diag only defined for square matrices")
+        diag_shape = diag.shape
+        if len(diag_shape) == 0:  # scalar tensor = constant diagonal
+            diag_tensor = ConstantDiagLinearOperator(diag.unsqueeze(-1), diag_shape=self.shape[-1])
+        elif diag_shape[-1] == 1:
+            diag_tensor = ConstantDiagLinearOperator(diag, diag_shape=self.shape[-1])
+        else:
+            try:
+                expanded_diag = diag.expand(self.shape[:-1])
+            except RuntimeError:
+                raise RuntimeError(
+                    "add_diag for LinearOperator of size {} received invalid diagonal of size {}.".format(
+                        self.shape, diag_shape
+                    )
+                )
+            diag_tensor = DiagLinearOperator(expanded_diag)
+        return KroneckerProductAddedDiagLinearOperator(self, diag_tensor)
+
+    def diagonalization(self, method=None):  # reference :147-152
+        return super().diagonalization(method="symeig" if method is None else method)
+
+    def _symeig(self, eigenvectors: bool = False, return_evals_as_lazy: bool = False, symeig_dtype_evals: bool = False):
+        """Per-factor eigendecompositions (reference :338-360): evals = Kronecker product of the factors' eigenvalues
+        [*batch, N], evecs = Kronecker product of the factors' eigenvector matrices.  `symeig_dtype_evals` keeps the
+        eigenvalues in `settings._linalg_dtype_symeig` (the closed-form solve shifts and inverts them there, like
+        the reference's fp64 solve, kronecker_product_added_diag_linear_operator.py:147-161)."""
+        evals, evecs = None, []
+        for op in self.linear_ops:
+            dense = op.to_dense()
+            ev, q = torch.linalg.eigh(dense.to(dtype=settings._linalg_dtype_symeig.value()))
+            ev = ev.clamp_min(0.0)
+            if not symeig_dtype_evals:
+                ev = ev.to(dtype=dense.dtype)
+            evals = ev if evals is None else (evals.unsqueeze(-1) * ev.unsqueeze(-2)).reshape(*ev.shape[:-1], -1)
+            evecs.append(DenseLinearOperator(q.to(dtype=dense.dtype)))
+        return evals, (KroneckerProductLinearOperator(*evecs) if eigenvectors else None)
 
     def _diagonal(self) -> Tensor:
         return _kron_diag(*self.linear_ops)

@@ -620,6 +620,39 @@ def diagonalization(matmul_closure, init_vecs, max_iter, tridiagonal_jitter=1e-6
     return evals, q_mat @ evecs
 
 
+def kron_added_diag_eig(K1, K2):
+    """Per-factor eigendecompositions of K1 (x) K2 (kronecker_product_linear_operator.py:338-360, each factor through
+    LinearOperator._symeig :878-901: eigh in fp64, eigenvalues clamped at 0): evals [*B, n1 n2] = l1_i l2_j in the
+    Kronecker order, and the factors' eigenvector matrices."""
+    l1, q1 = np.linalg.eigh(K1.astype(np.float64))
+    l2, q2 = np.linalg.eigh(K2.astype(np.float64))
+    l1, l2 = np.maximum(l1, 0.0), np.maximum(l2, 0.0)
+    evals = (l1[..., :, None] * l2[..., None, :]).reshape(*l1.shape[:-1], -1)
+    return evals, q1, q2
+
+
+def kron_added_diag_solve(K1, K2, sigma2, rhs):
+    """(K1 (x) K2 + sigma2 I)^-1 rhs with a constant diagonal, restating
+    KroneckerProductAddedDiagLinearOperator._solve (kronecker_product_added_diag_linear_operator.py:147-161): in fp64,
+    Q (Q^T rhs / (lambda + sigma2)) with Q = Q1 (x) Q2 applied factor by factor.  sigma2 [*B,1], rhs [*B, n1 n2, c]."""
+    evals, q1, q2 = kron_added_diag_eig(K1, K2)
+    n1, n2, c = K1.shape[-1], K2.shape[-1], rhs.shape[-1]
+
+    def kron_apply(a, b, v):  # (a (x) b) v
+        v4 = v.reshape(*v.shape[:-2], n1, n2, c)
+        return np.einsum("...ij,...ab,...jbc->...iac", a, b, v4).reshape(v.shape)
+
+    t = kron_apply(np.swapaxes(q1, -1, -2), np.swapaxes(q2, -1, -2), rhs.astype(np.float64))
+    t = t / (evals + sigma2.astype(np.float64))[..., None]
+    return kron_apply(q1, q2, t)
+
+
+def kron_added_diag_logdet(K1, K2, sigma2):
+    """logdet(K1 (x) K2 + sigma2 I) = sum log(lambda + sigma2)  (:86-90)."""
+    evals, _, _ = kron_added_diag_eig(K1, K2)
+    return np.log(evals + sigma2.astype(np.float64)).sum(-1)
+
+
 # ----------------------------------------------------------------------------------
 # Backward passes (SURVEY 8(f) rank 1)
 # ----------------------------------------------------------------------------------

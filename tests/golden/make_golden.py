@@ -534,12 +534,47 @@ def g11_diagonalization():
     save("g11_diagonalization", checksum=cases.checksum(C, d, v0, tv, Kd, dd, v1), v0=v0, v1=v1, **out)
 
 
+def g12_kronecker_added_diag():
+    """SURVEY 8(f) rank 3, second half: the operator the reference's default routing builds for
+    `KroneckerProduct + ConstantDiag` / `.add_diagonal(sigma2)`: eigendecomposition closed forms for solve, logdet and
+    inv_quad_logdet, with the gradients the reference's autograd yields (N = 24 * 36 = 864 > max_cholesky_size)."""
+    from linear_operator.operators import KroneckerProductAddedDiagLinearOperator
+
+    K1, K2, _, rhs = cases.kron_factors(1301, 2, 24, 36, 3)
+    sig = np.array([[0.3], [0.05]], dtype=np.float32)
+    W = cases.randn(1302, 2, 864, 3, dtype=np.float32)
+    out = {}
+
+    def leaves():
+        return [T(x).clone().requires_grad_(True) for x in (K1, K2, sig, rhs)]
+
+    k1, k2, st, rt = leaves()
+    A = KroneckerProductLinearOperator(DenseLinearOperator(k1), DenseLinearOperator(k2)) + ConstantDiagLinearOperator(st, 864)
+    assert isinstance(A, KroneckerProductAddedDiagLinearOperator)
+    x = A.solve(rt)
+    (x * T(W)).sum().backward()
+    out["x"], out["x_dK1"], out["x_dK2"], out["x_dsig"], out["x_drhs"] = x, k1.grad, k2.grad, st.grad, rt.grad
+    k1, k2, st, rt = leaves()
+    A = KroneckerProductLinearOperator(DenseLinearOperator(k1), DenseLinearOperator(k2)).add_diagonal(st)
+    assert isinstance(A, KroneckerProductAddedDiagLinearOperator)
+    iq, ld = A.inv_quad_logdet(rt, logdet=True)
+    (iq.sum() + (ld * T(np.array([1.5, -0.5], dtype=np.float32))).sum()).backward()
+    out["iq"], out["ld"] = iq, ld
+    out["iql_dK1"], out["iql_dK2"], out["iql_dsig"], out["iql_drhs"] = k1.grad, k2.grad, st.grad, rt.grad
+    dense = torch.stack([torch.kron(T(K1)[i].double(), T(K2)[i].double()) for i in range(2)])
+    dense = dense + torch.diag_embed(T(sig).double().expand(2, 864))
+    out["x_exact"] = np.linalg.solve(dense.numpy(), rhs.astype(np.float64))
+    out["ld_exact"] = np.linalg.slogdet(dense.numpy())[1]
+    save("g12_kron_added_diag", checksum=cases.checksum(K1, K2, sig, rhs, W), **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
-                     ("g9", g9_backward), ("g10", g10_backward_preconditioned), ("g11", g11_diagonalization)):
+                     ("g9", g9_backward), ("g10", g10_backward_preconditioned), ("g11", g11_diagonalization),
+                     ("g12", g12_kronecker_added_diag)):
         if name in todo:
             fn()
     print("done")

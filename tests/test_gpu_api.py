@@ -304,6 +304,58 @@ def test_diagonalization_lanczos_and_symeig():
         A.diagonalization(method="qr")
 
 
+def test_kronecker_added_diag_eig_closed_forms():
+    """SURVEY 8(f) rank 3, second half: `KroneckerProduct + ConstantDiag` / `.add_diagonal(sigma2)` build the
+    KroneckerProductAddedDiagLinearOperator of the reference's default routing: solve / logdet / inv_quad_logdet from
+    the factors' eigendecompositions (no CG: the Kronecker matvec kernel applies Q and Q^T), values and gradients
+    against golden g12 (the reference's own fp64 closed form and autograd)."""
+    from linear_operator_amd.operators import KroneckerProductAddedDiagLinearOperator
+    from linear_operator_amd import kernels as K
+
+    g = load_golden("g12_kron_added_diag")
+    K1, K2, _, rhs = cases.kron_factors(1301, 2, 24, 36, 3)
+    sig = np.array([[0.3], [0.05]], dtype=np.float32)
+    W = cases.randn(1302, 2, 864, 3, dtype=np.float32)
+
+    def close(a, b, rel):
+        a, b = host(a), np.asarray(b)
+        return a.shape == b.shape and np.abs(a - b).max() <= rel * np.abs(b).max()
+
+    def leaves():
+        return [dev(x).clone().requires_grad_(True) for x in (K1, K2, sig, rhs)]
+
+    k1, k2, st, rt = leaves()
+    A = KroneckerProductLinearOperator(DenseLinearOperator(k1), DenseLinearOperator(k2)) + ConstantDiagLinearOperator(st, 864)
+    assert isinstance(A, KroneckerProductAddedDiagLinearOperator)
+    K._hip.prof_enable(True)
+    x = A.solve(rt)
+    torch.cuda.synchronize()
+    prof = K._hip.prof_report()
+    K._hip.prof_enable(False)
+    assert any(k.startswith("kron") for k in prof) and not any(k.startswith("cg") for k in prof), prof.keys()
+    assert max_rel_err_cols(host(x), g["x_exact"]) < 1e-4 and max_rel_err_cols(host(x), g["x"]) < 1e-4
+    (x * dev(W)).sum().backward()
+    assert close(rt.grad, g["x_drhs"], 1e-3) and close(st.grad, g["x_dsig"], 2e-3)
+    assert close(k1.grad, g["x_dK1"], 2e-3) and close(k2.grad, g["x_dK2"], 2e-3)
+    k1, k2, st, rt = leaves()
+    A = KroneckerProductLinearOperator(DenseLinearOperator(k1), DenseLinearOperator(k2)).add_diagonal(st)
+    assert isinstance(A, KroneckerProductAddedDiagLinearOperator)
+    iq, ld = A.inv_quad_logdet(rt, logdet=True)
+    assert np.allclose(host(iq), g["iq"], rtol=1e-4) and np.allclose(host(ld), g["ld_exact"], rtol=1e-5)
+    (iq.sum() + (ld * dev(np.array([1.5, -0.5], dtype=np.float32))).sum()).backward()
+    assert close(rt.grad, g["iql_drhs"], 1e-3) and close(st.grad, g["iql_dsig"], 2e-3)
+    assert close(k1.grad, g["iql_dK1"], 2e-3) and close(k2.grad, g["iql_dK2"], 2e-3)
+    assert np.allclose(host(A.logdet()), g["ld_exact"], rtol=1e-5)
+    # a non-constant diagonal keeps the reference's CG branch (without a preconditioner, :132-134)
+    dfull = dev(np.broadcast_to(sig, (2, 864)).copy())
+    Ad = KroneckerProductLinearOperator(DenseLinearOperator(dev(K1)), DenseLinearOperator(dev(K2))) + DiagLinearOperator(dfull)
+    assert isinstance(Ad, KroneckerProductAddedDiagLinearOperator) and not Ad._diag_is_constant
+    with settings.cg_tolerance(1e-4), settings.max_cg_iterations(2000), warnings.catch_warnings():
+        warnings.simplefilter("ignore", NumericalWarning)
+        xd = Ad.solve(dev(rhs))
+    assert max_rel_err_cols(host(xd), g["x_exact"]) < 5e-3
+
+
 def test_backward_passes_against_reference_autograd():
     """gradients through Matmul / Solve / InvQuad / InvQuadLogdet on the HIP path (forward solves,
     the extra backward solve and the `_bilinear_derivative` contractions of csrc/lo_bilinear.hip) against the

@@ -360,6 +360,38 @@ def test_g11_diagonalization_forward():
     assert np.abs((q2 * e2) @ q2.T - M).max() < 2e-3 * np.abs(M).max()
 
 
+def test_g12_kronecker_added_diag_closed_forms():
+    """eigendecomposition closed forms of KroneckerProduct + ConstantDiag (solve, logdet,
+    inv_quad) and the gradients the reference's autograd produces for them, restated through the exact inverse."""
+    g = load_golden("g12_kron_added_diag")
+    K1, K2, _, rhs = cases.kron_factors(1301, 2, 24, 36, 3)
+    sig = np.array([[0.3], [0.05]], dtype=np.float32)
+    W = cases.randn(1302, 2, 864, 3, dtype=np.float32)
+    assert cases.checksum(K1, K2, sig, rhs, W) == g["checksum"]
+    x = orc.kron_added_diag_solve(K1, K2, sig, rhs)
+    assert max_rel_err_cols(x, g["x_exact"]) < 1e-9 and max_rel_err_cols(g["x"], x) < 1e-4
+    ld = orc.kron_added_diag_logdet(K1, K2, sig)
+    assert np.allclose(ld, g["ld_exact"], rtol=1e-10) and np.allclose(g["ld"], ld, rtol=1e-5)
+    assert np.allclose(g["iq"], (x * rhs).sum((-2, -1)), rtol=1e-4)
+    # gradients: Solve.backward factors (U, V) contracted against the Kronecker structure, rhs gradient = A^-1 W
+    xg, U, V = orc.solve_backward(lambda r: orc.kron_added_diag_solve(K1, K2, sig, r), x, W.astype(np.float64))
+    assert max_rel_err_cols(g["x_drhs"], xg) < 1e-3
+    dK1, dK2 = orc.bilinear_derivative_kron(K1.astype(np.float64), K2.astype(np.float64), U, V)
+    close = lambda a, b, rel: np.abs(a - b).max() <= rel * np.abs(b).max()  # noqa: E731
+    assert close(g["x_dK1"], dK1, 2e-3) and close(g["x_dK2"], dK2, 2e-3)
+    assert close(g["x_dsig"], orc.bilinear_derivative_diag(U, V, constant=True), 2e-3)
+    # d logdet = tr(A^-1 dA): through the dense inverse of one member
+    w = np.array([1.5, -0.5])
+    for b in range(2):
+        dense = np.kron(K1[b].astype(np.float64), K2[b].astype(np.float64)) + sig[b, 0] * np.eye(864)
+        G = np.linalg.inv(dense)
+        xb = x[b]
+        Gt = (w[b] * G - xb @ xb.T).reshape(24, 36, 24, 36)  # d(iq.sum + w ld) / dA
+        assert close(g["iql_dK1"][b], np.einsum("iajb,ab->ij", Gt, K2[b].astype(np.float64)), 2e-3)
+        assert close(g["iql_dK2"][b], np.einsum("iajb,ij->ab", Gt, K1[b].astype(np.float64)), 2e-3)
+        assert close(g["iql_dsig"][b], np.trace(Gt.reshape(864, 864)), 2e-3)
+
+
 def test_g9_backward_passes():
     """gradients the reference's autograd Functions produce for Matmul / Solve / InvQuad /
     InvQuadLogdet, restated with the oracle's CG and the closed-form `_bilinear_derivative` contractions."""
