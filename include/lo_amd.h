@@ -220,6 +220,37 @@ size_t lo_bilinear_kron_workspace_bytes(int64_t B, int64_t n1, int64_t n2, int64
 int lo_bilinear_kron_f32(const float* K1, const float* K2, const float* U, const float* V, int64_t B, int64_t n1,
                          int64_t n2, int64_t D, float* dK1, float* dK2, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- shifted MINRES: the reference's second iterative solver -------------------------- */
+/* Replaces linear_operator.utils.minres.minres (utils/minres.py:10-207; update block :210-282): solutions of
+ * (value * K + shift_q I) x_q = rhs for all shifts at once, optional preconditioner (Woodbury descriptor or closure).
+ * It is what contour_integral_quad (utils/contour_integral_quad.py:137-144) and sqrt_inv_matmul call.
+ *   rhs [B,N,c]; shifts [n_shifts] or [n_shifts, B] (shifts_per_member); x [n_shifts, B, N, c].
+ * Stop rule (:178-183): every 10th iteration, mean over shifts / members / columns of ||update|| / ||solution|| <
+ * tolerance; the loop body runs at most max_iter + 2 times (:134; max_iter already min'ed with N + 1, :60).        */
+typedef struct lo_minres_params {
+  int64_t c;
+  int32_t n_shifts;
+  int32_t max_iter;
+  int32_t has_value;          /* 0: value = None (:66-68)                                                          */
+  int32_t shifts_per_member;  /* 0: shifts [n_shifts]; 1: shifts [n_shifts, B]                                     */
+  float value;
+  float tolerance;            /* settings.minres_tolerance                                                          */
+  float eps;                  /* 1e-25 (:13)                                                                        */
+  float pad;
+} lo_minres_params;
+
+typedef struct lo_minres_info {
+  int32_t iterations;
+  int32_t matvecs;
+  int32_t converged;
+  float conv;                 /* last evaluated mean relative update norm                                           */
+} lo_minres_info;
+
+size_t lo_minres_workspace_bytes(const lo_op_desc* op, const lo_precond_desc* pre, const lo_minres_params* prm);
+int lo_minres_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user, const lo_precond_desc* pre,
+                  lo_matvec_cb precond_cb, void* precond_user, const lo_minres_params* prm, const float* rhs,
+                  const float* shifts, float* x, void* ws, size_t ws_bytes, lo_minres_info* info, void* stream);
+
 /* ---- measurement aid (no reference counterpart) ------------------------------------------------ */
 /* Opt-in HIP-event timing of every kernel launch of the library, recorded on the launch stream.
  * lo_prof_report writes "name count total_ms" lines into buf (returns the byte count) and resets.

@@ -35,6 +35,7 @@ EXPORTS = [
     "lo_tridiag_eigh_slq_workspace_bytes", "lo_tridiag_eigh_slq_f32",
     "lo_bilinear_dense_f32", "lo_bilinear_diag_f32", "lo_bilinear_root_workspace_bytes", "lo_bilinear_root_f32",
     "lo_bilinear_kron_workspace_bytes", "lo_bilinear_kron_f32",
+    "lo_minres_workspace_bytes", "lo_minres_f32",
     "lo_prof_enable", "lo_prof_report", "lo_hbm_triad_f32",
 ]
 
@@ -63,6 +64,16 @@ class CgInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("matvecs", C.c_int32), ("tolerance_reached", C.c_int32),
                 ("nan_detected", C.c_int32), ("skipped", C.c_int32), ("last_tridiag_iter", C.c_int32),
                 ("mean_residual", C.c_float), ("reserved", C.c_float)]
+
+
+class MinresParams(C.Structure):
+    _fields_ = [("c", C.c_int64), ("n_shifts", C.c_int32), ("max_iter", C.c_int32), ("has_value", C.c_int32),
+                ("shifts_per_member", C.c_int32), ("value", C.c_float), ("tolerance", C.c_float), ("eps", C.c_float),
+                ("pad", C.c_float)]
+
+
+class MinresInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("matvecs", C.c_int32), ("converged", C.c_int32), ("conv", C.c_float)]
 
 
 MATVEC_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p)
@@ -102,6 +113,12 @@ def load():
     lib.lo_cg_solve_f32.argtypes = [P(OpDesc), MATVEC_CB, C.c_void_p, P(PrecondDesc), MATVEC_CB, C.c_void_p,
                                     P(CgParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz,
                                     P(CgInfo), C.c_void_p]
+    lib.lo_minres_workspace_bytes.restype = sz
+    lib.lo_minres_workspace_bytes.argtypes = [P(OpDesc), P(PrecondDesc), P(MinresParams)]
+    lib.lo_minres_f32.restype = C.c_int
+    lib.lo_minres_f32.argtypes = [P(OpDesc), MATVEC_CB, C.c_void_p, P(PrecondDesc), MATVEC_CB, C.c_void_p,
+                                  P(MinresParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, P(MinresInfo),
+                                  C.c_void_p]
     lib.lo_pivoted_cholesky_workspace_bytes.restype = sz
     lib.lo_pivoted_cholesky_workspace_bytes.argtypes = [P(OpDesc), C.c_int32]
     lib.lo_pivoted_cholesky_f32.restype = C.c_int

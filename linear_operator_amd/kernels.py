@@ -162,6 +162,67 @@ def _wrap_closure(fn: Callable, device):
     return _hip.MATVEC_CB(cb), err
 
 
+@dataclass
+class MinresResult:
+    x: torch.Tensor  # [n_shifts, *batch, N, c]
+    iterations: int
+    matvecs: int
+    converged: bool
+    conv: float
+
+
+def minres_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, shifts: torch.Tensor, *,
+                 value: Optional[float] = None, precond: Optional[WoodburyPreconditioner] = None,
+                 matvec_closure: Optional[Callable] = None, precond_closure: Optional[Callable] = None,
+                 closure_batch_shape=None, max_iter: int = 1000, tolerance: float = 1e-4,
+                 eps: float = 1e-25) -> MinresResult:
+    """lo_minres_f32: the reference's shifted MINRES (utils/minres.py:10-207) on the device.
+    rhs [*batch, N, c]; shifts [Q] or [Q, *batch]; returns x [Q, *batch, N, c] (scaled back by the rhs norms)."""
+    lib = _hip.load()
+    _hip.require_hip(rhs, shifts)
+    N, c = rhs.shape[-2:]
+    rhs3 = _flat(rhs, 2)
+    B = rhs3.shape[0]
+    dev = rhs.device
+    Q = shifts.shape[0]
+    per_member = shifts.dim() > 1
+    sh = shifts.to(torch.float32)
+    sh = (sh.expand(Q, *rhs.shape[:-2]).reshape(Q, B) if per_member else sh.reshape(Q)).contiguous()
+    if desc is None:
+        if matvec_closure is None:
+            raise ValueError("need an operator descriptor or a matvec closure")
+        s = _hip.OpDesc()
+        s.kind, s.diag_mode, s.B, s.N, s.R, s.n2 = _hip.LO_OP_CALLBACK, _hip.LO_DIAG_NONE, B, N, 0, 0
+        bshape = tuple(closure_batch_shape) if closure_batch_shape is not None else tuple(rhs.shape[:-2])
+        mv_cb, mv_err = _wrap_closure(lambda v: matvec_closure(v.reshape(*bshape, N, c)), dev)
+    else:
+        if desc.B != B or desc.N != N:
+            raise RuntimeError(f"minres: rhs {tuple(rhs.shape)} does not match operator batch {desc.B}, N {desc.N}")
+        s = desc.c_struct()
+        mv_cb, mv_err = _hip.MATVEC_CB(), []
+    if precond_closure is not None:
+        bshape_p = tuple(closure_batch_shape) if closure_batch_shape is not None else tuple(rhs.shape[:-2])
+        pc_cb, pc_err = _wrap_closure(lambda v: precond_closure(v.reshape(*bshape_p, N, c)), dev)
+    else:
+        pc_cb, pc_err = _hip.MATVEC_CB(), []
+    pre_s = precond.c_struct() if precond is not None else None
+    pre_p = C.byref(pre_s) if pre_s is not None else None
+    prm = _hip.MinresParams()
+    prm.c, prm.n_shifts, prm.max_iter = c, Q, max_iter
+    prm.has_value, prm.value = (0, 1.0) if value is None else (1, float(value))
+    prm.shifts_per_member, prm.tolerance, prm.eps = int(per_member), tolerance, eps
+    ws = _hip.workspace(lib.lo_minres_workspace_bytes(C.byref(s), pre_p, C.byref(prm)), dev)
+    x = torch.empty(Q, *rhs3.shape, dtype=torch.float32, device=dev)
+    info = _hip.MinresInfo()
+    rc = lib.lo_minres_f32(C.byref(s), mv_cb, None, pre_p, pc_cb, None, C.byref(prm), _hip.ptr(rhs3), _hip.ptr(sh),
+                           _hip.ptr(x), _hip.ptr(ws), ws.numel(), C.byref(info), _hip.stream_ptr(dev))
+    for e in (mv_err + pc_err):
+        raise e
+    _hip.check(rc, "lo_minres_f32")
+    return MinresResult(x.reshape(Q, *rhs.shape), info.iterations, info.matvecs, bool(info.converged),
+                        float(info.conv))
+
+
 def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optional[torch.Tensor] = None,
              precond: Optional[WoodburyPreconditioner] = None, matvec_closure: Optional[Callable] = None,
              precond_closure: Optional[Callable] = None, closure_batch_shape=None, n_tridiag: int = 0,

@@ -196,6 +196,24 @@ class memory_efficient(_feature_flag):
     _default = False
 
 
+class minres_tolerance(_value_context):
+    """Relative update-norm tolerance that stops MINRES (settings.py:464-471); default 1e-4."""
+
+    _global_value = 1e-4
+
+
+class num_contour_quadrature(_value_context):
+    """Quadrature points of contour integral quadrature (settings.py:474-481); default 15."""
+
+    _global_value = 15
+
+
+class ciq_samples(_feature_flag):
+    """Draw samples with contour integral quadrature (settings.py:226-241); default off."""
+
+    _default = False
+
+
 class min_preconditioning_size(_value_context):
     """No preconditioner below this N (settings.py:453-461)."""
 
@@ -268,7 +286,8 @@ class verbose_linalg(_feature_flag):
 __all__ = [
     "fast_computations", "linalg_dtypes", "cholesky_jitter", "cholesky_max_tries", "cg_tolerance", "debug", "deterministic_probes",
     "max_cg_iterations", "max_cholesky_size", "max_lanczos_quadrature_iterations", "max_preconditioner_size",
-    "max_root_decomposition_size", "memory_efficient", "min_preconditioning_size", "num_trace_samples",
+    "max_root_decomposition_size", "memory_efficient", "min_preconditioning_size", "minres_tolerance",
+    "num_contour_quadrature", "ciq_samples", "num_trace_samples",
     "preconditioner_tolerance", "skip_logdet_forward", "terminate_cg_by_size", "trace_mode", "tridiagonal_jitter",
     "verbose_linalg",
 ]

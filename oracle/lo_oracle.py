@@ -654,6 +654,107 @@ def kron_added_diag_logdet(K1, K2, sigma2):
 
 
 # ----------------------------------------------------------------------------------
+# MINRES with shifts
+# ----------------------------------------------------------------------------------
+
+
+class MinresInfo:
+    iterations = 0
+    converged = False
+
+
+def minres(matmul_closure, rhs, eps=1e-25, shifts=None, value=None, max_iter=1000, preconditioner=None,
+           tolerance=1e-4):
+    """Restates linear_operator.utils.minres.minres (utils/minres.py:10-207 and the update block :210-282):
+    solutions of (value * K + shift_q I) x = rhs for all shifts at once -- one preconditioned Lanczos recurrence
+    (alpha, beta, z, q) shared by the shifts, one QR (Givens) recurrence and one pair of search vectors per shift.
+    rhs [*B,N,c]; shifts None | [Q] | [Q,*B]; returns ([Q,*B,N,c] or [*B,N,c] when there is one shift, info).
+    Stop: every 10th iteration, mean over everything of ||search update|| / ||solution|| < tolerance (:178-183)."""
+    dt = rhs.dtype
+    info = MinresInfo()
+    if shifts is None:
+        shifts = np.zeros((), dtype=dt)  # :43-44
+    shifts = np.asarray(shifts, dtype=dt)
+    squeeze = rhs.ndim == 1
+    if squeeze:
+        rhs = rhs[..., None]
+    rhs_norm = np.linalg.norm(rhs, axis=-2, keepdims=True).astype(dt)  # :52-55
+    rhs_is_zero = rhs_norm < 1e-10
+    rhs_norm = np.where(rhs_is_zero, dt.type(1), rhs_norm)
+    rhs = rhs / rhs_norm
+    max_iter = min(max_iter, rhs.shape[-2] + 1)  # :60
+    eps = dt.type(eps)
+    val = None if value is None else dt.type(value)
+
+    def mm(v):
+        p = matmul_closure(v).astype(dt)
+        return p if val is None else p * val
+
+    prod = mm(rhs)  # :66-68 (its values are not used: shape only)
+    pad = prod.ndim - shifts.ndim + 1  # _pad_with_singletons(shifts, 0, ...)  :71
+    shifts = shifts.reshape(shifts.shape + (1,) * pad)
+    nq = shifts.shape[0]
+    solution = np.zeros((nq,) + prod.shape, dtype=dt)
+    z2 = np.zeros_like(prod)
+    z1 = np.broadcast_to(rhs, prod.shape).copy()
+    q1 = z1.copy() if preconditioner is None else preconditioner(z1).astype(dt)
+    beta_prev = np.sqrt((z1 * q1).sum(-2, keepdims=True)).astype(dt)  # :80
+    with np.errstate(invalid="ignore", divide="ignore"):  # an all-zero column: 0 / 0 here, masked at the end (:201)
+        z1 = z1 / beta_prev
+        q1 = q1 / beta_prev
+    sc_shape = solution.shape[:-2] + (1, rhs.shape[-1])
+    cos2, sin2 = np.ones(sc_shape, dt), np.zeros(sc_shape, dt)
+    cos1, sin1 = np.ones(sc_shape, dt), np.zeros(sc_shape, dt)
+    s2 = np.zeros_like(solution)
+    s1 = np.zeros_like(solution)
+    scale_prev = np.broadcast_to(beta_prev, sc_shape).copy()  # :113
+    for i in range(max_iter + 2):  # :134
+        prod = mm(q1)
+        alpha = (prod * q1).sum(-2, keepdims=True).astype(dt)  # :141-142
+        zc = prod - alpha * z1 - beta_prev * z2  # :144
+        qc = zc.copy() if preconditioner is None else preconditioner(zc).astype(dt)
+        beta = np.maximum(np.sqrt((zc * qc).sum(-2, keepdims=True)), eps).astype(dt)  # :147-150
+        zc = zc / beta
+        qc = qc / beta
+        # ---- QR / solution update for every shift (:236-282)
+        subsub = sin2 * beta_prev
+        sub = cos2 * beta_prev
+        alpha_s = alpha + shifts
+        diag = alpha_s * cos1 - sin1 * sub
+        sub = sub * cos1 + sin1 * alpha_s
+        radius = np.sqrt(diag * diag + beta * beta)
+        cosc = diag / radius
+        sinc = beta / radius
+        diag = diag * cosc + sinc * beta
+        scale_curr = -(scale_prev * sinc)
+        scale_prev = scale_prev * cosc
+        sc = (q1 - sub * s1 - subsub * s2) / diag
+        upd = sc * scale_prev
+        solution = solution + upd
+        info.iterations = i + 1
+        if (i + 1) % 10 == 0:  # :178-183
+            with np.errstate(invalid="ignore", divide="ignore"):
+                conv = (np.linalg.norm(upd, axis=-2) / np.linalg.norm(solution, axis=-2)).mean()
+            if conv < tolerance:
+                info.converged = True
+                break
+        z2, z1 = z1, zc  # :186-198
+        q1 = qc
+        beta_prev = beta
+        cos2, cos1 = cos1, cosc
+        sin2, sin1 = sin1, sinc
+        s2, s1 = s1, sc
+        scale_prev = scale_curr
+    solution = np.where(rhs_is_zero, dt.type(0), solution)  # :201
+    if squeeze:
+        solution = solution[..., 0]
+        rhs_norm = rhs_norm[..., 0]
+    if shifts.size == 1:
+        solution = solution[0]  # :208-210
+    return solution * rhs_norm, info
+
+
+# ----------------------------------------------------------------------------------
 # Backward passes (SURVEY 8(f) rank 1)
 # ----------------------------------------------------------------------------------
 

@@ -568,13 +568,40 @@ def g12_kronecker_added_diag():
     save("g12_kron_added_diag", checksum=cases.checksum(K1, K2, sig, rhs, W), **out)
 
 
+def g13_minres():
+    """linear_operator.utils.minres.minres -- several shifts at once, the (value = -1, per-member
+    shifts) form contour_integral_quad calls it with, a vector right-hand side without shifts, the Woodbury
+    preconditioner closure of AddedDiagLinearOperator, and an all-zero column."""
+    from linear_operator.utils.minres import minres
+
+    C, d, rhs = cases.lowrank_diag(1401, 2, 300, 8, 3)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+    mm = lambda v: A._matmul(v)  # noqa: E731
+    sh = np.array([0.0, 0.5, 3.0], dtype=np.float32)
+    sh2 = -np.array([[0.0, 0.0], [0.3, 0.2], [2.0, 5.0]], dtype=np.float32)
+    out = {"sh": sh, "sh2": sh2}
+    out["x_shifts"] = minres(mm, T(rhs), shifts=T(sh), max_iter=200)
+    out["x_ciq"] = minres(mm, T(rhs), shifts=T(sh2), value=-1, max_iter=200)
+    A0 = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C[0])), DiagLinearOperator(T(d[0])))
+    out["x_vec"] = minres(lambda v: A0._matmul(v), T(rhs[0, :, 0]), max_iter=200)  # 1-D rhs, non-batch operator
+    rz = rhs.copy()
+    rz[1, :, 2] = 0.0
+    out["x_zero_col"] = minres(mm, T(rz), shifts=T(sh[:2]), max_iter=30)
+    with settings.min_preconditioning_size(0), settings.max_preconditioner_size(4):
+        pre, _, _ = A._preconditioner()
+        out["x_precond"] = minres(mm, T(rhs), shifts=T(sh), max_iter=200, preconditioner=pre)
+    A64 = (T(C) @ T(C).mT + torch.diag_embed(T(d))).double().numpy()
+    out["x_exact"] = np.stack([np.linalg.solve(A64 + s * np.eye(300), rhs.astype(np.float64)) for s in sh])
+    save("g13_minres", checksum=cases.checksum(C, d, rhs), **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
                      ("g9", g9_backward), ("g10", g10_backward_preconditioned), ("g11", g11_diagonalization),
-                     ("g12", g12_kronecker_added_diag)):
+                     ("g12", g12_kronecker_added_diag), ("g13", g13_minres)):
         if name in todo:
             fn()
     print("done")

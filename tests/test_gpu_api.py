@@ -536,3 +536,56 @@ def test_preconditioner_memo_hits_and_invalidates():
     A3 = C.astype(np.float64) @ np.swapaxes(C.astype(np.float64), -1, -2) + np.stack([np.diag(2.0 * v) for v in d.astype(np.float64)])
     assert max_rel_err_cols(host(x3), np.linalg.solve(A3, rhs.astype(np.float64))) < 1e-4
     assert len(adl._precond_memo) <= adl.PRECONDITIONER_MEMO_SIZE
+
+
+def test_minres_with_shifts_against_reference_and_oracle():
+    """utils.minres (csrc/lo_minres.hip) -- several shifts, the (value = -1, per-member shifts) form
+    of contour_integral_quad, a vector rhs, an all-zero column, the Woodbury preconditioner closure and an opaque
+    Python closure -- against golden g13 (the reference), the oracle and the exact fp64 solves.  fp32 recurrences
+    stopped at a 1e-4 relative update norm agree to a few 1e-4 (see tests/test_oracle_vs_golden.py)."""
+    from linear_operator_amd.utils import minres
+    from oracle import lo_oracle as orc
+
+    g = load_golden("g13_minres")
+    C, d, rhs = cases.lowrank_diag(1401, 2, 300, 8, 3)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C)), DiagLinearOperator(dev(d)))
+    sh, sh2 = dev(g["sh"]), dev(g["sh2"])
+    x = minres(A._matmul, dev(rhs), shifts=sh, max_iter=200)
+    assert tuple(x.shape) == (3, 2, 300, 3)
+    for q in range(3):
+        assert max_rel_err_cols(host(x[q]), g["x_shifts"][q]) < 5e-4
+        assert max_rel_err_cols(host(x[q]), g["x_exact"][q]) < 5e-4
+    xo, info = orc.minres(lambda v: orc.matvec_lowrank_diag(C, d, v), rhs, shifts=g["sh"], max_iter=200)
+    assert max_rel_err_cols(host(x).reshape(6, 300, 3), xo.reshape(6, 300, 3)) < 5e-4
+    x2 = minres(A._matmul, dev(rhs), shifts=sh2, value=-1, max_iter=200)
+    for q in range(3):
+        assert max_rel_err_cols(host(x2[q]), g["x_ciq"][q]) < 5e-4
+    A0 = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C[0])), DiagLinearOperator(dev(d[0])))
+    x3 = minres(A0._matmul, dev(rhs[0, :, 0]), max_iter=200)
+    assert tuple(x3.shape) == (300,) and np.abs(host(x3) - g["x_vec"]).max() < 5e-4 * np.abs(g["x_vec"]).max()
+    rz = rhs.copy()
+    rz[1, :, 2] = 0.0
+    x4 = host(minres(A._matmul, dev(rz), shifts=sh[:2], max_iter=30))
+    assert np.all(x4[:, 1, :, 2] == 0)
+    keep = np.ones((2, 3), bool)
+    keep[1, 2] = False
+    for q in range(2):
+        e = np.linalg.norm(x4[q] - g["x_zero_col"][q], axis=-2) / np.maximum(np.linalg.norm(g["x_zero_col"][q], axis=-2), 1e-30)
+        assert e[keep].max() < 5e-4
+    with settings.min_preconditioning_size(0), settings.max_preconditioner_size(4):
+        pre, _, _ = A._preconditioner()
+        x5 = minres(A._matmul, dev(rhs), shifts=sh, max_iter=200, preconditioner=pre)
+    for q in range(3):
+        assert max_rel_err_cols(host(x5[q]), g["x_precond"][q]) < 1e-3
+    # opaque closures for the product and the preconditioner (called back once per iteration)
+    dense = A.to_dense()
+    x6 = minres(lambda v: dense @ v, dev(rhs), shifts=sh, max_iter=200, preconditioner=lambda v: v / dev(d).unsqueeze(-1))
+    # (with a preconditioner P the shift enters the preconditioned recurrence: the systems solved are K + sigma P --
+    # same in the reference; only sigma = 0 is comparable with the plain exact solve)
+    assert max_rel_err_cols(host(x6[0]), g["x_exact"][0]) < 1e-3
+    xo6, _ = orc.minres(lambda v: orc.matvec_lowrank_diag(C, d, v), rhs, shifts=g["sh"], max_iter=200,
+                        preconditioner=lambda v: v / d[..., None])
+    assert max_rel_err_cols(host(x6).reshape(6, 300, 3), xo6.reshape(6, 300, 3)) < 1e-3
+    # a dense tensor as the "closure" (reference :36-37)
+    x7 = minres(dense, dev(rhs), shifts=sh, max_iter=200)
+    assert max_rel_err_cols(host(x7).reshape(6, 300, 3), g["x_exact"].reshape(6, 300, 3)) < 5e-4

@@ -392,6 +392,42 @@ def test_g12_kronecker_added_diag_closed_forms():
         assert close(g["iql_dsig"][b], np.trace(Gt.reshape(864, 864)), 2e-3)
 
 
+def test_g13_minres_with_shifts():
+    """shifted MINRES.  The recurrences run in fp32 and stop on a 1e-4 relative update norm, so two
+    correct implementations agree to a few 1e-4 of the solution norm (the reference itself is 7e-5 from the exact
+    solve here); both are also held against the exact fp64 solves."""
+    g = load_golden("g13_minres")
+    C, d, rhs = cases.lowrank_diag(1401, 2, 300, 8, 3)
+    assert cases.checksum(C, d, rhs) == g["checksum"]
+    mv = lambda v: orc.matvec_lowrank_diag(C, d, v)  # noqa: E731
+    x, info = orc.minres(mv, rhs, shifts=g["sh"], max_iter=200)
+    assert x.shape == g["x_shifts"].shape == (3, 2, 300, 3) and info.converged and info.iterations % 10 == 0
+    for q in range(3):
+        assert max_rel_err_cols(x[q], g["x_shifts"][q]) < 5e-4
+        assert max_rel_err_cols(x[q], g["x_exact"][q]) < 5e-4 and max_rel_err_cols(g["x_shifts"][q], g["x_exact"][q]) < 5e-4
+    x2, _ = orc.minres(mv, rhs, shifts=g["sh2"], value=-1, max_iter=200)
+    assert x2.shape == g["x_ciq"].shape
+    for q in range(3):
+        assert max_rel_err_cols(x2[q], g["x_ciq"][q]) < 5e-4
+    x3, _ = orc.minres(lambda v: orc.matvec_lowrank_diag(C[0], d[0], v), rhs[0, :, 0], max_iter=200)
+    assert x3.shape == g["x_vec"].shape == (300,)
+    assert np.abs(x3 - g["x_vec"]).max() < 5e-4 * np.abs(g["x_vec"]).max()
+    rz = rhs.copy()
+    rz[1, :, 2] = 0.0
+    x4, info4 = orc.minres(mv, rz, shifts=g["sh"][:2], max_iter=30)
+    assert info4.iterations == 32 and not info4.converged  # 0/0 in the stop test: the loop runs out (max_iter + 2)
+    assert np.all(x4[:, 1, :, 2] == 0) and np.all(g["x_zero_col"][:, 1, :, 2] == 0)
+    keep = np.ones((2, 3), bool)
+    keep[1, 2] = False
+    for q in range(2):
+        e = np.linalg.norm(x4[q] - g["x_zero_col"][q], axis=-2) / np.maximum(np.linalg.norm(g["x_zero_col"][q], axis=-2), 1e-30)
+        assert e[keep].max() < 5e-4
+    pre = orc.Preconditioner(orc.pivoted_cholesky(orc.LowRankRowSource(C), 4)[0], d)
+    x5, _ = orc.minres(mv, rhs, shifts=g["sh"], max_iter=200, preconditioner=pre.apply)
+    for q in range(3):
+        assert max_rel_err_cols(x5[q], g["x_precond"][q]) < 1e-3
+
+
 def test_g9_backward_passes():
     """gradients the reference's autograd Functions produce for Matmul / Solve / InvQuad /
     InvQuadLogdet, restated with the oracle's CG and the closed-form `_bilinear_derivative` contractions."""
