@@ -7,7 +7,7 @@ CPU fallback for the iterative path.  See DESIGN.md / INTEGRATION.md.
 """
 from . import operators, settings, utils
 from .functions import (add_diagonal, add_jitter, diagonal, diagonalization, inv_quad, inv_quad_logdet, logdet, matmul,
-                        pivoted_cholesky, solve)
+                        pivoted_cholesky, solve, sqrt_inv_matmul)
 from .operators import LinearOperator, to_dense, to_linear_operator
 
 __version__ = "0.1.0"
@@ -15,5 +15,5 @@ __version__ = "0.1.0"
 __all__ = [
     "LinearOperator", "to_dense", "to_linear_operator", "operators", "settings", "utils",
     "add_diagonal", "add_jitter", "diagonal", "diagonalization", "inv_quad", "inv_quad_logdet", "logdet", "matmul", "pivoted_cholesky",
-    "solve",
+    "solve", "sqrt_inv_matmul",
 ]

@@ -46,9 +46,13 @@ def pivoted_cholesky(input, rank: int, error_tol=None, return_pivots: bool = Fal
     return _op(input).pivoted_cholesky(rank=rank, error_tol=error_tol, return_pivots=return_pivots)
 
 
+def sqrt_inv_matmul(input, rhs, lhs=None):
+    return _op(input).sqrt_inv_matmul(rhs, lhs)
+
+
 def solve(input, rhs, lhs=None):
     return _op(input).solve(right_tensor=rhs, left_tensor=lhs)
 
 
 __all__ = ["add_diagonal", "add_jitter", "diagonal", "diagonalization", "inv_quad", "inv_quad_logdet", "logdet", "matmul",
-           "pivoted_cholesky", "solve"]
+           "pivoted_cholesky", "solve", "sqrt_inv_matmul"]

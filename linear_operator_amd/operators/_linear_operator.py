@@ -487,6 +487,19 @@ class LinearOperator(object):
             self._root_decomposition_cache = roots
         return inv_roots
 
+    def sqrt_inv_matmul(self, rhs: Tensor, lhs: Optional[Tensor] = None):
+        """A^{-1/2} rhs, or (lhs A^{-1/2} rhs, diag(lhs A^-1 lhs^T)) when `lhs` is given, by contour integral
+        quadrature over shifted MINRES solves (reference :2422-2466, functions/_sqrt_inv_matmul.py)."""
+        from ..functions._sqrt_inv_matmul import SqrtInvMatmul
+
+        squeeze = rhs.dim() == 1
+        if squeeze:
+            rhs = rhs.unsqueeze(-1)
+        res, inv_quad_res = SqrtInvMatmul.apply(self.representation_tree(), rhs, lhs, *self.representation())
+        if squeeze:
+            res = res.squeeze(-1)
+        return res if lhs is None else (res, inv_quad_res)
+
     def _symeig(self, eigenvectors: bool = False, return_evals_as_lazy: bool = False):
         """Dense symmetric eigendecomposition in `settings._linalg_dtype_symeig` (ATen plumbing; reference :878-901)."""
         from .dense_linear_operator import DenseLinearOperator

@@ -20,6 +20,8 @@ HIP kernels use exactly the same order, so pivots and L agree bit for bit.
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 # ----------------------------------------------------------------------------------
@@ -752,6 +754,65 @@ def minres(matmul_closure, rhs, eps=1e-25, shifts=None, value=None, max_iter=100
     if shifts.size == 1:
         solution = solution[0]  # :208-210
     return solution * rhs_norm, info
+
+
+def contour_integral_quad(matmul_closure, rhs, inverse=False, num_contour_quadrature=15, max_lanczos_iter=20,
+                          shift_offset=0.0, minres_tolerance=1e-4, max_iter=1000):
+    """Restates contour_integral_quad without a preconditioner (utils/contour_integral_quad.py:14-156):
+    spectrum ends from the tridiagonal of a 20-step CG run on the first column (:56-96), quadrature nodes and weights
+    from the Jacobi elliptic functions (:100-126, scipy), all shifted solves by one MINRES call with value = -1
+    (:137-144), one more product with K unless `inverse` (:147-148).
+    rhs [*B,N,c] -> (solves [Q,*B,N,c], weights [Q,*B,1,1], no_shift_solves, shifts [Q+1,*B])."""
+    from scipy.special import ellipj, ellipk
+
+    dt = rhs.dtype
+    init = np.ascontiguousarray(rhs[..., :1])
+    _, t_mat, _ = linear_cg(matmul_closure, init, n_tridiag=1, max_iter=max_lanczos_iter, tolerance=1e-5,
+                            max_tridiag_iter=max_lanczos_iter)
+    t_mat = t_mat[0]  # squeeze(0): one tridiagonal column
+    eigs = np.linalg.eigvalsh(t_mat)
+    if eigs.min() <= 0:
+        raise RuntimeError("oracle: the diagonal fallback of :95-96 is not restated")
+    max_eig, min_eig = eigs.max(-1), eigs.min(-1)
+    k2 = min_eig / max_eig
+    nq = num_contour_quadrature
+    flat_shifts = np.zeros((nq + 1, k2.size), dtype=dt)
+    flat_weights = np.zeros((nq, k2.size), dtype=dt)
+    for i, (sub_k2, sub_min) in enumerate(zip(k2.reshape(-1).tolist(), min_eig.reshape(-1).tolist())):
+        Kp = ellipk(1 - sub_k2)
+        t = 1j * (np.arange(1, nq + 1) - 0.5) * Kp / nq
+        sn, cn, dn, _ = ellipj(np.imag(t), 1 - sub_k2)
+        cn = 1.0 / cn
+        dn = dn * cn
+        sn = 1j * sn * cn
+        w = np.sqrt(sub_min) * sn
+        flat_shifts[1:, i] = np.real(np.power(w, 2)).astype(dt)
+        constant = -2 * Kp * np.sqrt(sub_min) / (math.pi * nq)
+        flat_weights[:, i] = (cn * dn).astype(dt) * dt.type(constant)
+    weights = flat_weights.reshape((nq,) + k2.shape + (1, 1))
+    shifts = flat_shifts.reshape((nq + 1,) + k2.shape) - dt.type(shift_offset)
+    solves, _ = minres(matmul_closure, rhs, shifts=shifts, value=-1, max_iter=max_iter, tolerance=minres_tolerance)
+    no_shift = solves[0]
+    solves = solves[1:]
+    if not inverse:
+        solves = np.stack([matmul_closure(sv) for sv in solves])
+    return solves, weights, no_shift, shifts
+
+
+def sqrt_inv_matmul(matmul_closure, rhs, lhs=None, num_contour_quadrature=15):
+    """SqrtInvMatmul.forward (functions/_sqrt_inv_matmul.py:18-51): A^{-1/2} rhs, or (lhs A^{-1/2} rhs,
+    -sum(lhs o no_shift_solves^T)) = (..., diag(lhs A^-1 lhs^T)) when lhs is given (the no-shift solve has value -1)."""
+    if lhs is None:
+        solves, weights, _, _ = contour_integral_quad(matmul_closure, rhs, inverse=True,
+                                                       num_contour_quadrature=num_contour_quadrature)
+        return (solves * weights).sum(0)
+    terms = np.concatenate([rhs, np.swapaxes(lhs, -1, -2)], axis=-1)
+    solves, weights, no_shift, _ = contour_integral_quad(matmul_closure, terms, inverse=True,
+                                                          num_contour_quadrature=num_contour_quadrature)
+    c = rhs.shape[-1]
+    res = lhs @ (solves[..., :c] * weights).sum(0)
+    inv_quad = -(np.swapaxes(no_shift[..., c:], -1, -2) * lhs).sum(-1)
+    return res, inv_quad
 
 
 # ----------------------------------------------------------------------------------

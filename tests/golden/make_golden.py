@@ -595,13 +595,45 @@ def g13_minres():
     save("g13_minres", checksum=cases.checksum(C, d, rhs), **out)
 
 
+def g14_sqrt_inv_matmul():
+    """contour integral quadrature -- LinearOperator.sqrt_inv_matmul (A^{-1/2} R and
+    L A^{-1/2} R with the inverse quadratic form of L) forward and backward, N = 300 (no preconditioner below
+    settings.min_preconditioning_size), 15 quadrature points."""
+    C, d, rhs = cases.lowrank_diag(1501, 2, 300, 8, 3)
+    lhs = cases.randn(1502, 2, 4, 300, dtype=np.float32)
+    W = cases.randn(1503, 2, 300, 3, dtype=np.float32)
+    W2 = cases.randn(1504, 2, 4, 3, dtype=np.float32)
+    out = {}
+    Ct, dt, rt = [T(x).clone().requires_grad_(True) for x in (C, d, rhs)]
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+    res = A.sqrt_inv_matmul(rt)
+    (res * T(W)).sum().backward()
+    out["res"], out["dC"], out["dd"], out["drhs"] = res, Ct.grad, dt.grad, rt.grad
+    Ct, dt, rt, lt = [T(x).clone().requires_grad_(True) for x in (C, d, rhs, lhs)]
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+    res2, iq = A.sqrt_inv_matmul(rt, lt)
+    ((res2 * T(W2)).sum() + (iq * T(np.array([[1.0, -0.5, 2.0, 0.3]], dtype=np.float32))).sum()).backward()
+    out["l_res"], out["l_iq"] = res2, iq
+    out["l_dC"], out["l_dd"], out["l_drhs"], out["l_dlhs"] = Ct.grad, dt.grad, rt.grad, lt.grad
+    solves, weights, no_shift, shifts = linear_operator.utils.contour_integral_quad(
+        AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d))), T(rhs), inverse=False)
+    out["sqrt_res"] = (solves * weights).sum(0)  # A^{1/2} rhs
+    out["shifts"], out["weights"] = shifts, weights
+    A64 = (T(C) @ T(C).mT + torch.diag_embed(T(d))).double().numpy()
+    ev, Q = np.linalg.eigh(A64)
+    out["exact_inv_sqrt"] = (Q / np.sqrt(ev)[..., None, :]) @ np.swapaxes(Q, -1, -2) @ rhs.astype(np.float64)
+    out["exact_sqrt"] = (Q * np.sqrt(ev)[..., None, :]) @ np.swapaxes(Q, -1, -2) @ rhs.astype(np.float64)
+    save("g14_sqrt_inv_matmul", checksum=cases.checksum(C, d, rhs, lhs, W, W2), **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
                      ("g9", g9_backward), ("g10", g10_backward_preconditioned), ("g11", g11_diagonalization),
-                     ("g12", g12_kronecker_added_diag), ("g13", g13_minres)):
+                     ("g12", g12_kronecker_added_diag), ("g13", g13_minres),
+                     ("g14", g14_sqrt_inv_matmul)):
         if name in todo:
             fn()
     print("done")

@@ -589,3 +589,46 @@ def test_minres_with_shifts_against_reference_and_oracle():
     # a dense tensor as the "closure" (reference :36-37)
     x7 = minres(dense, dev(rhs), shifts=sh, max_iter=200)
     assert max_rel_err_cols(host(x7).reshape(6, 300, 3), g["x_exact"].reshape(6, 300, 3)) < 5e-4
+
+
+def test_sqrt_inv_matmul_contour_integral_quadrature():
+    """LinearOperator.sqrt_inv_matmul = contour integral quadrature over ONE shifted-MINRES run on
+    the device: A^{-1/2} R, L A^{-1/2} R with the inverse quadratic form, A^{1/2} R through contour_integral_quad, and
+    the backward pass -- against golden g14 (reference values and autograd gradients) and the exact matrix functions."""
+    from linear_operator_amd.utils import contour_integral_quad
+
+    g = load_golden("g14_sqrt_inv_matmul")
+    C, d, rhs = cases.lowrank_diag(1501, 2, 300, 8, 3)
+    lhs = cases.randn(1502, 2, 4, 300, dtype=np.float32)
+    W = cases.randn(1503, 2, 300, 3, dtype=np.float32)
+    W2 = cases.randn(1504, 2, 4, 3, dtype=np.float32)
+
+    def close(a, b, rel):
+        a, b = host(a), np.asarray(b)
+        return a.shape == b.shape and np.abs(a - b).max() <= rel * np.abs(b).max()
+
+    Ct, dt, rt = [dev(x).clone().requires_grad_(True) for x in (C, d, rhs)]
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+    res = A.sqrt_inv_matmul(rt)
+    assert max_rel_err_cols(host(res), g["exact_inv_sqrt"]) < 5e-4 and max_rel_err_cols(host(res), g["res"]) < 5e-4
+    (res * dev(W)).sum().backward()
+    assert close(rt.grad, g["drhs"], 2e-3) and close(dt.grad, g["dd"], 5e-3) and close(Ct.grad, g["dC"], 5e-3)
+    Ct, dt, rt, lt = [dev(x).clone().requires_grad_(True) for x in (C, d, rhs, lhs)]
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+    res2, iq = A.sqrt_inv_matmul(rt, lt)
+    assert close(res2, g["l_res"], 1e-3) and np.allclose(host(iq), g["l_iq"], rtol=1e-3)
+    ((res2 * dev(W2)).sum() + (iq * dev(np.array([[1.0, -0.5, 2.0, 0.3]], dtype=np.float32))).sum()).backward()
+    assert close(rt.grad, g["l_drhs"], 2e-3) and close(lt.grad, g["l_dlhs"], 2e-3)
+    assert close(dt.grad, g["l_dd"], 5e-3) and close(Ct.grad, g["l_dC"], 5e-3)
+    with torch.no_grad():
+        A0 = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C)), DiagLinearOperator(dev(d)))
+        solves, weights, _, shifts = contour_integral_quad(A0, dev(rhs), inverse=False)
+    assert tuple(shifts.shape) == g["shifts"].shape and tuple(weights.shape) == g["weights"].shape
+    assert np.allclose(host(shifts), g["shifts"], rtol=5e-2)
+    sq = host((solves * weights).sum(0))
+    assert max_rel_err_cols(sq, g["exact_sqrt"]) < 2e-4
+    # vector right-hand side, non-batch operator, functional form
+    A1 = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C[0])), DiagLinearOperator(dev(d[0])))
+    v = lo.sqrt_inv_matmul(A1, dev(rhs[0, :, 0]))
+    assert tuple(v.shape) == (300,)
+    assert np.abs(host(v) - g["exact_inv_sqrt"][0, :, 0]).max() < 5e-4 * np.abs(g["exact_inv_sqrt"][0, :, 0]).max()
