@@ -54,21 +54,23 @@ def contour_integral_quad(linear_op, rhs, inverse=False, weights=None, shifts=No
         min_eig = approx_eigs.min(dim=-1)[0]
         k2 = min_eig / max_eig
 
-        flat_shifts = torch.zeros(num_contour_quadrature + 1, k2.numel(), dtype=k2.dtype, device=k2.device)
-        flat_weights = torch.zeros(num_contour_quadrature, k2.numel(), dtype=k2.dtype, device=k2.device)
+        # nodes and weights for every batch member at once (the reference loops over the members, :103-126; the
+        # scipy functions are ufuncs, so the same double-precision values come out of one vectorised call)
         n_q = num_contour_quadrature
-        for i, (sub_k2, sub_min_eig) in enumerate(zip(k2.flatten().tolist(), min_eig.flatten().tolist())):
-            Kp = ellipk(1 - sub_k2)  # complete elliptic integral of the first kind (:106)
-            t = 1j * (np.arange(1, n_q + 1) - 0.5) * Kp / n_q
-            sn, cn, dn, _ = ellipj(np.imag(t), 1 - sub_k2)  # Jacobi elliptic functions (:109)
-            cn = 1.0 / cn
-            dn = dn * cn
-            sn = 1j * sn * cn
-            w = np.sqrt(sub_min_eig) * sn
-            w_pow2 = np.real(np.power(w, 2))
-            constant = -2 * Kp * np.sqrt(sub_min_eig) / (math.pi * n_q)  # :118
-            flat_shifts[1:, i].copy_(torch.tensor(w_pow2, dtype=rhs.dtype, device=rhs.device))
-            flat_weights[:, i].copy_(torch.tensor(cn * dn, dtype=rhs.dtype, device=rhs.device).mul_(constant))
+        k2_h = k2.flatten().double().cpu().numpy()
+        min_h = min_eig.flatten().double().cpu().numpy()
+        Kp = ellipk(1 - k2_h)  # complete elliptic integral of the first kind (:106)
+        u = (np.arange(1, n_q + 1) - 0.5)[:, None] * Kp[None, :] / n_q  # imag(t), t = 1j (j - 1/2) K' / N
+        sn, cn, dn, _ = ellipj(u, (1 - k2_h)[None, :])  # Jacobi elliptic functions (:109)
+        cn = 1.0 / cn
+        dn = dn * cn
+        sn = 1j * sn * cn
+        w = np.sqrt(min_h)[None, :] * sn
+        w_pow2 = np.real(np.power(w, 2))
+        constant = -2 * Kp * np.sqrt(min_h) / (math.pi * n_q)  # :118
+        flat_shifts = torch.zeros(n_q + 1, k2.numel(), dtype=k2.dtype, device=k2.device)
+        flat_shifts[1:] = torch.as_tensor(w_pow2, dtype=rhs.dtype).to(rhs.device)
+        flat_weights = (torch.as_tensor(cn * dn, dtype=rhs.dtype) * torch.as_tensor(constant, dtype=rhs.dtype)).to(rhs.device)
         weights = flat_weights.view(n_q, *k2.shape, 1, 1)
         shifts = flat_shifts.view(n_q + 1, *k2.shape)
         shifts.sub_(shift_offset)
