@@ -601,7 +601,17 @@ class LinearOperator(object):
             return RootLinearOperator(inv_root)
         raise RuntimeError(f"Unknown root inv decomposition method '{method}'")
 
-    def zero_mean_mvn_samples(self, num_samples: int) -> Tensor:  # reference :2746-2793 (root-based branch)
+    def zero_mean_mvn_samples(self, num_samples: int) -> Tensor:  # reference :2746-2793
+        if settings.ciq_samples.on():  # A^{1/2} z by contour integral quadrature (:2759-2776)
+            from ..utils.contour_integral_quad import contour_integral_quad
+
+            # (the samples ride in the column dimension of one shifted-MINRES run; the reference stacks them in a
+            # leading batch dimension, which gives the same independent solves)
+            base_samples = torch.randn(*self.batch_shape, self.size(-1), num_samples, dtype=self.dtype,
+                                       device=self.device)
+            solves, weights, _, _ = contour_integral_quad(
+                self, base_samples, inverse=False, num_contour_quadrature=settings.num_contour_quadrature.value())
+            return (solves * weights).sum(0).permute(-1, *range(self.dim() - 1)).contiguous()
         if self.size()[-2:] == torch.Size([1, 1]):
             covar_root = self.to_dense().sqrt()
         else:

@@ -627,6 +627,16 @@ def test_sqrt_inv_matmul_contour_integral_quadrature():
     assert np.allclose(host(shifts), g["shifts"], rtol=5e-2)
     sq = host((solves * weights).sum(0))
     assert max_rel_err_cols(sq, g["exact_sqrt"]) < 2e-4
+    # settings.ciq_samples: zero_mean_mvn_samples = A^{1/2} z with the base samples drawn by torch.randn
+    z = cases.randn(1505, 2, 300, 5, dtype=np.float32)
+    with settings.ciq_samples(True), mock.patch("linear_operator_amd.operators._linear_operator.torch.randn",
+                                                side_effect=lambda *a, **k: dev(z)):
+        smp = A0.zero_mean_mvn_samples(5)
+    assert tuple(smp.shape) == (5, 2, 300)
+    A64 = (C.astype(np.float64) @ np.swapaxes(C.astype(np.float64), -1, -2)) + np.stack([np.diag(x) for x in d.astype(np.float64)])
+    ev, Qe = np.linalg.eigh(A64)
+    exact = (Qe * np.sqrt(ev)[..., None, :]) @ np.swapaxes(Qe, -1, -2) @ z.astype(np.float64)  # [2, 300, 5]
+    assert max_rel_err_cols(np.moveaxis(host(smp), 0, -1), exact) < 5e-4
     # vector right-hand side, non-batch operator, functional form
     A1 = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C[0])), DiagLinearOperator(dev(d[0])))
     v = lo.sqrt_inv_matmul(A1, dev(rhs[0, :, 0]))
