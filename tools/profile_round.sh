@@ -10,6 +10,10 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats
 cp $(find /tmp/p_stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_e2e -- python $GRAFT_REPO_ROOT/tools/mb_e2e.py > $OUT/e2e_under_rocprof.log 2>&1
 cp $(find /tmp/p_e2e -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_end_to_end.csv
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_cfg3 -- python $GRAFT_REPO_ROOT/tools/mb_cfg3.py > $OUT/cfg3_under_rocprof.log 2>&1
+cp $(find /tmp/p_cfg3 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_cfg3_cg.csv
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_mr -- python $GRAFT_REPO_ROOT/tools/mb_minres.py > $OUT/minres_under_rocprof.log 2>&1
+cp $(find /tmp/p_mr -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_minres.csv
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- $B > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- $B > /dev/null 2>&1
 { python $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/p_fetch; python $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/p_write; } > $OUT/pmc_fetch_write_summary.txt
