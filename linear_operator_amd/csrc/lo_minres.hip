@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kThreads) void k_mr_div(MrDev d, float* __restrict_
 // without a preconditioner also the partials of z_c . z_c
 __global__ __launch_bounds__(kThreads) void k_mr_lanczos(MrDev d, float* __restrict__ zc, const float* __restrict__ q1,
                                                           const float* __restrict__ z1, const float* __restrict__ z2,
-                                                          int have_dot, int want_bpart, int rows_per) {
+                                                          int want_bpart, int rows_per) {
   __shared__ float red[kThreads];
   __shared__ float alpha_s[kMaxCols];
   const int s = blockIdx.x, b = blockIdx.y, S = gridDim.x;
@@ -125,7 +125,6 @@ __global__ __launch_bounds__(kThreads) void k_mr_lanczos(MrDev d, float* __restr
     alpha_s[col] = a;
     if (s == 0) d.alpha[(size_t)b * c + col] = a;
   }
-  (void)have_dot;
   __syncthreads();
   const int nrs = kThreads / c;
   const int col = threadIdx.x % c, slot = threadIdx.x / c;
@@ -450,7 +449,7 @@ int lo_minres_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user, 
     if (rc) return rc;
     ++matvecs;
     LO_PROF_BEGIN("mr_lanczos", st);
-    hipLaunchKernelGGL(k_mr_lanczos, gridv, block, 0, st, d, zc, q1, z1, z2, 1, precond ? 0 : 1, sp.rows);
+    hipLaunchKernelGGL(k_mr_lanczos, gridv, block, 0, st, d, zc, q1, z1, z2, precond ? 0 : 1, sp.rows);
     LO_PROF_END(st);
     LO_LAUNCH_CHECK();
     if (precond) {

@@ -14,7 +14,7 @@ from __future__ import annotations
 import torch
 from torch import Tensor
 
-from .. import settings
+from .. import _hip, settings
 from .added_diag_linear_operator import AddedDiagLinearOperator
 from .dense_linear_operator import DenseLinearOperator
 from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
@@ -43,13 +43,23 @@ class KroneckerProductAddedDiagLinearOperator(AddedDiagLinearOperator):
         used inside the autograd Functions' forward (their backward goes through `_bilinear_derivative`)."""
         if self._eig_cache is None:
             with torch.no_grad():
-                evals, evecs = self.linear_op.detach()._symeig(eigenvectors=True, symeig_dtype_evals=True)
+                evals, evecs = self._symeig_of_product(self.linear_op.detach())
             self._eig_cache = (evals, evecs._transpose_nonbatch(), evecs)
         return self._eig_cache
+
+    @staticmethod
+    def _symeig_of_product(op):
+        """Eigenvalues in the symeig dtype when the operator is a Kronecker product (its factors are decomposed one
+        by one); any other operator goes through its own `_symeig`."""
+        if isinstance(op, KroneckerProductLinearOperator):
+            return op._symeig(eigenvectors=True, symeig_dtype_evals=True)
+        return op._symeig(eigenvectors=True)
 
     def _solve(self, rhs: Tensor, preconditioner=None, num_tridiag: int = 0):
         if not self._diag_is_constant:
             return super()._solve(rhs, preconditioner=preconditioner, num_tridiag=num_tridiag)
+        if isinstance(self.linear_op, KroneckerProductLinearOperator) and len(self.linear_op.linear_ops) == 2:
+            _hip.require_hip(rhs)  # Q and Q^T are applied by the Kronecker matvec kernel: no ATen route for this solve
         evals, q_t, q = self._factor_eig()
         sig = self.diag_tensor._diagonal().to(evals.dtype)  # [*batch, N]
         inv = (evals + sig).reciprocal().to(rhs.dtype).unsqueeze(-1)
@@ -64,7 +74,7 @@ class KroneckerProductAddedDiagLinearOperator(AddedDiagLinearOperator):
 
     def _logdet(self) -> Tensor:
         if self._diag_is_constant:  # :86-90, differentiable through the factors' eigh
-            evals, _ = self.linear_op._symeig(eigenvectors=True, symeig_dtype_evals=True)
+            evals, _ = self._symeig_of_product(self.linear_op)
             return torch.log(evals + self.diag_tensor._diagonal().to(evals.dtype)).sum(dim=-1).to(self.dtype)
         return super().inv_quad_logdet(logdet=True)[1]
 

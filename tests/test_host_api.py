@@ -167,3 +167,39 @@ def test_linear_cg_argument_errors_match_reference():
         sq.inv_quad_logdet(torch.randn(2, 900, 1), logdet=True)
     with pytest.raises(RuntimeError, match="must be specifed"):
         sq.inv_quad_logdet(None, logdet=False)
+
+
+def test_kronecker_added_diag_routing_and_closed_form_plumbing_cpu():
+    """`KroneckerProduct + ConstantDiag / Diag / .add_diagonal` build the KroneckerProductAddedDiagLinearOperator like the
+    reference (kronecker_product_linear_operator.py:98-145); its logdet (pure ATen eigh plumbing) against golden g12 and
+    the symeig diagonalization of a Kronecker product are checked here, the solves (Kronecker matvec kernel) on the GPU."""
+    from linear_operator_amd.operators import KroneckerProductAddedDiagLinearOperator
+
+    torch.set_num_threads(1)  # (torch's fp64 LAPACK calls hang with many threads in the build container)
+    g = load_golden("g12_kron_added_diag")
+    K1, K2, _, rhs = cases.kron_factors(1301, 2, 24, 36, 3)
+    sig = np.array([[0.3], [0.05]], dtype=np.float32)
+    kp = KroneckerProductLinearOperator(DenseLinearOperator(T(K1)), DenseLinearOperator(T(K2)))
+    a1 = kp + ConstantDiagLinearOperator(T(sig), 864)
+    a2 = kp.add_diagonal(T(sig))
+    a3 = kp.add_diagonal(torch.tensor(0.3))
+    a4 = kp + DiagLinearOperator(T(np.broadcast_to(sig, (2, 864)).copy()))
+    for a, const in ((a1, True), (a2, True), (a3, True), (a4, False)):
+        assert isinstance(a, KroneckerProductAddedDiagLinearOperator) and isinstance(a, AddedDiagLinearOperator)
+        assert a._diag_is_constant == const and a._preconditioner() == (None, None, None)
+    assert isinstance(AddedDiagLinearOperator(kp, ConstantDiagLinearOperator(T(sig), 864)), AddedDiagLinearOperator)
+    assert not isinstance(AddedDiagLinearOperator(kp, ConstantDiagLinearOperator(T(sig), 864)),
+                          KroneckerProductAddedDiagLinearOperator)  # the explicit class keeps the CG path
+    assert isinstance(a1 + ConstantDiagLinearOperator(T(sig), 864), KroneckerProductAddedDiagLinearOperator)
+    assert np.allclose(a1.logdet().numpy(), g["ld_exact"], rtol=1e-5)
+    _, ld = a2.inv_quad_logdet(None, logdet=True)
+    assert np.allclose(ld.numpy(), g["ld_exact"], rtol=1e-5)
+    evals, evecs = kp.diagonalization()  # symeig by default for Kronecker products (:147-152)
+    dense = np.stack([np.kron(K1[b].astype(np.float64), K2[b].astype(np.float64)) for b in range(2)])
+    assert np.allclose(np.sort(evals.numpy(), -1), np.linalg.eigvalsh(dense), rtol=1e-4, atol=1e-5)
+    q = evecs.to_dense().numpy()
+    assert np.abs((q * evals.numpy()[..., None, :]) @ np.swapaxes(q, -1, -2) - dense).max() < 1e-3
+    with settings.max_cholesky_size(0), pytest.raises(_hip.HipExtensionError):
+        a1.solve(T(rhs))  # the solve needs the Kronecker matvec kernel: no silent ATen route
+    with pytest.raises(_hip.HipExtensionError):
+        lo.utils.minres(T(np.eye(8, dtype=np.float32)).matmul, torch.randn(8, 1))
