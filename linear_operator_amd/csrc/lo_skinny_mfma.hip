@@ -24,7 +24,6 @@ namespace lo {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int MF_MAXT = 4;  // up to 4 output tiles of 32 (R4 <= 128) in tn
 
 using TnFuseM = TnFuse;
 
