@@ -9,7 +9,7 @@ is identical whenever CG ends at the iteration floors (all BASELINE configs exce
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Sequence
+from typing import Callable, Optional
 
 import torch
 import torch.distributed as dist

@@ -1,9 +1,7 @@
 """Matmul Function (reference: linear_operator/functions/_matmul.py:9-66), forward and backward."""
 from __future__ import annotations
 
-import torch
 from torch.autograd import Function
-
 
 
 class Matmul(Function):

@@ -18,8 +18,7 @@ from torch import Tensor
 from .. import kernels as K
 from .. import settings
 from ..utils.warnings import NumericalWarning
-from ._linear_operator import LinearOperator
-from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
+from .diag_linear_operator import DiagLinearOperator
 from .root_linear_operator import RootLinearOperator
 from .sum_linear_operator import PsdSumLinearOperator, SumLinearOperator, _attach_diag
 

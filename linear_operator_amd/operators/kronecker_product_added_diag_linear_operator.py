@@ -14,9 +14,8 @@ from __future__ import annotations
 import torch
 from torch import Tensor
 
-from .. import _hip, settings
+from .. import _hip
 from .added_diag_linear_operator import AddedDiagLinearOperator
-from .dense_linear_operator import DenseLinearOperator
 from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
 from .kronecker_product_linear_operator import KroneckerProductLinearOperator
 

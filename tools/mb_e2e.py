@@ -2,7 +2,7 @@
 every kernel including the torch glue."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-from linear_operator_amd import _hip, kernels as K
+from linear_operator_amd import kernels as K
 B, N, R = 512, 8192, 32
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 Cm = torch.randn(B, N, R, generator=g, device="cuda") / R ** 0.5

@@ -2,7 +2,7 @@
 form) against the CG path of the explicit AddedDiagLinearOperator, 128 members of 256 (x) 256."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-from linear_operator_amd import _hip, settings
+from linear_operator_amd import settings
 from linear_operator_amd.operators import (AddedDiagLinearOperator, ConstantDiagLinearOperator, DenseLinearOperator,
                                            KroneckerProductLinearOperator)
 dev = torch.device("cuda"); g = torch.Generator(device=dev); g.manual_seed(5)

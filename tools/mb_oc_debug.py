@@ -1,4 +1,4 @@
-import os, sys, torch
+import sys, torch
 sys.path.insert(0, "/root/repo")
 from linear_operator_amd import kernels as K
 dev = torch.device("cuda"); g = torch.Generator(device=dev); g.manual_seed(3)
