@@ -1,5 +1,8 @@
+"""Preconditioned contour integral quadrature (N above settings.min_preconditioning_size): ||A^-1/2 b||^2 against b^T A^-1 b."""
 import sys, torch, numpy as np, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests/golden"); sys.path.insert(0, "/root/repo/tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p_ in (ROOT, os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "tests")): sys.path.insert(0, p_)
 import cases
 from linear_operator_amd import settings, _hip
 from linear_operator_amd.operators import AddedDiagLinearOperator, DiagLinearOperator, LowRankRootLinearOperator

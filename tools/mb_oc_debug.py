@@ -1,5 +1,6 @@
-import sys, torch
-sys.path.insert(0, "/root/repo")
+"""Phase timers of the resident CG kernel: run with LO_OC_DEBUG=<member index> (prints 100 MHz tick counts)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from linear_operator_amd import kernels as K
 dev = torch.device("cuda"); g = torch.Generator(device=dev); g.manual_seed(3)
 B, N, R = 512, 8192, 32
