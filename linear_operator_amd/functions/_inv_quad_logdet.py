@@ -14,7 +14,7 @@ from ..utils.lanczos import lanczos_tridiag_to_diag
 from ..utils.stochastic_lq import StochasticLQ
 
 
-def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, ppv, coef, logdet_grad):
+def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, U, V, logdet_grad):
     """d/d(theta) of  logdet P  -  (1/P) sum_p (P^-1 z_p)^T P (P^-1 z_p)  for the pivoted-Cholesky preconditioner
     P = L L^T + D of an AddedDiagLinearOperator, chained to the operator's own tensors (what the reference obtains
     through autograd: `precond_arg_grads` :211-213 plus the graph of logdet_p, added_diag_linear_operator.py:159-184):
@@ -35,7 +35,6 @@ def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, ppv
         return matrix_arg_grads
     wb = pre.woodbury
     g = logdet_grad  # [*batch, 1, 1]
-    U, V = -ppv * coef, ppv * g
     # position of the two components inside the representation
     first_is_diag = linear_op.linear_ops[0] is linear_op._diag_tensor
     n_first = len(linear_op.linear_ops[0].representation())
@@ -64,6 +63,26 @@ def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, ppv
                 if e is not None:
                     matrix_arg_grads[i] = e if matrix_arg_grads[i] is None else matrix_arg_grads[i] + e
     return matrix_arg_grads
+
+
+def _bilinear_derivative_where_needed(precond_lt, precond_args, left, right):
+    """precond_lt._bilinear_derivative(left, right) restricted to the components whose tensors take a gradient: the
+    pivoted-Cholesky factor of the preconditioner is built outside autograd (its contribution is chained by hand in
+    `_add_preconditioner_terms`), so only the diagonal's tensor normally asks for one."""
+    if not any(t.requires_grad for t in precond_args):
+        return [None] * len(precond_args)
+    components = getattr(precond_lt, "linear_ops", None)
+    if components is None:
+        return list(precond_lt._bilinear_derivative(left, right))
+    grads, pos = [], 0
+    for op in components:
+        n = len(op.representation())
+        if any(t.requires_grad for t in precond_args[pos: pos + n]):
+            grads += list(op._bilinear_derivative(left, right))
+        else:
+            grads += [None] * n
+        pos += n
+    return grads
 
 
 class InvQuadLogdet(Function):
@@ -175,14 +194,11 @@ class InvQuadLogdet(Function):
         # graph back to the operator's tensors (PivotedCholesky.backward, the QR of _init_cache) and logdet P is added
         # outside with its own graph; here the preconditioner is built by kernels outside autograd, so both
         # contributions are chained by hand into the gradients of the operator's tensors.
-        if any(t.requires_grad for t in precond_args):
-            precond_arg_grads = precond_lt._bilinear_derivative(
-                -precond_probe_vectors * coef, precond_probe_vectors * logdet_grad_output
-            )
-        else:
-            precond_arg_grads = [None] * len(precond_args)
+        pre_left = -precond_probe_vectors * coef
+        pre_right = precond_probe_vectors * logdet_grad_output
+        precond_arg_grads = _bilinear_derivative_where_needed(precond_lt, precond_args, pre_left, pre_right)
         matrix_arg_grads = _add_preconditioner_terms(
-            ctx, linear_op, list(matrix_arg_grads), matrix_args, precond_probe_vectors, coef, logdet_grad_output
+            ctx, linear_op, list(matrix_arg_grads), matrix_args, pre_left, pre_right, logdet_grad_output
         )
 
         if ctx.inv_quad:
