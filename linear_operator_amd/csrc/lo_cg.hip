@@ -438,7 +438,7 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   int oc_iters = std::min(10, prm->max_iter - 1);
   if (prm->n_tridiag) oc_iters = std::max(oc_iters, std::min(prm->max_tridiag_iter, prm->max_iter - 1));
   oc_iters = std::max(1, oc_iters + 1);
-  const bool oc_shape = op->kind == LO_OP_LOWRANK_DIAG && c <= 64 && N >= 1024 && N <= 16384;
+  const bool oc_shape = op->kind == LO_OP_LOWRANK_DIAG && c <= 64 && N >= 1024 && N <= 32768;
   const size_t oc_n = oc_shape ? (size_t)B * c : 1;
   dd.oc_resid = ar.take<float>(oc_n * oc_iters);
   dd.oc_init_conv = ar.take<int>(oc_n);

@@ -17,7 +17,7 @@ struct OnchipArgs {
   float* ab_rec;      // [iters, B, c, 2] masked alpha / beta per iteration (second generation, n_tridiag > 0) or nullptr
   int64_t B;
   int N, RW;          // rows per workgroup
-  int GW;             // workgroups per member (group size): 8 (first generation), 4 or 8 (second)
+  int GW;             // workgroups per member (group size): 8 (first generation); 8, 16 or 32 (second)
   int iters;          // iterations to run (k = 0 .. iters-1)
   float eps, stop_after;
   // state out (streaming engine layout, c == 1)

@@ -6,8 +6,8 @@
 // instructions) is paid once per ROW, a member occupies 8 CUs, and while a group waits for a hand-off (two per
 // iteration, ~1 us each) its CUs idle.  Here a thread owns FOUR rows and TWO workgroups share a CU:
 //   * workgroup = 256 threads x 4 rows = 1024 rows; a member of N <= 8192 rows is a group of 8 workgroups but only
-//     4 CUs' worth of resources, so 64 members are in flight instead of 32 (groups of 4 / 16 for N <= 4096 /
-//     16384); the two workgroups resident on a CU belong to different members, so one computes while the other
+//     4 CUs' worth of resources, so 64 members are in flight instead of 32 (groups of 16 / 32 for N <= 16384 /
+//     32768); the two workgroups resident on a CU belong to different members, so one computes while the other
 //     waits for its hand-off;
 //   * the 4 C rows of a thread live in VGPRs (4 x 32 floats -- the register file of a CU is 512 KiB, four times
 //     its LDS), the 4 Q rows in LDS (1024 x 16 floats = 64 KiB per workgroup, 16-byte slots XOR-swizzled so that
@@ -33,7 +33,7 @@ constexpr int R4_TPB = 256;
 constexpr int R4_NR = 4;                 // rows per thread
 constexpr int R4_WAVES = R4_TPB / 64;    // 4
 constexpr int R4_ROWS = R4_TPB * R4_NR;  // rows per workgroup
-constexpr int R4_MAXGW = 16;
+constexpr int R4_MAXGW = 32;
 constexpr int R4_SLOT = 40;
 constexpr unsigned R4_MAXSPIN = 1u << 20;  // ~0.5 s of polling: co-residency was lost (never seen on a dedicated GPU)
 
@@ -96,28 +96,60 @@ __device__ __forceinline__ void r4_group_sum(R4Shared& sh, int cnt, R4Group& g) 
     else
       __hip_atomic_store(slot + (size_t)g.wig * R4_SLOT + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (stamp) c2 = wall_clock64();
-    float vals[GW];
-    unsigned spin = 0;
-    for (;;) {
-      bool ok = true;
-#pragma unroll
-      for (int w = 0; w < GW; ++w) {
-        const unsigned long long x =
-            __hip_atomic_load(slot + (size_t)w * R4_SLOT + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = ok && ((unsigned)(x >> 32) == tag);
-        vals[w] = __uint_as_float((unsigned)(x & 0xffffffffull));
-      }
-      if (ok) break;
-      if (++spin > R4_MAXSPIN ||
-          ((spin & 1023u) == 0 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        atomicExch(g.err, 1);  // timed out, or another workgroup already did: give up at once
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
     float tot = 0.f;
+    unsigned spin = 0;
+    if constexpr (GW <= 16) {
+      float vals[GW];
+      for (;;) {
+        bool ok = true;
 #pragma unroll
-    for (int w = 0; w < GW; ++w) tot += vals[w];
+        for (int w = 0; w < GW; ++w) {
+          const unsigned long long x =
+              __hip_atomic_load(slot + (size_t)w * R4_SLOT + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && ((unsigned)(x >> 32) == tag);
+          vals[w] = __uint_as_float((unsigned)(x & 0xffffffffull));
+        }
+        if (ok) break;
+        if (++spin > R4_MAXSPIN ||
+            ((spin & 1023u) == 0 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          atomicExch(g.err, 1);  // timed out, or another workgroup already did: give up at once
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int w = 0; w < GW; ++w) tot += vals[w];
+    } else {
+      // large groups: wait for all tags first, then read the (now final: a granule of this parity is not rewritten
+      // before every workgroup has finished this all-reduce) values again -- 32 values need not stay in registers
+      // (32-bit halves of the granules: tag = upper word, value = lower word; the writer stores both with one 64-bit
+      // store, so a matching tag means the value word next to it is the one of this all-reduce)
+      const unsigned* words = reinterpret_cast<const unsigned*>(slot);
+      for (;;) {
+        unsigned bad = 0;  // (no short-circuit: all tag loads must be in flight together)
+#pragma unroll
+        for (int w = 0; w < GW; ++w)
+          bad |= __hip_atomic_load(words + 2 * ((size_t)w * R4_SLOT + t) + 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT) ^ tag;
+        if (bad == 0) break;
+        if (++spin > R4_MAXSPIN ||
+            ((spin & 1023u) == 0 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          atomicExch(g.err, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int h = 0; h < GW; h += 16) {  // 16 loads in flight, summed in the fixed order w = 0 .. GW-1
+        float v[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w)
+          v[w] = __uint_as_float(__hip_atomic_load(words + 2 * ((size_t)(h + w) * R4_SLOT + t), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += v[w];
+      }
+    }
     sh.res[t] = tot;
     if (stamp) {
       c3 = wall_clock64();
@@ -439,7 +471,7 @@ bool onchip4_eligible(int RC, int RK, int64_t N, int64_t c) {
   return rc_ok && rk_ok && c >= 1 && c <= 64 && N >= 1024 && N <= (int64_t)R4_MAXGW * R4_ROWS;
 }
 
-int onchip4_group_size(int64_t N) { return N <= 8 * (int64_t)R4_ROWS ? 8 : 16; }
+int onchip4_group_size(int64_t N) { return N <= 8 * (int64_t)R4_ROWS ? 8 : (N <= 16 * (int64_t)R4_ROWS ? 16 : 32); }
 
 template <int RC, int RK, int GW, bool MC>
 static int onchip4_go(const OnchipArgs& a, int nwg, hipStream_t st) {
@@ -460,9 +492,8 @@ static int onchip4_go(const OnchipArgs& a, int nwg, hipStream_t st) {
 // workgroups do not fit on a CU (the caller then runs the first generation).
 int onchip4_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st) {
   const bool mc = a.c > 1 || a.ab_rec != nullptr;
-#define LO_OC(C_, K_)                                                                                         \
-  return a.GW == 8 ? (mc ? onchip4_go<C_, K_, 8, true>(a, nwg, st) : onchip4_go<C_, K_, 8, false>(a, nwg, st)) \
-                   : (mc ? onchip4_go<C_, K_, 16, true>(a, nwg, st) : onchip4_go<C_, K_, 16, false>(a, nwg, st))
+#define LO_OC_G(C_, K_, G_) (mc ? onchip4_go<C_, K_, G_, true>(a, nwg, st) : onchip4_go<C_, K_, G_, false>(a, nwg, st))
+#define LO_OC(C_, K_) return a.GW == 8 ? LO_OC_G(C_, K_, 8) : (a.GW == 16 ? LO_OC_G(C_, K_, 16) : LO_OC_G(C_, K_, 32))
   if (RC == 32 && RK == 16) LO_OC(32, 16);
   else if (RC == 32 && RK == 8) LO_OC(32, 8);
   else if (RC == 32 && RK == 4) LO_OC(32, 4);
@@ -473,6 +504,7 @@ int onchip4_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st)
   else if (RC == 8 && RK == 8) LO_OC(8, 8);
   else if (RC == 8 && RK == 4) LO_OC(8, 4);
 #undef LO_OC
+#undef LO_OC_G
   return LO_ERR_UNSUPPORTED;
 }
 

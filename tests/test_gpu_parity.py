@@ -434,7 +434,8 @@ def test_lanczos_against_reference():
 
 
 # ------------------------------------------------------------------------------------------- operator-resident CG
-@pytest.mark.parametrize("N,R", [(8192, 32), (4096, 16), (2048, 8), (5000, 32), (4096, 20), (3000, 6)])
+@pytest.mark.parametrize("N,R", [(8192, 32), (4096, 16), (2048, 8), (5000, 32), (4096, 20), (3000, 6), (20000, 32),
+                                 (32768, 16)])  # (groups of 8 / 16 / 32 workgroups)
 def test_onchip_cg_matches_streaming_engine_and_oracle(N, R):
     """The operator-resident fast path (8 workgroups per member, C in LDS, Q in VGPRs, granule all-reduces) runs the
     same arithmetic as the streaming engine: same iteration count, solutions equal to summation-order noise."""

@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from linear_operator_amd import kernels as K
 dev = torch.device("cuda"); g = torch.Generator(device=dev); g.manual_seed(3)
-B, N, R = 512, 8192, 32
+B, N, R = int(os.environ.get('OC_B', 512)), int(os.environ.get('OC_N', 8192)), 32
 Cm = torch.randn(B, N, R, generator=g, device=dev) / R ** 0.5
 d = torch.rand(B, N, generator=g, device=dev) + 0.5
 rhs = torch.randn(B, N, 1, generator=g, device=dev)
