@@ -329,7 +329,7 @@ __global__ __launch_bounds__(PO_TPB) void k_pc_onchip(PoArgs a) {
 // ---- second generation: 4 rows per thread, two workgroups per CU (same idea as lo_cg_onchip4.hip) -------------
 // Workgroup = 256 threads x 4 rows; the 4 C rows of a thread live in VGPRs, the L rows of the workgroup in LDS
 // (1024 x 16 floats, 16-byte slots XOR-swizzled), so the pivot index is a run-time value and the pivot loop is a
-// plain loop.  A member is a group of GW = 8 (N <= 8192) or 16 (N <= 16384) workgroups; two workgroups of
+// plain loop.  A member is a group of GW = 8 (N <= 8192), 16 (N <= 16384) or 32 (N <= 32768) workgroups; two workgroups of
 // different members share a CU, one updates its rows while the other waits for its exchange.  Arithmetic and
 // operation order per row are those of the first generation, hence bit-identical results.
 constexpr int P4_TPB = 256;
@@ -362,27 +362,57 @@ __device__ __forceinline__ void p4_gather(P4Shared<GW>& sh, int cnt, unsigned lo
       __hip_atomic_store(slot + (size_t)wig * PO_SLOT + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else
       __hip_atomic_store(slot + (size_t)wig * PO_SLOT + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned vals[GW];
     unsigned spin = 0;
-    for (;;) {
-      bool ok = true;
+    if constexpr (GW <= 16) {
+      unsigned vals[GW];
+      for (;;) {
+        bool ok = true;
 #pragma unroll
-      for (int w = 0; w < GW; ++w) {
-        const unsigned long long x =
-            __hip_atomic_load(slot + (size_t)w * PO_SLOT + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = ok && ((unsigned)(x >> 32) == tag);
-        vals[w] = (unsigned)(x & 0xffffffffull);
+        for (int w = 0; w < GW; ++w) {
+          const unsigned long long x =
+              __hip_atomic_load(slot + (size_t)w * PO_SLOT + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && ((unsigned)(x >> 32) == tag);
+          vals[w] = (unsigned)(x & 0xffffffffull);
+        }
+        if (ok) break;
+        if (++spin > PO_MAXSPIN ||
+            ((spin & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          atomicExch(err, 1);  // timed out, or another workgroup already did: give up at once
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
       }
-      if (ok) break;
-      if (++spin > PO_MAXSPIN ||
-          ((spin & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        atomicExch(err, 1);  // timed out, or another workgroup already did: give up at once
-        break;
+#pragma unroll
+      for (int w = 0; w < GW; ++w) sh.gath[w][t] = vals[w];
+    } else {
+      // large groups: poll the tag words (upper halves of the granules, all loads in flight together), then fetch
+      // the value words -- final once the tags match, see lo_cg_onchip4.hip -- straight into LDS
+      const unsigned* words = reinterpret_cast<const unsigned*>(slot);
+      for (;;) {
+        unsigned bad = 0;
+#pragma unroll
+        for (int w = 0; w < GW; ++w)
+          bad |= __hip_atomic_load(words + 2 * ((size_t)w * PO_SLOT + t) + 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT) ^ tag;
+        if (bad == 0) break;
+        if (++spin > PO_MAXSPIN ||
+            ((spin & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          atomicExch(err, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
       }
-      __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int h = 0; h < GW; h += 16) {
+        unsigned v[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w)
+          v[w] = __hip_atomic_load(words + 2 * ((size_t)(h + w) * PO_SLOT + t), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) sh.gath[h + w][t] = v[w];
+      }
     }
-#pragma unroll
-    for (int w = 0; w < GW; ++w) sh.gath[w][t] = vals[w];
   }
   __syncthreads();
 }
@@ -518,9 +548,13 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
       float etot = __uint_as_float(sh.gath[lane % GW][3]);
       etot = bfly_add<1>(etot); etot = bfly_add<2>(etot); etot = bfly_add<4>(etot);
       po_amax_step<1>(vb, jb); po_amax_step<2>(vb, jb); po_amax_step<4>(vb, jb);
-      if constexpr (GW == 16) {
+      if constexpr (GW >= 16) {
         etot = bfly_add<8>(etot);
         po_amax_step<8>(vb, jb);
+      }
+      if constexpr (GW == 32) {
+        etot = bfly_add<16>(etot);
+        po_amax_step<16>(vb, jb);
       }
       vb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vb)));
       jb = __builtin_amdgcn_readfirstlane(jb);
@@ -677,7 +711,7 @@ bool pc_onchip_eligible(const lo_op_desc* op, int max_rank) {
   if (g_onchip_disabled || op->kind != LO_OP_LOWRANK_DIAG) return false;
   const int64_t R = op->R;  // (any rank up to 32: zero-padded to 8 / 16 / 32 columns in the workspace)
   return R >= 1 && R <= 32 && max_rank <= PO_MAXR && op->N >= 1024 &&
-         op->N <= (int64_t)16 * P4_ROWS && onchip_num_workgroups() >= 64;
+         op->N <= (int64_t)32 * P4_ROWS && onchip_num_workgroups() >= 64;
 }
 
 static int po_padded_rank(int64_t R) { return R <= 8 ? 8 : (R <= 16 ? 16 : 32); }
@@ -728,18 +762,21 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   }
   const int nwg = onchip_num_workgroups();
   // second generation (4 rows per thread, two workgroups per CU) when two workgroups fit on a CU
-  const int gw2 = op->N <= (int64_t)8 * P4_ROWS ? 8 : 16;
+  const int gw2 = op->N <= (int64_t)8 * P4_ROWS ? 8 : (op->N <= (int64_t)16 * P4_ROWS ? 16 : 32);
   bool gen2 = !(getenv("LO_OC_GEN1") && op->N <= (int64_t)PO_GW * PO_TPB);
   if (gen2) {
     int per_cu = 0;
     hipError_t e = hipErrorUnknown;
 #define LO_OCC(R_, G_) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pc_onchip4<R_, G_>, P4_TPB, 0)
     if (RP == 32 && gw2 == 8) LO_OCC(32, 8);
-    else if (RP == 32) LO_OCC(32, 16);
+    else if (RP == 32 && gw2 == 16) LO_OCC(32, 16);
+    else if (RP == 32) LO_OCC(32, 32);
     else if (RP == 16 && gw2 == 8) LO_OCC(16, 8);
-    else if (RP == 16) LO_OCC(16, 16);
+    else if (RP == 16 && gw2 == 16) LO_OCC(16, 16);
+    else if (RP == 16) LO_OCC(16, 32);
     else if (gw2 == 8) LO_OCC(8, 8);
-    else LO_OCC(8, 16);
+    else if (gw2 == 16) LO_OCC(8, 16);
+    else LO_OCC(8, 32);
 #undef LO_OCC
     gen2 = (e == hipSuccess) && per_cu >= 2;
   }
@@ -771,11 +808,14 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
     dim3 grid2(2 * nwg), block2(P4_TPB);
 #define LO_GO(R_, G_) hipLaunchKernelGGL((k_pc_onchip4<R_, G_>), grid2, block2, 0, st, a)
     if (RP == 32 && gw == 8) LO_GO(32, 8);
-    else if (RP == 32) LO_GO(32, 16);
+    else if (RP == 32 && gw == 16) LO_GO(32, 16);
+    else if (RP == 32) LO_GO(32, 32);
     else if (RP == 16 && gw == 8) LO_GO(16, 8);
-    else if (RP == 16) LO_GO(16, 16);
+    else if (RP == 16 && gw == 16) LO_GO(16, 16);
+    else if (RP == 16) LO_GO(16, 32);
     else if (gw == 8) LO_GO(8, 8);
-    else LO_GO(8, 16);
+    else if (gw == 16) LO_GO(8, 16);
+    else LO_GO(8, 32);
 #undef LO_GO
   } else if (RP == 32) hipLaunchKernelGGL((k_pc_onchip<32>), grid, block, 0, st, a);
   else if (RP == 16) hipLaunchKernelGGL((k_pc_onchip<16>), grid, block, 0, st, a);

@@ -217,7 +217,8 @@ def test_pivoted_cholesky_bench_shape_bit_exact():
 
 
 @pytest.mark.parametrize("N,R,B", [(8192, 32, 70), (4096, 16, 33), (1500, 8, 5), (5000, 32, 9), (12000, 16, 3),
-                                   (4096, 20, 7), (3000, 5, 4), (8192, 30, 10)])  # (ranks padded to 8 / 16 / 32)
+                                   (4096, 20, 7), (3000, 5, 4), (8192, 30, 10),  # (ranks padded to 8 / 16 / 32)
+                                   (20000, 32, 5), (32768, 16, 4)])  # (groups of 32 workgroups)
 def test_onchip_pivoted_cholesky_matches_streaming_engine_and_oracle(N, R, B):
     """Operator-resident pivoted Cholesky (one 8-workgroup group per member, C rows in LDS, L rows in VGPRs, one
     granule exchange per pivot): L, permutation and rank bit-identical to the streaming engine and to the oracle."""

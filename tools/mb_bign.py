@@ -8,7 +8,11 @@ for B, N, R in ((128, 32768, 32), (256, 16384, 32)):
     d = torch.rand(B, N, generator=g, device=dev) + 0.5
     rhs = torch.randn(B, N, 1, generator=g, device=dev)
     desc = K.lowrank_diag_descriptor(Cm, d)
-    L, _ = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15)
+    for on in (True, False):
+        K.set_onchip_cg(on)
+        K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15); torch.cuda.synchronize()
+        t0 = time.perf_counter(); L, _ = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15); torch.cuda.synchronize()
+        print(f"B={B} N={N}: resident={on}: pivoted Cholesky (rank 15) {1e3*(time.perf_counter()-t0):.2f} ms")
     pre = K.precond_build(L, d, False)
     for on in (True, False):
         K.set_onchip_cg(on)
