@@ -19,6 +19,10 @@ with settings.cg_tolerance(1e-4), settings.num_trace_samples(16):
         t0 = time.perf_counter(); l = fwd(); torch.cuda.synchronize(); t1 = time.perf_counter()
         l.backward(); torch.cuda.synchronize(); t2 = time.perf_counter()
         print(f"forward {1e3*(t1-t0):.2f} ms, backward {1e3*(t2-t1):.2f} ms")
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-        fwd().backward(); torch.cuda.synchronize()
+    if len(sys.argv) > 1 and sys.argv[1] == "forward":
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            fwd(); torch.cuda.synchronize()
+    else:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            fwd().backward(); torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60))
