@@ -643,6 +643,24 @@ def test_onchip_timeout_falls_back_to_streaming_engines(monkeypatch):
     assert torch.equal(L0, L1) and torch.equal(p0, p1)
     assert res.iterations == ref.iterations and res.tolerance_reached
     assert max_rel_err_cols(host(res.x), host(ref.x)) < 2e-5
+    # several columns with tridiagonals: the aborted resident attempt (its replay kernels ran on unusable records) must
+    # leave nothing behind in the returned tridiagonals
+    monkeypatch.delenv("LO_OC_TEST_FALLBACK")
+    C5, d5, rhs5 = cases.lowrank_diag(3901, 6, 4096, 32, 5)
+    rhs5[..., :4] /= np.linalg.norm(rhs5[..., :4], axis=-2, keepdims=True)
+    desc5 = K.lowrank_diag_descriptor(dev(C5), dev(d5))
+    pre5 = _default_precond(desc5, dev(d5), False)
+    ref5 = K.cg_solve(desc5, dev(rhs5), precond=pre5, tolerance=1e-4, n_tridiag=4)
+    monkeypatch.setenv("LO_OC_TEST_FALLBACK", "1")
+    K._hip.prof_enable(True)
+    res5 = K.cg_solve(desc5, dev(rhs5), precond=pre5, tolerance=1e-4, n_tridiag=4)
+    torch.cuda.synchronize()
+    prof5 = K._hip.prof_report()
+    K._hip.prof_enable(False)
+    assert "cg_onchip" in prof5 and any(k.startswith("skinny_") for k in prof5)
+    assert res5.iterations == ref5.iterations == 21 and res5.t_mat.shape == ref5.t_mat.shape
+    assert max_rel_err_cols(host(res5.x), host(ref5.x)) < 2e-5
+    _assert_tridiag_close(res5.t_mat, ref5.t_mat, 4096)
 
 
 def test_cg_many_columns_mfma_paths_vs_oracle():
@@ -653,7 +671,16 @@ def test_cg_many_columns_mfma_paths_vs_oracle():
     rhs[..., :16] /= np.sqrt((rhs[..., :16] ** 2).sum(-2, keepdims=True))
     desc = K.lowrank_diag_descriptor(dev(C), dev(d))
     pre = _default_precond(desc, dev(d), False)
-    res = K.cg_solve(desc, dev(rhs), precond=pre, n_tridiag=16, tolerance=1e-4)
+    try:  # (the resident kernel would take this shape: the streaming matrix-core engine is what is under test here)
+        K.set_onchip_cg(False)
+        K._hip.prof_enable(True)
+        res = K.cg_solve(desc, dev(rhs), precond=pre, n_tridiag=16, tolerance=1e-4)
+        torch.cuda.synchronize()
+        prof = K._hip.prof_report()
+        K._hip.prof_enable(False)
+    finally:
+        K.set_onchip_cg(True)
+    assert any(k.startswith("skinny_tn_mfma") for k in prof) and "cg_onchip" not in prof
     Lo, _ = orc.pivoted_cholesky(orc.LowRankRowSource(C), 15)
     po = orc.Preconditioner(Lo, d)
     xo, to, info = orc.linear_cg(lambda v: orc.matvec_lowrank_diag(C, d, v), rhs, n_tridiag=16, tolerance=1e-4,
