@@ -65,6 +65,31 @@ def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, U, 
     return matrix_arg_grads
 
 
+def _zero_mean_mvn_samples_columns(precond_lt, num_samples):
+    """`precond_lt.zero_mean_mvn_samples(P)` [P, *batch, N] rearranged to [*batch, N, P] (reference :91-94).  For the
+    preconditioner of an AddedDiagLinearOperator, P = L L^T + D, the draws L e1 + sqrt(d) o e2 are formed directly in the
+    column layout (one GEMM and one fused multiply-add instead of two sample tensors, their sum and two transposed
+    copies)."""
+    from ..operators.diag_linear_operator import DiagLinearOperator
+    from ..operators.root_linear_operator import RootLinearOperator
+    from ..operators.sum_linear_operator import PsdSumLinearOperator
+
+    ops = getattr(precond_lt, "linear_ops", ())
+    if isinstance(precond_lt, PsdSumLinearOperator) and len(ops) == 2:
+        root = next((o for o in ops if isinstance(o, RootLinearOperator)), None)
+        diag = next((o for o in ops if isinstance(o, DiagLinearOperator)), None)
+        L = root._dense_root() if root is not None else None
+        if L is not None and diag is not None:
+            batch = precond_lt.batch_shape
+            n = precond_lt.size(-1)
+            e1 = torch.randn(*batch, L.size(-1), num_samples, dtype=L.dtype, device=L.device)
+            e2 = torch.randn(*batch, n, num_samples, dtype=L.dtype, device=L.device)
+            d = diag._diagonal().expand(*batch, n)
+            return torch.addcmul(L.expand(*batch, *L.shape[-2:]) @ e1, d.sqrt().unsqueeze(-1), e2)
+    samples = precond_lt.zero_mean_mvn_samples(num_samples)  # [P, *batch, N]
+    return samples.unsqueeze(-2).transpose(0, -2).squeeze(0).mT.contiguous()
+
+
 def _bilinear_derivative_where_needed(precond_lt, precond_args, left, right):
     """precond_lt._bilinear_derivative(left, right) restricted to the components whose tensors take a gradient: the
     pivoted-Cholesky factor of the preconditioner is built outside autograd (its contribution is chained by hand in
@@ -110,8 +135,7 @@ class InvQuadLogdet(Function):
             if settings.deterministic_probes.on():
                 raise NotImplementedError("deterministic_probes is deprecated in the reference and not implemented")
             num_random_probes = settings.num_trace_samples.value()
-            probe_vectors = precond_lt.zero_mean_mvn_samples(num_random_probes)  # [P, *batch, N]
-            probe_vectors = probe_vectors.unsqueeze(-2).transpose(0, -2).squeeze(0).mT.contiguous()  # [*batch, N, P]
+            probe_vectors = _zero_mean_mvn_samples_columns(precond_lt, num_random_probes)  # [*batch, N, P]
             probe_vector_norms = torch.linalg.vector_norm(probe_vectors, ord=2, dim=-2, keepdim=True)
             probe_vectors = probe_vectors.div(probe_vector_norms)
 
