@@ -148,7 +148,25 @@ def other_configs(device):
     V = torch.randn(B_PER_GPU, N, 16, generator=g, device=device)
     t, (q_mat, _) = _time(lambda: K.lanczos_tridiag(desc, V, 20), 1)
     res["cfg3_B512_lanczos_P16_k20"] = {"ms": t * 1e3, "member_probe_steps_per_s": B_PER_GPU * 16 * q_mat.shape[-1] / t}
-    del Cm, d, full, desc, V, q_mat
+    # the same operator through the host API, forward + backward (one GP marginal-likelihood gradient step): probes
+    # drawn from the preconditioner, resident CG with tridiagonals, SLQ, then the reference's backward formulas
+    from linear_operator_amd import settings as lo_settings
+    from linear_operator_amd.operators import AddedDiagLinearOperator, DiagLinearOperator, LowRankRootLinearOperator
+
+    Cg, dg = Cm.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    y = full[..., 16:].contiguous()
+
+    def train_step():
+        Cg.grad = dg.grad = None
+        A = AddedDiagLinearOperator(LowRankRootLinearOperator(Cg), DiagLinearOperator(dg))
+        iq, ld = A.inv_quad_logdet(y, logdet=True)
+        (iq.sum() + ld.sum()).backward()
+        return iq
+
+    with lo_settings.cg_tolerance(TOL), lo_settings.num_trace_samples(16):
+        t, _ = _time(train_step, 2)
+    res["cfg3_B512_inv_quad_logdet_forward_backward_host_api"] = {"ms": t * 1e3, "member_steps_per_s": B_PER_GPU / t}
+    del Cm, d, full, desc, V, q_mat, Cg, dg, y
     # cfg4 shard: 128 of 1024 Kronecker members (256 (x) 256 + 1e-2 I), CG to tolerance 1e-3
     n = 256
     X1 = torch.randn(128, n, n, generator=g, device=device) / 16
