@@ -10,7 +10,6 @@ from torch.autograd import Function
 
 from .. import settings
 from ..utils import lanczos
-from ._common import not_yet
 
 
 class Diagonalization(Function):
@@ -35,11 +34,21 @@ class Diagonalization(Function):
             q_mat = q_mat.squeeze(1)
         q_mat = q_mat.squeeze(0)
         eigenvalues = eigenvalues.squeeze(0)
+        ctx.save_for_backward(*matrix_args, q_mat, eigenvalues)
         return eigenvalues, q_mat
 
     @staticmethod
-    def backward(ctx, evals_grad_output, evecs_grad_output):
-        not_yet("Diagonalization")
+    def backward(ctx, evals_grad_output, evecs_grad_output):  # reference :62-88
+        """Explicit eigendecomposition gradients (Ionescu et al. 2015) as a DENSE dL/dM -- like the reference, which
+        returns it in the slot of one dense matrix argument (:86)."""
+        q_mat, eigenvalues = ctx.saved_tensors[-2], ctx.saved_tensors[-1]
+        # (K~)_ij = 1_{i != j} / (sigma_i - sigma_j), a little jitter against zeros
+        kmat = (eigenvalues.unsqueeze(-1) - eigenvalues.unsqueeze(-2) + 1e-10).reciprocal()
+        torch.diagonal(kmat, dim1=-1, dim2=-2).zero_()
+        inner_term = kmat.mT * q_mat.mT.matmul(evecs_grad_output)  # dU = U (K~^T o (U^T dL/dU)) U^T
+        term1 = q_mat.matmul(inner_term).matmul(q_mat.mT)
+        term2 = q_mat.matmul(torch.diag_embed(evals_grad_output)).matmul(q_mat.mT)  # dSigma = U dL/dSigma U^T
+        return tuple([None] * 6 + [term1 + term2])
 
 
 __all__ = ["Diagonalization"]

@@ -837,6 +837,31 @@ def bilinear_derivative_root(C, U, V):
     return U @ (np.swapaxes(V, -1, -2) @ C) + V @ (np.swapaxes(U, -1, -2) @ C)
 
 
+def root_decomposition_backward(q_mat, evals, root_grad=None, inverse_grad=None):
+    """RootDecomposition.backward (functions/_root_decomposition.py:104-171) for ONE probe vector: with
+    R_inv = Q / sqrt(lambda), the factors handed to `_bilinear_derivative` are
+    left = grad_R - R_inv grad_Rinv^T R_inv  and  right = R_inv / 2.   q_mat [*B,N,k] (= Q V), evals [*B,k]."""
+    inverse = q_mat / np.sqrt(evals)[..., None, :]
+    left = np.zeros_like(inverse)
+    if root_grad is not None:
+        left = left + root_grad
+    if inverse_grad is not None:
+        left = left - inverse @ np.swapaxes(inverse_grad, -1, -2) @ inverse
+    return left, inverse / 2.0
+
+
+def diagonalization_backward(q_mat, evals, evals_grad, evecs_grad):
+    """Diagonalization.backward (functions/_diagonalization.py:62-88): dense dL/dM =
+    Q (K~^T o (Q^T dL/dQ)) Q^T + Q diag(dL/dlambda) Q^T,  K~_ij = 1_{i != j} / (lambda_i - lambda_j + 1e-10)."""
+    kmat = 1.0 / (evals[..., :, None] - evals[..., None, :] + 1e-10)
+    idx = np.arange(evals.shape[-1])
+    kmat[..., idx, idx] = 0.0
+    inner = np.swapaxes(kmat, -1, -2) * (np.swapaxes(q_mat, -1, -2) @ evecs_grad)
+    term1 = q_mat @ inner @ np.swapaxes(q_mat, -1, -2)
+    term2 = (q_mat * evals_grad[..., None, :]) @ np.swapaxes(q_mat, -1, -2)
+    return term1 + term2
+
+
 def solve_backward(solve_fn, right_solves, grad_output):
     """Solve.backward without a left tensor (functions/_solve.py:70-115): returns (rhs_grad, U, V) where
     (U, V) = ([L | R], -[R | L] / 2) are the factors handed to `_bilinear_derivative`, L = A^-1 grad_output."""

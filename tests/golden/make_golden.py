@@ -626,14 +626,56 @@ def g14_sqrt_inv_matmul():
     save("g14_sqrt_inv_matmul", checksum=cases.checksum(C, d, rhs, lhs, W, W2), **out)
 
 
+def g15_lanczos_consumers_backward():
+    """Backward of RootDecomposition and Diagonalization (functions/_root_decomposition.py:104-171,
+    functions/_diagonalization.py:62-88) with sign-invariant losses (R R^T t, R_inv R_inv^T t, Q diag(s) Q^T)."""
+    from unittest import mock
+
+    from linear_operator.functions._root_decomposition import RootDecomposition
+
+    C, d, _ = cases.lowrank_diag(1601, 2, 256, 8, 1)
+    v1 = cases.randn(1602, 2, 256, 1, dtype=np.float32)
+    tv = cases.randn(1603, 2, 256, 2, dtype=np.float32)
+    W1 = cases.randn(1604, 2, 256, 2, dtype=np.float32)
+    W2 = cases.randn(1605, 2, 256, 2, dtype=np.float32)
+    out = {}
+    for name, want_inv in (("both", True), ("root", False)):
+        Ct, dt = T(C).clone().requires_grad_(True), T(d).clone().requires_grad_(True)
+        A = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+        root, inv = RootDecomposition.apply(A.representation_tree(), 12, A.dtype, A.device, A.batch_shape,
+                                            A.matrix_shape, True, want_inv, T(v1), *A.representation())
+        loss = ((root @ (root.mT @ T(tv))) * T(W1)).sum()
+        if want_inv:
+            loss = loss + ((inv @ (inv.mT @ T(tv))) * T(W2)).sum()
+        loss.backward()
+        out[f"{name}_loss"], out[f"{name}_dC"], out[f"{name}_dd"] = loss.detach(), Ct.grad, dt.grad
+    Kd, dd, _ = cases.dense_diag(1606, 1, 40, 1)
+    M0 = (T(Kd[0]) + torch.diag_embed(T(dd[0])))
+    v2 = cases.randn(1607, 40, 1, dtype=np.float32)
+    w = cases.randn(1608, 40, dtype=np.float32)
+    sdiag = cases.randn(1609, 40, dtype=np.float32)
+    Ws = cases.randn(1610, 40, 40, dtype=np.float32)
+    M = M0.clone().requires_grad_(True)
+    with mock.patch("linear_operator.utils.lanczos.torch.randn", side_effect=lambda *a, dtype=None, device=None, **k: T(v2)):
+        evals, evecs = DenseLinearOperator(M).diagonalization(method="lanczos")
+    q = evecs.to_dense()
+    order = torch.argsort(evals)  # (fix the eigenvalue order: the weights must meet the same eigenpairs everywhere)
+    evs, qs = evals[order], q[:, order]
+    loss = (evs * T(w)).sum() + (((qs * T(sdiag)) @ qs.mT) * T(Ws)).sum()
+    loss.backward()
+    out["diag_loss"], out["diag_dM"], out["diag_M"] = loss.detach(), M.grad, M0
+    save("g15_lanczos_consumers_backward", checksum=cases.checksum(C, d, v1, tv, W1, W2, Kd, dd, v2, w, sdiag, Ws),
+         v2=v2, **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
                      ("g9", g9_backward), ("g10", g10_backward_preconditioned), ("g11", g11_diagonalization),
                      ("g12", g12_kronecker_added_diag), ("g13", g13_minres),
-                     ("g14", g14_sqrt_inv_matmul)):
+                     ("g14", g14_sqrt_inv_matmul), ("g15", g15_lanczos_consumers_backward)):
         if name in todo:
             fn()
     print("done")

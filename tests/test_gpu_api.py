@@ -642,3 +642,46 @@ def test_sqrt_inv_matmul_contour_integral_quadrature():
     v = lo.sqrt_inv_matmul(A1, dev(rhs[0, :, 0]))
     assert tuple(v.shape) == (300,)
     assert np.abs(host(v) - g["exact_inv_sqrt"][0, :, 0]).max() < 5e-4 * np.abs(g["exact_inv_sqrt"][0, :, 0]).max()
+
+
+def test_backward_of_root_decomposition_and_diagonalization():
+    """RootDecomposition.backward / Diagonalization.backward (reference functions/_root_decomposition.py:104-171,
+    _diagonalization.py:62-88): gradients of sign-invariant losses against golden g15 (the reference's autograd)."""
+    from linear_operator_amd.functions._root_decomposition import RootDecomposition
+
+    g = load_golden("g15_lanczos_consumers_backward")
+    C, d, _ = cases.lowrank_diag(1601, 2, 256, 8, 1)
+    v1 = cases.randn(1602, 2, 256, 1, dtype=np.float32)
+    tv = cases.randn(1603, 2, 256, 2, dtype=np.float32)
+    W1 = cases.randn(1604, 2, 256, 2, dtype=np.float32)
+    W2 = cases.randn(1605, 2, 256, 2, dtype=np.float32)
+    w = cases.randn(1608, 40, dtype=np.float32)
+    sdiag = cases.randn(1609, 40, dtype=np.float32)
+    Ws = cases.randn(1610, 40, 40, dtype=np.float32)
+
+    def close(a, b, rel):
+        a, b = host(a), np.asarray(b)
+        return a.shape == b.shape and np.abs(a - b).max() <= rel * np.abs(b).max()
+
+    for name, want_inv in (("both", True), ("root", False)):
+        Ct, dt = dev(C).clone().requires_grad_(True), dev(d).clone().requires_grad_(True)
+        A = AddedDiagLinearOperator(LowRankRootLinearOperator(Ct), DiagLinearOperator(dt))
+        root, inv = RootDecomposition.apply(A.representation_tree(), 12, A.dtype, A.device, A.batch_shape,
+                                            A.matrix_shape, True, want_inv, dev(v1), *A.representation())
+        loss = ((root @ (root.mT @ dev(tv))) * dev(W1)).sum()
+        if want_inv:
+            loss = loss + ((inv @ (inv.mT @ dev(tv))) * dev(W2)).sum()
+        loss.backward()
+        assert abs(loss.item() - float(g[f"{name}_loss"])) < 2e-2 * abs(float(g[f"{name}_loss"]))
+        assert close(Ct.grad, g[f"{name}_dC"], 3e-2) and close(dt.grad, g[f"{name}_dd"], 3e-2)
+    M = dev(g["diag_M"]).clone().requires_grad_(True)
+    with mock.patch("linear_operator_amd.utils.lanczos.torch.randn", side_effect=lambda *a, **k: dev(g["v2"])):
+        evals, evecs = DenseLinearOperator(M).diagonalization(method="lanczos")
+    q = evecs.to_dense()
+    order = torch.argsort(evals)
+    evs, qs = evals[order], q[:, order]
+    loss = (evs * dev(w)).sum() + (((qs * dev(sdiag)) @ qs.mT) * dev(Ws)).sum()
+    loss.backward()
+    assert abs(loss.item() - float(g["diag_loss"])) < 2e-2 * abs(float(g["diag_loss"]))
+    gm, rm = host(M.grad), g["diag_dM"]
+    assert np.abs(0.5 * (gm + gm.T) - 0.5 * (rm + rm.T)).max() < 5e-2 * np.abs(rm).max()

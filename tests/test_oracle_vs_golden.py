@@ -453,6 +453,41 @@ def test_g14_contour_integral_quadrature():
     assert np.allclose(iq, g["l_iq"], rtol=1e-3)
 
 
+def test_g15_backward_of_lanczos_consumers():
+    """RootDecomposition.backward / Diagonalization.backward restated on top of the oracle's forward passes: gradients
+    of sign-invariant losses against the reference's autograd (fp32 Lanczos bases: percent-level agreement)."""
+    g = load_golden("g15_lanczos_consumers_backward")
+    C, d, _ = cases.lowrank_diag(1601, 2, 256, 8, 1)
+    v1 = cases.randn(1602, 2, 256, 1, dtype=np.float32)
+    tv = cases.randn(1603, 2, 256, 2, dtype=np.float32)
+    W1 = cases.randn(1604, 2, 256, 2, dtype=np.float32)
+    W2 = cases.randn(1605, 2, 256, 2, dtype=np.float32)
+    Kd, dd, _ = cases.dense_diag(1606, 1, 40, 1)
+    w = cases.randn(1608, 40, dtype=np.float32)
+    sdiag = cases.randn(1609, 40, dtype=np.float32)
+    Ws = cases.randn(1610, 40, 40, dtype=np.float32)
+    mv = lambda v: orc.matvec_lowrank_diag(C.astype(np.float64), d.astype(np.float64), v)  # noqa: E731
+    close = lambda a, b, rel: np.abs(a - b).max() <= rel * np.abs(b).max()  # noqa: E731
+    T_ = lambda a: np.swapaxes(a, -1, -2)  # noqa: E731
+    # forward in fp64 (the gradient formulas are what is under test), one probe vector
+    root, inv = orc.root_decomposition(mv, v1.astype(np.float64), 12)
+    evals = (root ** 2).sum(-2)  # R = Q sqrt(lambda) with orthonormal Q columns
+    q = root / np.sqrt(evals)[..., None, :]
+    tv64 = tv.astype(np.float64)
+    # d/dR of sum((R R^T t) o W) = W (R^T t)^T + t (R^T W)^T
+    gR = W1 @ T_(T_(root) @ tv64) + tv64 @ T_(T_(root) @ W1)
+    gI = W2 @ T_(T_(inv) @ tv64) + tv64 @ T_(T_(inv) @ W2)
+    for name, gi in (("both", gI), ("root", None)):
+        left, right = orc.root_decomposition_backward(q, evals, gR, gi)
+        assert close(g[f"{name}_dC"], orc.bilinear_derivative_root(C.astype(np.float64), left, right), 3e-2)
+        assert close(g[f"{name}_dd"], orc.bilinear_derivative_diag(left, right), 3e-2)
+    M = g["diag_M"].astype(np.float64)
+    ev, Q = np.linalg.eigh(M)  # complete decomposition, ascending like the golden's ordering
+    dq = (Ws + Ws.T) @ (Q * sdiag)  # d/dQ of sum((Q diag(s) Q^T) o Ws)
+    dM = orc.diagonalization_backward(Q, ev, w.astype(np.float64), dq)
+    assert close(0.5 * (g["diag_dM"] + g["diag_dM"].T), 0.5 * (dM + dM.T), 5e-2)
+
+
 def test_g9_backward_passes():
     """gradients the reference's autograd Functions produce for Matmul / Solve / InvQuad /
     InvQuadLogdet, restated with the oracle's CG and the closed-form `_bilinear_derivative` contractions."""
