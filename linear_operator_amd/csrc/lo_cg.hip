@@ -620,58 +620,58 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     }
     if (rc && rc != LO_ERR_UNSUPPORTED) return rc;
     if (rc == LO_OK) {  // (LO_ERR_UNSUPPORTED: no resident kernel fits this device / shape -> streaming engine)
-    const int ktri = prm->n_tridiag ? std::min(a.iters, (int)prm->max_tridiag_iter) : 0;
-    const unsigned tri_grid = (unsigned)(((size_t)B * std::max(1, (int)prm->n_tridiag) + kThreads - 1) / kThreads);
-    if (ktri) {
-      LO_HIP_CHECK(hipMemsetAsync(d.oc_maxoff, 0, sizeof(int) * (prm->max_tridiag_iter + 1), st));
-      hipLaunchKernelGGL(k_oc_maxoff, dim3(tri_grid), block, 0, st, d, d.oc_ab, ktri);
-    }
-    hipLaunchKernelGGL(k_cg_ctrl_onchip, dim3(1), block, 0, st, d, d.oc_resid, d.oc_init_conv, a.iters, ktri);
-    if (ktri) hipLaunchKernelGGL(k_oc_tridiag, dim3(tri_grid), block, 0, st, d, d.oc_ab, ktri);
-    LO_LAUNCH_CHECK();
-    int oc_err = 0;
-    LO_HIP_CHECK(hipMemcpyAsync(&oc_err, d.oc_err, sizeof(int), hipMemcpyDeviceToHost, st));
-    LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
-    LO_HIP_CHECK(hipStreamSynchronize(st));
-    if (oc_dbg) {
-      long long ts[10];
-      LO_HIP_CHECK(hipMemcpy(ts, a.dbg, sizeof(ts), hipMemcpyDeviceToHost));
-      fprintf(stderr, "onchip member0 (100 MHz ticks): load %lld init %lld iters %lld store %lld | wg-wait %lld publish %lld poll %lld\n",
-              ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5], ts[6], ts[7]);
-    }
-    if (oc_err == 0) {
-      k_start = a.iters;
-    } else {  // a group hand-off timed out: redo everything with the streaming engine
-      fprintf(stderr, "liblo_amd: operator-resident CG timed out, falling back to the streaming engine\n");
-      LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, sizeof(CgCtrl), st));
-      memset(&h, 0, sizeof(h));
-    }
+      const int ktri = prm->n_tridiag ? std::min(a.iters, (int)prm->max_tridiag_iter) : 0;
+      const unsigned tri_grid = (unsigned)(((size_t)B * std::max(1, (int)prm->n_tridiag) + kThreads - 1) / kThreads);
+      if (ktri) {
+        LO_HIP_CHECK(hipMemsetAsync(d.oc_maxoff, 0, sizeof(int) * (prm->max_tridiag_iter + 1), st));
+        hipLaunchKernelGGL(k_oc_maxoff, dim3(tri_grid), block, 0, st, d, d.oc_ab, ktri);
+      }
+      hipLaunchKernelGGL(k_cg_ctrl_onchip, dim3(1), block, 0, st, d, d.oc_resid, d.oc_init_conv, a.iters, ktri);
+      if (ktri) hipLaunchKernelGGL(k_oc_tridiag, dim3(tri_grid), block, 0, st, d, d.oc_ab, ktri);
+      LO_LAUNCH_CHECK();
+      int oc_err = 0;
+      LO_HIP_CHECK(hipMemcpyAsync(&oc_err, d.oc_err, sizeof(int), hipMemcpyDeviceToHost, st));
+      LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
+      LO_HIP_CHECK(hipStreamSynchronize(st));
+      if (oc_dbg) {
+        long long ts[10];
+        LO_HIP_CHECK(hipMemcpy(ts, a.dbg, sizeof(ts), hipMemcpyDeviceToHost));
+        fprintf(stderr, "onchip member0 (100 MHz ticks): load %lld init %lld iters %lld store %lld | wg-wait %lld publish %lld poll %lld\n",
+                ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5], ts[6], ts[7]);
+      }
+      if (oc_err == 0) {
+        k_start = a.iters;
+      } else {  // a group hand-off timed out: redo everything with the streaming engine
+        fprintf(stderr, "liblo_amd: operator-resident CG timed out, falling back to the streaming engine\n");
+        LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, sizeof(CgCtrl), st));
+        memset(&h, 0, sizeof(h));
+      }
     }
   }
   int matvecs = 0;
   if (k_start == 0) {
-  // ---- initialisation (linear_cg.py:177-215) ----
-  rc = vec_dot_part(rhs, rhs, c, d.pAp_part, B, N, sp, nullptr, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_cg_init_scal, dim3(1), block, 0, st, d, d.pAp_part);
-  hipLaunchKernelGGL(k_cg_init_vec, gridv, block, 0, st, d, rhs, x0, sp.rows);
-  LO_LAUNCH_CHECK();
-  if (x0) {
-    rc = matvec_run(&pl, d.x, d.Ap, nullptr, nullptr, st);
+    // ---- initialisation (linear_cg.py:177-215) ----
+    rc = vec_dot_part(rhs, rhs, c, d.pAp_part, B, N, sp, nullptr, st);
     if (rc) return rc;
-    ++matvecs;
-    const size_t nv = (size_t)B * N * c;
-    hipLaunchKernelGGL(k_cg_sub, dim3((unsigned)std::min<size_t>((nv + 255) / 256, 8192)), block, 0, st, d.r, d.Ap, nv);
+    hipLaunchKernelGGL(k_cg_init_scal, dim3(1), block, 0, st, d, d.pAp_part);
+    hipLaunchKernelGGL(k_cg_init_vec, gridv, block, 0, st, d, rhs, x0, sp.rows);
     LO_LAUNCH_CHECK();
-  }
-  rc = vec_dot_part(d.r, d.r, c, d.rr_part, B, N, sp, nullptr, st);
-  if (rc) return rc;
-  if (precond) {
-    rc = apply_precond(d.r, d.z, d.rz_part);
+    if (x0) {
+      rc = matvec_run(&pl, d.x, d.Ap, nullptr, nullptr, st);
+      if (rc) return rc;
+      ++matvecs;
+      const size_t nv = (size_t)B * N * c;
+      hipLaunchKernelGGL(k_cg_sub, dim3((unsigned)std::min<size_t>((nv + 255) / 256, 8192)), block, 0, st, d.r, d.Ap, nv);
+      LO_LAUNCH_CHECK();
+    }
+    rc = vec_dot_part(d.r, d.r, c, d.rr_part, B, N, sp, nullptr, st);
     if (rc) return rc;
-  }
-  hipLaunchKernelGGL(k_cg_ctrl_init, dim3(1), block, 0, st, d);
-  LO_LAUNCH_CHECK();
+    if (precond) {
+      rc = apply_precond(d.r, d.z, d.rz_part);
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_cg_ctrl_init, dim3(1), block, 0, st, d);
+    LO_LAUNCH_CHECK();
   }  // k_start == 0
 
   // ---- iterations ----
