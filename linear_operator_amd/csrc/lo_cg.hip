@@ -14,6 +14,7 @@
 //   precond    z = P^-1 r ; rz_part = sum r o z                 (:268, :35-36 fused)
 //   ctrl       beta (:34-42), residual norms (:298-300), stop rule (:302-308), tridiag (:311-332)
 #include <algorithm>
+#include <cstddef>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -434,7 +435,7 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   dd.ctrl_part = ar.take<float>(3 * 256);
   // operator-resident fast path scratch (c == 1): granule buffer, error word, per-iteration residuals
   dd.oc_gbuf = ar.take<unsigned long long>(onchip_gbuf_bytes(64) / sizeof(unsigned long long));
-  dd.oc_err = ar.take<int>(4);  // [0] error word, [1] member counter of the dynamic hand-out
+  dd.oc_err = reinterpret_cast<int*>(reinterpret_cast<char*>(dd.ctrl) + offsetof(CgCtrl, oc_err));  // (+ oc_next)
   int oc_iters = std::min(10, prm->max_iter - 1);
   if (prm->n_tridiag) oc_iters = std::max(oc_iters, std::min(prm->max_tridiag_iter, prm->max_iter - 1));
   oc_iters = std::max(1, oc_iters + 1);
@@ -561,6 +562,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
 
   // ---- operator-resident fast path for the guaranteed iterations (lo_cg_onchip.hip) ----
   int k_start = 0;
+  bool x_written = false;  // the resident kernel already wrote result * rhs_norm
   CgCtrl h;
   memset(&h, 0, sizeof(h));
   int kfloor0 = std::min(10, prm->max_iter - 1);
@@ -598,6 +600,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.iters = kfloor0 + 1;
     a.eps = prm->eps; a.stop_after = prm->stop_updating_after;
     a.x = d.x; a.r = d.r; a.p = d.p; a.z = d.z;
+    a.xout = oc_gen2 ? x : nullptr;
     a.rhs_norm = d.rhs_norm; a.rz = d.rz; a.alpha = d.alpha; a.beta = d.beta; a.resid_norm = d.resid_norm;
     a.rhs_is_zero = d.rhs_is_zero; a.has_conv = d.has_conv;
     a.resid_rec = d.oc_resid; a.init_conv = d.oc_init_conv; a.gbuf = d.oc_gbuf; a.err = d.oc_err; a.next_member = d.oc_err + 1;
@@ -608,11 +611,12 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.dbg_member = oc_dbg ? atoi(getenv("LO_OC_DEBUG")) : 0;  // LO_OC_DEBUG=<member index to time>
     LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(64), st));  // whole allocation (either generation)
     // LO_OC_TEST_FALLBACK: start with the error word set, as if a hand-off had timed out (exercises the host fallback)
-    LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 0, 4 * sizeof(int), st));
+    // (error word and member counter live in the control block: cleared with it, copied back with it)
     if (getenv("LO_OC_TEST_FALLBACK")) LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 1, 1, st));
     if (oc_dbg) LO_HIP_CHECK(hipMemsetAsync(a.dbg, 0, 10 * sizeof(long long), st));
     rc = LO_ERR_UNSUPPORTED;
     if (oc_gen2) rc = onchip4_launch(pl.R4, ocR4, a, oc_nwg, st);
+    const bool oc_gen2_ran = oc_gen2 && rc == LO_OK;
     if (rc == LO_ERR_UNSUPPORTED && oc_gen1_ok) {
       a.GW = 8;
       a.RW = (int)((N + 7) / 8);
@@ -629,10 +633,9 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       hipLaunchKernelGGL(k_cg_ctrl_onchip, dim3(1), block, 0, st, d, d.oc_resid, d.oc_init_conv, a.iters, ktri);
       if (ktri) hipLaunchKernelGGL(k_oc_tridiag, dim3(tri_grid), block, 0, st, d, d.oc_ab, ktri);
       LO_LAUNCH_CHECK();
-      int oc_err = 0;
-      LO_HIP_CHECK(hipMemcpyAsync(&oc_err, d.oc_err, sizeof(int), hipMemcpyDeviceToHost, st));
       LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
       LO_HIP_CHECK(hipStreamSynchronize(st));
+      const int oc_err = h.oc_err;
       if (oc_dbg) {
         long long ts[10];
         LO_HIP_CHECK(hipMemcpy(ts, a.dbg, sizeof(ts), hipMemcpyDeviceToHost));
@@ -641,6 +644,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       }
       if (oc_err == 0) {
         k_start = a.iters;
+        x_written = (a.xout != nullptr) && oc_gen2_ran;
       } else {  // a group hand-off timed out: redo everything with the streaming engine
         fprintf(stderr, "liblo_amd: operator-resident CG timed out, falling back to the streaming engine\n");
         LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, sizeof(CgCtrl), st));
@@ -740,9 +744,11 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     rc = poll();
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_cg_final, gridv, block, 0, st, d, x, sp.rows);
-  LO_LAUNCH_CHECK();
-  LO_HIP_CHECK(hipStreamSynchronize(st));
+  if (!(x_written && launched == k_start)) {  // (no streaming iteration after the resident phase: x is final already)
+    hipLaunchKernelGGL(k_cg_final, gridv, block, 0, st, d, x, sp.rows);
+    LO_LAUNCH_CHECK();
+    LO_HIP_CHECK(hipStreamSynchronize(st));
+  }
 
   info->iterations = h.iterations;
   info->matvecs = matvecs + h.iterations;

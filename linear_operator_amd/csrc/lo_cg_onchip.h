@@ -22,6 +22,7 @@ struct OnchipArgs {
   float eps, stop_after;
   // state out (streaming engine layout, c == 1)
   float *x, *r, *p, *z;
+  float* xout;        // second generation: result.mul(rhs_norm) (linear_cg.py:335) written along with the state, or nullptr
   float *rhs_norm, *rz, *alpha, *beta, *resid_norm;
   int *rhs_is_zero, *has_conv;
   float* resid_rec;   // [iters, B, c] residual norm after each iteration (for the stop rule / NaN check)

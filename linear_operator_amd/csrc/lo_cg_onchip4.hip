@@ -437,6 +437,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip4(OnchipA
       if (tw + R4_TPB * q < nv) {
         const size_t o = ((size_t)b * a.N + row0 + tw + R4_TPB * q) * nc + col;
         a.x[o] = x_s[t + R4_TPB * q];
+        if (a.xout) a.xout[o] = x_s[t + R4_TPB * q] * nrm;  // final when the stop rule holds at the floor (:335)
         a.r[o] = r[q];
         a.p[o] = p[q];
         if (a.z) a.z[o] = z[q];  // no z buffer in the unpreconditioned engine (z = r)

@@ -73,6 +73,8 @@ struct CgCtrl {
   int last_tridiag_iter;
   int tri_disabled;       // update_tridiag == False (linear_cg.py:326-327)
   float mean_resid;
+  int oc_err;             // operator-resident kernels: a group exchange timed out (host falls back to streaming)
+  int oc_next;            // operator-resident kernels: shared counter of the dynamic member hand-out
 };
 
 // fused-update arguments of the skinny tn kernels (VMODE 1: p-update, VMODE 2: r/x-update; see lo_skinny.hip)
