@@ -262,19 +262,20 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip4(OnchipA
       d_s[lr] = dq;
       dinv_s[lr] = diq;
     }
-    {  // Q rows -> LDS, coalesced and swizzled, one row-slot group (R4_NR float4 per thread) at a time: the loads
-       // in flight stay within the VGPR budget next to the 128 registers of C
+    {  // Q rows -> LDS, coalesced and swizzled, QB float4 per thread in flight at a time (next to the loads of C that
+       // are still landing in their 128 registers; nothing else is live in this phase)
       const float4* qsrc = reinterpret_cast<const float4*>(a.Q + ((size_t)b * a.N + row0) * RK);
+      constexpr int QB = R4_NR * NQ;  // (all of them: 64 registers for RK = 16)
 #pragma unroll
-      for (int i0 = 0; i0 < R4_NR * NQ; i0 += R4_NR) {
-        float4 v[R4_NR];
+      for (int i0 = 0; i0 < R4_NR * NQ; i0 += QB) {
+        float4 v[QB];
 #pragma unroll
-        for (int i = 0; i < R4_NR; ++i) {
+        for (int i = 0; i < QB; ++i) {
           const int f = (i0 + i) * R4_TPB + tl;
           v[i] = (f / NQ < nv) ? qsrc[f] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int i = 0; i < R4_NR; ++i) {
+        for (int i = 0; i < QB; ++i) {
           const int f = (i0 + i) * R4_TPB + tl;
           q_s[q_slot<NQ>(f / NQ, f % NQ)] = v[i];
         }
