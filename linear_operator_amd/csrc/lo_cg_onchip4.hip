@@ -265,7 +265,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip4(OnchipA
     {  // Q rows -> LDS, coalesced and swizzled, QB float4 per thread in flight at a time (next to the loads of C that
        // are still landing in their 128 registers; nothing else is live in this phase)
       const float4* qsrc = reinterpret_cast<const float4*>(a.Q + ((size_t)b * a.N + row0) * RK);
-      constexpr int QB = R4_NR * NQ;  // (all of them: 64 registers for RK = 16)
+      constexpr int QB = (R4_NR * NQ >= 8) ? 8 : R4_NR * NQ;  // (16 at once measured slower)
 #pragma unroll
       for (int i0 = 0; i0 < R4_NR * NQ; i0 += QB) {
         float4 v[QB];
