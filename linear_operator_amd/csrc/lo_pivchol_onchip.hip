@@ -578,6 +578,8 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
       // Schur update of row m for the 4 rows of this thread IN LOCKSTEP: the products and sums of a row are a
       // dependent chain in the mandated order, the 4 rows give the instruction-level parallelism (computed for every
       // row, applied below only where the reference writes)
+      long long d0 = 0, d1 = 0, d2 = 0;
+      if (stamp) d0 = wall_clock64();
       float rowv[P4_NR], accs[P4_NR];
 #pragma unroll
       for (int q = 0; q < P4_NR; ++q) rowv[q] = gc[0] * Cr[q][0];
@@ -585,6 +587,7 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
       for (int r = 1; r < RC; ++r)
 #pragma unroll
         for (int q = 0; q < P4_NR; ++q) rowv[q] = rowv[q] + gc[r] * Cr[q][r];
+      if (stamp) { asm volatile("" :: "v"(rowv[0]), "v"(rowv[1]), "v"(rowv[2]), "v"(rowv[3])); d1 = wall_clock64(); }
 #pragma unroll
       for (int q = 0; q < P4_NR; ++q) accs[q] = 0.f;
       for (int j4 = 0; 4 * j4 < m; ++j4) {  // :83-89, sequential in j
@@ -608,22 +611,24 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
           for (int q = 0; q < P4_NR; ++q) accs[q] = accs[q] + u4.w * l4[q].w;
         }
       }
+      if (stamp) { asm volatile("" :: "v"(accs[0]), "v"(accs[1]), "v"(accs[2]), "v"(accs[3])); d2 = wall_clock64(); a.dbg[7] += d0 - c2; a.dbg[8] += d1 - d0; a.dbg[9] += d2 - d1; }
+      // write-back without divergent control flow: the four quotients are formed in lockstep (independent divisions),
+      // the new L entry is ONE 4-byte LDS store into its 16-byte slot (no read-modify-write of the float4)
       const int ms = m >> 2, me = m & 3;
+      float vq[P4_NR];
+#pragma unroll
+      for (int q = 0; q < P4_NR; ++q) vq[q] = ((m > 0) ? rowv[q] - accs[q] : rowv[q]) / piv;  // :91
 #pragma unroll
       for (int q = 0; q < P4_NR; ++q) {
-        if (pos[q] == PO_INVALID) continue;
+        const int pq = pos[q];
+        const bool live = pq != PO_INVALID;
         // permutation swap of positions m and jb (:67-70), tracked per row
-        if (pos[q] == jb) pos[q] = m;
-        else if (pos[q] == m) pos[q] = jb;
-        if (pos[q] < m) continue;  // already pivoted rows keep L[m] = 0
-        const int lr = t + P4_TPB * q;
-        float v = (m > 0) ? rowv[q] - accs[q] : rowv[q];
-        v = v / piv;                                   // :91
-        const float val = (pos[q] == m) ? piv : v;     // the pivot row gets sqrt(max) (:73-74)
-        float4 l4 = l_s[l_slot(lr, ms)];
-        if (me == 0) l4.x = val; else if (me == 1) l4.y = val; else if (me == 2) l4.z = val; else l4.w = val;
-        l_s[l_slot(lr, ms)] = l4;
-        if (pos[q] > m) dg[q] = dg[q] - v * v;         // :94-95
+        const int np = (pq == jb) ? m : ((pq == m) ? jb : pq);
+        if (live) pos[q] = np;
+        const float val = (np == m) ? piv : vq[q];  // the pivot row gets sqrt(max) (:73-74)
+        if (live && np >= m)                         // already pivoted rows keep L[m] = 0
+          reinterpret_cast<float*>(&l_s[l_slot(t + P4_TPB * q, ms)])[me] = val;
+        if (live && np > m) dg[q] = dg[q] - vq[q] * vq[q];  // :94-95
       }
       // sh.gath / sh.part are next written after the barrier that follows the candidate reduction
       if (stamp) {
@@ -737,7 +742,7 @@ static void po_layout(const lo_op_desc* op, int max_rank, Arena& ar, PoLayout* l
   l->orig = ar.take<float>(B);
   l->swaps = ar.take<int>((size_t)B * max_rank);
   l->gbuf = ar.take<unsigned long long>((size_t)64 * 2 * PO_GW * PO_SLOT);
-  l->dbg = ar.take<long long>(8);
+  l->dbg = ar.take<long long>(12);
 }
 
 size_t pc_onchip_workspace_bytes(const lo_op_desc* op, int max_rank) {
@@ -798,7 +803,7 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
   const bool debug = getenv("LO_OC_DEBUG") != nullptr;
   a.dbg = debug ? l.dbg : nullptr;
-  if (debug) LO_HIP_CHECK(hipMemsetAsync(l.dbg, 0, 8 * sizeof(long long), st));
+  if (debug) LO_HIP_CHECK(hipMemsetAsync(l.dbg, 0, 12 * sizeof(long long), st));
   LO_HIP_CHECK(hipMemsetAsync(l.err, 0, 4 * sizeof(int), st));
   if (getenv("LO_OC_TEST_FALLBACK")) LO_HIP_CHECK(hipMemsetAsync(l.err, 1, 1, st));  // as if an exchange had timed out
   LO_HIP_CHECK(hipMemsetAsync(l.gbuf, 0, sizeof(unsigned long long) * (size_t)64 * 2 * PO_GW * PO_SLOT, st));
@@ -831,10 +836,11 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   LO_HIP_CHECK(hipMemcpyAsync(h, l.err, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   LO_HIP_CHECK(hipStreamSynchronize(st));
   if (debug) {
-    long long ts[8];
+    long long ts[12];
     LO_HIP_CHECK(hipMemcpy(ts, l.dbg, sizeof(ts), hipMemcpyDeviceToHost));
     fprintf(stderr, "pc_onchip member0 (100 MHz ticks): load %lld pivots %lld store %lld | reduce+publish %lld gather %lld update %lld\n",
             ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4], ts[5], ts[6]);
+    fprintf(stderr, "  update split: winner+row fetch %lld, C.C chain %lld, L.L chain %lld\n", ts[7], ts[8], ts[9]);
   }
   if (h[0]) return LO_ERR_LAUNCH;
   *rank_out = h[1];
