@@ -9,6 +9,7 @@
 // The two data-dependent decisions are batch-global; a single-workgroup control kernel takes them on the
 // device and the host reads one word per decision (the reference does the same through bool(tensor)).
 #include <algorithm>
+#include <stdlib.h>
 #include <cstring>
 #include <stdint.h>
 
@@ -356,22 +357,31 @@ __global__ __launch_bounds__(kThreads) void k_lz_scal(LzDev d, int what, int ti,
   }
 }
 
-// r = Aq - beta_prev * q_prev  (:108), beta_prev = t[k, k-1]
-__global__ __launch_bounds__(kThreads) void k_lz_sub_prev(LzDev d, int k) {
+
+// r -= beta_{k-1} q_{k-1} (:108) and the partials of alpha_k = q_k . r (:109) in one pass
+__global__ __launch_bounds__(kThreads) void k_lz_sub_prev_dot(LzDev d, int k) {
+  __shared__ float red[kThreads];
   const int s = blockIdx.x;
   const int64_t b = blockIdx.y;
   const int c = d.P, N = (int)d.N;
   const int nrs = kThreads / c;
   const int col = threadIdx.x % c, slot = threadIdx.x / c;
-  if (slot >= nrs) return;
   const int r0 = s * d.rows, r1 = min(N, r0 + d.rows);
-  const size_t base = (size_t)b * N * c + col;
-  const float beta = tptr(d, k, k - 1)[(size_t)b * c + col];
-  const float* qp = d.q + qoff(d, k - 1);
-  for (int row = r0 + slot; row < r1; row += nrs) {
-    const size_t i = base + (size_t)row * c;
-    d.r[i] = d.r[i] - qp[i] * beta;
+  float acc = 0.f;
+  if (slot < nrs) {
+    const size_t base = (size_t)b * N * c + col;
+    const float beta = tptr(d, k, k - 1)[(size_t)b * c + col];
+    const float* qp = d.q + qoff(d, k - 1);
+    const float* qk = d.q + qoff(d, k);
+    for (int row = r0 + slot; row < r1; row += nrs) {
+      const size_t i = base + (size_t)row * c;
+      const float rv = d.r[i] - qp[i] * beta;
+      d.r[i] = rv;
+      acc = fmaf(qk[i], rv, acc);
+    }
   }
+  const float tot = block_colsum(slot < nrs ? acc : 0.f, c, nrs, red);
+  if (threadIdx.x < c) d.part[(((size_t)b * d.S + s) * (d.max_iter + 1)) * c + col] = tot;
 }
 
 // q_mat [kstore, B, N, P] (working order, :69-76) -> [P, B, N, k] (returned order, lanczos.py:154): LDS-tiled
@@ -507,21 +517,21 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
   // float4 kernels: P a power of two in 4 .. 64 (column quads per row 1 .. 16), 16-byte aligned rows
   const bool vec4 = (P == 4 || P == 8 || P == 16 || P == 32 || P == 64) && ((uintptr_t)q_mat % 16) == 0 &&
                     ((uintptr_t)d.r % 16) == 0 && ((uintptr_t)d.coef % 16) == 0;
-  auto multidot = [&](int nq) {
+  auto multidot = [&](const LzDev& d, int nq) {
     LO_PROF_BEGIN("lz_multidot", st);
     if (nq <= kLzMaxQ && vec4) hipLaunchKernelGGL((k_lz_multidot4<kLzMaxQ>), grid, block, 0, st, d, nq);
     else if (nq <= kLzMaxQ) hipLaunchKernelGGL((k_lz_multidot<kLzMaxQ>), grid, block, 0, st, d, nq);
     else hipLaunchKernelGGL(k_lz_multidot_any, grid, block, 0, st, d, nq);
     LO_PROF_END(st);
   };
-  auto correct = [&](int nq) {  // also leaves the partials of ||r||^2 in slot 0 of `part`
+  auto correct = [&](const LzDev& d, int nq) {  // also leaves the partials of ||r||^2 in slot 0 of `part`
     LO_PROF_BEGIN("lz_correct", st);
     if (nq <= kLzMaxQ && vec4) hipLaunchKernelGGL((k_lz_correct4<kLzMaxQ>), grid, block, 0, st, d, nq);
     else if (nq <= kLzMaxQ) hipLaunchKernelGGL((k_lz_correct<kLzMaxQ>), grid, block, 0, st, d, nq);
     else hipLaunchKernelGGL(k_lz_correct_any, grid, block, 0, st, d, nq);
     LO_PROF_END(st);
   };
-  auto reduce = [&](int nq, int check) {
+  auto reduce = [&](const LzDev& d, int nq, int check) {
     if (check) (void)hipMemsetAsync(&d.ctrl->need_reorth, 0, sizeof(int), st);
     LO_PROF_BEGIN("lz_reduce", st);
     hipLaunchKernelGGL(k_lz_reduce, dim3((unsigned)B), block, 0, st, d, nq, check);
@@ -567,11 +577,8 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
     for (k = 1; k < num_iter; ++k) {
       rc = matvec_run(&pl, q(k), d.r, nullptr, nullptr, st);  // :108
       if (rc) return rc;
-      LO_PROF_BEGIN("lz_sub_prev", st);
-      hipLaunchKernelGGL(k_lz_sub_prev, grid, block, 0, st, d, k);
-      LO_PROF_END(st);
-      LO_PROF_BEGIN("lz_dot", st);
-      hipLaunchKernelGGL(k_lz_dot, grid, block, 0, st, d, q(k), d.r);
+      LO_PROF_BEGIN("lz_sub_prev_dot", st);
+      hipLaunchKernelGGL(k_lz_sub_prev_dot, grid, block, 0, st, d, k);
       LO_PROF_END(st);
       LO_PROF_BEGIN("lz_scal", st);
       hipLaunchKernelGGL(k_lz_scal, one, block, 0, st, d, 1, k, k, 0, 0);  // alpha_k -> t[k,k]  (:109-111)
@@ -582,19 +589,22 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
         hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 1, q(k), d.r, d.scal);  // r -= alpha q_k  (:116)
         LO_PROF_END(st);
         // full re-orthogonalisation (:118-120)
-        multidot(k + 1);
-        reduce(k + 1, 0);
-        correct(k + 1);
-        // normalise (||r||^2 partials come out of the correction kernel); beta_k -> t[k,k+1], t[k+1,k]  (:121-128)
+        multidot(d, k + 1);
+        reduce(d, k + 1, 0);
+        correct(d, k + 1);
+        // normalise (||r||^2 partials come out of the correction kernel); beta_k -> t[k,k+1], t[k+1,k]  (:121-128);
+        // the normalised vector is written straight into its place q_{k+1} (:145) and checked / re-orthogonalised there
         LO_PROF_BEGIN("lz_scal", st);
         hipLaunchKernelGGL(k_lz_scal, one, block, 0, st, d, 0, k, k + 1, 1, 1);
         LO_PROF_END(st);
         LO_PROF_BEGIN("lz_axpy", st);
-        hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 0, d.r, d.r, d.scal);
+        hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 0, d.r, q(k + 1), d.scal);
         LO_PROF_END(st);
+        LzDev dn = d;
+        dn.r = q(k + 1);
         // inner products with the normalised r (:131)
-        multidot(k + 1);
-        reduce(k + 1, 1);
+        multidot(dn, k + 1);
+        reduce(dn, k + 1, 1);
         LO_LAUNCH_CHECK();
         LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(LzCtrl), hipMemcpyDeviceToHost, st));
         LO_HIP_CHECK(hipStreamSynchronize(st));
@@ -605,20 +615,19 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
             could = true;
             break;
           }
-          correct(k + 1);  // uses the coefficients just computed
+          correct(dn, k + 1);  // uses the coefficients just computed
           LO_PROF_BEGIN("lz_scal", st);
           hipLaunchKernelGGL(k_lz_scal, one, block, 0, st, d, 0, -1, -1, 0, 0);
           LO_PROF_END(st);
           LO_PROF_BEGIN("lz_axpy", st);
-          hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 0, d.r, d.r, d.scal);
+          hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 0, dn.r, dn.r, d.scal);
           LO_PROF_END(st);
-          multidot(k + 1);
-          reduce(k + 1, 1);
+          multidot(dn, k + 1);
+          reduce(dn, k + 1, 1);
           LO_LAUNCH_CHECK();
           LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(LzCtrl), hipMemcpyDeviceToHost, st));
           LO_HIP_CHECK(hipStreamSynchronize(st));
         }
-        LO_HIP_CHECK(hipMemcpyAsync(q(k + 1), d.r, sizeof(float) * nv, hipMemcpyDeviceToDevice, st));  // :145
         if (all_small || !could) break;  // :147
       }
     }
