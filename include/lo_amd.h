@@ -211,8 +211,10 @@ int lo_bilinear_dense_f32(const float* U, const float* V, int64_t B, int64_t N, 
 int lo_bilinear_diag_f32(const float* U, const float* V, int64_t B, int64_t N, int64_t D, int32_t constant, float* out,
                          void* ws, size_t ws_bytes, void* stream);
 size_t lo_bilinear_root_workspace_bytes(int64_t B, int64_t N, int64_t R, int64_t D);
+/* rowdot (optional, [B,N]): sum_d U o V of the same rows, i.e. the Diag derivative of an AddedDiag(Root, Diag)
+ * operator, produced in the same pass (NULL: not wanted).                                                          */
 int lo_bilinear_root_f32(const float* C, const float* U, const float* V, int64_t B, int64_t N, int64_t R, int64_t D,
-                         float* out, void* ws, size_t ws_bytes, void* stream);
+                         float* out, float* rowdot, void* ws, size_t ws_bytes, void* stream);
 
 /*   kron : dK1 [B,n1,n1] = sum_d U_d K2 V_d^T, dK2 [B,n2,n2] = sum_d U_d^T K1 V_d with U_d, V_d the [n1,n2] views of
  *          the columns (autograd of the Kronecker matvec, kronecker_product_linear_operator.py:34-45)            */

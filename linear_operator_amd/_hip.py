@@ -18,7 +18,7 @@ _lib = None
 
 LO_OP_LOWRANK_DIAG, LO_OP_DENSE_DIAG, LO_OP_KRON_DIAG, LO_OP_CALLBACK = 0, 1, 2, 3
 LO_DIAG_NONE, LO_DIAG_FULL, LO_DIAG_CONST = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 LO_ERR_UNSUPPORTED = -4
 _ERR = {-1: "bad argument", -2: "HIP launch/runtime failure", -3: "workspace too small", -4: "unsupported shape"}
@@ -169,7 +169,7 @@ def load():
     lib.lo_bilinear_root_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64]
     lib.lo_bilinear_root_f32.restype = C.c_int
     lib.lo_bilinear_root_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
-                                         C.c_void_p, C.c_void_p, sz, C.c_void_p]
+                                         C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p]
     lib.lo_bilinear_kron_workspace_bytes.restype = sz
     lib.lo_bilinear_kron_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64]
     lib.lo_bilinear_kron_f32.restype = C.c_int

@@ -214,9 +214,12 @@ __global__ __launch_bounds__(kThreads) void k_bil_root_t_mfma(const float* __res
 }
 
 // Root, phase B: out[b, n, rho] = sum_d U[n,d] T1[d,rho] + V[n,d] T2[d,rho], T = sum_s tpart (fixed order)
+// Optional `rowdot` [B, N] = sum_d U o V (the Diag derivative of an AddedDiag operator, diag_linear_operator.py:37-45):
+// the rows of U and V are in this thread's hands anyway.
 __global__ __launch_bounds__(kThreads) void k_bil_root_out(const float* __restrict__ U, const float* __restrict__ V,
                                                             const float* __restrict__ tpart, int S, int N, int R,
-                                                            int D, float* __restrict__ out) {
+                                                            int D, float* __restrict__ out,
+                                                            float* __restrict__ rowdot) {
   extern __shared__ float sh[];  // t1 [D][R] | t2 [D][R]
   const int64_t b = blockIdx.y;
   const int npair = D * R;
@@ -234,14 +237,17 @@ __global__ __launch_bounds__(kThreads) void k_bil_root_out(const float* __restri
   const float* u = U + ((size_t)b * N + row) * D;
   const float* v = V + ((size_t)b * N + row) * D;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float dot = 0.f;
   for (int d = 0; d < D; ++d) {
     const float ud = u[d], vd = v[d];
+    dot = fmaf(ud, vd, dot);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int rho = 4 * g + e;
       if (rho < R) acc[e] = fmaf(ud, sh[d * R + rho], fmaf(vd, sh[npair + d * R + rho], acc[e]));
     }
   }
+  if (rowdot && g == 0) rowdot[(size_t)b * N + row] = dot;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int rho = 4 * g + e;
@@ -294,7 +300,7 @@ size_t lo_bilinear_root_workspace_bytes(int64_t B, int64_t N, int64_t R, int64_t
 }
 
 int lo_bilinear_root_f32(const float* C, const float* U, const float* V, int64_t B, int64_t N, int64_t R, int64_t D,
-                         float* out, void* ws, size_t ws_bytes, void* stream) {
+                         float* out, float* rowdot, void* ws, size_t ws_bytes, void* stream) {
   if (!C || !U || !V || !out || !ws || B < 1 || N < 1 || R < 1 || D < 1 || B > 65535) return LO_ERR_BADARG;
   if (D * R > 8 * kThreads) return LO_ERR_UNSUPPORTED;
   const size_t lds_a = sizeof(float) * (size_t)kBrRows * (R + 2 * D), lds_b = sizeof(float) * (size_t)2 * D * R;
@@ -317,7 +323,7 @@ int lo_bilinear_root_f32(const float* C, const float* U, const float* V, int64_t
   const int64_t items = N * ((R + 3) / 4);
   LO_PROF_BEGIN("bil_root_out", st);
   hipLaunchKernelGGL(k_bil_root_out, dim3((unsigned)((items + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads),
-                     lds_b, st, U, V, tpart, sp.S, (int)N, (int)R, (int)D, out);
+                     lds_b, st, U, V, tpart, sp.S, (int)N, (int)R, (int)D, out, rowdot);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;

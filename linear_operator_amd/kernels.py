@@ -506,8 +506,9 @@ def bilinear_diag(left_vecs: torch.Tensor, right_vecs: torch.Tensor, batch_shape
     return out.reshape(*bs, 1) if constant else out.reshape(*bs, N)
 
 
-def bilinear_root(root: torch.Tensor, left_vecs: torch.Tensor, right_vecs: torch.Tensor):
-    """lo_bilinear_root_f32: U (V^T C) + V (U^T C) [*batch, N, R] for K = C C^T (autograd of the two-GEMM matvec)."""
+def bilinear_root(root: torch.Tensor, left_vecs: torch.Tensor, right_vecs: torch.Tensor, with_rowdot: bool = False):
+    """lo_bilinear_root_f32: U (V^T C) + V (U^T C) [*batch, N, R] for K = C C^T (autograd of the two-GEMM matvec).
+    `with_rowdot`: also return sum_d U o V [*batch, N] (the Diag derivative for the same factors) from the same pass."""
     lib = _hip.load()
     U, V, bs = _uv(left_vecs, right_vecs, root.shape[:-2])
     B, N, D = U.shape
@@ -516,9 +517,13 @@ def bilinear_root(root: torch.Tensor, left_vecs: torch.Tensor, right_vecs: torch
     _hip.require_hip(Cm)
     dev = U.device
     out = torch.empty(B, N, R, dtype=torch.float32, device=dev)
+    rowdot = torch.empty(B, N, dtype=torch.float32, device=dev) if with_rowdot else None
     ws = _hip.workspace(lib.lo_bilinear_root_workspace_bytes(B, N, R, D), dev)
-    _hip.check(lib.lo_bilinear_root_f32(_hip.ptr(Cm), _hip.ptr(U), _hip.ptr(V), B, N, R, D, _hip.ptr(out), _hip.ptr(ws),
-                                        ws.numel(), _hip.stream_ptr(dev)), "lo_bilinear_root_f32")
+    _hip.check(lib.lo_bilinear_root_f32(_hip.ptr(Cm), _hip.ptr(U), _hip.ptr(V), B, N, R, D, _hip.ptr(out),
+                                        _hip.ptr(rowdot), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)),
+               "lo_bilinear_root_f32")
+    if with_rowdot:
+        return out.reshape(*bs, N, R), rowdot.reshape(*bs, N)
     return out.reshape(*bs, N, R)
 
 

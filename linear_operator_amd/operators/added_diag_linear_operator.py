@@ -91,6 +91,22 @@ class AddedDiagLinearOperator(SumLinearOperator):
                 return K.matvec(desc, rhs.expand(*desc.batch_shape, *rhs.shape[-2:]))
         return torch.addcmul(self._linear_op._matmul(rhs), self._diag_tensor._diag.unsqueeze(-1), rhs)
 
+    def _bilinear_derivative(self, left_vecs: Tensor, right_vecs: Tensor):
+        """Sum rule (reference sum_linear_operator.py:59-62).  For a dense root plus a full diagonal both derivatives
+        -- U (V^T C) + V (U^T C) and sum_d U o V -- come out of ONE pass over the factors (csrc/lo_bilinear.hip)."""
+        root_op, diag_op = self._linear_op, self._diag_tensor
+        r = root_op._dense_root() if isinstance(root_op, RootLinearOperator) else None
+        fused = (r is not None and type(diag_op) is DiagLinearOperator and r.requires_grad
+                 and diag_op._diag.requires_grad and left_vecs.is_cuda and left_vecs.dtype == torch.float32)
+        if not fused:
+            return super()._bilinear_derivative(left_vecs, right_vecs)
+        d_root, d_diag = K.bilinear_root(r, left_vecs, right_vecs, with_rowdot=True)
+        d_root = d_root if tuple(d_root.shape) == tuple(r.shape) else d_root.sum_to_size(*r.shape)
+        dshape = diag_op._diag.shape
+        d_diag = d_diag if tuple(d_diag.shape) == tuple(dshape) else d_diag.sum_to_size(*dshape)
+        grads = {id(root_op): (d_root,), id(diag_op): (d_diag,)}
+        return tuple(g for op in self.linear_ops for g in grads[id(op)])
+
     def add_diagonal(self, diag: Tensor):
         return self.__class__(self._linear_op, self._diag_tensor.add_diagonal(diag))
 

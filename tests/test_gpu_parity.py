@@ -731,3 +731,8 @@ def test_bilinear_derivative_root_all_engines(N, R, D):
     ref = orc.bilinear_derivative_root(C.astype(np.float64), U.astype(np.float64), V.astype(np.float64))
     assert out.shape == ref.shape
     assert np.abs(out - ref).max() <= 2e-5 * np.abs(ref).max()
+    # the Diag derivative of the same factors from the same pass
+    out2, rowdot = K.bilinear_root(dev(C), dev(U), dev(V), with_rowdot=True)
+    assert torch.equal(out2, dev(out))
+    rd = orc.bilinear_derivative_diag(U.astype(np.float64), V.astype(np.float64))
+    assert np.abs(host(rowdot) - rd).max() <= 2e-5 * np.abs(rd).max()
