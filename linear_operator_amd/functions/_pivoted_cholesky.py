@@ -63,11 +63,14 @@ def _dense_root_vjp(r, perm, inv_perm, grad_L, m):
     with torch.enable_grad():
         l11 = psd_safe_cholesky(k11)
     l11d = l11.detach()
-    rest = torch.linalg.solve_triangular(l11d, krows[..., m:, :].mT, upper=False).mT  # K21 L11^-T
+    # the two N x m triangular solves become GEMMs with the explicit m x m inverse (m <= max_preconditioner_size)
+    eye = torch.eye(m, dtype=l11d.dtype, device=l11d.device).expand(*l11d.shape[:-2], m, m)
+    l11_inv = torch.linalg.solve_triangular(l11d, eye, upper=False)
+    rest = krows[..., m:, :] @ l11_inv.mT  # K21 L11^-T
     g2 = gp[..., m:, :]
-    lbar = gp[..., :m, :] - torch.linalg.solve_triangular(l11d.mT, g2.mT @ rest, upper=True)
+    lbar = gp[..., :m, :] - l11_inv.mT @ (g2.mT @ rest)
     (k11bar,) = torch.autograd.grad(l11, k11, grad_outputs=lbar)
-    k21bar = torch.linalg.solve_triangular(l11d, g2, upper=False, left=False)  # G2 L11^-1
+    k21bar = g2 @ l11_inv  # G2 L11^-1
     kbar = torch.cat([k11bar, k21bar], dim=-2)
     rp_bar = kbar @ rm
     rp_bar[..., :m, :] += kbar.mT @ rp
