@@ -44,37 +44,39 @@ class PivotedCholesky(Function):
         return tuple([None, None, None] + list(grads))
 
 
-def _dense_root_vjp(r, perm, inv_perm, grad_L, m):
+def _dense_root_vjp(r, perm, grad_L, m):
     """The same pull-back for K = R R^T written out by hand (a dozen passes over [*, N, m] / [*, N, R] data instead of
     the autograd tape of the generic re-expression); only the m x m Cholesky goes through autograd, so the
     triangular / symmetric conventions of its backward are the ones the generic path (and the reference) get.
-      Lp = [L11; K21 L11^-T],  K11 = chol^-1 ...:  with G = grad_L in pivot order, G = [G11; G2], Rest = K21 L11^-T:
+      pivoted factor = [L11; K21 L11^-T]:  with G = grad_L split into its pivot rows G11 and the others G2, Rest = K21 L11^-T:
       bar L11 = G11 - L11^-T (G2^T Rest),  bar K21 = G2 L11^-1,  bar K11 = chol_backward(bar L11),
       bar Rp = bar Krows Rm,  bar Rm += bar Krows^T Rp   (Krows = Rp Rm^T, Rm = the m pivot rows)."""
     from ..utils.cholesky import psd_safe_cholesky
 
     R = r.size(-1)
-    idx = perm.unsqueeze(-1)
-    rp = torch.gather(r, -2, idx.expand(*perm.shape, R))  # rows in pivot order
-    gp = torch.gather(grad_L.contiguous(), -2, idx.expand(*perm.shape, m))
-    rm = rp[..., :m, :]
-    krows = rp @ rm.mT  # K[perm][:, pivots]  [*, N, m]
-    k11 = krows[..., :m, :].detach().clone().requires_grad_(True)
+    # Everything stays in the ORIGINAL row order: only the m pivot rows are gathered / scattered (the factor's row
+    # perm[i] is row i of the pivoted factor, so "the rows below the pivots" are simply all non-pivot rows).
+    piv = perm[..., :m]
+    idx_r = piv.unsqueeze(-1).expand(*piv.shape, R)
+    idx_m = piv.unsqueeze(-1).expand(*piv.shape, m)
+    grad_L = grad_L.contiguous()
+    rm = torch.gather(r, -2, idx_r)  # the m pivot rows of the root  [*, m, R]
+    krows = r @ rm.mT  # K[:, pivots]  [*, N, m]
+    k11 = torch.gather(krows, -2, idx_m).detach().clone().requires_grad_(True)
     with torch.enable_grad():
         l11 = psd_safe_cholesky(k11)
     l11d = l11.detach()
-    # the two N x m triangular solves become GEMMs with the explicit m x m inverse (m <= max_preconditioner_size)
+    # the N x m triangular solves become GEMMs with the explicit m x m inverse (m <= max_preconditioner_size)
     eye = torch.eye(m, dtype=l11d.dtype, device=l11d.device).expand(*l11d.shape[:-2], m, m)
     l11_inv = torch.linalg.solve_triangular(l11d, eye, upper=False)
-    rest = krows[..., m:, :] @ l11_inv.mT  # K21 L11^-T
-    g2 = gp[..., m:, :]
-    lbar = gp[..., :m, :] - l11_inv.mT @ (g2.mT @ rest)
+    g11 = torch.gather(grad_L, -2, idx_m)
+    g2 = grad_L.scatter(-2, idx_m, 0.0)  # gradient of the non-pivot rows (pivot rows zeroed)
+    rest = krows @ l11_inv.mT  # K21 L11^-T (its pivot rows meet zeros of g2 only)
+    lbar = g11 - l11_inv.mT @ (g2.mT @ rest)
     (k11bar,) = torch.autograd.grad(l11, k11, grad_outputs=lbar)
-    k21bar = g2 @ l11_inv  # G2 L11^-1
-    kbar = torch.cat([k11bar, k21bar], dim=-2)
-    rp_bar = kbar @ rm
-    rp_bar[..., :m, :] += kbar.mT @ rp
-    return torch.gather(rp_bar, -2, inv_perm.unsqueeze(-1).expand(*inv_perm.shape, R))
+    kbar = (g2 @ l11_inv).scatter(-2, idx_m, k11bar)  # bar K[:, pivots]: G2 L11^-1 below, bar K11 on the pivot rows
+    r_bar = kbar @ rm
+    return r_bar.scatter_add(-2, idx_r, kbar.mT @ r)
 
 
 def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False):
@@ -94,7 +96,7 @@ def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False):
     inv_perm = inverse_permutation(perm)
     reps = linear_op.representation()
     if not generic and isinstance(linear_op, RootLinearOperator) and len(reps) == 1 and linear_op._dense_root() is reps[0]:
-        return [_dense_root_vjp(reps[0].detach(), perm, inv_perm, grad_L, m)]
+        return [_dense_root_vjp(reps[0].detach(), perm, grad_L, m)]
     leaves = []
     for t in linear_op.representation():
         leaves.append(t.detach().requires_grad_(True) if t.dtype.is_floating_point else t.detach())
