@@ -93,10 +93,10 @@ def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False):
 
     m = grad_L.size(-1)
     perm = full_permutation
-    inv_perm = inverse_permutation(perm)
     reps = linear_op.representation()
     if not generic and isinstance(linear_op, RootLinearOperator) and len(reps) == 1 and linear_op._dense_root() is reps[0]:
         return [_dense_root_vjp(reps[0].detach(), perm, grad_L, m)]
+    inv_perm = inverse_permutation(perm)
     leaves = []
     for t in linear_op.representation():
         leaves.append(t.detach().requires_grad_(True) if t.dtype.is_floating_point else t.detach())
