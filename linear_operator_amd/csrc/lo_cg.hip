@@ -26,6 +26,9 @@
 namespace lo {
 
 bool g_onchip_disabled = false;
+// A chunk of columns goes to the column-lockstep kernel (16 at a time on the matrix cores) when it has at least this
+// many live columns; fewer are cheaper one after the other on the second-generation kernel.
+constexpr int kLockstepMinCols = 4;
 
 struct CgDev {
   int64_t B, N;
@@ -44,6 +47,7 @@ struct CgDev {
   CgCtrl* ctrl;
   float* ctrl_part;  // [3, kCtrlMaxG] per-workgroup partials of the control step
   unsigned long long* oc_gbuf;
+  unsigned long long* ls_gbuf;  // granules of the column-lockstep kernel (lo_cg_lockstep.hip) or nullptr
   int* oc_err;
   float* oc_resid;
   int* oc_init_conv;
@@ -446,6 +450,9 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   dd.oc_ab = (oc_shape && prm->n_tridiag) ? ar.take<float>(2 * oc_n * oc_iters) : nullptr;
   dd.oc_maxoff = ar.take<int>((size_t)std::max(1, (int)prm->max_tridiag_iter) + 1);
   dd.oc_dbg = ar.take<long long>(16);
+  dd.ls_gbuf = (oc_shape && c >= kLockstepMinCols && N <= 8192)
+                   ? ar.take<unsigned long long>(lockstep_gbuf_bytes(32, 8) / sizeof(unsigned long long))
+                   : nullptr;
   dd.oc_zero_q = nullptr;
   dd.oc_ones = nullptr;
   if (!pre && !precond && oc_shape) {
@@ -572,56 +579,88 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   // 1/d = 1, i.e. z = r and r.z = ||r||^2, which is the reference's unpreconditioned update (linear_cg.py:49-95)
   const bool oc_nopre = !pre && !precond_cb && d.oc_zero_q != nullptr;
   const int ocR4 = oc_nopre ? 4 : preR4;
-  // (the first generation handles one column without tridiagonals; the second loops over the columns)
+  // (the first generation handles one column without tridiagonals; the second loops over the columns; the third
+  // advances 16 columns together on the matrix cores)
   const bool oc_gen1_ok = !oc_nopre && prm->n_tridiag == 0 && c == 1 && onchip_eligible(pl.R4, preR4, N, c);
-  const bool oc_ok = (op->kind == LO_OP_LOWRANK_DIAG) && (pre || oc_nopre) && !precond_cb && !x0 &&
-                     prm->max_iter >= 11 && prm->max_iter > kfloor0 && oc_nwg >= 64 && !g_onchip_disabled &&
-                     (prm->n_tridiag == 0 || d.oc_ab != nullptr) &&
-                     (oc_gen1_ok || onchip4_eligible(pl.R4, ocR4, N, c));
+  const bool oc_base = (op->kind == LO_OP_LOWRANK_DIAG) && (pre || oc_nopre) && !precond_cb && !x0 &&
+                       prm->max_iter >= 11 && prm->max_iter > kfloor0 && oc_nwg >= 64 && !g_onchip_disabled &&
+                       (prm->n_tridiag == 0 || d.oc_ab != nullptr) && B < (1 << 24) - 1024;
+  // column split: full chunks of 16 (and a last chunk of at least kLockstepMinCols) -> lockstep kernel, the rest serial
+  int ls_cols = 0;
+  if (oc_base && d.ls_gbuf && !getenv("LO_OC_NO_LOCKSTEP") &&
+      lockstep_eligible(pl.R4, pre ? preR4 : 0, pre != nullptr, N, c)) {
+    const int full = (c / 16) * 16, rem = c - full;
+    ls_cols = full + (rem >= kLockstepMinCols ? rem : 0);
+  }
+  const bool oc_ok = oc_base && (ls_cols == c || oc_gen1_ok || onchip4_eligible(pl.R4, ocR4, N, c - ls_cols));
   // second generation (4 rows per thread, lo_cg_onchip4.hip) unless LO_OC_GEN1 asks for the first one
   // (the dynamic member hand-out passes indices through fp32 granules: exact below 2^24)
-  const bool oc_gen2 = oc_ok && onchip4_eligible(pl.R4, ocR4, N, c) && B < (1 << 24) - 1024 &&
+  const bool oc_gen2 = oc_ok && ls_cols < c && onchip4_eligible(pl.R4, ocR4, N, c - ls_cols) &&
                        !(getenv("LO_OC_GEN1") && oc_gen1_ok);
   if (oc_ok) {
     OnchipArgs a;
     a.C = pl.Apad; a.d = op->d;
     a.d_mode = op->diag_mode;
     if (oc_nopre) {
-      LO_HIP_CHECK(hipMemsetAsync(d.oc_zero_q, 0, sizeof(float) * (size_t)B * N * 4, st));
-      LO_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)d.oc_ones, 0x3f800000, (size_t)B, st));  // 1.0f
+      if (ls_cols < c) {
+        LO_HIP_CHECK(hipMemsetAsync(d.oc_zero_q, 0, sizeof(float) * (size_t)B * N * 4, st));
+        LO_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)d.oc_ones, 0x3f800000, (size_t)B, st));  // 1.0f
+      }
       a.Q = d.oc_zero_q; a.dinv = d.oc_ones; a.dinv_mode = LO_DIAG_CONST;
     } else {
       a.Q = Qp; a.dinv = pre->dinv; a.dinv_mode = pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL;
     }
     a.rhs = rhs; a.B = B; a.N = (int)N;
     a.c = c; a.ab_rec = prm->n_tridiag ? d.oc_ab : nullptr;
-    a.GW = oc_gen2 ? onchip4_group_size(N) : 8;
-    a.RW = (int)((N + a.GW - 1) / a.GW);
+    a.col0 = 0; a.ncols = c; a.RK = pre ? preR4 : 0; a.RCg = pl.R4;
     a.iters = kfloor0 + 1;
     a.eps = prm->eps; a.stop_after = prm->stop_updating_after;
     a.x = d.x; a.r = d.r; a.p = d.p; a.z = d.z;
-    a.xout = oc_gen2 ? x : nullptr;
     a.rhs_norm = d.rhs_norm; a.rz = d.rz; a.alpha = d.alpha; a.beta = d.beta; a.resid_norm = d.resid_norm;
     a.rhs_is_zero = d.rhs_is_zero; a.has_conv = d.has_conv;
-    a.resid_rec = d.oc_resid; a.init_conv = d.oc_init_conv; a.gbuf = d.oc_gbuf; a.err = d.oc_err; a.next_member = d.oc_err + 1;
+    a.resid_rec = d.oc_resid; a.init_conv = d.oc_init_conv; a.err = d.oc_err;
     a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
     a.prefetch = getenv("LO_OC_NO_PREFETCH") ? 0 : 1;
     const bool oc_dbg = getenv("LO_OC_DEBUG") != nullptr && B >= 8;
     a.dbg = oc_dbg ? d.oc_dbg : nullptr;
     a.dbg_member = oc_dbg ? atoi(getenv("LO_OC_DEBUG")) : 0;  // LO_OC_DEBUG=<member index to time>
-    LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(64), st));  // whole allocation (either generation)
     // LO_OC_TEST_FALLBACK: start with the error word set, as if a hand-off had timed out (exercises the host fallback)
-    // (error word and member counter live in the control block: cleared with it, copied back with it)
+    // (error word and member counters live in the control block: cleared with it, copied back with it)
     if (getenv("LO_OC_TEST_FALLBACK")) LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 1, 1, st));
     if (oc_dbg) LO_HIP_CHECK(hipMemsetAsync(a.dbg, 0, 10 * sizeof(long long), st));
-    rc = LO_ERR_UNSUPPORTED;
-    if (oc_gen2) rc = onchip4_launch(pl.R4, ocR4, a, oc_nwg, st);
-    const bool oc_gen2_ran = oc_gen2 && rc == LO_OK;
-    if (rc == LO_ERR_UNSUPPORTED && oc_gen1_ok) {
+    rc = LO_OK;
+    bool xout_ok = true;  // every launched kernel wrote result * rhs_norm itself
+    if (ls_cols) {  // third generation: columns [0, ls_cols)
       a.GW = 8;
       a.RW = (int)((N + 7) / 8);
-      rc = onchip_launch(pl.R4, preR4, a, oc_nwg, st);
+      a.ncols = ls_cols;
+      a.xout = x;
+      a.gbuf = d.ls_gbuf; a.next_member = d.oc_err + 2;
+      LO_HIP_CHECK(hipMemsetAsync(d.ls_gbuf, 0, lockstep_gbuf_bytes(32, 8), st));
+      rc = lockstep_launch(pl.R4, pre != nullptr, a, std::min(oc_nwg, 256), st);
+      if (rc == LO_ERR_UNSUPPORTED) {  // (does not fit this device: all columns go to the serial kernels)
+        ls_cols = 0;
+        rc = (oc_gen1_ok || onchip4_eligible(pl.R4, ocR4, N, c)) ? LO_OK : LO_ERR_UNSUPPORTED;
+      }
     }
+    if (rc == LO_OK && ls_cols < c) {  // second (first) generation: columns [ls_cols, c)
+      const bool gen2 = onchip4_eligible(pl.R4, ocR4, N, c - ls_cols) && !(getenv("LO_OC_GEN1") && oc_gen1_ok);
+      a.GW = gen2 ? onchip4_group_size(N) : 8;
+      a.RW = (int)((N + a.GW - 1) / a.GW);
+      a.col0 = ls_cols; a.ncols = c - ls_cols;
+      a.xout = gen2 ? x : nullptr;
+      a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
+      LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(64), st));  // whole allocation (either generation)
+      rc = LO_ERR_UNSUPPORTED;
+      if (gen2) rc = onchip4_launch(pl.R4, ocR4, a, oc_nwg, st);
+      xout_ok = gen2 && rc == LO_OK;
+      if (rc == LO_ERR_UNSUPPORTED && oc_gen1_ok) {
+        a.GW = 8;
+        a.RW = (int)((N + 7) / 8);
+        rc = onchip_launch(pl.R4, preR4, a, oc_nwg, st);
+      }
+    }
+    (void)oc_gen2;
     if (rc && rc != LO_ERR_UNSUPPORTED) return rc;
     if (rc == LO_OK) {  // (LO_ERR_UNSUPPORTED: no resident kernel fits this device / shape -> streaming engine)
       const int ktri = prm->n_tridiag ? std::min(a.iters, (int)prm->max_tridiag_iter) : 0;
@@ -644,7 +683,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       }
       if (oc_err == 0) {
         k_start = a.iters;
-        x_written = (a.xout != nullptr) && oc_gen2_ran;
+        x_written = xout_ok;
       } else {  // a group hand-off timed out: redo everything with the streaming engine
         fprintf(stderr, "liblo_amd: operator-resident CG timed out, falling back to the streaming engine\n");
         LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, sizeof(CgCtrl), st));

@@ -13,7 +13,10 @@ struct OnchipArgs {
   const float* dinv;  // [B, N] or [B]
   int d_mode, dinv_mode;
   const float* rhs;   // [B, N, c]
-  int c;              // right-hand-side columns (first generation: 1)
+  int c;              // right-hand-side columns of the vectors (row stride; first generation: 1)
+  int col0, ncols;    // columns [col0, col0 + ncols) are solved by this launch (second / third generation)
+  int RK;             // floats per row of Q (third generation; the others take it as a template parameter)
+  int RCg;            // floats per row of C in HBM (third generation: 8, 16 or 32)
   float* ab_rec;      // [iters, B, c, 2] masked alpha / beta per iteration (second generation, n_tridiag > 0) or nullptr
   int64_t B;
   int N, RW;          // rows per workgroup
@@ -38,5 +41,9 @@ struct OnchipArgs {
 
 int onchip_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st);
 int onchip4_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st);
+// third generation (lo_cg_lockstep.hip): 16 columns of a member advance together on the matrix cores
+int lockstep_launch(int RC, bool pre, const OnchipArgs& a, int nwg, hipStream_t st);
+bool lockstep_eligible(int RC, int RK, bool pre, int64_t N, int64_t ncols);
+size_t lockstep_gbuf_bytes(int ngroups, int GW);
 
 }  // namespace lo

@@ -286,8 +286,9 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip4(OnchipA
 
     // The right-hand-side columns are solved one after the other against the resident rows (each column is an
     // independent recurrence in the reference: every scalar of linear_cg.py carries a trailing column dimension).
-    const int nc = MC ? a.c : 1;
-    for (int col = 0; col < nc; ++col) {
+    const int nc = MC ? a.c : 1;  // row stride of the vectors; this launch solves columns [col0, col0 + ncols)
+    const int cfirst = MC ? a.col0 : 0, clast = MC ? a.col0 + a.ncols : 1;
+    for (int col = cfirst; col < clast; ++col) {
     const size_t bc = (size_t)b * nc + col;
     // ---- initialisation (linear_cg.py:177-215) ----
     float sc[2];
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip4(OnchipA
     float beta = 0.f, alpha = 0.f;
     rn = sqrtf(rr);
 
-    if (stamp && col == 0) {
+    if (stamp && col == cfirst) {
       a.dbg[2] = wall_clock64();
       g.dbg = a.dbg;
     }
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip4(OnchipA
       }
     }
 
-    if (stamp && col == 0) a.dbg[3] = wall_clock64();
+    if (stamp && col == cfirst) a.dbg[3] = wall_clock64();
     g.dbg = nullptr;
     // ---- write the state back in the streaming engine's layout ----
     int tw = t;

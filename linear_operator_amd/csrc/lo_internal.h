@@ -75,6 +75,7 @@ struct CgCtrl {
   float mean_resid;
   int oc_err;             // operator-resident kernels: a group exchange timed out (host falls back to streaming)
   int oc_next;            // operator-resident kernels: shared counter of the dynamic member hand-out
+  int oc_next_ls;         // the same for the column-lockstep kernel (both may run in one solve)
 };
 
 // fused-update arguments of the skinny tn kernels (VMODE 1: p-update, VMODE 2: r/x-update; see lo_skinny.hip)
