@@ -621,13 +621,15 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.resid_rec = d.oc_resid; a.init_conv = d.oc_init_conv; a.err = d.oc_err;
     a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
     a.prefetch = getenv("LO_OC_NO_PREFETCH") ? 0 : 1;
-    const bool oc_dbg = getenv("LO_OC_DEBUG") != nullptr && B >= 8;
-    a.dbg = oc_dbg ? d.oc_dbg : nullptr;
-    a.dbg_member = oc_dbg ? atoi(getenv("LO_OC_DEBUG")) : 0;  // LO_OC_DEBUG=<member index to time>
+    // LO_OC_DEBUG=<member index to time> (serial-column kernels), LO_LS_DEBUG=<member> (lockstep kernel)
+    const bool ls_dbg = getenv("LO_LS_DEBUG") != nullptr && B >= 8;
+    const bool oc_dbg = !ls_dbg && getenv("LO_OC_DEBUG") != nullptr && B >= 8;
+    a.dbg = nullptr;
+    a.dbg_member = oc_dbg ? atoi(getenv("LO_OC_DEBUG")) : (ls_dbg ? atoi(getenv("LO_LS_DEBUG")) : 0);
     // LO_OC_TEST_FALLBACK: start with the error word set, as if a hand-off had timed out (exercises the host fallback)
     // (error word and member counters live in the control block: cleared with it, copied back with it)
     if (getenv("LO_OC_TEST_FALLBACK")) LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 1, 1, st));
-    if (oc_dbg) LO_HIP_CHECK(hipMemsetAsync(a.dbg, 0, 10 * sizeof(long long), st));
+    if (oc_dbg || ls_dbg) LO_HIP_CHECK(hipMemsetAsync(d.oc_dbg, 0, 16 * sizeof(long long), st));
     rc = LO_OK;
     bool xout_ok = true;  // every launched kernel wrote result * rhs_norm itself
     if (ls_cols) {  // third generation: columns [0, ls_cols)
@@ -636,6 +638,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       a.ncols = ls_cols;
       a.xout = x;
       a.gbuf = d.ls_gbuf; a.next_member = d.oc_err + 2;
+      a.dbg = ls_dbg ? d.oc_dbg : nullptr;
       LO_HIP_CHECK(hipMemsetAsync(d.ls_gbuf, 0, lockstep_gbuf_bytes(32, 8), st));
       rc = lockstep_launch(pl.R4, pre != nullptr, a, std::min(oc_nwg, 256), st);
       if (rc == LO_ERR_UNSUPPORTED) {  // (does not fit this device: all columns go to the serial kernels)
@@ -650,6 +653,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       a.col0 = ls_cols; a.ncols = c - ls_cols;
       a.xout = gen2 ? x : nullptr;
       a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
+      a.dbg = oc_dbg ? d.oc_dbg : nullptr;
       LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(64), st));  // whole allocation (either generation)
       rc = LO_ERR_UNSUPPORTED;
       if (gen2) rc = onchip4_launch(pl.R4, ocR4, a, oc_nwg, st);
@@ -675,9 +679,16 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
       LO_HIP_CHECK(hipStreamSynchronize(st));
       const int oc_err = h.oc_err;
+      if (ls_dbg) {
+        long long ts[10];
+        LO_HIP_CHECK(hipMemcpy(ts, d.oc_dbg, sizeof(ts), hipMemcpyDeviceToHost));
+        fprintf(stderr, "lockstep item (100 MHz ticks): load+H %lld init %lld iters %lld store %lld | direction %lld "
+                "alpha+x+r %lld reduce-mfma %lld cross-wave %lld group-sum %lld\n",
+                ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5], ts[6], ts[7], ts[8], ts[9]);
+      }
       if (oc_dbg) {
         long long ts[10];
-        LO_HIP_CHECK(hipMemcpy(ts, a.dbg, sizeof(ts), hipMemcpyDeviceToHost));
+        LO_HIP_CHECK(hipMemcpy(ts, d.oc_dbg, sizeof(ts), hipMemcpyDeviceToHost));
         fprintf(stderr, "onchip member0 (100 MHz ticks): load %lld init %lld iters %lld store %lld | wg-wait %lld publish %lld poll %lld\n",
                 ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5], ts[6], ts[7]);
       }

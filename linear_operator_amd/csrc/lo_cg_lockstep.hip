@@ -135,7 +135,9 @@ __device__ __forceinline__ void ls_group_sum(float (*part)[LS_NVP], float* res, 
 
 // RC: padded rank of C (16 or 32).  PRE: Woodbury preconditioner z = r/d' - Q (Q^T r) with Q [.., 16] (zero padded);
 // !PRE: z = r.  GW: workgroups per member.
-template <int RC, bool PRE, int GW>
+// DBG: phase timers (wall_clock64) of one work item; a separate instantiation so that the production kernel does not
+// carry their registers.
+template <int RC, bool PRE, int GW, bool DBG>
 __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
   constexpr int NH = RC / 16;                   // 16-row blocks of T = C^T p
   constexpr int OFF_U = NH * 256;               // payload: W | U | three scalars per column
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
     const int ncol = min(LS_NC, a.col0 + a.ncols - cbase); // live columns
     const bool col_ok = n < ncol;
     const size_t brow = (size_t)b * a.N + row0;
-    const bool stamp = a.dbg && b == a.dbg_member && ch == 0 && wig == 0 && t == 0;
+    const bool stamp = DBG && a.dbg && b == a.dbg_member && ch == 0 && wig == 0 && t == 0;
     if (stamp) a.dbg[0] = wall_clock64();
 
     // ---- rhs columns -> registers (D layout); sum of squares for the normalisation (linear_cg.py:177) ----
@@ -299,11 +301,14 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
       accu = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // two-stage cross-wave sum of a payload held in (accw, accu, three per-column scalars), then the group all-reduce
+    long long* tdbg = nullptr;  // phase timers of the stamped work item (iteration loop only)
     auto allreduce = [&](float s0, float s1, float s2) {
+      long long c0 = 0;
+      if (DBG && tdbg) c0 = wall_clock64();
       s0 = kk_sum(s0);
       s1 = kk_sum(s1);
       s2 = kk_sum(s2);
-      __syncthreads();  // (res / part readers of the previous all-reduce are done)
+      __syncthreads();  // (measured: without this re-alignment of the waves the iteration is 10 % slower)
       if (w >= 4) {
 #pragma unroll
         for (int h = 0; h < NH; ++h)
@@ -335,7 +340,13 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
           part[w][OFF_S + 32 + n] += s2;
         }
       }
+      if (DBG && tdbg) {
+        const long long c1 = wall_clock64();
+        tdbg[8] += c1 - c0;  // cross-wave stage (incl. waiting for the slowest wave)
+        c0 = c1;
+      }
       ls_group_sum<GW>(part, res, NV, g);
+      if (DBG && tdbg) tdbg[9] += wall_clock64() - c0;  // publish + poll + sum
     };
 
     allreduce(ss, 0.f, 0.f);
@@ -370,6 +381,8 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
       for (int h = 0; h < NH; ++h) accw[h] = f32x4{0.f, 0.f, 0.f, 0.f};
       accu = f32x4{0.f, 0.f, 0.f, 0.f};
       float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      long long tc0 = 0;
+      if (DBG && tdbg) tc0 = wall_clock64();
       const int L = opaque(lane), kq = L >> 4, nq = L & 15;
       const float* cw = c_s + lrow0 * RC;
       const float* ew = (PRE ? dinv_s : d_s) + lrow0 + 4 * kq;
@@ -399,6 +412,7 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
           }
         }
       }
+      if (DBG && tdbg) tdbg[7] += wall_clock64() - tc0;  // reduce products
       allreduce(s0, s1, s2);
     };
 
@@ -422,9 +436,14 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
     const bool rec = (wig == 0 && w == 0 && kk == 0 && col_ok);
     const size_t bc = (size_t)b * ldc + cbase + n;
     if (rec) a.init_conv[bc] = conv ? 1 : 0;
-    if (stamp) a.dbg[2] = wall_clock64();
+    if (stamp) {
+      a.dbg[2] = wall_clock64();
+      if constexpr (DBG) tdbg = a.dbg;
+    }
 
     for (int k = 0; k < a.iters; ++k) {
+      long long c0 = 0;
+      if (DBG && tdbg) c0 = wall_clock64();
       // ---- search direction: p = z + beta p with z = r/d - Q u formed on the fly (:268, :46); the small
       //      recurrences for C^T p, Q^T D p and sum d p^2 ----
       {
@@ -480,6 +499,11 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
           }
         }
       }
+      if (DBG && tdbg) {
+        const long long c1 = wall_clock64();
+        tdbg[5] += c1 - c0;  // search direction
+        c0 = c1;
+      }
       // ---- p.Ap = |C^T p|^2 + sum d p^2 ; alpha (:250-260) ----
       {
         float tt = 0.f;
@@ -518,6 +542,11 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
           r[blk] = acc;
         }
       }
+      if (DBG && tdbg) {
+        const long long c1 = wall_clock64();
+        tdbg[6] += c1 - c0;  // alpha, x and r updates
+        c0 = c1;
+      }
       reduce();
       {
         float uu = 0.f;
@@ -544,6 +573,7 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
       }
     }
     if (stamp) a.dbg[3] = wall_clock64();
+    tdbg = nullptr;
 
     // ---- write the state back in the streaming engine's layout (p is the direction of the last iteration; the
     //      streaming loop forms z + beta p itself) ----
@@ -610,15 +640,15 @@ bool lockstep_eligible(int RC, int RK, bool pre, int64_t N, int64_t ncols) {
   return rc_ok && rk_ok && ncols >= 1 && N >= 1024 && N <= 8 * (int64_t)LS_ROWS;
 }
 
-template <int RC, bool PRE, int GW>
+template <int RC, bool PRE, int GW, bool DBG = false>
 static int lockstep_go(const OnchipArgs& a, int nwg, hipStream_t st) {
   // the spin-waiting groups need ALL workgroups resident: one per CU
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_lockstep<RC, PRE, GW>, LS_TPB, 0) != hipSuccess ||
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_lockstep<RC, PRE, GW, DBG>, LS_TPB, 0) != hipSuccess ||
       per_cu < 1)
     return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("cg_lockstep", st);
-  hipLaunchKernelGGL((k_cg_lockstep<RC, PRE, GW>), dim3(nwg), dim3(LS_TPB), 0, st, a);
+  hipLaunchKernelGGL((k_cg_lockstep<RC, PRE, GW, DBG>), dim3(nwg), dim3(LS_TPB), 0, st, a);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
@@ -626,6 +656,7 @@ static int lockstep_go(const OnchipArgs& a, int nwg, hipStream_t st) {
 
 // nwg = number of CUs used (multiple of 64) = workgroups launched.  a.RK = floats per row of Q (PRE) or 0.
 int lockstep_launch(int RC, bool pre, const OnchipArgs& a, int nwg, hipStream_t st) {
+  if (RC == 32 && pre && a.dbg) return lockstep_go<32, true, 8, true>(a, nwg, st);
   if (RC == 32) return pre ? lockstep_go<32, true, 8>(a, nwg, st) : lockstep_go<32, false, 8>(a, nwg, st);
   if (RC == 16 || RC == 8) return pre ? lockstep_go<16, true, 8>(a, nwg, st) : lockstep_go<16, false, 8>(a, nwg, st);
   return LO_ERR_UNSUPPORTED;

@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "lockstep or onchip" > gpurun_out/t_lockstep.log 2>&1
-tail -25 gpurun_out/t_lockstep.log
+for i in 1 2 3; do timeout 300 python tools/mb_lockstep.py 2>&1 | grep -v amdgpu.ids; done > gpurun_out/mb_lockstep.log
+LS_C=1 timeout 300 python tools/mb_lockstep.py 2>&1 | grep -v amdgpu.ids >> gpurun_out/mb_lockstep.log
+rocm-smi --showclocks 2>/dev/null | grep -i "sclk\|mclk" | head -4 >> gpurun_out/mb_lockstep.log
+cat gpurun_out/mb_lockstep.log
