@@ -36,7 +36,10 @@ from linear_operator_amd import kernels as K  # noqa: E402
 B_PER_GPU, N, R, C_COLS, RANK_K = 512, 8192, 32, 1, 15
 TOL = 1e-4
 ITERS_FLOOR = 11  # linear_cg.py:303 -- the iterations the operator-resident kernel runs in one launch
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+PROFILE_DIR = "r02"  # profiles/<dir>/ holds the rocprofv3 summaries of this command (tools/profile_round.sh)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0  # the guide's measured float4-copy rate: the ceiling a streaming kernel can reach
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (v_mfma_f32_16x16x4_f32 / 32x32x2, MI355X_MICROARCH.md)
 
 
 def make_problem(device, seed):
@@ -63,9 +66,9 @@ def algorithmic_bytes(name, k_eff):
         r = R if name.endswith("R32") else k_eff
         return 4 * B * (N * r + N + 2 * N * c)  # stream A once + diagonal + vector in + vector out
     if name == "cg_onchip":
-        # operator-resident CG: ONE launch runs all guaranteed iterations.  Algorithmic bytes per member and
-        # iteration as SURVEY 8(d): matvec 4(NR+N+2Nc) + CG state 4*8*N*c + rank-k preconditioner 4(N*k+2N*c)
-        return B * ITERS_FLOOR * (4 * (N * R + N + 2 * N * c) + 32 * N * c + 4 * (N * k_eff + 2 * N * c))
+        # operator-resident CG: ONE launch runs all guaranteed iterations and reads the operator ONCE.  Compulsory
+        # bytes per launch: C, Q, d, 1/d, the right-hand side in and the solution out
+        return 4 * B * N * (R + k_eff + 2 + 2 * c)
     if name == "cg_update_xr":
         return 4 * B * N * c * 6  # r, Ap, x, p read; r, x written
     if name == "cg_update_p":
@@ -114,10 +117,36 @@ def _time(fn, reps):
     return (time.perf_counter() - t0) / reps, out
 
 
+def _profiled(fn):
+    """Run fn once more with the library's HIP-event timers on (events on the launch stream): {name: (launches, ms)}."""
+    torch.cuda.synchronize()
+    _hip.prof_enable(True)
+    try:
+        fn()
+        torch.cuda.synchronize()
+        return _hip.prof_report()
+    finally:
+        _hip.prof_enable(False)
+
+
+def _roof(kernel, workload, prof_entry, bound, work, note):
+    """One per-kernel roofline entry: `work` = compulsory bytes (bound 'hbm') or flop (bound 'mfma') per launch."""
+    cnt, ms = prof_entry
+    avg_s = ms / cnt * 1e-3
+    if bound == "hbm":
+        achieved, peak, unit = work / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+    else:
+        achieved, peak, unit = work / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+    return {"kernel": kernel, "workload": workload, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+            "frac": achieved / peak, "per_launch": work, "avg_launch_us": avg_s * 1e6, "launches_timed": cnt,
+            "note": note}
+
+
 def other_configs(device):
     """Quick single-GPU numbers for the remaining BASELINE.json configs (not the headline metric; parity for these
-    shapes is covered by tests/).  cfg4 / cfg5 are run at the per-GPU shard of their 8-GPU batch."""
-    res = {}
+    shapes is covered by tests/), and a roofline entry for the dominant kernel of each (HIP-event timed, like the
+    headline kernel).  cfg4 / cfg5 are run at the per-GPU shard of their 8-GPU batch."""
+    res, roofs = {}, []
     g = torch.Generator(device=device)
     g.manual_seed(77)
     # cfg2: batch 64 low-rank + diag, end-to-end solve (preconditioner build + CG)
@@ -144,19 +173,52 @@ def other_configs(device):
     res["cfg3_B512_inv_quad_logdet"] = {"ms": t * 1e3, "member_solve_logdets_per_s": B_PER_GPU / t,
                                         "iterations": r.iterations,
                                         "member_matvec_columns_per_s": B_PER_GPU * 17 * r.matvecs / t}
+    prof = _profiled(iql)
+    it3 = r.iterations
+    if "cg_lockstep" in prof:  # 16 probe columns in lockstep on the matrix cores
+        flop = 2.0 * B_PER_GPU * N * (2 * R + 2 * RANK_K) * 16 * it3
+        roofs.append(_roof("k_cg_lockstep<32,pre>", "cfg3: 16 probe columns x 21 iterations, 512 members", prof["cg_lockstep"],
+                           "mfma", flop,
+                           "fp32 matrix cores (v_mfma_f32_16x16x4_f32): 2 N (2R + 2k) flop per member, column and "
+                           "iteration (k = 15; the kernel multiplies with Q zero-padded to 16); compulsory HBM bytes per "
+                           f"launch {4 * B_PER_GPU * N * (R + RANK_K + 2 + 6 * 16) / 1e9:.2f} GB (operator once, rhs in, "
+                           "x / r / p / z and the scaled result out)"))
+    if "cg_onchip" in prof:  # the 17th column (inv_quad right-hand side) on the serial-column resident kernel
+        roofs.append(_roof("k_cg_onchip4<32,16,8,true>", "cfg3: 17th column x 21 iterations, 512 members", prof["cg_onchip"],
+                           "hbm", 4 * B_PER_GPU * N * (R + RANK_K + 2 + 6),
+                           "compulsory bytes per launch (operator once + one column's vectors); latency-bound by the "
+                           "per-iteration group all-reduces"))
+    if "pc_onchip" in prof:
+        roofs.append(_roof("k_pc_onchip4<32,8>", "rank-15 pivoted Cholesky of 512 x (8192 x 32) roots", prof["pc_onchip"],
+                           "hbm", 4 * B_PER_GPU * (N * R + RANK_K * N + N),
+                           "compulsory bytes per launch: C once in, the 15 rows of L and the permutation out; bound by "
+                           "one group exchange per pivot"))
     # explicit Lanczos on the same operator: 16 probe vectors, 20 steps, full re-orthogonalisation
     V = torch.randn(B_PER_GPU, N, 16, generator=g, device=device)
     t, (q_mat, _) = _time(lambda: K.lanczos_tridiag(desc, V, 20), 1)
-    res["cfg3_B512_lanczos_P16_k20"] = {"ms": t * 1e3, "member_probe_steps_per_s": B_PER_GPU * 16 * q_mat.shape[-1] / t}
+    steps = q_mat.shape[-1]
+    lz_bytes = sum(4 * B_PER_GPU * ((N * R + N + 2 * N * 16) + 2 * (j + 1) * N * 16) for j in range(steps))
+    res["cfg3_B512_lanczos_P16_k20"] = {"ms": t * 1e3, "member_probe_steps_per_s": B_PER_GPU * 16 * steps / t}
+    roofs.append({"kernel": "lanczos_tridiag (whole call: matvec + Gram-Schmidt kernels of every step)",
+                  "workload": "512 members, 16 probes, 20 steps", "bound": "hbm",
+                  "achieved": lz_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lz_bytes / t / 1e9 / HBM_PEAK_GBS,
+                  "per_launch": lz_bytes, "avg_launch_us": t * 1e6, "launches_timed": 1,
+                  "note": "SURVEY 8(d) model per step j: matvec 4(NR + N + 2NP) + re-orthogonalisation 4 * 2 (j+1) N P "
+                          "(Q_{<=j} read once for the coefficients, once for the correction), wall time of the call"})
     # the same operator through the host API, forward + backward (one GP marginal-likelihood gradient step): probes
     # drawn from the preconditioner, resident CG with tridiagonals, SLQ, then the reference's backward formulas
     from linear_operator_amd import settings as lo_settings
     from linear_operator_amd.operators import AddedDiagLinearOperator, DiagLinearOperator, LowRankRootLinearOperator
+    from linear_operator_amd.operators.added_diag_linear_operator import clear_preconditioner_memo
 
     Cg, dg = Cm.clone().requires_grad_(True), d.clone().requires_grad_(True)
     y = full[..., 16:].contiguous()
 
     def train_step():
+        # a real training step changes the leaves every step: drop the memoised factorisation so that the pivoted
+        # Cholesky and the preconditioner build are part of every timed step (the backward solve of the SAME step
+        # still reuses the forward's preconditioner, as the reference's cached operator does)
+        clear_preconditioner_memo()
         Cg.grad = dg.grad = None
         A = AddedDiagLinearOperator(LowRankRootLinearOperator(Cg), DiagLinearOperator(dg))
         iq, ld = A.inv_quad_logdet(y, logdet=True)
@@ -165,7 +227,8 @@ def other_configs(device):
 
     with lo_settings.cg_tolerance(TOL), lo_settings.num_trace_samples(16):
         t, _ = _time(train_step, 2)
-    res["cfg3_B512_inv_quad_logdet_forward_backward_host_api"] = {"ms": t * 1e3, "member_steps_per_s": B_PER_GPU / t}
+    res["cfg3_B512_inv_quad_logdet_forward_backward_host_api"] = {"ms": t * 1e3, "member_steps_per_s": B_PER_GPU / t,
+                                                                  "preconditioner": "rebuilt every step"}
     del Cm, d, full, desc, V, q_mat, Cg, dg, y
     # cfg4 shard: 128 of 1024 Kronecker members (256 (x) 256 + 1e-2 I), CG to tolerance 1e-3
     n = 256
@@ -183,6 +246,11 @@ def other_configs(device):
 
     t, r = _time(kron, 1)
     res["cfg4_shard_B128_kron_solve"] = {"ms": t * 1e3, "solves_per_s": 128 / t, "iterations": r.iterations}
+    prof = _profiled(kron)
+    if "kron_gemm_mfma" in prof:
+        roofs.append(_roof("k_kron_nt_mfma", "cfg4 shard: 128 members, one of the two 256^3 GEMMs of a Kronecker matvec",
+                           prof["kron_gemm_mfma"], "mfma", 2.0 * 128 * n * n * n,
+                           "fp32 matrix cores (v_mfma_f32_32x32x2_f32), 2 n^3 flop per member and GEMM"))
     del X1, X2, K1, K2, desc
     # cfg5 shard: 4 of the 32 dense 16384^2 members a GPU owns, 17 columns, CG with tridiagonals
     Nd = 16384
@@ -201,7 +269,11 @@ def other_configs(device):
     mv_bytes = 4 * 4 * (Nd * Nd + Nd + 2 * Nd * 17)
     res["cfg5_shard_B4_dense_cg"] = {"ms": t * 1e3, "iterations": r.iterations,
                                      "matvec_algorithmic_GBs": mv_bytes * r.matvecs / t / 1e9}
-    return res
+    prof = _profiled(dense)
+    if "dense_mv_mfma" in prof:
+        roofs.append(_roof("k_dense_mv_mfma", "cfg5 shard: 4 members of 16384^2, 17 columns, one matvec", prof["dense_mv_mfma"],
+                           "hbm", mv_bytes, "4 (N^2 + N + 2 N c) bytes per member: K streamed once for all 17 columns"))
+    return res, roofs
 
 
 def main():
@@ -312,14 +384,23 @@ def main():
         achieved = alg / avg_s / 1e9
         tn, nn = prof.get("skinny_tn_R32"), prof.get("skinny_nn_R32")
         mv_alg = 4 * B_PER_GPU * (N * R + N + 2 * N * C_COLS)  # 1,146,880 B per member
+        # SURVEY 8(d)'s per-ITERATION streaming model (matvec + CG state + rank-k preconditioner): what a kernel that
+        # re-reads the operator every iteration would have to move.  Reported as an equivalent rate only -- the
+        # resident kernel does not move these bytes, so this is NOT a roofline fraction.
+        per_iter = 4 * (N * R + N + 2 * N * C_COLS) + 32 * N * C_COLS + 4 * (N * RANK_K + 2 * N * C_COLS)
+        equiv = {"bytes_per_member_iteration": per_iter, "iterations": ITERS_FLOOR,
+                 "equivalent_GBs": B_PER_GPU * ITERS_FLOOR * per_iter / avg_s / 1e9,
+                 "note": "per-iteration streaming model of SURVEY 8(d) divided by the launch time: the rate a "
+                         "streaming engine would need to match this kernel; not HBM traffic"}
         if tn and nn:
             mv_s = (tn[1] / tn[0] + nn[1] / nn[0]) * 1e-3
             mv_note = "C^T p + C t + d o p kernel pair = one batched CG matvec (north_star 60% target)"
         else:
             # fused kernel: the matvec cannot be timed on its own; charge it the WHOLE iteration (upper bound)
             mv_s = avg_s / ITERS_FLOOR
-            mv_note = ("operator-resident kernel: time of one full CG iteration (matvec + preconditioner + updates) "
-                       "charged to the matvec; north_star target is <= 122 us for the matvec alone")
+            mv_note = ("operator-resident kernel: wall time of one full CG iteration (matvec + preconditioner + "
+                       "updates) next to north_star's budget of 122 us for the streamed matvec alone; equivalent rate, "
+                       "not HBM traffic")
         kernels = {k: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2),
                        "alg_GBs": round(algorithmic_bytes(k, RANK_K) / (v[1] / v[0] * 1e-3) / 1e9, 1)}
                    for k, v in sorted(prof.items())}
@@ -328,11 +409,15 @@ def main():
             triad_gbs = round(_hip.hbm_triad_gbs(device), 1)
         except Exception:  # noqa: BLE001
             pass
-        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (run separately; see profiles/*/README.md)
+        # HBM bytes per launch from rocprofv3 PMC passes: they cannot be collected from inside this process, so the
+        # figure comes from the committed profile of this very command (tools/profile_round.sh) and says so.
+        traffic, traffic_source = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_gen2", "traffic.json")))
-            if dom == "cg_onchip" and tj["kernel"].startswith("k_cg_onchip"):
+            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_DIR, "traffic.json")))
+            if tj.get("prof_name") == dom:
                 traffic = tj["traffic_bytes_per_launch"]
+                traffic_source = (f"profiles/{PROFILE_DIR}/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                  f"`bench.py --no-extras`, kernel {tj['kernel']}, FETCH x2 (gfx950 correction) + WRITE")
         except Exception:  # noqa: BLE001
             pass
         out = {
@@ -358,22 +443,24 @@ def main():
                              "with the next solve") if world > 1 else "single GPU",
             },
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "achievable_peak_triad": triad_gbs,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
+                         "triad_this_box": triad_gbs,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6, "launches_timed": cnt,
-                         "note": ("frac > 1 is possible for cg_onchip: the algorithmic figure charges C and Q once per "
-                                  "iteration, the kernel keeps them in LDS/VGPRs and reads them from HBM once per solve")
-                         if dom == "cg_onchip" else ""},
-            "matvec_roofline": {"algorithmic_bytes": mv_alg, "avg_us": mv_s * 1e6,
-                                "achieved_GBs": mv_alg / mv_s / 1e9, "frac_of_8TBs": mv_alg / mv_s / 1e9 / HBM_PEAK_GBS,
-                                "note": mv_note},
+                         "note": ("per-launch compulsory bytes (C, Q, d, 1/d, rhs in, x out; the kernel keeps the operator "
+                                  "on chip for all 11 iterations) / launch time.  The kernel is bound by the latency of "
+                                  "its per-iteration group all-reduce, not by HBM") if dom == "cg_onchip" else ""},
+            "equivalent_streaming_rate": equiv,
+            "matvec_equivalent": {"algorithmic_bytes": mv_alg, "avg_us": mv_s * 1e6,
+                                  "equivalent_GBs": mv_alg / mv_s / 1e9, "north_star_budget_us": 122.0, "note": mv_note},
             "solves_per_sec_end_to_end": total_members / e2e,
             "end_to_end_ms": e2e * 1e3,
             "kernels": kernels,
             "final_mean_residual": res.mean_residual,
         }
         if world == 1 and not args.no_extras:
-            out["other_configs"] = other_configs(device)
+            out["other_configs"], out["rooflines"] = other_configs(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     if use_dist:

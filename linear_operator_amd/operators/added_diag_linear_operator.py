@@ -48,7 +48,16 @@ _precond_memo: "list[tuple]" = []
 
 
 def _memo_key(tensors, extra):
+    """None when a tensor cannot be keyed (inference tensors do not track a version counter): the memo is skipped.
+    Writes through `.data` do not bump the version counter -- call clear_preconditioner_memo() after such updates."""
+    if any(t.is_inference() for t in tensors):
+        return None
     return tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype) for t in tensors) + extra
+
+
+def clear_preconditioner_memo():
+    """Drop the memoised preconditioners (and the references to the tensors they were built from)."""
+    _precond_memo.clear()
 
 
 class AddedDiagLinearOperator(SumLinearOperator):
@@ -126,7 +135,7 @@ class AddedDiagLinearOperator(SumLinearOperator):
             tensors = self.representation()
             key = _memo_key(tensors, (max_iter, settings.preconditioner_tolerance.value(), type(self._linear_op),
                                       type(self._diag_tensor)))
-            for entry in _precond_memo:
+            for entry in (_precond_memo if key is not None else ()):
                 if entry[0] == key:
                     (self._piv_chol_self, self._piv_chol_perm, self._woodbury, self._q_cache,
                      self._precond_logdet_cache, self._constant_diag, self._noise) = entry[2]
@@ -141,7 +150,7 @@ class AddedDiagLinearOperator(SumLinearOperator):
                 )
                 return None, None, None
             self._init_cache()
-            if PRECONDITIONER_MEMO_SIZE > 0:
+            if PRECONDITIONER_MEMO_SIZE > 0 and key is not None:
                 _precond_memo.insert(0, (key, tensors, (self._piv_chol_self, self._piv_chol_perm, self._woodbury,
                                                         self._q_cache, self._precond_logdet_cache, self._constant_diag,
                                                         self._noise)))
