@@ -47,6 +47,9 @@ extern "C" {
 #define LO_OP_DENSE_DIAG 1   /* AddedDiag(Dense(K), Diag(d)):             y = K v + d o v             */
 #define LO_OP_KRON_DIAG 2    /* AddedDiag(Kron(K1,K2), Diag(d)):          y = (K1 (x) K2) v + d o v   */
 #define LO_OP_CALLBACK 3     /* opaque closure (the reference's matmul_closure argument)              */
+#define LO_OP_SUM 4          /* SumLinearOperator / PsdSum of up to LO_MAX_TERMS structured terms (+ one diagonal):
+                              *   y = sum_i A_i v + d o v   (sum_linear_operator.py:47-51)              */
+#define LO_MAX_TERMS 4
 
 /* diagonal storage */
 #define LO_DIAG_NONE 0  /* no diagonal term (plain Root / Dense / Kron operator)                    */
@@ -64,6 +67,11 @@ typedef struct lo_op_desc {
   const float* A0;   /* LOWRANK: C [B,N,R];  DENSE: K [B,N,N];  KRON: K1 [B,n1,n1]                 */
   const float* A1;   /* KRON: K2 [B,n2,n2]; others NULL                                            */
   const float* d;    /* diagonal, layout per diag_mode (NULL if LO_DIAG_NONE)                      */
+  int32_t nterms;    /* SUM: number of terms (2 .. LO_MAX_TERMS); others 0                         */
+  int32_t reserved;
+  const struct lo_op_desc* terms; /* SUM: HOST array of nterms descriptors of kind LOWRANK / DENSE / KRON with
+                      * diag_mode LO_DIAG_NONE and the same B, N (summed left to right, like the reference's
+                      * Python sum()); the SUM's own (diag_mode, d) is the one diagonal of the tree */
 } lo_op_desc;
 
 /* Callbacks for LO_OP_CALLBACK and for a user preconditioner closure.
@@ -90,7 +98,9 @@ typedef struct lo_cg_params {
   int32_t n_tridiag;        /* tridiagonalise the first n_tridiag columns (0 = none)              */
   int32_t max_iter;         /* n_iter (already min'ed with N if terminate_cg_by_size, :170)        */
   int32_t max_tridiag_iter; /* n_tridiag_iter = min(max_tridiag_iter, N) (:171)                    */
-  int32_t reserved;
+  int32_t floor_max_iter;   /* the caller's ORIGINAL max_iter for the stop-rule floors min(10, max_iter-1) and
+                             * min(n_tridiag_iter, max_iter-1) (:303-305), which the reference evaluates with the
+                             * unclipped value; 0 = same as max_iter                                */
   float tolerance;          /* settings.cg_tolerance (:150-151)                                    */
   float eps;                /* 1e-10 (:104)                                                        */
   float stop_updating_after;/* 1e-10 (:105)                                                        */
@@ -152,6 +162,17 @@ int lo_cg_set_onchip(int enable);
 size_t lo_pivoted_cholesky_workspace_bytes(const lo_op_desc* op, int32_t max_rank);
 int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_tol, float* L_rows, int64_t* perm,
                             int32_t* rank_out, void* ws, size_t ws_bytes, void* stream);
+/* The same for an operator that does not lower to a descriptor: the generic row fetch of the reference
+ * (`matrix[..., pi_m, :]`, _pivoted_cholesky.py:81 -> LinearOperator.__getitem__ tensor-index branch,
+ * operators/_linear_operator.py:2882-2902) stays a callback, everything else runs in the same kernels.
+ *   diag    [B, N] device: matrix._diagonal() (:39)
+ *   row_cb  fetches, for the pivots piv [B] (int64, DEVICE pointer), the rows K[b, piv[b], :] into rows [B, N];
+ *           must enqueue on `stream` and must not synchronise; called once per pivot.  Returns 0 on success. */
+typedef int (*lo_rowfetch_cb)(void* user, const int64_t* piv, float* rows, int64_t B, int64_t N, void* stream);
+size_t lo_pivoted_cholesky_cb_workspace_bytes(int64_t B, int64_t N, int32_t max_rank);
+int lo_pivoted_cholesky_cb_f32(int64_t B, int64_t N, const float* diag, lo_rowfetch_cb row_cb, void* row_user,
+                               int32_t max_rank, float error_tol, float* L_rows, int64_t* perm, int32_t* rank_out,
+                               void* ws, size_t ws_bytes, void* stream);
 
 /* ---- AddedDiagLinearOperator._init_cache* (added_diag_linear_operator.py:144-184) ------------- */
 /* From L [B,N,k] and the diagonal builds Q [B,N,k] (the reference's _q_cache, up to the sign/rotation

@@ -16,9 +16,10 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "liblo_amd.so")
 _lib = None
 
-LO_OP_LOWRANK_DIAG, LO_OP_DENSE_DIAG, LO_OP_KRON_DIAG, LO_OP_CALLBACK = 0, 1, 2, 3
+LO_OP_LOWRANK_DIAG, LO_OP_DENSE_DIAG, LO_OP_KRON_DIAG, LO_OP_CALLBACK, LO_OP_SUM = 0, 1, 2, 3, 4
+LO_MAX_TERMS = 4
 LO_DIAG_NONE, LO_DIAG_FULL, LO_DIAG_CONST = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 LO_ERR_UNSUPPORTED = -4
 _ERR = {-1: "bad argument", -2: "HIP launch/runtime failure", -3: "workspace too small", -4: "unsupported shape"}
@@ -28,6 +29,7 @@ EXPORTS = [
     "lo_matvec_workspace_bytes", "lo_matvec_f32",
     "lo_cg_workspace_bytes", "lo_cg_solve_f32", "lo_cg_set_onchip",
     "lo_pivoted_cholesky_workspace_bytes", "lo_pivoted_cholesky_f32",
+    "lo_pivoted_cholesky_cb_workspace_bytes", "lo_pivoted_cholesky_cb_f32",
     "lo_precond_build_workspace_bytes", "lo_precond_build_f32", "lo_precond_build_strided_f32",
     "lo_precond_apply_workspace_bytes", "lo_precond_apply_f32",
     "lo_lanczos_workspace_bytes", "lo_lanczos_tridiag_f32", "lo_lanczos_permute_f32",
@@ -45,8 +47,12 @@ class HipExtensionError(RuntimeError):
 
 
 class OpDesc(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("diag_mode", C.c_int32), ("B", C.c_int64), ("N", C.c_int64), ("R", C.c_int64),
-                ("n2", C.c_int64), ("A0", C.c_void_p), ("A1", C.c_void_p), ("d", C.c_void_p)]
+    pass
+
+
+OpDesc._fields_ = [("kind", C.c_int32), ("diag_mode", C.c_int32), ("B", C.c_int64), ("N", C.c_int64), ("R", C.c_int64),
+                   ("n2", C.c_int64), ("A0", C.c_void_p), ("A1", C.c_void_p), ("d", C.c_void_p),
+                   ("nterms", C.c_int32), ("reserved", C.c_int32), ("terms", C.POINTER(OpDesc))]
 
 
 class PrecondDesc(C.Structure):
@@ -56,7 +62,7 @@ class PrecondDesc(C.Structure):
 
 class CgParams(C.Structure):
     _fields_ = [("c", C.c_int64), ("n_tridiag", C.c_int32), ("max_iter", C.c_int32), ("max_tridiag_iter", C.c_int32),
-                ("reserved", C.c_int32), ("tolerance", C.c_float), ("eps", C.c_float),
+                ("floor_max_iter", C.c_int32), ("tolerance", C.c_float), ("eps", C.c_float),
                 ("stop_updating_after", C.c_float), ("pad", C.c_float)]
 
 
@@ -76,6 +82,7 @@ class MinresInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("matvecs", C.c_int32), ("converged", C.c_int32), ("conv", C.c_float)]
 
 
+ROWFETCH_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p)
 MATVEC_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p)
 
 
@@ -124,6 +131,12 @@ def load():
     lib.lo_pivoted_cholesky_f32.restype = C.c_int
     lib.lo_pivoted_cholesky_f32.argtypes = [P(OpDesc), C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                             P(C.c_int32), C.c_void_p, sz, C.c_void_p]
+    lib.lo_pivoted_cholesky_cb_workspace_bytes.restype = sz
+    lib.lo_pivoted_cholesky_cb_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
+    lib.lo_pivoted_cholesky_cb_f32.restype = C.c_int
+    lib.lo_pivoted_cholesky_cb_f32.argtypes = [C.c_int64, C.c_int64, C.c_void_p, ROWFETCH_CB, C.c_void_p, C.c_int32,
+                                               C.c_float, C.c_void_p, C.c_void_p, P(C.c_int32), C.c_void_p, sz,
+                                               C.c_void_p]
     lib.lo_precond_build_workspace_bytes.restype = sz
     lib.lo_precond_build_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
     lib.lo_precond_build_f32.restype = C.c_int
@@ -249,10 +262,10 @@ class DevArray:
     """Borrowed device pointer exposed through __cuda_array_interface__ so that torch can view it
     (used to hand the C engine's buffers to Python matvec closures without a copy)."""
 
-    def __init__(self, p: int, shape):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(p), False),
+    def __init__(self, p: int, shape, typestr: str = "<f4"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(p), False),
                                          "version": 2, "strides": None}
 
 
-def as_tensor(p: int, shape, device) -> torch.Tensor:
-    return torch.as_tensor(DevArray(p, shape), device=device)
+def as_tensor(p: int, shape, device, typestr: str = "<f4") -> torch.Tensor:
+    return torch.as_tensor(DevArray(p, shape, typestr), device=device)

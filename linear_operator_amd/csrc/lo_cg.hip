@@ -33,7 +33,7 @@ constexpr int kLockstepMinCols = 4;
 struct CgDev {
   int64_t B, N;
   int c, S, S_dot, S_rz;
-  int n_tridiag, max_iter, n_tridiag_iter, T;
+  int n_tridiag, max_iter, n_tridiag_iter, T;  // max_iter: the value the stop-rule floors are taken from
   float tol, eps, stop_after;
   int check_nan_first;
   // vectors
@@ -440,8 +440,9 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   // operator-resident fast path scratch (c == 1): granule buffer, error word, per-iteration residuals
   dd.oc_gbuf = ar.take<unsigned long long>(onchip_gbuf_bytes(64) / sizeof(unsigned long long));
   dd.oc_err = reinterpret_cast<int*>(reinterpret_cast<char*>(dd.ctrl) + offsetof(CgCtrl, oc_err));  // (+ oc_next)
-  int oc_iters = std::min(10, prm->max_iter - 1);
-  if (prm->n_tridiag) oc_iters = std::max(oc_iters, std::min(prm->max_tridiag_iter, prm->max_iter - 1));
+  const int fmi0 = prm->floor_max_iter > 0 ? prm->floor_max_iter : prm->max_iter;
+  int oc_iters = std::min(10, fmi0 - 1);
+  if (prm->n_tridiag) oc_iters = std::max(oc_iters, std::min(prm->max_tridiag_iter, fmi0 - 1));
   oc_iters = std::max(1, oc_iters + 1);
   const bool oc_shape = op->kind == LO_OP_LOWRANK_DIAG && c <= 64 && N >= 1024 && N <= 32768;
   const size_t oc_n = oc_shape ? (size_t)B * c : 1;
@@ -531,6 +532,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
 
   CgDev d;
   MatvecPlan pl;
+  PlanGuard pl_guard(&pl);
   const float* Qp = nullptr;
   float* upart = nullptr;
   int rc = LO_OK;
@@ -538,7 +540,8 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   if (rc) return rc;
   const Split sp = pl.sp;
   d.n_tridiag = prm->n_tridiag;
-  d.max_iter = prm->max_iter;
+  const int fmi = prm->floor_max_iter > 0 ? prm->floor_max_iter : prm->max_iter;  // (linear_cg.py:303-305)
+  d.max_iter = fmi;
   d.n_tridiag_iter = prm->max_tridiag_iter;
   d.T = prm->max_tridiag_iter;
   d.tol = prm->tolerance;
@@ -572,8 +575,8 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   bool x_written = false;  // the resident kernel already wrote result * rhs_norm
   CgCtrl h;
   memset(&h, 0, sizeof(h));
-  int kfloor0 = std::min(10, prm->max_iter - 1);
-  if (prm->n_tridiag) kfloor0 = std::max(kfloor0, std::min(prm->max_tridiag_iter, prm->max_iter - 1));  // first stop
+  int kfloor0 = std::min(10, fmi - 1);
+  if (prm->n_tridiag) kfloor0 = std::max(kfloor0, std::min(prm->max_tridiag_iter, fmi - 1));  // first stop
   const int oc_nwg = onchip_num_workgroups();
   // no preconditioner (N < min_preconditioning_size in the host API): the resident kernel runs with Q = 0 and
   // 1/d = 1, i.e. z = r and r.z = ||r||^2, which is the reference's unpreconditioned update (linear_cg.py:49-95)
@@ -730,9 +733,9 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
 
   // ---- iterations ----
   const float* zsrc = precond ? d.z : d.r;
-  const int kfloor = std::min(10, prm->max_iter - 1);
+  const int kfloor = std::min(10, fmi - 1);
   int first_poll = kfloor;
-  if (prm->n_tridiag) first_poll = std::max(first_poll, std::min(prm->max_tridiag_iter, prm->max_iter - 1));
+  if (prm->n_tridiag) first_poll = std::max(first_poll, std::min(prm->max_tridiag_iter, fmi - 1));
   const bool opaque = (op->kind == LO_OP_CALLBACK) || (precond_cb != nullptr);
   const int chunk = opaque ? 1 : 4;
   auto poll = [&]() -> int {

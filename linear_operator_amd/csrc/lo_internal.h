@@ -144,7 +144,24 @@ struct MatvecPlan {
   float* kron_tmp;    // [B,N,c]
   lo_matvec_cb cb;
   void* cb_user;
+  // LO_OP_SUM: one sub-plan per term (host heap, released by matvec_plan_free) and the buffer a term beyond the
+  // first is computed into before it is added onto y
+  int nterms;
+  MatvecPlan* sub;
+  float* ytmp;        // [B,N,c]
 };
+void matvec_plan_free(MatvecPlan* pl);
+// releases a plan's sub-plans on every exit path of the function that owns it
+struct PlanGuard {
+  MatvecPlan* p;
+  explicit PlanGuard(MatvecPlan* q) : p(q) {
+    p->sub = nullptr;
+    p->nterms = 0;
+  }
+  ~PlanGuard() { matvec_plan_free(p); }
+};
+// y += a (elementwise, n floats)
+int vec_axpy1(float* y, const float* a, size_t n, const int* stop, hipStream_t st);
 size_t matvec_plan_bytes(const lo_op_desc* op, int64_t c, Split sp);
 int matvec_plan_init(MatvecPlan* pl, const lo_op_desc* op, lo_matvec_cb cb, void* cb_user, int64_t c, Split sp,
                      Arena* ar, hipStream_t st);

@@ -505,6 +505,7 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
   d.q = q_mat;
   d.t = t_mat;
   MatvecPlan pl;
+  PlanGuard pl_guard(&pl);
   int rc = matvec_plan_init(&pl, op, matvec, matvec_user, P, sp, &ar, st);
   if (rc) return rc;
   if (!ar.ok) return LO_ERR_WORKSPACE;

@@ -13,8 +13,24 @@ static int padded_rank(int64_t R) {
   return (int)(4 * p);
 }
 
+static bool sum_terms_ok(const lo_op_desc* op) {
+  if (op->nterms < 2 || op->nterms > LO_MAX_TERMS || !op->terms) return false;
+  for (int i = 0; i < op->nterms; ++i) {
+    const lo_op_desc& t = op->terms[i];
+    const bool kind_ok = t.kind == LO_OP_LOWRANK_DIAG || t.kind == LO_OP_DENSE_DIAG || t.kind == LO_OP_KRON_DIAG;
+    if (!kind_ok || t.diag_mode != LO_DIAG_NONE || t.B != op->B || t.N != op->N) return false;
+  }
+  return true;
+}
+
 size_t matvec_plan_bytes(const lo_op_desc* op, int64_t c, Split sp) {
   Arena ar(nullptr, 0);
+  if (op->kind == LO_OP_SUM) {
+    if (!sum_terms_ok(op)) return 256;
+    size_t total = align_up((size_t)op->B * op->N * c * sizeof(float), 256) + 256;
+    for (int i = 0; i < op->nterms; ++i) total += matvec_plan_bytes(&op->terms[i], c, sp);
+    return total;
+  }
   if (op->kind == LO_OP_LOWRANK_DIAG) {
     const int R4 = padded_rank(op->R);
     if (R4 != op->R) ar.take<float>((size_t)op->B * op->N * R4);
@@ -37,6 +53,9 @@ int matvec_plan_init(MatvecPlan* pl, const lo_op_desc* op, lo_matvec_cb cb, void
   pl->kron_tmp = nullptr;
   pl->lda = pl->R4 = 0;
   pl->S_dot = sp.S;
+  pl->nterms = 0;
+  pl->sub = nullptr;
+  pl->ytmp = nullptr;
   if (op->B < 1 || op->N < 1 || c < 1) return LO_ERR_BADARG;
   if (op->diag_mode != LO_DIAG_NONE && !op->d) return LO_ERR_BADARG;
   switch (op->kind) {
@@ -72,10 +91,37 @@ int matvec_plan_init(MatvecPlan* pl, const lo_op_desc* op, lo_matvec_cb cb, void
     case LO_OP_CALLBACK:
       if (!cb) return LO_ERR_BADARG;
       break;
+    case LO_OP_SUM: {
+      if (!sum_terms_ok(op)) return LO_ERR_BADARG;
+      pl->ytmp = ar->take<float>((size_t)op->B * op->N * c);
+      pl->nterms = op->nterms;
+      pl->sub = new MatvecPlan[op->nterms];
+      for (int i = 0; i < op->nterms; ++i) {
+        lo_op_desc t = op->terms[i];
+        if (i == 0) {  // the tree's one diagonal rides on the first term's epilogue
+          t.diag_mode = op->diag_mode;
+          t.d = op->d;
+        }
+        const int rc = matvec_plan_init(&pl->sub[i], &t, nullptr, nullptr, c, sp, ar, st);
+        if (rc) {
+          matvec_plan_free(pl);
+          return rc;
+        }
+      }
+      break;
+    }
     default:
       return LO_ERR_BADARG;
   }
   return ar->ok ? LO_OK : LO_ERR_WORKSPACE;
+}
+
+void matvec_plan_free(MatvecPlan* pl) {
+  if (pl->sub) {
+    for (int i = 0; i < pl->nterms; ++i) matvec_plan_free(&pl->sub[i]);
+    delete[] pl->sub;
+    pl->sub = nullptr;
+  }
 }
 
 int matvec_run(const MatvecPlan* pl, const float* v, float* y, float* dot_part, const int* stop, hipStream_t st) {
@@ -105,6 +151,14 @@ int matvec_run(const MatvecPlan* pl, const float* v, float* y, float* dot_part, 
       if (rc) return LO_ERR_LAUNCH;
       if (dot_part) rc = vec_dot_part(v, y, pl->c, dot_part, op.B, op.N, pl->sp, stop, st);
       return rc;
+    case LO_OP_SUM:  // sum(op._matmul(rhs) for op in linear_ops), left to right (sum_linear_operator.py:47-51)
+      rc = matvec_run(&pl->sub[0], v, y, nullptr, stop, st);
+      for (int i = 1; i < pl->nterms && !rc; ++i) {
+        rc = matvec_run(&pl->sub[i], v, pl->ytmp, nullptr, stop, st);
+        if (!rc) rc = vec_axpy1(y, pl->ytmp, (size_t)op.B * op.N * pl->c, stop, st);
+      }
+      if (!rc && dot_part) rc = vec_dot_part(v, y, pl->c, dot_part, op.B, op.N, pl->sp, stop, st);
+      return rc;
   }
   return LO_ERR_BADARG;
 }
@@ -128,7 +182,7 @@ using namespace lo;
 
 extern "C" {
 
-int lo_abi_version(void) { return 2; }
+int lo_abi_version(void) { return 3; }
 const char* lo_target_arch(void) { return "gfx950"; }
 
 size_t lo_matvec_workspace_bytes(const lo_op_desc* op, int64_t c) {
@@ -146,7 +200,9 @@ int lo_matvec_f32(const lo_op_desc* op, const float* v, float* y, int64_t c, voi
   MatvecPlan pl;
   int rc = matvec_plan_init(&pl, op, nullptr, nullptr, c, sp, &ar, st);
   if (rc) return rc;
-  return matvec_run(&pl, v, y, nullptr, nullptr, st);
+  rc = matvec_run(&pl, v, y, nullptr, nullptr, st);
+  matvec_plan_free(&pl);
+  return rc;
 }
 
 }  // extern "C"

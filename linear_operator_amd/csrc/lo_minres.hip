@@ -389,6 +389,7 @@ int lo_minres_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user, 
   const int c = (int)prm->c, Q = prm->n_shifts;
   MrDev d;
   MatvecPlan pl;
+  PlanGuard pl_guard(&pl);
   MrHost h;
   int rc = LO_OK;
   mr_layout(op, pre, precond_cb != nullptr, prm, ws, ws_bytes, &d, &pl, matvec, matvec_user, &h, st, &rc, true);

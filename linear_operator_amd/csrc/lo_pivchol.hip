@@ -21,6 +21,8 @@
 #pragma clang fp contract(off)
 
 #include "lo_device.h"
+#include <string.h>
+
 #include "lo_internal.h"
 
 namespace lo {
@@ -32,6 +34,10 @@ struct PcCtrl {
 
 struct PcDev {
   lo_op_desc op;
+  // the terms whose rows / diagonals are summed left to right (SumLinearOperator._diagonal / _getitem of the
+  // reference, sum_linear_operator.py:31-45): one entry for a plain operator
+  int nterms;
+  lo_op_desc terms[LO_MAX_TERMS];
   int64_t B, N;
   int S, rows;     // position split
   int max_rank;
@@ -57,13 +63,14 @@ __device__ __forceinline__ float seq_dot(const float* __restrict__ a, const floa
   return acc;
 }
 
-__device__ __forceinline__ float src_diag(const PcDev& d, int64_t b, int i) {
-  const lo_op_desc& op = d.op;
+__device__ __forceinline__ float src_diag(const PcDev& d, const lo_op_desc& op, int64_t b, int i) {
   if (op.kind == LO_OP_LOWRANK_DIAG) {
     const float* ci = op.A0 + ((size_t)b * d.N + i) * op.R;
     return seq_dot(ci, ci, (int)op.R);
   } else if (op.kind == LO_OP_DENSE_DIAG) {
     return op.A0[((size_t)b * d.N + i) * d.N + i];
+  } else if (op.kind == LO_OP_CALLBACK) {  // generic operator: A1 = matrix._diagonal(), A0 = the fetched pivot rows
+    return op.A1[(size_t)b * d.N + i];
   } else {
     const int n1 = (int)op.R, n2 = (int)op.n2;
     const int i1 = i / n2, i2 = i % n2;
@@ -134,28 +141,35 @@ __global__ __launch_bounds__(kThreads) void k_pc_init(PcDev d) {
   const int64_t b = blockIdx.y;
   const int N = (int)d.N;
   const int j0 = s * d.rows, j1 = min(N, j0 + d.rows);
-  const bool lowrank = d.op.kind == LO_OP_LOWRANK_DIAG;
-  const int R = lowrank ? (int)d.op.R : 0;
-  const int tp = lowrank ? tile_positions(R) : kThreads;
+  // positions are walked in tiles small enough for the fattest low-rank term's LDS tile
+  int tp = kThreads;
+  for (int it = 0; it < d.nterms; ++it)
+    if (d.terms[it].kind == LO_OP_LOWRANK_DIAG) tp = min(tp, tile_positions((int)d.terms[it].R));
   float lmax = -INFINITY, lsum = 0.f;
   float bv = -INFINITY;
   int bj = 0x7fffffff;
   for (int t0 = j0; t0 < j1; t0 += tp) {
     const int np = min(tp, j1 - t0);
-    if (lowrank) {
-      __syncthreads();
-      stage_rows(d.op.A0 + (size_t)b * N * R, R, nullptr, t0, np, sh);
-      __syncthreads();
-    }
     const int i = t0 + threadIdx.x;
-    if ((int)threadIdx.x < np) {
-      float v;
-      if (lowrank) {
-        const float* row = sh + threadIdx.x * (R + 1);
-        v = seq_dot(row, row, R);                      // (root ** 2).sum(-1), root_linear_operator.py:22-28
-      } else {
-        v = src_diag(d, b, i);
+    float v = 0.f;
+    for (int it = 0; it < d.nterms; ++it) {
+      const lo_op_desc& op = d.terms[it];
+      float tv = 0.f;
+      if (op.kind == LO_OP_LOWRANK_DIAG) {
+        const int R = (int)op.R;
+        __syncthreads();
+        stage_rows(op.A0 + (size_t)b * N * R, R, nullptr, t0, np, sh);
+        __syncthreads();
+        if ((int)threadIdx.x < np) {
+          const float* row = sh + threadIdx.x * (R + 1);
+          tv = seq_dot(row, row, R);                   // (root ** 2).sum(-1), root_linear_operator.py:22-28
+        }
+      } else if ((int)threadIdx.x < np) {
+        tv = src_diag(d, op, b, i);
       }
+      v = (it == 0) ? tv : v + tv;                     // sum(op._diagonal() for op in linear_ops), left to right
+    }
+    if ((int)threadIdx.x < np) {
       d.diag[(size_t)b * N + i] = v;
       d.perm[(size_t)b * N + i] = i;
       lmax = fmaxf(lmax, v);
@@ -247,45 +261,68 @@ __global__ __launch_bounds__(kThreads) void k_pc_update(PcDev d, int m) {
   const int s = blockIdx.x;
   const int64_t b = blockIdx.y;
   const int N = (int)d.N;
-  const lo_op_desc& op = d.op;
   const long long* perm = d.perm + (size_t)b * N;
   float* diag = d.diag + (size_t)b * N;
   float* Lb = d.L + (size_t)b * d.max_rank * N;
   const int pim = (int)d.pim[b];
   const float piv = sqrtf(d.maxval[b]);
-  const bool lowrank = op.kind == LO_OP_LOWRANK_DIAG;
-  const int R = lowrank ? (int)op.R : 0;
+  // shared memory: [max_rank] L[j][pi_m] | per low-rank term its row C[pi_m,:] | one row tile (reused by the terms)
   float* upd = sh;
   float* crow = sh + d.max_rank;
-  float* tile = crow + R;
+  int Rtot = 0, tp = kThreads;
+  for (int it = 0; it < d.nterms; ++it)
+    if (d.terms[it].kind == LO_OP_LOWRANK_DIAG) {
+      Rtot += (int)d.terms[it].R;
+      tp = min(tp, tile_positions((int)d.terms[it].R));
+    }
+  float* tile = crow + Rtot;
   for (int j = threadIdx.x; j < m; j += kThreads) upd[j] = Lb[(size_t)j * N + pim];
-  for (int r = threadIdx.x; r < R; r += kThreads) crow[r] = op.A0[((size_t)b * N + pim) * R + r];
+  {
+    int off = 0;
+    for (int it = 0; it < d.nterms; ++it) {
+      const lo_op_desc& tm = d.terms[it];
+      if (tm.kind != LO_OP_LOWRANK_DIAG) continue;
+      const int R = (int)tm.R;
+      for (int r = threadIdx.x; r < R; r += kThreads) crow[off + r] = tm.A0[((size_t)b * N + pim) * R + r];
+      off += R;
+    }
+  }
   __syncthreads();
   const int j0 = max(s * d.rows, m + 1), j1 = min(N, (s + 1) * d.rows);
-  const int tp = lowrank ? tile_positions(R) : kThreads;
   float lerr = 0.f;
   float bv = -INFINITY;
   int bj = 0x7fffffff;
-  const int n1 = (int)op.R, n2 = (int)op.n2;
   for (int t0 = j0; t0 < j1; t0 += tp) {
     const int np = min(tp, j1 - t0);
-    if (lowrank) {
-      __syncthreads();
-      stage_rows(op.A0 + (size_t)b * N * R, R, perm, t0, np, tile);
-      __syncthreads();
-    }
-    if ((int)threadIdx.x < np) {
-      const int j = t0 + threadIdx.x;
-      const int i = (int)perm[j];
-      float rowv;
-      if (lowrank) {
-        rowv = seq_dot(crow, tile + threadIdx.x * (R + 1), R);
-      } else if (op.kind == LO_OP_DENSE_DIAG) {
-        rowv = op.A0[((size_t)b * N + pim) * N + i];
-      } else {
-        const int p1 = pim / n2, p2 = pim % n2, i1 = i / n2, i2 = i % n2;
-        rowv = op.A0[((size_t)b * n1 + p1) * n1 + i1] * op.A1[((size_t)b * n2 + p2) * n2 + i2];
+    const bool live = (int)threadIdx.x < np;
+    const int j = t0 + threadIdx.x;
+    const int i = live ? (int)perm[j] : 0;
+    float rowv = 0.f;
+    int off = 0;
+    for (int it = 0; it < d.nterms; ++it) {   // row pi_m of the sum = sum of the terms' rows, left to right
+      const lo_op_desc& tm = d.terms[it];
+      float tv = 0.f;
+      if (tm.kind == LO_OP_LOWRANK_DIAG) {
+        const int R = (int)tm.R;
+        __syncthreads();
+        stage_rows(tm.A0 + (size_t)b * N * R, R, perm, t0, np, tile);
+        __syncthreads();
+        if (live) tv = seq_dot(crow + off, tile + threadIdx.x * (R + 1), R);
+        off += R;
+      } else if (live) {
+        if (tm.kind == LO_OP_DENSE_DIAG) {
+          tv = tm.A0[((size_t)b * N + pim) * N + i];
+        } else if (tm.kind == LO_OP_CALLBACK) {
+          tv = tm.A0[(size_t)b * N + i];  // row pi_m of this member, fetched by the host callback for this pivot
+        } else {
+          const int n1 = (int)tm.R, n2 = (int)tm.n2;
+          const int p1 = pim / n2, p2 = pim % n2, i1 = i / n2, i2 = i % n2;
+          tv = tm.A0[((size_t)b * n1 + p1) * n1 + i1] * tm.A1[((size_t)b * n2 + p2) * n2 + i2];
+        }
       }
+      rowv = (it == 0) ? tv : rowv + tv;
+    }
+    if (live) {
       float v = rowv;
       if (m > 0) {
         float acc = upd[0] * Lb[i];
@@ -312,6 +349,13 @@ static void pc_layout(const lo_op_desc* op, int max_rank, Arena& ar, PcDev* d) {
   const int64_t B = op->B, N = op->N;
   Split sp = choose_split(B, N, 1024);
   d->op = *op;
+  if (op->kind == LO_OP_SUM) {
+    d->nterms = op->terms ? std::min<int>(std::max<int>(op->nterms, 0), LO_MAX_TERMS) : 0;
+    for (int i = 0; i < d->nterms; ++i) d->terms[i] = op->terms[i];
+  } else {
+    d->nterms = 1;
+    d->terms[0] = *op;
+  }
   d->B = B; d->N = N; d->S = sp.S; d->rows = sp.rows; d->max_rank = max_rank;
   d->ctrl = ar.take<PcCtrl>(1);
   d->diag = ar.take<float>((size_t)B * N);
@@ -324,6 +368,10 @@ static void pc_layout(const lo_op_desc* op, int max_rank, Arena& ar, PcDev* d) {
   d->arg_v = ar.take<float>((size_t)B * sp.S);
   d->arg_j = ar.take<int>((size_t)B * sp.S);
 }
+
+int pc_stream(const lo_op_desc* op, const float* diag0, lo_rowfetch_cb row_cb, void* row_user, int32_t max_rank,
+              float error_tol, float* L_rows, int64_t* perm, int32_t* rank_out, void* ws, size_t ws_bytes,
+              hipStream_t st);
 
 }  // namespace lo
 
@@ -342,20 +390,69 @@ size_t lo_pivoted_cholesky_workspace_bytes(const lo_op_desc* op, int32_t max_ran
 int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_tol, float* L_rows, int64_t* perm,
                             int32_t* rank_out, void* ws, size_t ws_bytes, void* stream) {
   if (!op || !L_rows || !perm || !rank_out || !ws || max_rank < 1) return LO_ERR_BADARG;
-  if (op->kind != LO_OP_LOWRANK_DIAG && op->kind != LO_OP_DENSE_DIAG && op->kind != LO_OP_KRON_DIAG)
+  if (op->kind == LO_OP_SUM) {
+    if (op->nterms < 2 || op->nterms > LO_MAX_TERMS || !op->terms) return LO_ERR_BADARG;
+    for (int i = 0; i < op->nterms; ++i) {
+      const lo_op_desc& t = op->terms[i];
+      if ((t.kind != LO_OP_LOWRANK_DIAG && t.kind != LO_OP_DENSE_DIAG && t.kind != LO_OP_KRON_DIAG) || t.B != op->B ||
+          t.N != op->N)
+        return LO_ERR_BADARG;
+    }
+  } else if (op->kind != LO_OP_LOWRANK_DIAG && op->kind != LO_OP_DENSE_DIAG && op->kind != LO_OP_KRON_DIAG) {
     return LO_ERR_UNSUPPORTED;
+  }
   if (op->N > 0x7ffffff0) return LO_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t B = op->B, N = op->N;
-  const int rank = (int)std::min<int64_t>(max_rank, N);  // :33
+  const int rank = (int)std::min<int64_t>(max_rank, op->N);  // :33
   if (pc_onchip_eligible(op, max_rank)) {  // operator-resident fast path (lo_pivchol_onchip.hip), same results
     const int rc = pc_onchip_run(op, rank, max_rank, error_tol, L_rows, (long long*)perm, rank_out, ws, ws_bytes, st);
     if (rc != LO_ERR_LAUNCH) return rc;
     (void)hipGetLastError();  // exchange timed out (co-residency lost): redo with the streaming engine
   }
+  return pc_stream(op, nullptr, nullptr, nullptr, max_rank, error_tol, L_rows, perm, rank_out, ws, ws_bytes, st);
+}
+
+size_t lo_pivoted_cholesky_cb_workspace_bytes(int64_t B, int64_t N, int32_t max_rank) {
+  lo_op_desc op;
+  memset(&op, 0, sizeof(op));
+  op.kind = LO_OP_CALLBACK; op.B = B; op.N = N;
+  Arena ar(nullptr, 0);
+  PcDev d;
+  pc_layout(&op, max_rank, ar, &d);
+  ar.take<float>((size_t)B * N);  // the fetched rows
+  return ar.off + 1024;
+}
+
+int lo_pivoted_cholesky_cb_f32(int64_t B, int64_t N, const float* diag, lo_rowfetch_cb row_cb, void* row_user,
+                               int32_t max_rank, float error_tol, float* L_rows, int64_t* perm, int32_t* rank_out,
+                               void* ws, size_t ws_bytes, void* stream) {
+  if (!diag || !row_cb || !L_rows || !perm || !rank_out || !ws || max_rank < 1 || B < 1 || N < 1) return LO_ERR_BADARG;
+  if (N > 0x7ffffff0) return LO_ERR_UNSUPPORTED;
+  lo_op_desc op;
+  memset(&op, 0, sizeof(op));
+  op.kind = LO_OP_CALLBACK; op.B = B; op.N = N;
+  return pc_stream(&op, diag, row_cb, row_user, max_rank, error_tol, L_rows, perm, rank_out, ws, ws_bytes,
+                   (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+namespace lo {
+
+// streaming engine shared by the descriptor and the callback entry points
+int pc_stream(const lo_op_desc* op, const float* diag0, lo_rowfetch_cb row_cb, void* row_user, int32_t max_rank,
+              float error_tol, float* L_rows, int64_t* perm, int32_t* rank_out, void* ws, size_t ws_bytes,
+              hipStream_t st) {
+  const int64_t B = op->B, N = op->N;
+  const int rank = (int)std::min<int64_t>(max_rank, N);  // :33
   Arena ar(ws, ws_bytes);
   PcDev d;
   pc_layout(op, max_rank, ar, &d);
+  if (row_cb) {  // generic operator: one "term" whose rows arrive through the callback
+    float* rows = ar.take<float>((size_t)B * N);
+    d.terms[0].A0 = rows;
+    d.terms[0].A1 = diag0;
+  }
   if (!ar.ok) return LO_ERR_WORKSPACE;
   d.tol = error_tol;
   d.L = L_rows;
@@ -363,12 +460,22 @@ int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_
   LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, sizeof(PcCtrl), st));
   LO_HIP_CHECK(hipMemsetAsync(L_rows, 0, sizeof(float) * (size_t)B * max_rank * N, st));  // L = zeros :36-42
   dim3 grid(d.S, (unsigned)B), block(kThreads);
-  const size_t R = (op->kind == LO_OP_LOWRANK_DIAG) ? (size_t)op->R : 0;
-  size_t tile_floats = 0;
-  if (R) {
-    size_t tp = 12288 / (R + 1);
-    tp = tp >= (size_t)kThreads ? (size_t)kThreads : (tp < 1 ? 1 : tp);
-    tile_floats = tp * (R + 1);
+  // shared memory: the pivot rows of all low-rank terms (R floats in total) + one row tile sized for the walk of the
+  // fattest low-rank term (the kernels walk min over the terms of tile_positions(R_i) positions at a time)
+  size_t R = 0, tile_floats = 0;
+  {
+    size_t tpmin = kThreads;
+    for (int it = 0; it < d.nterms; ++it)
+      if (d.terms[it].kind == LO_OP_LOWRANK_DIAG) {
+        const size_t Ri = (size_t)d.terms[it].R;
+        R += Ri;
+        size_t tp = 12288 / (Ri + 1);
+        tp = tp >= (size_t)kThreads ? (size_t)kThreads : (tp < 1 ? 1 : tp);
+        tpmin = std::min(tpmin, tp);
+      }
+    for (int it = 0; it < d.nterms; ++it)
+      if (d.terms[it].kind == LO_OP_LOWRANK_DIAG)
+        tile_floats = std::max(tile_floats, tpmin * ((size_t)d.terms[it].R + 1));
   }
   if ((tile_floats + R + max_rank) * sizeof(float) > 60000) return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("pc_init", st);
@@ -381,6 +488,10 @@ int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_
     hipLaunchKernelGGL(k_pc_ctrl, dim3(1), block, 0, st, d, m);
     LO_PROF_END(st);
     if (m + 1 < N) {  // :77
+      if (row_cb) {  // row = matrix[..., pi_m, :] (:81): the reference's generic __getitem__, as a callback
+        if (row_cb(row_user, (const int64_t*)d.pim, const_cast<float*>(d.terms[0].A0), B, N, (void*)st))
+          return LO_ERR_LAUNCH;
+      }
       LO_PROF_BEGIN("pc_update", st);
       hipLaunchKernelGGL(k_pc_update, grid, block, (max_rank + R + tile_floats) * sizeof(float), st, d, m);
       LO_PROF_END(st);
@@ -394,4 +505,4 @@ int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_
   return LO_OK;
 }
 
-}  // extern "C"
+}  // namespace lo

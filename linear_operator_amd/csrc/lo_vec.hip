@@ -82,4 +82,28 @@ int vec_add_diag(const float* dd, int dd_mode, const float* v, float* y, int64_t
   return LO_OK;
 }
 
+__global__ __launch_bounds__(kThreads) void k_axpy1(float* __restrict__ y, const float* __restrict__ a, size_t n,
+                                                     const int* __restrict__ stop) {
+  if (stop && *stop) return;
+  const size_t n4 = n / 4;
+  const size_t stride = (size_t)gridDim.x * kThreads;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
+    float4 yv = reinterpret_cast<float4*>(y)[i];
+    const float4 av = reinterpret_cast<const float4*>(a)[i];
+    yv.x += av.x; yv.y += av.y; yv.z += av.z; yv.w += av.w;
+    reinterpret_cast<float4*>(y)[i] = yv;
+  }
+  for (size_t i = 4 * n4 + (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) y[i] += a[i];
+}
+
+// y += a: the accumulation step of a SumLinearOperator matvec (sum_linear_operator.py:47-51)
+int vec_axpy1(float* y, const float* a, size_t n, const int* stop, hipStream_t st) {
+  const unsigned grid = (unsigned)std::min<size_t>((n / 4 + kThreads - 1) / kThreads + 1, 16384);
+  LO_PROF_BEGIN("vec_axpy1", st);
+  hipLaunchKernelGGL(k_axpy1, dim3(grid), dim3(kThreads), 0, st, y, a, n, stop);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
 }  // namespace lo

@@ -21,8 +21,8 @@ def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, U, 
         wrt L :  2 g P^-1 L  +  U (V^T L) + V (U^T L),   U = -ppv / P, V = ppv g      (then through the pivoted Cholesky)
         wrt d :  g diag(P^-1)   (the probes' term sum_p U o V already reaches d: the diagonal's tensor is itself one of
                                  the preconditioner arguments of the Function and receives `precond_arg_grads`)
-    Skipped (the estimator stays unbiased without it) when the preconditioner is not the Woodbury closure of an
-    AddedDiagLinearOperator over a dense-root or dense operator."""
+    Applies to the Woodbury closure of an AddedDiagLinearOperator; the pull-back through the pivoted Cholesky works
+    for any operator (pivoted_cholesky_vjp reaches the pivot columns through the differentiable Matmul)."""
     from ..operators.added_diag_linear_operator import AddedDiagLinearOperator, WoodburyPreconditionClosure
     from ..operators.diag_linear_operator import ConstantDiagLinearOperator
     from ._pivoted_cholesky import pivoted_cholesky_vjp
@@ -31,7 +31,7 @@ def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, U, 
     if not isinstance(pre, WoodburyPreconditionClosure) or not isinstance(linear_op, AddedDiagLinearOperator):
         return matrix_arg_grads
     L, perm = getattr(pre, "piv_chol", None), getattr(pre, "piv_perm", None)
-    if L is None or perm is None or not any(t.requires_grad for t in matrix_args):
+    if not any(t.requires_grad for t in matrix_args):
         return matrix_arg_grads
     wb = pre.woodbury
     g = logdet_grad  # [*batch, 1, 1]
@@ -52,8 +52,9 @@ def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, U, 
             gd = gd.sum(-1, keepdim=True)
         gd = gd if tuple(gd.shape) == tuple(diag_leaf.shape) else gd.sum_to_size(*diag_leaf.shape)
         matrix_arg_grads[diag_idx] = gd if matrix_arg_grads[diag_idx] is None else matrix_arg_grads[diag_idx] + gd
-    # ---- low-rank part, through the pivoted Cholesky
-    if any(t.requires_grad for t in matrix_args[op_slice]):
+    # ---- low-rank part, through the pivoted Cholesky (needs the factor and its pivots; the diagonal part above only
+    #      needs the Woodbury cache, so it is added even when they are not available)
+    if L is not None and perm is not None and any(t.requires_grad for t in matrix_args[op_slice]):
         Lc = L.contiguous()
         GL = 2.0 * g * pre(Lc) + K.bilinear_root(Lc, U, V)
         extra = pivoted_cholesky_vjp(linear_op._linear_op, perm, GL)

@@ -1,7 +1,7 @@
 """PivotedCholesky Function (reference: linear_operator/functions/_pivoted_cholesky.py:12-147), forward on the
 device through csrc/lo_pivchol.hip (rows generated from the operator descriptor instead of the generic
-__getitem__ / gather / scatter chain).  Operators without a descriptor (opaque trees) are evaluated to a
-dense tensor first."""
+__getitem__ / gather / scatter chain).  Operators without a descriptor (opaque trees) keep the reference's generic
+row access as a per-pivot callback (lo_pivoted_cholesky_cb_f32); nothing is densified."""
 from __future__ import annotations
 
 import torch
@@ -9,7 +9,6 @@ from torch.autograd import Function
 
 from .. import kernels as K
 from .. import settings
-from ._common import not_yet
 
 
 class PivotedCholesky(Function):
@@ -24,11 +23,14 @@ class PivotedCholesky(Function):
             )
         desc = matrix._kernel_descriptor()
         if desc is not None and desc.diag_mode != 0:
-            desc = None  # the kernel factors descriptor WITHOUT its diagonal; a genuine A + D goes dense
-        if desc is None:
-            dense = matrix.to_dense()
-            desc = K.dense_diag_descriptor(dense, None)
-        L, perm = K.pivoted_cholesky(desc, max_iter, float(error_tol))
+            desc = None  # the kernels factor a descriptor WITHOUT its diagonal; a genuine A + D takes the generic path
+        if desc is not None:
+            L, perm = K.pivoted_cholesky(desc, max_iter, float(error_tol))
+        else:
+            # no descriptor: the reference's generic accesses -- matrix._diagonal() (:39) and one row per pivot through
+            # LinearOperator.__getitem__ (:81) -- feed the same kernels; nothing is densified
+            diag = matrix._diagonal().to(torch.float32).contiguous()
+            L, perm = K.pivoted_cholesky_generic(diag, matrix._get_rows, max_iter, float(error_tol))
         ctx.mark_non_differentiable(perm)
         ctx.representation_tree = representation_tree
         ctx.save_for_backward(perm, *matrix_args)
@@ -39,8 +41,6 @@ class PivotedCholesky(Function):
         perm, *matrix_args = ctx.saved_tensors
         linear_op = ctx.representation_tree(*matrix_args)
         grads = pivoted_cholesky_vjp(linear_op, perm, grad_output)
-        if grads is None:
-            not_yet("PivotedCholesky (operators other than dense / dense-root)")
         return tuple([None, None, None] + list(grads))
 
 
@@ -111,7 +111,14 @@ def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False):
             rows = torch.gather(kd, -2, perm.unsqueeze(-1).expand(*perm.shape, kd.size(-1)))
             krows = torch.gather(rows, -1, perm[..., :m].unsqueeze(-2).expand(*perm.shape[:-1], perm.size(-1), m))
         else:
-            return None
+            # any other operator (sums, Kronecker products, non-dense roots ...): the m pivot columns K e_pi through the
+            # differentiable Matmul Function (its backward is the operator's _bilinear_derivative), rows put in pivot
+            # order afterwards -- the reference reaches the same entries through __getitem__ on the rebuilt operator
+            n = op.size(-1)
+            onehot = torch.zeros(*perm.shape[:-1], n, m, dtype=grad_L.dtype, device=grad_L.device)
+            onehot.scatter_(-2, perm[..., :m].unsqueeze(-2), 1.0)
+            kcols = op.matmul(onehot)  # K[:, pivots]  (K symmetric)
+            krows = torch.gather(kcols, -2, perm.unsqueeze(-1).expand(*perm.shape, m))
         l11 = psd_safe_cholesky(krows[..., :m, :])
         rest = torch.linalg.solve_triangular(l11, krows[..., m:, :].mT, upper=False).mT
         res_pivoted = torch.cat([l11, rest], dim=-2)

@@ -28,12 +28,15 @@ class OperatorDescriptor:
     R: int = 0
     n2: int = 0
     batch_shape: torch.Size = torch.Size()
+    terms: tuple = ()  # LO_OP_SUM: the summed structured terms (descriptors without a diagonal), left to right
 
     @property
     def device(self):
         for t in (self.A0, self.A1, self.d):
             if t is not None:
                 return t.device
+        for term in self.terms:
+            return term.device
         raise ValueError("empty descriptor")
 
     def c_struct(self) -> _hip.OpDesc:
@@ -42,11 +45,30 @@ class OperatorDescriptor:
         s.A0 = None if self.A0 is None else self.A0.data_ptr()
         s.A1 = None if self.A1 is None else self.A1.data_ptr()
         s.d = None if self.d is None else self.d.data_ptr()
+        s.nterms = len(self.terms)
+        if self.terms:  # host array of term descriptors; kept alive by the returned struct
+            arr = (_hip.OpDesc * len(self.terms))(*[t.c_struct() for t in self.terms])
+            s.terms = C.cast(arr, C.POINTER(_hip.OpDesc))
+            s._terms_keepalive = arr
         return s
 
     def without_diag(self) -> "OperatorDescriptor":
         return OperatorDescriptor(self.kind, self.B, self.N, self.A0, self.A1, None, _hip.LO_DIAG_NONE, self.R,
-                                  self.n2, self.batch_shape)
+                                  self.n2, self.batch_shape, self.terms)
+
+
+def sum_descriptor(terms, d: Optional[torch.Tensor] = None, const_diag: bool = False):
+    """SumLinearOperator(A_1, ..., A_n) (+ one diagonal): y = sum_i A_i v + d o v (sum_linear_operator.py:47-51).
+    `terms`: 2 .. LO_MAX_TERMS descriptors of kind low-rank / dense / Kronecker WITHOUT a diagonal, same batch and N."""
+    terms = tuple(terms)
+    if not 2 <= len(terms) <= _hip.LO_MAX_TERMS:
+        raise ValueError(f"a lowered sum holds 2 .. {_hip.LO_MAX_TERMS} terms, got {len(terms)}")
+    t0 = terms[0]
+    for t in terms:
+        if t.kind == _hip.LO_OP_SUM or t.diag_mode != _hip.LO_DIAG_NONE or (t.B, t.N) != (t0.B, t0.N):
+            raise ValueError("sum terms must be plain structured operators of one batch and size")
+    return _with_diag(OperatorDescriptor(_hip.LO_OP_SUM, t0.B, t0.N, batch_shape=t0.batch_shape, terms=terms), d,
+                      const_diag)
 
 
 def _flat(t: torch.Tensor, keep: int) -> torch.Tensor:
@@ -227,7 +249,7 @@ def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optio
              precond: Optional[WoodburyPreconditioner] = None, matvec_closure: Optional[Callable] = None,
              precond_closure: Optional[Callable] = None, closure_batch_shape=None, n_tridiag: int = 0,
              max_iter: int = 1000, max_tridiag_iter: int = 20, tolerance: float = 1.0, eps: float = 1e-10,
-             stop_updating_after: float = 1e-10) -> CGResult:
+             stop_updating_after: float = 1e-10, floor_max_iter: int = 0) -> CGResult:
     """lo_cg_solve_f32: the reference's linear_cg (utils/linear_cg.py:98-359) on the device.
 
     rhs [*batch, N, c].  Either `desc` (structured operator, fully native loop) or `matvec_closure`
@@ -270,6 +292,7 @@ def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optio
     pre_s = precond.c_struct() if precond is not None else None
     prm = _hip.CgParams()
     prm.c, prm.n_tridiag, prm.max_iter, prm.max_tridiag_iter = c, n_tridiag, max_iter, max_tridiag_iter
+    prm.floor_max_iter = floor_max_iter  # the reference's stop-rule floors use the unclipped max_iter (:303-305)
     prm.tolerance, prm.eps, prm.stop_updating_after = tolerance, eps, stop_updating_after
     ws_bytes = lib.lo_cg_workspace_bytes(C.byref(s), C.byref(pre_s) if pre_s is not None else None, C.byref(prm))
     ws = _hip.workspace(ws_bytes, dev)
@@ -327,6 +350,49 @@ def pivoted_cholesky(desc: OperatorDescriptor, rank: int, error_tol: float = 1e-
     if contiguous:
         L = L.contiguous()
     bs = tuple(desc.batch_shape)
+    return L.reshape(*bs, N, m.value), perm.reshape(*bs, N)
+
+
+def pivoted_cholesky_generic(diag: torch.Tensor, row_fetch: Callable, rank: int, error_tol: float = 1e-3,
+                             contiguous: bool = True):
+    """lo_pivoted_cholesky_cb_f32: PivotedCholesky.forward for an operator that does not lower to a descriptor.
+    diag [*batch, N] = matrix._diagonal(); row_fetch(piv [*batch] int64 device tensor) -> rows [*batch, N] is the
+    reference's generic row access `matrix[..., pi_m, :]` (_pivoted_cholesky.py:81), called once per pivot without a
+    host synchronisation; pivot search, Schur update and the stopping rule run in the same kernels as for lowered
+    operators.  Returns (L [*batch, N, m], permutation [*batch, N])."""
+    lib = _hip.load()
+    _hip.require_hip(diag)
+    dev = diag.device
+    bs = tuple(diag.shape[:-1])
+    N = diag.shape[-1]
+    d2 = _flat(diag, 1)
+    B = d2.shape[0]
+    max_rank = min(int(rank), N)
+    L_rows = torch.empty(B, max_rank, N, dtype=torch.float32, device=dev)
+    perm = torch.empty(B, N, dtype=torch.int64, device=dev)
+    err = []
+
+    def cb(user, piv_ptr, rows_ptr, B_, N_, stream):
+        try:
+            piv = _hip.as_tensor(piv_ptr, (B_,), dev, "<i8")
+            rows = _hip.as_tensor(rows_ptr, (B_, N_), dev)
+            rows.copy_(row_fetch(piv.reshape(bs)).reshape(B_, N_))
+            return 0
+        except BaseException as e:  # noqa: BLE001 -- must not unwind through C
+            err.append(e)
+            return 1
+
+    c_cb = _hip.ROWFETCH_CB(cb)
+    ws = _hip.workspace(lib.lo_pivoted_cholesky_cb_workspace_bytes(B, N, max_rank), dev)
+    m = C.c_int32(0)
+    rc = lib.lo_pivoted_cholesky_cb_f32(B, N, _hip.ptr(d2), c_cb, None, max_rank, float(error_tol), _hip.ptr(L_rows),
+                                        _hip.ptr(perm), C.byref(m), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev))
+    if err:
+        raise err[0]
+    _hip.check(rc, "lo_pivoted_cholesky_cb_f32")
+    L = L_rows[:, : m.value, :].mT
+    if contiguous:
+        L = L.contiguous()
     return L.reshape(*bs, N, m.value), perm.reshape(*bs, N)
 
 

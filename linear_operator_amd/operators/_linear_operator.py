@@ -242,6 +242,108 @@ class LinearOperator(object):
         eye = torch.eye(n, dtype=self.dtype, device=self.device).expand(*self.batch_shape, n, n).contiguous()
         return self._matmul(eye)
 
+    # ------------------------------------------------------------------ element / row access (reference :395-461, :2829-2925)
+    def _get_indices(self, row_index: Tensor, col_index: Tensor, *batch_indices: Tensor) -> Tensor:
+        """Elements K[batch_indices..., row_index, col_index] for broadcastable tensor indices, one per dimension.
+        Dense / Diag / Root / Kronecker / Sum override this with closed forms (as in the reference); the default for
+        an opaque operator fetches the distinct rows with `_t_matmul` on one-hot columns and gathers from them."""
+        final_shape = torch.broadcast_shapes(*(i.shape for i in batch_indices), row_index.shape, col_index.shape)
+        row_index = row_index.expand(final_shape).reshape(-1)
+        col_index = col_index.expand(final_shape).reshape(-1)
+        bidx = [i.expand(final_shape).reshape(-1) for i in batch_indices]
+        bshape = self.batch_shape
+        flat_b = torch.zeros_like(row_index)
+        for i, size in zip(bidx, bshape):
+            flat_b = flat_b * size + i
+        n = self.size(-2)
+        key = flat_b * n + row_index  # one entry per requested (member, row)
+        uniq, inverse = torch.unique(key, return_inverse=True)
+        ub, ur = uniq // n, uniq % n
+        nb = max(1, bshape.numel())
+        # rows per member, padded to the largest count: column j of member b selects its j-th requested row
+        counts = torch.bincount(ub, minlength=nb)
+        m = int(counts.max().item())
+        start = torch.cumsum(counts, 0) - counts
+        slot = torch.arange(uniq.numel(), device=uniq.device) - start[ub]
+        onehot = torch.zeros(nb, n, m, dtype=self.dtype, device=self.device)
+        onehot[ub, ur, slot] = 1.0
+        rows = self._t_matmul(onehot.reshape(*bshape, n, m)).reshape(nb, self.size(-1), m)  # K^T e = rows of K
+        res = rows[ub[inverse], col_index, slot[inverse]]
+        return res.reshape(final_shape)
+
+    def _get_rows(self, row_index: Tensor) -> Tensor:
+        """K[..., row_index, :] for one row per batch member (row_index [*batch] int64) -> [*batch, N]: the access
+        PivotedCholesky.forward makes per pivot (`apply_permutation(matrix, pi_m.unsqueeze(-1))`,
+        _pivoted_cholesky.py:81 -> utils/permutation.py:64-88 -> __getitem__ with tensor indices on every dimension)."""
+        if type(self)._get_indices is LinearOperator._get_indices:
+            # opaque operator: row pi of K is (K^T e_pi)^T -- one product per pivot, no host synchronisation
+            onehot = torch.zeros(*self.batch_shape, self.size(-2), 1, dtype=self.dtype, device=self.device)
+            onehot.scatter_(-2, row_index.reshape(*self.batch_shape, 1, 1), 1.0)
+            return self._t_matmul(onehot).squeeze(-1)
+        left = row_index.unsqueeze(-1)
+        batch_idx = []
+        for i, size in enumerate(self.batch_shape):
+            shape = [1] * (len(self.batch_shape) + 2)
+            shape[i] = size
+            batch_idx.append(torch.arange(size, device=self.device).view(*shape))
+        right = torch.arange(self.size(-1), device=self.device)
+        res = self.__getitem__((*batch_idx, left.unsqueeze(-1), right.unsqueeze(-2)))
+        return to_dense(res).squeeze(-2)
+
+    def _getitem(self, row_index, col_index, *batch_indices):
+        """Sub-operator for int / slice (and lone tensor) indices.  Generic version: index the dense evaluation (the
+        reference builds lazily indexed operators per class, :436-461; this path is not on the iterative hot path)."""
+        from .dense_linear_operator import DenseLinearOperator
+
+        return DenseLinearOperator(self.to_dense()[(*batch_indices, row_index, col_index)])
+
+    def __getitem__(self, index):  # reference :2829-2925
+        ndimension = self.dim()
+        index = index if isinstance(index, tuple) else (index,)
+        index = tuple(torch.tensor(idx) if isinstance(idx, list) else idx for idx in index)
+        index = tuple(idx.item() if torch.is_tensor(idx) and not len(idx.shape) else idx for idx in index)
+        ellipsis_locs = tuple(i for i, item in enumerate(index) if item is Ellipsis)
+        if len(ellipsis_locs) > 1:
+            raise RuntimeError(f"Cannot have multiple ellipsis in a __getitem__ call. Received index {index}.")
+        noop = slice(None, None, None)
+        if len(ellipsis_locs) == 1:
+            loc = ellipsis_locs[0]
+            fill = ndimension - (len(index) - 1)
+            index = index[:loc] + tuple(noop for _ in range(fill)) + index[loc + 1:]
+        index = index + tuple(noop for _ in range(ndimension - len(index)))
+        *batch_indices, row_index, col_index = index
+        batch_has_tensor = bool(batch_indices) and any(torch.is_tensor(i) for i in batch_indices)
+        row_tensor, col_tensor = torch.is_tensor(row_index), torch.is_tensor(col_index)
+        absorbed = (batch_has_tensor and (row_tensor or col_tensor)) or (not batch_has_tensor and row_tensor and col_tensor)
+        squeeze_row = squeeze_col = False
+        if isinstance(row_index, int):
+            row_index, squeeze_row = slice(row_index, row_index + 1, None), True
+        if isinstance(col_index, int):
+            col_index, squeeze_col = slice(col_index, col_index + 1, None), True
+        if absorbed:
+            orig = [*batch_indices, row_index, col_index]
+            tshape = torch.broadcast_shapes(*[i.shape for i in orig if torch.is_tensor(i)])
+            flat = []
+            for dim, i in enumerate(orig):
+                if torch.is_tensor(i):
+                    flat.append(i.expand(tshape).reshape(-1))
+                elif isinstance(i, int):
+                    flat.append(torch.full((tshape.numel(),), i, dtype=torch.long, device=self.device))
+                else:
+                    raise NotImplementedError("mixing slices with tensor indices that absorb the matrix dimensions")
+            *nb, nr, nc = flat
+            res = self._get_indices(nr, nc, *nb)
+            res = res.view(*tshape)
+        else:
+            res = self._getitem(row_index, col_index, *batch_indices)
+        if squeeze_row or squeeze_col or absorbed:
+            res = to_dense(res)
+        if squeeze_row:
+            res = res.squeeze(-2)
+        if squeeze_col:
+            res = res.squeeze(-1)
+        return res
+
     def diagonal(self, offset: int = 0, dim1: int = -2, dim2: int = -1) -> Tensor:
         if not (offset == 0 and dim1 in (-2, self.dim() - 2) and dim2 in (-1, self.dim() - 1)):
             raise NotImplementedError("LinearOperator.diagonal only computes the main diagonal of the last two dims")

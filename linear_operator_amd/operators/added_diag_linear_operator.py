@@ -91,7 +91,8 @@ class AddedDiagLinearOperator(SumLinearOperator):
         self._woodbury = None
 
     def _kernel_descriptor(self, batch_shape=None):
-        return _attach_diag(self._linear_op, self._diag_tensor, torch.Size(batch_shape or self.batch_shape))
+        return _attach_diag(self._linear_op, self._diag_tensor,
+                            torch.Size(self.batch_shape if batch_shape is None else batch_shape))
 
     def _matmul(self, rhs: Tensor) -> Tensor:
         if rhs.dim() >= 2 and rhs.is_cuda and rhs.dtype == torch.float32:
@@ -165,7 +166,11 @@ class AddedDiagLinearOperator(SumLinearOperator):
         preconditioner build reads it in place and the transposed copy of _pivoted_cholesky.py:105 is skipped."""
         desc = self._linear_op._kernel_descriptor()
         if desc is None or desc.diag_mode != 0 or self.device.type != "cuda" or self.dtype != torch.float32:
-            return self._linear_op.pivoted_cholesky(rank=max_iter)
+            L, perm = self._linear_op.pivoted_cholesky(rank=max_iter, return_pivots=True)
+            self._piv_chol_perm = perm  # (the backward pass of the preconditioner terms needs the pivots here too)
+            # detached: the rest of the cache is built by kernels outside autograd and the factor's derivative is
+            # chained by hand (functions/_inv_quad_logdet._add_preconditioner_terms), exactly as on the lowered path
+            return L.detach()
         tol = settings.preconditioner_tolerance.value()
         L, perm = K.pivoted_cholesky(desc, min(max_iter, self.size(-1)), float(tol), contiguous=False)
         self._piv_chol_perm = perm  # needed by the backward pass of the preconditioner terms

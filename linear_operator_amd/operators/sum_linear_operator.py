@@ -21,14 +21,42 @@ class SumLinearOperator(LinearOperator):
         self.linear_ops = linear_ops
 
     def _kernel_descriptor(self, batch_shape=None):
-        """`X + D` sums lower like AddedDiag (one structured term + one diagonal)."""
-        from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
+        """Lowering of the sum (reference `_matmul` :47-51, `_diagonal` :31-32): one structured term + at most one
+        diagonal lowers like AddedDiag; 2 .. LO_MAX_TERMS structured terms (nested sums flattened, left to right)
+        + at most one diagonal lower to an LO_OP_SUM descriptor -- matvec, CG, Lanczos, MINRES and the pivoted
+        Cholesky then run on the device without per-term Python calls."""
+        from .. import kernels as K
+        from .diag_linear_operator import DiagLinearOperator
 
-        diags = [op for op in self.linear_ops if isinstance(op, DiagLinearOperator)]
-        others = [op for op in self.linear_ops if not isinstance(op, DiagLinearOperator)]
-        if len(others) != 1 or len(diags) > 1:
+        batch_shape = torch.Size(self.batch_shape if batch_shape is None else batch_shape)
+        flat = []
+
+        def walk(op):
+            if isinstance(op, SumLinearOperator):  # (AddedDiag is a sum of its operator and its diagonal)
+                for sub in op.linear_ops:
+                    walk(sub)
+            else:
+                flat.append(op)
+
+        for op in self.linear_ops:
+            walk(op)
+        diags = [op for op in flat if isinstance(op, DiagLinearOperator)]
+        others = [op for op in flat if not isinstance(op, DiagLinearOperator)]
+        if len(diags) > 1 or not others:
             return None
-        return _attach_diag(others[0], diags[0] if diags else None, batch_shape or self.batch_shape)
+        if len(others) == 1:
+            return _attach_diag(others[0], diags[0] if diags else None, batch_shape)
+        if len(others) > K._hip.LO_MAX_TERMS:
+            return None
+        terms = []
+        for op in others:
+            desc = op._kernel_descriptor(batch_shape)
+            if desc is None or desc.diag_mode != 0 or desc.kind == K._hip.LO_OP_SUM:
+                return None
+            terms.append(desc)
+        if len({(t.B, t.N) for t in terms}) != 1:
+            return None
+        return _sum_with_diag(K.sum_descriptor(terms), diags[0] if diags else None, batch_shape)
 
     def _diagonal(self) -> Tensor:
         return sum(op._diagonal() for op in self.linear_ops)
@@ -89,11 +117,16 @@ class PsdSumLinearOperator(SumLinearOperator):
 
 def _attach_diag(base_op, diag_op, batch_shape):
     """Descriptor of `base_op (+ diag_op)` expanded to batch_shape, or None."""
-    from .diag_linear_operator import ConstantDiagLinearOperator
-
     desc = base_op._kernel_descriptor(batch_shape)
     if desc is None or desc.diag_mode != 0:
         return None
+    return _sum_with_diag(desc, diag_op, batch_shape)
+
+
+def _sum_with_diag(desc, diag_op, batch_shape):
+    """Attach a (Constant)DiagLinearOperator to a diagonal-free descriptor, or None if its tensor cannot be used."""
+    from .diag_linear_operator import ConstantDiagLinearOperator
+
     if diag_op is None:
         return desc
     from .. import kernels as K

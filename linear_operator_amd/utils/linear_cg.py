@@ -79,7 +79,22 @@ def linear_cg(
     num_rows = rhs.size(-2)
     n_iter = min(max_iter, num_rows) if settings.terminate_cg_by_size.on() else max_iter  # :170
     n_tridiag_iter = min(max_tridiag_iter, num_rows)  # :171
+    # The reference broadcasts a batched operator against an unbatched right-hand side inside the closure's matmul
+    # (residual = rhs - matmul_closure(x0), :186); the kernels want the broadcast made explicit.
     batch_shape = rhs.shape[:-2]
+    if torch.is_tensor(matmul_closure):
+        op_batch = matmul_closure.shape[:-2]
+    else:
+        op_batch = getattr(getattr(matmul_closure, "__self__", None), "batch_shape", torch.Size())
+    try:
+        full_batch = torch.broadcast_shapes(batch_shape, op_batch)
+    except RuntimeError:
+        full_batch = batch_shape
+    if full_batch != batch_shape:
+        rhs = rhs.expand(*full_batch, *rhs.shape[-2:])
+        if initial_guess is not None:
+            initial_guess = initial_guess.expand(*full_batch, *initial_guess.shape[-2:])
+        batch_shape = full_batch
 
     if settings.verbose_linalg.on():
         settings.verbose_linalg.logger.debug(
@@ -101,7 +116,7 @@ def linear_cg(
     res = K.cg_solve(
         desc, rhs, x0=initial_guess, precond=woodbury, matvec_closure=closure, precond_closure=precond_closure,
         n_tridiag=n_tridiag, max_iter=n_iter, max_tridiag_iter=n_tridiag_iter, tolerance=float(tolerance),
-        eps=float(eps), stop_updating_after=float(stop_updating_after),
+        eps=float(eps), stop_updating_after=float(stop_updating_after), floor_max_iter=max_iter,
     )
     if res.nan_detected:  # :199-200
         raise RuntimeError("NaNs encountered when trying to perform matrix-vector multiplication")

@@ -38,12 +38,14 @@ def matvec_lowrank_diag(C, d, v):
     C [*B,N,R], d [*B,N], v [*B,N,c].
     """
     t = np.matmul(np.swapaxes(C, -1, -2), v)
-    return np.matmul(C, t) + d[..., None] * v
+    y = np.matmul(C, t)
+    return y if d is None else y + d[..., None] * v  # (d None: the plain RootLinearOperator)
 
 
 def matvec_dense_diag(K, d, v):
     """y = K v + d o v.  reference: added_diag_linear_operator.py:72-76 + dense_linear_operator.py:60-64."""
-    return np.matmul(K, v) + d[..., None] * v
+    y = np.matmul(K, v)
+    return y if d is None else y + d[..., None] * v  # (d None: the plain DenseLinearOperator)
 
 
 def matvec_kron(K1, K2, v):
@@ -301,6 +303,40 @@ class KronRowSource:
         r1 = np.take_along_axis(self.K1, i1[..., None, None], axis=-2)[..., 0, :]
         r2 = np.take_along_axis(self.K2, i2[..., None, None], axis=-2)[..., 0, :]
         return (r1[..., :, None] * r2[..., None, :]).reshape(*self.batch_shape, self.n)
+
+
+class SumRowSource:
+    """diag / row access for SumLinearOperator(*terms): `_diagonal` = sum of the terms' diagonals and rows through
+    `_get_indices` = sum of the terms' entries, both Python `sum()` left to right (sum_linear_operator.py:31-32,39-41)."""
+
+    def __init__(self, *sources):
+        self.sources = sources
+        self.n = sources[0].n
+        self.batch_shape = sources[0].batch_shape
+        self.dtype = sources[0].dtype
+
+    def diag(self):
+        acc = self.sources[0].diag()
+        for s in self.sources[1:]:
+            acc = acc + s.diag()
+        return acc
+
+    def row(self, idx):
+        acc = self.sources[0].row(idx)
+        for s in self.sources[1:]:
+            acc = acc + s.row(idx)
+        return acc
+
+
+def matvec_sum(matvecs, d, v):
+    """SumLinearOperator._matmul (sum_linear_operator.py:47-51) of the closures `matvecs` (left to right) plus the
+    diagonal term of an enclosing AddedDiagLinearOperator (added_diag_linear_operator.py:72-76); d may be None."""
+    acc = matvecs[0](v)
+    for mv in matvecs[1:]:
+        acc = acc + mv(v)
+    if d is not None:
+        acc = acc + d[..., None] * v
+    return acc
 
 
 def pivoted_cholesky(src, rank, error_tol=1e-3):

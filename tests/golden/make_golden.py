@@ -33,6 +33,8 @@ from linear_operator.operators import (  # noqa: E402
     DiagLinearOperator,
     KroneckerProductLinearOperator,
     LowRankRootLinearOperator,
+    PsdSumLinearOperator,
+    SumLinearOperator,
 )
 from linear_operator.utils import linear_cg as _ref_linear_cg  # noqa: E402
 from linear_operator.utils.lanczos import lanczos_tridiag, lanczos_tridiag_to_diag  # noqa: E402
@@ -668,14 +670,65 @@ def g15_lanczos_consumers_backward():
          v2=v2, **out)
 
 
+def g16_sum_operators():
+    """Real sums (north_star: "their Sum/Added/Kronecker compositions"): Sum(LowRankRoot, Dense) + Diag and
+    PsdSum(LowRankRoot, LowRankRoot) + Diag -- matmul (sum_linear_operator.py:47-51), pivoted Cholesky of the sum (rows
+    through SumLinearOperator._get_indices :39-41), solve, inv_quad_logdet with injected probes, and the gradients."""
+    print("G16 multi-term sums")
+    C, d, rhs = cases.lowrank_diag(1601, 3, 2048, 16, 1)
+    Kd, _, V = cases.dense_diag(1602, 3, 2048, 3)
+    Kd = (Kd * np.float32(0.25)).astype(np.float32)
+    Z, Zn = cases.probes(1603, 3, 2048, 6)
+    S = SumLinearOperator(LowRankRootLinearOperator(T(C)), DenseLinearOperator(T(Kd)))
+    A = _ProbedAddedDiag(S, DiagLinearOperator(T(d)))
+    A._probes = (T(Z), T(Zn))
+    out = {"mv": A._matmul(T(V)), "mv_sum_only": S._matmul(T(V))}
+    L, piv = S.pivoted_cholesky(rank=15, return_pivots=True)
+    out["pc_L"], out["pc_piv"] = L, piv
+    with settings.cg_tolerance(1e-4):
+        x, spy, w = _with_spy(lambda: A.solve(T(rhs)))
+    out["x"], out["x_matvecs"], out["x_warned"] = x, spy.records[0]["matvecs"], w
+    with settings.cg_tolerance(1e-4):
+        (iq, ld), spy, w = _with_spy(lambda: A.inv_quad_logdet(T(rhs), logdet=True))
+    solves, t_mat = spy.records[0]["out"]
+    _, _, logdet_p = A._preconditioner()
+    out.update(iq=iq, ld=ld, solves=solves, t_mat=t_mat, logdet_p=logdet_p, iql_matvecs=spy.records[0]["matvecs"])
+    dense = T(C).double() @ T(C).double().mT + T(Kd).double() + torch.diag_embed(T(d).double())
+    out["x_exact"] = np.linalg.solve(dense.numpy(), rhs.astype(np.float64)).astype(np.float32)
+    out["logdet_exact"] = np.linalg.slogdet(dense.numpy())[1].astype(np.float32)
+    # gradients of iq.sum() + ld.sum() through the preconditioned path (pivoted Cholesky of the SUM in the graph)
+    wproj = cases.randn(1604, 2048, 2, dtype=np.float32)
+    with settings.cg_tolerance(1e-5), settings.max_cg_iterations(200):
+        Ct, Kt, dt, rt = [T(a).clone().requires_grad_(True) for a in (C, Kd, d, rhs)]
+        Ag = _ProbedAddedDiag(SumLinearOperator(LowRankRootLinearOperator(Ct), DenseLinearOperator(Kt)),
+                              DiagLinearOperator(dt))
+        Ag._probes = (T(Z), T(Zn))
+        iq, ld = Ag.inv_quad_logdet(rt, logdet=True)
+        (iq.sum() + ld.sum()).backward()
+        out.update(g_iq=iq, g_ld=ld, g_dC=Ct.grad, g_dd=dt.grad, g_drhs=rt.grad, g_dK_proj=Kt.grad @ T(wproj),
+                   g_dK_diag=torch.diagonal(Kt.grad, dim1=-2, dim2=-1))
+    # PsdSum of two low-rank roots + diagonal: solve
+    C2, _, _ = cases.lowrank_diag(1605, 3, 2048, 8, 1)
+    P = PsdSumLinearOperator(LowRankRootLinearOperator(T(C)), LowRankRootLinearOperator(T(C2)))
+    A2 = AddedDiagLinearOperator(P, DiagLinearOperator(T(d)))
+    with settings.cg_tolerance(1e-4):
+        x2, spy, w = _with_spy(lambda: A2.solve(T(rhs)))
+    L2, piv2 = P.pivoted_cholesky(rank=15, return_pivots=True)
+    out.update(psd_x=x2, psd_matvecs=spy.records[0]["matvecs"], psd_pc_L=L2, psd_pc_piv=piv2,
+               psd_mv=A2._matmul(T(V)))
+    save("g16_sum_operators", checksum=cases.checksum(C, d, rhs, Kd, V, Z, wproj, C2), **out)
+
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
                      ("g9", g9_backward), ("g10", g10_backward_preconditioned), ("g11", g11_diagonalization),
                      ("g12", g12_kronecker_added_diag), ("g13", g13_minres),
-                     ("g14", g14_sqrt_inv_matmul), ("g15", g15_lanczos_consumers_backward)):
+                     ("g14", g14_sqrt_inv_matmul), ("g15", g15_lanczos_consumers_backward),
+                     ("g16", g16_sum_operators)):
         if name in todo:
             fn()
     print("done")

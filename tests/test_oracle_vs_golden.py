@@ -559,3 +559,51 @@ def test_g9_backward_passes():
     d1, d2 = orc.bilinear_derivative_kron(K1, K2, U, V)
     assert close(d1, g["kron_dK1"], 5e-3) and close(d2, g["kron_dK2"], 5e-3)
     assert np.allclose(orc.bilinear_derivative_diag(U, V, constant=True), g["kron_dsig"], rtol=5e-3)
+
+
+# ---------------------------------------------------------------- G16 multi-term sums
+def _g16_inputs():
+    C, d, rhs = cases.lowrank_diag(1601, 3, 2048, 16, 1)
+    Kd, _, V = cases.dense_diag(1602, 3, 2048, 3)
+    Kd = (Kd * np.float32(0.25)).astype(np.float32)
+    Z, Zn = cases.probes(1603, 3, 2048, 6)
+    wproj = cases.randn(1604, 2048, 2, dtype=np.float32)
+    C2, _, _ = cases.lowrank_diag(1605, 3, 2048, 8, 1)
+    return C, d, rhs, Kd, V, Z, Zn, wproj, C2
+
+
+def test_g16_sum_operators():
+    """Sum(LowRankRoot, Dense) + Diag and PsdSum(LowRankRoot, LowRankRoot) + Diag: matmul, pivoted Cholesky of the sum
+    (pivots exact), solve and inv_quad_logdet with the reference's probes."""
+    g = load_golden("g16_sum_operators")
+    C, d, rhs, Kd, V, Z, Zn, wproj, C2 = _g16_inputs()
+    _check_inputs(g, C, d, rhs, Kd, V, Z, wproj, C2)
+    terms = [lambda v: orc.matvec_lowrank_diag(C, None, v), lambda v: orc.matvec_dense_diag(Kd, None, v)]
+    mm = lambda v: orc.matvec_sum(terms, d, v)  # noqa: E731
+    assert max_rel_err_cols(mm(V), g["mv"]) < 1e-5
+    assert max_rel_err_cols(orc.matvec_sum(terms, None, V), g["mv_sum_only"]) < 1e-5
+    src = orc.SumRowSource(orc.LowRankRowSource(C), orc.DenseRowSource(Kd))
+    L, perm = orc.pivoted_cholesky(src, 15)
+    m = g["pc_L"].shape[-1]
+    assert L.shape[-1] == m and np.array_equal(perm[..., :m], g["pc_piv"][..., :m])
+    assert np.allclose(L, g["pc_L"], rtol=1e-5, atol=1e-6)
+    x, info, _ = orc.solve(mm, src, d, rhs, tolerance=1e-4)
+    assert info.matvecs == int(g["x_matvecs"])
+    assert max_rel_err_cols(x, g["x"]) < 1e-4 and max_rel_err_cols(x, g["x_exact"]) < 1e-4
+    iq, ld, solves, t_mat, info, pre = orc.inv_quad_logdet(mm, src, d, rhs, Z, tolerance=1e-4)
+    assert info.matvecs == int(g["iql_matvecs"])
+    assert max_rel_err_cols(solves, g["solves"]) < 1e-4
+    assert np.allclose(iq[..., 0], g["iq"], rtol=1e-4)
+    assert np.allclose(pre.logdet, g["logdet_p"], rtol=1e-5)
+    assert np.allclose(ld, g["ld"], rtol=1e-4, atol=2048 * 1.2e-7 * 150)
+    # PsdSum of two roots
+    terms2 = [lambda v: orc.matvec_lowrank_diag(C, None, v), lambda v: orc.matvec_lowrank_diag(C2, None, v)]
+    mm2 = lambda v: orc.matvec_sum(terms2, d, v)  # noqa: E731
+    assert max_rel_err_cols(mm2(V), g["psd_mv"]) < 1e-5
+    src2 = orc.SumRowSource(orc.LowRankRowSource(C), orc.LowRankRowSource(C2))
+    L2, perm2 = orc.pivoted_cholesky(src2, 15)
+    m2 = g["psd_pc_L"].shape[-1]
+    assert L2.shape[-1] == m2 and np.array_equal(perm2[..., :m2], g["psd_pc_piv"][..., :m2])
+    assert np.allclose(L2, g["psd_pc_L"], rtol=1e-5, atol=1e-6)
+    x2, info2, _ = orc.solve(mm2, src2, d, rhs, tolerance=1e-4)
+    assert info2.matvecs == int(g["psd_matvecs"]) and max_rel_err_cols(x2, g["psd_x"]) < 1e-4
