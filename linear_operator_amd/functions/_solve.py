@@ -1,5 +1,10 @@
-"""Solve Function + the Cholesky / CG dispatch, forward and backward (reference: linear_operator/functions/_solve.py:10-131).
-Backward = one more solve for A^-1 grad and the `_bilinear_derivative` contraction (csrc/lo_bilinear.hip)."""
+"""Solve Function: `L A^-1 R` (or `A^-1 R`) with its derivative (reference behaviour: linear_operator/functions/_solve.py:10-131).
+
+Forward: one solve for the stacked block `[L^T | R]`, through the exact Cholesky branch for small operators (ATen
+plumbing, BASELINE cfg1) or the device CG with the operator's preconditioner.  Backward: with `S_R = A^-1 R` saved from
+the forward and `S_L = A^-1 L^T g` (already available when a left factor was given, one more device solve otherwise)
+    d/dR = S_L,   d/dL = g S_R^T,   d/dA = -sym(S_L S_R^T)  -> `_bilinear_derivative` (csrc/lo_bilinear.hip).
+"""
 from __future__ import annotations
 
 import torch
@@ -9,81 +14,74 @@ from .. import settings
 
 
 def _solve(linear_op, rhs):
-    """N <= max_cholesky_size or fast solves off -> exact Cholesky (ATen plumbing, cfg1);
-    else preconditioned CG on the device (reference :17-22)."""
-    if settings.fast_computations.solves.off() or linear_op.size(-1) <= settings.max_cholesky_size.value():
+    """Cholesky for N <= max_cholesky_size (or fast solves switched off), else `linear_op._solve` with the
+    preconditioner built from the detached operator (reference :17-22)."""
+    small = linear_op.size(-1) <= settings.max_cholesky_size.value()
+    if small or settings.fast_computations.solves.off():
         return linear_op.cholesky()._cholesky_solve(rhs)
     with torch.no_grad():
         preconditioner = linear_op.detach()._solve_preconditioner()
     return linear_op._solve(rhs, preconditioner)
 
 
+def _symmetric_operator_grads(linear_op, s_left, s_right):
+    """Gradients w.r.t. the operator's tensors of -<S_L, dA S_R>, symmetrised: both orders stacked along the columns
+    with weight -1/2 each (the operator is symmetric, its representation may not be)."""
+    left = torch.cat((s_left, s_right), dim=-1)
+    right = torch.cat((s_right, s_left), dim=-1) * -0.5
+    return linear_op._bilinear_derivative(left, right)
+
+
 class Solve(Function):
     @staticmethod
     def forward(ctx, representation_tree, has_left, *args):
-        if has_left:
-            left_tensor, right_tensor, *matrix_args = args
-        else:
-            left_tensor = None
-            right_tensor, *matrix_args = args
-        orig_right_tensor = right_tensor
+        n_lead = 2 if has_left else 1
+        lead, matrix_args = args[:n_lead], args[n_lead:]
+        left = lead[0] if has_left else None
+        right = lead[-1]
+        ctx.representation_tree, ctx.has_left = representation_tree, has_left
+        ctx.is_vector = right.dim() == 1
+        cols = right.unsqueeze(-1) if ctx.is_vector else right
         linear_op = representation_tree(*matrix_args)
-        ctx.representation_tree = representation_tree
-        ctx.has_left = has_left
-        ctx.is_vector = right_tensor.ndimension() == 1
-        if ctx.is_vector:
-            right_tensor = right_tensor.unsqueeze(-1)
-        if has_left:  # one solve for [L^T | R], then L @ A^-1 R (reference :49-53)
-            rhs = torch.cat([left_tensor.mT, right_tensor], -1)
-            solves = _solve(linear_op, rhs)
-            res = left_tensor @ solves[..., left_tensor.size(-2):]
-            ctx.save_for_backward(solves, left_tensor, orig_right_tensor, *matrix_args)  # :60-66
+        if has_left:
+            n_left = left.size(-2)
+            solves = _solve(linear_op, torch.cat((left.mT, cols), dim=-1))  # [A^-1 L^T | A^-1 R] in one call
+            out = left @ solves[..., n_left:]
+            ctx.save_for_backward(solves, left, right, *matrix_args)
         else:
-            solves = _solve(linear_op, right_tensor)
-            res = solves
-            ctx.save_for_backward(solves, orig_right_tensor, *matrix_args)
-        return res.squeeze(-1) if ctx.is_vector else res
+            solves = out = _solve(linear_op, cols)
+            ctx.save_for_backward(solves, right, *matrix_args)
+        return out.squeeze(-1) if ctx.is_vector else out
 
     @staticmethod
-    def backward(ctx, grad_output):  # reference :70-131
-        if ctx.has_left:
-            solves, left_tensor, right_tensor, *matrix_args = ctx.saved_tensors
-            left_solves = solves[..., : left_tensor.size(-2)]
-            right_solves = solves[..., left_tensor.size(-2):]
-        else:
-            right_solves, right_tensor, *matrix_args = ctx.saved_tensors
-        linear_op = ctx.representation_tree(*matrix_args)
-        arg_grads = [None] * len(matrix_args)
-        left_grad = None
-        right_grad = None
+    def backward(ctx, grad_output):
+        saved = ctx.saved_tensors
+        n_head = 3 if ctx.has_left else 2
+        matrix_args = saved[n_head:]
+        n_fixed = 2  # representation_tree, has_left
+        none_head = (None,) * n_fixed
         if not any(ctx.needs_input_grad):
-            return tuple([None, None] + ([None] if ctx.has_left else []) + [None] + arg_grads)
-        if ctx.is_vector:
-            right_tensor = right_tensor.unsqueeze(-1)
-            grad_output = grad_output.unsqueeze(-1)
+            return none_head + (None,) * (len(saved) - 1)
+        g = grad_output.unsqueeze(-1) if ctx.is_vector else grad_output
+        if ctx.has_left:
+            solves, left, _ = saved[:3]
+            n_left = left.size(-2)
+            s_right = solves[..., n_left:]
+            s_left = solves[..., :n_left] @ g  # A^-1 L^T g without another solve
+            need_left, need_right = ctx.needs_input_grad[n_fixed], ctx.needs_input_grad[n_fixed + 1]
+            need_args = any(ctx.needs_input_grad[n_fixed + 2:])
+        else:
+            s_right = saved[0]
+            s_left = Solve.apply(ctx.representation_tree, False, g.contiguous(), *matrix_args)  # A^-1 g on the device
+            need_left, need_right = False, ctx.needs_input_grad[n_fixed]
+            need_args = any(ctx.needs_input_grad[n_fixed + 1:])
+        arg_grads = (None,) * len(matrix_args)
+        if need_args:
+            arg_grads = tuple(_symmetric_operator_grads(ctx.representation_tree(*matrix_args), s_left, s_right))
+        right_grad = None
+        if need_right:
+            right_grad = s_left.squeeze(-1) if ctx.is_vector else s_left
         if not ctx.has_left:
-            left_solves = Solve.apply(ctx.representation_tree, False, grad_output.contiguous(), *matrix_args)  # A^-1 g
-            if any(ctx.needs_input_grad[3:]):
-                # symmetric in (left, right): concatenate both orders and halve (:101-107)
-                arg_grads = linear_op._bilinear_derivative(
-                    torch.cat([left_solves, right_solves], -1),
-                    torch.cat([right_solves, left_solves], -1).mul(-0.5),
-                )
-            if ctx.needs_input_grad[2]:
-                right_grad = left_solves
-                if ctx.is_vector:
-                    right_grad = right_grad.squeeze(-1)
-            return tuple([None, None] + [right_grad] + list(arg_grads))
-        left_solves = left_solves @ grad_output
-        if ctx.needs_input_grad[2]:
-            left_grad = grad_output @ right_solves.mT
-        if any(ctx.needs_input_grad[4:]):
-            arg_grads = linear_op._bilinear_derivative(
-                torch.cat([left_solves, right_solves], -1),
-                torch.cat([right_solves, left_solves], -1).mul(-0.5),
-            )
-        if ctx.needs_input_grad[3]:
-            right_grad = left_solves
-            if ctx.is_vector:
-                right_grad = right_grad.squeeze(-1)
-        return tuple([None, None] + [left_grad, right_grad] + list(arg_grads))
+            return none_head + (right_grad,) + arg_grads
+        left_grad = g @ s_right.mT if need_left else None
+        return none_head + (left_grad, right_grad) + arg_grads

@@ -80,29 +80,12 @@ class LowRankRootAddedDiagLinearOperator(AddedDiagLinearOperator):
         return K.precond_apply(pre, rhs.expand(*batch, *rhs.shape[-2:]).contiguous())
 
     def _logdet(self) -> Tensor:  # reference :97-103
-        return self._woodbury_factor().logdet
-
-    def solve(self, right_tensor: Tensor, left_tensor=None) -> Tensor:
-        """reference LinearOperator.solve (:2324-2379) -> Solve -> `_solve`.  The forward-only Solve Function would
-        rebuild the operator from its leaf tensors and lose the factorisation cached here, so the closed form is
-        called directly (same shape checks, same result)."""
-        if not self.is_square:
-            raise RuntimeError(
-                "solve only operates on (batches of) square (positive semi-definite) LinearOperators. "
-                "Got a {} of size {}.".format(self.__class__.__name__, self.size())
-            )
-        if self.dim() == 2 and right_tensor.dim() == 1:
-            if self.shape[-1] != right_tensor.numel():
-                raise RuntimeError(
-                    "LinearOperator (size={}) cannot be multiplied with right-hand-side Tensor (size={}).".format(
-                        self.shape, right_tensor.shape
-                    )
-                )
-        is_vec = right_tensor.dim() == 1
-        x = self._solve(right_tensor.unsqueeze(-1) if is_vec else right_tensor)
-        if left_tensor is not None:
-            return left_tensor @ x
-        return x.squeeze(-1) if is_vec else x
+        """Differentiable: the value comes from the fp64 capacitance Cholesky on the device, the gradient from
+        d logdet(C C^T + D) = diag(A^-1) for the diagonal and 2 A^-1 C for the root (_WoodburyLogdet)."""
+        C, d = self._root_and_diag()
+        if not (C.requires_grad or d.requires_grad):
+            return self._woodbury_factor().logdet.reshape(self.batch_shape)
+        return _WoodburyLogdet.apply(self, C, d).reshape(self.batch_shape)
 
     def __add__(self, other):  # reference :105-115
         if isinstance(other, DiagLinearOperator):
@@ -136,14 +119,39 @@ class LowRankRootAddedDiagLinearOperator(AddedDiagLinearOperator):
                 )
         inv_quad_term, logdet_term = None, None
         if inv_quad_rhs is not None:
-            rhs = inv_quad_rhs.unsqueeze(-1) if inv_quad_rhs.dim() == 1 else inv_quad_rhs
-            self_inv_rhs = self._solve(rhs)
-            inv_quad_term = (self_inv_rhs * rhs).sum(dim=-2)
-            if reduce_inv_quad:
-                inv_quad_term = inv_quad_term.sum(dim=-1)
+            # through the InvQuad Function (its backward solves with the same closed form and contracts with
+            # `_bilinear_derivative` of the root and the diagonal): gradients reach C, d and the right-hand side
+            inv_quad_term = self.inv_quad(inv_quad_rhs, reduce_inv_quad=reduce_inv_quad)
         if logdet:
             logdet_term = self._logdet()
         return inv_quad_term, logdet_term
+
+
+class _WoodburyLogdet(torch.autograd.Function):
+    """logdet(C C^T + D) with its exact gradient (the reference differentiates the torch expression of the capacitance
+    Cholesky, :94-103; the value here is produced by kernels outside autograd)."""
+
+    @staticmethod
+    def forward(ctx, op, C, d):
+        pre = op._woodbury_factor()
+        ctx.pre, ctx.batch = pre, op.batch_shape
+        ctx.save_for_backward(C)
+        return pre.logdet.reshape(op.batch_shape) if len(op.batch_shape) else pre.logdet.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad):
+        (C,) = ctx.saved_tensors
+        pre = ctx.pre
+        g = grad.reshape(*ctx.batch, 1, 1)
+        gC = gd = None
+        if ctx.needs_input_grad[1]:
+            gC = 2.0 * g * K.precond_apply(pre, C.contiguous())  # 2 A^-1 C (the full-root Woodbury apply IS A^-1)
+        if ctx.needs_input_grad[2]:
+            q = pre.Q[..., : pre.k]
+            dinv = pre.dinv.unsqueeze(-1) if pre.constant_diag else pre.dinv
+            pinv_diag = (dinv - (q * q).sum(-1)).reshape(*ctx.batch, -1)  # diag(A^-1) = 1/d - rowsum(Q^2)
+            gd = pinv_diag * g.squeeze(-1)
+        return None, gC, gd
 
 
 __all__ = ["LowRankRootAddedDiagLinearOperator"]

@@ -720,15 +720,47 @@ def g16_sum_operators():
 
 
 
+def g17_low_rank_root_added_diag_backward():
+    """Gradients of LowRankRootAddedDiagLinearOperator (the reference differentiates the torch expressions of the
+    Woodbury closed forms, low_rank_root_added_diag_linear_operator.py:62-103,117-170): inv_quad + logdet, solve, and
+    the constant-diagonal variant."""
+    from linear_operator.operators import LowRankRootAddedDiagLinearOperator
+
+    print("G17 LowRankRootAddedDiag gradients")
+    C, d, rhs = cases.lowrank_diag(1701, 3, 1024, 16, 3)
+    W = cases.randn(1702, 3, 1024, 3, dtype=np.float32)
+    out = {}
+    Ct, dt, rt = [T(a).clone().requires_grad_(True) for a in (C, d, rhs)]
+    A = LowRankRootLinearOperator(Ct) + DiagLinearOperator(dt)
+    assert isinstance(A, LowRankRootAddedDiagLinearOperator)
+    iq, ld = A.inv_quad_logdet(rt, logdet=True)
+    (iq.sum() + ld.sum()).backward()
+    out.update(iq=iq, ld=ld, dC=Ct.grad, dd=dt.grad, drhs=rt.grad)
+    Ct, dt, rt = [T(a).clone().requires_grad_(True) for a in (C, d, rhs)]
+    A = LowRankRootLinearOperator(Ct) + DiagLinearOperator(dt)
+    x = A.solve(rt)
+    (x * T(W)).sum().backward()
+    out.update(s_x=x, s_dC=Ct.grad, s_dd=dt.grad, s_drhs=rt.grad)
+    sig = np.array([[0.3], [0.7], [1.1]], dtype=np.float32)
+    Ct, st = T(C).clone().requires_grad_(True), T(sig).clone().requires_grad_(True)
+    Ac = LowRankRootLinearOperator(Ct).add_diagonal(st)
+    assert isinstance(Ac, LowRankRootAddedDiagLinearOperator)
+    ldc = Ac.logdet()
+    (ldc * T(np.array([1.0, -2.0, 0.5], dtype=np.float32))).sum().backward()
+    out.update(c_ld=ldc, c_dC=Ct.grad, c_dsig=st.grad)
+    save("g17_lowrank_added_diag_backward", checksum=cases.checksum(C, d, rhs, W, sig), **out)
+
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
                      ("g9", g9_backward), ("g10", g10_backward_preconditioned), ("g11", g11_diagonalization),
                      ("g12", g12_kronecker_added_diag), ("g13", g13_minres),
                      ("g14", g14_sqrt_inv_matmul), ("g15", g15_lanczos_consumers_backward),
-                     ("g16", g16_sum_operators)):
+                     ("g16", g16_sum_operators), ("g17", g17_low_rank_root_added_diag_backward)):
         if name in todo:
             fn()
     print("done")

@@ -826,3 +826,39 @@ def test_opaque_operator_pivoted_cholesky_through_the_row_fetch_callback():
     (iq0, ld0, dC0, dd0), (iq1, ld1, dC1, dd1) = outs
     assert np.allclose(iq0, iq1, rtol=1e-4) and np.allclose(ld0, ld1, rtol=1e-3, atol=2e-2)
     assert np.abs(dd0 - dd1).max() <= 5e-3 * np.abs(dd1).max() and np.abs(dC0 - dC1).max() <= 5e-3 * np.abs(dC1).max()
+
+
+def test_low_rank_root_added_diag_gradients_match_reference_autograd():
+    """`LowRankRoot + Diag` is what the default `+` routing builds: its inv_quad / logdet / solve must carry gradients
+    to the root, the diagonal and the right-hand side (the reference differentiates the Woodbury expressions; here
+    Solve / InvQuad Functions + the exact logdet gradient) -- golden g17 = the reference's autograd."""
+    from linear_operator_amd.operators import LowRankRootAddedDiagLinearOperator
+
+    g = load_golden("g17_lowrank_added_diag_backward")
+    C, d, rhs = cases.lowrank_diag(1701, 3, 1024, 16, 3)
+    W = cases.randn(1702, 3, 1024, 3, dtype=np.float32)
+
+    def close(a, b, rel=2e-4):
+        a, b = host(a), np.asarray(b)
+        return a.shape == b.shape and np.abs(a - b).max() <= rel * np.abs(b).max()
+
+    with settings.max_cholesky_size(0):
+        Ct, dt, rt = [dev(a).clone().requires_grad_(True) for a in (C, d, rhs)]
+        A = LowRankRootLinearOperator(Ct) + DiagLinearOperator(dt)
+        assert isinstance(A, LowRankRootAddedDiagLinearOperator)
+        iq, ld = A.inv_quad_logdet(rt, logdet=True)
+        (iq.sum() + ld.sum()).backward()
+        assert np.allclose(host(iq), g["iq"], rtol=1e-4) and np.allclose(host(ld), g["ld"], rtol=1e-5)
+        assert close(Ct.grad, g["dC"]) and close(dt.grad, g["dd"]) and close(rt.grad, g["drhs"])
+        Ct, dt, rt = [dev(a).clone().requires_grad_(True) for a in (C, d, rhs)]
+        A = LowRankRootLinearOperator(Ct) + DiagLinearOperator(dt)
+        x = A.solve(rt)
+        (x * dev(W)).sum().backward()
+        assert max_rel_err_cols(host(x), g["s_x"]) < 1e-4
+        assert close(Ct.grad, g["s_dC"]) and close(dt.grad, g["s_dd"]) and close(rt.grad, g["s_drhs"])
+        sig = np.array([[0.3], [0.7], [1.1]], dtype=np.float32)
+        Ct, st = dev(C).clone().requires_grad_(True), dev(sig).clone().requires_grad_(True)
+        Ac = LowRankRootLinearOperator(Ct).add_diagonal(st)
+        ldc = Ac.logdet()
+        (ldc * dev(np.array([1.0, -2.0, 0.5], dtype=np.float32))).sum().backward()
+        assert np.allclose(host(ldc), g["c_ld"], rtol=1e-5) and close(Ct.grad, g["c_dC"]) and close(st.grad, g["c_dsig"])
