@@ -92,6 +92,14 @@ typedef struct lo_precond_desc {
   const float* dinv;     /* reciprocal noise                                                       */
 } lo_precond_desc;
 
+/* Batch-sharded solves (one process per GPU, SURVEY.md section 8(e) "option A"): the reference's stopping rule is the
+ * mean residual over the WHOLE batch (linear_cg.py:302-308).  When the batch is split over ranks the engine hands the
+ * local statistics to this hook at every stopping-rule evaluation; the hook all-reduces (SUM) the three values in
+ * place over the ranks (8-byte-class collective: torch.distributed / RCCL on the host side) and every rank takes the
+ * same decision.  vals = {sum of residual norms, number of (member, column) pairs, abort request (NaN seen)}.
+ * All ranks call it the same number of times (once per iteration from the first possible stop on).  Returns 0 on success. */
+typedef int (*lo_stop_reduce_cb)(void* user, double* vals /* [3], in/out */);
+
 /* linear_cg arguments that are scalars in the reference signature (linear_cg.py:98-109). */
 typedef struct lo_cg_params {
   int64_t c;                /* number of right-hand-side columns                                  */
@@ -105,6 +113,9 @@ typedef struct lo_cg_params {
   float eps;                /* 1e-10 (:104)                                                        */
   float stop_updating_after;/* 1e-10 (:105)                                                        */
   float pad;
+  lo_stop_reduce_cb stop_reduce; /* NULL: the stopping rule sees this call's batch only (single process, or
+                                  * "option B": per-shard rule); else the batch-global rule over all ranks */
+  void* stop_reduce_user;
 } lo_cg_params;
 
 /* What the reference reports through its warning text / exception (host-readable after the call). */

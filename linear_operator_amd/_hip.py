@@ -46,6 +46,9 @@ class HipExtensionError(RuntimeError):
     pass
 
 
+STOP_REDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
+
+
 class OpDesc(C.Structure):
     pass
 
@@ -63,7 +66,8 @@ class PrecondDesc(C.Structure):
 class CgParams(C.Structure):
     _fields_ = [("c", C.c_int64), ("n_tridiag", C.c_int32), ("max_iter", C.c_int32), ("max_tridiag_iter", C.c_int32),
                 ("floor_max_iter", C.c_int32), ("tolerance", C.c_float), ("eps", C.c_float),
-                ("stop_updating_after", C.c_float), ("pad", C.c_float)]
+                ("stop_updating_after", C.c_float), ("pad", C.c_float), ("stop_reduce", STOP_REDUCE_CB),
+                ("stop_reduce_user", C.c_void_p)]
 
 
 class CgInfo(C.Structure):

@@ -544,7 +544,10 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   d.max_iter = fmi;
   d.n_tridiag_iter = prm->max_tridiag_iter;
   d.T = prm->max_tridiag_iter;
-  d.tol = prm->tolerance;
+  // batch-global stopping rule over several ranks (lo_stop_reduce_cb): the device never decides the tolerance stop
+  // itself (tol = -1 can not be undercut by a mean of norms); the host evaluates the rule on the all-reduced statistic
+  const bool global_rule = prm->stop_reduce != nullptr;
+  d.tol = global_rule ? -1.0f : prm->tolerance;
   d.eps = prm->eps;
   d.stop_after = prm->stop_updating_after;
   d.check_nan_first = (x0 == nullptr);
@@ -575,6 +578,27 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   bool x_written = false;  // the resident kernel already wrote result * rhs_norm
   CgCtrl h;
   memset(&h, 0, sizeof(h));
+  // linear_cg.py:302-308 on the statistic of ALL ranks; called exactly once per completed iteration k >= first stop
+  auto global_check = [&]() -> int {
+    if (!global_rule) return LO_OK;
+    const int kdone = h.iterations - 1;
+    double vals[3] = {(double)h.mean_resid * (double)(B * c), (double)(B * c), h.stop ? 1.0 : 0.0};
+    if (prm->stop_reduce(prm->stop_reduce_user, vals)) return LO_ERR_LAUNCH;
+    const float gmean = (float)(vals[0] / vals[1]);
+    h.mean_resid = gmean;
+    if (vals[2] > 0.0) {  // some rank stopped on its own (NaN in a product): everybody stops
+      h.stop = 1;
+      return LO_OK;
+    }
+    const int kfl = std::min(10, fmi - 1);
+    const bool stopnow = kdone >= kfl && gmean < prm->tolerance &&
+                         !(prm->n_tridiag && kdone < std::min(prm->max_tridiag_iter, fmi - 1));
+    if (stopnow) {
+      h.tol_reached = 1;
+      h.stop = 1;
+    }
+    return LO_OK;
+  };
   int kfloor0 = std::min(10, fmi - 1);
   if (prm->n_tridiag) kfloor0 = std::max(kfloor0, std::min(prm->max_tridiag_iter, fmi - 1));  // first stop
   const int oc_nwg = onchip_num_workgroups();
@@ -682,6 +706,10 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
       LO_HIP_CHECK(hipStreamSynchronize(st));
       const int oc_err = h.oc_err;
+      if (oc_err == 0) {
+        rc = global_check();
+        if (rc) return rc;
+      }
       if (ls_dbg) {
         long long ts[10];
         LO_HIP_CHECK(hipMemcpy(ts, d.oc_dbg, sizeof(ts), hipMemcpyDeviceToHost));
@@ -737,7 +765,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   int first_poll = kfloor;
   if (prm->n_tridiag) first_poll = std::max(first_poll, std::min(prm->max_tridiag_iter, fmi - 1));
   const bool opaque = (op->kind == LO_OP_CALLBACK) || (precond_cb != nullptr);
-  const int chunk = opaque ? 1 : 4;
+  const int chunk = (opaque || global_rule) ? 1 : 4;
   auto poll = [&]() -> int {
     LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
     LO_HIP_CHECK(hipStreamSynchronize(st));
@@ -790,6 +818,10 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     if (at_poll || k == prm->max_iter - 1 || (opaque && k == 0)) {
       rc = poll();
       if (rc) return rc;
+      if (k >= first_poll) {  // (one collective per iteration from the first possible stop on, on every rank)
+        rc = global_check();
+        if (rc) return rc;
+      }
     }
     ++k;
   }

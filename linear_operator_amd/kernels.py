@@ -249,7 +249,8 @@ def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optio
              precond: Optional[WoodburyPreconditioner] = None, matvec_closure: Optional[Callable] = None,
              precond_closure: Optional[Callable] = None, closure_batch_shape=None, n_tridiag: int = 0,
              max_iter: int = 1000, max_tridiag_iter: int = 20, tolerance: float = 1.0, eps: float = 1e-10,
-             stop_updating_after: float = 1e-10, floor_max_iter: int = 0) -> CGResult:
+             stop_updating_after: float = 1e-10, floor_max_iter: int = 0,
+             stop_reduce: Optional[Callable] = None) -> CGResult:
     """lo_cg_solve_f32: the reference's linear_cg (utils/linear_cg.py:98-359) on the device.
 
     rhs [*batch, N, c].  Either `desc` (structured operator, fully native loop) or `matvec_closure`
@@ -294,6 +295,19 @@ def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optio
     prm.c, prm.n_tridiag, prm.max_iter, prm.max_tridiag_iter = c, n_tridiag, max_iter, max_tridiag_iter
     prm.floor_max_iter = floor_max_iter  # the reference's stop-rule floors use the unclipped max_iter (:303-305)
     prm.tolerance, prm.eps, prm.stop_updating_after = tolerance, eps, stop_updating_after
+    sr_err = []
+    if stop_reduce is not None:  # batch-global stopping rule over the ranks of a process group (distributed.py)
+        def _sr(user, vals):
+            try:
+                out = stop_reduce([vals[0], vals[1], vals[2]])
+                vals[0], vals[1], vals[2] = float(out[0]), float(out[1]), float(out[2])
+                return 0
+            except BaseException as e:  # noqa: BLE001 -- must not unwind through C
+                sr_err.append(e)
+                return 1
+
+        prm.stop_reduce = _hip.STOP_REDUCE_CB(_sr)
+        keep.append(prm.stop_reduce)
     ws_bytes = lib.lo_cg_workspace_bytes(C.byref(s), C.byref(pre_s) if pre_s is not None else None, C.byref(prm))
     ws = _hip.workspace(ws_bytes, dev)
     x = torch.empty_like(rhs3)
@@ -304,7 +318,7 @@ def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optio
     rc = lib.lo_cg_solve_f32(C.byref(s), mv_cb, None, C.byref(pre_s) if pre_s is not None else None, pc_cb, None,
                              C.byref(prm), _hip.ptr(rhs3), _hip.ptr(x03), _hip.ptr(x), _hip.ptr(t_mat), _hip.ptr(ws),
                              ws.numel(), C.byref(info), _hip.stream_ptr(dev))
-    for e in (mv_err + pc_err):
+    for e in (mv_err + pc_err + sr_err):
         raise e
     _hip.check(rc, "lo_cg_solve_f32")
     if t_mat is not None:

@@ -172,7 +172,16 @@ class AddedDiagLinearOperator(SumLinearOperator):
             # chained by hand (functions/_inv_quad_logdet._add_preconditioner_terms), exactly as on the lowered path
             return L.detach()
         tol = settings.preconditioner_tolerance.value()
-        L, perm = K.pivoted_cholesky(desc, min(max_iter, self.size(-1)), float(tol), contiguous=False)
+        rank = min(max_iter, self.size(-1))
+        L, perm = K.pivoted_cholesky(desc, rank, float(tol), contiguous=False)
+        # batch-sharded runs under distributed.global_stopping_rule: the reference takes pivots while ANY member's
+        # error exceeds the tolerance (_pivoted_cholesky.py:57), i.e. the largest rank any shard takes on its own; a
+        # shard that stopped earlier continues to that rank (tolerance 0 never stops before the rank bound)
+        from .. import distributed
+
+        m_global = distributed.global_max_int(L.shape[-1])
+        if m_global > L.shape[-1]:
+            L, perm = K.pivoted_cholesky(desc, m_global, 0.0, contiguous=False)
         self._piv_chol_perm = perm  # needed by the backward pass of the preconditioner terms
         return L
 

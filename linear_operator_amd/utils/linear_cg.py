@@ -24,6 +24,14 @@ from .. import kernels as K
 from .warnings import NumericalWarning
 
 
+def _active_stop_reduce():
+    """The all-reduce hook of `distributed.global_stopping_rule(...)` when one is active (batch-sharded solves that
+    keep the reference's batch-GLOBAL stopping rule, linear_cg.py:302-308), else None."""
+    from .. import distributed
+
+    return distributed.active_stop_reduce()
+
+
 def _default_preconditioner(x):
     return x.clone()
 
@@ -117,6 +125,7 @@ def linear_cg(
         desc, rhs, x0=initial_guess, precond=woodbury, matvec_closure=closure, precond_closure=precond_closure,
         n_tridiag=n_tridiag, max_iter=n_iter, max_tridiag_iter=n_tridiag_iter, tolerance=float(tolerance),
         eps=float(eps), stop_updating_after=float(stop_updating_after), floor_max_iter=max_iter,
+        stop_reduce=_active_stop_reduce(),
     )
     if res.nan_detected:  # :199-200
         raise RuntimeError("NaNs encountered when trying to perform matrix-vector multiplication")

@@ -90,3 +90,65 @@ def test_shard_bounds_cover_batch():
             assert spans[0][0] == 0 and spans[-1][1] == B
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _worker_factory(rank, world, port, B, out_dir):
+    """Factory sharding (only this rank's members are ever built) and the plumbing of the batch-global stopping rule:
+    the oracle plays the per-shard solver and calls the active reducer the way the device engine does."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cases
+    from linear_operator_amd import distributed as D
+    from linear_operator_amd.operators import AddedDiagLinearOperator, DiagLinearOperator, LowRankRootLinearOperator
+    from oracle import lo_oracle as orc
+
+    C, d, rhs = cases.lowrank_diag(778, B, 96, 4, 2)
+    built = []
+
+    def factory(lo_, hi_):
+        built.append((lo_, hi_))
+        op = AddedDiagLinearOperator(LowRankRootLinearOperator(torch.from_numpy(C[lo_:hi_])),
+                                     DiagLinearOperator(torch.from_numpy(d[lo_:hi_])))
+        return op, torch.from_numpy(rhs[lo_:hi_])
+
+    seen = {}
+
+    def oracle_solve(op_s, rhs_s):
+        Cs, ds = (t.numpy() for t in op_s.representation())
+        x, _, info = orc.linear_cg(lambda v: orc.matvec_lowrank_diag(Cs, ds, v), rhs_s.numpy(), tolerance=1e-4)
+        red = D.active_stop_reduce()
+        seen["reducer"] = red
+        if red is not None:  # the statistic the engine hands over: local residual sum, local column count, abort flag
+            n = float(rhs_s.shape[0] * rhs_s.shape[-1])
+            seen["reduced"] = red([info.mean_residual * n, n, 0.0])
+            seen["m"] = D.global_max_int(10 + rank)
+        return torch.from_numpy(x)
+
+    x = D.sharded_solve_from_factory(factory, B, solve_fn=oracle_solve, global_rule=True)
+    lo_, hi_ = D.shard_bounds(B, rank, world)
+    assert built == [(lo_, hi_)], "only this rank's slice may be built"
+    assert isinstance(seen["reducer"], D.StopReduce) and D.active_stop_reduce() is None
+    assert abs(seen["reduced"][1] - B * 2) < 1e-9 and seen["reduced"][2] == 0.0  # counts of both ranks added up
+    assert seen["m"] == 10 + world - 1
+    x_local = D.sharded_solve_from_factory(factory, B, solve_fn=oracle_solve, gather=False)
+    assert x_local.shape[0] == hi_ - lo_ and seen["reducer"] is None
+    if rank == 0:
+        np.savez(os.path.join(out_dir, f"fac_{B}.npz"), x=x.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [6, 5])
+def test_factory_sharding_and_global_rule_plumbing_gloo_world2(tmp_path, B):
+    import cases
+    from oracle import lo_oracle as orc
+
+    port = _free_port()
+    mp.spawn(_worker_factory, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / f"fac_{B}.npz")
+    C, d, rhs = cases.lowrank_diag(778, B, 96, 4, 2)
+    full, _, _ = orc.linear_cg(lambda v: orc.matvec_lowrank_diag(C, d, v), rhs, tolerance=1e-4)
+    assert got["x"].shape == full.shape and np.allclose(got["x"], full, rtol=1e-5, atol=1e-6)

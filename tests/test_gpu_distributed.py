@@ -1,0 +1,222 @@
+"""GPU tests of the multi-GPU path on ONE device: the batch-global stopping rule across shards (virtual ranks =
+threads with a barrier all-reduce standing in for RCCL), the HIP kernels under a real `nccl` (RCCL) process group with a
+collective in flight, and the operator-resident kernels next to unrelated work on another stream."""
+import os
+import socket
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from conftest import max_rel_err_cols
+
+pytestmark = pytest.mark.gpu
+
+from linear_operator_amd import distributed as D  # noqa: E402
+from linear_operator_amd import kernels as K  # noqa: E402
+from linear_operator_amd import settings  # noqa: E402
+from linear_operator_amd.operators import (  # noqa: E402
+    AddedDiagLinearOperator, ConstantDiagLinearOperator, DiagLinearOperator, KroneckerProductLinearOperator,
+    LowRankRootLinearOperator,
+)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+class _ThreadAllReduce:
+    """SUM / MAX over `world` threads of one process (the collective of the virtual ranks)."""
+
+    def __init__(self, world):
+        self.world, self.barrier, self.lock = world, threading.Barrier(world), threading.Lock()
+        self.acc, self.out, self.calls = None, None, 0
+
+    def _combine(self, vals, op):
+        with self.lock:
+            self.acc = list(vals) if self.acc is None else [op(a, b) for a, b in zip(self.acc, vals)]
+        if self.barrier.wait() == 0:
+            self.out, self.acc = self.acc, None
+            self.calls += 1
+        self.barrier.wait()
+        return list(self.out)
+
+    def __call__(self, vals):
+        return self._combine(vals, lambda a, b: a + b)
+
+    def max_int(self, v):
+        return int(self._combine([v], max)[0])
+
+
+def test_global_stopping_rule_across_shards_reproduces_the_unsharded_iterations():
+    """BASELINE cfg4 in small: Kronecker + constant jitter, CG runs far beyond the floor, so the reference's stopping
+    rule (mean residual over the WHOLE batch, linear_cg.py:302-308) decides the iteration count.  Two shards solved
+    concurrently under distributed.global_stopping_rule take exactly the iterations of the unsharded solve (and
+    reproduce its solution); without it each shard stops on its own members' mean."""
+    B, n1, n2 = 6, 32, 32
+    K1, K2, sig, rhs = cases.kron_factors(2101, B, n1, n2, 1, sigma=1e-2)
+    # members of very different difficulty: the shards would stop at different iterations on their own
+    rhs[:3] *= 1e-3
+    N = n1 * n2
+
+    def make(lo, hi):
+        return AddedDiagLinearOperator(KroneckerProductLinearOperator(dev(K1[lo:hi]), dev(K2[lo:hi])),
+                                       ConstantDiagLinearOperator(dev(sig[lo:hi]), N))
+
+    iters = {}
+    real_cg = K.cg_solve
+
+    def spy(tag):
+        def f(*a, **kw):
+            r = real_cg(*a, **kw)
+            iters.setdefault(tag, []).append(r.iterations)
+            return r
+        return f
+
+    with settings.cg_tolerance(1e-3), settings.max_cg_iterations(500), settings.min_preconditioning_size(10 ** 9):
+        K.cg_solve = spy("full")
+        try:
+            x_full = make(0, B).solve(dev(rhs))
+        finally:
+            K.cg_solve = real_cg
+        red = _ThreadAllReduce(2)
+        out, errs = {}, []
+
+        def worker(rank, use_global):
+            try:
+                torch.cuda.set_device(0)
+                lo, hi = D.shard_bounds(B, rank, 2)
+                # (the settings are process-global and set by the main thread around the workers' lifetime)
+                if use_global:
+                    with D.global_stopping_rule(reducer=red):
+                        out[(use_global, rank)] = make(lo, hi).solve(dev(rhs[lo:hi]))
+                else:
+                    out[(use_global, rank)] = make(lo, hi).solve(dev(rhs[lo:hi]))
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+                red.barrier.abort()
+
+        for use_global in (True, False):
+            K.cg_solve = spy("global" if use_global else "local")
+            try:
+                ts = [threading.Thread(target=worker, args=(r, use_global)) for r in range(2)]
+                [t.start() for t in ts]
+                [t.join() for t in ts]
+            finally:
+                K.cg_solve = real_cg
+            assert not errs, errs
+    it_full = iters["full"][0]
+    assert it_full > 30, "the case must run beyond the floors for the rule to matter"
+    assert iters["global"] == [it_full, it_full], (iters, "sharded run with the global rule must match the unsharded count")
+    assert red.calls >= 1
+    assert len(set(iters["local"])) == 2 and max(iters["local"]) != it_full or min(iters["local"]) != it_full
+    x_glob = torch.cat([out[(True, 0)], out[(True, 1)]], 0)
+    assert max_rel_err_cols(host(x_glob), host(x_full)) < 2e-5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_hip_kernels_under_an_rccl_process_group_with_a_collective_in_flight():
+    """The product path under torch.distributed with backend nccl (= RCCL): a 1-rank group on this GPU, the solutions of
+    solve k all-gathered asynchronously while solve k+1 runs (what bench.py --gpus N does), the global stopping rule
+    through a real all_reduce.  The operator-resident kernels must either keep their co-residency or fall back to the
+    streaming engine -- results equal the quiet run bit for bit either way."""
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        Bn, N, R = 96, 8192, 32
+        C, d, rhs = cases.lowrank_diag(2201, Bn, N, R, 1)
+        desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+        L, _ = K.pivoted_cholesky(K.lowrank_diag_descriptor(dev(C), None), 15, contiguous=False)
+        pre = K.precond_build(L, dev(d), False)
+        rhs_t = dev(rhs)
+        ref = K.cg_solve(desc, rhs_t, precond=pre, tolerance=1e-4)
+        torch.cuda.synchronize()
+        big = torch.randn(64 * 1024 * 1024, device="cuda")  # 256 MiB payload keeps RCCL's kernel busy
+        gathered = [torch.empty_like(big) for _ in range(2)]
+        bufs = [torch.empty(Bn, N, 1, device="cuda") for _ in range(2)]
+        pending = []
+        for i in range(6):
+            pending.append(dist.all_gather_into_tensor(gathered[i % 2], big, async_op=True))
+            res = K.cg_solve(desc, rhs_t, precond=pre, tolerance=1e-4)
+            pending.append(dist.all_gather_into_tensor(bufs[i % 2], res.x, async_op=True))
+            assert res.iterations == ref.iterations and torch.equal(res.x, ref.x)
+            while len(pending) > 2:
+                pending.pop(0).wait()
+        for w in pending:
+            w.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(bufs[1], ref.x)
+        # the batch-global stopping rule through a real RCCL all_reduce (world 1: same decision as the local rule)
+        A = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C[:8])), DiagLinearOperator(dev(d[:8])))
+        with settings.cg_tolerance(1e-4):
+            x_local = A.solve(dev(rhs[:8]))
+            with D.global_stopping_rule() as red:
+                x_glob = A.solve(dev(rhs[:8]))
+            assert isinstance(red, D.StopReduce) and red.calls >= 1
+        assert torch.equal(x_local, x_glob)
+        # factory sharding: only the local slice is built, gathered result = full result
+        built = []
+
+        def factory(lo, hi):
+            built.append((lo, hi))
+            return (AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C[lo:hi])), DiagLinearOperator(dev(d[lo:hi]))),
+                    dev(rhs[lo:hi]))
+
+        with settings.cg_tolerance(1e-4):
+            x_all = D.sharded_solve_from_factory(factory, 8, global_rule=True)
+        assert built == [(0, 8)] and torch.equal(x_all, x_local)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_resident_kernels_next_to_unrelated_work_on_another_stream():
+    """The resident kernels need all their workgroups co-resident while another stream keeps CUs busy (as RCCL's kernels
+    do in the multi-GPU bench): solves and factorisations stay bit-identical to the quiet run (co-residency kept, or the
+    timeout fallback to the streaming engines taken)."""
+    Bn, N, R = 256, 8192, 32
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    Cm = torch.randn(Bn, N, R, generator=g, device="cuda") / R ** 0.5
+    d = torch.rand(Bn, N, generator=g, device="cuda") + 0.5
+    rhs = torch.randn(Bn, N, 1, generator=g, device="cuda")
+    full = torch.randn(Bn, N, 16, generator=g, device="cuda")
+    desc = K.lowrank_diag_descriptor(Cm, d)
+    L, _ = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15, contiguous=False)
+    pre = K.precond_build(L, d, False)
+    ref = K.cg_solve(desc, rhs, precond=pre, tolerance=1e-4).x.clone()
+    ref16 = K.cg_solve(desc, full, precond=pre, tolerance=1e-4, n_tridiag=16).x.clone()  # (lockstep kernel)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    b = torch.randn(4096, 4096, device="cuda")
+    big = torch.randn(64 * 1024 * 1024, device="cuda")
+    for kind in ("gemm", "stream"):
+        with torch.cuda.stream(side):
+            for _ in range(60):
+                if kind == "gemm":
+                    a @ b
+                else:
+                    big.mul_(1.0000001)
+        bad = 0
+        for _ in range(10):
+            x = K.cg_solve(desc, rhs, precond=pre, tolerance=1e-4).x
+            x16 = K.cg_solve(desc, full, precond=pre, tolerance=1e-4, n_tridiag=16).x
+            Lx, _ = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15, contiguous=False)
+            bad += int(not torch.equal(x, ref)) + int(not torch.equal(Lx, L)) + int(not torch.equal(x16, ref16))
+        torch.cuda.synchronize()
+        assert bad == 0, f"{bad} mismatches with background {kind} work"
