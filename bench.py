@@ -276,6 +276,98 @@ def other_configs(device):
     return res, roofs
 
 
+def strong_scaling(args, device, dist, rank, world):
+    """`--workload cfg4|cfg5`: BASELINE's sharded configs at their FULL batch (1024 Kronecker members / 256 dense
+    16384^2 members), split over the ranks (strong scaling).  Every rank constructs only its own members on its own
+    device (distributed.build_local_shard semantics); when even the shard exceeds the memory budget (cfg5 on one
+    GPU: 256 GiB) the shard is processed in resident chunks and the chunks reuse one chunk's synthetic data.
+    A step = preconditioner (pivoted Cholesky + build) + CG (+ tridiagonals and SLQ for cfg5) over the whole batch."""
+    from linear_operator_amd.distributed import shard_bounds
+
+    total = 1024 if args.workload == "cfg4" else 256
+    lo, hi = shard_bounds(total, rank, world)
+    mine = hi - lo
+    g = torch.Generator(device=device)
+    g.manual_seed(4000 + rank)
+    if args.workload == "cfg4":
+        n = 256
+        chunk = mine
+        X1 = torch.randn(chunk, n, n, generator=g, device=device) / 16
+        X2 = torch.randn(chunk, n, n, generator=g, device=device) / 16
+        K1 = X1 @ X1.mT + 0.1 * torch.eye(n, device=device)
+        K2 = X2 @ X2.mT + 0.1 * torch.eye(n, device=device)
+        del X1, X2
+        sig = torch.full((chunk,), 1e-2, device=device)
+        rhs = torch.randn(chunk, n * n, 1, generator=g, device=device)
+        desc = K.kron_diag_descriptor(K1, K2, sig, const_diag=True)
+
+        def solve_chunk():
+            L, _ = K.pivoted_cholesky(desc, RANK_K, contiguous=False)
+            return K.cg_solve(desc, rhs, precond=K.precond_build(L, sig, True), tolerance=1e-3)
+
+        cols, what = 1, "KroneckerProduct(256x256, 256x256) + 1e-2 I, N = 65536, 1 rhs column, tolerance 1e-3"
+    else:
+        Nd = 16384
+        chunk = min(mine, max(1, int(args.chunk_members)))
+        Y = torch.randn(chunk, Nd, 256, generator=g, device=device) / 16
+        Kd = Y @ Y.mT
+        del Y
+        d = torch.rand(chunk, Nd, generator=g, device=device) + 0.5
+        full = torch.randn(chunk, Nd, 17, generator=g, device=device)
+        full[..., :16] /= full[..., :16].norm(dim=-2, keepdim=True)
+        desc = K.dense_diag_descriptor(Kd, d)
+
+        def solve_chunk():
+            L, _ = K.pivoted_cholesky(desc, RANK_K, contiguous=False)
+            pre = K.precond_build(L, d, False)
+            r = K.cg_solve(desc, full, precond=pre, n_tridiag=16, tolerance=TOL)
+            K.tridiag_eigh_slq(r.t_mat, Nd)
+            return r
+
+        cols, what = 17, "AddedDiag(Dense 16384^2 (rank-256 PSD), Diag), 16 probes + 1 rhs, CG + SLQ logdet"
+    nchunks = (mine + chunk - 1) // chunk
+
+    def step():
+        r = None
+        for _ in range(nchunks):
+            r = solve_chunk()
+        return r
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    return {
+        "metric": "cg_member_matvecs_per_sec", "value": total * res.matvecs * args.steps / elapsed,
+        "unit": "member-matvecs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE {args.workload} at its full batch of {total} members: {what}",
+                   "total_members": total, "members_per_rank": mine, "resident_chunk": chunk,
+                   "chunks_per_step": nchunks, "rhs_columns": cols, "iterations": res.iterations,
+                   "note": ("every rank builds only its own members; " +
+                            ("chunks beyond the resident one reuse its synthetic data (the shard exceeds the memory "
+                             "budget)" if nchunks > 1 else "the whole shard is resident")),
+                   "sharding": f"batch x{world}, no collective inside the solve"},
+    }
+
+
 def main():
     # stdout carries exactly ONE JSON line: everything else that libraries print to fd 1 (RCCL prints a version banner
     # on process-group setup) is sent to stderr for the whole run; the JSON goes to the saved descriptor at the end.
@@ -288,6 +380,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the quick numbers for the other BASELINE configs")
+    ap.add_argument("--workload", choices=["headline", "cfg4", "cfg5"], default="headline",
+                    help="headline (default, weak scaling, the driver's contract) or BASELINE cfg4 / cfg5 at their "
+                         "full batch split over the ranks (strong scaling)")
+    ap.add_argument("--chunk-members", type=int, default=128,
+                    help="cfg5: members resident at a time per rank (1 GiB each)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -309,6 +406,17 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     _hip.load()
+
+    if args.workload != "headline":
+        out = strong_scaling(args, device, dist if use_dist else None, rank, world)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.stdout.flush()
+        if rank == 0:
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        os.close(real_stdout)
+        return
 
     Cm, d, rhs = make_problem(device, 1234 + rank)
     desc = K.lowrank_diag_descriptor(Cm, d)
