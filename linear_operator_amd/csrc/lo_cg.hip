@@ -452,7 +452,7 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   dd.oc_maxoff = ar.take<int>((size_t)std::max(1, (int)prm->max_tridiag_iter) + 1);
   dd.oc_dbg = ar.take<long long>(16);
   dd.ls_gbuf = (oc_shape && c >= kLockstepMinCols && N <= 8192)
-                   ? ar.take<unsigned long long>(lockstep_gbuf_bytes(32, 8) / sizeof(unsigned long long))
+                   ? ar.take<unsigned long long>(lockstep_gbuf_bytes(32, 16) / sizeof(unsigned long long))
                    : nullptr;
   dd.oc_zero_q = nullptr;
   dd.oc_ones = nullptr;
@@ -660,14 +660,19 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     rc = LO_OK;
     bool xout_ok = true;  // every launched kernel wrote result * rhs_norm itself
     if (ls_cols) {  // third generation: columns [0, ls_cols)
-      a.GW = 8;
-      a.RW = (int)((N + 7) / 8);
       a.ncols = ls_cols;
       a.xout = x;
       a.gbuf = d.ls_gbuf; a.next_member = d.oc_err + 2;
       a.dbg = ls_dbg ? d.oc_dbg : nullptr;
-      LO_HIP_CHECK(hipMemsetAsync(d.ls_gbuf, 0, lockstep_gbuf_bytes(32, 8), st));
+      LO_HIP_CHECK(hipMemsetAsync(d.ls_gbuf, 0, lockstep_gbuf_bytes(32, 16), st));
+      a.GW = lockstep_group_size(N);
+      a.RW = (int)((N + a.GW - 1) / a.GW);
       rc = lockstep_launch(pl.R4, pre != nullptr, a, std::min(oc_nwg, 256), st);
+      if (rc == LO_ERR_UNSUPPORTED && a.GW == 16) {  // (two workgroups per CU do not fit: one 1024-row workgroup)
+        a.GW = 8;
+        a.RW = (int)((N + 7) / 8);
+        rc = lockstep_launch(pl.R4, pre != nullptr, a, std::min(oc_nwg, 256), st);
+      }
       if (rc == LO_ERR_UNSUPPORTED) {  // (does not fit this device: all columns go to the serial kernels)
         ls_cols = 0;
         rc = (oc_gen1_ok || onchip4_eligible(pl.R4, ocR4, N, c)) ? LO_OK : LO_ERR_UNSUPPORTED;

@@ -43,8 +43,7 @@
 
 namespace lo {
 
-constexpr int LS_TPB = 512;
-constexpr int LS_ROWS = 1024;   // rows per workgroup
+constexpr int LS_WROWS = 128;   // rows per wave
 constexpr int LS_NBLK = 8;      // 16-row blocks per wave
 constexpr int LS_NC = 16;       // columns advanced together
 constexpr int LS_NVP = 832;     // payload slots allocated per workgroup (>= NV of every instantiation)
@@ -80,6 +79,11 @@ __device__ __forceinline__ int opaque(int v) {
   return v;
 }
 
+// granules in front of the per-CU arrival counters: (workgroups / GW) groups x 2 parities x (GW + 1) arrays
+__host__ __device__ inline size_t ngroups_total_slots(unsigned nwg, int GW) {
+  return (size_t)(nwg / GW) * 2 * (GW + 1) * LS_NVP;
+}
+
 struct LsGroup {
   unsigned long long* gslot;  // [2][GW][LS_NVP] granules of this group
   int wig;
@@ -88,32 +92,34 @@ struct LsGroup {
   bool same_xcd;
 };
 
-// part[0..3][0..cnt) hold the four second-stage partials of this workgroup.  Entry e is summed (fixed order),
-// published as a {tag, value} granule, the same entry of every workgroup of the group is polled and summed in fixed
-// order -> res[e], bitwise identical in all workgroups.  Starts and ends with a barrier.
-template <int GW>
+// part[0..NP)[0..cnt) hold the second-stage partials of this workgroup.  Entry e is summed (fixed order) and published
+// as a {tag, value} granule; the entries of all workgroups of the group are then summed in fixed order -> res[e],
+// bitwise identical in all workgroups.  Starts and ends with a barrier.
+//   GW <= 8 : every workgroup polls the entry of all GW workgroups itself (one hand-off);
+//   GW == 16: reduce-scatter + all-gather -- workgroup j sums the entries [j per, (j+1) per) of all 16 workgroups and
+//             publishes the totals, everybody then reads the totals (two hand-offs, 8 x fewer loads: the payload of a
+//             16-column iteration is 816 values).
+template <int GW, int NP, int TPB>
 __device__ __forceinline__ void ls_group_sum(float (*part)[LS_NVP], float* res, int cnt, LsGroup& g) {
   const int t = threadIdx.x;
   const unsigned tag = ++g.tag;
   __syncthreads();
-  unsigned long long* slot = g.gslot + (size_t)(tag & 1u) * GW * LS_NVP;
-  for (int e = t; e < cnt; e += LS_TPB) {
-    const float s = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
-    const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(s);
-    if (g.same_xcd)
-      __hip_atomic_store(slot + (size_t)g.wig * LS_NVP + e, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else
-      __hip_atomic_store(slot + (size_t)g.wig * LS_NVP + e, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  for (int e = t; e < cnt; e += LS_TPB) {
-    float vals[GW];
+  unsigned long long* slot = g.gslot + (size_t)(tag & 1u) * (GW + 1) * LS_NVP;  // GW partial arrays | one totals array
+  auto publish = [&](unsigned long long* dst, float v) {
+    const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+    if (g.same_xcd) __hip_atomic_store(dst, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(dst, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // sum over NW consecutive granules (stride LS_NVP) of entry e, waiting for their tags
+  auto gather8 = [&](const unsigned long long* src, int e) -> float {
+    float vals[8];
     unsigned spin = 0;
     for (;;) {
       bool ok = true;
 #pragma unroll
-      for (int w = 0; w < GW; ++w) {
+      for (int w = 0; w < 8; ++w) {
         const unsigned long long x =
-            __hip_atomic_load(slot + (size_t)w * LS_NVP + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_load(src + (size_t)w * LS_NVP + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = ok && ((unsigned)(x >> 32) == tag);
         vals[w] = __uint_as_float((unsigned)(x & 0xffffffffull));
       }
@@ -127,18 +133,54 @@ __device__ __forceinline__ void ls_group_sum(float (*part)[LS_NVP], float* res, 
     }
     float tot = 0.f;
 #pragma unroll
-    for (int w = 0; w < GW; ++w) tot += vals[w];
-    res[e] = tot;
+    for (int w = 0; w < 8; ++w) tot += vals[w];
+    return tot;
+  };
+  for (int e = t; e < cnt; e += TPB) {
+    float sum = part[0][e];
+#pragma unroll
+    for (int q = 1; q < NP; ++q) sum += part[q][e];
+    publish(slot + (size_t)g.wig * LS_NVP + e, sum);
+  }
+  if constexpr (GW == 8) {
+    for (int e = t; e < cnt; e += TPB) res[e] = gather8(slot, e);
+  } else {
+    static_assert(GW == 16, "group size");
+    unsigned long long* tot = slot + (size_t)GW * LS_NVP;
+    const int per = (cnt + GW - 1) / GW;
+    const int lo = g.wig * per, hi = min(cnt, lo + per);
+    for (int e = lo + t; e < hi; e += TPB)  // (fixed order: workgroups 0-7, then 8-15)
+      publish(tot + e, gather8(slot, e) + gather8(slot + (size_t)8 * LS_NVP, e));
+    for (int e = t; e < cnt; e += TPB) {
+      unsigned spin = 0;
+      unsigned long long x;
+      for (;;) {
+        x = __hip_atomic_load(tot + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == tag) break;
+        if (++spin > LS_MAXSPIN ||
+            ((spin & 1023u) == 0 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          atomicExch(g.err, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      res[e] = __uint_as_float((unsigned)(x & 0xffffffffull));
+    }
   }
   __syncthreads();
 }
 
 // RC: padded rank of C (16 or 32).  PRE: Woodbury preconditioner z = r/d' - Q (Q^T r) with Q [.., 16] (zero padded);
-// !PRE: z = r.  GW: workgroups per member.
+// !PRE: z = r.  GW: workgroups per member.  NW: waves per workgroup -- 8 (1024 rows, one workgroup per CU, GW = 8) or
+// 4 (512 rows, TWO workgroups per CU that belong to different members, GW = 16: while one waits for its hand-off the
+// other keeps the matrix cores busy).
 // DBG: phase timers (wall_clock64) of one work item; a separate instantiation so that the production kernel does not
 // carry their registers.
-template <int RC, bool PRE, int GW, bool DBG>
-__global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
+template <int RC, bool PRE, int GW, int NW, bool DBG>
+__global__ __launch_bounds__(NW * 64, 2) void k_cg_lockstep(OnchipArgs a) {
+  constexpr int LS_TPB = NW * 64;
+  constexpr int LS_ROWS = NW * LS_WROWS;        // rows per workgroup
+  constexpr int NP = NW / 2;                    // second-stage partials of the cross-wave sum
   constexpr int NH = RC / 16;                   // 16-row blocks of T = C^T p
   constexpr int OFF_U = NH * 256;               // payload: W | U | three scalars per column
   constexpr int OFF_S = OFF_U + (PRE ? 256 : 0);
@@ -147,7 +189,7 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
   __shared__ __attribute__((aligned(16))) float c_s[LS_ROWS * RC];
   __shared__ __attribute__((aligned(16))) float d_s[LS_ROWS];
   __shared__ __attribute__((aligned(16))) float dinv_s[LS_ROWS];
-  __shared__ float part[4][LS_NVP];
+  __shared__ float part[NP][LS_NVP];
   __shared__ float res[LS_NVP];
   __shared__ float h_s[NH * 4 * 64];            // H = C^T Q in the A-operand order [(h, s)][lane]
 
@@ -160,7 +202,7 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
   if (jx / GW >= groups_per_xcd) return;
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), kk = lane >> 4, n = lane & 15;
   LsGroup g;
-  g.gslot = a.gbuf + (size_t)grp * 2 * GW * LS_NVP;
+  g.gslot = a.gbuf + (size_t)grp * 2 * (GW + 1) * LS_NVP;
   g.wig = wig;
   g.tag = 0;
   g.err = a.err;
@@ -169,12 +211,30 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
     const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
     if (t < 2) {
       part[0][t] = t == 0 ? (float)xcc : (float)(xcc * xcc);
-      part[1][t] = 0.f; part[2][t] = 0.f; part[3][t] = 0.f;
+#pragma unroll
+      for (int q = 1; q < NP; ++q) part[q][t] = 0.f;
     }
-    ls_group_sum<GW>(part, res, 2, g);
+    ls_group_sum<GW, NP, LS_TPB>(part, res, 2, g);
     const float fx = (float)xcc;
     g.same_xcd = (res[0] == GW * fx) && (res[1] == GW * fx * fx) && (a.allow_l2_handoff != 0);
     __syncthreads();
+  }
+
+  if constexpr (NW == 4) {
+    // Two workgroups share a CU and both are deterministic loops of equal length: left alone they stay in phase --
+    // both in their matrix-core phases (halving each other's rate), then both waiting for their hand-offs (pipes idle).
+    // The first workgroup to arrive on a CU raises its wave priority: it gets the matrix cores whenever it wants them
+    // and finishes its compute phase at full rate, the other one computes while the first waits -- the complementary
+    // schedule establishes itself.  (CU identity from HW_REG_HW_ID[15:8] + XCC id; counters zeroed with the granules.)
+    __shared__ int cu_slot;
+    if (t == 0) {
+      const unsigned hwid = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);   // HW_REG_HW_ID
+      const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;
+      int* counters = reinterpret_cast<int*>(a.gbuf + (size_t)ngroups_total_slots(gridDim.x, GW));
+      cu_slot = atomicAdd(counters + ((xcc << 8) | ((hwid >> 8) & 0xffu)), 1);
+    }
+    __syncthreads();
+    if ((cu_slot & 1) == 0) __builtin_amdgcn_s_setprio(3);
   }
 
   const int row0 = wig * a.RW;
@@ -309,23 +369,23 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
       s1 = kk_sum(s1);
       s2 = kk_sum(s2);
       __syncthreads();  // (measured: without this re-alignment of the waves the iteration is 10 % slower)
-      if (w >= 4) {
+      if (w >= NP) {
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) part[w - 4][(h * 4 + i) * 64 + lane] = accw[h][i];
+          for (int i = 0; i < 4; ++i) part[w - NP][(h * 4 + i) * 64 + lane] = accw[h][i];
         if constexpr (PRE) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) part[w - 4][OFF_U + i * 64 + lane] = accu[i];
+          for (int i = 0; i < 4; ++i) part[w - NP][OFF_U + i * 64 + lane] = accu[i];
         }
         if (kk == 0) {
-          part[w - 4][OFF_S + n] = s0;
-          part[w - 4][OFF_S + 16 + n] = s1;
-          part[w - 4][OFF_S + 32 + n] = s2;
+          part[w - NP][OFF_S + n] = s0;
+          part[w - NP][OFF_S + 16 + n] = s1;
+          part[w - NP][OFF_S + 32 + n] = s2;
         }
       }
       __syncthreads();
-      if (w < 4) {
+      if (w < NP) {
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -345,7 +405,7 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
         tdbg[8] += c1 - c0;  // cross-wave stage (incl. waiting for the slowest wave)
         c0 = c1;
       }
-      ls_group_sum<GW>(part, res, NV, g);
+      ls_group_sum<GW, NP, LS_TPB>(part, res, NV, g);
       if (DBG && tdbg) tdbg[9] += wall_clock64() - c0;  // publish + poll + sum
     };
 
@@ -624,41 +684,57 @@ __global__ __launch_bounds__(LS_TPB) void k_cg_lockstep(OnchipArgs a) {
     __syncthreads();
     if (t == 0) {
       part[0][0] = (wig == 0) ? (float)(ngroups + atomicAdd(a.next_member, 1)) : 0.f;
-      part[1][0] = 0.f; part[2][0] = 0.f; part[3][0] = 0.f;
+#pragma unroll
+      for (int q = 1; q < NP; ++q) part[q][0] = 0.f;
     }
-    ls_group_sum<GW>(part, res, 1, g);
+    ls_group_sum<GW, NP, LS_TPB>(part, res, 1, g);
     item = (int64_t)res[0];
     __syncthreads();
   }
 }
 
-size_t lockstep_gbuf_bytes(int ngroups, int GW) { return (size_t)ngroups * 2 * GW * LS_NVP * sizeof(unsigned long long); }
+size_t lockstep_gbuf_bytes(int ngroups, int GW) {  // granules + 4096 per-CU arrival counters
+  return (size_t)ngroups * 2 * (GW + 1) * LS_NVP * sizeof(unsigned long long) + 4096 * sizeof(int);
+}
 
 bool lockstep_eligible(int RC, int RK, bool pre, int64_t N, int64_t ncols) {
   const bool rc_ok = (RC == 8 || RC == 16 || RC == 32);
   const bool rk_ok = !pre || (RK == 4 || RK == 8 || RK == 16);
-  return rc_ok && rk_ok && ncols >= 1 && N >= 1024 && N <= 8 * (int64_t)LS_ROWS;
+  return rc_ok && rk_ok && ncols >= 1 && N >= 1024 && N <= 8 * (int64_t)8 * LS_WROWS;
 }
 
-template <int RC, bool PRE, int GW, bool DBG = false>
-static int lockstep_go(const OnchipArgs& a, int nwg, hipStream_t st) {
-  // the spin-waiting groups need ALL workgroups resident: one per CU
+template <int RC, bool PRE, int GW, int NW, bool DBG = false>
+static int lockstep_go(const OnchipArgs& a, int ncu, hipStream_t st) {
+  // the spin-waiting groups need ALL workgroups resident: one (NW = 8) or two (NW = 4) per CU
+  constexpr int per_cu_needed = NW == 4 ? 2 : 1;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_lockstep<RC, PRE, GW, DBG>, LS_TPB, 0) != hipSuccess ||
-      per_cu < 1)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_lockstep<RC, PRE, GW, NW, DBG>, NW * 64, 0) !=
+          hipSuccess ||
+      per_cu < per_cu_needed)
     return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("cg_lockstep", st);
-  hipLaunchKernelGGL((k_cg_lockstep<RC, PRE, GW, DBG>), dim3(nwg), dim3(LS_TPB), 0, st, a);
+  hipLaunchKernelGGL((k_cg_lockstep<RC, PRE, GW, NW, DBG>), dim3(per_cu_needed * ncu), dim3(NW * 64), 0, st, a);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
 }
 
-// nwg = number of CUs used (multiple of 64) = workgroups launched.  a.RK = floats per row of Q (PRE) or 0.
-int lockstep_launch(int RC, bool pre, const OnchipArgs& a, int nwg, hipStream_t st) {
-  if (RC == 32 && pre && a.dbg) return lockstep_go<32, true, 8, true>(a, nwg, st);
-  if (RC == 32) return pre ? lockstep_go<32, true, 8>(a, nwg, st) : lockstep_go<32, false, 8>(a, nwg, st);
-  if (RC == 16 || RC == 8) return pre ? lockstep_go<16, true, 8>(a, nwg, st) : lockstep_go<16, false, 8>(a, nwg, st);
+// 8: one 1024-row workgroup per CU (default).  16 (LO_LS_V2=1, N > 4096): two 512-row workgroups per CU that belong to
+// different members.  Measured equal (3.78 vs 3.83 ms at cfg3): a wave's matrix-core stream is not software-pipelined
+// against its LDS operand reads, so one workgroup alone reaches ~55 % of the matrix rate and the second workgroup's
+// compute phase cannot fill the first one's hand-off wait any better than the second wave per SIMD already does.
+int lockstep_group_size(int64_t N) { return (N > 4096 && getenv("LO_LS_V2")) ? 16 : 8; }
+
+// ncu = number of CUs used (multiple of 64).  a.GW selects the variant (8: one 1024-row workgroup per CU; 16: two
+// 512-row workgroups per CU); a.RK = floats per row of Q (PRE) or 0.  LO_ERR_UNSUPPORTED when the workgroups do not
+// fit (the caller falls back to the other variant / the serial-column kernels).
+int lockstep_launch(int RC, bool pre, const OnchipArgs& a, int ncu, hipStream_t st) {
+  const bool v2 = a.GW == 16;
+#define LO_LS(C_, P_) (v2 ? lockstep_go<C_, P_, 16, 4>(a, ncu, st) : lockstep_go<C_, P_, 8, 8>(a, ncu, st))
+  if (RC == 32 && pre && a.dbg) return v2 ? lockstep_go<32, true, 16, 4, true>(a, ncu, st) : lockstep_go<32, true, 8, 8, true>(a, ncu, st);
+  if (RC == 32) return pre ? LO_LS(32, true) : LO_LS(32, false);
+  if (RC == 16 || RC == 8) return pre ? LO_LS(16, true) : LO_LS(16, false);
+#undef LO_LS
   return LO_ERR_UNSUPPORTED;
 }
 

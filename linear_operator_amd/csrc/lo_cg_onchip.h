@@ -45,5 +45,6 @@ int onchip4_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st)
 int lockstep_launch(int RC, bool pre, const OnchipArgs& a, int nwg, hipStream_t st);
 bool lockstep_eligible(int RC, int RK, bool pre, int64_t N, int64_t ncols);
 size_t lockstep_gbuf_bytes(int ngroups, int GW);
+int lockstep_group_size(int64_t N);
 
 }  // namespace lo

@@ -617,6 +617,28 @@ def test_lockstep_cg_matches_serial_resident_streaming_and_oracle(N, R, c, nt, m
     assert torch.equal(res.x, res2.x) and (not nt or torch.equal(res.t_mat, res2.t_mat))
 
 
+def test_lockstep_two_workgroups_per_cu_variant_matches_default(monkeypatch):
+    """LO_LS_V2: 512-row workgroups, two per CU, groups of 16 with the reduce-scatter all-reduce -- same results as the
+    default variant (different summation order across workgroups: compared to rounding noise) and reproducible."""
+    C, d, rhs = cases.lowrank_diag(5301, 37, 8192, 32, 16)
+    rhs /= np.linalg.norm(rhs, axis=-2, keepdims=True)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    pre = _default_precond(desc, dev(d), False)
+    kw = dict(precond=pre, tolerance=1e-4, n_tridiag=16)
+    ref = K.cg_solve(desc, dev(rhs), **kw)
+    monkeypatch.setenv("LO_LS_V2", "1")
+    K._hip.prof_enable(True)
+    res = K.cg_solve(desc, dev(rhs), **kw)
+    torch.cuda.synchronize()
+    prof = K._hip.prof_report()
+    K._hip.prof_enable(False)
+    res2 = K.cg_solve(desc, dev(rhs), **kw)
+    assert "cg_lockstep" in prof and res.iterations == ref.iterations == 21
+    assert max_rel_err_cols(host(res.x), host(ref.x)) < 2e-5 and res.t_mat.shape == ref.t_mat.shape
+    _assert_tridiag_close(res.t_mat, ref.t_mat, 8192)
+    assert torch.equal(res.x, res2.x) and torch.equal(res.t_mat, res2.t_mat)
+
+
 def test_onchip_cg_many_columns_hand_over():
     """Columns + tridiagonals + a tolerance the guaranteed iterations do not reach: the streaming loop continues from
     the resident kernel's per-column state."""
