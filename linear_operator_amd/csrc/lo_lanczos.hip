@@ -21,6 +21,7 @@ namespace lo {
 struct LzCtrl {
   int need_reorth;  // sum(inner_products > tol) != 0
   int all_small;    // sum(|beta| > 1e-6) == 0
+  int any_big;      // fused path: some |beta| > 1e-6 (all_small = !any_big)
 };
 
 struct LzDev {
@@ -33,6 +34,7 @@ struct LzDev {
   float* part;  // [B, S, (max_iter+1), P]
   float* coef;  // [B, (max_iter+1), P]
   float* scal;  // [B, P]
+  float* dot_part;  // [B, S_dot, P] partials of q_k . (A q_k) from the matvec epilogue (fused path)
   LzCtrl* ctrl;
 };
 
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(kThreads) void k_lz_dot(LzDev d, const float* __res
 // part[b,s,j,p] = sum_rows r o q_j  for j = 0..nq-1 in ONE pass over the rows: a thread keeps one accumulator per
 // previous vector (compile-time bound MAXQ so that the accumulators stay in registers), r is read once.
 constexpr int kLzMaxQ = 24;
+constexpr int kLzFusedQ = 20;  // fused step: basis vectors per pass (max_lanczos_quadrature_iterations = 20 -> nq <= 19)
 
 template <int MAXQ>
 __global__ __launch_bounds__(kThreads) void k_lz_multidot(LzDev d, int nq) {
@@ -384,6 +387,246 @@ __global__ __launch_bounds__(kThreads) void k_lz_sub_prev_dot(LzDev d, int k) {
   if (threadIdx.x < c) d.part[(((size_t)b * d.S + s) * (d.max_iter + 1)) * c + col] = tot;
 }
 
+
+// ---- fused step (P a power of two in 4 .. 64, at most kLzMaxQ basis vectors) ---------------------------------------
+// The step of lanczos.py:108-145 with Q_{<=k} read from HBM TWICE instead of three times and without the separate
+// vector passes: the raw product r = A q_k stays untouched; both passes form
+//     rv = (r - beta_{k-1} q_{k-1}) - alpha_k q_k                      (:108, :116)
+// on the fly from vectors they read anyway.  alpha_k = q_k . (A q_k) - beta_{k-1} (q_{k-1} . q_k) comes from the dot the
+// matvec epilogue fuses and from the orthogonality check of the previous step (:109-111 in exact arithmetic).
+//   pass 1 (k_lz_dots_fused):     c_j = q_j . rv for all j <= k                                      (:118)
+//   pass 2 (k_lz_correct_check):  rv -= sum_j c_j q_j, scaled with the predicted norm and written into q_{k+1}; partials of
+//                                 its squared norm and of the check products q_j . q_{k+1} (:119-131) -- the row's q_j
+//                                 values are still in registers
+//   k_lz_finish:                  beta_k = exact norm, t entries, check products, the two batch-global flags
+template <int MAXQ>
+__global__ __launch_bounds__(kThreads) void k_lz_dots_fused(LzDev d, int k) {
+  __shared__ float red[4][(MAXQ + 1) * 64];
+  const int nq = k + 1;
+  const int s = blockIdx.x;
+  const int64_t b = blockIdx.y;
+  const int c = d.P, c4 = c >> 2, N = (int)d.N;
+  const int nrs = kThreads / c4;
+  const int cq = threadIdx.x % c4, slot = threadIdx.x / c4;
+  const int r0 = s * d.rows, r1 = min(N, r0 + d.rows);
+  const size_t base = (size_t)b * N * c + 4 * cq;
+  const size_t qs = (size_t)d.B * d.N * d.P;
+  const float4 al = *reinterpret_cast<const float4*>(d.scal + (size_t)b * c + 4 * cq);
+  const float4 be = *reinterpret_cast<const float4*>(tptr(d, k, k - 1) + (size_t)b * c + 4 * cq);
+  float4 acc[MAXQ];
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);  // ||rv||^2 (slot nq)
+  for (int row = r0 + slot; row < r1; row += nrs) {
+    const size_t i = base + (size_t)row * c;
+    float4 rv = *reinterpret_cast<const float4*>(d.r + i);
+    const float4 qp = *reinterpret_cast<const float4*>(d.q + (size_t)(k - 1) * qs + i);
+    const float4 qk = *reinterpret_cast<const float4*>(d.q + (size_t)k * qs + i);
+    rv.x = (rv.x - qp.x * be.x) - al.x * qk.x;
+    rv.y = (rv.y - qp.y * be.y) - al.y * qk.y;
+    rv.z = (rv.z - qp.z * be.z) - al.z * qk.z;
+    rv.w = (rv.w - qp.w * be.w) - al.w * qk.w;
+    nn.x = fmaf(rv.x, rv.x, nn.x);
+    nn.y = fmaf(rv.y, rv.y, nn.y);
+    nn.z = fmaf(rv.z, rv.z, nn.z);
+    nn.w = fmaf(rv.w, rv.w, nn.w);
+#pragma unroll
+    for (int j = 0; j < MAXQ; ++j) {
+      if (j < nq) {
+        const float4 qv = *reinterpret_cast<const float4*>(d.q + (size_t)j * qs + i);
+        acc[j].x = fmaf(rv.x, qv.x, acc[j].x);
+        acc[j].y = fmaf(rv.y, qv.y, acc[j].y);
+        acc[j].z = fmaf(rv.z, qv.z, acc[j].z);
+        acc[j].w = fmaf(rv.w, qv.w, acc[j].w);
+      }
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j <= MAXQ; ++j) {
+    if (j <= nq) {
+      const float4 a4 = (j < MAXQ && j < nq) ? acc[j < MAXQ ? j : 0] : nn;
+      float v[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = v[e];
+        if (c4 <= 1) x = bfly_add<1>(x);
+        if (c4 <= 2) x = bfly_add<2>(x);
+        if (c4 <= 4) x = bfly_add<4>(x);
+        if (c4 <= 8) x = bfly_add<8>(x);
+        if (c4 <= 16) x = bfly_add<16>(x);
+        x = bfly_add<32>(x);
+        if (lane < c4) red[wave][j * 64 + 4 * lane + e] = x;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (nq + 1) * c; i += kThreads) {
+    const int j = i / c, p = i % c;
+    const float tot = (red[0][j * 64 + p] + red[1][j * 64 + p]) + (red[2][j * 64 + p] + red[3][j * 64 + p]);
+    d.part[(((size_t)b * d.S + s) * (d.max_iter + 1) + j) * c + p] = tot;
+  }
+}
+
+// coef[b, j, p] = sum_s part (j < nq) and the PREDICTED norm of the corrected vector: with an orthonormal basis
+// ||rv - Q c||^2 = ||rv||^2 - |c|^2 (the c_j are rounding-size: the components along q_k, q_{k-1} were just removed), so
+// pass 2 can write q_{k+1} already scaled by 1 / beta_pred.  The exact norm is measured in pass 2 and corrects beta_k.
+__global__ __launch_bounds__(kThreads) void k_lz_reduce_pred(LzDev d, int nq) {
+  const int64_t b = blockIdx.x;
+  for (int p = threadIdx.x; p < d.P; p += kThreads) {
+    float cc = 0.f, nrm2 = 0.f;
+    for (int j = 0; j <= nq; ++j) {
+      float acc = 0.f;
+      for (int s = 0; s < d.S; ++s) acc += d.part[(((size_t)b * d.S + s) * (d.max_iter + 1) + j) * d.P + p];
+      if (j < nq) {
+        d.coef[((size_t)b * (d.max_iter + 1) + j) * d.P + p] = acc;
+        cc = fmaf(acc, acc, cc);
+      } else {
+        nrm2 = acc;
+      }
+    }
+    d.scal[(size_t)b * d.P + p + (size_t)d.B * d.P] = sqrtf(fmaxf(nrm2 - cc, 1e-30f));  // beta_pred (second half of scal)
+  }
+}
+
+// pass 2: a thread owns TWO probe columns (coefficients, the row's basis values and the check accumulators of MAXQ
+// vectors stay in registers: 3 x 2 x MAXQ).  part[b, s, j] (j < nq) = check products, part[b, s, nq] = ||rv||^2.
+template <int MAXQ>
+__global__ __launch_bounds__(kThreads) void k_lz_correct_check(LzDev d, int k, float* __restrict__ out) {
+  __shared__ float red[4][(MAXQ + 1) * 64];
+  const int nq = k + 1;
+  const int s = blockIdx.x;
+  const int64_t b = blockIdx.y;
+  const int c = d.P, c2 = c >> 1, N = (int)d.N;
+  const int nrs = kThreads / c2;  // c2 = 2 .. 32 (power of two)
+  const int cp = threadIdx.x % c2, slot = threadIdx.x / c2;
+  const int r0 = s * d.rows, r1 = min(N, r0 + d.rows);
+  const size_t base = (size_t)b * N * c + 2 * cp;
+  const size_t qs = (size_t)d.B * d.N * d.P;
+  const float2 al = *reinterpret_cast<const float2*>(d.scal + (size_t)b * c + 2 * cp);
+  const float2 be = *reinterpret_cast<const float2*>(tptr(d, k, k - 1) + (size_t)b * c + 2 * cp);
+  const float2 bp = *reinterpret_cast<const float2*>(d.scal + (size_t)d.B * c + (size_t)b * c + 2 * cp);  // beta_pred
+  const float2 sc = make_float2(1.0f / bp.x, 1.0f / bp.y);
+  float2 cf[MAXQ], chk[MAXQ];
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) {
+    cf[j] = (j < nq) ? *reinterpret_cast<const float2*>(d.coef + ((size_t)b * (d.max_iter + 1) + j) * c + 2 * cp)
+                     : make_float2(0.f, 0.f);
+    chk[j] = make_float2(0.f, 0.f);
+  }
+  float2 rr = make_float2(0.f, 0.f);
+  for (int row = r0 + slot; row < r1; row += nrs) {
+    const size_t i = base + (size_t)row * c;
+    float2 qv[MAXQ];
+#pragma unroll
+    for (int j = 0; j < MAXQ; ++j)
+      qv[j] = (j < nq) ? *reinterpret_cast<const float2*>(d.q + (size_t)j * qs + i) : make_float2(0.f, 0.f);
+    float2 rv = *reinterpret_cast<const float2*>(d.r + i);
+    float2 qp = make_float2(0.f, 0.f), qk = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < MAXQ; ++j) {  // (k is uniform: selects, no divergence)
+      if (j == k - 1) qp = qv[j];
+      if (j == k) qk = qv[j];
+    }
+    rv.x = (rv.x - qp.x * be.x) - al.x * qk.x;
+    rv.y = (rv.y - qp.y * be.y) - al.y * qk.y;
+    float2 corr = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < MAXQ; ++j) {
+      corr.x = fmaf(qv[j].x, cf[j].x, corr.x);
+      corr.y = fmaf(qv[j].y, cf[j].y, corr.y);
+    }
+    rv.x = (rv.x - corr.x) * sc.x;   // (:119-128) corrected and scaled with the predicted norm
+    rv.y = (rv.y - corr.y) * sc.y;
+    *reinterpret_cast<float2*>(out + i) = rv;
+    rr.x = fmaf(rv.x, rv.x, rr.x);
+    rr.y = fmaf(rv.y, rv.y, rr.y);
+#pragma unroll
+    for (int j = 0; j < MAXQ; ++j) {
+      chk[j].x = fmaf(rv.x, qv[j].x, chk[j].x);
+      chk[j].y = fmaf(rv.y, qv[j].y, chk[j].y);
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j <= MAXQ; ++j) {
+    if (j <= nq) {
+      const float2 val = (j < MAXQ && j < nq) ? chk[j < MAXQ ? j : 0] : rr;  // slot nq carries ||rv||^2
+      float v[2] = {val.x, val.y};
+      if (j < nq || j == nq) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float x = v[e];
+          if (c2 <= 1) x = bfly_add<1>(x);
+          if (c2 <= 2) x = bfly_add<2>(x);
+          if (c2 <= 4) x = bfly_add<4>(x);
+          if (c2 <= 8) x = bfly_add<8>(x);
+          if (c2 <= 16) x = bfly_add<16>(x);
+          x = bfly_add<32>(x);
+          if (lane < c2) red[wave][j * 64 + 2 * lane + e] = x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (nq + 1) * c; i += kThreads) {
+    const int j = i / c, p = i % c;
+    const float tot = (red[0][j * 64 + p] + red[1][j * 64 + p]) + (red[2][j * 64 + p] + red[3][j * 64 + p]);
+    d.part[(((size_t)b * d.S + s) * (d.max_iter + 1) + j) * c + p] = tot;
+  }
+}
+
+// alpha_k = sum_s dot_part - beta_{k-1} (q_{k-1} . q_k) -> scal and t[k, k]  (:109-111).  The product q_{k-1} . q_k is
+// the normalised check product j = k-1 of the previous step (coef); no check exists before step 1.
+__global__ __launch_bounds__(kThreads) void k_lz_alpha(LzDev d, int k, const float* __restrict__ dot_part, int S_dot) {
+  const int64_t n = d.B * d.P;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t b = i / d.P;
+    const int p = (int)(i % d.P);
+    float acc = 0.f;
+    for (int s = 0; s < S_dot; ++s) acc += dot_part[((size_t)b * S_dot + s) * d.P + p];
+    if (k > 1) acc -= tptr(d, k, k - 1)[i] * d.coef[((size_t)b * (d.max_iter + 1) + (k - 1)) * d.P + p];
+    d.scal[i] = acc;
+    tptr(d, k, k)[i] = acc;
+  }
+}
+
+// after pass 2: beta_k = sqrt(sum ||rv||^2) -> scal, t[k, k+1], t[k+1, k] (:121-128); normalised check products -> coef,
+// need_reorth if any exceeds tol (signed, :131-134); any_big if some |beta_k| > 1e-6 (:147).  One workgroup per member.
+__global__ __launch_bounds__(kThreads) void k_lz_finish(LzDev d, int k) {
+  __shared__ float beta_s[kMaxCols];
+  __shared__ float red[kThreads];
+  const int nq = k + 1;
+  const int64_t b = blockIdx.x;
+  float big = 0.f, flag = 0.f;
+  for (int p = threadIdx.x; p < d.P; p += kThreads) {
+    float acc = 0.f;
+    for (int s = 0; s < d.S; ++s) acc += d.part[(((size_t)b * d.S + s) * (d.max_iter + 1) + nq) * d.P + p];
+    const float nrm = sqrtf(acc);  // norm of the stored (scaled) vector: 1 up to rounding
+    const float beta = d.scal[(size_t)d.B * d.P + (size_t)b * d.P + p] * nrm;  // the exact ||rv - Q c||
+    beta_s[p] = nrm;
+    d.scal[(size_t)b * d.P + p] = beta;
+    tptr(d, k, k + 1)[(size_t)b * d.P + p] = beta;
+    tptr(d, k + 1, k)[(size_t)b * d.P + p] = beta;
+    if (fabsf(beta) > 1e-6f) big = 1.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nq * d.P; i += kThreads) {
+    const int p = i % d.P, j = i / d.P;
+    float acc = 0.f;
+    for (int s = 0; s < d.S; ++s) acc += d.part[(((size_t)b * d.S + s) * (d.max_iter + 1) + j) * d.P + p];
+    const float v = acc / beta_s[p];  // product with the NORMALISED vector (:131)
+    d.coef[((size_t)b * (d.max_iter + 1) + j) * d.P + p] = v;
+    if (v > d.tol) flag = 1.f;
+  }
+  const float anyflag = block_sum256(flag, red);
+  const float anybig = block_sum256(big, red);
+  if (threadIdx.x == 0) {
+    if (anyflag > 0.f) atomicExch(&d.ctrl->need_reorth, 1);
+    if (anybig > 0.f) atomicExch(&d.ctrl->any_big, 1);
+  }
+}
+
 // q_mat [kstore, B, N, P] (working order, :69-76) -> [P, B, N, k] (returned order, lanczos.py:154): LDS-tiled
 // transpose, reads contiguous along P (and rows), writes contiguous along (row, k).  One workgroup = 32 rows of a member.
 constexpr int kLzTr = 32;
@@ -402,6 +645,31 @@ __global__ __launch_bounds__(kThreads) void k_lz_permute(const float* __restrict
   for (int e = threadIdx.x; e < P * nr * k; e += kThreads) {
     const int p = e / (nr * k), rem = e % (nr * k);  // rem = row * k + j: contiguous in qout
     qout[(((size_t)p * B + b) * N + n0) * k + rem] = tile[((rem % k) * kLzTr + rem / k) * ld + p];
+  }
+}
+
+// the same with 16-byte global accesses (P % 4 == 0 and k % 4 == 0: four consecutive outputs share a row)
+__global__ __launch_bounds__(kThreads) void k_lz_permute4(const float* __restrict__ qin, float* __restrict__ qout,
+                                                           int k, int64_t B, int N, int P) {
+  extern __shared__ float tile[];  // [k][kLzTr][P + 1]
+  const int64_t b = blockIdx.y;
+  const int n0 = blockIdx.x * kLzTr, nr = min(kLzTr, N - n0);
+  const int ld = P + 1;
+  const int nin = nr * P / 4;
+  for (int e = threadIdx.x; e < k * nin; e += kThreads) {
+    const int j = e / nin, rem = 4 * (e % nin);  // rem = row * P + p
+    const float4 v = *reinterpret_cast<const float4*>(qin + (((size_t)j * B + b) * N + n0) * P + rem);
+    float* t = tile + (j * kLzTr + rem / P) * ld + rem % P;
+    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+  }
+  __syncthreads();
+  const int nout = nr * k / 4;
+  for (int e = threadIdx.x; e < P * nout; e += kThreads) {
+    const int p = e / nout, rem = 4 * (e % nout);  // rem = row * k + j, j % 4 == 0
+    const int row = rem / k, j = rem % k;
+    const float* t = tile + (j * kLzTr + row) * ld + p;
+    const float4 v = make_float4(t[0], t[(size_t)kLzTr * ld], t[(size_t)2 * kLzTr * ld], t[(size_t)3 * kLzTr * ld]);
+    *reinterpret_cast<float4*>(qout + (((size_t)p * B + b) * N + n0) * k + rem) = v;
   }
 }
 
@@ -450,7 +718,8 @@ static void lz_layout(const lo_op_desc* op, int64_t P, int max_iter, Arena& ar, 
   d->r = ar.take<float>((size_t)op->B * op->N * P);
   d->part = ar.take<float>((size_t)op->B * sp.S * (max_iter + 1) * P);
   d->coef = ar.take<float>((size_t)op->B * (max_iter + 1) * P);
-  d->scal = ar.take<float>((size_t)op->B * P);
+  d->scal = ar.take<float>((size_t)op->B * P * 2);  // [B, P] scalars of the step | [B, P] predicted norms
+  d->dot_part = ar.take<float>((size_t)op->B * 64 * P);  // matvec dot partials [B, S_dot <= 64, P]
 }
 
 size_t lo_lanczos_workspace_bytes(const lo_op_desc* op, int64_t P, int32_t max_iter) {
@@ -482,8 +751,10 @@ int lo_lanczos_permute_f32(const float* q_in, int32_t k, int64_t B, int64_t N, i
   if (lds > 64 * 1024) return LO_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)((N + kLzTr - 1) / kLzTr), (unsigned)B);
+  const bool v4 = (P % 4 == 0) && (k % 4 == 0) && ((uintptr_t)q_in % 16 == 0) && ((uintptr_t)q_out % 16 == 0);
   LO_PROF_BEGIN("lz_permute", st);
-  hipLaunchKernelGGL(k_lz_permute, grid, dim3(kThreads), lds, st, q_in, q_out, (int)k, B, (int)N, (int)P);
+  if (v4) hipLaunchKernelGGL(k_lz_permute4, grid, dim3(kThreads), lds, st, q_in, q_out, (int)k, B, (int)N, (int)P);
+  else hipLaunchKernelGGL(k_lz_permute, grid, dim3(kThreads), lds, st, q_in, q_out, (int)k, B, (int)N, (int)P);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
@@ -575,7 +846,59 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
     hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 0, d.r, q(1), d.scal);  // q_1 = r / beta_0  (:98)
     LO_PROF_END(st);
     LO_LAUNCH_CHECK();
-    for (k = 1; k < num_iter; ++k) {
+    // fused path: float4 / float2 kernels, all basis vectors of a step in registers, matvec dot partials fit
+    // (kLzFusedQ accumulators keep pass 1 under 128 VGPRs: four waves per SIMD)
+    const bool fused = vec4 && num_iter <= kLzFusedQ + 1 && pl.S_dot <= 64 && !getenv("LO_LZ_UNFUSED");
+    for (k = 1; fused && k < num_iter; ++k) {
+      rc = matvec_run(&pl, q(k), d.r, d.dot_part, nullptr, st);  // r = A q_k (:108) + partials of q_k . r
+      if (rc) return rc;
+      LO_PROF_BEGIN("lz_alpha", st);
+      hipLaunchKernelGGL(k_lz_alpha, dim3((unsigned)std::min<int64_t>((B * P + kThreads - 1) / kThreads, 1024)), block,
+                         0, st, d, k, d.dot_part, pl.S_dot);
+      LO_PROF_END(st);
+      LO_LAUNCH_CHECK();
+      if (k + 1 >= num_iter) continue;  // :114 (the last step only needs alpha)
+      LO_PROF_BEGIN("lz_dots_fused", st);
+      hipLaunchKernelGGL((k_lz_dots_fused<kLzFusedQ>), grid, block, 0, st, d, k);
+      LO_PROF_END(st);
+      LO_PROF_BEGIN("lz_reduce", st);
+      hipLaunchKernelGGL(k_lz_reduce_pred, dim3((unsigned)B), block, 0, st, d, k + 1);
+      LO_PROF_END(st);
+      (void)hipMemsetAsync(d.ctrl, 0, sizeof(LzCtrl), st);
+      LO_PROF_BEGIN("lz_correct_check", st);
+      hipLaunchKernelGGL((k_lz_correct_check<kLzFusedQ>), grid, block, 0, st, d, k, q(k + 1));
+      LO_PROF_END(st);
+      LO_PROF_BEGIN("lz_finish", st);
+      hipLaunchKernelGGL(k_lz_finish, dim3((unsigned)B), block, 0, st, d, k);
+      LO_PROF_END(st);
+      LO_LAUNCH_CHECK();  // (q_{k+1} is stored normalised by pass 2: no separate normalisation pass)
+      LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(LzCtrl), hipMemcpyDeviceToHost, st));
+      LO_HIP_CHECK(hipStreamSynchronize(st));
+      const int all_small = h.any_big ? 0 : 1;
+      LzDev dn = d;
+      dn.r = q(k + 1);
+      bool could = false;
+      for (int it = 0; it < 10; ++it) {  // :133-142 (rare: one Gram-Schmidt pass normally suffices)
+        if (!h.need_reorth) {
+          could = true;
+          break;
+        }
+        correct(dn, k + 1);  // uses the normalised check products as coefficients
+        LO_PROF_BEGIN("lz_scal", st);
+        hipLaunchKernelGGL(k_lz_scal, one, block, 0, st, d, 0, -1, -1, 0, 0);
+        LO_PROF_END(st);
+        LO_PROF_BEGIN("lz_axpy", st);
+        hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 0, dn.r, dn.r, d.scal);
+        LO_PROF_END(st);
+        multidot(dn, k + 1);
+        reduce(dn, k + 1, 1);
+        LO_LAUNCH_CHECK();
+        LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(LzCtrl), hipMemcpyDeviceToHost, st));
+        LO_HIP_CHECK(hipStreamSynchronize(st));
+      }
+      if (all_small || !could) break;  // :147
+    }
+    for (; !fused && k < num_iter; ++k) {
       rc = matvec_run(&pl, q(k), d.r, nullptr, nullptr, st);  // :108
       if (rc) return rc;
       LO_PROF_BEGIN("lz_sub_prev_dot", st);
