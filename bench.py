@@ -51,9 +51,11 @@ def make_problem(device, seed):
     return Cm, d, rhs
 
 
-def build_precond(desc, d):
-    L, _ = K.pivoted_cholesky(desc, RANK_K, contiguous=False)  # [B, m, N] rows read in place by the build
-    return K.precond_build(L, d, constant_diag=False)
+def build_precond(desc, d, need_q=True):
+    """Rank-15 pivoted-Cholesky preconditioner of the low-rank operator, in the generic (Q, 1/d) form of the reference's
+    cache and in root form (F = M (I + M^T E M)^-1 M^T: what the operator-resident CG kernels use)."""
+    L, perm = K.pivoted_cholesky(desc, RANK_K, contiguous=False)  # [B, m, N] rows read in place by the build
+    return K.precond_build(L, d, constant_diag=False, root=desc.A0, perm=perm, need_q=need_q)
 
 
 def algorithmic_bytes(name, k_eff):
@@ -67,8 +69,9 @@ def algorithmic_bytes(name, k_eff):
         return 4 * B * (N * r + N + 2 * N * c)  # stream A once + diagonal + vector in + vector out
     if name == "cg_onchip":
         # operator-resident CG: ONE launch runs all guaranteed iterations and reads the operator ONCE.  Compulsory
-        # bytes per launch: C, Q, d, 1/d, the right-hand side in and the solution out
-        return 4 * B * N * (R + k_eff + 2 + 2 * c)
+        # bytes per launch with the root-form preconditioner (no second tall matrix): C, d, 1/d, the right-hand side in
+        # and the solution out, plus the two R x R matrices per member
+        return 4 * B * (N * (R + 2 + 2 * c) + 2 * R * R)
     if name == "cg_update_xr":
         return 4 * B * N * c * 6  # r, Ap, x, p read; r, x written
     if name == "cg_update_p":
@@ -467,7 +470,7 @@ def main():
     t1 = time.perf_counter()
     reps = 3
     for _ in range(reps):
-        p2 = build_precond(desc, d)
+        p2 = build_precond(desc, d, need_q=False)  # (the resident kernel needs the root form only)
         K.cg_solve(desc, rhs, precond=p2, tolerance=TOL)
     fence()
     e2e = (time.perf_counter() - t1) / reps
@@ -556,9 +559,10 @@ def main():
                          "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                          "triad_this_box": triad_gbs,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6, "launches_timed": cnt,
-                         "note": ("per-launch compulsory bytes (C, Q, d, 1/d, rhs in, x out; the kernel keeps the operator "
-                                  "on chip for all 11 iterations) / launch time.  The kernel is bound by the latency of "
-                                  "its per-iteration group all-reduce, not by HBM") if dom == "cg_onchip" else ""},
+                         "note": ("per-launch compulsory bytes (C, d, 1/d, rhs in, x out, root-form preconditioner "
+                                  "matrices; the kernel keeps the operator on chip for all 11 iterations) / launch time.  "
+                                  "The kernel is bound by VALU issue and the latency of its per-iteration group "
+                                  "all-reduce, not by HBM") if dom == "cg_onchip" else ""},
             "equivalent_streaming_rate": equiv,
             "matvec_equivalent": {"algorithmic_bytes": mv_alg, "avg_us": mv_s * 1e6,
                                   "equivalent_GBs": mv_alg / mv_s / 1e9, "north_star_budget_us": 122.0, "note": mv_note},

@@ -90,6 +90,16 @@ typedef struct lo_precond_desc {
   const float* Q;        /* [B, N, ldq]  (_q_cache; for constant diag it carries the 1/sqrt(sigma)  *
                           * factor so that z = r*dinv - Q (Q^T r) in both cases)                    */
   const float* dinv;     /* reciprocal noise                                                       */
+  /* Optional ROOT FORM of the same preconditioner (lo_precond_root_form_f32), valid when the operator is
+   * LO_OP_LOWRANK_DIAG and the factor L is the pivoted Cholesky factor of ITS root C: every column of L lies in the
+   * column space of C (L = C M), hence  P^-1 r = (r - C F (C^T (r o dinv))) o dinv  with the R x R matrix
+   * F = M (I + M^T E M)^-1 M^T, E = C^T D^-1 C.  The operator-resident CG kernels then need no second tall matrix and
+   * one group all-reduce per iteration.  NULL = not available (Q is used).                                        */
+  const float* F;        /* [B, rf_ld, rf_ld], zero padded, symmetric                               */
+  const float* EF;       /* [B, rf_ld, rf_ld] = E F                                                 */
+  const float* E;        /* [B, rf_ld, rf_ld] = C^T D^-1 C                                          */
+  int32_t rf_ld;         /* row stride of F / EF / E = padded root rank (8, 16 or 32); 0 = absent   */
+  int32_t reserved2;
 } lo_precond_desc;
 
 /* Batch-sharded solves (one process per GPU, SURVEY.md section 8(e) "option A"): the reference's stopping rule is the
@@ -198,6 +208,17 @@ int lo_precond_build_f32(const float* L, const float* d, int32_t diag_mode, int6
 int lo_precond_build_strided_f32(const float* L, int64_t ld_member, int64_t ld_row, int64_t ld_col, const float* d,
                                  int32_t diag_mode, int64_t B, int64_t N, int32_t k, float* Q, float* dinv,
                                  float* logdet_p, void* ws, size_t ws_bytes, void* stream);
+/* Root form of the pivoted-Cholesky preconditioner of a low-rank operator (see lo_precond_desc): from the root
+ * C [B, N, R] (R <= 32), the diagonal, the factor L (strided like lo_precond_build_strided_f32, k columns = pivots
+ * taken) and the permutation of lo_pivoted_cholesky_f32 (first k entries = pivots) computes, in fp64,
+ *   E = C^T D^-1 C,  M (L = C M: the recurrence of _pivoted_cholesky.py:77-92 on the pivot rows),
+ *   F = M (I + M^T E M)^-1 M^T,  EF,  logdet P = logdet(I + M^T E M) + sum log d  (== the value of the Q form)
+ * and writes F, EF, E as fp32 [B, rf_ld, rf_ld] (rf_ld = 8, 16 or 32 >= R), dinv ([B, N] FULL / [B] CONST), logdet_p [B]. */
+size_t lo_precond_root_form_workspace_bytes(int64_t B, int64_t N, int32_t R);
+int lo_precond_root_form_f32(const float* C, int32_t R, const float* d, int32_t diag_mode, const float* L,
+                             int64_t ld_member, int64_t ld_row, int64_t ld_col, const int64_t* perm, int64_t B,
+                             int64_t N, int32_t k, int32_t rf_ld, float* F, float* EF, float* E, float* dinv,
+                             float* logdet_p, void* ws, size_t ws_bytes, void* stream);
 /* z = P^{-1} r  (precondition_closure, added_diag_linear_operator.py:135-140) */
 size_t lo_precond_apply_workspace_bytes(int64_t B, int64_t N, int32_t k, int64_t c);
 int lo_precond_apply_f32(const lo_precond_desc* pre, const float* r, float* z, int64_t B, int64_t N, int64_t c, void* ws,

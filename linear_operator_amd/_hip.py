@@ -32,6 +32,7 @@ EXPORTS = [
     "lo_pivoted_cholesky_cb_workspace_bytes", "lo_pivoted_cholesky_cb_f32",
     "lo_precond_build_workspace_bytes", "lo_precond_build_f32", "lo_precond_build_strided_f32",
     "lo_precond_apply_workspace_bytes", "lo_precond_apply_f32",
+    "lo_precond_root_form_workspace_bytes", "lo_precond_root_form_f32",
     "lo_lanczos_workspace_bytes", "lo_lanczos_tridiag_f32", "lo_lanczos_permute_f32",
     "lo_root_from_lanczos_f32",
     "lo_tridiag_eigh_slq_workspace_bytes", "lo_tridiag_eigh_slq_f32",
@@ -60,7 +61,8 @@ OpDesc._fields_ = [("kind", C.c_int32), ("diag_mode", C.c_int32), ("B", C.c_int6
 
 class PrecondDesc(C.Structure):
     _fields_ = [("k", C.c_int32), ("ldq", C.c_int32), ("constant_diag", C.c_int32), ("reserved", C.c_int32),
-                ("Q", C.c_void_p), ("dinv", C.c_void_p)]
+                ("Q", C.c_void_p), ("dinv", C.c_void_p), ("F", C.c_void_p), ("EF", C.c_void_p), ("E", C.c_void_p),
+                ("rf_ld", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class CgParams(C.Structure):
@@ -150,6 +152,13 @@ def load():
     lib.lo_precond_build_strided_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32,
                                                  C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, sz, C.c_void_p]
+    lib.lo_precond_root_form_workspace_bytes.restype = sz
+    lib.lo_precond_root_form_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
+    lib.lo_precond_root_form_f32.restype = C.c_int
+    lib.lo_precond_root_form_f32.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                             C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                             C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, sz, C.c_void_p]
     lib.lo_precond_apply_workspace_bytes.restype = sz
     lib.lo_precond_apply_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int64]
     lib.lo_precond_apply_f32.restype = C.c_int

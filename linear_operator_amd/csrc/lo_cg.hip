@@ -465,7 +465,7 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
     const int R4 = padded_rank_k(pre->k);
     float* up = ar.take<float>((size_t)B * sp.S * R4 * c);
     if (upart) *upart = up;
-    if (pre->ldq != R4) {
+    if (pre->Q && pre->ldq != R4) {
       float* qp = ar.take<float>((size_t)B * N * R4);
       if (init && ar.ok && ws) {
         if (pre->ldq != pre->k) { if (rc_out) *rc_out = LO_ERR_BADARG; }
@@ -525,7 +525,8 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   if (prm->n_tridiag < 0 || prm->n_tridiag > prm->c) return LO_ERR_BADARG;
   if (prm->n_tridiag && !t_mat) return LO_ERR_BADARG;
   if (pre && precond_cb) return LO_ERR_BADARG;
-  if (pre && (pre->k < 1 || pre->k > kMaxRank || !pre->Q || !pre->dinv)) return LO_ERR_BADARG;
+  const bool pre_root = pre && pre->F && pre->EF && pre->rf_ld > 0;  // root form of the preconditioner available
+  if (pre && (pre->k < 1 || pre->k > kMaxRank || !pre->dinv || (!pre->Q && !pre_root))) return LO_ERR_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int64_t B = op->B, N = op->N;
   const int c = (int)prm->c;
@@ -614,7 +615,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
                        (prm->n_tridiag == 0 || d.oc_ab != nullptr) && B < (1 << 24) - 1024;
   // column split: full chunks of 16 (and a last chunk of at least kLockstepMinCols) -> lockstep kernel, the rest serial
   int ls_cols = 0;
-  if (oc_base && d.ls_gbuf && !getenv("LO_OC_NO_LOCKSTEP") &&
+  if (oc_base && d.ls_gbuf && !getenv("LO_OC_NO_LOCKSTEP") && (!pre || pre->Q) &&
       lockstep_eligible(pl.R4, pre ? preR4 : 0, pre != nullptr, N, c)) {
     const int full = (c / 16) * 16, rem = c - full;
     ls_cols = full + (rem >= kLockstepMinCols ? rem : 0);
@@ -629,7 +630,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.C = pl.Apad; a.d = op->d;
     a.d_mode = op->diag_mode;
     if (oc_nopre) {
-      if (ls_cols < c) {
+      if (ls_cols < c && (getenv("LO_OC_GEN2") || !onchip5_eligible(pl.R4, N, c - ls_cols))) {  // (second generation only)
         LO_HIP_CHECK(hipMemsetAsync(d.oc_zero_q, 0, sizeof(float) * (size_t)B * N * 4, st));
         LO_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)d.oc_ones, 0x3f800000, (size_t)B, st));  // 1.0f
       }
@@ -640,6 +641,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.rhs = rhs; a.B = B; a.N = (int)N;
     a.c = c; a.ab_rec = prm->n_tridiag ? d.oc_ab : nullptr;
     a.col0 = 0; a.ncols = c; a.RK = pre ? preR4 : 0; a.RCg = pl.R4;
+    a.F = nullptr; a.EF = nullptr;
     a.iters = kfloor0 + 1;
     a.eps = prm->eps; a.stop_after = prm->stop_updating_after;
     a.x = d.x; a.r = d.r; a.p = d.p; a.z = d.z;
@@ -678,7 +680,25 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
         rc = (oc_gen1_ok || onchip4_eligible(pl.R4, ocR4, N, c)) ? LO_OK : LO_ERR_UNSUPPORTED;
       }
     }
-    if (rc == LO_OK && ls_cols < c) {  // second (first) generation: columns [ls_cols, c)
+    bool serial_done = false;
+    if (rc == LO_OK && ls_cols < c && !getenv("LO_OC_GEN2") && onchip5_eligible(pl.R4, N, c - ls_cols) &&
+        (oc_nopre || (pre_root && pre->rf_ld == pl.R4))) {
+      // root-form serial-column kernel (one all-reduce per iteration): columns [ls_cols, c)
+      a.GW = onchip4_group_size(N);
+      a.RW = (int)((N + a.GW - 1) / a.GW);
+      a.col0 = ls_cols; a.ncols = c - ls_cols;
+      a.xout = x;
+      a.F = oc_nopre ? nullptr : pre->F;
+      a.EF = oc_nopre ? nullptr : pre->EF;
+      a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
+      a.dbg = oc_dbg ? d.oc_dbg : nullptr;
+      LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(64), st));
+      rc = onchip5_launch(pl.R4, a, oc_nwg, st);
+      if (rc == LO_OK) serial_done = true;
+      else if (rc == LO_ERR_UNSUPPORTED) rc = LO_OK;  // (does not fit: the Q-form kernels below)
+    }
+    if (rc == LO_OK && ls_cols < c && !serial_done && pre && !pre->Q) rc = LO_ERR_UNSUPPORTED;  // (root form only)
+    if (rc == LO_OK && ls_cols < c && !serial_done) {  // second (first) generation: columns [ls_cols, c)
       const bool gen2 = onchip4_eligible(pl.R4, ocR4, N, c - ls_cols) && !(getenv("LO_OC_GEN1") && oc_gen1_ok);
       a.GW = gen2 ? onchip4_group_size(N) : 8;
       a.RW = (int)((N + a.GW - 1) / a.GW);
@@ -738,6 +758,9 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       }
     }
   }
+  // a root-form-only preconditioner cannot feed the streaming engine (initial run, redo after a timeout, or the
+  // continuation beyond the resident iterations): the caller builds the Q form and calls again
+  if (pre && !pre->Q && (k_start == 0 || !h.stop)) return LO_ERR_UNSUPPORTED;
   int matvecs = 0;
   if (k_start == 0) {
     // ---- initialisation (linear_cg.py:177-215) ----

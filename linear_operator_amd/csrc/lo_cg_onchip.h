@@ -17,6 +17,8 @@ struct OnchipArgs {
   int col0, ncols;    // columns [col0, col0 + ncols) are solved by this launch (second / third generation)
   int RK;             // floats per row of Q (third generation; the others take it as a template parameter)
   int RCg;            // floats per row of C in HBM (third generation: 8, 16 or 32)
+  const float* F;     // root-form preconditioner (lo_precond_desc.F / EF), [B, RC, RC] each, or nullptr
+  const float* EF;
   float* ab_rec;      // [iters, B, c, 2] masked alpha / beta per iteration (second generation, n_tridiag > 0) or nullptr
   int64_t B;
   int N, RW;          // rows per workgroup
@@ -41,6 +43,9 @@ struct OnchipArgs {
 
 int onchip_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st);
 int onchip4_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st);
+// root-form serial-column kernel (k_cg_onchip5, lo_cg_onchip4.hip): one all-reduce per iteration
+int onchip5_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st);
+bool onchip5_eligible(int RC, int64_t N, int64_t c);
 // third generation (lo_cg_lockstep.hip): 16 columns of a member advance together on the matrix cores
 int lockstep_launch(int RC, bool pre, const OnchipArgs& a, int nwg, hipStream_t st);
 bool lockstep_eligible(int RC, int RK, bool pre, int64_t N, int64_t ncols);

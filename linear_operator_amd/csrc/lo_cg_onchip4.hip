@@ -511,4 +511,320 @@ int onchip4_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st)
   return LO_ERR_UNSUPPORTED;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Third generation of the serial-column kernel: ROOT-FORM preconditioner (lo_precond_desc.F / EF) and ONE group
+// all-reduce per iteration.  With P^-1 r = (r - C F w) / d, w = C^T (r / d), the iteration needs no second tall matrix:
+// the reduction delivers w (RC values), s1 = sum r^2, s2 = sum r^2 / d, rp = sum r o p_old, and the first wave derives
+//     v = F w,  E v = (E F) w,  r.z = s2 - w.v,  C^T p_new = (w - E v) + beta C^T p_old,
+//     sum d p_new^2 = (s2 - 2 w.v + v.E v) + 2 beta (rp - v . C^T p_old) + beta^2 sum d p_old^2,   p.Ap = |C^T p|^2 + sum d p^2
+// (tools/proto_root_form.py) from two RC x RC matrices in LDS before the others leave the all-reduce.  Per row the work
+// is three passes over the thread's C rows in VGPRs (z = (r - C v) / d, A p = C t + d p, the partials of w): the same
+// 12 RC FMAs per row as before, half the hand-offs.  Without a preconditioner F = 0: v = 0, z = r / 1.
+struct alignas(16) R5Post {
+  float v[32];
+  float t[32];
+  float alpha, beta, rn, pad;
+};
+
+template <int RC, int GW, bool MC>
+__global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipArgs a) {
+  constexpr int FLD = RC + 4;  // LDS row stride of F / EF (16-byte aligned rows, conflict-free float4 reads per lane)
+  __shared__ R4Shared sh;
+  __shared__ R5Post post;
+  __shared__ __attribute__((aligned(16))) float f_s[RC * FLD];
+  __shared__ __attribute__((aligned(16))) float ef_s[RC * FLD];
+  __shared__ float x_s[R4_ROWS], d_s[R4_ROWS], dinv_s[R4_ROWS];
+  const int wg = blockIdx.x;
+  const int xcd = wg % 8, jx = wg / 8;
+  const int groups_per_xcd = (gridDim.x / 8) / GW;
+  const int grp = xcd * groups_per_xcd + jx / GW;
+  const int wig = jx % GW;
+  const int ngroups = groups_per_xcd * 8;
+  if (jx / GW >= groups_per_xcd) return;
+  const int t = threadIdx.x, lane = t & 63;
+  R4Group g;
+  g.gslot = a.gbuf + (size_t)grp * 2 * GW * R4_SLOT;
+  g.wig = wig;
+  g.dbg = nullptr;
+  g.tag = 0;
+  g.err = a.err;
+  g.same_xcd = false;
+  {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
+    if (t < 64) {
+      sh.red[0][0] = (float)xcc;
+      sh.red[0][1] = (float)(xcc * xcc);
+    }
+    if (t < 2 * (R4_WAVES - 1)) sh.red[1 + t / 2][t % 2] = 0.f;
+    r4_group_sum<GW>(sh, 2, g);
+    const float fx = (float)xcc;
+    g.same_xcd = (sh.res[0] == GW * fx) && (sh.res[1] == GW * fx * fx) && (a.allow_l2_handoff != 0);
+    __syncthreads();
+  }
+  const int row0 = wig * a.RW;
+  const int nv = max(0, min(a.RW, a.N - row0));
+  const bool pre = a.F != nullptr;
+  int64_t b = grp;
+  while (b < a.B) {
+    const bool stamp = a.dbg && b == a.dbg_member && wig == 0 && t == 0;
+    if (stamp) a.dbg[0] = wall_clock64();
+    float Cr[R4_NR][RC];
+    int tl = t;
+    asm volatile("" : "+v"(tl));
+#pragma unroll
+    for (int q = 0; q < R4_NR; ++q) {
+      const int lr = tl + R4_TPB * q;
+      const size_t grow = (size_t)b * a.N + row0 + lr;
+      float dq = 0.f, diq = 0.f;
+      if (lr < nv) {
+        const float4* cp = reinterpret_cast<const float4*>(a.C + grow * RC);
+#pragma unroll
+        for (int i = 0; i < RC / 4; ++i) {
+          const float4 c4 = cp[i];
+          Cr[q][4 * i] = c4.x; Cr[q][4 * i + 1] = c4.y; Cr[q][4 * i + 2] = c4.z; Cr[q][4 * i + 3] = c4.w;
+        }
+        dq = (a.d_mode == LO_DIAG_FULL) ? a.d[grow] : (a.d_mode == LO_DIAG_CONST ? a.d[b] : 0.f);
+        diq = pre ? ((a.dinv_mode == LO_DIAG_FULL) ? a.dinv[grow] : a.dinv[b]) : 1.0f;
+      } else {
+#pragma unroll
+        for (int i = 0; i < RC; ++i) Cr[q][i] = 0.f;
+      }
+      d_s[lr] = dq;
+      dinv_s[lr] = diq;
+    }
+    for (int e = tl; e < RC * RC; e += R4_TPB) {  // F, EF -> LDS (zero without a preconditioner)
+      const int i = e / RC, j = e % RC;
+      f_s[i * FLD + j] = pre ? a.F[((size_t)b * RC + i) * RC + j] : 0.f;
+      ef_s[i * FLD + j] = pre ? a.EF[((size_t)b * RC + i) * RC + j] : 0.f;
+    }
+    __syncthreads();
+    if (stamp) a.dbg[1] = wall_clock64();
+
+    const int nc = MC ? a.c : 1;
+    const int cfirst = MC ? a.col0 : 0, clast = MC ? a.col0 + a.ncols : 1;
+    for (int col = cfirst; col < clast; ++col) {
+      const size_t bc = (size_t)b * nc + col;
+      float r[R4_NR], p[R4_NR];
+      float sc[3];
+      sc[0] = 0.f;
+      int tc = t;
+      asm volatile("" : "+v"(tc));
+#pragma unroll
+      for (int q = 0; q < R4_NR; ++q) {
+        const int lr = tc + R4_TPB * q;
+        r[q] = (lr < nv) ? a.rhs[((size_t)b * a.N + row0 + lr) * nc + col] : 0.f;
+        p[q] = 0.f;
+        x_s[lr] = 0.f;
+        sc[0] = fmaf(r[q], r[q], sc[0]);
+      }
+      r4_allreduce_scalars<GW>(sh, sc, 1, g);
+      float nrm = sqrtf(sh.res[0]);                          // rhs.norm(2, dim=-2)          :177
+      const bool rhs_zero = nrm < a.eps;                     // :178
+      if (rhs_zero) nrm = 1.0f;                              // :179
+#pragma unroll
+      for (int q = 0; q < R4_NR; ++q) r[q] = r[q] / nrm;     // :182
+      // first-wave state of the recurrences (uniform scalars replicated in the lanes; t_old = C^T p_old in lane j < RC)
+      float t_old = 0.f, dpp = 0.f, rz = 0.f, alpha = 0.f, beta = 0.f, rn = 0.f;
+      bool conv = false;
+      // one reduction: w = C^T (r / d), s1, s2, rp; then (first wave) the small algebra; k = -1 marks the initial one
+      auto reduce_and_post = [&](int k) {
+        sc[0] = 0.f; sc[1] = 0.f; sc[2] = 0.f;
+        float rd[R4_NR];
+#pragma unroll
+        for (int q = 0; q < R4_NR; ++q) {
+          const int lr = t + R4_TPB * q;
+          rd[q] = r[q] * dinv_s[lr];
+          sc[0] = fmaf(r[q], r[q], sc[0]);
+          if (pre) {
+            sc[1] = fmaf(rd[q], r[q], sc[1]);
+            sc[2] = fmaf(r[q], p[q], sc[2]);
+          } else {  // z = r: the "d" of the recurrences is the operator's diagonal itself
+            const float dr = d_s[lr] * r[q];
+            sc[1] = fmaf(dr, r[q], sc[1]);
+            sc[2] = fmaf(dr, p[q], sc[2]);
+          }
+        }
+        r4_allreduce<GW, RC>(
+            sh,
+            [&](int c) {
+              float v = Cr[0][c] * rd[0];
+#pragma unroll
+              for (int q = 1; q < R4_NR; ++q) v = fmaf(Cr[q][c], rd[q], v);
+              return v;
+            },
+            sc, 3, g);
+        if (t < 64) {  // ---- first wave: v, E v, scalars, t, alpha (sh.res holds w | s1 | s2 | rp) ----
+          const int j = lane & 31;
+          float mv = 0.f;  // lanes 0-31: (F w)_j, lanes 32-63: (E F w)_j
+          if (pre && j < RC) {
+            const float* row = (lane < 32 ? f_s : ef_s) + j * FLD;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int q = 0; q < RC; q += 4) {
+              const float4 m4 = *reinterpret_cast<const float4*>(row + q);
+              const float4 w4 = *reinterpret_cast<const float4*>(&sh.res[q]);
+              a0 = fmaf(m4.x, w4.x, a0); a1 = fmaf(m4.y, w4.y, a1); a2 = fmaf(m4.z, w4.z, a2); a3 = fmaf(m4.w, w4.w, a3);
+            }
+            mv = (a0 + a1) + (a2 + a3);
+          }
+          const float other = __shfl_xor(mv, 32, 64);
+          const float vj = lane < 32 ? mv : other, evj = lane < 32 ? other : mv;   // both halves hold (v_j, (E v)_j)
+          const float wj = (j < RC) ? sh.res[j] : 0.f;
+          const bool own = lane < 32 && j < RC;
+          const float s1 = sh.res[RC], s2 = sh.res[RC + 1], rp = sh.res[RC + 2];
+          const float wv = wave_sum_fast(own ? wj * vj : 0.f);
+          const float vev = wave_sum_fast(own ? vj * evj : 0.f);
+          const float vt = wave_sum_fast(own ? vj * t_old : 0.f);
+          const float rzn = pre ? s2 - wv : s1;              // residual_inner_prod :215 / :35-36
+          if (k >= 0) {                                      // closes iteration k: beta, residual norm, records
+            beta = (rz < a.eps) ? 0.f : rzn / rz;            // :39-42
+            rn = sqrtf(s1);                                  // :298
+            if (rhs_zero) rn = 0.f;                          // :299
+            if (wig == 0 && t == 0) {
+              a.resid_rec[(size_t)k * a.B * nc + bc] = rn;
+              if (MC && a.ab_rec) {
+                a.ab_rec[2 * ((size_t)k * a.B * nc + bc)] = alpha;
+                a.ab_rec[2 * ((size_t)k * a.B * nc + bc) + 1] = beta;
+              }
+            }
+            conv = rn < a.stop_after;                        // :300
+          } else {
+            beta = 0.f;
+            conv = sqrtf(s1) < a.stop_after;                 // :204-205
+            rn = sqrtf(s1);
+            if (wig == 0 && t == 0) a.init_conv[bc] = conv ? 1 : 0;
+          }
+          rz = rzn;
+          const float dzz = pre ? fmaf(-2.f, wv, s2) + vev : s2;
+          const float dzp = rp - vt;
+          dpp = fmaf(beta, fmaf(beta, dpp, 2.f * dzp), dzz);
+          t_old = fmaf(beta, t_old, wj - evj);               // C^T p_new (lanes j < RC of both halves)
+          const float tt = wave_sum_fast(own ? t_old * t_old : 0.f);
+          const float pAp = tt + dpp;
+          alpha = (pAp < a.eps) ? 0.f : rz / pAp;            // :254-257
+          if (conv) alpha = 0.f;                             // :260
+          if (own) {
+            post.v[j] = vj;
+            post.t[j] = t_old;
+          }
+          if (t == 0) {
+            post.alpha = alpha;
+            post.beta = beta;
+            post.rn = rn;
+          }
+        }
+        __syncthreads();
+      };
+      reduce_and_post(-1);
+      if (stamp && col == cfirst) {
+        a.dbg[2] = wall_clock64();
+        g.dbg = a.dbg;
+      }
+      float last_alpha = 0.f;
+      for (int k = 0; k < a.iters; ++k) {
+        const float al = post.alpha, be = post.beta;
+        last_alpha = al;
+        // p = beta p + (r - C v) / d  (:268, :46);  x += alpha p (:31);  r -= alpha (C t + d p) (:264)
+        float cv[R4_NR], y[R4_NR];
+#pragma unroll
+        for (int q = 0; q < R4_NR; ++q) { cv[q] = 0.f; y[q] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < RC; i += 4) {
+          const float4 v4 = *reinterpret_cast<const float4*>(&post.v[i]);
+          const float4 t4 = *reinterpret_cast<const float4*>(&post.t[i]);
+#pragma unroll
+          for (int q = 0; q < R4_NR; ++q) {
+            cv[q] = fmaf(Cr[q][i], v4.x, cv[q]);
+            cv[q] = fmaf(Cr[q][i + 1], v4.y, cv[q]);
+            cv[q] = fmaf(Cr[q][i + 2], v4.z, cv[q]);
+            cv[q] = fmaf(Cr[q][i + 3], v4.w, cv[q]);
+            y[q] = fmaf(Cr[q][i], t4.x, y[q]);
+            y[q] = fmaf(Cr[q][i + 1], t4.y, y[q]);
+            y[q] = fmaf(Cr[q][i + 2], t4.z, y[q]);
+            y[q] = fmaf(Cr[q][i + 3], t4.w, y[q]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < R4_NR; ++q) {
+          const int lr = t + R4_TPB * q;
+          p[q] = fmaf(be, p[q], (r[q] - cv[q]) * dinv_s[lr]);
+          x_s[lr] = fmaf(al, p[q], x_s[lr]);
+          r[q] = fmaf(-al, fmaf(d_s[lr], p[q], y[q]), r[q]);
+        }
+        __syncthreads();  // (post is rewritten by the next reduction's first wave)
+        reduce_and_post(k);
+      }
+      if (stamp && col == cfirst) a.dbg[3] = wall_clock64();
+      g.dbg = nullptr;
+      // ---- write the state back in the streaming engine's layout (z = (r - C v) / d from the last reduction) ----
+      int tw = t;
+      asm volatile("" : "+v"(tw));
+#pragma unroll
+      for (int q = 0; q < R4_NR; ++q) {
+        if (tw + R4_TPB * q < nv) {
+          const size_t o = ((size_t)b * a.N + row0 + tw + R4_TPB * q) * nc + col;
+          const int lr = t + R4_TPB * q;
+          a.x[o] = x_s[lr];
+          if (a.xout) a.xout[o] = x_s[lr] * nrm;             // :335
+          a.r[o] = r[q];
+          a.p[o] = p[q];
+          if (a.z) {
+            float cvq = 0.f;
+#pragma unroll
+            for (int i = 0; i < RC; ++i) cvq = fmaf(Cr[q][i], post.v[i], cvq);
+            a.z[o] = (r[q] - cvq) * dinv_s[lr];
+          }
+        }
+      }
+      if (wig == 0 && t == 0) {  // (thread 0 is a first-wave lane: its copies of the scalars are the current ones)
+        a.rhs_norm[bc] = nrm;
+        a.rhs_is_zero[bc] = rhs_zero ? 1 : 0;
+        a.rz[bc] = rz;
+        a.alpha[bc] = last_alpha;
+        a.beta[bc] = beta;
+        a.resid_norm[bc] = rn;
+        a.has_conv[bc] = conv ? 1 : 0;
+      }
+      __syncthreads();
+    }  // columns
+    if (stamp) a.dbg[4] = wall_clock64();
+    if (t < R4_WAVES) sh.red[t][0] = 0.f;
+    __syncthreads();
+    if (wig == 0 && t == 0) sh.red[0][0] = (float)(ngroups + atomicAdd(a.next_member, 1));
+    r4_group_sum<GW>(sh, 1, g);
+    b = (int64_t)sh.res[0];
+    __syncthreads();
+  }
+}
+
+bool onchip5_eligible(int RC, int64_t N, int64_t c) {
+  return (RC == 8 || RC == 16 || RC == 32) && c >= 1 && c <= 64 && N >= 1024 && N <= (int64_t)R4_MAXGW * R4_ROWS;
+}
+
+template <int RC, int GW, bool MC>
+static int onchip5_go(const OnchipArgs& a, int nwg, hipStream_t st) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_onchip5<RC, GW, MC>, R4_TPB, 0) != hipSuccess ||
+      per_cu < 2)
+    return LO_ERR_UNSUPPORTED;
+  LO_PROF_BEGIN("cg_onchip", st);
+  hipLaunchKernelGGL((k_cg_onchip5<RC, GW, MC>), dim3(2 * nwg), dim3(R4_TPB), 0, st, a);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+// a.F / a.EF [B, RC, RC] (or nullptr: no preconditioner).  Same launch geometry as onchip4_launch.
+int onchip5_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st) {
+  const bool mc = a.c > 1 || a.ab_rec != nullptr;
+#define LO_O5_G(C_, G_) (mc ? onchip5_go<C_, G_, true>(a, nwg, st) : onchip5_go<C_, G_, false>(a, nwg, st))
+#define LO_O5(C_) return a.GW == 8 ? LO_O5_G(C_, 8) : (a.GW == 16 ? LO_O5_G(C_, 16) : LO_O5_G(C_, 32))
+  if (RC == 32) LO_O5(32);
+  else if (RC == 16) LO_O5(16);
+  else if (RC == 8) LO_O5(8);
+#undef LO_O5
+#undef LO_O5_G
+  return LO_ERR_UNSUPPORTED;
+}
+
 }  // namespace lo

@@ -485,6 +485,115 @@ static int padded_k(int k) {
   return 4 * p;
 }
 
+// ---- root form (see lo_amd.h: lo_precond_desc.F / EF / E) ------------------------------------------------------------
+// One wave per member, fp64 in LDS: E from the Gram partials of W = C / sqrt(d) (or C^T C / sigma), the recurrence for
+// M on the pivot rows, G = I + M^T E M, its Cholesky factor, F = M G^-1 M^T = (M Lg^-T)(M Lg^-T)^T, EF, logdet.
+__global__ __launch_bounds__(64) void k_pb_rootform(const double* __restrict__ gpart, const double* __restrict__ logd_part,
+                                                     const float* __restrict__ C, int R, const float* __restrict__ dd,
+                                                     int diag_mode, const float* __restrict__ L, LStride ls,
+                                                     const long long* __restrict__ perm, int N, int k, int S, int ld,
+                                                     float* __restrict__ F, float* __restrict__ EF,
+                                                     float* __restrict__ Eo, float* __restrict__ logdet,
+                                                     float* __restrict__ dinv_const) {
+  __shared__ double E[kPbMaxK][kPbMaxK + 1];
+  __shared__ double M[kPbMaxK][kPbMaxK + 1];   // [R][k]
+  __shared__ double T[kPbMaxK][kPbMaxK + 1];   // scratch: E M, then Y = M Lg^-T
+  __shared__ double G[kPbMaxK][kPbMaxK + 1];
+  __shared__ double Fm[kPbMaxK][kPbMaxK + 1];
+  const int64_t b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const double sigma = (diag_mode == LO_DIAG_CONST) ? (double)dd[b] : 1.0;
+  for (int pr = lane; pr < R * R; pr += 64) {
+    double t = 0.0;
+    for (int s = 0; s < S; ++s) t += gpart[((size_t)b * S + s) * R * R + pr];
+    E[pr / R][pr % R] = t / sigma;  // (FULL: the rows were scaled by 1/sqrt(d); CONST: C^T C / sigma)
+  }
+  // M[:, j] = (C[pi_j, :]^T - sum_{i<j} M[:, i] L[pi_j, i]) / L[pi_j, j]
+  const float* Cb = C + (size_t)b * N * R;
+  const float* Lb = L + (size_t)b * ls.member;
+  for (int j = 0; j < k; ++j) {
+    const long long pj = perm[(size_t)b * N + j];
+    __syncthreads();
+    if (lane < R) {
+      double col = (double)Cb[(size_t)pj * R + lane];
+      for (int i = 0; i < j; ++i) col -= M[lane][i] * (double)Lb[(size_t)pj * ls.row + (size_t)i * ls.col];
+      M[lane][j] = col / (double)Lb[(size_t)pj * ls.row + (size_t)j * ls.col];
+    }
+  }
+  __syncthreads();
+  for (int pr = lane; pr < R * k; pr += 64) {  // T = E M  [R][k]
+    const int a = pr / k, j = pr % k;
+    double t = 0.0;
+    for (int c2 = 0; c2 < R; ++c2) t += E[a][c2] * M[c2][j];
+    T[a][j] = t;
+  }
+  __syncthreads();
+  for (int pr = lane; pr < k * k; pr += 64) {  // G = I + M^T T
+    const int i = pr / k, j = pr % k;
+    double t = (i == j) ? 1.0 : 0.0;
+    for (int a = 0; a < R; ++a) t += M[a][i] * T[a][j];
+    G[i][j] = t;
+  }
+  __syncthreads();
+  for (int j = 0; j < k; ++j) {  // right-looking Cholesky, lower factor in G's lower triangle
+    if (lane == 0) G[j][j] = sqrt(G[j][j]);
+    __syncthreads();
+    const double dj = G[j][j];
+    for (int i = j + 1 + lane; i < k; i += 64) G[i][j] /= dj;
+    __syncthreads();
+    for (int e = lane; e < (k - j - 1) * (k - j - 1); e += 64) {
+      const int i = j + 1 + e / (k - j - 1), c2 = j + 1 + e % (k - j - 1);
+      if (c2 <= i) G[i][c2] -= G[i][j] * G[c2][j];
+    }
+    __syncthreads();
+  }
+  // Y = M Lg^-T: row a of Y solves Lg y = M[a, :]^T (forward substitution), one lane per row
+  if (lane < R) {
+    for (int j = 0; j < k; ++j) {
+      double t = M[lane][j];
+      for (int i = 0; i < j; ++i) t -= G[j][i] * T[lane][i];
+      T[lane][j] = t / G[j][j];
+    }
+  }
+  __syncthreads();
+  for (int pr = lane; pr < R * R; pr += 64) {  // F = Y Y^T
+    const int a = pr / R, c2 = pr % R;
+    double t = 0.0;
+    for (int j = 0; j < k; ++j) t += T[a][j] * T[c2][j];
+    Fm[a][c2] = t;
+  }
+  __syncthreads();
+  float* Fb = F + (size_t)b * ld * ld;
+  float* EFb = EF + (size_t)b * ld * ld;
+  float* Eb = Eo + (size_t)b * ld * ld;
+  for (int pr = lane; pr < ld * ld; pr += 64) {
+    const int a = pr / ld, c2 = pr % ld;
+    double f = 0.0, ef = 0.0, e = 0.0;
+    if (a < R && c2 < R) {
+      f = Fm[a][c2];
+      e = E[a][c2];
+      for (int q = 0; q < R; ++q) ef += E[a][q] * Fm[q][c2];
+    }
+    Fb[pr] = (float)f;
+    EFb[pr] = (float)ef;
+    Eb[pr] = (float)e;
+  }
+  if (lane == 0) {
+    double ldt = 0.0;
+    for (int j = 0; j < k; ++j) ldt += log(fabs(G[j][j]));
+    ldt *= 2.0;
+    if (diag_mode == LO_DIAG_CONST) {
+      ldt += (double)N * log(sigma);
+      dinv_const[b] = (float)(1.0 / sigma);
+    } else {
+      double t = 0.0;
+      for (int s = 0; s < S; ++s) t += logd_part[b * S + s];
+      ldt += t;
+    }
+    logdet[b] = (float)ldt;
+  }
+}
+
 }  // namespace lo
 
 using namespace lo;
@@ -567,6 +676,51 @@ int lo_precond_build_strided_f32(const float* L, int64_t ld_member, int64_t ld_r
     hipLaunchKernelGGL((k_pb_q<16>), grid, block, 0, st, L, ls, d, diag_mode, (int)N, (int)k, ldq, sp.rows, Minv, Q, dinv);
   else
     hipLaunchKernelGGL((k_pb_q<32>), grid, block, 0, st, L, ls, d, diag_mode, (int)N, (int)k, ldq, sp.rows, Minv, Q, dinv);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+size_t lo_precond_root_form_workspace_bytes(int64_t B, int64_t N, int32_t R) {
+  Split sp = choose_split(B, N, 256);
+  Arena ar(nullptr, 0);
+  ar.take<double>((size_t)B * sp.S * R * R);
+  ar.take<double>((size_t)B * sp.S);
+  ar.take<float>((size_t)B * N);
+  return ar.off + 1024;
+}
+
+int lo_precond_root_form_f32(const float* C, int32_t R, const float* d, int32_t diag_mode, const float* L,
+                             int64_t ld_member, int64_t ld_row, int64_t ld_col, const int64_t* perm, int64_t B,
+                             int64_t N, int32_t k, int32_t rf_ld, float* F, float* EF, float* E, float* dinv,
+                             float* logdet_p, void* ws, size_t ws_bytes, void* stream) {
+  if (!C || !d || !L || !perm || !F || !EF || !E || !dinv || !logdet_p || !ws) return LO_ERR_BADARG;
+  if (diag_mode != LO_DIAG_FULL && diag_mode != LO_DIAG_CONST) return LO_ERR_BADARG;
+  if (R < 1 || R > kPbMaxK || k < 1 || k > kPbMaxK || rf_ld < R || rf_ld > kPbMaxK) return LO_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  Split sp = choose_split(B, N, 256);
+  Arena ar(ws, ws_bytes);
+  double* gpart = ar.take<double>((size_t)B * sp.S * R * R);
+  double* logd = ar.take<double>((size_t)B * sp.S);
+  float* scale = ar.take<float>((size_t)B * N);
+  if (!ar.ok) return LO_ERR_WORKSPACE;
+  dim3 grid(sp.S, (unsigned)B), block(kThreads);
+  const float* sc = nullptr;
+  if (diag_mode == LO_DIAG_FULL) {
+    LO_PROF_BEGIN("pb_scale", st);
+    hipLaunchKernelGGL(k_pb_scale, grid, block, 0, st, d, (int)N, sp.rows, scale, dinv, logd);
+    LO_PROF_END(st);
+    sc = scale;
+  }
+  const LStride cs{N * (int64_t)R, (int64_t)R, 1};
+  LO_PROF_BEGIN("pb_gram_root", st);  // E partials = W^T W, W = C / sqrt(d), fp64 matrix cores
+  if (R <= 16) hipLaunchKernelGGL((k_pb_gram_mfma_nk<1>), grid, block, 0, st, C, cs, sc, (int)N, (int)R, sp.rows, gpart);
+  else hipLaunchKernelGGL((k_pb_gram_mfma_nk<2>), grid, block, 0, st, C, cs, sc, (int)N, (int)R, sp.rows, gpart);
+  LO_PROF_END(st);
+  const LStride ls{ld_member, ld_row, ld_col};
+  LO_PROF_BEGIN("pb_rootform", st);
+  hipLaunchKernelGGL(k_pb_rootform, dim3((unsigned)B), dim3(64), 0, st, gpart, logd, C, (int)R, d, diag_mode, L, ls,
+                     (const long long*)perm, (int)N, (int)k, sp.S, (int)rf_ld, F, EF, E, logdet_p, dinv);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;

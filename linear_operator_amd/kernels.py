@@ -141,16 +141,38 @@ def matvec(desc: OperatorDescriptor, v: torch.Tensor) -> torch.Tensor:
 class WoodburyPreconditioner:
     """Device form of the reference's cached (Q, noise) pair, added_diag_linear_operator.py:63-70."""
 
-    Q: torch.Tensor  # [B, N, ldq]
+    Q: Optional[torch.Tensor]  # [B, N, ldq]; None for a root-form-only preconditioner (built on demand: ensure_q)
     dinv: torch.Tensor  # [B, N] or [B]
     k: int
     constant_diag: bool
     logdet: Optional[torch.Tensor] = None  # [B]
+    # root form (lo_precond_desc.F / EF / E): P^-1 r = (r - C F C^T (r o dinv)) o dinv for a low-rank operator whose
+    # pivoted-Cholesky factor this preconditioner was built from; [B, rf_ld, rf_ld] each
+    F: Optional[torch.Tensor] = None
+    EF: Optional[torch.Tensor] = None
+    E: Optional[torch.Tensor] = None
+    source: Optional[tuple] = None  # (L, d) the preconditioner was built from (to build Q later)
+
+    @property
+    def rf_ld(self) -> int:
+        return 0 if self.F is None else int(self.F.shape[-1])
+
+    def ensure_q(self) -> "WoodburyPreconditioner":
+        """Build the generic (Q, dinv) form if this preconditioner only carries the root form."""
+        if self.Q is None:
+            L, d = self.source
+            full = precond_build(L, d, self.constant_diag)
+            self.Q, self.dinv = full.Q, full.dinv
+        return self
 
     def c_struct(self) -> _hip.PrecondDesc:
         s = _hip.PrecondDesc()
-        s.k, s.ldq, s.constant_diag, s.reserved = self.k, self.Q.shape[-1], int(self.constant_diag), 0
-        s.Q, s.dinv = self.Q.data_ptr(), self.dinv.data_ptr()
+        s.k, s.constant_diag, s.reserved = self.k, int(self.constant_diag), 0
+        s.ldq = padded_rank(self.k) if self.Q is None else self.Q.shape[-1]
+        s.Q = None if self.Q is None else self.Q.data_ptr()
+        s.dinv = self.dinv.data_ptr()
+        if self.F is not None:
+            s.F, s.EF, s.E, s.rf_ld = self.F.data_ptr(), self.EF.data_ptr(), self.E.data_ptr(), self.rf_ld
         return s
 
 
@@ -320,6 +342,14 @@ def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optio
                              ws.numel(), C.byref(info), _hip.stream_ptr(dev))
     for e in (mv_err + pc_err + sr_err):
         raise e
+    if rc == _hip.LO_ERR_UNSUPPORTED and precond is not None and precond.Q is None:
+        # root-form-only preconditioner and the operator-resident kernels could not take the solve (shape outside
+        # their range, or a group hand-off timed out): build the generic Q form and run again
+        precond.ensure_q()
+        return cg_solve(desc, rhs, x0=x0, precond=precond, matvec_closure=matvec_closure,
+                        precond_closure=precond_closure, closure_batch_shape=closure_batch_shape, n_tridiag=n_tridiag,
+                        max_iter=max_iter, max_tridiag_iter=max_tridiag_iter, tolerance=tolerance, eps=eps,
+                        stop_updating_after=stop_updating_after, floor_max_iter=floor_max_iter, stop_reduce=stop_reduce)
     _hip.check(rc, "lo_cg_solve_f32")
     if t_mat is not None:
         m = info.last_tridiag_iter + 1
@@ -335,7 +365,7 @@ def precond_apply(pre: WoodburyPreconditioner, r: torch.Tensor) -> torch.Tensor:
     r3 = _flat(r, 2)
     B = r3.shape[0]
     z = torch.empty_like(r3)
-    s = pre.c_struct()
+    s = pre.ensure_q().c_struct()
     ws = _hip.workspace(lib.lo_precond_apply_workspace_bytes(B, N, pre.k, c), r.device)
     _hip.check(lib.lo_precond_apply_f32(C.byref(s), _hip.ptr(r3), _hip.ptr(z), B, N, c, _hip.ptr(ws), ws.numel(),
                                         _hip.stream_ptr(r.device)), "lo_precond_apply_f32")
@@ -410,6 +440,34 @@ def pivoted_cholesky_generic(diag: torch.Tensor, row_fetch: Callable, rank: int,
     return L.reshape(*bs, N, m.value), perm.reshape(*bs, N)
 
 
+def _root_form(lib, root, perm, L3, d, constant_diag, B, N, k, dev) -> WoodburyPreconditioner:
+    R = root.shape[-1]
+    C3 = _flat(root, 2)
+    p2 = _flat(perm, 1)
+    ld = padded_rank(R)
+    F = torch.empty(B, ld, ld, dtype=torch.float32, device=dev)
+    EF = torch.empty_like(F)
+    E = torch.empty_like(F)
+    if constant_diag:
+        d2 = d.contiguous().reshape(-1)
+        dinv = torch.empty(B, dtype=torch.float32, device=dev)
+        mode = _hip.LO_DIAG_CONST
+    else:
+        d2 = _flat(d, 1)
+        dinv = torch.empty(B, N, dtype=torch.float32, device=dev)
+        mode = _hip.LO_DIAG_FULL
+    logdet = torch.empty(B, dtype=torch.float32, device=dev)
+    ws = _hip.workspace(lib.lo_precond_root_form_workspace_bytes(B, N, R), dev)
+    sm, sr, sc = L3.stride()
+    if B == 1:
+        sm = 0
+    _hip.check(lib.lo_precond_root_form_f32(_hip.ptr(C3), R, _hip.ptr(d2), mode, _hip.ptr(L3), sm, sr, sc, _hip.ptr(p2),
+                                            B, N, k, ld, _hip.ptr(F), _hip.ptr(EF), _hip.ptr(E), _hip.ptr(dinv),
+                                            _hip.ptr(logdet), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)),
+               "lo_precond_root_form_f32")
+    return WoodburyPreconditioner(None, dinv, k, constant_diag, logdet, F, EF, E)
+
+
 def padded_rank(k: int) -> int:
     rq, p = (k + 3) // 4, 1
     while p < rq:
@@ -417,9 +475,13 @@ def padded_rank(k: int) -> int:
     return 4 * p
 
 
-def precond_build(L: torch.Tensor, d: torch.Tensor, constant_diag: bool) -> WoodburyPreconditioner:
+def precond_build(L: torch.Tensor, d: torch.Tensor, constant_diag: bool, root: Optional[torch.Tensor] = None,
+                  perm: Optional[torch.Tensor] = None, need_q: bool = True) -> WoodburyPreconditioner:
     """lo_precond_build_f32: AddedDiagLinearOperator._init_cache* (added_diag_linear_operator.py:144-184).
-    L [*batch, N, k]; d [*batch, N] (or [*batch] when constant_diag)."""
+    L [*batch, N, k]; d [*batch, N] (or [*batch] when constant_diag).
+    root, perm: the root C [*batch, N, R <= 32] of the low-rank operator L was factored from and the permutation
+    pivoted_cholesky returned -- adds the ROOT FORM (lo_precond_root_form_f32) the operator-resident CG kernels
+    prefer (one all-reduce per iteration, no second tall matrix); need_q=False then skips the generic Q."""
     lib = _hip.load()
     _hip.require_hip(L, d)
     N, k = L.shape[-2:]
@@ -428,6 +490,14 @@ def precond_build(L: torch.Tensor, d: torch.Tensor, constant_diag: bool) -> Wood
         L3 = L3.contiguous()
     B = L3.shape[0]
     dev = L.device
+    if root is not None and perm is not None and root.shape[-1] <= 32 and k >= 1:
+        rf = _root_form(lib, root, perm, L3, d, constant_diag, B, N, k, dev)
+        rf.source = (L, d)
+        if not need_q:
+            return rf
+        full = precond_build(L, d, constant_diag)
+        full.F, full.EF, full.E, full.source = rf.F, rf.EF, rf.E, rf.source
+        return full
     ldq = padded_rank(k)
     Q = torch.empty(B, N, ldq, dtype=torch.float32, device=dev)
     if constant_diag:

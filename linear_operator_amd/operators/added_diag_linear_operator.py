@@ -197,7 +197,15 @@ class AddedDiagLinearOperator(SumLinearOperator):
         if not (L.is_cuda and L.dtype == torch.float32):
             raise K._hip.HipExtensionError("the preconditioner cache is built by liblo_amd: fp32 HIP tensors only")
         d_arg = first[..., 0].contiguous() if self._constant_diag else noise.contiguous()
-        self._woodbury = K.precond_build(L, d_arg.to(torch.float32), self._constant_diag)
+        # for a low-rank root the kernels also get the root form of the preconditioner (F = M (I + M^T E M)^-1 M^T with
+        # L = C M): the operator-resident CG then needs one all-reduce per iteration and no second tall matrix
+        root = self._linear_op._dense_root() if isinstance(self._linear_op, RootLinearOperator) else None
+        perm = getattr(self, "_piv_chol_perm", None)
+        if root is not None and perm is not None and root.is_cuda and root.dtype == torch.float32 and root.shape[-1] <= 32:
+            root = root.detach().expand(*batch_shape, *root.shape[-2:])
+            self._woodbury = K.precond_build(L, d_arg.to(torch.float32), self._constant_diag, root=root, perm=perm)
+        else:
+            self._woodbury = K.precond_build(L, d_arg.to(torch.float32), self._constant_diag)
         self._q_cache = self._woodbury.Q[..., : self._woodbury.k].reshape(*batch_shape, n, self._woodbury.k)
         logdet = self._woodbury.logdet
         self._precond_logdet_cache = logdet.view(*batch_shape) if len(batch_shape) else logdet.squeeze()  # :172,:184

@@ -281,8 +281,12 @@ def test_preconditioner_build_apply():
 
 
 # ------------------------------------------------------------------------------------------- solve / inv_quad_logdet
-def _default_precond(desc, d_t, const):
-    L, _ = K.pivoted_cholesky(desc, 15)
+def _default_precond(desc, d_t, const, root_form=True):
+    """Rank-15 pivoted-Cholesky preconditioner.  For low-rank operators also in ROOT FORM (what the resident kernels
+    prefer); the generic Q form is always built as well (the streaming engine and precond_apply use it)."""
+    L, perm = K.pivoted_cholesky(desc, 15)
+    if root_form and desc.kind == K._hip.LO_OP_LOWRANK_DIAG and desc.R <= 32:
+        return K.precond_build(L, d_t, constant_diag=const, root=desc.A0, perm=perm)
     return K.precond_build(L, d_t, constant_diag=const)
 
 
@@ -637,6 +641,68 @@ def test_lockstep_two_workgroups_per_cu_variant_matches_default(monkeypatch):
     assert max_rel_err_cols(host(res.x), host(ref.x)) < 2e-5 and res.t_mat.shape == ref.t_mat.shape
     _assert_tridiag_close(res.t_mat, ref.t_mat, 8192)
     assert torch.equal(res.x, res2.x) and torch.equal(res.t_mat, res2.t_mat)
+
+
+@pytest.mark.parametrize("N,R,c,nt,const", [(8192, 32, 1, 0, False), (4096, 16, 3, 2, False), (5000, 20, 2, 0, True),
+                                            (20000, 32, 1, 0, False), (2048, 8, 1, 1, True)])
+def test_root_form_preconditioner_and_serial_kernel(N, R, c, nt, const, monkeypatch):
+    """The root form of the pivoted-Cholesky preconditioner (P^-1 r = (r - C F C^T (r/d)) / d, lo_precond_root_form_f32)
+    is the same operator as the Q form (same logdet, same apply), and the serial-column resident kernel built on it (one
+    all-reduce per iteration) gives the iterations / solutions / tridiagonals of the Q-form kernel and of the streaming
+    engine.  A root-form-ONLY preconditioner (no Q) works whenever the resident kernel takes the solve and rebuilds Q
+    on demand otherwise."""
+    B = 37
+    C, d, rhs = cases.lowrank_diag(5400 + R, B, N, R, c)
+    if const:
+        d = np.repeat(d[:, :1], N, axis=1)
+    if nt:
+        rhs[..., :nt] /= np.linalg.norm(rhs[..., :nt], axis=-2, keepdims=True)
+    d_t = dev(d[:, 0]) if const else dev(d)
+    desc = K.lowrank_diag_descriptor(dev(C), d_t, const_diag=const)
+    L, perm = K.pivoted_cholesky(desc, 15)
+    pre_q = K.precond_build(L, d_t, const)
+    pre_r = K.precond_build(L, d_t, const, root=desc.A0, perm=perm)
+    assert pre_r.F is not None and pre_r.Q is not None and pre_r.rf_ld == K.padded_rank(R)
+    assert np.allclose(host(pre_r.logdet), host(pre_q.logdet), rtol=2e-6)
+    # the two forms are the same operator: apply the root form by hand
+    v = dev(rhs)
+    dinv = pre_r.dinv.unsqueeze(-1) if not const else pre_r.dinv.reshape(B, 1, 1)
+    Cp = torch.nn.functional.pad(dev(C), (0, pre_r.rf_ld - R))
+    z_root = (v - Cp @ (pre_r.F @ (Cp.mT @ (v * dinv)))) * dinv
+    assert max_rel_err_cols(host(z_root), host(K.precond_apply(pre_q, v))) < 5e-6
+    assert torch.allclose(pre_r.EF, pre_r.E @ pre_r.F, rtol=1e-4, atol=1e-6)
+    kw = dict(tolerance=1e-4, n_tridiag=nt)
+    try:
+        K.set_onchip_cg(False)
+        ref = K.cg_solve(desc, v, precond=pre_q, **kw)
+    finally:
+        K.set_onchip_cg(True)
+    monkeypatch.setenv("LO_OC_GEN2", "1")
+    res_q = K.cg_solve(desc, v, precond=pre_r, **kw)        # Q-form resident kernel
+    monkeypatch.delenv("LO_OC_GEN2")
+    K._hip.prof_enable(True)
+    res_r = K.cg_solve(desc, v, precond=pre_r, **kw)        # root-form resident kernel
+    torch.cuda.synchronize()
+    prof = K._hip.prof_report()
+    K._hip.prof_enable(False)
+    assert "cg_onchip" in prof and not any(k.startswith("skinny_") for k in prof)
+    assert res_r.iterations == res_q.iterations == ref.iterations == (21 if nt else 11) and res_r.tolerance_reached
+    assert max_rel_err_cols(host(res_r.x), host(ref.x)) < 3e-5 and max_rel_err_cols(host(res_r.x), host(res_q.x)) < 3e-5
+    if nt:
+        assert res_r.t_mat.shape == ref.t_mat.shape
+        _assert_tridiag_close(res_r.t_mat, ref.t_mat, N)
+    assert torch.equal(res_r.x, K.cg_solve(desc, v, precond=pre_r, **kw).x)  # reproducible
+    # root form only
+    pre_o = K.precond_build(L, d_t, const, root=desc.A0, perm=perm, need_q=False)
+    assert pre_o.Q is None
+    res_o = K.cg_solve(desc, v, precond=pre_o, **kw)
+    assert torch.equal(res_o.x, res_r.x) and pre_o.Q is None
+    try:  # ... and when the resident kernels are off the Q form is built on demand
+        K.set_onchip_cg(False)
+        res_f = K.cg_solve(desc, v, precond=pre_o, **kw)
+    finally:
+        K.set_onchip_cg(True)
+    assert pre_o.Q is not None and max_rel_err_cols(host(res_f.x), host(ref.x)) < 1e-6
 
 
 def test_onchip_cg_many_columns_hand_over():

@@ -10,8 +10,8 @@ Cm = torch.randn(B, N, R, generator=g, device=dev) / R ** 0.5
 d = torch.rand(B, N, generator=g, device=dev) + 0.5
 rhs = torch.randn(B, N, 1, generator=g, device=dev)
 desc = K.lowrank_diag_descriptor(Cm, d)
-L, _ = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15, contiguous=False)
-pre = K.precond_build(L, d, False)
+L, perm = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15, contiguous=False)
+pre = K.precond_build(L, d, False, root=Cm, perm=perm)  # Q form + root form
 ref = K.cg_solve(desc, rhs, precond=pre, tolerance=1e-4).x.clone()
 torch.cuda.synchronize()
 side = torch.cuda.Stream()

@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_fullsize.py -q -m gpu -k cfg5 2>&1 | tail -15
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -q -m gpu > gpurun_out/t_all.log 2>&1
+tail -12 gpurun_out/t_all.log

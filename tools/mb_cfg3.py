@@ -9,8 +9,8 @@ Cm = torch.randn(B, N, R, generator=g, device=dev) / R ** 0.5
 d = torch.rand(B, N, generator=g, device=dev) + 0.5
 full = torch.randn(B, N, 17, generator=g, device=dev); full[..., :16] /= full[..., :16].norm(dim=-2, keepdim=True)
 desc = K.lowrank_diag_descriptor(Cm, d)
-L, _ = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15, contiguous=False)
-pre = K.precond_build(L, d, False)
+L, perm = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15, contiguous=False)
+pre = K.precond_build(L, d, False, root=Cm, perm=perm)  # Q form + root form
 def run():
     return K.cg_solve(desc, full, precond=pre, n_tridiag=16, tolerance=1e-4)
 for on in (True, False):

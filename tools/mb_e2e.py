@@ -10,8 +10,8 @@ d = torch.rand(B, N, generator=g, device="cuda") + 0.5
 rhs = torch.randn(B, N, 1, generator=g, device="cuda")
 desc = K.lowrank_diag_descriptor(Cm, d)
 def e2e():
-    L, _ = K.pivoted_cholesky(desc, 15, contiguous=False)
-    pre = K.precond_build(L, d, False)
+    L, perm = K.pivoted_cholesky(desc, 15, contiguous=False)
+    pre = K.precond_build(L, d, False, root=Cm, perm=perm, need_q=False)  # root form only (what the resident CG needs)
     return K.cg_solve(desc, rhs, precond=pre, tolerance=1e-4)
 for _ in range(3): e2e()
 torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -11,8 +11,8 @@ Cm = torch.randn(B, N, R, generator=g, device=dev) / R ** 0.5
 d = torch.rand(B, N, generator=g, device=dev) + 0.5
 full = torch.randn(B, N, c, generator=g, device=dev); full /= full.norm(dim=-2, keepdim=True)
 desc = K.lowrank_diag_descriptor(Cm, d)
-L, _ = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15, contiguous=False)
-pre = K.precond_build(L, d, False)
+L, perm = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15, contiguous=False)
+pre = K.precond_build(L, d, False, root=Cm, perm=perm)  # Q form + root form
 nt = min(c, 16)
 def run():
     return K.cg_solve(desc, full, precond=pre, n_tridiag=nt, tolerance=1e-4)
