@@ -743,8 +743,11 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
                 ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5], ts[6], ts[7], ts[8], ts[9]);
       }
       if (oc_dbg) {
-        long long ts[10];
+        long long ts[12];
         LO_HIP_CHECK(hipMemcpy(ts, d.oc_dbg, sizeof(ts), hipMemcpyDeviceToHost));
+        if (ts[8] || ts[9])
+          fprintf(stderr, "  root-form kernel phases: updates %lld, w partials + all-reduce %lld, first-wave algebra %lld\n",
+                  ts[8], ts[9], ts[10]);
         fprintf(stderr, "onchip member0 (100 MHz ticks): load %lld init %lld iters %lld store %lld | wg-wait %lld publish %lld poll %lld\n",
                 ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5], ts[6], ts[7]);
       }

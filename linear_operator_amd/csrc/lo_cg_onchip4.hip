@@ -530,7 +530,7 @@ template <int RC, int GW, bool MC>
 __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipArgs a) {
   constexpr int FLD = RC + 4;  // LDS row stride of F / EF (16-byte aligned rows, conflict-free float4 reads per lane)
   __shared__ R4Shared sh;
-  __shared__ R5Post post;
+  __shared__ R5Post post[R4_WAVES];
   __shared__ __attribute__((aligned(16))) float f_s[RC * FLD];
   __shared__ __attribute__((aligned(16))) float ef_s[RC * FLD];
   __shared__ float x_s[R4_ROWS], d_s[R4_ROWS], dinv_s[R4_ROWS];
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
 #pragma unroll
       for (int q = 0; q < R4_NR; ++q) r[q] = r[q] / nrm;     // :182
       // first-wave state of the recurrences (uniform scalars replicated in the lanes; t_old = C^T p_old in lane j < RC)
-      float t_old = 0.f, dpp = 0.f, rz = 0.f, alpha = 0.f, beta = 0.f, rn = 0.f;
+      float t_old = 0.f, tt_old = 0.f, dpp = 0.f, rz = 0.f, alpha = 0.f, beta = 0.f, rn = 0.f;
       bool conv = false;
       // one reduction: w = C^T (r / d), s1, s2, rp; then (first wave) the small algebra; k = -1 marks the initial one
       auto reduce_and_post = [&](int k) {
@@ -644,6 +644,8 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
             sc[2] = fmaf(dr, p[q], sc[2]);
           }
         }
+        long long cr0 = 0;
+        if (g.dbg && t == 0) cr0 = wall_clock64();
         r4_allreduce<GW, RC>(
             sh,
             [&](int c) {
@@ -653,7 +655,10 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
               return v;
             },
             sc, 3, g);
-        if (t < 64) {  // ---- first wave: v, E v, scalars, t, alpha (sh.res holds w | s1 | s2 | rp) ----
+        if (g.dbg && t == 0) g.dbg[9] += wall_clock64() - cr0;  // partials of w + reduce-scatter + group all-reduce
+        long long cp0 = 0;
+        if (g.dbg && t == 0) cp0 = wall_clock64();
+        {  // ---- the small algebra, redundantly in every wave (no further barrier): sh.res holds w | s1 | s2 | rp ----
           const int j = lane & 31;
           float mv = 0.f;  // lanes 0-31: (F w)_j, lanes 32-63: (E F w)_j
           if (pre && j < RC) {
@@ -667,19 +672,27 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
             }
             mv = (a0 + a1) + (a2 + a3);
           }
-          const float other = __shfl_xor(mv, 32, 64);
-          const float vj = lane < 32 ? mv : other, evj = lane < 32 ? other : mv;   // both halves hold (v_j, (E v)_j)
+          // v_permlane32_swap of a value with itself: first result = the lower-half lane's value in both halves,
+          // second = the upper-half lane's: every lane gets (v_j, (E v)_j) with one instruction
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mv), __float_as_uint(mv), false, false);
+          const float vj = __uint_as_float(sw[0]), evj = __uint_as_float(sw[1]);
           const float wj = (j < RC) ? sh.res[j] : 0.f;
           const bool own = lane < 32 && j < RC;
           const float s1 = sh.res[RC], s2 = sh.res[RC + 1], rp = sh.res[RC + 2];
+          const float zj = wj - evj;                          // (C^T z)_j
+          // five independent sums (their butterflies interleave); |C^T p_new|^2 from the expansion so that it does not
+          // wait for beta: |zc + beta t|^2 = |zc|^2 + 2 beta zc.t + beta^2 |t|^2
           const float wv = wave_sum_fast(own ? wj * vj : 0.f);
           const float vev = wave_sum_fast(own ? vj * evj : 0.f);
           const float vt = wave_sum_fast(own ? vj * t_old : 0.f);
+          const float zz = wave_sum_fast(own ? zj * zj : 0.f);
+          const float zt = wave_sum_fast(own ? zj * t_old : 0.f);
           const float rzn = pre ? s2 - wv : s1;              // residual_inner_prod :215 / :35-36
+          float rnn = __builtin_amdgcn_sqrtf(s1);            // :298 / :204
           if (k >= 0) {                                      // closes iteration k: beta, residual norm, records
-            beta = (rz < a.eps) ? 0.f : rzn / rz;            // :39-42
-            rn = sqrtf(s1);                                  // :298
-            if (rhs_zero) rn = 0.f;                          // :299
+            beta = (rz < a.eps) ? 0.f : rzn * __builtin_amdgcn_rcpf(rz);  // :39-42
+            if (rhs_zero) rnn = 0.f;                         // :299
+            rn = rnn;
             if (wig == 0 && t == 0) {
               a.resid_rec[(size_t)k * a.B * nc + bc] = rn;
               if (MC && a.ab_rec) {
@@ -687,33 +700,28 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
                 a.ab_rec[2 * ((size_t)k * a.B * nc + bc) + 1] = beta;
               }
             }
-            conv = rn < a.stop_after;                        // :300
           } else {
             beta = 0.f;
-            conv = sqrtf(s1) < a.stop_after;                 // :204-205
-            rn = sqrtf(s1);
-            if (wig == 0 && t == 0) a.init_conv[bc] = conv ? 1 : 0;
+            rn = rnn;
+            if (wig == 0 && t == 0) a.init_conv[bc] = (rn < a.stop_after) ? 1 : 0;  // :204-205
           }
+          conv = rn < a.stop_after;                          // :300
           rz = rzn;
           const float dzz = pre ? fmaf(-2.f, wv, s2) + vev : s2;
           const float dzp = rp - vt;
           dpp = fmaf(beta, fmaf(beta, dpp, 2.f * dzp), dzz);
-          t_old = fmaf(beta, t_old, wj - evj);               // C^T p_new (lanes j < RC of both halves)
-          const float tt = wave_sum_fast(own ? t_old * t_old : 0.f);
-          const float pAp = tt + dpp;
-          alpha = (pAp < a.eps) ? 0.f : rz / pAp;            // :254-257
+          tt_old = fmaf(beta, fmaf(beta, tt_old, 2.f * zt), zz);  // |C^T p_new|^2
+          t_old = fmaf(beta, t_old, zj);                     // C^T p_new (lanes j < RC of both halves)
+          const float pAp = tt_old + dpp;
+          alpha = (pAp < a.eps) ? 0.f : rz * __builtin_amdgcn_rcpf(pAp);  // :254-257
           if (conv) alpha = 0.f;                             // :260
+          R5Post& mine = post[t >> 6];                       // this wave's own copy: written and read by the same wave
           if (own) {
-            post.v[j] = vj;
-            post.t[j] = t_old;
-          }
-          if (t == 0) {
-            post.alpha = alpha;
-            post.beta = beta;
-            post.rn = rn;
+            mine.v[j] = vj;
+            mine.t[j] = t_old;
           }
         }
-        __syncthreads();
+        if (g.dbg && t == 0) g.dbg[10] += wall_clock64() - cp0;  // small algebra
       };
       reduce_and_post(-1);
       if (stamp && col == cfirst) {
@@ -722,7 +730,10 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
       }
       float last_alpha = 0.f;
       for (int k = 0; k < a.iters; ++k) {
-        const float al = post.alpha, be = post.beta;
+        long long c0 = 0;
+        if (g.dbg && t == 0) c0 = wall_clock64();
+        const float al = alpha, be = beta;  // (identical in every wave: formed from the same all-reduced values)
+        const R5Post& mine = post[t >> 6];
         last_alpha = al;
         // p = beta p + (r - C v) / d  (:268, :46);  x += alpha p (:31);  r -= alpha (C t + d p) (:264)
         float cv[R4_NR], y[R4_NR];
@@ -730,8 +741,8 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
         for (int q = 0; q < R4_NR; ++q) { cv[q] = 0.f; y[q] = 0.f; }
 #pragma unroll
         for (int i = 0; i < RC; i += 4) {
-          const float4 v4 = *reinterpret_cast<const float4*>(&post.v[i]);
-          const float4 t4 = *reinterpret_cast<const float4*>(&post.t[i]);
+          const float4 v4 = *reinterpret_cast<const float4*>(&mine.v[i]);
+          const float4 t4 = *reinterpret_cast<const float4*>(&mine.t[i]);
 #pragma unroll
           for (int q = 0; q < R4_NR; ++q) {
             cv[q] = fmaf(Cr[q][i], v4.x, cv[q]);
@@ -751,7 +762,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
           x_s[lr] = fmaf(al, p[q], x_s[lr]);
           r[q] = fmaf(-al, fmaf(d_s[lr], p[q], y[q]), r[q]);
         }
-        __syncthreads();  // (post is rewritten by the next reduction's first wave)
+        if (g.dbg && t == 0) g.dbg[8] += wall_clock64() - c0;  // vector updates (three passes over the C rows incl. below)
         reduce_and_post(k);
       }
       if (stamp && col == cfirst) a.dbg[3] = wall_clock64();
@@ -771,7 +782,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
           if (a.z) {
             float cvq = 0.f;
 #pragma unroll
-            for (int i = 0; i < RC; ++i) cvq = fmaf(Cr[q][i], post.v[i], cvq);
+            for (int i = 0; i < RC; ++i) cvq = fmaf(Cr[q][i], post[t >> 6].v[i], cvq);
             a.z[o] = (r[q] - cvq) * dinv_s[lr];
           }
         }
