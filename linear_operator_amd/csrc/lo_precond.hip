@@ -485,6 +485,116 @@ static int padded_k(int k) {
   return 4 * p;
 }
 
+// Gram partials of W = C o sc for a ROOT C [B, N, R] (R <= 32, rows contiguous): the rows are staged through LDS with
+// coalesced 16-byte loads (the per-lane 4-byte loads of k_pb_gram_mfma_nk reach 1.7 TB/s only), then fed to the fp64
+// matrix cores as in k_pb_gram_mfma_nk.  gpart [B, S, R, R].
+template <int NA>
+__global__ __launch_bounds__(kThreads) void k_pb_gram_root(const float* __restrict__ C, const float* __restrict__ sc,
+                                                            int N, int R, int rows_per, double* __restrict__ gpart) {
+  constexpr int NB = (NA == 2) ? 3 : 1;
+  constexpr int TR = 128;                 // rows per tile: 32 per wave
+  constexpr int LD = 33;                  // tile row stride (conflict-free column reads)
+  __shared__ float tile[2][TR * LD];
+  __shared__ double red[4][64][4 * NB];
+  const int s = blockIdx.x, S = gridDim.x;
+  const int64_t b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int a = l & 15, kk = l >> 4;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  const float* Cb = C + (size_t)b * N * R;
+  const float* scb = sc ? sc + (size_t)b * N : nullptr;
+  const int RQ = R >> 2;                  // 16-byte pieces per row (R % 4 == 0 on this path)
+  // register prefetch: the next tile's 16-byte pieces (4 per thread at R = 32) are in flight while the matrix cores work
+  // on the current tile, and go to LDS afterwards
+  constexpr int PPT = TR * 8 / kThreads;  // pieces per thread at the widest root (R = 32)
+  float4 pv[PPT];
+  float ps[PPT];
+  auto issue = [&](int base) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int e = i * kThreads + threadIdx.x;
+      const int row = e / RQ, q = e % RQ;
+      pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ps[i] = 1.f;
+      if (e < TR * RQ && base + row < r1) {
+        pv[i] = *reinterpret_cast<const float4*>(Cb + (size_t)(base + row) * R + 4 * q);
+        if (scb) ps[i] = scb[base + row];
+      }
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int e = i * kThreads + threadIdx.x;
+      if (e < TR * RQ) {
+        const int row = e / RQ, q = e % RQ;
+        float* t = &tile[buf][row * LD + 4 * q];
+        t[0] = pv[i].x * ps[i]; t[1] = pv[i].y * ps[i]; t[2] = pv[i].z * ps[i]; t[3] = pv[i].w * ps[i];
+      }
+    }
+  };
+  // fp32 matrix cores inside a tile (32 rows per wave: the partial of a 32-term sum carries the rounding of the final
+  // fp32 result anyway), fp64 across tiles (8192 rows = 64 tiles per wave slice)
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  double acc00[4] = {0.0, 0.0, 0.0, 0.0}, acc01[4] = {0.0, 0.0, 0.0, 0.0}, acc11[4] = {0.0, 0.0, 0.0, 0.0};
+  int buf = 0;
+  issue(r0);
+  commit(0);
+  __syncthreads();
+  for (int base = r0; base < r1; base += TR) {
+    const bool more = base + TR < r1;
+    if (more) issue(base + TR);
+    f32x4 t00 = {0.f, 0.f, 0.f, 0.f}, t01 = t00, t11 = t00;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = 32 * wave + 4 * e + kk;
+      const float w0 = (a < R) ? tile[buf][row * LD + a] : 0.f;
+      t00 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, w0, t00, 0, 0, 0);
+      if (NA == 2) {
+        const float w1 = (a + 16 < R) ? tile[buf][row * LD + a + 16] : 0.f;
+        t01 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, w1, t01, 0, 0, 0);
+        t11 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, w1, t11, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc00[r] += (double)t00[r];
+      if (NA == 2) {
+        acc01[r] += (double)t01[r];
+        acc11[r] += (double)t11[r];
+      }
+    }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    red[wave][l][r] = acc00[r];
+    if (NA == 2) {
+      red[wave][l][4 + r] = acc01[r];
+      red[wave][l][8 + r] = acc11[r];
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double* gp = gpart + ((size_t)b * S + s) * R * R;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = 4 * kk + r, gj = a;  // fp32 MFMA result layout: D[4 (l / 16) + r][l % 16]
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) {
+        const double v = (red[0][l][4 * blk + r] + red[1][l][4 * blk + r]) + (red[2][l][4 * blk + r] + red[3][l][4 * blk + r]);
+        const int i = gi + (blk == 2 ? 16 : 0), j = gj + (blk >= 1 ? 16 : 0);
+        if (i < R && j < R) {
+          gp[i * R + j] = v;
+          if (blk == 1) gp[j * R + i] = v;  // G10 = G01^T
+        }
+      }
+    }
+  }
+}
+
 // ---- root form (see lo_amd.h: lo_precond_desc.F / EF / E) ------------------------------------------------------------
 // One wave per member, fp64 in LDS: E from the Gram partials of W = C / sqrt(d) (or C^T C / sigma), the recurrence for
 // M on the pivot rows, G = I + M^T E M, its Cholesky factor, F = M G^-1 M^T = (M Lg^-T)(M Lg^-T)^T, EF, logdet.
@@ -508,16 +618,24 @@ __global__ __launch_bounds__(64) void k_pb_rootform(const double* __restrict__ g
     for (int s = 0; s < S; ++s) t += gpart[((size_t)b * S + s) * R * R + pr];
     E[pr / R][pr % R] = t / sigma;  // (FULL: the rows were scaled by 1/sqrt(d); CONST: C^T C / sigma)
   }
-  // M[:, j] = (C[pi_j, :]^T - sum_{i<j} M[:, i] L[pi_j, i]) / L[pi_j, j]
+  // M[:, j] = (C[pi_j, :]^T - sum_{i<j} M[:, i] L[pi_j, i]) / L[pi_j, j]: the pivot rows of C and the pivot entries of
+  // L are fetched first (all loads in flight together: T <- C[pi_j, :], Fm <- L[pi_j, i]), the recurrence runs from LDS
   const float* Cb = C + (size_t)b * N * R;
   const float* Lb = L + (size_t)b * ls.member;
-  for (int j = 0; j < k; ++j) {
-    const long long pj = perm[(size_t)b * N + j];
-    __syncthreads();
-    if (lane < R) {
-      double col = (double)Cb[(size_t)pj * R + lane];
-      for (int i = 0; i < j; ++i) col -= M[lane][i] * (double)Lb[(size_t)pj * ls.row + (size_t)i * ls.col];
-      M[lane][j] = col / (double)Lb[(size_t)pj * ls.row + (size_t)j * ls.col];
+  for (int pr = lane; pr < k * R; pr += 64) {
+    const int j = pr / R, a = pr % R;
+    T[j][a] = (double)Cb[(size_t)perm[(size_t)b * N + j] * R + a];
+  }
+  for (int pr = lane; pr < k * k; pr += 64) {
+    const int j = pr / k, i = pr % k;
+    if (i <= j) Fm[j][i] = (double)Lb[(size_t)perm[(size_t)b * N + j] * ls.row + (size_t)i * ls.col];
+  }
+  __syncthreads();
+  if (lane < R) {  // (row `lane` of M depends on its own earlier entries only: no barrier inside the recurrence)
+    for (int j = 0; j < k; ++j) {
+      double col = T[j][lane];
+      for (int i = 0; i < j; ++i) col -= M[lane][i] * Fm[j][i];
+      M[lane][j] = col / Fm[j][j];
     }
   }
   __syncthreads();
@@ -714,8 +832,14 @@ int lo_precond_root_form_f32(const float* C, int32_t R, const float* d, int32_t 
   }
   const LStride cs{N * (int64_t)R, (int64_t)R, 1};
   LO_PROF_BEGIN("pb_gram_root", st);  // E partials = W^T W, W = C / sqrt(d), fp64 matrix cores
-  if (R <= 16) hipLaunchKernelGGL((k_pb_gram_mfma_nk<1>), grid, block, 0, st, C, cs, sc, (int)N, (int)R, sp.rows, gpart);
-  else hipLaunchKernelGGL((k_pb_gram_mfma_nk<2>), grid, block, 0, st, C, cs, sc, (int)N, (int)R, sp.rows, gpart);
+  if ((R % 4) == 0 && ((uintptr_t)C % 16) == 0) {  // LDS-staged rows (coalesced 16-byte loads)
+    if (R <= 16) hipLaunchKernelGGL((k_pb_gram_root<1>), grid, block, 0, st, C, sc, (int)N, (int)R, sp.rows, gpart);
+    else hipLaunchKernelGGL((k_pb_gram_root<2>), grid, block, 0, st, C, sc, (int)N, (int)R, sp.rows, gpart);
+  } else if (R <= 16) {
+    hipLaunchKernelGGL((k_pb_gram_mfma_nk<1>), grid, block, 0, st, C, cs, sc, (int)N, (int)R, sp.rows, gpart);
+  } else {
+    hipLaunchKernelGGL((k_pb_gram_mfma_nk<2>), grid, block, 0, st, C, cs, sc, (int)N, (int)R, sp.rows, gpart);
+  }
   LO_PROF_END(st);
   const LStride ls{ld_member, ld_row, ld_col};
   LO_PROF_BEGIN("pb_rootform", st);

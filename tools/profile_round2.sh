@@ -38,10 +38,10 @@ def grab(path, counter, kernel):
         if line.startswith(counter) and kernel in line:
             return float(re.search(r"avg=\s*([0-9.]+)", line).group(1))
     return None
-f = grab(f"{out}/pmc_fetch_write_bench.txt", "FETCH_SIZE", "k_cg_onchip4<32, 16, 8, false>")
-w = grab(f"{out}/pmc_fetch_write_bench.txt", "WRITE_SIZE", "k_cg_onchip4<32, 16, 8, false>")
+f = grab(f"{out}/pmc_fetch_write_bench.txt", "FETCH_SIZE", "k_cg_onchip5<32, 8, false>")
+w = grab(f"{out}/pmc_fetch_write_bench.txt", "WRITE_SIZE", "k_cg_onchip5<32, 8, false>")
 if f is not None and w is not None:
-    json.dump({"prof_name": "cg_onchip", "kernel": "k_cg_onchip4<32,16,8,false>", "FETCH_SIZE_KB_avg": f,
+    json.dump({"prof_name": "cg_onchip", "kernel": "k_cg_onchip5<32,8,false>", "FETCH_SIZE_KB_avg": f,
                "WRITE_SIZE_KB_avg": w, "fetch_correction": 2.0, "traffic_bytes_per_launch": (2.0 * f + w) * 1024,
                "source": "pmc_fetch_write_bench.txt (rocprofv3 --pmc, separate passes, `bench.py --no-extras`)"},
               open(f"{out}/traffic.json", "w"), indent=1)
@@ -53,6 +53,25 @@ if f is not None and w is not None:
                "source": "pmc_fetch_write_lockstep.txt (rocprofv3 --pmc, separate passes, tools/mb_lockstep.py)"},
               open(f"{out}/traffic_lockstep.json", "w"), indent=1)
 PY
+: > $OUT/pmc_utilisation_bench.txt
+for c in VALUBusy SALUBusy LdsUtil VALUUtilization SQ_INSTS_VALU SQ_INSTS_LDS; do
+  rm -rf /tmp/p_u
+  timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/p_u -- $B > /dev/null 2>&1
+  python - "$c" >> $OUT/pmc_utilisation_bench.txt <<'PY'
+import csv, glob, sys
+from collections import defaultdict
+c = sys.argv[1]
+rows = defaultdict(list)
+for f in glob.glob("/tmp/p_u/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_cg_onchip5" in r["Kernel_Name"] and r["Counter_Name"] == c:
+            rows[r["Dispatch_Id"]].append(float(r["Counter_Value"]))
+if not rows:
+    print(f"{c}: no rows"); sys.exit()
+per = [sum(v) for v in rows.values()]
+print(f"{c}: k_cg_onchip5 dispatches {len(per)}, per dispatch avg {sum(per)/len(per):.6g}")
+PY
+done
 cd $R && timeout 900 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.stderr
 tail -c 1500 $OUT/bench.json
 timeout 600 python bench.py --workload cfg4 --steps 2 --warmup 1 > $OUT/bench_cfg4_strong.json 2>> $OUT/bench.stderr
