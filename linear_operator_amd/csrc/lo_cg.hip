@@ -26,6 +26,7 @@
 namespace lo {
 
 bool g_onchip_disabled = false;
+static thread_local bool tls_no_fused_precond = false;  // set while a solve is redone after a timed-out hand-off
 // A chunk of columns goes to the column-lockstep kernel (16 at a time on the matrix cores) when it has at least this
 // many live columns; fewer are cheaper one after the other on the second-generation kernel.
 constexpr int kLockstepMinCols = 4;
@@ -48,6 +49,7 @@ struct CgDev {
   float* ctrl_part;  // [3, kCtrlMaxG] per-workgroup partials of the control step
   unsigned long long* oc_gbuf;
   unsigned long long* ls_gbuf;  // granules of the column-lockstep kernel (lo_cg_lockstep.hip) or nullptr
+  unsigned long long* pf_gbuf;  // granules of the fused preconditioner apply (lo_precond_fused.hip) or nullptr
   int* oc_err;
   float* oc_resid;
   int* oc_init_conv;
@@ -454,6 +456,9 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   dd.ls_gbuf = (oc_shape && c >= kLockstepMinCols && N <= 8192)
                    ? ar.take<unsigned long long>(lockstep_gbuf_bytes(32, 16) / sizeof(unsigned long long))
                    : nullptr;
+  dd.pf_gbuf = (pre && precond_fused_eligible(B, N, c, padded_rank_k(pre->k), sp.S))
+                   ? ar.take<unsigned long long>(precond_fused_gbuf_bytes() / sizeof(unsigned long long))
+                   : nullptr;
   dd.oc_zero_q = nullptr;
   dd.oc_ones = nullptr;
   if (!pre && !precond && oc_shape) {
@@ -809,8 +814,15 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   const int ctrl_G = (int)std::min<int64_t>(kCtrlMaxG, ((int64_t)B * c + kThreads - 1) / kThreads);
   int k = k_start;
   int launched = k_start;
+  // large-N single-column solves: the preconditioner apply fused with the r / x update, Q read once per iteration
+  bool pf_on = pre && pre->Q && d.pf_gbuf && !tls_no_fused_precond && oc_nwg >= 64 &&
+               precond_fused_eligible(B, N, c, preR4, sp.S);
+  bool p_done = false;  // the fused apply of the previous iteration already wrote this iteration's p
   while (k < prm->max_iter && !h.stop) {
-    if (matvec_can_fuse_pupdate(&pl)) {
+    if (p_done) {
+      rc = matvec_run(&pl, d.p, d.Ap, d.pAp_part, stop, st);
+      if (rc) return rc;
+    } else if (matvec_can_fuse_pupdate(&pl)) {
       rc = matvec_run_pupdate(&pl, d.p, zsrc, d.beta, k == 0 ? 1 : 0, d.Ap, d.pAp_part, stop, st);
       if (rc) return rc;
     } else {
@@ -821,7 +833,18 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       rc = matvec_run(&pl, d.p, d.Ap, d.pAp_part, stop, st);
       if (rc) return rc;
     }
-    if (pre) {
+    bool pre_done = false;
+    if (pre && pf_on) {
+      // single pass over Q: r / x update, Q^T r, group all-reduce, z = r/d - Q u, p = z + beta p (lo_precond_fused.hip)
+      rc = precond_fused_rupdate(Qp, pre->dinv, pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL, d.r, d.Ap, d.p, d.x,
+                                 d.z, d.pAp_part, d.S_dot, d.rz, d.has_conv, d.eps, d.alpha, d.rr_part, d.rz_part, sp.S,
+                                 B, N, d.pf_gbuf, d.oc_err, d.oc_err + 3, stop, oc_nwg, st);
+      if (rc == LO_ERR_UNSUPPORTED) pf_on = false;  // (does not fit this device: the two-launch path from now on)
+      else if (rc) return rc;
+      else pre_done = p_done = true;
+    }
+    if (pre_done) {
+    } else if (pre) {
       // r-update, x-update and the residual norm ride on the first pass over Q
       rc = skinny_tn_rupdate(Qp, preR4, preR4, d.r, d.Ap, d.p, d.x, d.pAp_part, d.S_dot, d.rz, d.has_conv, d.eps,
                              d.alpha, d.rr_part, c, upart, B, N, sp, stop, st);
@@ -849,6 +872,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     if (at_poll || k == prm->max_iter - 1 || (opaque && k == 0)) {
       rc = poll();
       if (rc) return rc;
+      if (pf_on && h.oc_err) break;  // a hand-off of the fused apply timed out: redo below
       if (k >= first_poll) {  // (one collective per iteration from the first possible stop on, on every rank)
         rc = global_check();
         if (rc) return rc;
@@ -859,6 +883,14 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   if (launched == 0 || !h.stop) {
     rc = poll();
     if (rc) return rc;
+  }
+  if (pf_on && h.oc_err) {  // (co-residency lost -- never seen on a dedicated GPU): the two-launch path for the whole solve
+    fprintf(stderr, "liblo_amd: fused preconditioner apply timed out, redoing the solve with the two-pass kernels\n");
+    tls_no_fused_precond = true;
+    const int rc2 = lo_cg_solve_f32(op, matvec, matvec_user, pre, precond_cb, precond_user, prm, rhs, x0, x, t_mat, ws,
+                                    ws_bytes, info, stream);
+    tls_no_fused_precond = false;
+    return rc2;
   }
   if (!(x_written && launched == k_start)) {  // (no streaming iteration after the resident phase: x is final already)
     hipLaunchKernelGGL(k_cg_final, gridv, block, 0, st, d, x, sp.rows);

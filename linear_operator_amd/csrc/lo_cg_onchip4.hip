@@ -26,164 +26,9 @@
 #include "lo_device.h"
 #include "lo_internal.h"
 #include "lo_cg_onchip.h"
+#include "lo_group_reduce.h"
 
 namespace lo {
-
-constexpr int R4_TPB = 256;
-constexpr int R4_NR = 4;                 // rows per thread
-constexpr int R4_WAVES = R4_TPB / 64;    // 4
-constexpr int R4_ROWS = R4_TPB * R4_NR;  // rows per workgroup
-constexpr int R4_MAXGW = 32;
-constexpr int R4_SLOT = 40;
-constexpr unsigned R4_MAXSPIN = 1u << 20;  // ~0.5 s of polling: co-residency was lost (never seen on a dedicated GPU)
-
-struct alignas(16) R4Shared {
-  float red[R4_WAVES][R4_SLOT];
-  float res[R4_SLOT];
-};
-
-// physical 16-byte slot of logical slot q of Q row r (NQ slots per row)
-template <int NQ>
-__device__ __forceinline__ int q_slot(int r, int q) {
-  if constexpr (NQ == 4) return r * 4 + (q ^ ((r >> 2) & 3));
-  else if constexpr (NQ == 2) return r * 2 + (q ^ ((r >> 3) & 1));
-  else return r;
-}
-
-// wave reduce-scatter of n register values (destroyed): lane l ends with the wave sum of component l >> (6 - log2 n)
-// The components come from a generator so that only n/2 temporaries are ever live (component j and j + n/2 are
-// formed right before their first halving step).
-template <int n, class Gen>
-__device__ __forceinline__ float r4_wave_rs(Gen gen) {
-  const int lane = threadIdx.x & 63;
-  constexpr int h0 = n / 2;
-  float w[h0];
-#pragma unroll
-  for (int j = 0; j < h0; ++j) w[j] = halve_pair<32>(gen(j), gen(j + h0), lane);
-  halving_steps<h0, 16, h0>(w, lane);
-  return w[0];
-}
-
-struct R4Group {
-  unsigned long long* gslot;  // [2][GW][R4_SLOT] granules of this group
-  int wig;
-  long long* dbg;  // phase timers of the stamped member (or nullptr)
-  unsigned tag;
-  int* err;
-  bool same_xcd;
-};
-
-// Second half of an all-reduce: sh.red[w][0..cnt) hold the wave partials.  Thread t < cnt sums them (fixed
-// order), publishes the granule, polls the same component of every workgroup of the group and sums those in fixed
-// order -> sh.res[t], bitwise identical in all workgroups.  Ends with a barrier.
-template <int GW>
-__device__ __forceinline__ void r4_group_sum(R4Shared& sh, int cnt, R4Group& g) {
-  const int t = threadIdx.x;
-  const unsigned tag = ++g.tag;
-  long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-  const bool stamp = g.dbg && t == 0;
-  if (stamp) c0 = wall_clock64();
-  __syncthreads();
-  if (stamp) c1 = wall_clock64();
-  if (t < cnt) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < R4_WAVES; ++w) s += sh.red[w][t];
-    unsigned long long* slot = g.gslot + (size_t)(tag & 1u) * GW * R4_SLOT;
-    const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(s);
-    if (g.same_xcd)
-      __hip_atomic_store(slot + (size_t)g.wig * R4_SLOT + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else
-      __hip_atomic_store(slot + (size_t)g.wig * R4_SLOT + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (stamp) c2 = wall_clock64();
-    float tot = 0.f;
-    unsigned spin = 0;
-    if constexpr (GW <= 16) {
-      float vals[GW];
-      for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int w = 0; w < GW; ++w) {
-          const unsigned long long x =
-              __hip_atomic_load(slot + (size_t)w * R4_SLOT + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = ok && ((unsigned)(x >> 32) == tag);
-          vals[w] = __uint_as_float((unsigned)(x & 0xffffffffull));
-        }
-        if (ok) break;
-        if (++spin > R4_MAXSPIN ||
-            ((spin & 1023u) == 0 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-          atomicExch(g.err, 1);  // timed out, or another workgroup already did: give up at once
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-#pragma unroll
-      for (int w = 0; w < GW; ++w) tot += vals[w];
-    } else {
-      // large groups: wait for all tags first, then read the (now final: a granule of this parity is not rewritten
-      // before every workgroup has finished this all-reduce) values again -- 32 values need not stay in registers
-      // (32-bit halves of the granules: tag = upper word, value = lower word; the writer stores both with one 64-bit
-      // store, so a matching tag means the value word next to it is the one of this all-reduce)
-      const unsigned* words = reinterpret_cast<const unsigned*>(slot);
-      for (;;) {
-        unsigned bad = 0;  // (no short-circuit: all tag loads must be in flight together)
-#pragma unroll
-        for (int w = 0; w < GW; ++w)
-          bad |= __hip_atomic_load(words + 2 * ((size_t)w * R4_SLOT + t) + 1, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT) ^ tag;
-        if (bad == 0) break;
-        if (++spin > R4_MAXSPIN ||
-            ((spin & 1023u) == 0 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-          atomicExch(g.err, 1);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-#pragma unroll
-      for (int h = 0; h < GW; h += 16) {  // 16 loads in flight, summed in the fixed order w = 0 .. GW-1
-        float v[16];
-#pragma unroll
-        for (int w = 0; w < 16; ++w)
-          v[w] = __uint_as_float(__hip_atomic_load(words + 2 * ((size_t)(h + w) * R4_SLOT + t), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT));
-#pragma unroll
-        for (int w = 0; w < 16; ++w) tot += v[w];
-      }
-    }
-    sh.res[t] = tot;
-    if (stamp) {
-      c3 = wall_clock64();
-      g.dbg[5] += c1 - c0;  // waiting for the slowest wave of this workgroup
-      g.dbg[6] += c2 - c1;  // wave-partial sum + publish
-      g.dbg[7] += c3 - c2;  // poll + sum
-    }
-  }
-  __syncthreads();
-}
-
-// all-reduce of n generated components + ns scalars over the whole group -> sh.res[0 .. n + ns)
-template <int GW, int n, class Gen>
-__device__ __forceinline__ void r4_allreduce(R4Shared& sh, Gen gen, const float* scal, int ns, R4Group& g) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  constexpr int sh_bits = (n == 32) ? 1 : (n == 16) ? 2 : (n == 8) ? 3 : 4;
-  const float mine = r4_wave_rs<n>(gen);
-  if ((lane & ((1 << sh_bits) - 1)) == 0) sh.red[wave][lane >> sh_bits] = mine;
-  for (int j = 0; j < ns; ++j) {
-    const float sv = wave_sum_fast(scal[j]);
-    if (lane == 0) sh.red[wave][n + j] = sv;
-  }
-  r4_group_sum<GW>(sh, n + ns, g);
-}
-
-template <int GW>
-__device__ __forceinline__ void r4_allreduce_scalars(R4Shared& sh, const float* scal, int ns, R4Group& g) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int j = 0; j < ns; ++j) {
-    const float sv = wave_sum_fast(scal[j]);
-    if (lane == 0) sh.red[wave][j] = sv;
-  }
-  r4_group_sum<GW>(sh, ns, g);
-}
 
 // MC: several right-hand-side columns and / or recorded alpha, beta (the single-column instantiation keeps the
 // column count a compile-time 1)

@@ -76,6 +76,7 @@ struct CgCtrl {
   int oc_err;             // operator-resident kernels: a group exchange timed out (host falls back to streaming)
   int oc_next;            // operator-resident kernels: shared counter of the dynamic member hand-out
   int oc_next_ls;         // the same for the column-lockstep kernel (both may run in one solve)
+  int pf_next;            // the same for the fused preconditioner apply of the streaming loop
 };
 
 // fused-update arguments of the skinny tn kernels (VMODE 1: p-update, VMODE 2: r/x-update; see lo_skinny.hip)
@@ -201,6 +202,16 @@ int onchip_num_workgroups();
 bool onchip4_eligible(int RC, int RK, int64_t N, int64_t c);  // lo_cg_onchip4.hip
 int onchip4_group_size(int64_t N);
 extern bool g_onchip_disabled;  // lo_cg_set_onchip(0): streaming engines only (tests compare the two)
+
+// ---- single-pass Woodbury apply fused with the CG r / x update (lo_precond_fused.hip) --------------
+bool precond_fused_eligible(int64_t B, int64_t N, int64_t c, int ldq, int S);
+size_t precond_fused_gbuf_bytes();
+// (also writes the next iteration's p = z + beta p; z itself is not stored)
+int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, float* r, const float* Ap, float* p,
+                          float* x, float* z, const float* pAp_part, int S_dot, const float* rz, const int* has_conv,
+                          float eps, float* alpha_out, float* rr_part, float* rz_part, int S, int64_t B, int64_t N,
+                          unsigned long long* gbuf, int* err, int* next_member, const int* stop, int ncu,
+                          hipStream_t st);
 
 // ---- operator-resident pivoted Cholesky (lo_pivchol_onchip.hip) ----------------------------------
 bool pc_onchip_eligible(const lo_op_desc* op, int max_rank);

@@ -1,0 +1,345 @@
+// lo_precond_fused.hip -- one pass over the Woodbury preconditioner's Q per CG iteration (single right-hand-side column,
+// large N): the residual / solution update of linear_cg.py:264,:31 and z = r o dinv - Q (Q^T r) (precondition_closure,
+// added_diag_linear_operator.py:135-140) in ONE kernel.
+//
+// The streaming engine applies the preconditioner in two launches -- Q^T r over the rows (skinny_tn, with the vector
+// updates fused), then z = r/d - Q u (skinny_nn) -- and streams Q twice.  For BASELINE cfg4 (Kronecker operator,
+// N = 65536, rank-15 preconditioner) Q is 537 MB for a 128-member shard and these two passes are 70 % of a CG iteration.
+// Here a member is a group of GW workgroups (256 threads x 4 rows); a thread keeps its four rows of Q (64 values) in
+// registers between the two halves and the group exchanges the 16 + 2 partial sums through the tagged granules of the
+// operator-resident kernels (lo_group_reduce.h): Q is read from HBM ONCE per iteration.  Groups are persistent, members
+// are handed out dynamically, four workgroups share a CU so that one group's hand-off wait is filled by another's
+// loads, and the r / x stores sit between the publication of the partial sums and the wait for the totals.  Results
+// are bitwise reproducible (fixed summation order); a timed-out hand-off sets the error word and the host redoes the
+// solve with the two-launch path.
+// The kernel also knows the new r.z after the exchange, hence beta: it writes the next search direction
+// p <- z + beta p instead of z, and the separate p-update pass of the streaming loop disappears.
+//   bound: HBM -- 4 N (16 + 8) bytes per member and iteration (Q once; r, Ap, p, x, dinv in; r, x, p out).
+#include <algorithm>
+#include <stdlib.h>
+
+#include "lo_device.h"
+#include "lo_internal.h"
+#include "lo_group_reduce.h"
+
+namespace lo {
+
+struct PfArgs {
+  const float* Q;         // [B, N, 16]
+  const float* dinv;      // [B, N] or [B]
+  int dinv_mode;
+  float* r;               // [B, N] in / out
+  const float* Ap;
+  float* p;               // in / out: the kernel also takes the NEXT iteration's p = z + beta p (linear_cg.py:34-46)
+  float* x;               // in / out
+  float* z;               // not written: z only feeds r.z and the p update, both done here
+  const float* pAp_part;  // [B, S_dot]
+  int S_dot;
+  const float* rz;        // [B]
+  const int* has_conv;    // [B]
+  float eps;
+  float* alpha_out;       // [B]
+  float* rr_part;         // [B, S]: slot 0 <- sum r^2, the others <- 0
+  float* rz_part;         // [B, S]: slot 0 <- r.z
+  int S;
+  int64_t B;
+  int N, RW;
+  unsigned long long* gbuf;
+  int* err;
+  int* next_member;
+  const int* stop;
+  int allow_l2_handoff;
+};
+
+// Group all-reduce for large groups (up to 64 workgroups) and a small payload: reduce-scatter + all-gather through tagged
+// granules, in two halves so that independent work can be placed between the publication and the wait.  Workgroup e owns
+// payload entry e: the 64 lanes of its first wave fetch that entry of all GW workgroups (one granule per lane -- the
+// fan-in costs lanes, not registers), sum them with the fixed-order wave butterfly and publish the total; everybody then
+// reads the cnt totals.  sh.red[w][0..cnt) hold the wave partials; result in sh.res[0..cnt).
+struct PfSlots {
+  unsigned long long* slot;
+  unsigned long long* tot;
+  unsigned tag;
+};
+
+__device__ __forceinline__ void pf_store(const R4Group& g, unsigned tag, unsigned long long* dst, float v) {
+  const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+  if (g.same_xcd) __hip_atomic_store(dst, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_store(dst, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// every lane of the wave takes part; lanes with active == false only vote
+__device__ __forceinline__ float pf_wait(const R4Group& g, unsigned tag, const unsigned long long* src, bool active) {
+  unsigned long long x = 0;
+  unsigned spin = 0;
+  for (;;) {
+    bool ok = true;
+    if (active) {
+      x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = (unsigned)(x >> 32) == tag;
+    }
+    if (__all(ok)) break;
+    if (++spin > R4_MAXSPIN ||
+        ((spin & 1023u) == 0 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      atomicExch(g.err, 1);  // timed out, or another workgroup already did: give up at once
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return active ? __uint_as_float((unsigned)(x & 0xffffffffull)) : 0.f;
+}
+
+template <int GW>
+__device__ __forceinline__ PfSlots pf_publish(R4Shared& sh, int cnt, R4Group& g) {
+  const int t = threadIdx.x;
+  PfSlots ps;
+  ps.tag = ++g.tag;
+  __syncthreads();
+  ps.slot = g.gslot + (size_t)(ps.tag & 1u) * (GW + 1) * R4_SLOT;  // GW partial arrays | totals
+  ps.tot = ps.slot + (size_t)GW * R4_SLOT;
+  if (t < cnt) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < R4_WAVES; ++w) s += sh.red[w][t];
+    pf_store(g, ps.tag, ps.slot + (size_t)g.wig * R4_SLOT + t, s);
+  }
+  return ps;
+}
+
+template <int GW>
+__device__ __forceinline__ void pf_collect(R4Shared& sh, int cnt, R4Group& g, const PfSlots& ps) {
+  const int t = threadIdx.x;
+  if (t < 64) {
+    for (int e = g.wig; e < cnt; e += GW) {  // entries this workgroup owns
+      const float v = pf_wait(g, ps.tag, ps.slot + (size_t)t * R4_SLOT + e, t < GW);
+      const float total = wave_sum_fast(v);
+      if (t == 0) pf_store(g, ps.tag, ps.tot + e, total);
+    }
+    const float r = pf_wait(g, ps.tag, ps.tot + t, t < cnt);
+    if (t < cnt) sh.res[t] = r;
+  }
+  __syncthreads();
+}
+
+// value of quad lane K in all four lanes of the quad (DPP quad_perm)
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf,
+                                                    false));
+}
+__device__ __forceinline__ float quad_pick(float v, int k) {
+  return k == 0 ? quad_bcast<0>(v) : (k == 1 ? quad_bcast<1>(v) : (k == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+}
+
+template <int GW, int OCC>
+__global__ __launch_bounds__(R4_TPB, OCC) void k_precond_fused(PfArgs a) {
+  if (a.stop && *a.stop) return;
+  __shared__ R4Shared sh;
+  __shared__ float alpha_s, rzo_s;
+  const int wg = blockIdx.x;
+  const int xcd = wg % 8, jx = wg / 8;
+  const int groups_per_xcd = (gridDim.x / 8) / GW;
+  const int grp = xcd * groups_per_xcd + jx / GW;
+  const int wig = jx % GW;
+  const int ngroups = groups_per_xcd * 8;
+  if (jx / GW >= groups_per_xcd) return;
+  const int t = threadIdx.x;
+  R4Group g;
+  g.gslot = a.gbuf + (size_t)grp * 2 * (GW + 1) * R4_SLOT;
+  g.wig = wig;
+  g.dbg = nullptr;
+  g.tag = 0;
+  g.err = a.err;
+  g.same_xcd = false;
+  {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
+    if (t < 64) {
+      sh.red[0][0] = (float)xcc;
+      sh.red[0][1] = (float)(xcc * xcc);
+    }
+    if (t < 2 * (R4_WAVES - 1)) sh.red[1 + t / 2][t % 2] = 0.f;
+    const PfSlots ps = pf_publish<GW>(sh, 2, g);
+    pf_collect<GW>(sh, 2, g, ps);
+    const float fx = (float)xcc;
+    g.same_xcd = (sh.res[0] == GW * fx) && (sh.res[1] == GW * fx * fx) && (a.allow_l2_handoff != 0);
+    __syncthreads();
+  }
+  const int row0 = wig * a.RW;
+  const int nv = max(0, min(a.RW, a.N - row0));
+  // Ownership of Q: thread t holds the 16-byte piece (row = 64 i + (t >> 2), columns 4 (t & 3) .. + 3) for i = 0 .. 15:
+  // consecutive lanes read consecutive pieces (fully coalesced 1 KiB per wave instruction), the four lanes of a quad
+  // share a row.  Ownership of the vectors: of the 16 rows of a quad, lane qd has the four with i % 4 == qd; the others
+  // get r through a DPP quad broadcast.
+  constexpr int NP = R4_ROWS * 4 / R4_TPB;  // 16 pieces per thread
+  constexpr int NV = NP / 4;                // 4 vector rows per thread
+  const int qd = t & 3, rsub = t >> 2;
+  int64_t b = grp;
+  while (b < a.B) {
+    float4 Qp[NP];
+    float rv[NV], apv[NV], dv[NV];
+    const size_t mb = (size_t)b * a.N + row0;
+    const float4* qsrc = reinterpret_cast<const float4*>(a.Q + mb * 16);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int lr = 64 * i + rsub;
+      Qp[i] = (lr < nv) ? qsrc[i * R4_TPB + t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int lr = 64 * (4 * j + qd) + rsub;
+      const bool ok = lr < nv;
+      rv[j] = ok ? a.r[mb + lr] : 0.f;
+      apv[j] = ok ? a.Ap[mb + lr] : 0.f;
+      dv[j] = ok ? ((a.dinv_mode == LO_DIAG_FULL) ? a.dinv[mb + lr] : a.dinv[b]) : 0.f;
+    }
+    if (t < 64) {  // masked alpha from the matvec's p.Ap partials (linear_cg.py:250-260), while the loads are in flight
+      float pAp = 0.f;
+      for (int s = t; s < a.S_dot; s += 64) pAp += a.pAp_part[(size_t)b * a.S_dot + s];
+      pAp = wave_sum_fast(pAp);
+      const float rzo = a.rz[b];
+      float al = (pAp < a.eps) ? 0.f : rzo / pAp;
+      if (a.has_conv[b]) al = 0.f;
+      if (t == 0) {
+        rzo_s = rzo;
+        alpha_s = al;
+        if (wig == 0) a.alpha_out[b] = al;
+      }
+    }
+    __syncthreads();
+    const float al = alpha_s;
+    float sc0 = 0.f, sc1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      rv[j] = fmaf(-al, apv[j], rv[j]);  // r -= alpha Ap     :264
+      dv[j] *= rv[j];                    // r / d
+      sc0 = fmaf(rv[j], rv[j], sc0);
+      sc1 = fmaf(dv[j], rv[j], sc1);
+    }
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);  // partial of (Q^T r)[4 qd .. 4 qd + 3]
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const float ri = quad_pick(rv[i >> 2], i & 3);
+      u.x = fmaf(Qp[i].x, ri, u.x);
+      u.y = fmaf(Qp[i].y, ri, u.y);
+      u.z = fmaf(Qp[i].z, ri, u.z);
+      u.w = fmaf(Qp[i].w, ri, u.w);
+    }
+    // wave: sum over the lanes of equal quad index (lane bits 2..5), then the two scalars over all lanes
+    {
+      float v[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xx = v[e];
+        xx = bfly_add<4>(xx); xx = bfly_add<8>(xx); xx = bfly_add<16>(xx); xx = bfly_add<32>(xx);
+        v[e] = xx;
+      }
+      const int lane = t & 63, wave = t >> 6;
+      if (lane < 4) {
+        sh.red[wave][4 * lane] = v[0]; sh.red[wave][4 * lane + 1] = v[1];
+        sh.red[wave][4 * lane + 2] = v[2]; sh.red[wave][4 * lane + 3] = v[3];
+      }
+      const float s0 = wave_sum_fast(sc0), s1 = wave_sum_fast(sc1);
+      if (lane == 0) {
+        sh.red[wave][16] = s0;
+        sh.red[wave][17] = s1;
+        // the next member rides on the same all-reduce: drawn by the group's first workgroup (exact below 2^24)
+        sh.red[wave][18] = (wig == 0 && wave == 0) ? (float)(ngroups + atomicAdd(a.next_member, 1)) : 0.f;
+      }
+    }
+    const PfSlots ps = pf_publish<GW>(sh, 19, g);
+    // while the partial sums travel: store r, update x
+    float pv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int lr = 64 * (4 * j + qd) + rsub;
+      pv[j] = 0.f;
+      if (lr < nv) {
+        pv[j] = a.p[mb + lr];
+        a.r[mb + lr] = rv[j];
+        a.x[mb + lr] = fmaf(al, pv[j], a.x[mb + lr]);  // x += alpha p      :31
+      }
+    }
+    pf_collect<GW>(sh, 19, g, ps);
+    const float4 ut = *reinterpret_cast<const float4*>(&sh.res[4 * qd]);
+    float uu = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) uu = fmaf(sh.res[j], sh.res[j], uu);
+    const float srr = sh.res[16], srz = sh.res[17] - uu;  // r.z = sum r^2/d - |Q^T r|^2
+    const float rzo = rzo_s;
+    const float beta = (rzo < a.eps) ? 0.f : srz / rzo;  // the control step's rule (:39-42) on the same numbers
+    const int64_t bnext = (int64_t)sh.res[18];
+    float zv[NV];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      float part = Qp[i].x * ut.x;
+      part = fmaf(Qp[i].y, ut.y, part);
+      part = fmaf(Qp[i].z, ut.z, part);
+      part = fmaf(Qp[i].w, ut.w, part);
+      part = bfly_add<1>(part);
+      part = bfly_add<2>(part);  // (Q u)[row] in all four lanes of the row
+      if ((i & 3) == 0) zv[i >> 2] = part;
+      else if (qd == (i & 3)) zv[i >> 2] = part;
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int lr = 64 * (4 * j + qd) + rsub;
+      // z = r/d - Q (Q^T r) (:140) goes straight into p <- z + beta p (:46)
+      if (lr < nv) a.p[mb + lr] = fmaf(pv[j], beta, dv[j] - zv[j]);
+    }
+    if (wig == 0 && t < a.S) {  // the control step sums S partials per member: the totals go to slot 0
+      a.rr_part[(size_t)b * a.S + t] = (t == 0) ? srr : 0.f;
+      a.rz_part[(size_t)b * a.S + t] = (t == 0) ? srz : 0.f;
+    }
+    __syncthreads();  // (sh.res / alpha_s / rzo_s are reused by the next member)
+    b = bnext;
+  }
+}
+
+static int pf_group_size(int64_t N) { return N <= 16 * (int64_t)R4_ROWS ? 16 : (N <= 32 * (int64_t)R4_ROWS ? 32 : 64); }
+
+bool precond_fused_eligible(int64_t B, int64_t N, int64_t c, int ldq, int S) {
+  return c == 1 && ldq == 16 && N >= 8 * (int64_t)R4_ROWS && N <= 64 * (int64_t)R4_ROWS && B < (1 << 24) - 4096 &&
+         S <= R4_TPB && !getenv("LO_NO_FUSED_PRECOND");
+}
+
+size_t precond_fused_gbuf_bytes() { return (size_t)64 * 2 * 65 * R4_SLOT * sizeof(unsigned long long) + 256; }
+
+template <int GW, int OCC>
+static int pf_go(PfArgs& a, int ncu, hipStream_t st) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_precond_fused<GW, OCC>, R4_TPB, 0) != hipSuccess ||
+      per_cu < 1)
+    return LO_ERR_UNSUPPORTED;
+  per_cu = std::min(per_cu, OCC);
+  const int nwg = per_cu * ncu;
+  if ((nwg / 8) < GW) return LO_ERR_UNSUPPORTED;
+  LO_PROF_BEGIN("precond_fused", st);
+  hipLaunchKernelGGL((k_precond_fused<GW, OCC>), dim3(nwg), dim3(R4_TPB), 0, st, a);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+// gbuf: precond_fused_gbuf_bytes() of zeroed memory (re-zeroed by this call); counters: err / next_member ints.
+int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, float* r, const float* Ap, float* p,
+                          float* x, float* z, const float* pAp_part, int S_dot, const float* rz, const int* has_conv,
+                          float eps, float* alpha_out, float* rr_part, float* rz_part, int S, int64_t B, int64_t N,
+                          unsigned long long* gbuf, int* err, int* next_member, const int* stop, int ncu,
+                          hipStream_t st) {
+  PfArgs a;
+  a.Q = Q; a.dinv = dinv; a.dinv_mode = dinv_mode; a.r = r; a.Ap = Ap; a.p = p; a.x = x; a.z = z;
+  a.pAp_part = pAp_part; a.S_dot = S_dot; a.rz = rz; a.has_conv = has_conv; a.eps = eps; a.alpha_out = alpha_out;
+  a.rr_part = rr_part; a.rz_part = rz_part; a.S = S; a.B = B; a.N = (int)N;
+  const int GW = pf_group_size(N);
+  a.RW = (int)((N + GW - 1) / GW);
+  a.gbuf = gbuf; a.err = err; a.next_member = next_member; a.stop = stop;
+  a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
+  LO_HIP_CHECK(hipMemsetAsync(gbuf, 0, precond_fused_gbuf_bytes(), st));
+  LO_HIP_CHECK(hipMemsetAsync(next_member, 0, sizeof(int), st));
+  // four workgroups per CU (110 VGPRs): cfg4 153 us per call against 188 us with two or three
+  if (GW == 16) return pf_go<16, 4>(a, ncu, st);
+  if (GW == 32) return pf_go<32, 4>(a, ncu, st);
+  return pf_go<64, 4>(a, ncu, st);
+}
+
+}  // namespace lo

@@ -705,6 +705,42 @@ def test_root_form_preconditioner_and_serial_kernel(N, R, c, nt, const, monkeypa
     assert pre_o.Q is not None and max_rel_err_cols(host(res_f.x), host(ref.x)) < 1e-6
 
 
+@pytest.mark.parametrize("kind,N", [("dense", 8192), ("kron", 16384), ("dense", 10000), ("kron", 65536)])
+def test_fused_preconditioner_apply_matches_two_pass_path(kind, N, monkeypatch):
+    """Single-column CG on large operators that are not resident (dense, Kronecker): the preconditioner apply fused with
+    the r / x update reads Q once per iteration (lo_precond_fused.hip, groups of 16-64 workgroups, one all-reduce); same
+    iteration count and solution as the two-launch path, bitwise reproducible."""
+    B = 5 if N < 65536 else 19
+    if kind == "dense":
+        K0, d, rhs = cases.dense_diag(5600 + N % 97, B, N, 1)
+        d_t = dev(d)
+        desc = K.dense_diag_descriptor(dev(K0), d_t)
+        const = False
+    else:
+        n = int(round(N ** 0.5))
+        K1, K2, sig, rhs = cases.kron_factors(5700, B, n, n, 1)
+        d_t = dev(sig[:, 0])
+        desc = K.kron_diag_descriptor(dev(K1), dev(K2), d_t, const_diag=True)
+        const = True
+    L, _ = K.pivoted_cholesky(desc, 15)
+    pre = K.precond_build(L, d_t, const)
+    kw = dict(precond=pre, tolerance=1e-3, max_iter=400)
+    monkeypatch.setenv("LO_NO_FUSED_PRECOND", "1")
+    ref = K.cg_solve(desc, dev(rhs), **kw)
+    monkeypatch.delenv("LO_NO_FUSED_PRECOND")
+    K._hip.prof_enable(True)
+    res = K.cg_solve(desc, dev(rhs), **kw)
+    torch.cuda.synchronize()
+    prof = K._hip.prof_report()
+    K._hip.prof_enable(False)
+    # (the initial z = P^-1 r of linear_cg.py:213 still takes the two-launch path: one skinny pair in the profile)
+    assert prof.get("precond_fused", (0, 0))[0] >= res.iterations - 1 and prof.get("skinny_tn_R16", (0, 0))[0] <= 1
+    assert abs(res.iterations - ref.iterations) <= 1 and res.tolerance_reached == ref.tolerance_reached
+    assert max_rel_err_cols(host(res.x), host(ref.x)) < 1e-4
+    res2 = K.cg_solve(desc, dev(rhs), **kw)
+    assert torch.equal(res.x, res2.x) and res2.iterations == res.iterations
+
+
 def test_onchip_cg_many_columns_hand_over():
     """Columns + tridiagonals + a tolerance the guaranteed iterations do not reach: the streaming loop continues from
     the resident kernel's per-column state."""
