@@ -253,7 +253,14 @@ def other_configs(device):
     if "kron_gemm_mfma" in prof:
         roofs.append(_roof("k_kron_nt_mfma", "cfg4 shard: 128 members, one of the two 256^3 GEMMs of a Kronecker matvec",
                            prof["kron_gemm_mfma"], "mfma", 2.0 * 128 * n * n * n,
-                           "fp32 matrix cores (v_mfma_f32_32x32x2_f32), 2 n^3 flop per member and GEMM"))
+                           "fp32 matrix cores (v_mfma_f32_32x32x2_f32), 2 n^3 flop per member and GEMM; with K = 256 "
+                           "the GEMM sits at the ridge (operands + result 100 - 130 MB per launch ~ its MFMA time): "
+                           "tools/mb_kron_rate.py, DESIGN 4.6"))
+    if "precond_fused" in prof:
+        roofs.append(_roof("k_precond_fused<64,4>", "cfg4 shard: 128 members x 65536 rows, one CG iteration's Woodbury "
+                           "apply + r / x / p updates", prof["precond_fused"], "hbm", 4 * 128 * n * n * (16 + 7),
+                           "4 N (16 + 7) bytes per member and iteration: Q once; r, Ap, p, x in; r, x, p out (constant "
+                           "diagonal)"))
     del X1, X2, K1, K2, desc
     # cfg5 shard: 4 of the 32 dense 16384^2 members a GPU owns, 17 columns, CG with tridiagonals
     Nd = 16384
