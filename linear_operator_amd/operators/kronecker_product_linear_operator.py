@@ -1,9 +1,12 @@
 """KroneckerProductLinearOperator K1 (x) ... (x) KP -- `_matmul`, `_diagonal`, `_get_indices` only
 (reference: operators/kronecker_product_linear_operator.py:20-45, 62-96, 188-216, 272-284).  Two dense factors
-lower to the batched-GEMM kernel pair in csrc/lo_kron.hip.  `+ Diag` / `add_diagonal` build the
+lower to the batched-GEMM kernel pair in csrc/lo_kron.hip; products of more dense factors are regrouped into two
+dense groups (`_two_groups`) and lower the same way.  `+ Diag` / `add_diagonal` build the
 KroneckerProductAddedDiagLinearOperator like the reference (:98-145): eigendecomposition closed forms for a
 constant diagonal, the CG path otherwise (an explicit AddedDiagLinearOperator(kron, diag) is always the CG path)."""
 from __future__ import annotations
+
+import math
 
 import torch
 from torch import Tensor
@@ -37,6 +40,32 @@ def _kron_matmul(ops, kp_shape, rhs):
     return res
 
 
+def _dense_kron(ts):
+    res = ts[0]
+    for nxt in ts[1:]:
+        res = (res.unsqueeze(-1).unsqueeze(-3) * nxt.unsqueeze(-2).unsqueeze(-4)).reshape(
+            *torch.broadcast_shapes(res.shape[:-2], nxt.shape[:-2]), res.shape[-2] * nxt.shape[-2],
+            res.shape[-1] * nxt.shape[-1])
+    return res
+
+
+def _group_pullback(dG: Tensor, ts):
+    """Gradients of the factors of G = T_1 (x) .. (x) T_p from dG: dT_i[a, b] = sum over the other factors' indices of
+    dG[(.., a, ..), (.., b, ..)] prod_{j != i} T_j[r_j, c_j]."""
+    if len(ts) == 1:
+        return [dG]
+    p = len(ts)
+    sizes = [t.shape[-1] for t in ts]
+    dG = dG.reshape(*dG.shape[:-2], *sizes, *sizes)
+    rows, cols = "abcdefgh"[:p], "ijklmnop"[:p]
+    out = []
+    for i in range(p):
+        others = ",".join(f"...{rows[j]}{cols[j]}" for j in range(p) if j != i)
+        expr = f"...{rows}{cols},{others}->...{rows[i]}{cols[i]}"
+        out.append(torch.einsum(expr, dG, *[ts[j] for j in range(p) if j != i]))
+    return out
+
+
 class KroneckerProductLinearOperator(LinearOperator):
     def __init__(self, *linear_ops):
         try:
@@ -56,12 +85,43 @@ class KroneckerProductLinearOperator(LinearOperator):
         super().__init__(*linear_ops)
         self.linear_ops = linear_ops
 
+    # ---- lowering: the kernels take TWO dense factors.  A product of more factors is regrouped as
+    #      (K_1 (x) .. (x) K_j) (x) (K_j+1 (x) .. (x) K_m) with the split that balances the two sides, the groups formed
+    #      densely (they are small: the whole point of the structure is n_i << N); gradients are pulled back to the
+    #      individual factors by contracting the group's gradient with the other factors of the group.
+    _kMaxGroup = 2048  # largest side of a regrouped factor (B x n^2 floats are materialised)
+
+    def _two_groups(self):
+        """(A, B, j): dense group tensors and the split index, or None when the product does not lower."""
+        ops = self.linear_ops
+        if len(ops) < 2 or not all(isinstance(op, DenseLinearOperator) for op in ops):
+            return None
+        ts = [op.tensor for op in ops]
+        if not all(t.is_cuda and t.dtype == torch.float32 and t.shape[-1] == t.shape[-2] for t in ts):
+            return None
+        if len(ts) == 2:
+            return ts[0], ts[1], 1
+        sizes = [t.shape[-1] for t in ts]
+        best = None
+        for j in range(1, len(ts)):
+            na, nb = math.prod(sizes[:j]), math.prod(sizes[j:])
+            if best is None or max(na, nb) < best[0]:
+                best = (max(na, nb), j)
+        if best[0] > self._kMaxGroup:
+            return None
+        j = best[1]
+        cache = getattr(self, "_groups_cache", None)
+        if cache is None:
+            with torch.no_grad():
+                cache = (_dense_kron(ts[:j]), _dense_kron(ts[j:]), j)
+            self._groups_cache = cache
+        return cache
+
     def _kernel_descriptor(self, batch_shape=None):
-        if len(self.linear_ops) != 2 or not all(isinstance(op, DenseLinearOperator) for op in self.linear_ops):
+        groups = self._two_groups()
+        if groups is None:
             return None
-        k1, k2 = (op.tensor for op in self.linear_ops)
-        if not all(t.is_cuda and t.dtype == torch.float32 and t.shape[-1] == t.shape[-2] for t in (k1, k2)):
-            return None
+        k1, k2, _ = groups
         bs = torch.Size(batch_shape) if batch_shape is not None else self.batch_shape
         k1 = k1.expand(*bs, *k1.shape[-2:])
         k2 = k2.expand(*bs, *k2.shape[-2:])
@@ -70,13 +130,14 @@ class KroneckerProductLinearOperator(LinearOperator):
     def _bilinear_derivative(self, left_vecs: Tensor, right_vecs: Tensor):
         """(dK1, dK2) = (sum_d U_d K2 V_d^T, sum_d U_d^T K1 V_d): the reference's generic autograd version
         (_linear_operator.py:336-393) applied to the Kronecker matvec (:34-45); two dense factors on this path."""
-        if len(self.linear_ops) != 2 or not all(isinstance(op, DenseLinearOperator) for op in self.linear_ops):
+        groups = self._two_groups()
+        if groups is None:
             return super()._bilinear_derivative(left_vecs, right_vecs)
-        k1, k2 = (op.tensor for op in self.linear_ops)
+        k1, k2, j = groups
         d1, d2 = K.bilinear_kron(k1, k2, left_vecs, right_vecs)
-        d1 = d1 if tuple(d1.shape) == tuple(k1.shape) else d1.sum_to_size(*k1.shape)
-        d2 = d2 if tuple(d2.shape) == tuple(k2.shape) else d2.sum_to_size(*k2.shape)
-        return (d1, d2)
+        ts = [op.tensor for op in self.linear_ops]
+        grads = _group_pullback(d1, ts[:j]) + _group_pullback(d2, ts[j:])
+        return tuple(g if tuple(g.shape) == tuple(t.shape) else g.sum_to_size(*t.shape) for g, t in zip(grads, ts))
 
     def __add__(self, other):  # reference :98-114
         from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator

@@ -6,7 +6,10 @@ On the HIP path the closed form is the SAME kernel sequence as the preconditione
 with the full root C in the place of the pivoted-Cholesky factor, `z = r/d - Q (Q^T r)` with
 `Q = D^-1/2 W R^-1`, `R^T R = I + W^T W`, `W = D^-1/2 C` IS `(C C^T + D)^-1 r` (Woodbury), and the cached
 `logdet P = 2 sum log|R_ii| + sum log d` is `logdet(C C^T + D)`; the capacitance matrix is factored in fp64
-(csrc/lo_precond.hip), the reference factors it in the operator's dtype."""
+(csrc/lo_precond.hip), the reference factors it in the operator's dtype.
+
+Roots of rank > 32 (beyond the register-resident R x R algebra of those kernels) take the reference's own route: the
+closed forms as plain batched library GEMMs + an R x R Cholesky (rocBLAS / hipSOLVER through ATen) on the device."""
 from __future__ import annotations
 
 import torch
@@ -49,13 +52,21 @@ class LowRankRootAddedDiagLinearOperator(AddedDiagLinearOperator):
             C, d = self._root_and_diag()
             if not (C.is_cuda and C.dtype == torch.float32):
                 raise K._hip.HipExtensionError("the Woodbury closed form runs in liblo_amd: fp32 HIP tensors only")
-            if C.shape[-1] > 32:
-                raise K._hip.HipExtensionError("LowRankRootAddedDiagLinearOperator: root rank > 32 is not supported")
+            assert C.shape[-1] <= 32  # (larger roots never get here: _wide_root)
             first = d[..., :1]
             const = bool(torch.equal(d, first.expand_as(d)))
             d_arg = first[..., 0].contiguous() if const else d.contiguous()
             self._woodbury_cache = K.precond_build(C.contiguous(), d_arg, const)
         return self._woodbury_cache
+
+    def _wide_root(self) -> bool:
+        """Rank > 32: library GEMM route (HIP tensors only, like the kernels -- no CPU fallback)."""
+        root = self._linear_op.root
+        if root.shape[-1] <= 32:
+            return False
+        if root.device.type != "cuda":
+            raise K._hip.HipExtensionError("LowRankRootAddedDiagLinearOperator runs on HIP tensors only")
+        return True
 
     @property
     def chol_cap_mat(self) -> Tensor:  # reference :36-47 (small R x R factor; kept for API compatibility)
@@ -75,6 +86,11 @@ class LowRankRootAddedDiagLinearOperator(AddedDiagLinearOperator):
         return None
 
     def _solve(self, rhs: Tensor, preconditioner=None, num_tridiag: int = 0):  # reference :62-89
+        if self._wide_root():  # D^-1 r - D^-1 C cap^-1 C^T D^-1 r with library GEMMs
+            C, d = self._root_and_diag()
+            Cd = C / d.unsqueeze(-1)
+            small = torch.cholesky_solve(Cd.mT @ rhs, self.chol_cap_mat)
+            return rhs / d.unsqueeze(-1) - Cd @ small
         pre = self._woodbury_factor()
         batch = torch.broadcast_shapes(self.batch_shape, rhs.shape[:-2])
         return K.precond_apply(pre, rhs.expand(*batch, *rhs.shape[-2:]).contiguous())
@@ -83,6 +99,8 @@ class LowRankRootAddedDiagLinearOperator(AddedDiagLinearOperator):
         """Differentiable: the value comes from the fp64 capacitance Cholesky on the device, the gradient from
         d logdet(C C^T + D) = diag(A^-1) for the diagonal and 2 A^-1 C for the root (_WoodburyLogdet)."""
         C, d = self._root_and_diag()
+        if self._wide_root():  # reference :97-103, differentiated by autograd like there
+            return 2.0 * self.chol_cap_mat.diagonal(dim1=-1, dim2=-2).log().sum(-1) + d.log().sum(-1)
         if not (C.requires_grad or d.requires_grad):
             return self._woodbury_factor().logdet.reshape(self.batch_shape)
         return _WoodburyLogdet.apply(self, C, d).reshape(self.batch_shape)

@@ -751,16 +751,74 @@ def g17_low_rank_root_added_diag_backward():
     save("g17_lowrank_added_diag_backward", checksum=cases.checksum(C, d, rhs, W, sig), **out)
 
 
+def g18_low_rank_root_added_diag_wide_root():
+    """LowRankRootAddedDiagLinearOperator with a root of rank 48 (> 32): solve, inv_quad_logdet and their gradients
+    (low_rank_root_added_diag_linear_operator.py:62-103,117-170)."""
+    from linear_operator.operators import LowRankRootAddedDiagLinearOperator
+
+    print("G18 LowRankRootAddedDiag, rank 48")
+    C, d, rhs = cases.lowrank_diag(1801, 2, 768, 48, 2)
+    W = cases.randn(1802, 2, 768, 2, dtype=np.float32)
+    out = {}
+    Ct, dt, rt = [T(a).clone().requires_grad_(True) for a in (C, d, rhs)]
+    A = LowRankRootLinearOperator(Ct) + DiagLinearOperator(dt)
+    assert isinstance(A, LowRankRootAddedDiagLinearOperator)
+    iq, ld = A.inv_quad_logdet(rt, logdet=True)
+    (iq.sum() + ld.sum()).backward()
+    out.update(iq=iq, ld=ld, dC=Ct.grad, dd=dt.grad, drhs=rt.grad)
+    Ct, dt, rt = [T(a).clone().requires_grad_(True) for a in (C, d, rhs)]
+    A = LowRankRootLinearOperator(Ct) + DiagLinearOperator(dt)
+    x = A.solve(rt)
+    (x * T(W)).sum().backward()
+    out.update(s_x=x, s_dC=Ct.grad, s_dd=dt.grad, s_drhs=rt.grad)
+    save("g18_lowrank_added_diag_rank48", checksum=cases.checksum(C, d, rhs, W), **out)
+
+def g19_kronecker_three_factors():
+    """KroneckerProductLinearOperator of THREE dense factors (kronecker_product_linear_operator.py:34-45, 272-284):
+    matmul, and `AddedDiag(kron, Diag)` solve / inv_quad_logdet with the reference's autograd gradients for the three
+    factors (N = 6 * 8 * 10 = 480 <= max_cholesky_size: the reference's exact Cholesky route)."""
+    print("G19 Kronecker, three factors")
+    K1, K2, _, rhs = cases.kron_factors(1901, 2, 6, 8, 3)
+    K3, _, _, _ = cases.kron_factors(1902, 2, 10, 2, 1)
+    rhs = cases.randn(1903, 2, 480, 3, dtype=np.float32)
+    d = (np.abs(cases.randn(1904, 2, 480, dtype=np.float32)) * 0.2 + 0.3).astype(np.float32)
+    W = cases.randn(1905, 2, 480, 3, dtype=np.float32)
+    out = {}
+
+    def leaves():
+        return [T(x).clone().requires_grad_(True) for x in (K1, K2, K3, d, rhs)]
+
+    k1, k2, k3, dt, rt = leaves()
+    Kp = KroneckerProductLinearOperator(DenseLinearOperator(k1), DenseLinearOperator(k2), DenseLinearOperator(k3))
+    out["mm"] = Kp.matmul(rt)
+    A = AddedDiagLinearOperator(Kp, DiagLinearOperator(dt))
+    x = A.solve(rt)
+    (x * T(W)).sum().backward()
+    out.update(x=x, x_dK1=k1.grad, x_dK2=k2.grad, x_dK3=k3.grad, x_dd=dt.grad, x_drhs=rt.grad)
+    k1, k2, k3, dt, rt = leaves()
+    Kp = KroneckerProductLinearOperator(DenseLinearOperator(k1), DenseLinearOperator(k2), DenseLinearOperator(k3))
+    A = AddedDiagLinearOperator(Kp, DiagLinearOperator(dt))
+    iq, ld = A.inv_quad_logdet(rt, logdet=True)
+    (iq.sum() + (ld * T(np.array([1.5, -0.5], dtype=np.float32))).sum()).backward()
+    out.update(iq=iq, ld=ld, iql_dK1=k1.grad, iql_dK2=k2.grad, iql_dK3=k3.grad, iql_dd=dt.grad, iql_drhs=rt.grad)
+    dense = torch.stack([torch.kron(torch.kron(T(K1)[i].double(), T(K2)[i].double()), T(K3)[i].double()) for i in range(2)])
+    out["mm_exact"] = (dense @ T(rhs).double()).numpy()
+    dense = dense + torch.diag_embed(T(d).double())
+    out["x_exact"] = np.linalg.solve(dense.numpy(), rhs.astype(np.float64))
+    out["ld_exact"] = np.linalg.slogdet(dense.numpy())[1]
+    save("g19_kron_three_factors", checksum=cases.checksum(K1, K2, K3, d, rhs, W), **out)
+
 
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g19", "g18", "g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
                      ("g9", g9_backward), ("g10", g10_backward_preconditioned), ("g11", g11_diagonalization),
                      ("g12", g12_kronecker_added_diag), ("g13", g13_minres),
                      ("g14", g14_sqrt_inv_matmul), ("g15", g15_lanczos_consumers_backward),
-                     ("g16", g16_sum_operators), ("g17", g17_low_rank_root_added_diag_backward)):
+                     ("g16", g16_sum_operators), ("g17", g17_low_rank_root_added_diag_backward),
+                     ("g18", g18_low_rank_root_added_diag_wide_root), ("g19", g19_kronecker_three_factors)):
         if name in todo:
             fn()
     print("done")

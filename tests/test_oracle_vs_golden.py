@@ -607,3 +607,51 @@ def test_g16_sum_operators():
     assert np.allclose(L2, g["psd_pc_L"], rtol=1e-5, atol=1e-6)
     x2, info2, _ = orc.solve(mm2, src2, d, rhs, tolerance=1e-4)
     assert info2.matvecs == int(g["psd_matvecs"]) and max_rel_err_cols(x2, g["psd_x"]) < 1e-4
+
+
+def test_g18_low_rank_root_added_diag_rank48():
+    """The rank-48 root (beyond the kernels' 32-column Woodbury algebra): the reference's fp32 solve / inv_quad / logdet
+    against the oracle's fp64 Woodbury forms."""
+    g = load_golden("g18_lowrank_added_diag_rank48")
+    C, d, rhs = cases.lowrank_diag(1801, 2, 768, 48, 2)
+    W = cases.randn(1802, 2, 768, 2, dtype=np.float32)
+    assert cases.checksum(C, d, rhs, W) == g["checksum"]
+    C64, d64, r64 = C.astype(np.float64), d.astype(np.float64), rhs.astype(np.float64)
+    x = orc.woodbury_solve(C64, d64, r64)
+    assert max_rel_err_cols(x, g["s_x"]) < 1e-4
+    assert np.allclose((r64 * x).sum((-2, -1)), g["iq"], rtol=1e-4)
+    dense = C64 @ C64.transpose(0, 2, 1) + np.stack([np.diag(v) for v in d64])
+    assert np.allclose(np.linalg.slogdet(dense)[1], g["ld"], rtol=1e-5)
+
+
+def _g19_inputs():
+    K1, K2, _, _ = cases.kron_factors(1901, 2, 6, 8, 3)
+    K3, _, _, _ = cases.kron_factors(1902, 2, 10, 2, 1)
+    rhs = cases.randn(1903, 2, 480, 3, dtype=np.float32)
+    d = (np.abs(cases.randn(1904, 2, 480, dtype=np.float32)) * 0.2 + 0.3).astype(np.float32)
+    W = cases.randn(1905, 2, 480, 3, dtype=np.float32)
+    return K1, K2, K3, d, rhs, W
+
+
+def test_g19_kronecker_three_factors():
+    """Three Kronecker factors: the oracle's two-factor matvec on the regrouped product (K1 (x) K2) (x) K3 -- the
+    lowering the HIP path uses -- against the reference's matmul, and the reference's solve / logdet / factor gradients
+    against the dense fp64 values."""
+    g = load_golden("g19_kron_three_factors")
+    K1, K2, K3, d, rhs, W = _g19_inputs()
+    assert cases.checksum(K1, K2, K3, d, rhs, W) == g["checksum"]
+    K12 = np.stack([np.kron(K1[b].astype(np.float64), K2[b].astype(np.float64)) for b in range(2)])
+    mm = orc.matvec_kron(K12.astype(np.float64), K3.astype(np.float64), rhs.astype(np.float64))
+    assert max_rel_err_cols(mm, g["mm_exact"]) < 1e-12 and max_rel_err_cols(g["mm"], mm) < 1e-5
+    assert max_rel_err_cols(g["x"], g["x_exact"]) < 1e-4 and np.allclose(g["ld"], g["ld_exact"], rtol=1e-5)
+    close = lambda a, b, rel: np.abs(a - b).max() <= rel * np.abs(b).max()  # noqa: E731
+    w = np.array([1.5, -0.5])
+    for b in range(2):
+        k1, k2, k3 = (k[b].astype(np.float64) for k in (K1, K2, K3))
+        G = np.linalg.inv(np.kron(np.kron(k1, k2), k3) + np.diag(d[b].astype(np.float64)))
+        xb = g["x_exact"][b]
+        Gt = (w[b] * G - xb @ xb.T).reshape(6, 8, 10, 6, 8, 10)  # d(iq.sum + w ld) / dA
+        assert close(g["iql_dK1"][b], np.einsum("iakjbl,ab,kl->ij", Gt, k2, k3), 2e-3)
+        assert close(g["iql_dK2"][b], np.einsum("iakjbl,ij,kl->ab", Gt, k1, k3), 2e-3)
+        assert close(g["iql_dK3"][b], np.einsum("iakjbl,ij,ab->kl", Gt, k1, k2), 2e-3)
+        assert close(g["iql_dd"][b], np.diag(Gt.reshape(480, 480)), 2e-3)

@@ -1,2 +1,2 @@
 #!/bin/bash
-python tools/mb_kron_rate.py 2>&1 | tail -10
+python -m pytest tests/test_gpu_api.py -q -x -k "three_factors or rank_above_32 or kron" > gpurun_out/pytest_gpu.log 2>&1; tail -30 gpurun_out/pytest_gpu.log
