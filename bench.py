@@ -428,6 +428,11 @@ def main():
         os.close(real_stdout)
         return
 
+    if use_dist:
+        # The all-gather of solve k runs on RCCL's stream while solve k + 1 computes.  The resident CG kernel fills every
+        # CU with two workgroups; a workgroup RCCL's kernel displaces stalls its whole group until the gather ends.
+        # Leaving 32 CUs' worth of slots unused (liblo_amd reads the variable at every launch) gives RCCL room.
+        os.environ.setdefault("LO_OC_RESERVE_CUS", "32")
     Cm, d, rhs = make_problem(device, 1234 + rank)
     desc = K.lowrank_diag_descriptor(Cm, d)
     pre = build_precond(desc, d)
@@ -558,7 +563,9 @@ def main():
                 "batch_per_gpu": B_PER_GPU, "N": N, "R": R, "rhs_columns": C_COLS, "precond_rank": RANK_K,
                 "iterations": res.iterations, "matvecs_per_solve": matvecs_per_solve,
                 "sharding": (f"batch x{world}, one all_gather of the solutions per solve, issued asynchronously and overlapped "
-                             "with the next solve") if world > 1 else "single GPU",
+                             "with the next solve; resident kernels leave "
+                             f"{os.environ.get('LO_OC_RESERVE_CUS', '0')} CUs' worth of slots to RCCL")
+                if world > 1 else "single GPU",
             },
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

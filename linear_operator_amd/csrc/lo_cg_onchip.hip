@@ -24,6 +24,7 @@
 // evaluated by lo_cg.hip's control kernel, which continues with the streaming loop in the (rare) case that the
 // tolerance is not yet met.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "lo_device.h"
 #include "lo_internal.h"
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(OC_TPB) void k_cg_onchip(OnchipArgs a) {
   const int groups_per_xcd = (gridDim.x / 8) / OC_GW;
   const int grp = xcd * groups_per_xcd + j / OC_GW;
   const int wig = j % OC_GW;
-  const int ngroups = gridDim.x / OC_GW;
+  const int ngroups = groups_per_xcd * 8;
   if (j / OC_GW >= groups_per_xcd) return;  // grid not a multiple of 64: spare workgroups idle
   const int t = threadIdx.x;
   unsigned long long* gslot = a.gbuf + (size_t)grp * 2 * OC_GW * 40;
@@ -426,7 +427,12 @@ int onchip_num_workgroups() {
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
   int cus = prop.multiProcessorCount;
-  return (cus / 64) * 64;  // multiple of 8 XCDs x 8 workgroups per group
+  // LO_OC_RESERVE_CUS=<n>: leave n CUs' worth of workgroup slots unused so that a concurrently running collective
+  // (RCCL's all-gather kernel on its own stream) finds room WITHOUT displacing workgroups of a resident group -- a
+  // displaced workgroup stalls its whole group until the other kernel ends.  The spare slots end up scattered over the
+  // CUs (the dispatcher balances), each big enough for a 256-thread workgroup of <= 256 VGPRs.
+  if (const char* e = getenv("LO_OC_RESERVE_CUS")) cus = std::max(64, cus - std::max(0, atoi(e)));
+  return (cus / 32) * 32;  // 2 workgroups per CU: a multiple of 8 XCDs x 8 workgroups per group
 }
 
 int onchip_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st) {

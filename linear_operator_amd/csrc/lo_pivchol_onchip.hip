@@ -266,7 +266,7 @@ __global__ __launch_bounds__(PO_TPB) void k_pc_onchip(PoArgs a) {
   const int groups_per_xcd = (gridDim.x / 8) / PO_GW;
   const int grp = xcd * groups_per_xcd + jx / PO_GW;
   const int wig = jx % PO_GW;
-  const int ngroups = gridDim.x / PO_GW;
+  const int ngroups = groups_per_xcd * 8;
   if (jx / PO_GW >= groups_per_xcd) return;
   const int t = threadIdx.x;
   unsigned long long* gslot = a.gbuf + (size_t)grp * 2 * PO_GW * PO_SLOT;

@@ -220,3 +220,32 @@ def test_resident_kernels_next_to_unrelated_work_on_another_stream():
             bad += int(not torch.equal(x, ref)) + int(not torch.equal(Lx, L)) + int(not torch.equal(x16, ref16))
         torch.cuda.synchronize()
         assert bad == 0, f"{bad} mismatches with background {kind} work"
+
+
+def test_reserved_cus_leave_results_bit_identical(monkeypatch):
+    """LO_OC_RESERVE_CUS (set by bench.py when RCCL's all-gather overlaps the next solve) shrinks the resident kernels'
+    grids: fewer groups, the same per-member arithmetic -- solutions, pivots and factors must not change by a bit."""
+    import numpy as np
+    from linear_operator_amd import kernels as K
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    B, N, R = 200, 8192, 32
+    Cm = torch.randn(B, N, R, generator=g, device="cuda") / R ** 0.5
+    d = torch.rand(B, N, generator=g, device="cuda") + 0.5
+    rhs = torch.randn(B, N, 17, generator=g, device="cuda")
+
+    def run():
+        L, perm = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15, contiguous=False)
+        pre = K.precond_build(L, d, False, root=Cm, perm=perm)
+        r = K.cg_solve(K.lowrank_diag_descriptor(Cm, d), rhs, precond=pre, n_tridiag=16, tolerance=1e-4)
+        return L.clone(), perm.clone(), r.x.clone(), r.t_mat.clone(), r.iterations
+
+    ref = run()
+    for reserve in ("32", "64", "100"):
+        monkeypatch.setenv("LO_OC_RESERVE_CUS", reserve)
+        got = run()
+        assert got[4] == ref[4]
+        for a, b in zip(got[:4], ref[:4]):
+            assert torch.equal(a, b), reserve
+    monkeypatch.delenv("LO_OC_RESERVE_CUS")
