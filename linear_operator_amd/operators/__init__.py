@@ -4,7 +4,7 @@ from .added_diag_linear_operator import AddedDiagLinearOperator
 from .dense_linear_operator import DenseLinearOperator, to_linear_operator
 from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
 from .identity_linear_operator import IdentityLinearOperator
-from .kronecker_product_linear_operator import KroneckerProductLinearOperator
+from .kronecker_product_linear_operator import KroneckerProductDiagLinearOperator, KroneckerProductLinearOperator
 from .kronecker_product_added_diag_linear_operator import KroneckerProductAddedDiagLinearOperator
 from .linear_operator_representation_tree import LinearOperatorRepresentationTree
 from .low_rank_root_added_diag_linear_operator import LowRankRootAddedDiagLinearOperator
@@ -14,7 +14,7 @@ from .sum_linear_operator import PsdSumLinearOperator, SumLinearOperator
 __all__ = [
     "LowRankRootAddedDiagLinearOperator", "KroneckerProductAddedDiagLinearOperator",
     "LinearOperator", "to_dense", "to_linear_operator", "AddedDiagLinearOperator", "DenseLinearOperator",
-    "DiagLinearOperator", "ConstantDiagLinearOperator", "IdentityLinearOperator", "KroneckerProductLinearOperator",
+    "DiagLinearOperator", "ConstantDiagLinearOperator", "IdentityLinearOperator", "KroneckerProductLinearOperator", "KroneckerProductDiagLinearOperator",
     "LinearOperatorRepresentationTree", "RootLinearOperator", "LowRankRootLinearOperator", "SumLinearOperator",
     "PsdSumLinearOperator",
 ]

@@ -67,6 +67,12 @@ class DiagLinearOperator(LinearOperator):
     def logdet(self):
         return self._diag.log().sum(-1)
 
+    def abs(self):
+        return DiagLinearOperator(self._diag.abs())
+
+    def sqrt(self):
+        return DiagLinearOperator(self._diag.sqrt())
+
     def solve(self, right_tensor: Tensor, left_tensor=None) -> Tensor:
         res = self.inverse()._matmul(right_tensor)
         return left_tensor @ res if left_tensor is not None else res
@@ -121,6 +127,12 @@ class ConstantDiagLinearOperator(DiagLinearOperator):
 
     def inverse(self):
         return self.__class__(self.diag_values.reciprocal(), diag_shape=self.diag_shape)
+
+    def abs(self):
+        return self.__class__(self.diag_values.abs(), diag_shape=self.diag_shape)
+
+    def sqrt(self):
+        return self.__class__(self.diag_values.sqrt(), diag_shape=self.diag_shape)
 
 
 __all__ = ["DiagLinearOperator", "ConstantDiagLinearOperator"]

@@ -7,8 +7,13 @@ Constant diagonal sigma^2 I (the GP noise case): no CG at all.  Per-factor symme
     (K + sigma^2 I)^-1 r = Q (Q^T r / (lambda + sigma^2)),   Q = Q_1 (x) Q_2,  lambda = L_1 (x) L_2          (:153-161)
     logdet = sum log(lambda + sigma^2)                                                                        (:86-90)
 and the two products with Q / Q^T over the N = prod n_i rows run on the Kronecker matvec kernels (csrc/lo_kron.hip).
+Kronecker-structured diagonal D = D_1 (x) .. (x) D_P with the factor shapes of K (:94-128, :166-219; the multitask
+noise model): K + D = D^1/2 (S + I) D^1/2 with S = (x)_i D_i^-1/2 K_i D_i^-1/2 = Q Lambda Q^T per factor, so
+    (K + D)^-1 r = D^-1/2 Q ((Lambda + 1)^-1 (Q^T D^-1/2 r)),    logdet = sum log d + sum log(lambda + 1)
+-- ONE formulation for the reference's two branches (factors with constant diagonals are the case where Q_i are the
+eigenvectors of K_i themselves, :189-193).
 Other diagonals follow the reference's last branch: the AddedDiag CG path, WITHOUT a preconditioner (:132-134).
-The Kronecker-structured-diagonal branches (:166-219) and the lazy Matmul roots (:224-294) are not on this path."""
+The lazy Matmul roots (:224-294) are not on this path."""
 from __future__ import annotations
 
 import torch
@@ -17,7 +22,8 @@ from torch import Tensor
 from .. import _hip
 from .added_diag_linear_operator import AddedDiagLinearOperator
 from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
-from .kronecker_product_linear_operator import KroneckerProductLinearOperator
+from .kronecker_product_linear_operator import KroneckerProductDiagLinearOperator, KroneckerProductLinearOperator
+from .. import settings
 
 
 class KroneckerProductAddedDiagLinearOperator(AddedDiagLinearOperator):
@@ -35,6 +41,7 @@ class KroneckerProductAddedDiagLinearOperator(AddedDiagLinearOperator):
             )
         self._diag_is_constant = isinstance(self.diag_tensor, ConstantDiagLinearOperator)
         self._eig_cache = None
+        self._sym_cache = None
 
     # ------------------------------------------------------------------ eigendecomposition of the factors
     def _factor_eig(self):
@@ -54,7 +61,42 @@ class KroneckerProductAddedDiagLinearOperator(AddedDiagLinearOperator):
             return op._symeig(eigenvectors=True, symeig_dtype_evals=True)
         return op._symeig(eigenvectors=True)
 
+    # ------------------------------------------------------------------ Kronecker-structured diagonal
+    def _structured(self) -> bool:
+        lt, dlt = self.linear_op, self.diag_tensor
+        return (isinstance(dlt, KroneckerProductDiagLinearOperator) and isinstance(lt, KroneckerProductLinearOperator)
+                and len(lt.linear_ops) == len(dlt.linear_ops)
+                and all(a.shape[-1] == b.shape[-1] for a, b in zip(lt.linear_ops, dlt.linear_ops)))
+
+    def _symmetrized_eig(self, detach: bool):
+        """(D^-1/2 as a vector [*batch, N], eigenvalues of S [*batch, N], Q) in the symeig dtype; per-factor eigh."""
+        dt = settings._linalg_dtype_symeig.value()
+        roots, evals, evecs = [], None, []
+        for k_op, d_op in zip(self.linear_op.linear_ops, self.diag_tensor.linear_ops):
+            kd, dd = k_op.to_dense(), d_op._diag
+            if detach:
+                kd, dd = kd.detach(), dd.detach()
+            ir = dd.to(dt).rsqrt()
+            ev, q = torch.linalg.eigh(ir.unsqueeze(-1) * kd.to(dt) * ir.unsqueeze(-2))
+            ev = ev.clamp_min(0.0)
+            roots.append(DiagLinearOperator(ir))
+            evals = ev if evals is None else (evals.unsqueeze(-1) * ev.unsqueeze(-2)).reshape(*ev.shape[:-1], -1)
+            evecs.append(q)
+        return KroneckerProductDiagLinearOperator(*roots)._diag, evals, evecs
+
+    def _solve_structured(self, rhs: Tensor) -> Tensor:
+        if self._sym_cache is None:
+            with torch.no_grad():
+                ir, evals, evecs = self._symmetrized_eig(detach=True)
+                q = KroneckerProductLinearOperator(*[e.to(self.dtype) for e in evecs])
+                self._sym_cache = (ir.to(self.dtype).unsqueeze(-1), (evals + 1.0).reciprocal().to(self.dtype).unsqueeze(-1),
+                                   q._transpose_nonbatch(), q)
+        ir, inv, q_t, q = self._sym_cache
+        return ir * q._matmul(inv * q_t._matmul(ir * rhs))
+
     def _solve(self, rhs: Tensor, preconditioner=None, num_tridiag: int = 0):
+        if not self._diag_is_constant and self._structured():
+            return self._solve_structured(rhs)
         if not self._diag_is_constant:
             return super()._solve(rhs, preconditioner=preconditioner, num_tridiag=num_tridiag)
         if isinstance(self.linear_op, KroneckerProductLinearOperator) and len(self.linear_op.linear_ops) == 2:
@@ -75,6 +117,9 @@ class KroneckerProductAddedDiagLinearOperator(AddedDiagLinearOperator):
         if self._diag_is_constant:  # :86-90, differentiable through the factors' eigh
             evals, _ = self._symeig_of_product(self.linear_op)
             return torch.log(evals + self.diag_tensor._diagonal().to(evals.dtype)).sum(dim=-1).to(self.dtype)
+        if self._structured():  # :94-128, differentiable through the factors' eigh and the diagonal factors
+            ir, evals, _ = self._symmetrized_eig(detach=False)
+            return (torch.log1p(evals).sum(dim=-1) - 2.0 * ir.log().sum(dim=-1)).to(self.dtype)
         return super().inv_quad_logdet(logdet=True)[1]
 
     def inv_quad_logdet(self, inv_quad_rhs=None, logdet: bool = False, reduce_inv_quad: bool = True):  # :68-82

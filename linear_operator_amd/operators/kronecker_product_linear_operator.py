@@ -16,6 +16,7 @@ from .. import settings
 from ..utils.broadcasting import _matmul_broadcast_shape
 from ._linear_operator import LinearOperator
 from .dense_linear_operator import DenseLinearOperator, to_linear_operator
+from .diag_linear_operator import DiagLinearOperator
 
 
 def _kron_diag(*ops) -> Tensor:
@@ -143,7 +144,7 @@ class KroneckerProductLinearOperator(LinearOperator):
         from .diag_linear_operator import ConstantDiagLinearOperator, DiagLinearOperator
         from .kronecker_product_added_diag_linear_operator import KroneckerProductAddedDiagLinearOperator
 
-        if isinstance(other, ConstantDiagLinearOperator):
+        if isinstance(other, (KroneckerProductDiagLinearOperator, ConstantDiagLinearOperator)):
             return KroneckerProductAddedDiagLinearOperator(self, other)
         if isinstance(other, DiagLinearOperator):
             return self.add_diagonal(other._diagonal())
@@ -248,4 +249,63 @@ class KroneckerProductLinearOperator(LinearOperator):
         return res
 
 
-__all__ = ["KroneckerProductLinearOperator"]
+class KroneckerProductDiagLinearOperator(DiagLinearOperator):
+    """D_1 (x) .. (x) D_P of diagonal operators (reference :436-541): a diagonal whose N = prod n_i entries are never
+    stored as leaves -- the representation is the factors' own tensors, so gradients reach the factors."""
+
+    def __init__(self, *linear_ops):
+        if not all(isinstance(op, DiagLinearOperator) for op in linear_ops):
+            raise RuntimeError("Components of KroneckerProductDiagLinearOperator must be DiagLinearOperator.")
+        LinearOperator.__init__(self, *linear_ops)
+        self.linear_ops = linear_ops
+
+    @property
+    def _diag(self) -> Tensor:
+        return _kron_diag(*self.linear_ops)
+
+    def _size(self) -> torch.Size:
+        shapes = [op._diag.shape for op in self.linear_ops]
+        n = math.prod(sh[-1] for sh in shapes)
+        return torch.Size((*torch.broadcast_shapes(*(sh[:-1] for sh in shapes)), n, n))
+
+    def _expand_batch(self, batch_shape):
+        return self.__class__(*[op._expand_batch(batch_shape) for op in self.linear_ops])
+
+    def _bilinear_derivative(self, left_vecs: Tensor, right_vecs: Tensor):
+        """sum_cols u o v is the gradient of the full diagonal [*batch, N]; factor i receives its contraction with the
+        other factors' diagonals, handed to the factor's own rule (full / constant diagonal)."""
+        g = K.bilinear_diag(left_vecs, right_vecs, self.batch_shape)
+        diags = [op._diag for op in self.linear_ops]
+        p = len(diags)
+        g = g.reshape(*g.shape[:-1], *(dg.shape[-1] for dg in diags))
+        idx = "abcdefgh"[:p]
+        out = []
+        for i, op in enumerate(self.linear_ops):
+            if p == 1:
+                gi = g
+            else:
+                others = ",".join(f"...{idx[j]}" for j in range(p) if j != i)
+                gi = torch.einsum(f"...{idx},{others}->...{idx[i]}", g, *[diags[j] for j in range(p) if j != i])
+            leaf = op.representation()[0]
+            if leaf.shape[-1] == 1 and op._diag.shape[-1] != 1:  # constant factor: d(sigma) = sum of its diagonal's
+                gi = gi.sum(-1, keepdim=True)
+            out.append(gi if tuple(gi.shape) == tuple(leaf.shape) else gi.sum_to_size(*leaf.shape))
+        return tuple(out)
+
+    def abs(self):
+        return self.__class__(*[op.abs() for op in self.linear_ops])
+
+    def sqrt(self):
+        return self.__class__(*[op.sqrt() for op in self.linear_ops])
+
+    def inverse(self):
+        return self.__class__(*[op.inverse() for op in self.linear_ops])
+
+    def exp(self):
+        raise NotImplementedError(f"torch.exp({self.__class__.__name__}) is not implemented.")
+
+    def log(self):
+        raise NotImplementedError(f"torch.log({self.__class__.__name__}) is not implemented.")
+
+
+__all__ = ["KroneckerProductLinearOperator", "KroneckerProductDiagLinearOperator"]

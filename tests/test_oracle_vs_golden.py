@@ -655,3 +655,35 @@ def test_g19_kronecker_three_factors():
         assert close(g["iql_dK2"][b], np.einsum("iakjbl,ij,kl->ab", Gt, k1, k3), 2e-3)
         assert close(g["iql_dK3"][b], np.einsum("iakjbl,ij,ab->kl", Gt, k1, k2), 2e-3)
         assert close(g["iql_dd"][b], np.diag(Gt.reshape(480, 480)), 2e-3)
+
+
+def _g20_inputs():
+    K1, K2, _, _ = cases.kron_factors(2001, 2, 6, 8, 3)
+    rhs = cases.randn(2002, 2, 48, 3, dtype=np.float32)
+    W = cases.randn(2003, 2, 48, 3, dtype=np.float32)
+    d1 = (np.abs(cases.randn(2004, 2, 6, dtype=np.float32)) * 0.3 + 0.4).astype(np.float32)
+    d2 = (np.abs(cases.randn(2005, 2, 8, dtype=np.float32)) * 0.3 + 0.4).astype(np.float32)
+    c1 = np.array([[0.6], [0.9]], dtype=np.float32)
+    c2 = np.array([[0.5], [0.3]], dtype=np.float32)
+    return K1, K2, rhs, W, d1, d2, c1, c2
+
+
+def test_g20_kronecker_structured_diagonal():
+    """KroneckerProduct + KroneckerProductDiag: the reference's structured solve / logdet against the dense fp64 values,
+    and the symmetrised eigendecomposition form the HIP path uses ((K + D)^-1 = D^-1/2 Q (L + 1)^-1 Q^T D^-1/2 with
+    D_i^-1/2 K_i D_i^-1/2 = Q_i L_i Q_i^T) restated in numpy."""
+    g = load_golden("g20_kron_structured_diag")
+    K1, K2, rhs, W, d1, d2, c1, c2 = _g20_inputs()
+    assert cases.checksum(K1, K2, rhs, W, d1, d2, c1, c2) == g["checksum"]
+    for tag, (a, b) in (("full", (d1, d2)), ("const", (np.broadcast_to(c1, (2, 6)), np.broadcast_to(c2, (2, 8))))):
+        assert max_rel_err_cols(g[f"{tag}_x"], g[f"{tag}_x_exact"]) < 1e-4
+        if tag == "full":
+            assert np.allclose(g["full_ld"], g["full_ld_exact"], rtol=1e-5)
+        for i in range(2):
+            ia, ib = 1 / np.sqrt(a[i].astype(np.float64)), 1 / np.sqrt(b[i].astype(np.float64))
+            l1, q1 = np.linalg.eigh(ia[:, None] * K1[i].astype(np.float64) * ia[None, :])
+            l2, q2 = np.linalg.eigh(ib[:, None] * K2[i].astype(np.float64) * ib[None, :])
+            ir, lam, q = np.kron(ia, ib), np.kron(l1, l2), np.kron(q1, q2)
+            x = ir[:, None] * (q @ ((q.T @ (ir[:, None] * rhs[i].astype(np.float64))) / (lam + 1)[:, None]))
+            assert max_rel_err_cols(x, g[f"{tag}_x_exact"][i]) < 1e-10
+            assert abs(np.log1p(lam).sum() - 2 * np.log(ir).sum() - g[f"{tag}_ld_exact"][i]) < 1e-9
