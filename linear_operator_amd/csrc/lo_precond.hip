@@ -712,6 +712,230 @@ __global__ __launch_bounds__(64) void k_pb_rootform(const double* __restrict__ g
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide preconditioners, 32 < k <= 128 (settings.max_preconditioner_size beyond the register-resident algebra above).
+// Same mathematics -- G = I + W^T W in fp64, G = T T^T, Q = W T^-T -- as three plain kernels:
+//   k_pbw_gram : 32 x 32 tiles of the lower triangle of W^T W, fp64 accumulation of fp32 products, rows staged in LDS;
+//   k_pbw_chol : one workgroup per member, T and X = T^-1 packed lower-triangular in LDS (2 x 66 KB at k = 128), logdet;
+//   k_pbw_q    : Q = (W X^T) per 64-row tile, 4 x 8 register tile per thread, fp32.
+constexpr int kPbWideMaxK = 128;
+constexpr int kPbwRows = 64;  // rows staged per step
+
+__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // packed lower triangle, j <= i
+
+// grid (S, tile pairs, B); tile pair p -> (ti >= tj).  gpart [B, S, k, k]: only the lower triangle is written.
+__global__ __launch_bounds__(kThreads) void k_pbw_gram(const float* __restrict__ L, LStride ls,
+                                                        const float* __restrict__ sc, int N, int k, int rows_per,
+                                                        double* __restrict__ gpart) {
+  __shared__ float wi[kPbwRows][33];
+  __shared__ float wj[kPbwRows][33];
+  const int s = blockIdx.x, S = gridDim.x;
+  const int64_t b = blockIdx.z;
+  int ti = 0, p = blockIdx.y;
+  while (p > ti) { p -= ti + 1; ++ti; }
+  const int tj = p;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  const int ta = threadIdx.x >> 4, tb = threadIdx.x & 15;  // outputs (2 ta + {0,1}, 2 tb + {0,1}) of the tile
+  double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  const float* Lb = L + (size_t)b * ls.member;
+  for (int rc = r0; rc < r1; rc += kPbwRows) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < kPbwRows * 32; e += kThreads) {
+      int rr, cc;
+      if (ls.row == 1) { rr = e % kPbwRows; cc = e / kPbwRows; } else { cc = e & 31; rr = e >> 5; }
+      const int row = rc + rr;
+      float vi = 0.f, vj = 0.f;
+      if (row < r1) {
+        const float f = sc ? sc[(size_t)b * N + row] : 1.0f;
+        const int ci = 32 * ti + cc, cj = 32 * tj + cc;
+        if (ci < k) vi = L[(size_t)b * ls.member + (size_t)row * ls.row + (size_t)ci * ls.col] * f;
+        if (cj < k) vj = (ti == tj) ? vi : L[(size_t)b * ls.member + (size_t)row * ls.row + (size_t)cj * ls.col] * f;
+      }
+      wi[rr][cc] = vi;
+      wj[rr][cc] = vj;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int rr = 0; rr < kPbwRows; ++rr) {
+      const double a0 = wi[rr][2 * ta], a1 = wi[rr][2 * ta + 1];
+      const double b0 = wj[rr][2 * tb], b1 = wj[rr][2 * tb + 1];
+      acc[0][0] = fma(a0, b0, acc[0][0]); acc[0][1] = fma(a0, b1, acc[0][1]);
+      acc[1][0] = fma(a1, b0, acc[1][0]); acc[1][1] = fma(a1, b1, acc[1][1]);
+    }
+  }
+  (void)Lb;
+  double* g = gpart + ((size_t)b * S + s) * k * k;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int i = 32 * ti + 2 * ta + x, j = 32 * tj + 2 * tb + y;
+      if (i < k && j <= i) g[(size_t)i * k + j] = acc[x][y];
+    }
+}
+
+// One workgroup per member.  Dynamic LDS: T (packed lower) | X (packed lower), k (k + 1) doubles.
+// Xt [B, k, k] fp32: Xt[c][a] = X[a][c] (c <= a), zero above -- the operand layout k_pbw_q reads.
+__global__ __launch_bounds__(kThreads) void k_pbw_chol(const double* __restrict__ gpart, const double* __restrict__ logd_part,
+                                                        const float* __restrict__ dd, int diag_mode, int N, int k, int S,
+                                                        float* __restrict__ Xt, float* __restrict__ logdet,
+                                                        float* __restrict__ dinv_const) {
+  extern __shared__ double tx[];
+  const int np = k * (k + 1) / 2;
+  double* T = tx;
+  double* X = tx + np;
+  const int64_t b = blockIdx.x;
+  const int t = threadIdx.x;
+  const double sigma = (diag_mode == LO_DIAG_CONST) ? (double)dd[b] : 1.0;
+  for (int e = t; e < np; e += kThreads) {
+    int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+    while (tri(i + 1, 0) <= e) ++i;
+    while (tri(i, 0) > e) --i;
+    const int j = e - tri(i, 0);
+    double v = 0.0;
+    for (int s = 0; s < S; ++s) v += gpart[(((size_t)b * S + s) * k + i) * k + j];  // fixed order
+    if (diag_mode == LO_DIAG_CONST) v /= sigma;
+    T[e] = v + (i == j ? 1.0 : 0.0);
+  }
+  // right-looking Cholesky, column by column
+  for (int j = 0; j < k; ++j) {
+    __syncthreads();
+    const double piv = sqrt(T[tri(j, j)]);
+    __syncthreads();
+    for (int i = j + t; i < k; i += kThreads) T[tri(i, j)] = (i == j) ? piv : T[tri(i, j)] / piv;
+    __syncthreads();
+    const int m = k - j - 1;  // trailing block rows j+1 .. k-1
+    for (int e = t; e < m * (m + 1) / 2; e += kThreads) {
+      int ii = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
+      while (tri(ii + 1, 0) <= e) ++ii;
+      while (tri(ii, 0) > e) --ii;
+      const int ll = e - tri(ii, 0);
+      const int i = j + 1 + ii, l = j + 1 + ll;
+      T[tri(i, l)] = fma(-T[tri(i, j)], T[tri(l, j)], T[tri(i, l)]);
+    }
+  }
+  __syncthreads();
+  // X = T^-1, one column per thread (forward substitution down the column)
+  for (int c = t; c < k; c += kThreads) {
+    X[tri(c, c)] = 1.0 / T[tri(c, c)];
+    for (int i = c + 1; i < k; ++i) {
+      double sacc = 0.0;
+      for (int l = c; l < i; ++l) sacc = fma(T[tri(i, l)], X[tri(l, c)], sacc);
+      X[tri(i, c)] = -sacc / T[tri(i, i)];
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < k * k; e += kThreads) {
+    const int c = e / k, a = e % k;
+    Xt[(size_t)b * k * k + e] = (c <= a) ? (float)X[tri(a, c)] : 0.f;
+  }
+  if (t == 0) {
+    double ldt = 0.0;
+    for (int j = 0; j < k; ++j) ldt += log(T[tri(j, j)]);
+    ldt *= 2.0;
+    if (diag_mode == LO_DIAG_CONST) {
+      ldt += (double)N * log(sigma);
+      dinv_const[b] = (float)(1.0 / sigma);
+    } else {
+      double acc = 0.0;
+      for (int s = 0; s < S; ++s) acc += logd_part[b * S + s];
+      ldt += acc;
+    }
+    logdet[b] = (float)ldt;
+  }
+}
+
+// Q[row][a] = (1 / d_row) sum_c L[row][c] Xt[c][a].  grid (row tiles of 64, B); dynamic LDS: Xt (k x ldq)
+// | L tile transposed (k x 64).
+__global__ __launch_bounds__(kThreads) void k_pbw_q(const float* __restrict__ L, LStride ls, const float* __restrict__ sc,
+                                                     const float* __restrict__ dd, int diag_mode, int N, int k, int ldq,
+                                                     const float* __restrict__ Xt, float* __restrict__ Q) {
+  extern __shared__ float qs[];
+  float* xs = qs;                       // [k][ldq]
+  float* lt = qs + (size_t)k * ldq;     // [k][64]
+  const int64_t b = blockIdx.y;
+  const int r0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+  for (int e = t; e < k * ldq; e += kThreads) {
+    const int c = e / ldq, a = e % ldq;
+    xs[e] = (a < k) ? Xt[(size_t)b * k * k + (size_t)c * k + a] : 0.f;
+  }
+  for (int e = t; e < k * 64; e += kThreads) {
+    int rr, cc;
+    if (ls.row == 1) { rr = e & 63; cc = e >> 6; } else { cc = e % k; rr = e / k; }
+    const int row = r0 + rr;
+    lt[cc * 64 + rr] = (row < N) ? L[(size_t)b * ls.member + (size_t)row * ls.row + (size_t)cc * ls.col] : 0.f;
+  }
+  __syncthreads();
+  const int tr = t >> 4, ta = t & 15;  // rows 4 tr .. + 3; columns a = 8 ta + 128 h .. + 7
+  for (int a0 = 8 * ta; a0 < ldq; a0 += 128) {
+    float acc[4][8];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 8; ++y) acc[x][y] = 0.f;
+    for (int c = 0; c < k; ++c) {
+      const float4 l4 = *reinterpret_cast<const float4*>(&lt[c * 64 + 4 * tr]);
+      const float4 xa = *reinterpret_cast<const float4*>(&xs[(size_t)c * ldq + a0]);
+      const float4 xb = *reinterpret_cast<const float4*>(&xs[(size_t)c * ldq + a0 + 4]);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
+      const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 8; ++y) acc[x][y] = fmaf(lv[x], xv[y], acc[x][y]);
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int row = r0 + 4 * tr + x;
+      if (row >= N) continue;
+      // Q = D^-1/2 W T^-T with W = D^-1/2 L: the row factor is 1/d
+      const float f = (diag_mode == LO_DIAG_CONST) ? 1.0f / dd[b] : sc[(size_t)b * N + row] * sc[(size_t)b * N + row];
+      float4 o0 = make_float4(acc[x][0] * f, acc[x][1] * f, acc[x][2] * f, acc[x][3] * f);
+      float4 o1 = make_float4(acc[x][4] * f, acc[x][5] * f, acc[x][6] * f, acc[x][7] * f);
+      float* q = Q + ((size_t)b * N + row) * ldq + a0;
+      *reinterpret_cast<float4*>(q) = o0;
+      *reinterpret_cast<float4*>(q + 4) = o1;
+    }
+  }
+}
+
+static int precond_build_wide(const float* L, LStride ls, const float* d, int diag_mode, int64_t B, int64_t N, int k,
+                              float* Q, float* dinv, float* logdet_p, double* gpart, double* logd, float* Xt,
+                              float* scale, Split sp, hipStream_t st) {
+  const int ldq = padded_k(k);
+  dim3 block(kThreads);
+  const float* sc = nullptr;
+  if (diag_mode == LO_DIAG_FULL) {
+    LO_PROF_BEGIN("pb_scale", st);
+    hipLaunchKernelGGL(k_pb_scale, dim3(sp.S, (unsigned)B), block, 0, st, d, (int)N, sp.rows, scale, dinv, logd);
+    LO_PROF_END(st);
+    sc = scale;
+  }
+  const int nt = (k + 31) / 32;
+  LO_PROF_BEGIN("pbw_gram", st);
+  hipLaunchKernelGGL(k_pbw_gram, dim3(sp.S, nt * (nt + 1) / 2, (unsigned)B), block, 0, st, L, ls, sc, (int)N, k, sp.rows,
+                     gpart);
+  LO_PROF_END(st);
+  const size_t chol_lds = (size_t)k * (k + 1) * sizeof(double);
+  LO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pbw_chol), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)chol_lds));
+  LO_PROF_BEGIN("pbw_chol", st);
+  hipLaunchKernelGGL(k_pbw_chol, dim3((unsigned)B), block, chol_lds, st, gpart, logd, d, diag_mode, (int)N, k, sp.S, Xt,
+                     logdet_p, dinv);
+  LO_PROF_END(st);
+  const size_t q_lds = ((size_t)k * ldq + (size_t)k * 64) * sizeof(float);
+  LO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pbw_q), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)q_lds));
+  LO_PROF_BEGIN("pbw_q", st);
+  hipLaunchKernelGGL(k_pbw_q, dim3((unsigned)((N + 63) / 64), (unsigned)B), block, q_lds, st, L, ls, sc, d, diag_mode,
+                     (int)N, k, ldq, Xt, Q);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
 }  // namespace lo
 
 using namespace lo;
@@ -740,7 +964,7 @@ int lo_precond_build_strided_f32(const float* L, int64_t ld_member, int64_t ld_r
   const LStride ls{ld_member, ld_row, ld_col};
   if (!L || !d || !Q || !dinv || !logdet_p || !ws) return LO_ERR_BADARG;
   if (diag_mode != LO_DIAG_FULL && diag_mode != LO_DIAG_CONST) return LO_ERR_BADARG;
-  if (k < 1 || k > kPbMaxK) return LO_ERR_UNSUPPORTED;
+  if (k < 1 || k > kPbWideMaxK) return LO_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   Split sp = choose_split(B, N, 256);
   Arena ar(ws, ws_bytes);
@@ -749,6 +973,9 @@ int lo_precond_build_strided_f32(const float* L, int64_t ld_member, int64_t ld_r
   double* Minv = ar.take<double>((size_t)B * k * k);
   float* scale = ar.take<float>((size_t)B * N);
   if (!ar.ok) return LO_ERR_WORKSPACE;
+  if (k > kPbMaxK)  // (Minv's storage holds the fp32 k x k operand of the Q kernel)
+    return precond_build_wide(L, ls, d, diag_mode, B, N, k, Q, dinv, logdet_p, gpart, logd,
+                              reinterpret_cast<float*>(Minv), scale, sp, st);
   const int ldq = padded_k(k);
   dim3 grid(sp.S, (unsigned)B), block(kThreads);
   // rows layout ([B, m, N] as the pivoted-Cholesky kernels write it), k <= 16: fp64 matrix cores, 16-byte loads

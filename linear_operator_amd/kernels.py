@@ -490,7 +490,7 @@ def precond_build(L: torch.Tensor, d: torch.Tensor, constant_diag: bool, root: O
         L3 = L3.contiguous()
     B = L3.shape[0]
     dev = L.device
-    if root is not None and perm is not None and root.shape[-1] <= 32 and k >= 1:
+    if root is not None and perm is not None and root.shape[-1] <= 32 and 1 <= k <= 32:
         rf = _root_form(lib, root, perm, L3, d, constant_diag, B, N, k, dev)
         rf.source = (L, d)
         if not need_q:
@@ -666,12 +666,22 @@ def bilinear_root(root: torch.Tensor, left_vecs: torch.Tensor, right_vecs: torch
     Cm = root.expand(*bs, N, R).contiguous().reshape(B, N, R)
     _hip.require_hip(Cm)
     dev = U.device
-    out = torch.empty(B, N, R, dtype=torch.float32, device=dev)
-    rowdot = torch.empty(B, N, dtype=torch.float32, device=dev) if with_rowdot else None
-    ws = _hip.workspace(lib.lo_bilinear_root_workspace_bytes(B, N, R, D), dev)
-    _hip.check(lib.lo_bilinear_root_f32(_hip.ptr(Cm), _hip.ptr(U), _hip.ptr(V), B, N, R, D, _hip.ptr(out),
-                                        _hip.ptr(rowdot), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)),
-               "lo_bilinear_root_f32")
+    # the kernel keeps a D x R tile on chip (D R <= 2048): wider problems go in column chunks, the derivative is a sum
+    # over the columns
+    dmax = max(1, 2048 // R)
+    out, rowdot = None, None
+    for d0 in range(0, D, dmax):
+        Uc, Vc = (U, V) if D <= dmax else (U[..., d0:d0 + dmax].contiguous(), V[..., d0:d0 + dmax].contiguous())
+        Dc = Uc.shape[-1]
+        o = torch.empty(B, N, R, dtype=torch.float32, device=dev)
+        rd = torch.empty(B, N, dtype=torch.float32, device=dev) if with_rowdot else None
+        ws = _hip.workspace(lib.lo_bilinear_root_workspace_bytes(B, N, R, Dc), dev)
+        _hip.check(lib.lo_bilinear_root_f32(_hip.ptr(Cm), _hip.ptr(Uc), _hip.ptr(Vc), B, N, R, Dc, _hip.ptr(o),
+                                            _hip.ptr(rd), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)),
+                   "lo_bilinear_root_f32")
+        out = o if out is None else out.add_(o)
+        if with_rowdot:
+            rowdot = rd if rowdot is None else rowdot.add_(rd)
     if with_rowdot:
         return out.reshape(*bs, N, R), rowdot.reshape(*bs, N)
     return out.reshape(*bs, N, R)

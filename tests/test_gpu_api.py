@@ -436,13 +436,18 @@ def test_backward_passes_against_reference_autograd():
             assert close(k1t.grad, g["kron_dK1"], 5e-3) and close(k2t.grad, g["kron_dK2"], 5e-3)
             assert close(skt.grad, g["kron_dsig"], 5e-3) and close(rkt.grad, g["kron_drhs"], 5e-3)
 
-    # operators without a closed-form derivative on this path say so (three Kronecker factors)
+    # three Kronecker factors: regrouped into two dense groups, the group gradient pulled back to the factor
     K1, K2, s, vk = cases.kron_factors(906, 2, 4, 4, 1)
     k1 = dev(K1).requires_grad_(True)
     Ak3 = KroneckerProductLinearOperator(DenseLinearOperator(k1), DenseLinearOperator(dev(K2)),
                                          DenseLinearOperator(dev(K2)))
-    with pytest.raises(NotImplementedError, match="_bilinear_derivative"):
-        (Ak3 @ dev(cases.randn(909, 2, 64, 1, dtype=np.float32))).sum().backward()
+    v3 = cases.randn(909, 2, 64, 1, dtype=np.float32)
+    (Ak3 @ dev(v3)).sum().backward()
+    k64 = torch.from_numpy(K1).double().requires_grad_(True)
+    k2d = torch.from_numpy(K2).double()
+    dense3 = torch.stack([torch.kron(torch.kron(k64[b], k2d[b]), k2d[b]) for b in range(2)])
+    (dense3 @ torch.from_numpy(v3).double()).sum().backward()
+    assert np.abs(host(k1.grad) - k64.grad.numpy()).max() <= 1e-5 * np.abs(k64.grad.numpy()).max()
 
 
 def test_pivoted_cholesky_vjp_hand_written_matches_autograd_tape():
@@ -994,3 +999,38 @@ def test_kronecker_product_plus_kronecker_structured_diagonal():
                 iq.sum().backward()
             for t, name in zip(lv, ("iql_dK1", "iql_dK2", "iql_da", "iql_db", "iql_drhs")):
                 assert close(t.grad, g[f"{tag}_{name}"]), (tag, name)
+
+
+def test_host_api_with_max_preconditioner_size_above_32():
+    """`settings.max_preconditioner_size(48)` through the operator API: solve and its gradients against the exact dense
+    fp64 values / autograd, inv_quad_logdet forward + backward (the preconditioner-logdet correction and the
+    pivoted-Cholesky pull-back run with a 48-column factor)."""
+    Kd, d, rhs = cases.dense_diag(9300, 2, 1200, 3)
+    W = cases.randn(9301, 2, 1200, 3, dtype=np.float32)
+    Kt64 = torch.from_numpy(Kd).double().requires_grad_(True)
+    dt64 = torch.from_numpy(d).double().requires_grad_(True)
+    x64 = torch.linalg.solve(Kt64 + torch.diag_embed(dt64), torch.from_numpy(rhs).double())
+    (x64 * torch.from_numpy(W).double()).sum().backward()
+    ld64 = torch.logdet(Kt64.detach() + torch.diag_embed(dt64.detach()))
+
+    def close(a, b, rel):
+        a, b = host(a).astype(np.float64), b.detach().numpy()
+        return a.shape == b.shape and np.abs(a - b).max() <= rel * np.abs(b).max()
+
+    with settings.max_cholesky_size(0), settings.min_preconditioning_size(0), settings.max_preconditioner_size(48), \
+            settings.cg_tolerance(1e-5), settings.num_trace_samples(64):
+        Kt, dt = dev(Kd).clone().requires_grad_(True), dev(d).clone().requires_grad_(True)
+        A = AddedDiagLinearOperator(DenseLinearOperator(Kt), DiagLinearOperator(dt))
+        x = A.solve(dev(rhs))
+        A._preconditioner()  # (the solve ran on the Function's rebuilt operator: build this instance's cache to look at it)
+        assert A._woodbury.k == 48 and A._woodbury.Q.shape[-1] == 64
+        (x * dev(W)).sum().backward()
+        assert max_rel_err_cols(host(x), x64.detach().numpy()) < 1e-4
+        sym = 0.5 * (Kt.grad + Kt.grad.mT)
+        assert close(sym, 0.5 * (Kt64.grad + Kt64.grad.mT), 2e-3) and close(dt.grad, dt64.grad, 2e-3)
+        Kt, dt = dev(Kd).clone().requires_grad_(True), dev(d).clone().requires_grad_(True)
+        A = AddedDiagLinearOperator(DenseLinearOperator(Kt), DiagLinearOperator(dt))
+        iq, ld = A.inv_quad_logdet(dev(rhs), logdet=True)
+        (iq.sum() + ld.sum()).backward()
+        assert np.allclose(host(ld), ld64.numpy(), rtol=2e-2)
+        assert bool(torch.isfinite(Kt.grad).all()) and bool(torch.isfinite(dt.grad).all())

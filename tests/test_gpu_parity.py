@@ -941,3 +941,32 @@ def test_bilinear_derivative_root_all_engines(N, R, D):
     assert torch.equal(out2, dev(out))
     rd = orc.bilinear_derivative_diag(U.astype(np.float64), V.astype(np.float64))
     assert np.abs(host(rowdot) - rd).max() <= 2e-5 * np.abs(rd).max()
+
+
+@pytest.mark.parametrize("k", [33, 40, 64, 100, 128])
+def test_wide_preconditioner_rank_above_32(k):
+    """`max_preconditioner_size` beyond the register-resident k <= 32 algebra: tiled fp64 Gram, packed Cholesky and
+    triangular inverse in LDS, Q = W T^-T (lo_precond.hip, k_pbw_*).  Pivots bit-exact, apply and logdet against the
+    oracle's fp64 QR form, and CG with it reaches the exact solution in fewer iterations than without."""
+    for const in (False, True):
+        Kd, d, rhs = cases.dense_diag(9100 + k, 2, 1100, 3)
+        if const:
+            d = np.broadcast_to(d[:, :1], d.shape).copy()
+        L, piv = K.pivoted_cholesky(K.dense_diag_descriptor(dev(Kd), None), k)
+        Lo, pivo = orc.pivoted_cholesky(orc.DenseRowSource(Kd), k)
+        assert np.array_equal(host(piv), pivo) and np.array_equal(host(L), Lo)
+        darg = dev(d[:, 0].copy()) if const else dev(d)
+        pre_o = orc.Preconditioner(Lo.astype(np.float64), d.astype(np.float64))
+        for layout in ("nk", "rows"):
+            if layout == "rows":
+                L, _ = K.pivoted_cholesky(K.dense_diag_descriptor(dev(Kd), None), k, contiguous=False)
+            pre = K.precond_build(L, darg, const)
+            z = host(K.precond_apply(pre, dev(rhs)))
+            assert max_rel_err_cols(z, pre_o.apply(rhs.astype(np.float64))) < 5e-5, (k, const, layout)
+            assert np.allclose(host(pre.logdet), pre_o.logdet, rtol=1e-5), (k, const, layout)
+        desc = K.dense_diag_descriptor(dev(Kd), darg, const_diag=const)
+        res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-5, max_iter=300)
+        res0 = K.cg_solve(desc, dev(rhs), tolerance=1e-5, max_iter=300)
+        A = Kd.astype(np.float64) + np.stack([np.diag(v) for v in d.astype(np.float64)])
+        assert max_rel_err_cols(host(res.x), np.linalg.solve(A, rhs.astype(np.float64))) < 1e-4
+        assert res.iterations <= res0.iterations

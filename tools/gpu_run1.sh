@@ -1,2 +1,2 @@
 #!/bin/bash
-python -m pytest tests/test_gpu_sweep.py -q -x > gpurun_out/pytest_gpu.log 2>&1; tail -30 gpurun_out/pytest_gpu.log
+python -m pytest tests -q -x -m gpu > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -3
