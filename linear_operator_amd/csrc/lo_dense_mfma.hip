@@ -14,6 +14,7 @@
 //   half h = lane >> 5 taking k in [32 h, 32 h + 32) of the slab.
 // Epilogue fused: + d o v, store, CG inner product partial sum_rows v o y (one per 128-row tile).
 #include <algorithm>
+#include <stdlib.h>
 
 #include "lo_device.h"
 #include "lo_internal.h"
@@ -147,12 +148,259 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma(const float* __restr
   }
 }
 
+// ---- 5 <= c <= 20: sixteen columns on v_mfma_f32_16x16x4_f32, up to four more on the vector ALU ---------------------
+// The 32-column tile above spends half of its matrix-core time on zero columns at c = 17 (16 probes + the right-hand
+// side) and sits at 50 % matrix-core duty next to the HBM stream.  Here the first 16 columns use the 16-wide
+// instruction (A operand: lane (m = l & 15, kk = l >> 4) reads K[row m][4 kk .. 4 kk + 3] of a 16-k group with one
+// 16-byte LDS read and feeds the four values to four MFMAs whose k index is 4 kk + j; B: v[16 g + 4 kk + j][m]) and the
+// columns 16 .. c-1 ride on the SAME A registers: one FMA per K element and column (v of those columns contiguous in k
+// in LDS, one broadcast 16-byte read per group).  Same workgroup tile (64 rows, waves = 2 row tiles x 2 k-halves),
+// same staging, same epilogue semantics and dot-partial layout as the kernel above.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int DM_VLD = 20;  // row stride of the v slab [128 k][16 cols]: the four kk groups of a B read hit 2 x 16 banks
+
+template <bool DOT, int NV>
+__global__ __launch_bounds__(kThreads) void k_dense_mv_mfma16(const float* __restrict__ K, const float* __restrict__ dd,
+                                                               int dd_mode, const float* __restrict__ v, int ldv, int c,
+                                                               float* __restrict__ y, float* __restrict__ dot_part,
+                                                               int ldd, int N, const int* __restrict__ stop) {
+  if (stop && *stop) return;
+  __shared__ __attribute__((aligned(16))) float k_s[DM_ROWS * DM_LD];
+  __shared__ float v_s[DM_KB * DM_VLD];
+  __shared__ __attribute__((aligned(16))) float vx_s[(NV > 0 ? NV : 1) * DM_KB];
+  __shared__ float dot_s[4][32];
+  const int tile = blockIdx.x, b = blockIdx.y, S = gridDim.x;
+  const int row0 = tile * DM_ROWS;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = lane & 15, kk = lane >> 4;
+  const int wr = wave & 1, wk = wave >> 1;
+  const int cm = min(c, 16);  // matrix-core columns
+  const float* Kb = K + (size_t)b * N * N;
+  const size_t vbase = (size_t)b * N * ldv;
+
+  float4 kreg[8];
+  float vreg[8];
+  float vxreg[2];
+  const bool full_rows = ((N & 3) == 0) && (row0 + DM_ROWS <= N);
+  auto load_slab = [&](int kb) {
+    if (full_rows && kb + DM_KB <= N) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = threadIdx.x + kThreads * u;
+        const int r = f >> 5, q = f & 31;
+        kreg[u] = *reinterpret_cast<const float4*>(Kb + (size_t)(row0 + r) * N + kb + 4 * q);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = threadIdx.x + kThreads * u;
+        const int r = f >> 5, q = f & 31;
+        const int grow = row0 + r, gk = kb + 4 * q;
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = (grow < N && gk + e < N) ? Kb[(size_t)grow * N + gk + e] : 0.f;
+        kreg[u] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = threadIdx.x + kThreads * u;  // [128 k][16 cols]
+      const int kr = e >> 4, col = e & 15;
+      vreg[u] = (col < cm && kb + kr < N) ? v[vbase + (size_t)(kb + kr) * ldv + col] : 0.f;
+    }
+    if constexpr (NV > 0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = threadIdx.x + kThreads * u;  // [NV][128 k]
+        const int x = e >> 7, kr = e & 127;
+        vxreg[u] = (x < NV && kb + kr < N) ? v[vbase + (size_t)(kb + kr) * ldv + 16 + x] : 0.f;
+      }
+    }
+  };
+  auto store_slab = [&]() {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int f = threadIdx.x + kThreads * u;
+      const int r = f >> 5, q = f & 31;
+      *reinterpret_cast<float4*>(&k_s[r * DM_LD + 4 * q]) = kreg[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = threadIdx.x + kThreads * u;
+      v_s[(e >> 4) * DM_VLD + (e & 15)] = vreg[u];
+    }
+    if constexpr (NV > 0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = threadIdx.x + kThreads * u;
+        if (e < NV * DM_KB) vx_s[e] = vxreg[u];
+      }
+    }
+  };
+
+  f32x4 acc[2];
+  float yx[2][NV > 0 ? NV : 1];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < (NV > 0 ? NV : 1); ++x) yx[rb][x] = 0.f;
+  }
+
+  load_slab(0);
+  for (int kb = 0; kb < N; kb += DM_KB) {
+    __syncthreads();
+    store_slab();
+    __syncthreads();
+    if (kb + DM_KB < N) load_slab(kb + DM_KB);
+    const float* arow = &k_s[(32 * wr + m) * DM_LD + 64 * wk + 4 * kk];
+    const float* bcol = &v_s[(64 * wk + 4 * kk) * DM_VLD + m];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + 16 * g);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(arow + 16 * DM_LD + 16 * g);
+      float bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = bcol[(16 * g + j) * DM_VLD];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bv[j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bv[j], acc[1], 0, 0, 0);
+      }
+      if constexpr (NV > 0) {
+#pragma unroll
+        for (int x = 0; x < NV; ++x) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(&vx_s[x * DM_KB + 64 * wk + 16 * g + 4 * kk]);
+          yx[0][x] = fmaf(a0[3], w4[3], fmaf(a0[2], w4[2], fmaf(a0[1], w4[1], fmaf(a0[0], w4[0], yx[0][x]))));
+          yx[1][x] = fmaf(a1[3], w4[3], fmaf(a1[2], w4[2], fmaf(a1[1], w4[1], fmaf(a1[0], w4[0], yx[1][x]))));
+        }
+      }
+    }
+  }
+  // vector-ALU columns: sum the four k groups of a lane quadruple (every lane ends with the total of row m)
+  if constexpr (NV > 0) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int x = 0; x < NV; ++x) yx[rb][x] = bfly_add<32>(bfly_add<16>(yx[rb][x]));
+  }
+  // the two waves that share a row tile sum their k-halves through LDS (fixed order: half 0 + half 1)
+  __syncthreads();
+  float* red = k_s;  // reuse: [2 row tiles][8 + 2 NV values][64 lanes]
+  constexpr int NRED = 8 + 2 * (NV > 0 ? NV : 0);
+  if (wk == 1) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[(wr * NRED + 4 * rb + i) * 64 + lane] = acc[rb][i];
+      if constexpr (NV > 0) {
+#pragma unroll
+        for (int x = 0; x < NV; ++x) red[(wr * NRED + 8 + NV * rb + x) * 64 + lane] = yx[rb][x];
+      }
+    }
+  }
+  __syncthreads();
+  if (wk == 0) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[rb][i] += red[(wr * NRED + 4 * rb + i) * 64 + lane];
+      if constexpr (NV > 0) {
+#pragma unroll
+        for (int x = 0; x < NV; ++x) yx[rb][x] += red[(wr * NRED + 8 + NV * rb + x) * 64 + lane];
+      }
+    }
+  }
+  const float ddc = (dd_mode == LO_DIAG_CONST) ? dd[b] : 0.f;
+  float dacc = 0.f;
+  float dax[NV > 0 ? NV : 1];
+#pragma unroll
+  for (int x = 0; x < (NV > 0 ? NV : 1); ++x) dax[x] = 0.f;
+  if (wk == 0) {
+    if (m < cm) {  // matrix-core columns: D[row = 4 kk + i][col = m] per 16-row block
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = row0 + 32 * wr + 16 * rb + 4 * kk + i;
+          if (row < N) {
+            const float dv = (dd_mode == LO_DIAG_FULL) ? dd[(size_t)b * N + row] : ddc;
+            const size_t o = vbase + (size_t)row * ldv + m;
+            const float vin = v[o];
+            const float yv = fmaf(dv, vin, acc[rb][i]);
+            y[o] = yv;
+            if (DOT) dacc = fmaf(vin, yv, dacc);
+          }
+        }
+    }
+    if constexpr (NV > 0) {
+      if (kk == 0) {  // vector-ALU columns: lane m holds row m of the block
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const int row = row0 + 32 * wr + 16 * rb + m;
+          if (row < N) {
+            const float dv = (dd_mode == LO_DIAG_FULL) ? dd[(size_t)b * N + row] : ddc;
+#pragma unroll
+            for (int x = 0; x < NV; ++x) {
+              const size_t o = vbase + (size_t)row * ldv + 16 + x;
+              const float vin = v[o];
+              const float yv = fmaf(dv, vin, yx[rb][x]);
+              y[o] = yv;
+              if (DOT) dax[x] = fmaf(vin, yv, dax[x]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (DOT) {
+    dacc = bfly_add<32>(bfly_add<16>(dacc));  // over the four row groups: every lane has the total of column m
+    if (kk == 0) dot_s[wave][m] = dacc;        // (waves with wk == 1 contribute 0)
+    if constexpr (NV > 0) {
+#pragma unroll
+      for (int x = 0; x < NV; ++x) {
+        const float tot = wave_sum_fast(dax[x]);  // lanes with kk != 0 hold 0
+        if (lane == 0) dot_s[wave][16 + x] = tot;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < c)
+      dot_part[((size_t)b * S + tile) * ldd + threadIdx.x] =
+          (dot_s[0][threadIdx.x] + dot_s[1][threadIdx.x]) + (dot_s[2][threadIdx.x] + dot_s[3][threadIdx.x]);
+  }
+}
+
+template <bool DOT>
+static void launch_mv16(int nv, dim3 grid, hipStream_t st, const float* K, const float* d, int dd_mode, const float* v,
+                        int ldv, int c, float* y, float* dot_part, int N, const int* stop) {
+  dim3 block(kThreads);
+#define LO_MV16(NV_) \
+  hipLaunchKernelGGL((k_dense_mv_mfma16<DOT, NV_>), grid, block, 0, st, K, d, dd_mode, v, ldv, c, y, dot_part, ldv, N, stop)
+  switch (nv) {
+    case 0: LO_MV16(0); break;
+    case 1: LO_MV16(1); break;
+    case 2: LO_MV16(2); break;
+    case 3: LO_MV16(3); break;
+    default: LO_MV16(4); break;
+  }
+#undef LO_MV16
+}
+
 bool dense_mfma_ok(int64_t N, int64_t c) { return c > 4 && N >= 256; }
 int dense_mfma_tiles(int64_t N) { return (int)((N + DM_ROWS - 1) / DM_ROWS); }
 
 int dense_matvec_mfma(const float* K, const float* d, int dd_mode, const float* v, float* y, float* dot_part, int64_t B,
                       int64_t N, int64_t c, const int* stop, hipStream_t st) {
   dim3 grid(dense_mfma_tiles(N), (unsigned)B), block(kThreads);
+  if (c <= 20 && !getenv("LO_DENSE_MFMA32")) {  // 16 columns on the 16-wide instruction + up to 4 on the vector ALU
+    const int nv = (int)std::max<int64_t>(0, c - 16);
+    LO_PROF_BEGIN("dense_mv_mfma", st);
+    if (dot_part) launch_mv16<true>(nv, grid, st, K, d, dd_mode, v, (int)c, (int)c, y, dot_part, (int)N, stop);
+    else launch_mv16<false>(nv, grid, st, K, d, dd_mode, v, (int)c, (int)c, y, dot_part, (int)N, stop);
+    LO_PROF_END(st);
+    LO_LAUNCH_CHECK();
+    return LO_OK;
+  }
   for (int64_t c0 = 0; c0 < c; c0 += 32) {  // column tiles of 32 (K is re-streamed per tile: only for c > 32)
     const int cn = (int)std::min<int64_t>(32, c - c0);
     LO_PROF_BEGIN("dense_mv_mfma", st);
