@@ -132,17 +132,33 @@ def _profiled(fn):
         _hip.prof_enable(False)
 
 
-def _roof(kernel, workload, prof_entry, bound, work, note):
-    """One per-kernel roofline entry: `work` = compulsory bytes (bound 'hbm') or flop (bound 'mfma') per launch."""
+def _committed_traffic(fname, key=None):
+    """(bytes per launch, source string) of a kernel from the committed rocprofv3 counter summary, or (None, None)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_DIR, fname)))
+        ent = tj["kernels"][key] if key else tj
+        return float(ent["traffic_bytes_per_launch"]), (
+            f"profiles/{PROFILE_DIR}/{fname}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel {ent['kernel']}, "
+            "FETCH x2 (gfx950 correction) + WRITE")
+    except Exception:  # noqa: BLE001 -- no committed profile for this kernel: no traffic figure
+        return None, None
+
+
+def _roof(kernel, workload, prof_entry, bound, work, note, traffic=(None, None)):
+    """One per-kernel roofline entry: `work` = compulsory bytes (bound 'hbm') or flop (bound 'mfma') per launch;
+    `traffic` = (HBM bytes per launch from the committed counter profile of the same workload, its source)."""
     cnt, ms = prof_entry
     avg_s = ms / cnt * 1e-3
     if bound == "hbm":
         achieved, peak, unit = work / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
     else:
         achieved, peak, unit = work / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
-    return {"kernel": kernel, "workload": workload, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-            "frac": achieved / peak, "per_launch": work, "avg_launch_us": avg_s * 1e6, "launches_timed": cnt,
-            "note": note}
+    out = {"kernel": kernel, "workload": workload, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+           "frac": achieved / peak, "per_launch": work, "avg_launch_us": avg_s * 1e6, "launches_timed": cnt,
+           "note": note}
+    if traffic[0]:
+        out["traffic"], out["traffic_source"] = traffic[0], traffic[1]
+    return out
 
 
 def other_configs(device):
@@ -185,9 +201,9 @@ def other_configs(device):
                            "fp32 matrix cores (v_mfma_f32_16x16x4_f32): 2 N (2R + 2k) flop per member, column and "
                            "iteration (k = 15; the kernel multiplies with Q zero-padded to 16); compulsory HBM bytes per "
                            f"launch {4 * B_PER_GPU * N * (R + RANK_K + 2 + 6 * 16) / 1e9:.2f} GB (operator once, rhs in, "
-                           "x / r / p / z and the scaled result out)"))
+                           "x / r / p / z and the scaled result out)", _committed_traffic("traffic_lockstep.json")))
     if "cg_onchip" in prof:  # the 17th column (inv_quad right-hand side) on the serial-column resident kernel
-        roofs.append(_roof("k_cg_onchip4<32,16,8,true>", "cfg3: 17th column x 21 iterations, 512 members", prof["cg_onchip"],
+        roofs.append(_roof("k_cg_onchip5<32,8,true>", "cfg3: 17th column x 21 iterations, 512 members", prof["cg_onchip"],
                            "hbm", 4 * B_PER_GPU * N * (R + RANK_K + 2 + 6),
                            "compulsory bytes per launch (operator once + one column's vectors); latency-bound by the "
                            "per-iteration group all-reduces"))
@@ -255,12 +271,12 @@ def other_configs(device):
                            prof["kron_gemm_mfma"], "mfma", 2.0 * 128 * n * n * n,
                            "fp32 matrix cores (v_mfma_f32_32x32x2_f32), 2 n^3 flop per member and GEMM; with K = 256 "
                            "the GEMM sits at the ridge (operands + result 100 - 130 MB per launch ~ its MFMA time): "
-                           "tools/mb_kron_rate.py, DESIGN 4.6"))
+                           "tools/mb_kron_rate.py, DESIGN 4.6", _committed_traffic("traffic_cfg45.json", "kron_gemm_mfma")))
     if "precond_fused" in prof:
         roofs.append(_roof("k_precond_fused<64,4>", "cfg4 shard: 128 members x 65536 rows, one CG iteration's Woodbury "
                            "apply + r / x / p updates", prof["precond_fused"], "hbm", 4 * 128 * n * n * (16 + 7),
                            "4 N (16 + 7) bytes per member and iteration: Q once; r, Ap, p, x in; r, x, p out (constant "
-                           "diagonal)"))
+                           "diagonal)", _committed_traffic("traffic_cfg45.json", "precond_fused")))
     del X1, X2, K1, K2, desc
     # cfg5 shard: 4 of the 32 dense 16384^2 members a GPU owns, 17 columns, CG with tridiagonals
     Nd = 16384
@@ -281,8 +297,10 @@ def other_configs(device):
                                      "matvec_algorithmic_GBs": mv_bytes * r.matvecs / t / 1e9}
     prof = _profiled(dense)
     if "dense_mv_mfma" in prof:
-        roofs.append(_roof("k_dense_mv_mfma", "cfg5 shard: 4 members of 16384^2, 17 columns, one matvec", prof["dense_mv_mfma"],
-                           "hbm", mv_bytes, "4 (N^2 + N + 2 N c) bytes per member: K streamed once for all 17 columns"))
+        roofs.append(_roof("k_dense_mv_mfma16<true,1>", "cfg5 shard: 4 members of 16384^2, 17 columns, one matvec",
+                           prof["dense_mv_mfma"], "hbm", mv_bytes,
+                           "4 (N^2 + N + 2 N c) bytes per member: K streamed once for all 17 columns (the committed "
+                           "counter profile is of 8 members: twice the bytes)"))
     return res, roofs
 
 

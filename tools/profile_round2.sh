@@ -20,6 +20,8 @@ stats cfg3 python $R/tools/mb_cfg3.py
 stats lockstep python $R/tools/mb_lockstep.py
 stats lanczos python $R/tools/mb_lanczos.py
 stats cfg45 python $R/tools/mb_cfg45.py
+stats iql python $R/tools/mb_iql_pieces.py
+python $R/tools/mb_kron_rate.py > $OUT/kron_rate.txt 2>&1
 pmc() {  # name, counter, command...
   local name=$1 ctr=$2; shift 2
   rm -rf /tmp/q_${name}_$ctr
@@ -30,6 +32,8 @@ pmc() {  # name, counter, command...
 { pmc cfg3 FETCH_SIZE python $R/tools/mb_lockstep.py; pmc cfg3 WRITE_SIZE python $R/tools/mb_lockstep.py; } > $OUT/pmc_fetch_write_lockstep.txt
 { pmc cfg45 FETCH_SIZE python $R/tools/mb_cfg45.py; pmc cfg45 WRITE_SIZE python $R/tools/mb_cfg45.py; } > $OUT/pmc_fetch_write_cfg45.txt
 { pmc lanczos FETCH_SIZE python $R/tools/mb_lanczos.py; pmc lanczos WRITE_SIZE python $R/tools/mb_lanczos.py; } > $OUT/pmc_fetch_write_lanczos.txt
+# matrix-core / vector / LDS utilisation of the lockstep kernel (tools/pmc_lockstep.sh, same output directory)
+bash $R/tools/pmc_lockstep.sh > /dev/null 2>&1
 python - "$OUT" <<'PY'
 import json, re, sys
 out = sys.argv[1]
@@ -52,6 +56,17 @@ if f is not None and w is not None:
                "WRITE_SIZE_KB_avg": w, "fetch_correction": 2.0, "traffic_bytes_per_launch": (2.0 * f + w) * 1024,
                "source": "pmc_fetch_write_lockstep.txt (rocprofv3 --pmc, separate passes, tools/mb_lockstep.py)"},
               open(f"{out}/traffic_lockstep.json", "w"), indent=1)
+others = {}
+for name, kern in (("precond_fused", "k_precond_fused"), ("dense_mv_mfma", "k_dense_mv_mfma16"), ("kron_gemm_mfma", "k_kron_nt_mfma<true>"),
+                   ("kron_gemm_mfma_first", "k_kron_nt_mfma<false>")):
+    f = grab(f"{out}/pmc_fetch_write_cfg45.txt", "FETCH_SIZE", kern)
+    w = grab(f"{out}/pmc_fetch_write_cfg45.txt", "WRITE_SIZE", kern)
+    if f is not None and w is not None:
+        others[name] = {"kernel": kern, "FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w, "fetch_correction": 2.0,
+                        "traffic_bytes_per_launch": (2.0 * f + w) * 1024}
+if others:
+    json.dump({"source": "pmc_fetch_write_cfg45.txt (rocprofv3 --pmc, separate passes, tools/mb_cfg45.py)", "kernels": others},
+              open(f"{out}/traffic_cfg45.json", "w"), indent=1)
 PY
 : > $OUT/pmc_utilisation_bench.txt
 for c in VALUBusy SALUBusy LdsUtil VALUUtilization SQ_INSTS_VALU SQ_INSTS_LDS; do
