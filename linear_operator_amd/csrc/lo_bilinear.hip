@@ -64,16 +64,25 @@ __global__ __launch_bounds__(kThreads) void k_bil_dense(const float* __restrict_
   }
 }
 
-// out[b, n] = sum_d U o V
+// out[b, n] = sum_d U o V.  A workgroup takes `rb` consecutive rows = rb * D CONTIGUOUS floats of U and V: the products
+// are formed with coalesced loads (a thread per row would issue D loads of stride D each), parked in LDS, and thread r
+// sums its row in fixed order (stride D reads).
+constexpr int kBdiagLds = 8192;  // floats
 __global__ __launch_bounds__(kThreads) void k_bil_diag(const float* __restrict__ U, const float* __restrict__ V,
-                                                        int64_t rows, int D, float* __restrict__ out) {
-  const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (r >= rows) return;
-  const float* u = U + (size_t)r * D;
-  const float* v = V + (size_t)r * D;
-  float acc = 0.f;
-  for (int d = 0; d < D; ++d) acc = fmaf(u[d], v[d], acc);
-  out[r] = acc;
+                                                        int64_t rows, int D, int rb, float* __restrict__ out) {
+  __shared__ float prod[kBdiagLds];
+  const int64_t r0 = (int64_t)blockIdx.x * rb;
+  const int nr = (int)min((int64_t)rb, rows - r0);
+  if (nr <= 0) return;
+  const size_t base = (size_t)r0 * D;
+  const int ne = nr * D;
+  for (int e = threadIdx.x; e < ne; e += kThreads) prod[e] = U[base + e] * V[base + e];
+  __syncthreads();
+  for (int r = threadIdx.x; r < nr; r += kThreads) {
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) acc += prod[r * D + d];
+    out[r0 + r] = acc;
+  }
 }
 
 // out[b] = sum_n rowdot[b, n]  (fixed order: thread-strided partials, then the block tree)
@@ -215,43 +224,85 @@ __global__ __launch_bounds__(kThreads) void k_bil_root_t_mfma(const float* __res
 
 // Root, phase B: out[b, n, rho] = sum_d U[n,d] T1[d,rho] + V[n,d] T2[d,rho], T = sum_s tpart (fixed order)
 // Optional `rowdot` [B, N] = sum_d U o V (the Diag derivative of an AddedDiag operator, diag_linear_operator.py:37-45):
-// the rows of U and V are in this thread's hands anyway.
+// the rows of U and V are in the workgroup's hands anyway.
+// = a [rows x 2D] x [2D x R] product: a workgroup stages 32 * nw rows of U and V (contiguous rows * D floats each,
+// coalesced) and T1 | T2 (reduced over the S slices once per workgroup) in LDS; wave w forms the 32 rows 32 w .. + 31
+// with v_mfma_f32_32x32x2_f32, one 32-column block of the output at a time (stores of 128 contiguous bytes per row).
+typedef float bo_f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(kThreads) void k_bil_root_out(const float* __restrict__ U, const float* __restrict__ V,
                                                             const float* __restrict__ tpart, int S, int N, int R,
-                                                            int D, float* __restrict__ out,
+                                                            int D, int nw, float* __restrict__ out,
                                                             float* __restrict__ rowdot) {
-  extern __shared__ float sh[];  // t1 [D][R] | t2 [D][R]
+  extern __shared__ float sh[];  // t1 [DE][RP] | t2 [DE][RP] | u_s [rows][DP] | v_s [rows][DP]
+  const int DE = (D + 1) & ~1;     // k extent, even (the instruction takes two k per step)
+  const int DP = DE | 1;           // odd row stride of the U / V tiles: conflict-free column reads
+  const int RP = (R + 31) & ~31;   // whole 32-column blocks
+  const int rows = 32 * nw;
+  float* t1 = sh;
+  float* t2 = t1 + DE * RP;
+  float* u_s = t2 + DE * RP;
+  float* v_s = u_s + rows * DP;
   const int64_t b = blockIdx.y;
+  const int row0 = blockIdx.x * rows;
+  const int nr = min(rows, N - row0);
   const int npair = D * R;
-  for (int e = threadIdx.x; e < 2 * npair; e += kThreads) {
+  for (int e = threadIdx.x; e < 2 * DE * RP; e += kThreads) {
+    const int which = e / (DE * RP), rem = e % (DE * RP), d = rem / RP, rho = rem % RP;
     float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += tpart[((size_t)b * S + s) * 2 * npair + e];
+    if (d < D && rho < R)
+      for (int s = 0; s < S; ++s) acc += tpart[((size_t)b * S + s) * 2 * npair + (size_t)which * npair + d * R + rho];
     sh[e] = acc;
   }
-  __syncthreads();
-  // thread = (row, group of 4 columns): consecutive threads write consecutive 16-byte pieces
-  const int R4 = (R + 3) / 4;
-  const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  const int row = (int)(idx / R4), g = (int)(idx % R4);
-  if (row >= N) return;
-  const float* u = U + ((size_t)b * N + row) * D;
-  const float* v = V + ((size_t)b * N + row) * D;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  float dot = 0.f;
-  for (int d = 0; d < D; ++d) {
-    const float ud = u[d], vd = v[d];
-    dot = fmaf(ud, vd, dot);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int rho = 4 * g + e;
-      if (rho < R) acc[e] = fmaf(ud, sh[d * R + rho], fmaf(vd, sh[npair + d * R + rho], acc[e]));
+  const size_t base = ((size_t)b * N + row0) * D;
+  {  // the nr * D staged floats are contiguous in U / V; (row, column) of element e advanced without divisions
+    const int step_r = kThreads / D, step_d = kThreads % D;
+    int r = threadIdx.x / D, d = threadIdx.x % D;
+    for (int e = threadIdx.x; e < nr * D; e += kThreads) {
+      u_s[r * DP + d] = U[base + e];
+      v_s[r * DP + d] = V[base + e];
+      r += step_r;
+      d += step_d;
+      if (d >= D) { d -= D; ++r; }
+    }
+    // padding: columns D .. DP-1 of every row, and the rows beyond nr
+    for (int e = threadIdx.x; e < rows * (DP - D); e += kThreads) {
+      const int rr = e / (DP - D), dd = D + e % (DP - D);
+      u_s[rr * DP + dd] = 0.f;
+      v_s[rr * DP + dd] = 0.f;
+    }
+    for (int e = nr * DP + threadIdx.x; e < rows * DP; e += kThreads) {
+      u_s[e] = 0.f;
+      v_s[e] = 0.f;
     }
   }
-  if (rowdot && g == 0) rowdot[(size_t)b * N + row] = dot;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  if (rowdot && threadIdx.x < nr) {
+    float dot = 0.f;
+    for (int d = 0; d < D; ++d) dot = fmaf(u_s[threadIdx.x * DP + d], v_s[threadIdx.x * DP + d], dot);
+    rowdot[(size_t)b * N + row0 + threadIdx.x] = dot;
+  }
+  if (wave >= nw) return;
+  const float* ua = u_s + (32 * wave + li) * DP + h;
+  const float* va = v_s + (32 * wave + li) * DP + h;
+  for (int cb = 0; cb < RP; cb += 32) {
+    bo_f32x16 acc;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int rho = 4 * g + e;
-    if (rho < R) out[((size_t)b * N + row) * R + rho] = acc[e];
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const float* b1 = t1 + h * RP + cb + li;
+    const float* b2 = t2 + h * RP + cb + li;
+    for (int k = 0; k < DE; k += 2) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[k], b1[k * RP], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[k], b2[k * RP], acc, 0, 0, 0);
+    }
+    const int col = cb + li;
+    if (col < R) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (r < nr) out[((size_t)b * N + row0 + r) * R + col] = acc[e];
+      }
+    }
   }
 }
 
@@ -285,9 +336,11 @@ int lo_bilinear_diag_f32(const float* U, const float* V, int64_t B, int64_t N, i
     if (!ws || ws_bytes < sizeof(float) * (size_t)rows) return LO_ERR_WORKSPACE;
     rowdot = (float*)ws;
   }
+  if (D > kBdiagLds) return LO_ERR_UNSUPPORTED;
+  const int rb = (int)std::min<int64_t>(kThreads, kBdiagLds / D);
   LO_PROF_BEGIN("bil_diag", st);
-  hipLaunchKernelGGL(k_bil_diag, dim3((unsigned)((rows + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, U, V, rows,
-                     (int)D, rowdot);
+  hipLaunchKernelGGL(k_bil_diag, dim3((unsigned)((rows + rb - 1) / rb)), dim3(kThreads), 0, st, U, V, rows, (int)D, rb,
+                     rowdot);
   LO_PROF_END(st);
   if (constant) hipLaunchKernelGGL(k_bil_sum_rows, dim3((unsigned)B), dim3(kThreads), 0, st, rowdot, (int)N, out);
   LO_LAUNCH_CHECK();
@@ -320,10 +373,17 @@ int lo_bilinear_root_f32(const float* C, const float* U, const float* V, int64_t
     hipLaunchKernelGGL(k_bil_root_t, dim3(sp.S, (unsigned)B), dim3(kThreads), lds_a, st, C, U, V, (int)N, (int)R,
                        (int)D, sp.rows, tpart);
   LO_PROF_END(st);
-  const int64_t items = N * ((R + 3) / 4);
+  const int DE = ((int)D + 1) & ~1, DP = DE | 1, RP = ((int)R + 31) & ~31;
+  int nw = 4;  // waves = 32-row blocks per workgroup: as many as fit 64 KB of LDS
+  size_t lds_o = 0;
+  for (; nw >= 1; nw >>= 1) {
+    lds_o = sizeof(float) * ((size_t)2 * DE * RP + (size_t)2 * 32 * nw * DP);
+    if (lds_o <= 64 * 1024) break;
+  }
+  if (nw < 1) return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("bil_root_out", st);
-  hipLaunchKernelGGL(k_bil_root_out, dim3((unsigned)((items + kThreads - 1) / kThreads), (unsigned)B), dim3(kThreads),
-                     lds_b, st, U, V, tpart, sp.S, (int)N, (int)R, (int)D, out, rowdot);
+  hipLaunchKernelGGL(k_bil_root_out, dim3((unsigned)((N + 32 * nw - 1) / (32 * nw)), (unsigned)B), dim3(kThreads), lds_o,
+                     st, U, V, tpart, sp.S, (int)N, (int)R, (int)D, nw, out, rowdot);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;

@@ -56,8 +56,8 @@ def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, U, 
     #      needs the Woodbury cache, so it is added even when they are not available)
     if L is not None and perm is not None and any(t.requires_grad for t in matrix_args[op_slice]):
         Lc = L.contiguous()
-        GL = 2.0 * g * pre(Lc) + K.bilinear_root(Lc, U, V)
-        extra = pivoted_cholesky_vjp(linear_op._linear_op, perm, GL)
+        GL = torch.addcmul(K.bilinear_root(Lc, U, V), pre(Lc), 2.0 * g)  # one pass: 2 g P^-1 L + U (V^T L) + V (U^T L)
+        extra = pivoted_cholesky_vjp(linear_op._linear_op, perm, GL, factor=Lc)
         if extra is not None:
             idxs = range(*op_slice.indices(len(matrix_arg_grads)))
             for i, e in zip(idxs, extra):
@@ -193,26 +193,26 @@ class InvQuadLogdet(Function):
         # un-normalise the probe-vector solves (:183-186)
         coef = 1.0 / ctx.probe_vectors.size(-1)
         # (the three per-probe / per-member factors are combined first: one pass over the [*, N, P] solves)
-        probe_vector_solves = solves.narrow(-1, 0, ctx.num_random_probes).mul(
-            ctx.probe_vector_norms.mul(logdet_grad_output).mul(coef)
-        )
+        n_p, n_q = ctx.num_random_probes, (ctx.num_inv_quad_solves if ctx.inv_quad else 0)
+        # left / right factors of the bilinear derivative: [probe part | inv_quad part], filled in place (no torch.cat)
+        left_factors = torch.empty(*solves.shape[:-1], n_p + n_q, dtype=solves.dtype, device=solves.device)
+        right_factors = torch.empty_like(left_factors)
+        probe_vector_solves = left_factors.narrow(-1, 0, n_p)
+        torch.mul(solves.narrow(-1, 0, n_p), ctx.probe_vector_norms.mul(logdet_grad_output).mul(coef),
+                  out=probe_vector_solves)
 
         # probes were drawn from N(0, P); P^-1 probes are draws from N(0, P^-1)  (:188-193)
         if ctx.preconditioner is not None:
             precond_probe_vectors = ctx.preconditioner((ctx.probe_vectors * ctx.probe_vector_norms).contiguous())
         else:
             precond_probe_vectors = ctx.probe_vectors * ctx.probe_vector_norms
-
-        left_factors_list = [probe_vector_solves]
-        right_factors_list = [precond_probe_vectors]
+        right_factors.narrow(-1, 0, n_p).copy_(precond_probe_vectors)
         neg_inv_quad_solves_times_grad_out = None
         if ctx.inv_quad:
-            inv_quad_solves = solves.narrow(-1, ctx.num_random_probes, ctx.num_inv_quad_solves)
-            neg_inv_quad_solves_times_grad_out = inv_quad_solves.mul(inv_quad_grad_output).mul(-1)
-            left_factors_list.append(neg_inv_quad_solves_times_grad_out)
-            right_factors_list.append(inv_quad_solves)
-        left_factors = torch.cat(left_factors_list, -1)
-        right_factors = torch.cat(right_factors_list, -1)
+            inv_quad_solves = solves.narrow(-1, n_p, n_q)
+            neg_inv_quad_solves_times_grad_out = left_factors.narrow(-1, n_p, n_q)
+            torch.mul(inv_quad_solves, inv_quad_grad_output.mul(-1), out=neg_inv_quad_solves_times_grad_out)
+            right_factors.narrow(-1, n_p, n_q).copy_(inv_quad_solves)
         matrix_arg_grads = linear_op._bilinear_derivative(left_factors, right_factors)
 
         # preconditioner gradient (:211-213).  In the reference the preconditioner tensors (L, d) carry an autograd

@@ -44,13 +44,16 @@ class PivotedCholesky(Function):
         return tuple([None, None, None] + list(grads))
 
 
-def _dense_root_vjp(r, perm, grad_L, m):
+def _dense_root_vjp(r, perm, grad_L, m, factor=None):
     """The same pull-back for K = R R^T written out by hand (a dozen passes over [*, N, m] / [*, N, R] data instead of
     the autograd tape of the generic re-expression); only the m x m Cholesky goes through autograd, so the
     triangular / symmetric conventions of its backward are the ones the generic path (and the reference) get.
       pivoted factor = [L11; K21 L11^-T]:  with G = grad_L split into its pivot rows G11 and the others G2, Rest = K21 L11^-T:
       bar L11 = G11 - L11^-T (G2^T Rest),  bar K21 = G2 L11^-1,  bar K11 = chol_backward(bar L11),
-      bar Rp = bar Krows Rm,  bar Rm += bar Krows^T Rp   (Krows = Rp Rm^T, Rm = the m pivot rows)."""
+      bar Rp = bar Krows Rm,  bar Rm += bar Krows^T Rp   (Krows = Rp Rm^T, Rm = the m pivot rows).
+    `factor`: the pivoted-Cholesky factor L [*, N, m] itself when the caller has it (the preconditioner cache does):
+    Rest = K21 L11^-T IS its non-pivot rows and L11 its pivot rows, so the N x R x m and N x m x m products that
+    rebuild them are skipped."""
     from ..utils.cholesky import psd_safe_cholesky
 
     R = r.size(-1)
@@ -61,8 +64,12 @@ def _dense_root_vjp(r, perm, grad_L, m):
     idx_m = piv.unsqueeze(-1).expand(*piv.shape, m)
     grad_L = grad_L.contiguous()
     rm = torch.gather(r, -2, idx_r)  # the m pivot rows of the root  [*, m, R]
-    krows = r @ rm.mT  # K[:, pivots]  [*, N, m]
-    k11 = torch.gather(krows, -2, idx_m).detach().clone().requires_grad_(True)
+    if factor is not None:
+        rest = factor if factor.is_contiguous() else factor.contiguous()
+        k11 = (rm @ rm.mT).detach().requires_grad_(True)  # K[pivots, pivots]  [*, m, m]
+    else:
+        krows = r @ rm.mT  # K[:, pivots]  [*, N, m]
+        k11 = torch.gather(krows, -2, idx_m).detach().clone().requires_grad_(True)
     with torch.enable_grad():
         l11 = psd_safe_cholesky(k11)
     l11d = l11.detach()
@@ -71,15 +78,19 @@ def _dense_root_vjp(r, perm, grad_L, m):
     l11_inv = torch.linalg.solve_triangular(l11d, eye, upper=False)
     g11 = torch.gather(grad_L, -2, idx_m)
     g2 = grad_L.scatter(-2, idx_m, 0.0)  # gradient of the non-pivot rows (pivot rows zeroed)
-    rest = krows @ l11_inv.mT  # K21 L11^-T (its pivot rows meet zeros of g2 only)
+    if factor is None:
+        rest = krows @ l11_inv.mT  # K21 L11^-T (its pivot rows meet zeros of g2 only)
     lbar = g11 - l11_inv.mT @ (g2.mT @ rest)
     (k11bar,) = torch.autograd.grad(l11, k11, grad_outputs=lbar)
-    kbar = (g2 @ l11_inv).scatter(-2, idx_m, k11bar)  # bar K[:, pivots]: G2 L11^-1 below, bar K11 on the pivot rows
-    r_bar = kbar @ rm
-    return r_bar.scatter_add(-2, idx_r, kbar.mT @ r)
+    # bar K[:, pivots] = G2 L11^-1 below the pivots (kb0) and bar K11 on the pivot rows (S); with Krows = R Rm^T
+    #   bar R = kb0 Rm + [pivot rows] (S Rm + (kb0 + S)^T R):
+    # the N-sized work is ONE product G2 (L11^-1 Rm) and ONE reduction G2^T R, the rest is m x m / m x R algebra
+    r_bar = g2 @ (l11_inv @ rm)
+    piv_rows = k11bar @ rm + l11_inv.mT @ (g2.mT @ r) + k11bar.mT @ rm
+    return r_bar.scatter_add_(-2, idx_r, piv_rows)
 
 
-def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False):
+def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False, factor=None):
     """Vector-Jacobian product of the pivoted-Cholesky factor L [*batch, N, m] with respect to the tensors that
     represent `linear_op`, the way PivotedCholesky.backward does it (reference :107-147): re-express the factor of
     the SAME pivots as  Pi^T [chol(K_pp); (chol(K_pp)^-1 K_pr)^T]  with differentiable ATen ops on the m pivot rows
@@ -95,7 +106,7 @@ def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False):
     perm = full_permutation
     reps = linear_op.representation()
     if not generic and isinstance(linear_op, RootLinearOperator) and len(reps) == 1 and linear_op._dense_root() is reps[0]:
-        return [_dense_root_vjp(reps[0].detach(), perm, grad_L, m)]
+        return [_dense_root_vjp(reps[0].detach(), perm, grad_L, m, factor=factor)]
     inv_perm = inverse_permutation(perm)
     leaves = []
     for t in linear_op.representation():

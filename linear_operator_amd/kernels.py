@@ -668,7 +668,9 @@ def bilinear_root(root: torch.Tensor, left_vecs: torch.Tensor, right_vecs: torch
     dev = U.device
     # the kernel keeps a D x R tile on chip (D R <= 2048): wider problems go in column chunks, the derivative is a sum
     # over the columns
-    dmax = max(1, 2048 // R)
+    # (phase A: D R <= 2048; phase B: T1 | T2 padded to 32-column blocks + 32 staged rows of U, V in 64 KB of LDS)
+    rp = (R + 31) // 32 * 32
+    dmax = max(1, min(2048 // R, (16000 // (2 * rp + 64)) & ~1))
     out, rowdot = None, None
     for d0 in range(0, D, dmax):
         Uc, Vc = (U, V) if D <= dmax else (U[..., d0:d0 + dmax].contiguous(), V[..., d0:d0 + dmax].contiguous())
