@@ -1,2 +1,2 @@
 #!/bin/bash
-python -m pytest tests -q -x -m gpu > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -3; grep -E "^E " gpurun_out/pytest_gpu.log | head -10
+python tools/mb_dist_overlap.py 2>&1 | grep -E "^reserve"
