@@ -430,6 +430,9 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
+        # at most 32 RCCL channels (= workgroups): the resident kernels leave 32 CUs' worth of slots (LO_OC_RESERVE_CUS
+        # below) and a 16 MB per-rank all-gather does not need more
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
