@@ -598,7 +598,9 @@ __global__ __launch_bounds__(kThreads) void k_pb_gram_root(const float* __restri
 // ---- root form (see lo_amd.h: lo_precond_desc.F / EF / E) ------------------------------------------------------------
 // One wave per member, fp64 in LDS: E from the Gram partials of W = C / sqrt(d) (or C^T C / sigma), the recurrence for
 // M on the pivot rows, G = I + M^T E M, its Cholesky factor, F = M G^-1 M^T = (M Lg^-T)(M Lg^-T)^T, EF, logdet.
-__global__ __launch_bounds__(64) void k_pb_rootform(const double* __restrict__ gpart, const double* __restrict__ logd_part,
+// (256 threads: the kernel is a chain of global-load latencies -- pivots -> pivot rows of C and L, S partial Gram
+// matrices -- and small fp64 loops; with one wave every lane walked 8 - 16 dependent loads one after the other: 74 us)
+__global__ __launch_bounds__(kThreads) void k_pb_rootform(const double* __restrict__ gpart, const double* __restrict__ logd_part,
                                                      const float* __restrict__ C, int R, const float* __restrict__ dd,
                                                      int diag_mode, const float* __restrict__ L, LStride ls,
                                                      const long long* __restrict__ perm, int N, int k, int S, int ld,
@@ -610,10 +612,13 @@ __global__ __launch_bounds__(64) void k_pb_rootform(const double* __restrict__ g
   __shared__ double T[kPbMaxK][kPbMaxK + 1];   // scratch: E M, then Y = M Lg^-T
   __shared__ double G[kPbMaxK][kPbMaxK + 1];
   __shared__ double Fm[kPbMaxK][kPbMaxK + 1];
+  __shared__ long long piv[kPbMaxK];
   const int64_t b = blockIdx.x;
   const int lane = threadIdx.x;
+  constexpr int NT = kThreads;
   const double sigma = (diag_mode == LO_DIAG_CONST) ? (double)dd[b] : 1.0;
-  for (int pr = lane; pr < R * R; pr += 64) {
+  if (lane < k) piv[lane] = perm[(size_t)b * N + lane];
+  for (int pr = lane; pr < R * R; pr += NT) {
     double t = 0.0;
     for (int s = 0; s < S; ++s) t += gpart[((size_t)b * S + s) * R * R + pr];
     E[pr / R][pr % R] = t / sigma;  // (FULL: the rows were scaled by 1/sqrt(d); CONST: C^T C / sigma)
@@ -622,13 +627,14 @@ __global__ __launch_bounds__(64) void k_pb_rootform(const double* __restrict__ g
   // L are fetched first (all loads in flight together: T <- C[pi_j, :], Fm <- L[pi_j, i]), the recurrence runs from LDS
   const float* Cb = C + (size_t)b * N * R;
   const float* Lb = L + (size_t)b * ls.member;
-  for (int pr = lane; pr < k * R; pr += 64) {
+  __syncthreads();
+  for (int pr = lane; pr < k * R; pr += NT) {
     const int j = pr / R, a = pr % R;
-    T[j][a] = (double)Cb[(size_t)perm[(size_t)b * N + j] * R + a];
+    T[j][a] = (double)Cb[(size_t)piv[j] * R + a];
   }
-  for (int pr = lane; pr < k * k; pr += 64) {
+  for (int pr = lane; pr < k * k; pr += NT) {
     const int j = pr / k, i = pr % k;
-    if (i <= j) Fm[j][i] = (double)Lb[(size_t)perm[(size_t)b * N + j] * ls.row + (size_t)i * ls.col];
+    if (i <= j) Fm[j][i] = (double)Lb[(size_t)piv[j] * ls.row + (size_t)i * ls.col];
   }
   __syncthreads();
   if (lane < R) {  // (row `lane` of M depends on its own earlier entries only: no barrier inside the recurrence)
@@ -639,14 +645,14 @@ __global__ __launch_bounds__(64) void k_pb_rootform(const double* __restrict__ g
     }
   }
   __syncthreads();
-  for (int pr = lane; pr < R * k; pr += 64) {  // T = E M  [R][k]
+  for (int pr = lane; pr < R * k; pr += NT) {  // T = E M  [R][k]
     const int a = pr / k, j = pr % k;
     double t = 0.0;
     for (int c2 = 0; c2 < R; ++c2) t += E[a][c2] * M[c2][j];
     T[a][j] = t;
   }
   __syncthreads();
-  for (int pr = lane; pr < k * k; pr += 64) {  // G = I + M^T T
+  for (int pr = lane; pr < k * k; pr += NT) {  // G = I + M^T T
     const int i = pr / k, j = pr % k;
     double t = (i == j) ? 1.0 : 0.0;
     for (int a = 0; a < R; ++a) t += M[a][i] * T[a][j];
@@ -657,9 +663,9 @@ __global__ __launch_bounds__(64) void k_pb_rootform(const double* __restrict__ g
     if (lane == 0) G[j][j] = sqrt(G[j][j]);
     __syncthreads();
     const double dj = G[j][j];
-    for (int i = j + 1 + lane; i < k; i += 64) G[i][j] /= dj;
+    for (int i = j + 1 + lane; i < k; i += NT) G[i][j] /= dj;
     __syncthreads();
-    for (int e = lane; e < (k - j - 1) * (k - j - 1); e += 64) {
+    for (int e = lane; e < (k - j - 1) * (k - j - 1); e += NT) {
       const int i = j + 1 + e / (k - j - 1), c2 = j + 1 + e % (k - j - 1);
       if (c2 <= i) G[i][c2] -= G[i][j] * G[c2][j];
     }
@@ -674,7 +680,7 @@ __global__ __launch_bounds__(64) void k_pb_rootform(const double* __restrict__ g
     }
   }
   __syncthreads();
-  for (int pr = lane; pr < R * R; pr += 64) {  // F = Y Y^T
+  for (int pr = lane; pr < R * R; pr += NT) {  // F = Y Y^T
     const int a = pr / R, c2 = pr % R;
     double t = 0.0;
     for (int j = 0; j < k; ++j) t += T[a][j] * T[c2][j];
@@ -684,7 +690,7 @@ __global__ __launch_bounds__(64) void k_pb_rootform(const double* __restrict__ g
   float* Fb = F + (size_t)b * ld * ld;
   float* EFb = EF + (size_t)b * ld * ld;
   float* Eb = Eo + (size_t)b * ld * ld;
-  for (int pr = lane; pr < ld * ld; pr += 64) {
+  for (int pr = lane; pr < ld * ld; pr += NT) {
     const int a = pr / ld, c2 = pr % ld;
     double f = 0.0, ef = 0.0, e = 0.0;
     if (a < R && c2 < R) {
@@ -1070,7 +1076,7 @@ int lo_precond_root_form_f32(const float* C, int32_t R, const float* d, int32_t 
   LO_PROF_END(st);
   const LStride ls{ld_member, ld_row, ld_col};
   LO_PROF_BEGIN("pb_rootform", st);
-  hipLaunchKernelGGL(k_pb_rootform, dim3((unsigned)B), dim3(64), 0, st, gpart, logd, C, (int)R, d, diag_mode, L, ls,
+  hipLaunchKernelGGL(k_pb_rootform, dim3((unsigned)B), dim3(kThreads), 0, st, gpart, logd, C, (int)R, d, diag_mode, L, ls,
                      (const long long*)perm, (int)N, (int)k, sp.S, (int)rf_ld, F, EF, E, logdet_p, dinv);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();

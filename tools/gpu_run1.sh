@@ -1,8 +1,3 @@
 #!/bin/bash
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 20 --warmup 3 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['n_gpus'])"
-export MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1
-LO_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --steps 40 --warmup 3 --no-extras --no-cpu-baseline 2> gpurun_out/dist_err.log | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['config']['sharding'])"
+python tools/mb_rootform.py 2>&1 | grep "^B="
+python -m pytest tests/test_gpu_parity.py -q -x -k "root_form or onchip or lockstep or precond" 2>&1 | tail -2
