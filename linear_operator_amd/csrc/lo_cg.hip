@@ -411,6 +411,8 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   CgDev dd;
   dd.B = B; dd.N = N; dd.c = (int)c; dd.S = sp.S;
   dd.ctrl = ar.take<CgCtrl>(1);
+  // (granule buffer of the serial resident kernels right behind the control block: ONE memset clears both)
+  dd.oc_gbuf = ar.take<unsigned long long>(onchip_gbuf_bytes(64) / sizeof(unsigned long long));
   dd.x = ar.take<float>(nv);
   dd.r = ar.take<float>(nv);
   dd.p = ar.take<float>(nv);
@@ -440,7 +442,6 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   dd.prev_beta = ar.take<float>(nt);
   dd.ctrl_part = ar.take<float>(3 * 256);
   // operator-resident fast path scratch (c == 1): granule buffer, error word, per-iteration residuals
-  dd.oc_gbuf = ar.take<unsigned long long>(onchip_gbuf_bytes(64) / sizeof(unsigned long long));
   dd.oc_err = reinterpret_cast<int*>(reinterpret_cast<char*>(dd.ctrl) + offsetof(CgCtrl, oc_err));  // (+ oc_next)
   const int fmi0 = prm->floor_max_iter > 0 ? prm->floor_max_iter : prm->max_iter;
   int oc_iters = std::min(10, fmi0 - 1);
@@ -563,7 +564,13 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   const int* stop = &d.ctrl->stop;
   dim3 gridv(sp.S, (unsigned)B), block(kThreads);
 
-  LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, sizeof(CgCtrl), st));
+  {  // control block (+ the granule buffer behind it when a resident kernel may run)
+    const bool oc_possible = op->kind == LO_OP_LOWRANK_DIAG && !g_onchip_disabled;
+    const size_t span = oc_possible ? (size_t)(reinterpret_cast<char*>(d.oc_gbuf) - reinterpret_cast<char*>(d.ctrl)) +
+                                          onchip_gbuf_bytes(64)
+                                    : sizeof(CgCtrl);
+    LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, span, st));
+  }
   if (prm->n_tridiag)
     LO_HIP_CHECK(hipMemsetAsync(t_mat, 0, sizeof(float) * (size_t)prm->n_tridiag * B * d.T * d.T, st));
 
@@ -697,8 +704,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       a.EF = oc_nopre ? nullptr : pre->EF;
       a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
       a.dbg = oc_dbg ? d.oc_dbg : nullptr;
-      LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(64), st));
-      rc = onchip5_launch(pl.R4, a, oc_nwg, st);
+      rc = onchip5_launch(pl.R4, a, oc_nwg, st);  // (d.oc_gbuf was cleared together with the control block)
       if (rc == LO_OK) serial_done = true;
       else if (rc == LO_ERR_UNSUPPORTED) rc = LO_OK;  // (does not fit: the Q-form kernels below)
     }

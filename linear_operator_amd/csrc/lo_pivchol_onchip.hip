@@ -17,7 +17,7 @@
 //
 // The batch-global stopping rule (:57: one shared m, stop when max_b error <= tol) cannot be evaluated inside
 // a kernel whose groups work on different members at different times, so the kernel takes all `rank` pivots and
-// records the error after each; k_po_rank then finds the reference's m*, and k_po_perm rebuilds the permutation
+// records the error after each; k_po_perm then finds the reference's m* (po_rank) and rebuilds the permutation
 // from the recorded swaps 0..m*-1 and clears the rows of L the reference would not have written.
 #include <algorithm>
 #include <math.h>
@@ -665,8 +665,9 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
 // m* = number of pivots the reference takes: pivot 0 always, pivot m >= 1 while max_b error_{m-1} > tol (:57, :99).
 // Wave w evaluates the pivots m = w + 1, w + 5, ... (max over the members with wave butterflies, no barriers inside);
 // thread 0 then takes the first failing m.
-__global__ __launch_bounds__(kThreads) void k_po_rank(PoArgs a, float tol, int* m_out) {
-  __shared__ int cont_s[PO_MAXR + 1];
+// (Evaluated by EVERY workgroup of k_po_perm -- 14 x B error values from L2 -- instead of a one-workgroup kernel in
+// front of it: one launch and its gap less on a path where every launch is ~1 % of the factorisation.)
+__device__ __forceinline__ int po_rank(const PoArgs& a, float tol, int* cont_s, int* mstar_s) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int m = 1 + wave; m < a.rank; m += kThreads / 64) {
     float lmax = -INFINITY, lnan = 0.f;
@@ -688,13 +689,19 @@ __global__ __launch_bounds__(kThreads) void k_po_rank(PoArgs a, float tol, int* 
         mstar = m;
         break;
       }
-    *m_out = mstar;
+    *mstar_s = mstar;
   }
+  __syncthreads();
+  return *mstar_s;
 }
 
-__global__ __launch_bounds__(kThreads) void k_po_perm(PoArgs a, const int* __restrict__ m_in, long long* __restrict__ perm) {
+__global__ __launch_bounds__(kThreads) void k_po_perm(PoArgs a, float tol, int* __restrict__ m_out,
+                                                       long long* __restrict__ perm) {
+  __shared__ int cont_s[PO_MAXR + 1];
+  __shared__ int mstar_s;
   const int64_t b = blockIdx.x;
-  const int mstar = *m_in;
+  const int mstar = po_rank(a, tol, cont_s, &mstar_s);
+  if (b == 0 && threadIdx.x == 0) *m_out = mstar;
   long long* pb = perm + (size_t)b * a.N;
   for (int i = threadIdx.x; i < a.N; i += kThreads) pb[i] = i;
   if (mstar < a.rank) {
@@ -827,9 +834,8 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   else hipLaunchKernelGGL((k_pc_onchip<8>), grid, block, 0, st, a);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_po_rank, dim3(1), dim3(kThreads), 0, st, a, tol, l.m_out);
   LO_PROF_BEGIN("pc_onchip_perm", st);
-  hipLaunchKernelGGL(k_po_perm, dim3((unsigned)op->B), dim3(kThreads), 0, st, a, l.m_out, perm);
+  hipLaunchKernelGGL(k_po_perm, dim3((unsigned)op->B), dim3(kThreads), 0, st, a, tol, l.m_out, perm);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   int h[2];

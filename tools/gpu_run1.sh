@@ -1,3 +1,5 @@
 #!/bin/bash
-python tools/mb_rootform.py 2>&1 | grep "^B="
-python -m pytest tests/test_gpu_parity.py -q -x -k "root_form or onchip or lockstep or precond" 2>&1 | tail -2
+python -m pytest tests -q -x -m gpu > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -3; grep -E "^E " gpurun_out/pytest_gpu.log | head -10
+python bench.py --steps 30 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['end_to_end_ms'])"
