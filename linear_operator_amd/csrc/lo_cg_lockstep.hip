@@ -713,6 +713,7 @@ static int lockstep_go(const OnchipArgs& a, int ncu, hipStream_t st) {
       per_cu < per_cu_needed)
     return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("cg_lockstep", st);
+  ResidentLaunch guard(st);
   hipLaunchKernelGGL((k_cg_lockstep<RC, PRE, GW, NW, DBG>), dim3(per_cu_needed * ncu), dim3(NW * 64), 0, st, a);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();

@@ -24,6 +24,7 @@
 // evaluated by lo_cg.hip's control kernel, which continues with the streaming loop in the (rare) case that the
 // tolerance is not yet met.
 #include <algorithm>
+#include <mutex>
 #include <stdlib.h>
 
 #include "lo_device.h"
@@ -422,6 +423,33 @@ bool onchip_eligible(int RC, int RK, int64_t N, int64_t c) {
   return rc_ok && rk_ok && c == 1 && N <= (int64_t)OC_GW * OC_TPB && N >= 1024;
 }
 
+namespace {
+std::mutex g_res_mu;
+hipStream_t g_res_last = nullptr;
+int g_res_last_dev = -1;
+bool g_res_have = false;
+hipEvent_t g_res_ev[16] = {};
+}  // namespace
+
+ResidentLaunch::ResidentLaunch(hipStream_t st) {
+  g_res_mu.lock();
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
+  if (g_res_have && g_res_last_dev == dev && g_res_last != st && !getenv("LO_NO_RESIDENT_ORDER")) {
+    if (!g_res_ev[dev] && hipEventCreateWithFlags(&g_res_ev[dev], hipEventDisableTiming) != hipSuccess) g_res_ev[dev] = nullptr;
+    // (a stream the caller has destroyed in the meantime makes the record fail: nothing left to wait for)
+    if (g_res_ev[dev] && hipEventRecord(g_res_ev[dev], g_res_last) == hipSuccess)
+      (void)hipStreamWaitEvent(st, g_res_ev[dev], 0);
+    else
+      (void)hipGetLastError();
+  }
+  g_res_last = st;
+  g_res_last_dev = dev;
+  g_res_have = true;
+}
+
+ResidentLaunch::~ResidentLaunch() { g_res_mu.unlock(); }
+
 int onchip_num_workgroups() {
   int dev = 0;
   hipDeviceProp_t prop;
@@ -437,6 +465,7 @@ int onchip_num_workgroups() {
 
 int onchip_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st) {
   dim3 grid(nwg), block(OC_TPB);
+  ResidentLaunch guard(st);
   LO_PROF_BEGIN("cg_onchip", st);
 #define LO_OC(C_, K_) hipLaunchKernelGGL((k_cg_onchip<C_, K_>), grid, block, 0, st, a)
   if (RC == 32 && RK == 16) LO_OC(32, 16);

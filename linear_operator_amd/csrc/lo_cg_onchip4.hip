@@ -330,6 +330,7 @@ static int onchip4_go(const OnchipArgs& a, int nwg, hipStream_t st) {
       per_cu < (half ? 1 : 2))
     return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("cg_onchip", st);
+  ResidentLaunch guard(st);
   hipLaunchKernelGGL((k_cg_onchip4<RC, RK, GW, MC>), dim3(half ? nwg : 2 * nwg), dim3(R4_TPB), 0, st, a);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
@@ -664,6 +665,7 @@ static int onchip5_go(const OnchipArgs& a, int nwg, hipStream_t st) {
       per_cu < 2)
     return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("cg_onchip", st);
+  ResidentLaunch guard(st);
   hipLaunchKernelGGL((k_cg_onchip5<RC, GW, MC>), dim3(2 * nwg), dim3(R4_TPB), 0, st, a);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();

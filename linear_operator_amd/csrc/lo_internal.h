@@ -201,6 +201,17 @@ bool onchip_eligible(int RC, int RK, int64_t N, int64_t c);
 int onchip_num_workgroups();
 bool onchip4_eligible(int RC, int RK, int64_t N, int64_t c);  // lo_cg_onchip4.hip
 int onchip4_group_size(int64_t N);
+// Kernels whose workgroups wait for each other need ALL of them resident: two such kernels on two streams of one
+// process would each take part of the CUs and spin until the hand-off timeout.  Construct a ResidentLaunch right before
+// such a launch (same scope): if the previous resident kernel of this process went to a DIFFERENT stream, the new stream
+// is made to wait for everything submitted to that stream so far; host threads are serialised for the duration of the
+// launch call.  No cost when all solves use one stream.
+struct ResidentLaunch {
+  explicit ResidentLaunch(hipStream_t st);
+  ~ResidentLaunch();
+  ResidentLaunch(const ResidentLaunch&) = delete;
+  ResidentLaunch& operator=(const ResidentLaunch&) = delete;
+};
 extern bool g_onchip_disabled;  // lo_cg_set_onchip(0): streaming engines only (tests compare the two)
 
 // ---- single-pass Woodbury apply fused with the CG r / x update (lo_precond_fused.hip) --------------

@@ -816,6 +816,8 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   LO_HIP_CHECK(hipMemsetAsync(l.gbuf, 0, sizeof(unsigned long long) * (size_t)64 * 2 * PO_GW * PO_SLOT, st));
   dim3 grid(nwg), block(PO_TPB);
   LO_PROF_BEGIN("pc_onchip", st);
+  {
+  ResidentLaunch guard(st);
   if (gen2) {
     dim3 grid2(2 * nwg), block2(P4_TPB);
 #define LO_GO(R_, G_) hipLaunchKernelGGL((k_pc_onchip4<R_, G_>), grid2, block2, 0, st, a)
@@ -832,6 +834,7 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   } else if (RP == 32) hipLaunchKernelGGL((k_pc_onchip<32>), grid, block, 0, st, a);
   else if (RP == 16) hipLaunchKernelGGL((k_pc_onchip<16>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((k_pc_onchip<8>), grid, block, 0, st, a);
+  }
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   LO_PROF_BEGIN("pc_onchip_perm", st);

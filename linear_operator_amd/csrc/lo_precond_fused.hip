@@ -314,6 +314,7 @@ static int pf_go(PfArgs& a, int ncu, hipStream_t st) {
   const int nwg = per_cu * ncu;
   if ((nwg / 8) < GW) return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("precond_fused", st);
+  ResidentLaunch guard(st);
   hipLaunchKernelGGL((k_precond_fused<GW, OCC>), dim3(nwg), dim3(R4_TPB), 0, st, a);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();

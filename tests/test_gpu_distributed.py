@@ -249,3 +249,52 @@ def test_reserved_cus_leave_results_bit_identical(monkeypatch):
         for a, b in zip(got[:4], ref[:4]):
             assert torch.equal(a, b), reserve
     monkeypatch.delenv("LO_OC_RESERVE_CUS")
+
+
+def test_two_host_threads_solving_on_two_streams_do_not_starve_each_other():
+    """Two operator-resident kernels at once would each hold part of the CUs and spin until the hand-off timeout
+    (0.5 s per launch).  liblo_amd orders resident launches that arrive on different streams (ResidentLaunch,
+    lo_internal.h): two Python threads solving concurrently on their own streams finish quickly, bit-identical to the
+    single-threaded results."""
+    import threading
+    import time
+    from linear_operator_amd import kernels as K
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(21)
+    B, N, R = 256, 8192, 32
+    data = []
+    for _ in range(2):
+        Cm = torch.randn(B, N, R, generator=g, device="cuda") / R ** 0.5
+        d = torch.rand(B, N, generator=g, device="cuda") + 0.5
+        rhs = torch.randn(B, N, 1, generator=g, device="cuda")
+        L, perm = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15, contiguous=False)
+        pre = K.precond_build(L, d, False, root=Cm, perm=perm)
+        ref = K.cg_solve(K.lowrank_diag_descriptor(Cm, d), rhs, precond=pre, tolerance=1e-4).x.clone()
+        data.append((Cm, d, rhs, pre, ref))
+    torch.cuda.synchronize()
+    bad, errs = [0, 0], []
+
+    def worker(i):
+        try:
+            Cm, d, rhs, pre, ref = data[i]
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(20):
+                    x = K.cg_solve(K.lowrank_diag_descriptor(Cm, d), rhs, precond=pre, tolerance=1e-4).x
+                    Lx, _ = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15, contiguous=False)
+                    bad[i] += int(not torch.equal(x, ref))
+            s.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    assert not errs, errs
+    assert bad == [0, 0]
+    assert dt < 2.0, f"40 solves + 40 factorisations took {dt:.2f} s: resident kernels timed out against each other"
