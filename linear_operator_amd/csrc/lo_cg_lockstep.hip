@@ -28,7 +28,7 @@
 //     sum d p_new^2 = dzz + 2 beta dzp + beta^2 sum d p_old^2,   dzz = s2 - 2|u|^2 + u^T G u,   dzp = rp - u^T (Q^T D p_old)
 //     p.Ap = |C^T p|^2 + sum d p^2
 // identical to the reference's iteration in exact arithmetic; in fp32 the solutions and the Lanczos coefficients agree
-// with the fp64 iteration as closely as the reference's own fp32 arithmetic does (tools/proto_single_reduction.py).
+// with the fp64 iteration as closely as the reference's own fp32 arithmetic does (tests/proto/proto_single_reduction.py).
 // Without a preconditioner (z = r): u, H, G vanish, s2 -> sum r^2, dzz -> sum d r^2, dzp -> sum d r p.
 //
 // Cross-wave sums go through LDS in two stages (waves 4-7 store, waves 0-3 add and store, every thread sums four

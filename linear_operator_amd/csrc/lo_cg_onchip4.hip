@@ -363,7 +363,7 @@ int onchip4_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st)
 // the reduction delivers w (RC values), s1 = sum r^2, s2 = sum r^2 / d, rp = sum r o p_old, and the first wave derives
 //     v = F w,  E v = (E F) w,  r.z = s2 - w.v,  C^T p_new = (w - E v) + beta C^T p_old,
 //     sum d p_new^2 = (s2 - 2 w.v + v.E v) + 2 beta (rp - v . C^T p_old) + beta^2 sum d p_old^2,   p.Ap = |C^T p|^2 + sum d p^2
-// (tools/proto_root_form.py) from two RC x RC matrices in LDS before the others leave the all-reduce.  Per row the work
+// (tests/proto/proto_root_form.py) from two RC x RC matrices in LDS before the others leave the all-reduce.  Per row the work
 // is three passes over the thread's C rows in VGPRs (z = (r - C v) / d, A p = C t + d p, the partials of w): the same
 // 12 RC FMAs per row as before, half the hand-offs.  Without a preconditioner F = 0: v = 0, z = r / 1.
 struct alignas(16) R5Post {

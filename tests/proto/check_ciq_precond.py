@@ -1,7 +1,7 @@
 """Preconditioned contour integral quadrature (N above settings.min_preconditioning_size): ||A^-1/2 b||^2 against b^T A^-1 b."""
 import sys, torch, numpy as np, time
 import os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p_ in (ROOT, os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "tests")): sys.path.insert(0, p_)
 import cases
 from linear_operator_amd import settings, _hip
