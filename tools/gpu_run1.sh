@@ -1,2 +1,5 @@
 #!/bin/bash
-LO_NO_RESIDENT_ORDER=1 timeout 300 python -m pytest tests/test_gpu_distributed.py -q -x -k two_host_threads 2>&1 | grep -E "passed|failed|assert|took|timed out" | head -8
+for v in 0 1; do for np in 0 1; do
+  echo "== V2=$v NOPRE=$np"
+  env $( [ $v = 1 ] && echo LO_LS_V2=1 ) $( [ $np = 1 ] && echo LS_NOPRE=1 ) python tools/mb_lockstep.py 2>&1 | grep -E "cg_solve|cg_lockstep"
+done; done

@@ -13,6 +13,7 @@ full = torch.randn(B, N, c, generator=g, device=dev); full /= full.norm(dim=-2, 
 desc = K.lowrank_diag_descriptor(Cm, d)
 L, perm = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15, contiguous=False)
 pre = K.precond_build(L, d, False, root=Cm, perm=perm)  # Q form + root form
+if os.environ.get("LS_NOPRE"): pre = None  # (z = r: the kernel without Q, H, G)
 nt = min(c, 16)
 def run():
     return K.cg_solve(desc, full, precond=pre, n_tridiag=nt, tolerance=1e-4)
