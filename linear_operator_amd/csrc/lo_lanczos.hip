@@ -782,7 +782,9 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
   if (!ar.ok) return LO_ERR_WORKSPACE;
   const size_t nv = (size_t)B * N * P;
   dim3 grid(sp.S, (unsigned)B), block(kThreads), one(1);
-  LO_HIP_CHECK(hipMemsetAsync(q_mat, 0, sizeof(float) * nv * max_iter, st));
+  // (q_mat is NOT cleared up front -- 5.4 GB at the cfg3 shape, 0.8 ms: every stored vector is written in full; only
+  //  the vectors an early stop leaves unwritten are cleared at the end, as the reference's zeros-initialised q_mat :69)
+  int q_hi = 0;  // highest basis vector written so far
   LO_HIP_CHECK(hipMemsetAsync(t_mat, 0, sizeof(float) * (size_t)max_iter * max_iter * B * P, st));
   LzCtrl h;
   auto q = [&](int k) { return q_mat + (size_t)k * nv; };
@@ -845,6 +847,7 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
     LO_PROF_BEGIN("lz_axpy", st);
     hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 0, d.r, q(1), d.scal);  // q_1 = r / beta_0  (:98)
     LO_PROF_END(st);
+    q_hi = 1;
     LO_LAUNCH_CHECK();
     // fused path: float4 / float2 kernels, all basis vectors of a step in registers, matvec dot partials fit
     // (kLzFusedQ accumulators keep pass 1 under 128 VGPRs: four waves per SIMD)
@@ -868,6 +871,7 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
       LO_PROF_BEGIN("lz_correct_check", st);
       hipLaunchKernelGGL((k_lz_correct_check<kLzFusedQ>), grid, block, 0, st, d, k, q(k + 1));
       LO_PROF_END(st);
+      q_hi = std::max(q_hi, k + 1);
       LO_PROF_BEGIN("lz_finish", st);
       hipLaunchKernelGGL(k_lz_finish, dim3((unsigned)B), block, 0, st, d, k);
       LO_PROF_END(st);
@@ -924,6 +928,7 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
         LO_PROF_BEGIN("lz_axpy", st);
         hipLaunchKernelGGL(k_lz_axpy, grid, block, 0, st, d, 0, d.r, q(k + 1), d.scal);
         LO_PROF_END(st);
+        q_hi = std::max(q_hi, k + 1);
         LzDev dn = d;
         dn.r = q(k + 1);
         // inner products with the normalised r (:131)
@@ -957,6 +962,8 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
     }
     if (k == num_iter) k = num_iter - 1;
   }
+  if (q_hi + 1 < max_iter)
+    LO_HIP_CHECK(hipMemsetAsync(q(q_hi + 1), 0, sizeof(float) * nv * (size_t)(max_iter - q_hi - 1), st));
   LO_HIP_CHECK(hipStreamSynchronize(st));
   *iters_out = k + 1;  // :151
   return LO_OK;
