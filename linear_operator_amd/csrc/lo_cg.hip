@@ -50,6 +50,7 @@ struct CgDev {
   unsigned long long* oc_gbuf;
   unsigned long long* ls_gbuf;  // granules of the column-lockstep kernel (lo_cg_lockstep.hip) or nullptr
   unsigned long long* pf_gbuf;  // granules of the fused preconditioner apply (lo_precond_fused.hip) or nullptr
+  int* pf_ctr;                  // one member hand-out counter per launch of that kernel (max_iter + 1 ints)
   int* oc_err;
   float* oc_resid;
   int* oc_init_conv;
@@ -457,9 +458,10 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   dd.ls_gbuf = (oc_shape && c >= kLockstepMinCols && N <= 8192)
                    ? ar.take<unsigned long long>(lockstep_gbuf_bytes(32, 16) / sizeof(unsigned long long))
                    : nullptr;
-  dd.pf_gbuf = (pre && precond_fused_eligible(B, N, c, padded_rank_k(pre->k), sp.S))
-                   ? ar.take<unsigned long long>(precond_fused_gbuf_bytes() / sizeof(unsigned long long))
-                   : nullptr;
+  const bool pf_shape = pre && precond_fused_eligible(B, N, c, padded_rank_k(pre->k), sp.S);
+  dd.pf_gbuf = pf_shape ? ar.take<unsigned long long>(precond_fused_gbuf_bytes() / sizeof(unsigned long long)) : nullptr;
+  // (decided by the shape, not by the pointer: the sizing pass runs on a null arena)
+  dd.pf_ctr = pf_shape ? ar.take<int>((size_t)std::max(1, (int)prm->max_iter) + 1) : nullptr;
   dd.oc_zero_q = nullptr;
   dd.oc_ones = nullptr;
   if (!pre && !precond && oc_shape) {
@@ -824,6 +826,11 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   bool pf_on = pre && pre->Q && d.pf_gbuf && !tls_no_fused_precond && oc_nwg >= 64 &&
                precond_fused_eligible(B, N, c, preR4, sp.S);
   bool p_done = false;  // the fused apply of the previous iteration already wrote this iteration's p
+  int pf_launch = 0;
+  if (pf_on) {  // granules and hand-out counters of the fused apply: cleared once per solve (tags are unique per launch)
+    LO_HIP_CHECK(hipMemsetAsync(d.pf_gbuf, 0, precond_fused_gbuf_bytes(), st));
+    LO_HIP_CHECK(hipMemsetAsync(d.pf_ctr, 0, sizeof(int) * ((size_t)std::max(1, (int)prm->max_iter) + 1), st));
+  }
   while (k < prm->max_iter && !h.stop) {
     if (p_done) {
       rc = matvec_run(&pl, d.p, d.Ap, d.pAp_part, stop, st);
@@ -844,11 +851,13 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       // single pass over Q: r / x update, Q^T r, group all-reduce, z = r/d - Q u, p = z + beta p (lo_precond_fused.hip)
       rc = precond_fused_rupdate(Qp, pre->dinv, pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL, d.r, d.Ap, d.p, d.x,
                                  d.z, d.pAp_part, d.S_dot, d.rz, d.has_conv, d.eps, d.alpha, d.rr_part, d.rz_part, sp.S,
-                                 B, N, d.pf_gbuf, d.oc_err, d.oc_err + 3, stop, oc_nwg, st);
+                                 B, N, d.pf_gbuf, d.oc_err, d.pf_ctr + pf_launch, pf_launch, stop, oc_nwg, st);
+      ++pf_launch;
       if (rc == LO_ERR_UNSUPPORTED) pf_on = false;  // (does not fit this device: the two-launch path from now on)
       else if (rc) return rc;
       else pre_done = p_done = true;
     }
+    if (!pre_done) p_done = false;  // (the two-launch path below leaves the p update to the next iteration's first step)
     if (pre_done) {
     } else if (pre) {
       // r-update, x-update and the residual norm ride on the first pass over Q

@@ -221,7 +221,7 @@ size_t precond_fused_gbuf_bytes();
 int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, float* r, const float* Ap, float* p,
                           float* x, float* z, const float* pAp_part, int S_dot, const float* rz, const int* has_conv,
                           float eps, float* alpha_out, float* rr_part, float* rz_part, int S, int64_t B, int64_t N,
-                          unsigned long long* gbuf, int* err, int* next_member, const int* stop, int ncu,
+                          unsigned long long* gbuf, int* err, int* next_member, int launch, const int* stop, int ncu,
                           hipStream_t st);
 
 // ---- operator-resident pivoted Cholesky (lo_pivchol_onchip.hip) ----------------------------------
