@@ -55,14 +55,15 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// float index of C[row][col] inside the swizzled LDS image (rows of RC floats, 16-byte slots).  RC = 32: slot ^ (row & 7)
-// -- the 4-byte reads of the reduce product (rows 4 kk + i, 16 consecutive columns per kk) then split the two kk of a
-// half-wave over the two halves of the banks and the 16-byte reads of the expand product see 8 distinct slot rotations
-// in 8 consecutive rows; with (row >> 1) & 7 SQ_LDS_BANK_CONFLICT was 25 % of the LDS-active cycles, now 0.2 % (same
-// kernel time: the kernel is not LDS-bound).
+// float index of C[row][col] inside the swizzled LDS image (rows of RC floats, 16-byte slots).
+// RC = 32: slot ^ ((row >> 1) & 7).  Measured alternative slot ^ (row & 7): SQ_LDS_BANK_CONFLICT drops from 25 % of the
+// LDS-active cycles to 0.2 % (the two kk of a half-wave then use different halves of the banks in the 4-byte reads of
+// the reduce product) -- and the kernel gets 4.5 % SLOWER on the same box (4.00 vs 3.83 ms, three runs each): the
+// kernel is not LDS-bound, and with the conflict-free pattern the waves of a SIMD leave their LDS phases in step and
+// collide on the matrix pipe instead.  Kept as measured.
 template <int RC>
 __device__ __forceinline__ int c_idx(int row, int col) {
-  if constexpr (RC == 32) return row * 32 + ((((col >> 2) ^ (row & 7))) << 2) + (col & 3);
+  if constexpr (RC == 32) return row * 32 + ((((col >> 2) ^ ((row >> 1) & 7))) << 2) + (col & 3);
   else return row * 16 + ((((col >> 2) ^ ((row >> 2) & 3))) << 2) + (col & 3);
 }
 
