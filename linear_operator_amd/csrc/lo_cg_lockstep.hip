@@ -59,8 +59,7 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // RC = 32: slot ^ ((row >> 1) & 7).  Measured alternative slot ^ (row & 7): SQ_LDS_BANK_CONFLICT drops from 25 % of the
 // LDS-active cycles to 0.2 % (the two kk of a half-wave then use different halves of the banks in the 4-byte reads of
 // the reduce product) -- and the kernel gets 4.5 % SLOWER on the same box (4.00 vs 3.83 ms, three runs each): the
-// kernel is not LDS-bound, and with the conflict-free pattern the waves of a SIMD leave their LDS phases in step and
-// collide on the matrix pipe instead.  Kept as measured.
+// kernel is not LDS-bound (the cause of the slowdown was not isolated).  Kept as measured.
 template <int RC>
 __device__ __forceinline__ int c_idx(int row, int col) {
   if constexpr (RC == 32) return row * 32 + ((((col >> 2) ^ ((row >> 1) & 7))) << 2) + (col & 3);
