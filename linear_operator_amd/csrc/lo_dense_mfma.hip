@@ -1,4 +1,4 @@
-// lo_dense_mfma.hip -- y = K v + d o v for dense K [B,N,N] and MANY columns (4 < c <= 32) on the matrix cores
+// lo_dense_mfma.hip -- y = K v + d o v for dense K [B,N,N] and 2 <= c <= 32 columns (per pass) on the matrix cores
 // (reference: AddedDiagLinearOperator._matmul added_diag_linear_operator.py:72-76 over DenseLinearOperator._matmul
 // dense_linear_operator.py:60-64; BASELINE cfg5: dense 16384^2 with 16 probes + 1 rhs).
 // HBM-bound: K (N^2 floats per member) is streamed exactly ONCE for all columns -- the 4-column VALU kernel in
@@ -386,7 +386,9 @@ static void launch_mv16(int nv, dim3 grid, hipStream_t st, const float* K, const
 #undef LO_MV16
 }
 
-bool dense_mfma_ok(int64_t N, int64_t c) { return c > 4 && N >= 256; }
+// c = 1 stays on the vector-ALU kernel (6.2 TB/s at 16384^2); from two columns on the 16-wide matrix-core tile streams K
+// faster (5.8 - 6.0 TB/s against 4.2 / 4.2 / 2.2 TB/s of the VALU kernel at c = 2 / 3 / 4: tools/mb_dense_cols.py)
+bool dense_mfma_ok(int64_t N, int64_t c) { return c >= 2 && N >= 256; }
 int dense_mfma_tiles(int64_t N) { return (int)((N + DM_ROWS - 1) / DM_ROWS); }
 
 int dense_matvec_mfma(const float* K, const float* d, int dd_mode, const float* v, float* y, float* dot_part, int64_t B,
