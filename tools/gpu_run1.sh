@@ -1,3 +1,2 @@
 #!/bin/bash
-python tools/mb_dense_cols.py 2>&1 | grep "^c=" | head -5
-python -m pytest tests -q -x -m gpu > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -2; grep -E "^E " gpurun_out/pytest_gpu.log | head -5
+python tools/mb_lowrank_cols.py 2>&1 | grep "^R="
