@@ -190,6 +190,10 @@ int kron_matvec(const float* K1, const float* K2, const float* v, float* tmp, fl
 int kron_bilinear(const float* K1, const float* K2, const float* U, const float* V, float* tmp, float* dK1, float* dK2,
                   int64_t B, int n1, int n2, int64_t D, hipStream_t st);
 bool kron_mfma_ok(int n1, int n2, int64_t c);
+bool kron_mfma_cols_ok(int n1, int n2, int64_t c);  // c > 1 on the matrix-core engine (columns moved to the front)
+int kron_matvec_mfma_cols(const float* K1, const float* K2, const float* diag, int diag_mode, const float* v,
+                          float* buf_a, float* buf_b, float* y, int64_t B, int n1, int n2, int64_t c, const int* stop,
+                          hipStream_t st);
 int kron_S_dot(int n1, int n2, int64_t c, int S_default);
 int kron_matvec_mfma(const float* K1, const float* K2, const float* diag, int diag_mode, const float* v, float* tmp,
                      float* y, float* dot_part, int64_t B, int n1, int n2, const int* stop, hipStream_t st);

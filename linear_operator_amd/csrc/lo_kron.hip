@@ -115,6 +115,7 @@ struct KmArgs {
   int diag_mode;
   const float* v;   // [z][M][N]
   float* dot_part;  // [z][tiles] or nullptr
+  int a_div;        // operand A of batch item z is matrix z / a_div (several right-hand-side columns share a factor)
 };
 
 __device__ __forceinline__ int km_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int tile = rest % tiles, z = (rest / tiles) * 8 + xcd;
   if (z >= g.B) return;
   const int m0 = (tile / tiles_n) * KM_BM, n0 = (tile % tiles_n) * KM_BN;
-  const float* A = g.A + (size_t)z * g.M * g.K + (size_t)m0 * g.K;
+  const float* A = g.A + (size_t)(z / g.a_div) * g.M * g.K + (size_t)m0 * g.K;
   const float* Bm = g.Bm + (size_t)z * g.N * g.K + (size_t)n0 * g.K;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
   const int wr = wave & 1, wc = wave >> 1;  // wave quadrant: rows 64 wr .. +63, columns 64 wc .. +63
@@ -248,6 +249,7 @@ int kron_matvec_mfma(const float* K1, const float* K2, const float* diag, int di
                      float* y, float* dot_part, int64_t B, int n1, int n2, const int* stop, hipStream_t st) {
   KmArgs g;
   g.B = (int)B;
+  g.a_div = 1;
   g.A = K2; g.Bm = v; g.D = tmp;  // Tt [n2, n1]
   g.M = n2; g.N = n1; g.K = n2;
   g.diag = nullptr; g.diag_mode = LO_DIAG_NONE; g.v = nullptr; g.dot_part = nullptr;
@@ -260,6 +262,84 @@ int kron_matvec_mfma(const float* K1, const float* K2, const float* diag, int di
   g.diag = diag; g.diag_mode = diag ? diag_mode : LO_DIAG_NONE; g.v = v; g.dot_part = dot_part;
   LO_PROF_BEGIN("kron_gemm_mfma", st);
   hipLaunchKernelGGL((k_kron_nt_mfma<true>), dim3((unsigned)(((B + 7) / 8) * 8 * (g.M / KM_BM) * (g.N / KM_BN))), dim3(kThreads), 0, st, g, stop);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+// ---- several columns on the matrix-core engine ---------------------------------------------------------------------
+// The matrix-core GEMMs want k-contiguous operands, the vectors arrive as [B, N, c] (columns innermost).  For c > 1 the
+// columns are moved to the front once ([B, c, N]: a batch of B c single-column problems that share the factors),
+// both GEMMs run on the single-column engine with batch B c, and the result is moved back: two extra passes over
+// 2 N c floats per member against 4.5 ms -> 2.x ms for the products at cfg4's shape with 17 columns (the strided VALU
+// GEMM reaches 33 TFLOP/s, the matrix-core engine 72).
+//   in [Z][n][c] -> out [Z][c][n]   (to_front)   or   in [Z][c][n] -> out [Z][n][c] (+ dd o v: the operator's diagonal
+//   rides on the way back)
+__global__ __launch_bounds__(kThreads) void k_kron_cols(const float* __restrict__ in, float* __restrict__ out, int n,
+                                                         int c, int to_front, const float* __restrict__ dd, int dd_mode,
+                                                         const float* __restrict__ vin,
+                                                         const int* __restrict__ stop) {
+  if (stop && *stop) return;
+  extern __shared__ float tl[];  // [256][c + 1]
+  const int64_t z = blockIdx.y;
+  const int r0 = blockIdx.x * kThreads;
+  const int nr = min(kThreads, n - r0);
+  const int ld = c | 1;
+  if (to_front) {
+    const float* src = in + ((size_t)z * n + r0) * c;  // nr * c contiguous floats
+    for (int e = threadIdx.x; e < nr * c; e += kThreads) tl[(e / c) * ld + e % c] = src[e];
+    __syncthreads();
+    for (int col = 0; col < c; ++col)
+      if (threadIdx.x < nr) out[((size_t)z * c + col) * n + r0 + threadIdx.x] = tl[threadIdx.x * ld + col];
+  } else {
+    for (int col = 0; col < c; ++col)
+      if (threadIdx.x < nr) tl[threadIdx.x * ld + col] = in[((size_t)z * c + col) * n + r0 + threadIdx.x];
+    __syncthreads();
+    float* dst = out + ((size_t)z * n + r0) * c;
+    const float* vs = vin + ((size_t)z * n + r0) * c;
+    const float dconst = (dd_mode == LO_DIAG_CONST) ? dd[z] : 0.f;
+    for (int e = threadIdx.x; e < nr * c; e += kThreads) {
+      float val = tl[(e / c) * ld + e % c];
+      if (dd_mode == LO_DIAG_FULL) val = fmaf(dd[(size_t)z * n + r0 + e / c], vs[e], val);
+      else if (dd_mode == LO_DIAG_CONST) val = fmaf(dconst, vs[e], val);
+      dst[e] = val;
+    }
+  }
+}
+
+bool kron_mfma_cols_ok(int n1, int n2, int64_t c) { return c > 1 && c <= 64 && kron_mfma_ok(n1, n2, 1); }
+
+// y = (K1 (x) K2) v + dd o v for v, y [B, N, c]; buf_a, buf_b: B N c floats each
+int kron_matvec_mfma_cols(const float* K1, const float* K2, const float* diag, int diag_mode, const float* v,
+                          float* buf_a, float* buf_b, float* y, int64_t B, int n1, int n2, int64_t c, const int* stop,
+                          hipStream_t st) {
+  const int N = n1 * n2;
+  const size_t lds = sizeof(float) * (size_t)kThreads * ((size_t)c | 1);
+  dim3 tgrid((unsigned)((N + kThreads - 1) / kThreads), (unsigned)B);
+  LO_PROF_BEGIN("kron_cols", st);
+  hipLaunchKernelGGL(k_kron_cols, tgrid, dim3(kThreads), lds, st, v, buf_a, N, (int)c, 1, nullptr, LO_DIAG_NONE, nullptr,
+                     stop);
+  LO_PROF_END(st);
+  KmArgs g;
+  const int64_t Z = B * c;
+  g.B = (int)Z;
+  g.a_div = (int)c;
+  g.diag = nullptr; g.diag_mode = LO_DIAG_NONE; g.v = nullptr; g.dot_part = nullptr;
+  g.A = K2; g.Bm = buf_a; g.D = buf_b;  // Tt [n2, n1] per (member, column)
+  g.M = n2; g.N = n1; g.K = n2;
+  LO_PROF_BEGIN("kron_gemm_mfma", st);
+  hipLaunchKernelGGL((k_kron_nt_mfma<false>), dim3((unsigned)(((Z + 7) / 8) * 8 * (g.M / KM_BM) * (g.N / KM_BN))),
+                     dim3(kThreads), 0, st, g, stop);
+  LO_PROF_END(st);
+  g.A = K1; g.Bm = buf_b; g.D = buf_a;  // Y [n1, n2]
+  g.M = n1; g.N = n2; g.K = n1;
+  LO_PROF_BEGIN("kron_gemm_mfma", st);
+  hipLaunchKernelGGL((k_kron_nt_mfma<false>), dim3((unsigned)(((Z + 7) / 8) * 8 * (g.M / KM_BM) * (g.N / KM_BN))),
+                     dim3(kThreads), 0, st, g, stop);
+  LO_PROF_END(st);
+  LO_PROF_BEGIN("kron_cols", st);
+  hipLaunchKernelGGL(k_kron_cols, tgrid, dim3(kThreads), lds, st, buf_a, y, N, (int)c, 0, diag,
+                     diag ? diag_mode : LO_DIAG_NONE, v, stop);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;

@@ -36,7 +36,7 @@ size_t matvec_plan_bytes(const lo_op_desc* op, int64_t c, Split sp) {
     if (R4 != op->R) ar.take<float>((size_t)op->B * op->N * R4);
     ar.take<float>((size_t)op->B * sp.S * R4 * c);
   } else if (op->kind == LO_OP_KRON_DIAG) {
-    ar.take<float>((size_t)op->B * op->N * c);
+    ar.take<float>((size_t)op->B * op->N * c * (kron_mfma_cols_ok((int)op->R, (int)op->n2, c) ? 2 : 1));
   }
   return ar.off + 256;
 }
@@ -84,7 +84,7 @@ int matvec_plan_init(MatvecPlan* pl, const lo_op_desc* op, lo_matvec_cb cb, void
     }
     case LO_OP_KRON_DIAG: {
       if (!op->A0 || !op->A1 || op->R * op->n2 != op->N) return LO_ERR_BADARG;
-      pl->kron_tmp = ar->take<float>((size_t)op->B * op->N * c);
+      pl->kron_tmp = ar->take<float>((size_t)op->B * op->N * c * (kron_mfma_cols_ok((int)op->R, (int)op->n2, c) ? 2 : 1));
       pl->S_dot = kron_S_dot((int)op->R, (int)op->n2, c, sp.S);
       break;
     }
@@ -140,10 +140,17 @@ int matvec_run(const MatvecPlan* pl, const float* v, float* y, float* dot_part, 
       if (kron_mfma_ok((int)op.R, (int)op.n2, pl->c))
         return kron_matvec_mfma(op.A0, op.A1, op.d, op.diag_mode, v, pl->kron_tmp, y, dot_part, op.B, (int)op.R,
                                 (int)op.n2, stop, st);
-      rc = kron_matvec(op.A0, op.A1, v, pl->kron_tmp, y, op.B, (int)op.R, (int)op.n2, pl->c, stop, st);
-      if (rc) return rc;
-      rc = vec_add_diag(op.d, op.diag_mode, v, y, pl->c, op.B, op.N, pl->sp, stop, st);
-      if (rc) return rc;
+      if (kron_mfma_cols_ok((int)op.R, (int)op.n2, pl->c)) {  // (the diagonal rides on the way back of the columns)
+        rc = kron_matvec_mfma_cols(op.A0, op.A1, op.d, op.diag_mode, v, pl->kron_tmp,
+                                   pl->kron_tmp + (size_t)op.B * op.N * pl->c, y, op.B, (int)op.R, (int)op.n2, pl->c,
+                                   stop, st);
+        if (rc) return rc;
+      } else {
+        rc = kron_matvec(op.A0, op.A1, v, pl->kron_tmp, y, op.B, (int)op.R, (int)op.n2, pl->c, stop, st);
+        if (rc) return rc;
+        rc = vec_add_diag(op.d, op.diag_mode, v, y, pl->c, op.B, op.N, pl->sp, stop, st);
+        if (rc) return rc;
+      }
       if (dot_part) rc = vec_dot_part(v, y, pl->c, dot_part, op.B, op.N, pl->sp, stop, st);
       return rc;
     case LO_OP_CALLBACK:
