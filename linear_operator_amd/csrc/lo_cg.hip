@@ -698,7 +698,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     if (rc == LO_OK && ls_cols < c && !getenv("LO_OC_GEN2") && onchip5_eligible(pl.R4, N, c - ls_cols) &&
         (oc_nopre || (pre_root && pre->rf_ld == pl.R4))) {
       // root-form serial-column kernel (one all-reduce per iteration): columns [ls_cols, c)
-      a.GW = onchip4_group_size(N);
+      a.GW = getenv("LO_OC_GW8") ? onchip4_group_size(N) : onchip5_group_size(N);
       a.RW = (int)((N + a.GW - 1) / a.GW);
       a.col0 = ls_cols; a.ncols = c - ls_cols;
       a.xout = x;

@@ -320,6 +320,14 @@ bool onchip4_eligible(int RC, int RK, int64_t N, int64_t c) {
 }
 
 int onchip4_group_size(int64_t N) { return N <= 8 * (int64_t)R4_ROWS ? 8 : (N <= 16 * (int64_t)R4_ROWS ? 16 : 32); }
+// Root-form kernel: the smallest group that holds the member (1024 rows per workgroup).  Small members used to take 8
+// workgroups with mostly idle threads: N = 1024 .. 4096 ran at the N = 8192 time per solve; with 1 / 2 / 4 workgroups
+// 8 / 4 / 2 x more members are resident at a time (and a group of one needs no hand-off at all).
+int onchip5_group_size(int64_t N) {
+  for (int gw = 1; gw < 32; gw *= 2)
+    if (N <= (int64_t)gw * R4_ROWS) return gw;
+  return 32;
+}
 
 template <int RC, int RK, int GW, bool MC>
 static int onchip4_go(const OnchipArgs& a, int nwg, hipStream_t st) {
@@ -676,10 +684,22 @@ static int onchip5_go(const OnchipArgs& a, int nwg, hipStream_t st) {
 int onchip5_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st) {
   const bool mc = a.c > 1 || a.ab_rec != nullptr;
 #define LO_O5_G(C_, G_) (mc ? onchip5_go<C_, G_, true>(a, nwg, st) : onchip5_go<C_, G_, false>(a, nwg, st))
-#define LO_O5(C_) return a.GW == 8 ? LO_O5_G(C_, 8) : (a.GW == 16 ? LO_O5_G(C_, 16) : LO_O5_G(C_, 32))
-  if (RC == 32) LO_O5(32);
-  else if (RC == 16) LO_O5(16);
-  else if (RC == 8) LO_O5(8);
+#define LO_O5(C_)                                                                                    \
+  switch (a.GW) {                                                                                    \
+    case 1: return LO_O5_G(C_, 1);                                                                   \
+    case 2: return LO_O5_G(C_, 2);                                                                   \
+    case 4: return LO_O5_G(C_, 4);                                                                   \
+    case 8: return LO_O5_G(C_, 8);                                                                   \
+    case 16: return LO_O5_G(C_, 16);                                                                 \
+    default: return LO_O5_G(C_, 32);                                                                 \
+  }
+  if (RC == 32) {
+    LO_O5(32);
+  } else if (RC == 16) {
+    LO_O5(16);
+  } else if (RC == 8) {
+    LO_O5(8);
+  }
 #undef LO_O5
 #undef LO_O5_G
   return LO_ERR_UNSUPPORTED;

@@ -75,7 +75,9 @@ __device__ __forceinline__ void r4_group_sum(R4Shared& sh, int cnt, R4Group& g) 
     if (stamp) c2 = wall_clock64();
     float tot = 0.f;
     unsigned spin = 0;
-    if constexpr (GW <= 16) {
+    if constexpr (GW == 1) {
+      tot = s;  // a group of one: nothing to wait for
+    } else if constexpr (GW <= 16) {
       float vals[GW];
       for (;;) {
         bool ok = true;

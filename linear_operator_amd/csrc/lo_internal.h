@@ -205,6 +205,7 @@ bool onchip_eligible(int RC, int RK, int64_t N, int64_t c);
 int onchip_num_workgroups();
 bool onchip4_eligible(int RC, int RK, int64_t N, int64_t c);  // lo_cg_onchip4.hip
 int onchip4_group_size(int64_t N);
+int onchip5_group_size(int64_t N);
 // Kernels whose workgroups wait for each other need ALL of them resident: two such kernels on two streams of one
 // process would each take part of the CUs and spin until the hand-off timeout.  Construct a ResidentLaunch right before
 // such a launch (same scope): if the previous resident kernel of this process went to a DIFFERENT stream, the new stream
