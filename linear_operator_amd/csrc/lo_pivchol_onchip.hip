@@ -546,8 +546,18 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
       const int myj = (int)sh.gath[lane % GW][1];
       int jb = myj;
       float etot = __uint_as_float(sh.gath[lane % GW][3]);
-      etot = bfly_add<1>(etot); etot = bfly_add<2>(etot); etot = bfly_add<4>(etot);
-      po_amax_step<1>(vb, jb); po_amax_step<2>(vb, jb); po_amax_step<4>(vb, jb);
+      if constexpr (GW >= 2) {  // (lane l holds candidate l % GW: only the butterfly steps below GW combine distinct ones)
+        etot = bfly_add<1>(etot);
+        po_amax_step<1>(vb, jb);
+      }
+      if constexpr (GW >= 4) {
+        etot = bfly_add<2>(etot);
+        po_amax_step<2>(vb, jb);
+      }
+      if constexpr (GW >= 8) {
+        etot = bfly_add<4>(etot);
+        po_amax_step<4>(vb, jb);
+      }
       if constexpr (GW >= 16) {
         etot = bfly_add<8>(etot);
         po_amax_step<8>(vb, jb);
@@ -774,21 +784,30 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   }
   const int nwg = onchip_num_workgroups();
   // second generation (4 rows per thread, two workgroups per CU) when two workgroups fit on a CU
-  const int gw2 = op->N <= (int64_t)8 * P4_ROWS ? 8 : (op->N <= (int64_t)16 * P4_ROWS ? 16 : 32);
+  // (smallest group that holds the member: small members no longer occupy 8 mostly idle workgroups)
+  int gw2 = 32;
+  for (int gq = 1; gq < 32; gq *= 2)
+    if (op->N <= (int64_t)gq * P4_ROWS) {
+      gw2 = gq;
+      break;
+    }
+  if (getenv("LO_OC_GW8")) gw2 = std::max(gw2, 8);
   bool gen2 = !(getenv("LO_OC_GEN1") && op->N <= (int64_t)PO_GW * PO_TPB);
   if (gen2) {
     int per_cu = 0;
     hipError_t e = hipErrorUnknown;
 #define LO_OCC(R_, G_) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pc_onchip4<R_, G_>, P4_TPB, 0)
-    if (RP == 32 && gw2 == 8) LO_OCC(32, 8);
-    else if (RP == 32 && gw2 == 16) LO_OCC(32, 16);
-    else if (RP == 32) LO_OCC(32, 32);
-    else if (RP == 16 && gw2 == 8) LO_OCC(16, 8);
-    else if (RP == 16 && gw2 == 16) LO_OCC(16, 16);
-    else if (RP == 16) LO_OCC(16, 32);
-    else if (gw2 == 8) LO_OCC(8, 8);
-    else if (gw2 == 16) LO_OCC(8, 16);
-    else LO_OCC(8, 32);
+#define LO_OCC_R(R_)                       \
+  switch (gw2) {                           \
+    case 1: LO_OCC(R_, 1); break;          \
+    case 2: LO_OCC(R_, 2); break;          \
+    case 4: LO_OCC(R_, 4); break;          \
+    case 8: LO_OCC(R_, 8); break;          \
+    case 16: LO_OCC(R_, 16); break;        \
+    default: LO_OCC(R_, 32); break;        \
+  }
+    if (RP == 32) { LO_OCC_R(32) } else if (RP == 16) { LO_OCC_R(16) } else { LO_OCC_R(8) }
+#undef LO_OCC_R
 #undef LO_OCC
     gen2 = (e == hipSuccess) && per_cu >= 2;
   }
@@ -821,15 +840,17 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   if (gen2) {
     dim3 grid2(2 * nwg), block2(P4_TPB);
 #define LO_GO(R_, G_) hipLaunchKernelGGL((k_pc_onchip4<R_, G_>), grid2, block2, 0, st, a)
-    if (RP == 32 && gw == 8) LO_GO(32, 8);
-    else if (RP == 32 && gw == 16) LO_GO(32, 16);
-    else if (RP == 32) LO_GO(32, 32);
-    else if (RP == 16 && gw == 8) LO_GO(16, 8);
-    else if (RP == 16 && gw == 16) LO_GO(16, 16);
-    else if (RP == 16) LO_GO(16, 32);
-    else if (gw == 8) LO_GO(8, 8);
-    else if (gw == 16) LO_GO(8, 16);
-    else LO_GO(8, 32);
+#define LO_GO_R(R_)                      \
+  switch (gw) {                          \
+    case 1: LO_GO(R_, 1); break;         \
+    case 2: LO_GO(R_, 2); break;         \
+    case 4: LO_GO(R_, 4); break;         \
+    case 8: LO_GO(R_, 8); break;         \
+    case 16: LO_GO(R_, 16); break;       \
+    default: LO_GO(R_, 32); break;       \
+  }
+    if (RP == 32) { LO_GO_R(32) } else if (RP == 16) { LO_GO_R(16) } else { LO_GO_R(8) }
+#undef LO_GO_R
 #undef LO_GO
   } else if (RP == 32) hipLaunchKernelGGL((k_pc_onchip<32>), grid, block, 0, st, a);
   else if (RP == 16) hipLaunchKernelGGL((k_pc_onchip<16>), grid, block, 0, st, a);
