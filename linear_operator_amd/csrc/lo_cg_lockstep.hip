@@ -99,7 +99,8 @@ struct LsGroup {
 // part[0..NP)[0..cnt) hold the second-stage partials of this workgroup.  Entry e is summed (fixed order) and published
 // as a {tag, value} granule; the entries of all workgroups of the group are then summed in fixed order -> res[e],
 // bitwise identical in all workgroups.  Starts and ends with a barrier.
-//   GW <= 8 : every workgroup polls the entry of all GW workgroups itself (one hand-off);
+//   GW <= 8 : every workgroup polls the entry of all GW workgroups itself (one hand-off; GW = 1 / 2 / 4 for members of
+//             up to 1024 / 2048 / 4096 rows, so that small members do not occupy eight mostly idle workgroups);
 //   GW == 16: reduce-scatter + all-gather -- workgroup j sums the entries [j per, (j+1) per) of all 16 workgroups and
 //             publishes the totals, everybody then reads the totals (two hand-offs, 8 x fewer loads: the payload of a
 //             16-column iteration is 816 values).
@@ -115,13 +116,14 @@ __device__ __forceinline__ void ls_group_sum(float (*part)[LS_NVP], float* res, 
     else __hip_atomic_store(dst, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // sum over NW consecutive granules (stride LS_NVP) of entry e, waiting for their tags
+  constexpr int NG = GW < 8 ? GW : 8;  // granules of one entry gathered at a time
   auto gather8 = [&](const unsigned long long* src, int e) -> float {
-    float vals[8];
+    float vals[NG];
     unsigned spin = 0;
     for (;;) {
       bool ok = true;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) {
+      for (int w = 0; w < NG; ++w) {
         const unsigned long long x =
             __hip_atomic_load(src + (size_t)w * LS_NVP + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = ok && ((unsigned)(x >> 32) == tag);
@@ -137,7 +139,7 @@ __device__ __forceinline__ void ls_group_sum(float (*part)[LS_NVP], float* res, 
     }
     float tot = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) tot += vals[w];
+    for (int w = 0; w < NG; ++w) tot += vals[w];
     return tot;
   };
   for (int e = t; e < cnt; e += TPB) {
@@ -146,7 +148,7 @@ __device__ __forceinline__ void ls_group_sum(float (*part)[LS_NVP], float* res, 
     for (int q = 1; q < NP; ++q) sum += part[q][e];
     publish(slot + (size_t)g.wig * LS_NVP + e, sum);
   }
-  if constexpr (GW == 8) {
+  if constexpr (GW <= 8) {
     for (int e = t; e < cnt; e += TPB) res[e] = gather8(slot, e);
   } else {
     static_assert(GW == 16, "group size");
@@ -728,14 +730,22 @@ static int lockstep_go(const OnchipArgs& a, int ncu, hipStream_t st) {
 // different members.  Measured equal (3.78 vs 3.83 ms at cfg3): a wave's matrix-core stream is not software-pipelined
 // against its LDS operand reads, so one workgroup alone reaches ~55 % of the matrix rate and the second workgroup's
 // compute phase cannot fill the first one's hand-off wait any better than the second wave per SIMD already does.
-int lockstep_group_size(int64_t N) { return (N > 4096 && getenv("LO_LS_V2")) ? 16 : 8; }
+int lockstep_group_size(int64_t N) {
+  if (N > 4096 && getenv("LO_LS_V2")) return 16;
+  if (getenv("LO_OC_GW8")) return 8;
+  return N <= 1024 ? 1 : (N <= 2048 ? 2 : (N <= 4096 ? 4 : 8));
+}
 
 // ncu = number of CUs used (multiple of 64).  a.GW selects the variant (8: one 1024-row workgroup per CU; 16: two
 // 512-row workgroups per CU); a.RK = floats per row of Q (PRE) or 0.  LO_ERR_UNSUPPORTED when the workgroups do not
 // fit (the caller falls back to the other variant / the serial-column kernels).
 int lockstep_launch(int RC, bool pre, const OnchipArgs& a, int ncu, hipStream_t st) {
   const bool v2 = a.GW == 16;
-#define LO_LS(C_, P_) (v2 ? lockstep_go<C_, P_, 16, 4>(a, ncu, st) : lockstep_go<C_, P_, 8, 8>(a, ncu, st))
+#define LO_LS(C_, P_)                                                      \
+  (v2 ? lockstep_go<C_, P_, 16, 4>(a, ncu, st)                             \
+      : (a.GW == 8 ? lockstep_go<C_, P_, 8, 8>(a, ncu, st)                 \
+                   : (a.GW == 4 ? lockstep_go<C_, P_, 4, 8>(a, ncu, st)    \
+                                : (a.GW == 2 ? lockstep_go<C_, P_, 2, 8>(a, ncu, st) : lockstep_go<C_, P_, 1, 8>(a, ncu, st)))))
   if (RC == 32 && pre && a.dbg) return v2 ? lockstep_go<32, true, 16, 4, true>(a, ncu, st) : lockstep_go<32, true, 8, 8, true>(a, ncu, st);
   if (RC == 32) return pre ? LO_LS(32, true) : LO_LS(32, false);
   if (RC == 16 || RC == 8) return pre ? LO_LS(16, true) : LO_LS(16, false);

@@ -1,4 +1,5 @@
 #!/bin/bash
-python tools/mb_pc_sweep.py 2>&1 | grep "^R="
+for n in 1024 2048 4096 8192; do LS_N=$n python tools/mb_lockstep.py 2>&1 | grep -E "cg_solve"; done
+echo "== groups of 8 (old)"
+for n in 1024 2048 4096; do LO_OC_GW8=1 LS_N=$n python tools/mb_lockstep.py 2>&1 | grep -E "cg_solve"; done
 python -m pytest tests -q -x -m gpu > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -2; grep -E "^E " gpurun_out/pytest_gpu.log | head -5
-LO_OC_GW8=1 python tools/mb_pc_sweep.py 2>&1 | grep "^R=" | head -4
