@@ -159,3 +159,38 @@ def test_sweep_preconditioner_and_lanczos_against_oracle():
         qh = host(q).astype(np.float64)
         gram = np.swapaxes(qh, -1, -2) @ qh
         assert np.abs(gram - np.eye(gram.shape[-1])).max() < 1e-4, tag
+
+
+@pytest.mark.parametrize("N", [1024, 1100, 2048, 2049, 4096])
+def test_small_members_take_small_groups(N):
+    """Members of up to 1024 / 2048 / 4096 rows run the resident kernels in groups of 1 / 2 / 4 workgroups (a group of
+    one has no hand-off at all): pivoted Cholesky bit-identical to the oracle, serial-column and 16-column lockstep CG
+    with tridiagonals against the exact solution, and identical results with the groups of eight of `LO_OC_GW8`."""
+    import os
+
+    B, R = 37, 32
+    C, d, _ = cases.lowrank_diag(9500 + N, B, N, R, 1)
+    rhs = cases.randn(9600 + N, B, N, 17, dtype=np.float32)
+    L, piv = K.pivoted_cholesky(K.lowrank_diag_descriptor(dev(C), None), 15)
+    Lo, pivo = orc.pivoted_cholesky(orc.LowRankRowSource(C), 15)
+    assert np.array_equal(host(piv), pivo) and np.array_equal(host(L), Lo)
+    Lr, perm = K.pivoted_cholesky(K.lowrank_diag_descriptor(dev(C), None), 15, contiguous=False)
+    pre = K.precond_build(Lr, dev(d), False, root=dev(C), perm=perm)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    C64, d64, r64 = C.astype(np.float64), d.astype(np.float64), rhs.astype(np.float64)
+    Cd = C64 / d64[..., None]
+    cap = np.eye(R) + np.swapaxes(C64, -1, -2) @ Cd
+    exact = r64 / d64[..., None] - Cd @ np.linalg.solve(cap, np.swapaxes(Cd, -1, -2) @ r64)
+    res17 = K.cg_solve(desc, dev(rhs), precond=pre, n_tridiag=16, tolerance=1e-5)       # lockstep + serial column
+    res1 = K.cg_solve(desc, dev(rhs[..., :1].copy()), precond=pre, tolerance=1e-5)      # serial column alone
+    assert max_rel_err_cols(host(res17.x), exact) < 1e-4 and bool(torch.isfinite(res17.t_mat).all())
+    assert max_rel_err_cols(host(res1.x), exact[..., :1]) < 1e-4
+    os.environ["LO_OC_GW8"] = "1"
+    try:
+        ref17 = K.cg_solve(desc, dev(rhs), precond=pre, n_tridiag=16, tolerance=1e-5)
+        L8, piv8 = K.pivoted_cholesky(K.lowrank_diag_descriptor(dev(C), None), 15)
+    finally:
+        del os.environ["LO_OC_GW8"]
+    assert res17.iterations == ref17.iterations
+    assert max_rel_err_cols(host(res17.x), host(ref17.x).astype(np.float64)) < 1e-5
+    assert torch.equal(L8, L) and torch.equal(piv8, piv)
