@@ -448,7 +448,7 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   int oc_iters = std::min(10, fmi0 - 1);
   if (prm->n_tridiag) oc_iters = std::max(oc_iters, std::min(prm->max_tridiag_iter, fmi0 - 1));
   oc_iters = std::max(1, oc_iters + 1);
-  const bool oc_shape = op->kind == LO_OP_LOWRANK_DIAG && c <= 64 && N >= 1024 && N <= 32768;
+  const bool oc_shape = op->kind == LO_OP_LOWRANK_DIAG && c <= 64 && N >= 256 && N <= 32768;
   const size_t oc_n = oc_shape ? (size_t)B * c : 1;
   dd.oc_resid = ar.take<float>(oc_n * oc_iters);
   dd.oc_init_conv = ar.take<int>(oc_n);
@@ -634,7 +634,9 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     const int full = (c / 16) * 16, rem = c - full;
     ls_cols = full + (rem >= kLockstepMinCols ? rem : 0);
   }
-  const bool oc_ok = oc_base && (ls_cols == c || oc_gen1_ok || onchip4_eligible(pl.R4, ocR4, N, c - ls_cols));
+  const bool oc_root_ok = onchip5_eligible(pl.R4, N, c - ls_cols) && (oc_nopre || (pre_root && pre->rf_ld == pl.R4));
+  const bool oc_ok = oc_base && (ls_cols == c || oc_gen1_ok || oc_root_ok ||
+                                 onchip4_eligible(pl.R4, ocR4, N, c - ls_cols));
   // second generation (4 rows per thread, lo_cg_onchip4.hip) unless LO_OC_GEN1 asks for the first one
   // (the dynamic member hand-out passes indices through fp32 granules: exact below 2^24)
   const bool oc_gen2 = oc_ok && ls_cols < c && onchip4_eligible(pl.R4, ocR4, N, c - ls_cols) &&

@@ -706,7 +706,7 @@ size_t lockstep_gbuf_bytes(int ngroups, int GW) {  // granules + 4096 per-CU arr
 bool lockstep_eligible(int RC, int RK, bool pre, int64_t N, int64_t ncols) {
   const bool rc_ok = (RC == 8 || RC == 16 || RC == 32);
   const bool rk_ok = !pre || (RK == 4 || RK == 8 || RK == 16);
-  return rc_ok && rk_ok && ncols >= 1 && N >= 1024 && N <= 8 * (int64_t)8 * LS_WROWS;
+  return rc_ok && rk_ok && ncols >= 1 && N >= 256 && N <= 8 * (int64_t)8 * LS_WROWS;  // (N < 1024: a group of one)
 }
 
 template <int RC, bool PRE, int GW, int NW, bool DBG = false>

@@ -663,7 +663,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
 }
 
 bool onchip5_eligible(int RC, int64_t N, int64_t c) {
-  return (RC == 8 || RC == 16 || RC == 32) && c >= 1 && c <= 64 && N >= 1024 && N <= (int64_t)R4_MAXGW * R4_ROWS;
+  return (RC == 8 || RC == 16 || RC == 32) && c >= 1 && c <= 64 && N >= 256 && N <= (int64_t)R4_MAXGW * R4_ROWS;
 }
 
 template <int RC, int GW, bool MC>

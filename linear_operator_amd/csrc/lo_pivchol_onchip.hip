@@ -732,7 +732,7 @@ __global__ __launch_bounds__(kThreads) void k_po_perm(PoArgs a, float tol, int* 
 bool pc_onchip_eligible(const lo_op_desc* op, int max_rank) {
   if (g_onchip_disabled || op->kind != LO_OP_LOWRANK_DIAG) return false;
   const int64_t R = op->R;  // (any rank up to 32: zero-padded to 8 / 16 / 32 columns in the workspace)
-  return R >= 1 && R <= 32 && max_rank <= PO_MAXR && op->N >= 1024 &&
+  return R >= 1 && R <= 32 && max_rank <= PO_MAXR && op->N >= 256 &&
          op->N <= (int64_t)32 * P4_ROWS && onchip_num_workgroups() >= 64;
 }
 
