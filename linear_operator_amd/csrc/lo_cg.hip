@@ -413,7 +413,7 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   dd.B = B; dd.N = N; dd.c = (int)c; dd.S = sp.S;
   dd.ctrl = ar.take<CgCtrl>(1);
   // (granule buffer of the serial resident kernels right behind the control block: ONE memset clears both)
-  dd.oc_gbuf = ar.take<unsigned long long>(onchip_gbuf_bytes(64) / sizeof(unsigned long long));
+  dd.oc_gbuf = ar.take<unsigned long long>(onchip_gbuf_bytes(66) / sizeof(unsigned long long));
   dd.x = ar.take<float>(nv);
   dd.r = ar.take<float>(nv);
   dd.p = ar.take<float>(nv);
@@ -448,7 +448,7 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   int oc_iters = std::min(10, fmi0 - 1);
   if (prm->n_tridiag) oc_iters = std::max(oc_iters, std::min(prm->max_tridiag_iter, fmi0 - 1));
   oc_iters = std::max(1, oc_iters + 1);
-  const bool oc_shape = op->kind == LO_OP_LOWRANK_DIAG && c <= 64 && N >= 256 && N <= 32768;
+  const bool oc_shape = op->kind == LO_OP_LOWRANK_DIAG && c <= 64 && N >= 256 && N <= 65536;
   const size_t oc_n = oc_shape ? (size_t)B * c : 1;
   dd.oc_resid = ar.take<float>(oc_n * oc_iters);
   dd.oc_init_conv = ar.take<int>(oc_n);
@@ -569,7 +569,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   {  // control block (+ the granule buffer behind it when a resident kernel may run)
     const bool oc_possible = op->kind == LO_OP_LOWRANK_DIAG && !g_onchip_disabled;
     const size_t span = oc_possible ? (size_t)(reinterpret_cast<char*>(d.oc_gbuf) - reinterpret_cast<char*>(d.ctrl)) +
-                                          onchip_gbuf_bytes(64)
+                                          onchip_gbuf_bytes(66)
                                     : sizeof(CgCtrl);
     LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, span, st));
   }
@@ -700,7 +700,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     if (rc == LO_OK && ls_cols < c && !getenv("LO_OC_GEN2") && onchip5_eligible(pl.R4, N, c - ls_cols) &&
         (oc_nopre || (pre_root && pre->rf_ld == pl.R4))) {
       // root-form serial-column kernel (one all-reduce per iteration): columns [ls_cols, c)
-      a.GW = getenv("LO_OC_GW8") ? onchip4_group_size(N) : onchip5_group_size(N);
+      a.GW = (getenv("LO_OC_GW8") && N <= 32768) ? onchip4_group_size(N) : onchip5_group_size(N);
       a.RW = (int)((N + a.GW - 1) / a.GW);
       a.col0 = ls_cols; a.ncols = c - ls_cols;
       a.xout = x;
@@ -721,7 +721,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       a.xout = gen2 ? x : nullptr;
       a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
       a.dbg = oc_dbg ? d.oc_dbg : nullptr;
-      LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(64), st));  // whole allocation (either generation)
+      LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(66), st));  // whole allocation (either generation)
       rc = LO_ERR_UNSUPPORTED;
       if (gen2) rc = onchip4_launch(pl.R4, ocR4, a, oc_nwg, st);
       xout_ok = gen2 && rc == LO_OK;

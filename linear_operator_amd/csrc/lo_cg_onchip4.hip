@@ -324,9 +324,9 @@ int onchip4_group_size(int64_t N) { return N <= 8 * (int64_t)R4_ROWS ? 8 : (N <=
 // workgroups with mostly idle threads: N = 1024 .. 4096 ran at the N = 8192 time per solve; with 1 / 2 / 4 workgroups
 // 8 / 4 / 2 x more members are resident at a time (and a group of one needs no hand-off at all).
 int onchip5_group_size(int64_t N) {
-  for (int gw = 1; gw < 32; gw *= 2)
+  for (int gw = 1; gw < 64; gw *= 2)
     if (N <= (int64_t)gw * R4_ROWS) return gw;
-  return 32;
+  return 64;  // (up to 65536 rows: 8 members resident at a time, two-hop lane-parallel all-reduce)
 }
 
 template <int RC, int RK, int GW, bool MC>
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
   if (jx / GW >= groups_per_xcd) return;
   const int t = threadIdx.x, lane = t & 63;
   R4Group g;
-  g.gslot = a.gbuf + (size_t)grp * 2 * GW * R4_SLOT;
+  g.gslot = a.gbuf + (size_t)grp * 2 * (GW == 64 ? GW + 1 : GW) * R4_SLOT;
   g.wig = wig;
   g.dbg = nullptr;
   g.tag = 0;
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
 }
 
 bool onchip5_eligible(int RC, int64_t N, int64_t c) {
-  return (RC == 8 || RC == 16 || RC == 32) && c >= 1 && c <= 64 && N >= 256 && N <= (int64_t)R4_MAXGW * R4_ROWS;
+  return (RC == 8 || RC == 16 || RC == 32) && c >= 1 && c <= 64 && N >= 256 && N <= (int64_t)64 * R4_ROWS;
 }
 
 template <int RC, int GW, bool MC>
@@ -691,7 +691,8 @@ int onchip5_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st) {
     case 4: return LO_O5_G(C_, 4);                                                                   \
     case 8: return LO_O5_G(C_, 8);                                                                   \
     case 16: return LO_O5_G(C_, 16);                                                                 \
-    default: return LO_O5_G(C_, 32);                                                                 \
+    case 32: return LO_O5_G(C_, 32);                                                                 \
+    default: return LO_O5_G(C_, 64);                                                                 \
   }
   if (RC == 32) {
     LO_O5(32);

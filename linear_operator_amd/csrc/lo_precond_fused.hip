@@ -52,76 +52,7 @@ struct PfArgs {
   unsigned tag_base;  // tags of this launch start above it: the granules of earlier launches of the solve never match
 };
 
-// Group all-reduce for large groups (up to 64 workgroups) and a small payload: reduce-scatter + all-gather through tagged
-// granules, in two halves so that independent work can be placed between the publication and the wait.  Workgroup e owns
-// payload entry e: the 64 lanes of its first wave fetch that entry of all GW workgroups (one granule per lane -- the
-// fan-in costs lanes, not registers), sum them with the fixed-order wave butterfly and publish the total; everybody then
-// reads the cnt totals.  sh.red[w][0..cnt) hold the wave partials; result in sh.res[0..cnt).
-struct PfSlots {
-  unsigned long long* slot;
-  unsigned long long* tot;
-  unsigned tag;
-};
-
-__device__ __forceinline__ void pf_store(const R4Group& g, unsigned tag, unsigned long long* dst, float v) {
-  const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
-  if (g.same_xcd) __hip_atomic_store(dst, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  else __hip_atomic_store(dst, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// every lane of the wave takes part; lanes with active == false only vote
-__device__ __forceinline__ float pf_wait(const R4Group& g, unsigned tag, const unsigned long long* src, bool active) {
-  unsigned long long x = 0;
-  unsigned spin = 0;
-  for (;;) {
-    bool ok = true;
-    if (active) {
-      x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ok = (unsigned)(x >> 32) == tag;
-    }
-    if (__all(ok)) break;
-    if (++spin > R4_MAXSPIN ||
-        ((spin & 1023u) == 0 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-      atomicExch(g.err, 1);  // timed out, or another workgroup already did: give up at once
-      break;
-    }
-    __builtin_amdgcn_s_sleep(1);
-  }
-  return active ? __uint_as_float((unsigned)(x & 0xffffffffull)) : 0.f;
-}
-
-template <int GW>
-__device__ __forceinline__ PfSlots pf_publish(R4Shared& sh, int cnt, R4Group& g) {
-  const int t = threadIdx.x;
-  PfSlots ps;
-  ps.tag = ++g.tag;
-  __syncthreads();
-  ps.slot = g.gslot + (size_t)(ps.tag & 1u) * (GW + 1) * R4_SLOT;  // GW partial arrays | totals
-  ps.tot = ps.slot + (size_t)GW * R4_SLOT;
-  if (t < cnt) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < R4_WAVES; ++w) s += sh.red[w][t];
-    pf_store(g, ps.tag, ps.slot + (size_t)g.wig * R4_SLOT + t, s);
-  }
-  return ps;
-}
-
-template <int GW>
-__device__ __forceinline__ void pf_collect(R4Shared& sh, int cnt, R4Group& g, const PfSlots& ps) {
-  const int t = threadIdx.x;
-  if (t < 64) {
-    for (int e = g.wig; e < cnt; e += GW) {  // entries this workgroup owns
-      const float v = pf_wait(g, ps.tag, ps.slot + (size_t)t * R4_SLOT + e, t < GW);
-      const float total = wave_sum_fast(v);
-      if (t == 0) pf_store(g, ps.tag, ps.tot + e, total);
-    }
-    const float r = pf_wait(g, ps.tag, ps.tot + t, t < cnt);
-    if (t < cnt) sh.res[t] = r;
-  }
-  __syncthreads();
-}
-
+// (pf_publish / pf_collect: the lane-parallel reduce-scatter all-reduce for groups of up to 64 workgroups, lo_group_reduce.h)
 // value of quad lane K in all four lanes of the quad (DPP quad_perm)
 template <int K>
 __device__ __forceinline__ float quad_bcast(float v) {

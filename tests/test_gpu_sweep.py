@@ -194,3 +194,32 @@ def test_small_members_take_small_groups(N):
     assert res17.iterations == ref17.iterations
     assert max_rel_err_cols(host(res17.x), host(ref17.x).astype(np.float64)) < 1e-5
     assert torch.equal(L8, L) and torch.equal(piv8, piv)
+
+
+@pytest.mark.parametrize("N,c", [(40000, 1), (65536, 1), (50000, 3)])
+def test_large_members_take_groups_of_64(N, c):
+    """32768 < N <= 65536: the root-form resident CG runs a member on 64 workgroups (lane-parallel two-hop all-reduce)
+    instead of falling to the streaming engine; against the exact fp64 Woodbury solution."""
+    from linear_operator_amd import _hip
+
+    B, R = 20, 32
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9700 + N)
+    Cm = torch.randn(B, N, R, generator=g, device="cuda") / R ** 0.5
+    d = torch.rand(B, N, generator=g, device="cuda") + 0.5
+    rhs = torch.randn(B, N, c, generator=g, device="cuda")
+    L, perm = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cm, None), 15, contiguous=False)
+    pre = K.precond_build(L, d, False, root=Cm, perm=perm)
+    desc = K.lowrank_diag_descriptor(Cm, d)
+    _hip.prof_enable(True)
+    res = K.cg_solve(desc, rhs, precond=pre, tolerance=1e-5)
+    torch.cuda.synchronize()
+    prof = _hip.prof_report()
+    _hip.prof_enable(False)
+    assert "cg_onchip" in prof, sorted(prof)
+    C64, d64, r64 = Cm.double(), d.double(), rhs.double()
+    Cd = C64 / d64.unsqueeze(-1)
+    cap = torch.eye(R, device="cuda", dtype=torch.float64) + C64.mT @ Cd
+    exact = r64 / d64.unsqueeze(-1) - Cd @ torch.linalg.solve(cap, Cd.mT @ r64)
+    err = ((res.x.double() - exact).norm(dim=-2) / exact.norm(dim=-2)).max().item()
+    assert err < 1e-4, (N, c, res.iterations, err)
