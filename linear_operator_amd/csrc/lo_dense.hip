@@ -126,9 +126,9 @@ int dense_S_dot(int64_t B, int64_t N, int64_t c) {
 }
 
 int dense_matvec(const float* K, const float* d, int dd_mode, const float* v, float* y, float* dot_part, int64_t B,
-                 int64_t N, int64_t c, int rows_per_wg, const int* stop, hipStream_t st) {
+                 int64_t N, int64_t c, int rows_per_wg, float* ypart, const int* stop, hipStream_t st) {
   if (c < 1) return LO_ERR_BADARG;
-  if (dense_mfma_ok(N, c)) return dense_matvec_mfma(K, d, dd_mode, v, y, dot_part, B, N, c, stop, st);
+  if (dense_mfma_ok(N, c)) return dense_matvec_mfma(K, d, dd_mode, v, y, dot_part, B, N, c, ypart, stop, st);
   const int S = (int)((N + rows_per_wg - 1) / rows_per_wg);
   dim3 grid(S, (unsigned)B), block(kThreads);
   for (int64_t c0 = 0; c0 < c; c0 += 4) {

@@ -159,11 +159,15 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma(const float* __restr
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int DM_VLD = 20;  // row stride of the v slab [128 k][16 cols]: the four kk groups of a B read hit 2 x 16 banks
 
+// Split-K (kchunk < N, gridDim.z slices): a single operator of N = 4000 has 63 row tiles for 256 CUs -- each slice takes a
+// range of K's columns and leaves its raw partial product in ypart [slice][B][N][c]; k_dense_mv_finish adds the slices in
+// fixed order, the diagonal term and the dot partials.
 template <bool DOT, int NV>
 __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma16(const float* __restrict__ K, const float* __restrict__ dd,
                                                                int dd_mode, const float* __restrict__ v, int ldv, int c,
                                                                float* __restrict__ y, float* __restrict__ dot_part,
-                                                               int ldd, int N, const int* __restrict__ stop) {
+                                                               int ldd, int N, int kchunk, float* __restrict__ ypart,
+                                                               const int* __restrict__ stop) {
   if (stop && *stop) return;
   __shared__ __attribute__((aligned(16))) float k_s[DM_ROWS * DM_LD];
   __shared__ float v_s[DM_KB * DM_VLD];
@@ -247,12 +251,14 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma16(const float* __res
     for (int x = 0; x < (NV > 0 ? NV : 1); ++x) yx[rb][x] = 0.f;
   }
 
-  load_slab(0);
-  for (int kb = 0; kb < N; kb += DM_KB) {
+  const int kbeg = blockIdx.z * kchunk, kend = min(N, kbeg + kchunk);  // (kchunk: a multiple of the slab width)
+  const bool split = kchunk < N;
+  load_slab(kbeg);
+  for (int kb = kbeg; kb < kend; kb += DM_KB) {
     __syncthreads();
     store_slab();
     __syncthreads();
-    if (kb + DM_KB < N) load_slab(kb + DM_KB);
+    if (kb + DM_KB < kend) load_slab(kb + DM_KB);
     const float* arow = &k_s[(32 * wr + m) * DM_LD + 64 * wk + 4 * kk];
     const float* bcol = &v_s[(64 * wk + 4 * kk) * DM_VLD + m];
 #pragma unroll
@@ -310,6 +316,33 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma16(const float* __res
         for (int x = 0; x < NV; ++x) yx[rb][x] += red[(wr * NRED + 8 + NV * rb + x) * 64 + lane];
       }
     }
+  }
+  if (split) {  // raw partial of this slice (the epilogue runs in k_dense_mv_finish)
+    if (wk == 0) {
+      float* yp = ypart + ((size_t)blockIdx.z * gridDim.y + b) * (size_t)N * c;
+      if (m < cm) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 32 * wr + 16 * rb + 4 * kk + i;
+            if (row < N) yp[(size_t)row * c + m] = acc[rb][i];
+          }
+      }
+      if constexpr (NV > 0) {
+        if (kk == 0) {
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) {
+            const int row = row0 + 32 * wr + 16 * rb + m;
+            if (row < N) {
+#pragma unroll
+              for (int x = 0; x < NV; ++x) yp[(size_t)row * c + 16 + x] = yx[rb][x];
+            }
+          }
+        }
+      }
+    }
+    return;
   }
   const float ddc = (dd_mode == LO_DIAG_CONST) ? dd[b] : 0.f;
   float dacc = 0.f;
@@ -370,12 +403,63 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma16(const float* __res
   }
 }
 
+// y = sum_slices ypart + dd o v; dot partial per 64-row tile and column (the layout of the fused epilogue).
+// grid (tiles, B); thread = (row r = t / 4 of the tile, column phase t % 4).
+__global__ __launch_bounds__(kThreads) void k_dense_mv_finish(const float* __restrict__ ypart, int nslice,
+                                                               const float* __restrict__ dd, int dd_mode,
+                                                               const float* __restrict__ v, int c,
+                                                               float* __restrict__ y, float* __restrict__ dot_part,
+                                                               int N, const int* __restrict__ stop) {
+  if (stop && *stop) return;
+  __shared__ float red[kThreads / 64][32];
+  const int tile = blockIdx.x, b = blockIdx.y, S = gridDim.x, B = gridDim.y;
+  const int r = threadIdx.x >> 2, ph = threadIdx.x & 3;
+  const int row = tile * DM_ROWS + r;
+  const float dv = (row < N) ? ((dd_mode == LO_DIAG_FULL) ? dd[(size_t)b * N + row]
+                                                          : (dd_mode == LO_DIAG_CONST ? dd[b] : 0.f))
+                             : 0.f;
+  for (int c0 = 0; c0 < c; c0 += 4) {  // columns ph, ph + 4, ...: one per thread and pass
+    const int col = c0 + ph;
+    float dot = 0.f;
+    if (row < N && col < c) {
+      const size_t o = ((size_t)b * N + row) * c + col;
+      float acc = 0.f;
+      for (int s = 0; s < nslice; ++s) acc += ypart[((size_t)s * B + b) * (size_t)N * c + (size_t)row * c + col];
+      const float vin = v[o];
+      const float yv = fmaf(dv, vin, acc);
+      y[o] = yv;
+      dot = vin * yv;
+    }
+    if (dot_part) {  // sum over the 64 rows of the tile: lanes of equal phase (bits 2..5 of the lane), then the 4 waves
+      float t = dot;
+      t = bfly_add<4>(t); t = bfly_add<8>(t); t = bfly_add<16>(t); t = bfly_add<32>(t);
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      __syncthreads();
+      if (lane < 4) red[wave][lane] = t;
+      __syncthreads();
+      if (threadIdx.x < 4 && c0 + threadIdx.x < c)
+        dot_part[((size_t)b * S + tile) * c + c0 + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    }
+  }
+}
+
+// number of K slices: enough workgroups for the chip (3 per CU) when tiles x B alone are too few
+int dense_mfma_slices(int64_t B, int64_t N, int64_t c) {
+  if (!dense_mfma_ok(N, c) || c > 20) return 1;
+  const int64_t wgs = B * dense_mfma_tiles(N);
+  int ks = (int)std::min<int64_t>(16, (768 + wgs - 1) / wgs);
+  ks = (int)std::min<int64_t>(ks, std::max<int64_t>(1, N / (4 * DM_KB)));  // at least four slabs per slice
+  return std::max(1, ks);
+}
+
 template <bool DOT>
 static void launch_mv16(int nv, dim3 grid, hipStream_t st, const float* K, const float* d, int dd_mode, const float* v,
-                        int ldv, int c, float* y, float* dot_part, int N, const int* stop) {
+                        int ldv, int c, float* y, float* dot_part, int N, int kchunk, float* ypart, const int* stop) {
   dim3 block(kThreads);
-#define LO_MV16(NV_) \
-  hipLaunchKernelGGL((k_dense_mv_mfma16<DOT, NV_>), grid, block, 0, st, K, d, dd_mode, v, ldv, c, y, dot_part, ldv, N, stop)
+#define LO_MV16(NV_)                                                                                                   \
+  hipLaunchKernelGGL((k_dense_mv_mfma16<DOT, NV_>), grid, block, 0, st, K, d, dd_mode, v, ldv, c, y, dot_part, ldv, N, \
+                     kchunk, ypart, stop)
   switch (nv) {
     case 0: LO_MV16(0); break;
     case 1: LO_MV16(1); break;
@@ -392,14 +476,26 @@ bool dense_mfma_ok(int64_t N, int64_t c) { return c >= 2 && N >= 256; }
 int dense_mfma_tiles(int64_t N) { return (int)((N + DM_ROWS - 1) / DM_ROWS); }
 
 int dense_matvec_mfma(const float* K, const float* d, int dd_mode, const float* v, float* y, float* dot_part, int64_t B,
-                      int64_t N, int64_t c, const int* stop, hipStream_t st) {
+                      int64_t N, int64_t c, float* ypart, const int* stop, hipStream_t st) {
   dim3 grid(dense_mfma_tiles(N), (unsigned)B), block(kThreads);
   if (c <= 20 && !getenv("LO_DENSE_MFMA32")) {  // 16 columns on the 16-wide instruction + up to 4 on the vector ALU
     const int nv = (int)std::max<int64_t>(0, c - 16);
+    const int ks = ypart ? dense_mfma_slices(B, N, c) : 1;
+    int kchunk = (int)N;
+    if (ks > 1) {
+      kchunk = (int)(((N + ks - 1) / ks + DM_KB - 1) / DM_KB * DM_KB);
+      grid.z = (unsigned)((N + kchunk - 1) / kchunk);
+    }
     LO_PROF_BEGIN("dense_mv_mfma", st);
-    if (dot_part) launch_mv16<true>(nv, grid, st, K, d, dd_mode, v, (int)c, (int)c, y, dot_part, (int)N, stop);
-    else launch_mv16<false>(nv, grid, st, K, d, dd_mode, v, (int)c, (int)c, y, dot_part, (int)N, stop);
+    if (dot_part) launch_mv16<true>(nv, grid, st, K, d, dd_mode, v, (int)c, (int)c, y, dot_part, (int)N, kchunk, ypart, stop);
+    else launch_mv16<false>(nv, grid, st, K, d, dd_mode, v, (int)c, (int)c, y, dot_part, (int)N, kchunk, ypart, stop);
     LO_PROF_END(st);
+    if (grid.z > 1) {
+      LO_PROF_BEGIN("dense_mv_finish", st);
+      hipLaunchKernelGGL(k_dense_mv_finish, dim3(grid.x, (unsigned)B), block, 0, st, ypart, (int)grid.z, d,
+                         d ? dd_mode : LO_DIAG_NONE, v, (int)c, y, dot_part, (int)N, stop);
+      LO_PROF_END(st);
+    }
     LO_LAUNCH_CHECK();
     return LO_OK;
   }

@@ -143,6 +143,7 @@ struct MatvecPlan {
   int lda, R4;
   float* tpart;       // [B,S,R4,c]
   float* kron_tmp;    // [B,N,c]
+  float* dense_part;  // split-K partials of the dense matvec (small batches) or nullptr
   lo_matvec_cb cb;
   void* cb_user;
   // LO_OP_SUM: one sub-plan per term (host heap, released by matvec_plan_free) and the buffer a term beyond the
@@ -176,14 +177,16 @@ int matvec_run_pupdate(const MatvecPlan* pl, float* p, const float* z, const flo
 
 // dense / kron kernels
 int dense_matvec(const float* K, const float* d, int dd_mode, const float* v, float* y, float* dot_part, int64_t B,
-                 int64_t N, int64_t c, int rows_per_wg, const int* stop, hipStream_t st);
+                 int64_t N, int64_t c, int rows_per_wg, float* ypart, const int* stop, hipStream_t st);
 int dense_rows_per_wg(int64_t B, int64_t N);
 // number of dot partials per (member, column) the dense matvec writes for this shape (VALU vs MFMA tiling)
 int dense_S_dot(int64_t B, int64_t N, int64_t c);
 bool dense_mfma_ok(int64_t N, int64_t c);
 int dense_mfma_tiles(int64_t N);
+// ypart: dense_mfma_slices(B, N, c) * B * N * c floats for the split-K partials of small batches, or nullptr (no split)
+int dense_mfma_slices(int64_t B, int64_t N, int64_t c);
 int dense_matvec_mfma(const float* K, const float* d, int dd_mode, const float* v, float* y, float* dot_part, int64_t B,
-                      int64_t N, int64_t c, const int* stop, hipStream_t st);
+                      int64_t N, int64_t c, float* ypart, const int* stop, hipStream_t st);
 int kron_matvec(const float* K1, const float* K2, const float* v, float* tmp, float* y, int64_t B, int n1, int n2,
                 int64_t c, const int* stop, hipStream_t st);
 // matrix-core engine (c == 1, factors multiples of 128): diagonal term and CG dot partials fused in the epilogue

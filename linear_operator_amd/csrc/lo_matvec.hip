@@ -37,6 +37,9 @@ size_t matvec_plan_bytes(const lo_op_desc* op, int64_t c, Split sp) {
     ar.take<float>((size_t)op->B * sp.S * R4 * c);
   } else if (op->kind == LO_OP_KRON_DIAG) {
     ar.take<float>((size_t)op->B * op->N * c * (kron_mfma_cols_ok((int)op->R, (int)op->n2, c) ? 2 : 1));
+  } else if (op->kind == LO_OP_DENSE_DIAG) {
+    const int ks = dense_mfma_slices(op->B, op->N, c);
+    if (ks > 1) ar.take<float>((size_t)ks * op->B * op->N * c);
   }
   return ar.off + 256;
 }
@@ -51,6 +54,7 @@ int matvec_plan_init(MatvecPlan* pl, const lo_op_desc* op, lo_matvec_cb cb, void
   pl->Apad = nullptr;
   pl->tpart = nullptr;
   pl->kron_tmp = nullptr;
+  pl->dense_part = nullptr;
   pl->lda = pl->R4 = 0;
   pl->S_dot = sp.S;
   pl->nterms = 0;
@@ -80,6 +84,10 @@ int matvec_plan_init(MatvecPlan* pl, const lo_op_desc* op, lo_matvec_cb cb, void
     case LO_OP_DENSE_DIAG: {
       if (!op->A0) return LO_ERR_BADARG;
       pl->S_dot = dense_S_dot(op->B, op->N, c);
+      {
+        const int ks = dense_mfma_slices(op->B, op->N, c);
+        if (ks > 1) pl->dense_part = ar->take<float>((size_t)ks * op->B * op->N * c);
+      }
       break;
     }
     case LO_OP_KRON_DIAG: {
@@ -135,7 +143,7 @@ int matvec_run(const MatvecPlan* pl, const float* v, float* y, float* dot_part, 
                        op.N, pl->sp, stop, st);
     case LO_OP_DENSE_DIAG:
       return dense_matvec(op.A0, op.d, op.diag_mode, v, y, dot_part, op.B, op.N, pl->c,
-                          dense_rows_per_wg(op.B, op.N), stop, st);
+                          dense_rows_per_wg(op.B, op.N), pl->dense_part, stop, st);
     case LO_OP_KRON_DIAG:
       if (kron_mfma_ok((int)op.R, (int)op.n2, pl->c))
         return kron_matvec_mfma(op.A0, op.A1, op.d, op.diag_mode, v, pl->kron_tmp, y, dot_part, op.B, (int)op.R,
