@@ -198,9 +198,7 @@ __global__ __launch_bounds__(kThreads) void k_cg_update_xr(CgDev d, int rows_per
 // entry inside the returned [: last_tridiag_iter + 1]^2 block is touched.
 constexpr int kCtrlMaxG = 256;
 
-__global__ __launch_bounds__(kThreads) void k_cg_scal(CgDev d, int k) {
-  if (d.ctrl->stop) return;
-  __shared__ float red[kThreads];
+__device__ __forceinline__ void cg_scal_body(const CgDev& d, int k, float* red) {
   const int64_t n = d.B * d.c;
   const bool tri = d.n_tridiag && k < d.n_tridiag_iter && !d.ctrl->tri_disabled;
   const int T = d.T;
@@ -250,9 +248,13 @@ __global__ __launch_bounds__(kThreads) void k_cg_scal(CgDev d, int k) {
   }
 }
 
-__global__ __launch_bounds__(kThreads) void k_cg_ctrl(CgDev d, int k, int G) {
+__global__ __launch_bounds__(kThreads) void k_cg_scal(CgDev d, int k) {
   if (d.ctrl->stop) return;
   __shared__ float red[kThreads];
+  cg_scal_body(d, k, red);
+}
+
+__device__ __forceinline__ void cg_ctrl_body(const CgDev& d, int k, int G, float* red) {
   const int t = threadIdx.x;
   const float ls = (t < G) ? d.ctrl_part[t] : 0.f;
   const float ln = (t < G) ? d.ctrl_part[kCtrlMaxG + t] : 0.f;
@@ -279,6 +281,22 @@ __global__ __launch_bounds__(kThreads) void k_cg_ctrl(CgDev d, int k, int G) {
       d.ctrl->last_tridiag_iter = k;                       // :329
     }
   }
+}
+
+__global__ __launch_bounds__(kThreads) void k_cg_ctrl(CgDev d, int k, int G) {
+  if (d.ctrl->stop) return;
+  __shared__ float red[kThreads];
+  cg_ctrl_body(d, k, G, red);
+}
+
+// B c <= 256 (one workgroup of partials): both halves of the control step in ONE launch
+__global__ __launch_bounds__(kThreads) void k_cg_scal_ctrl(CgDev d, int k) {
+  if (d.ctrl->stop) return;
+  __shared__ float red[kThreads];
+  cg_scal_body(d, k, red);
+  __threadfence_block();
+  __syncthreads();
+  cg_ctrl_body(d, k, 1, red);
 }
 
 // ---- after the operator-resident kernel ran iterations 0 .. iters-1 for every column ----
@@ -880,8 +898,12 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       }
     }
     LO_PROF_BEGIN("cg_ctrl", st);
-    hipLaunchKernelGGL(k_cg_scal, dim3(ctrl_G), block, 0, st, d, k);
-    hipLaunchKernelGGL(k_cg_ctrl, dim3(1), block, 0, st, d, k, ctrl_G);
+    if (ctrl_G == 1) {
+      hipLaunchKernelGGL(k_cg_scal_ctrl, dim3(1), block, 0, st, d, k);
+    } else {
+      hipLaunchKernelGGL(k_cg_scal, dim3(ctrl_G), block, 0, st, d, k);
+      hipLaunchKernelGGL(k_cg_ctrl, dim3(1), block, 0, st, d, k, ctrl_G);
+    }
     LO_PROF_END(st);
     LO_LAUNCH_CHECK();
     ++launched;
