@@ -27,6 +27,57 @@ namespace lo {
 
 bool g_onchip_disabled = false;
 static thread_local bool tls_no_fused_precond = false;  // set while a solve is redone after a timed-out hand-off
+
+// hipGraph of one CG iteration: captured on a private side stream, replayed on the caller's stream.
+struct GraphReplay {
+  hipStream_t side = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  bool capturing = false;
+  bool begin() {
+    if (!side && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) {
+      side = nullptr;
+      (void)hipGetLastError();
+      return false;
+    }
+    if (hipStreamBeginCapture(side, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    capturing = true;
+    return true;
+  }
+  bool end() {
+    capturing = false;
+    if (hipStreamEndCapture(side, &graph) != hipSuccess || !graph) {
+      (void)hipGetLastError();
+      graph = nullptr;
+      return false;
+    }
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      exec = nullptr;
+      return false;
+    }
+    return true;
+  }
+  void reset() {
+    if (capturing) {
+      hipGraph_t g2 = nullptr;
+      (void)hipStreamEndCapture(side, &g2);
+      if (g2) (void)hipGraphDestroy(g2);
+      capturing = false;
+    }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    exec = nullptr;
+    graph = nullptr;
+  }
+  ~GraphReplay() {
+    reset();
+    if (side) (void)hipStreamDestroy(side);
+  }
+};
 // A chunk of columns goes to the column-lockstep kernel (16 at a time on the matrix cores) when it has at least this
 // many live columns; fewer are cheaper one after the other on the second-generation kernel.
 constexpr int kLockstepMinCols = 4;
@@ -248,9 +299,11 @@ __device__ __forceinline__ void cg_scal_body(const CgDev& d, int k, float* red) 
   }
 }
 
+// k < 0: the iteration index is read from the control block (graph replay: the previous control step left it there)
 __global__ __launch_bounds__(kThreads) void k_cg_scal(CgDev d, int k) {
   if (d.ctrl->stop) return;
   __shared__ float red[kThreads];
+  if (k < 0) k = d.ctrl->iterations;
   cg_scal_body(d, k, red);
 }
 
@@ -286,6 +339,7 @@ __device__ __forceinline__ void cg_ctrl_body(const CgDev& d, int k, int G, float
 __global__ __launch_bounds__(kThreads) void k_cg_ctrl(CgDev d, int k, int G) {
   if (d.ctrl->stop) return;
   __shared__ float red[kThreads];
+  if (k < 0) k = d.ctrl->iterations;
   cg_ctrl_body(d, k, G, red);
 }
 
@@ -293,6 +347,7 @@ __global__ __launch_bounds__(kThreads) void k_cg_ctrl(CgDev d, int k, int G) {
 __global__ __launch_bounds__(kThreads) void k_cg_scal_ctrl(CgDev d, int k) {
   if (d.ctrl->stop) return;
   __shared__ float red[kThreads];
+  if (k < 0) k = d.ctrl->iterations;
   cg_scal_body(d, k, red);
   __threadfence_block();
   __syncthreads();
@@ -846,66 +901,113 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   bool pf_on = pre && pre->Q && d.pf_gbuf && !tls_no_fused_precond && oc_nwg >= 64 &&
                precond_fused_eligible(B, N, c, preR4, sp.S);
   bool p_done = false;  // the fused apply of the previous iteration already wrote this iteration's p
-  int pf_launch = 0;
   if (pf_on) {  // granules and hand-out counters of the fused apply: cleared once per solve (tags are unique per launch)
     LO_HIP_CHECK(hipMemsetAsync(d.pf_gbuf, 0, precond_fused_gbuf_bytes(), st));
     LO_HIP_CHECK(hipMemsetAsync(d.pf_ctr, 0, sizeof(int) * ((size_t)std::max(1, (int)prm->max_iter) + 1), st));
   }
-  while (k < prm->max_iter && !h.stop) {
+  // One iteration's launches on stream `ls`.  dyn: the kernels that need the iteration index read it from the control
+  // block (the same launch sequence is then valid for every later iteration: it is captured once and replayed as a
+  // hipGraph -- the iterations of small / single operators are launch-bound: ~100 us of kernels, ~50 us of gaps).
+  auto issue = [&](int kk, bool dyn, hipStream_t ls) -> int {
+    int rcb;
     if (p_done) {
-      rc = matvec_run(&pl, d.p, d.Ap, d.pAp_part, stop, st);
-      if (rc) return rc;
+      rcb = matvec_run(&pl, d.p, d.Ap, d.pAp_part, stop, ls);
+      if (rcb) return rcb;
     } else if (matvec_can_fuse_pupdate(&pl)) {
-      rc = matvec_run_pupdate(&pl, d.p, zsrc, d.beta, k == 0 ? 1 : 0, d.Ap, d.pAp_part, stop, st);
-      if (rc) return rc;
+      rcb = matvec_run_pupdate(&pl, d.p, zsrc, d.beta, kk == 0 ? 1 : 0, d.Ap, d.pAp_part, stop, ls);
+      if (rcb) return rcb;
     } else {
-      LO_PROF_BEGIN("cg_update_p", st);
-      hipLaunchKernelGGL(k_cg_update_p, gridv, block, 0, st, d, zsrc, k == 0 ? 1 : 0, sp.rows);
-      LO_PROF_END(st);
+      LO_PROF_BEGIN("cg_update_p", ls);
+      hipLaunchKernelGGL(k_cg_update_p, gridv, block, 0, ls, d, zsrc, kk == 0 ? 1 : 0, sp.rows);
+      LO_PROF_END(ls);
       LO_LAUNCH_CHECK();
-      rc = matvec_run(&pl, d.p, d.Ap, d.pAp_part, stop, st);
-      if (rc) return rc;
+      rcb = matvec_run(&pl, d.p, d.Ap, d.pAp_part, stop, ls);
+      if (rcb) return rcb;
     }
     bool pre_done = false;
     if (pre && pf_on) {
       // single pass over Q: r / x update, Q^T r, group all-reduce, z = r/d - Q u, p = z + beta p (lo_precond_fused.hip)
-      rc = precond_fused_rupdate(Qp, pre->dinv, pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL, d.r, d.Ap, d.p, d.x,
-                                 d.z, d.pAp_part, d.S_dot, d.rz, d.has_conv, d.eps, d.alpha, d.rr_part, d.rz_part, sp.S,
-                                 B, N, d.pf_gbuf, d.oc_err, d.pf_ctr + pf_launch, pf_launch, stop, oc_nwg, st);
-      ++pf_launch;
-      if (rc == LO_ERR_UNSUPPORTED) pf_on = false;  // (does not fit this device: the two-launch path from now on)
-      else if (rc) return rc;
+      rcb = precond_fused_rupdate(Qp, pre->dinv, pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL, d.r, d.Ap, d.p, d.x,
+                                  d.z, d.pAp_part, d.S_dot, d.rz, d.has_conv, d.eps, d.alpha, d.rr_part, d.rz_part, sp.S,
+                                  B, N, d.pf_gbuf, d.oc_err, d.pf_ctr, kk, dyn ? &d.ctrl->iterations : nullptr,
+                                  (int)prm->max_iter, stop, oc_nwg, ls);
+      if (rcb == LO_ERR_UNSUPPORTED) pf_on = false;  // (does not fit this device: the two-launch path from now on)
+      else if (rcb) return rcb;
       else pre_done = p_done = true;
     }
     if (!pre_done) p_done = false;  // (the two-launch path below leaves the p update to the next iteration's first step)
     if (pre_done) {
     } else if (pre) {
       // r-update, x-update and the residual norm ride on the first pass over Q
-      rc = skinny_tn_rupdate(Qp, preR4, preR4, d.r, d.Ap, d.p, d.x, d.pAp_part, d.S_dot, d.rz, d.has_conv, d.eps,
-                             d.alpha, d.rr_part, c, upart, B, N, sp, stop, st);
-      if (rc) return rc;
-      rc = skinny_nn(Qp, preR4, preR4, upart, pre->dinv, pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL, -1.0f, d.r,
-                     c, d.z, d.rz_part, B, N, sp, stop, st);
-      if (rc) return rc;
+      rcb = skinny_tn_rupdate(Qp, preR4, preR4, d.r, d.Ap, d.p, d.x, d.pAp_part, d.S_dot, d.rz, d.has_conv, d.eps,
+                              d.alpha, d.rr_part, c, upart, B, N, sp, stop, ls);
+      if (rcb) return rcb;
+      rcb = skinny_nn(Qp, preR4, preR4, upart, pre->dinv, pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL, -1.0f, d.r,
+                      c, d.z, d.rz_part, B, N, sp, stop, ls);
+      if (rcb) return rcb;
     } else {
-      LO_PROF_BEGIN("cg_update_xr", st);
-      hipLaunchKernelGGL(k_cg_update_xr, gridv, block, 0, st, d, sp.rows);
-      LO_PROF_END(st);
+      LO_PROF_BEGIN("cg_update_xr", ls);
+      hipLaunchKernelGGL(k_cg_update_xr, gridv, block, 0, ls, d, sp.rows);
+      LO_PROF_END(ls);
       LO_LAUNCH_CHECK();
       if (precond) {
-        rc = apply_precond(d.r, d.z, d.rz_part);
-        if (rc) return rc;
+        if (dyn) return LO_ERR_UNSUPPORTED;  // (closure preconditioners are not replayed)
+        rcb = apply_precond(d.r, d.z, d.rz_part);
+        if (rcb) return rcb;
       }
     }
-    LO_PROF_BEGIN("cg_ctrl", st);
+    const int karg = dyn ? -1 : kk;
+    LO_PROF_BEGIN("cg_ctrl", ls);
     if (ctrl_G == 1) {
-      hipLaunchKernelGGL(k_cg_scal_ctrl, dim3(1), block, 0, st, d, k);
+      hipLaunchKernelGGL(k_cg_scal_ctrl, dim3(1), block, 0, ls, d, karg);
     } else {
-      hipLaunchKernelGGL(k_cg_scal, dim3(ctrl_G), block, 0, st, d, k);
-      hipLaunchKernelGGL(k_cg_ctrl, dim3(1), block, 0, st, d, k, ctrl_G);
+      hipLaunchKernelGGL(k_cg_scal, dim3(ctrl_G), block, 0, ls, d, karg);
+      hipLaunchKernelGGL(k_cg_ctrl, dim3(1), block, 0, ls, d, karg, ctrl_G);
     }
-    LO_PROF_END(st);
+    LO_PROF_END(ls);
     LO_LAUNCH_CHECK();
+    return LO_OK;
+  };
+  GraphReplay gr;  // (destroys the graph objects on every exit path)
+  // MEASURED SLOWER on ROCm 7.0 / MI355X (cfg4 shard 39.7 vs 38.2 ms, one dense GP of N = 4000 10.4 vs 9.8 ms: the
+  // replayed nodes start no closer together than individually launched kernels and the instantiation costs ~0.3 ms):
+  // opt-in only (LO_CG_GRAPH=1).
+  bool graph_ok = getenv("LO_CG_GRAPH") && !g_prof_on && !opaque && !precond_cb && op->kind != LO_OP_CALLBACK;
+  while (k < prm->max_iter && !h.stop) {
+    bool ran = false;
+    if (gr.exec) {
+      ran = hipGraphLaunch(gr.exec, st) == hipSuccess;
+      if (!ran) {
+        (void)hipGetLastError();
+        gr.reset();
+        graph_ok = false;
+      }
+    } else if (graph_ok && k >= k_start + 2 && prm->max_iter - k >= 8) {
+      // steady state reached (first-iteration flags gone, p_done settled): capture this iteration on a side stream
+      // (the caller's may be the legacy default stream, which cannot be captured) and replay it on the caller's
+      const bool pf0 = pf_on, pd0 = p_done;
+      if (gr.begin()) {
+        tls_graph_capture = true;
+        const int rcb = issue(k, true, gr.side);
+        tls_graph_capture = false;
+        const bool ok = gr.end() && rcb == LO_OK && pf_on == pf0 && p_done == pd0;
+        if (ok && hipGraphLaunch(gr.exec, st) == hipSuccess) {
+          ran = true;
+        } else {
+          (void)hipGetLastError();
+          gr.reset();
+          graph_ok = false;
+          pf_on = pf0;
+          p_done = pd0;
+        }
+      } else {
+        graph_ok = false;
+      }
+    }
+    if (!ran) {
+      rc = issue(k, false, st);
+      if (rc) return rc;
+    }
     ++launched;
     const bool at_poll = (k >= first_poll) && (((k - first_poll) % chunk) == 0);
     if (at_poll || k == prm->max_iter - 1 || (opaque && k == 0)) {

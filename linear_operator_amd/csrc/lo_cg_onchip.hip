@@ -431,8 +431,11 @@ bool g_res_have = false;
 hipEvent_t g_res_ev[16] = {};
 }  // namespace
 
+thread_local bool tls_graph_capture = false;
+
 ResidentLaunch::ResidentLaunch(hipStream_t st) {
   g_res_mu.lock();
+  if (tls_graph_capture) return;  // (the captured launch does not execute; the replay goes through the caller's guard)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
   if (g_res_have && g_res_last_dev == dev && g_res_last != st && !getenv("LO_NO_RESIDENT_ORDER")) {

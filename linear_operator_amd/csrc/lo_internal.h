@@ -220,6 +220,7 @@ struct ResidentLaunch {
   ResidentLaunch(const ResidentLaunch&) = delete;
   ResidentLaunch& operator=(const ResidentLaunch&) = delete;
 };
+extern thread_local bool tls_graph_capture;  // a CG iteration is being captured: no cross-stream event traffic
 extern bool g_onchip_disabled;  // lo_cg_set_onchip(0): streaming engines only (tests compare the two)
 
 // ---- single-pass Woodbury apply fused with the CG r / x update (lo_precond_fused.hip) --------------
@@ -229,8 +230,8 @@ size_t precond_fused_gbuf_bytes();
 int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, float* r, const float* Ap, float* p,
                           float* x, float* z, const float* pAp_part, int S_dot, const float* rz, const int* has_conv,
                           float eps, float* alpha_out, float* rr_part, float* rz_part, int S, int64_t B, int64_t N,
-                          unsigned long long* gbuf, int* err, int* next_member, int launch, const int* stop, int ncu,
-                          hipStream_t st);
+                          unsigned long long* gbuf, int* err, int* next_member, int launch, const int* iter_ptr,
+                          int max_launch, const int* stop, int ncu, hipStream_t st);
 
 // ---- operator-resident pivoted Cholesky (lo_pivchol_onchip.hip) ----------------------------------
 bool pc_onchip_eligible(const lo_op_desc* op, int max_rank);

@@ -50,6 +50,7 @@ struct PfArgs {
   const int* stop;
   int allow_l2_handoff;
   unsigned tag_base;  // tags of this launch start above it: the granules of earlier launches of the solve never match
+  const int* iter_ptr;  // replayed as a graph node: the launch index is read from the control block (else nullptr)
 };
 
 // (pf_publish / pf_collect: the lane-parallel reduce-scatter all-reduce for groups of up to 64 workgroups, lo_group_reduce.h)
@@ -80,6 +81,11 @@ __global__ __launch_bounds__(R4_TPB, OCC) void k_precond_fused(PfArgs a) {
   g.gslot = a.gbuf + (size_t)grp * 2 * (GW + 1) * R4_SLOT;
   g.wig = wig;
   g.dbg = nullptr;
+  if (a.iter_ptr) {  // (graph replay: same arguments every time, the iteration index lives on the device)
+    const int launch = *a.iter_ptr;
+    a.tag_base = (unsigned)launch * (unsigned)(a.B + 2);
+    a.next_member += launch;
+  }
   g.tag = a.tag_base;
   g.err = a.err;
   g.same_xcd = false;
@@ -253,15 +259,15 @@ static int pf_go(PfArgs& a, int ncu, hipStream_t st) {
   return LO_OK;
 }
 
-// gbuf: precond_fused_gbuf_bytes() of memory the CALLER zeroed once per solve, next_member: one zeroed int PER LAUNCH
-// of the solve (the caller passes a fresh one each time); `launch` = index of this launch within the solve: its tags
+// gbuf: precond_fused_gbuf_bytes() of memory the CALLER zeroed once per solve, next_member: base of one zeroed int PER
+// LAUNCH of the solve (max_launch + 1 of them); `launch` = index of this launch within the solve: its tags
 // start at launch * (B + 2), so nothing has to be cleared between the iterations (two memset launches per CG iteration
 // were 3 % of the cfg4 iteration).  LO_ERR_UNSUPPORTED when the tag space would wrap (the caller falls back).
 int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, float* r, const float* Ap, float* p,
                           float* x, float* z, const float* pAp_part, int S_dot, const float* rz, const int* has_conv,
                           float eps, float* alpha_out, float* rr_part, float* rz_part, int S, int64_t B, int64_t N,
-                          unsigned long long* gbuf, int* err, int* next_member, int launch, const int* stop, int ncu,
-                          hipStream_t st) {
+                          unsigned long long* gbuf, int* err, int* next_member, int launch, const int* iter_ptr,
+                          int max_launch, const int* stop, int ncu, hipStream_t st) {
   PfArgs a;
   a.Q = Q; a.dinv = dinv; a.dinv_mode = dinv_mode; a.r = r; a.Ap = Ap; a.p = p; a.x = x; a.z = z;
   a.pAp_part = pAp_part; a.S_dot = S_dot; a.rz = rz; a.has_conv = has_conv; a.eps = eps; a.alpha_out = alpha_out;
@@ -270,9 +276,12 @@ int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, floa
   a.RW = (int)((N + GW - 1) / GW);
   a.gbuf = gbuf; a.err = err; a.next_member = next_member; a.stop = stop;
   a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
+  // next_member: base of the per-launch counters; launch: index of this launch (iter_ptr: read on the device instead)
   const unsigned long long base = (unsigned long long)launch * (unsigned long long)(B + 2);
-  if (base + (unsigned long long)B + 2 >= 0xffff0000ull) return LO_ERR_UNSUPPORTED;
+  if ((unsigned long long)(max_launch + 1) * (unsigned long long)(B + 2) >= 0xffff0000ull) return LO_ERR_UNSUPPORTED;
   a.tag_base = (unsigned)base;
+  a.iter_ptr = iter_ptr;
+  if (!iter_ptr) a.next_member = next_member + launch;
   // four workgroups per CU (110 VGPRs): cfg4 153 us per call against 188 us with two or three
   if (GW == 16) return pf_go<16, 4>(a, ncu, st);
   if (GW == 32) return pf_go<32, 4>(a, ncu, st);
