@@ -41,7 +41,8 @@ struct Split {
   int S;
   int rows;
 };
-Split choose_split(int64_t B, int64_t N, int min_rows);
+// (max_split: 256 unless a caller's kernels hold the partials of a member in a fixed-size buffer)
+Split choose_split(int64_t B, int64_t N, int min_rows, int max_split = 256);
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -711,7 +711,7 @@ using namespace lo;
 extern "C" {
 
 static void lz_layout(const lo_op_desc* op, int64_t P, int max_iter, Arena& ar, LzDev* d, Split* spo) {
-  Split sp = choose_split(op->B, op->N, 256);
+  Split sp = choose_split(op->B, op->N, 256, 64);  // (the fused step keeps a member's dot partials in 64 slots)
   *spo = sp;
   d->B = op->B; d->N = op->N; d->P = (int)P; d->S = sp.S; d->rows = sp.rows; d->max_iter = max_iter;
   d->ctrl = ar.take<LzCtrl>(1);

@@ -9,12 +9,16 @@
 
 namespace lo {
 
-Split choose_split(int64_t B, int64_t N, int min_rows) {
-  // aim for >= ~1024 workgroups (4 per CU) but keep >= min_rows rows per workgroup
+Split choose_split(int64_t B, int64_t N, int min_rows, int max_split) {
+  // aim for >= ~1024 workgroups (4 per CU) but keep >= min_rows rows per workgroup; at most max_split slices (256: one
+  // very tall member -- N = 1M rows -- used to get 64 workgroups = a quarter of the CUs, 0.7 TB/s)
   int64_t S = (1024 + B - 1) / B;
   int64_t maxS = std::max<int64_t>(1, N / std::max(min_rows, 4));
   S = std::max<int64_t>(1, std::min<int64_t>(S, maxS));
-  S = std::min<int64_t>(S, 64);
+  // (every consumer sums the S partials of a member: beyond 64 slices only as far as a slice keeps >= 16 S rows)
+  int64_t cap = 64;
+  while (cap < max_split && (cap * 2) * (cap * 2) * 16 <= N) cap *= 2;
+  S = std::min<int64_t>(S, std::min<int64_t>(cap, max_split));
   int64_t rows = (N + S - 1) / S;
   rows = (rows + 3) / 4 * 4;
   S = (N + rows - 1) / rows;
