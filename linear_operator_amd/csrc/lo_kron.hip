@@ -123,7 +123,9 @@ __device__ __forceinline__ int km_row(int reg, int lane) { return (reg & 3) + 8 
 // D = A B^T for one 128 x 128 tile, K in slabs of 64 through LDS (row stride 68 floats: conflict-free ds_read_b128
 // of the MFMA operands), next slab fetched into registers while the current one is multiplied.  4 waves, each a
 // 64 x 64 quadrant = 2 x 2 MFMA tiles of 32 x 32.
-template <bool EPI>
+// GUARD: M, N, K are multiples of 4 but not of the tile (factor sizes of real Kronecker kernels are arbitrary): rows /
+// columns beyond the matrices are loaded as zeros and not stored.
+template <bool EPI, bool GUARD = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_kron_nt_mfma(
     KmArgs g, const int* __restrict__ stop) {
   if (stop && *stop) return;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   __shared__ float dot_s[4];
   // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs, so all tiles of a member get ids
   // of the same residue mod 8 -> one XCD, one L2: the member's operands are fetched from HBM once, not once per XCD
-  const int tiles_n = g.N / KM_BN, tiles = tiles_n * (g.M / KM_BM);
+  const int tiles_n = (g.N + KM_BN - 1) / KM_BN, tiles = tiles_n * ((g.M + KM_BM - 1) / KM_BM);
   const int id = blockIdx.x, xcd = id & 7, rest = id >> 3;
   const int tile = rest % tiles, z = (rest / tiles) * 8 + xcd;
   if (z >= g.B) return;
@@ -153,6 +155,19 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   float* bl = &b_s[sr * KM_LD + 4 * sq];
   float4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
 #define KM_LD4(p_) (*reinterpret_cast<const float4*>(p_))
+  // (guarded variant: float4 of row sr + 16 u at k if inside the matrix, else zeros)
+  auto ldg = [&](const float* base, int row_lim, int u, int kq) -> float4 {
+    return (sr + 16 * u < row_lim && kq + 4 * sq < g.K) ? KM_LD4(base + (size_t)u * rs + kq)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  const int a_lim = g.M - m0, b_lim = g.N - n0;  // valid rows of this tile's operands
+#define KM_LOADG(k0_)                                                                                        \
+  ra0 = ldg(ag, a_lim, 0, k0_); ra1 = ldg(ag, a_lim, 1, k0_); ra2 = ldg(ag, a_lim, 2, k0_);                    \
+  ra3 = ldg(ag, a_lim, 3, k0_); ra4 = ldg(ag, a_lim, 4, k0_); ra5 = ldg(ag, a_lim, 5, k0_);                    \
+  ra6 = ldg(ag, a_lim, 6, k0_); ra7 = ldg(ag, a_lim, 7, k0_);                                                  \
+  rb0 = ldg(bg, b_lim, 0, k0_); rb1 = ldg(bg, b_lim, 1, k0_); rb2 = ldg(bg, b_lim, 2, k0_);                    \
+  rb3 = ldg(bg, b_lim, 3, k0_); rb4 = ldg(bg, b_lim, 4, k0_); rb5 = ldg(bg, b_lim, 5, k0_);                    \
+  rb6 = ldg(bg, b_lim, 6, k0_); rb7 = ldg(bg, b_lim, 7, k0_);
 #define KM_LOAD(k0_)                                                                                         \
   ra0 = KM_LD4(ag + (k0_)); ra1 = KM_LD4(ag + rs + (k0_)); ra2 = KM_LD4(ag + 2 * rs + (k0_));               \
   ra3 = KM_LD4(ag + 3 * rs + (k0_)); ra4 = KM_LD4(ag + 4 * rs + (k0_)); ra5 = KM_LD4(ag + 5 * rs + (k0_));   \
@@ -169,7 +184,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     acc10[e] = 0.f;
     acc11[e] = 0.f;
   }
-  KM_LOAD(0)
+  if constexpr (GUARD) {
+    KM_LOADG(0)
+  } else {
+    KM_LOAD(0)
+  }
   for (int k0 = 0; k0 < g.K; k0 += KM_BK) {
     __syncthreads();
     KM_ST4(al, ra0); KM_ST4(al + 16 * KM_LD, ra1); KM_ST4(al + 32 * KM_LD, ra2); KM_ST4(al + 48 * KM_LD, ra3);
@@ -179,7 +198,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     KM_ST4(bl + 64 * KM_LD, rb4); KM_ST4(bl + 80 * KM_LD, rb5); KM_ST4(bl + 96 * KM_LD, rb6);
     KM_ST4(bl + 112 * KM_LD, rb7);
     __syncthreads();
-    {
+    if constexpr (GUARD) {
+      const int kn = k0 + KM_BK;  // (beyond K: the guard returns zeros, the loop ends before they are used)
+      KM_LOADG(kn)
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
       const int kn = min(k0 + KM_BK, g.K - KM_BK);
       KM_LOAD(kn)
       __builtin_amdgcn_sched_barrier(0);  // the scheduler would otherwise sink the loads below the MFMAs
@@ -205,6 +228,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   }
 #undef KM_LOAD
+#undef KM_LOADG
 #undef KM_LD4
 #undef KM_ST4
   float* D = g.D + (size_t)z * g.M * g.N;
@@ -214,7 +238,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = m0 + 64 * wr + 32 * rt + km_row(e, lane);
-      const size_t o = (size_t)row * g.N + n0 + 64 * wc + 32 * ct + li;
+      const int colg = n0 + 64 * wc + 32 * ct + li;
+      if (GUARD && (row >= g.M || colg >= g.N)) continue;
+      const size_t o = (size_t)row * g.N + colg;
       float yv = acc[e];
       if (EPI) {
         const float vin = g.v[(size_t)z * g.M * g.N + o];
@@ -237,11 +263,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 }
 
-bool kron_mfma_ok(int n1, int n2, int64_t c) {
-  return c == 1 && n1 % 128 == 0 && n2 % 128 == 0 && n1 >= 128 && n2 >= 128;
-}
+static bool km_aligned(int n1, int n2) { return n1 % 128 == 0 && n2 % 128 == 0; }
+// (factor sizes that are multiples of 4 and at least 64: tiles beyond the matrices are guarded; smaller or odd sizes
+//  stay on the strided VALU GEMM)
+bool kron_mfma_ok(int n1, int n2, int64_t c) { return c == 1 && n1 % 4 == 0 && n2 % 4 == 0 && n1 >= 64 && n2 >= 64; }
 int kron_S_dot(int n1, int n2, int64_t c, int S_default) {
-  return kron_mfma_ok(n1, n2, c) ? (n1 / KM_BM) * (n2 / KM_BN) : S_default;
+  return kron_mfma_ok(n1, n2, c) ? ((n1 + KM_BM - 1) / KM_BM) * ((n2 + KM_BN - 1) / KM_BN) : S_default;
+}
+
+template <bool EPI>
+static void km_launch(const KmArgs& g, int64_t Z, bool guard, const int* stop, hipStream_t st) {
+  const unsigned tiles = (unsigned)(((g.M + KM_BM - 1) / KM_BM) * ((g.N + KM_BN - 1) / KM_BN));
+  const dim3 grid((unsigned)(((Z + 7) / 8) * 8) * tiles);
+  if (guard) hipLaunchKernelGGL((k_kron_nt_mfma<EPI, true>), grid, dim3(kThreads), 0, st, g, stop);
+  else hipLaunchKernelGGL((k_kron_nt_mfma<EPI, false>), grid, dim3(kThreads), 0, st, g, stop);
 }
 
 // y = (K1 (x) K2) v + diag o v and (optionally) the dot partials sum v o y, c == 1, matrix cores
@@ -254,14 +289,14 @@ int kron_matvec_mfma(const float* K1, const float* K2, const float* diag, int di
   g.M = n2; g.N = n1; g.K = n2;
   g.diag = nullptr; g.diag_mode = LO_DIAG_NONE; g.v = nullptr; g.dot_part = nullptr;
   LO_PROF_BEGIN("kron_gemm_mfma", st);
-  hipLaunchKernelGGL((k_kron_nt_mfma<false>), dim3((unsigned)(((B + 7) / 8) * 8 * (g.M / KM_BM) * (g.N / KM_BN))), dim3(kThreads), 0, st, g, stop);
+  km_launch<false>(g, B, !km_aligned(n1, n2), stop, st);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   g.A = K1; g.Bm = tmp; g.D = y;  // Y [n1, n2]
   g.M = n1; g.N = n2; g.K = n1;
   g.diag = diag; g.diag_mode = diag ? diag_mode : LO_DIAG_NONE; g.v = v; g.dot_part = dot_part;
   LO_PROF_BEGIN("kron_gemm_mfma", st);
-  hipLaunchKernelGGL((k_kron_nt_mfma<true>), dim3((unsigned)(((B + 7) / 8) * 8 * (g.M / KM_BM) * (g.N / KM_BN))), dim3(kThreads), 0, st, g, stop);
+  km_launch<true>(g, B, !km_aligned(n1, n2), stop, st);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
@@ -328,14 +363,12 @@ int kron_matvec_mfma_cols(const float* K1, const float* K2, const float* diag, i
   g.A = K2; g.Bm = buf_a; g.D = buf_b;  // Tt [n2, n1] per (member, column)
   g.M = n2; g.N = n1; g.K = n2;
   LO_PROF_BEGIN("kron_gemm_mfma", st);
-  hipLaunchKernelGGL((k_kron_nt_mfma<false>), dim3((unsigned)(((Z + 7) / 8) * 8 * (g.M / KM_BM) * (g.N / KM_BN))),
-                     dim3(kThreads), 0, st, g, stop);
+  km_launch<false>(g, Z, !km_aligned(n1, n2), stop, st);
   LO_PROF_END(st);
   g.A = K1; g.Bm = buf_b; g.D = buf_a;  // Y [n1, n2]
   g.M = n1; g.N = n2; g.K = n1;
   LO_PROF_BEGIN("kron_gemm_mfma", st);
-  hipLaunchKernelGGL((k_kron_nt_mfma<false>), dim3((unsigned)(((Z + 7) / 8) * 8 * (g.M / KM_BM) * (g.N / KM_BN))),
-                     dim3(kThreads), 0, st, g, stop);
+  km_launch<false>(g, Z, !km_aligned(n1, n2), stop, st);
   LO_PROF_END(st);
   LO_PROF_BEGIN("kron_cols", st);
   hipLaunchKernelGGL(k_kron_cols, tgrid, dim3(kThreads), lds, st, buf_a, y, N, (int)c, 0, diag,

@@ -223,3 +223,30 @@ def test_large_members_take_groups_of_64(N, c):
     exact = r64 / d64.unsqueeze(-1) - Cd @ torch.linalg.solve(cap, Cd.mT @ r64)
     err = ((res.x.double() - exact).norm(dim=-2) / exact.norm(dim=-2)).max().item()
     assert err < 1e-4, (N, c, res.iterations, err)
+
+
+@pytest.mark.parametrize("n1,n2,c", [(64, 100, 1), (72, 68, 1), (64, 132, 3), (100, 64, 1), (76, 76, 9), (68, 96, 1)])
+def test_kronecker_factors_of_any_multiple_of_four_use_the_matrix_core_engine(n1, n2, c):
+    """Factor sizes that are multiples of 4 (>= 64) but not of the 128-wide tile: guarded tiles of the matrix-core GEMMs
+    (lo_kron.hip, GUARD) -- matvec with / without diagonal and a preconditioned CG solve against the dense fp64 values."""
+    from linear_operator_amd import _hip
+
+    B = 3
+    K1, K2, sig, rhs = cases.kron_factors(9800 + n1 + n2, B, n1, n2, c, sigma=0.05)
+    desc = K.kron_diag_descriptor(dev(K1), dev(K2), dev(sig[:, 0]), const_diag=True)
+    A = np.stack([np.kron(K1[b].astype(np.float64), K2[b].astype(np.float64)) for b in range(B)])
+    _hip.prof_enable(True)
+    y = host(K.matvec(desc, dev(rhs)))
+    torch.cuda.synchronize()
+    prof = _hip.prof_report()
+    _hip.prof_enable(False)
+    assert "kron_gemm_mfma" in prof, sorted(prof)
+    Ad = A + np.stack([sig[b, 0] * np.eye(n1 * n2) for b in range(B)])
+    assert max_rel_err_cols(y, Ad @ rhs.astype(np.float64)) < 1e-5
+    y0 = host(K.matvec(K.kron_diag_descriptor(dev(K1), dev(K2), None), dev(rhs)))
+    assert max_rel_err_cols(y0, A @ rhs.astype(np.float64)) < 1e-5
+    L, _ = K.pivoted_cholesky(desc, 15, contiguous=False)
+    pre = K.precond_build(L, dev(sig[:, 0]), True)
+    res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-5, max_iter=1500)
+    err = max_rel_err_cols(host(res.x), np.linalg.solve(Ad, rhs.astype(np.float64)))
+    assert err < 5e-4, (n1, n2, c, res.iterations, err)
