@@ -979,7 +979,10 @@ int lo_precond_build_strided_f32(const float* L, int64_t ld_member, int64_t ld_r
   double* Minv = ar.take<double>((size_t)B * k * k);
   float* scale = ar.take<float>((size_t)B * N);
   if (!ar.ok) return LO_ERR_WORKSPACE;
-  if (k > kPbMaxK)  // (Minv's storage holds the fp32 k x k operand of the Q kernel)
+  // wide path: k > 32, and 16 < k <= 32 in the rows layout [B, m, N] the pivoted-Cholesky kernels write (the fp64
+  // matrix-core kernels of that layout take 16 columns; the per-row VALU kernels that used to serve this case need
+  // 6.4 ms at 512 x 8192 x 17 against ~1 ms here)   (Minv's storage holds the fp32 k x k operand of the Q kernel)
+  if (k > kPbMaxK || (k > 16 && ld_col != 1))
     return precond_build_wide(L, ls, d, diag_mode, B, N, k, Q, dinv, logdet_p, gpart, logd,
                               reinterpret_cast<float*>(Minv), scale, sp, st);
   const int ldq = padded_k(k);

@@ -1,3 +1,3 @@
 #!/bin/bash
-python -m pytest tests -q -x -m gpu > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -1; grep -E "^E " gpurun_out/pytest_gpu.log | head -6
-python tools/mb_cfg45.py cfg4 2>&1 | grep -E "CG:|kron_gemm"
+python tools/mb_rank_sweep.py 2>&1 | grep "^rank"
+python -m pytest tests -q -x -m gpu -k "precond or wide or sweep or above_32" 2>&1 | tail -2
