@@ -34,8 +34,9 @@ constexpr int PO_TPB = 1024;
 constexpr int PO_GW = 8;
 constexpr int PO_WAVES = PO_TPB / 64;
 constexpr int PO_CLD = 36;    // LDS row stride of C (floats)
-constexpr int PO_SLOT = 64;   // granules per workgroup and parity
-constexpr int PO_MAXR = 16;   // pivots held in registers
+constexpr int PO_SLOT = 72;   // granules per workgroup and parity (header + 32 C entries + up to 32 L entries)
+constexpr int PO_MAXR = 16;   // pivots held in registers (first generation)
+constexpr int P4_MAXR = 32;   // pivots held in LDS (second generation, 8 slots of 16 bytes per row above 16)
 constexpr int PO_HDR = 4;     // value, position, (unused), error partial
 constexpr unsigned PO_MAXSPIN = 1u << 20;  // ~0.5 s of polling: co-residency was lost (never seen on a dedicated GPU)
 constexpr int PO_INVALID = 0x7fffffff;
@@ -79,7 +80,7 @@ __device__ __forceinline__ void po_gather(PoShared& sh, int cnt, unsigned long l
     else
       __hip_atomic_store(slot + (size_t)wig * PO_SLOT + t, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  const int w = t >> 6, i = t & 63;  // wave w polls workgroup w's granules (PO_SLOT == 64)
+  const int w = t >> 6, i = t & 63;  // wave w polls workgroup w's granules (at most 64 of the PO_SLOT are in use here)
   if (w < PO_GW && i < cnt) {
     const unsigned long long* src = slot + (size_t)w * PO_SLOT + i;
     unsigned long long g = 0;
@@ -347,7 +348,13 @@ struct alignas(16) P4Shared {
   unsigned gath[GW][PO_SLOT];
 };
 
-__device__ __forceinline__ int l_slot(int r, int q) { return r * 4 + (q ^ ((r >> 2) & 3)); }
+// LQ = 16-byte slots per row: 4 (rank <= 16, rows 64 bytes apart, XOR over groups of 4 rows) or 8 (rank <= 32, rows 128
+// bytes apart: two consecutive rows cover the 64 banks, XOR over pairs of rows)
+template <int LQ>
+__device__ __forceinline__ int l_slot(int r, int q) {
+  if constexpr (LQ == 4) return r * 4 + (q ^ ((r >> 2) & 3));
+  else return r * 8 + (q ^ ((r >> 1) & 7));
+}
 
 // thread t < cnt publishes sh.part[t] and fetches component t of every workgroup of the group into sh.gath
 template <int GW>
@@ -417,10 +424,14 @@ __device__ __forceinline__ void p4_gather(P4Shared<GW>& sh, int cnt, unsigned lo
   __syncthreads();
 }
 
-template <int RC, int GW>
+template <int RC, int GW, int LQ>
 __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
   __shared__ P4Shared<GW> sh;
-  __shared__ float4 l_s[P4_ROWS * 4];  // L rows (16 floats) of this workgroup, swizzled 16-byte slots
+  // L rows (4 * LQ floats) of this workgroup, swizzled 16-byte slots: 64 KB static (two workgroups per CU) for rank
+  // <= 16, 128 KB dynamic (one workgroup per CU) for rank <= 32
+  __shared__ float4 l_static[LQ == 4 ? P4_ROWS * 4 : 1];
+  extern __shared__ float4 l_dynamic[];
+  float4* const l_s = (LQ == 4) ? l_static : l_dynamic;
   const int wg = blockIdx.x;
   const int xcd = wg % 8, jx = wg / 8;
   const int groups_per_xcd = (gridDim.x / 8) / GW;
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
       dg[q] = valid ? acc : 0.f;
       pos[q] = valid ? row0 + lr : PO_INVALID;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) l_s[l_slot(lr, i)] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < LQ; ++i) l_s[l_slot<LQ>(lr, i)] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     if (stamp) a.dbg[1] = wall_clock64();
@@ -522,7 +533,7 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
           for (int r = 0; r < RC; ++r) sh.part[PO_HDR + r] = __float_as_uint(Cr[q][r]);
           const int lr = t + P4_TPB * q;
           for (int j4 = 0; 4 * j4 < m; ++j4) {
-            const float4 l4 = l_s[l_slot(lr, j4)];
+            const float4 l4 = l_s[l_slot<LQ>(lr, j4)];
             sh.part[PO_HDR + RC + 4 * j4] = __float_as_uint(l4.x);
             sh.part[PO_HDR + RC + 4 * j4 + 1] = __float_as_uint(l4.y);
             sh.part[PO_HDR + RC + 4 * j4 + 2] = __float_as_uint(l4.z);
@@ -605,7 +616,7 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
         const int j = 4 * j4;
         float4 l4[P4_NR];
 #pragma unroll
-        for (int q = 0; q < P4_NR; ++q) l4[q] = l_s[l_slot(t + P4_TPB * q, j4)];
+        for (int q = 0; q < P4_NR; ++q) l4[q] = l_s[l_slot<LQ>(t + P4_TPB * q, j4)];
 #pragma unroll
         for (int q = 0; q < P4_NR; ++q) accs[q] = (j == 0) ? u4.x * l4[q].x : accs[q] + u4.x * l4[q].x;
         if (j + 1 < m) {
@@ -637,7 +648,7 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
         if (live) pos[q] = np;
         const float val = (np == m) ? piv : vq[q];  // the pivot row gets sqrt(max) (:73-74)
         if (live && np >= m)                         // already pivoted rows keep L[m] = 0
-          reinterpret_cast<float*>(&l_s[l_slot(t + P4_TPB * q, ms)])[me] = val;
+          reinterpret_cast<float*>(&l_s[l_slot<LQ>(t + P4_TPB * q, ms)])[me] = val;
         if (live && np > m) dg[q] = dg[q] - vq[q] * vq[q];  // :94-95
       }
       // sh.gath / sh.part are next written after the barrier that follows the candidate reduction
@@ -657,8 +668,8 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
       if (lr < nv) {
         float* Lb = a.L + (size_t)b * a.max_rank * a.N + row0 + lr;
 #pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) {
-          const float4 l4 = l_s[l_slot(lr, j4)];
+        for (int j4 = 0; j4 < LQ; ++j4) {
+          const float4 l4 = l_s[l_slot<LQ>(lr, j4)];
           const int m0 = 4 * j4;
           if (m0 < a.max_rank) Lb[(size_t)m0 * a.N] = (m0 < a.rank) ? l4.x : 0.f;
           if (m0 + 1 < a.max_rank) Lb[(size_t)(m0 + 1) * a.N] = (m0 + 1 < a.rank) ? l4.y : 0.f;
@@ -707,7 +718,7 @@ __device__ __forceinline__ int po_rank(const PoArgs& a, float tol, int* cont_s, 
 
 __global__ __launch_bounds__(kThreads) void k_po_perm(PoArgs a, float tol, int* __restrict__ m_out,
                                                        long long* __restrict__ perm) {
-  __shared__ int cont_s[PO_MAXR + 1];
+  __shared__ int cont_s[P4_MAXR + 1];
   __shared__ int mstar_s;
   const int64_t b = blockIdx.x;
   const int mstar = po_rank(a, tol, cont_s, &mstar_s);
@@ -732,7 +743,8 @@ __global__ __launch_bounds__(kThreads) void k_po_perm(PoArgs a, float tol, int* 
 bool pc_onchip_eligible(const lo_op_desc* op, int max_rank) {
   if (g_onchip_disabled || op->kind != LO_OP_LOWRANK_DIAG) return false;
   const int64_t R = op->R;  // (any rank up to 32: zero-padded to 8 / 16 / 32 columns in the workspace)
-  return R >= 1 && R <= 32 && max_rank <= PO_MAXR && op->N >= 256 &&
+  // (rank 17 .. 32: second generation only, one workgroup per CU -- needs a full group of the member's size)
+  return R >= 1 && R <= 32 && max_rank <= P4_MAXR && op->N >= 256 &&
          op->N <= (int64_t)32 * P4_ROWS && onchip_num_workgroups() >= 64;
 }
 
@@ -792,26 +804,38 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
       break;
     }
   if (getenv("LO_OC_GW8")) gw2 = std::max(gw2, 8);
-  bool gen2 = !(getenv("LO_OC_GEN1") && op->N <= (int64_t)PO_GW * PO_TPB);
+  const bool wide = max_rank > PO_MAXR;  // rank 17 .. 32: 128 KB of L rows per workgroup, one workgroup per CU
+  const int wpc = wide ? 1 : 2;          // workgroups per CU the launch relies on
+  const size_t dyn_lds = wide ? sizeof(float4) * (size_t)P4_ROWS * 8 : 0;
+  bool gen2 = wide || !(getenv("LO_OC_GEN1") && op->N <= (int64_t)PO_GW * PO_TPB);
   if (gen2) {
     int per_cu = 0;
     hipError_t e = hipErrorUnknown;
-#define LO_OCC(R_, G_) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pc_onchip4<R_, G_>, P4_TPB, 0)
+#define LO_OCC(R_, G_)                                                                                               \
+  if (wide) {                                                                                                        \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pc_onchip4<R_, G_, 8>),                                  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);                               \
+    if (e == hipSuccess)                                                                                             \
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pc_onchip4<R_, G_, 8>, P4_TPB, dyn_lds);           \
+  } else {                                                                                                           \
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pc_onchip4<R_, G_, 4>, P4_TPB, 0);                   \
+  }
 #define LO_OCC_R(R_)                       \
   switch (gw2) {                           \
-    case 1: LO_OCC(R_, 1); break;          \
-    case 2: LO_OCC(R_, 2); break;          \
-    case 4: LO_OCC(R_, 4); break;          \
-    case 8: LO_OCC(R_, 8); break;          \
-    case 16: LO_OCC(R_, 16); break;        \
-    default: LO_OCC(R_, 32); break;        \
+    case 1: LO_OCC(R_, 1) break;           \
+    case 2: LO_OCC(R_, 2) break;           \
+    case 4: LO_OCC(R_, 4) break;           \
+    case 8: LO_OCC(R_, 8) break;           \
+    case 16: LO_OCC(R_, 16) break;         \
+    default: LO_OCC(R_, 32) break;         \
   }
     if (RP == 32) { LO_OCC_R(32) } else if (RP == 16) { LO_OCC_R(16) } else { LO_OCC_R(8) }
 #undef LO_OCC_R
 #undef LO_OCC
-    gen2 = (e == hipSuccess) && per_cu >= 2;
+    // every XCD must hold at least one whole group, all of its workgroups resident at once
+    gen2 = (e == hipSuccess) && per_cu >= wpc && (wpc * nwg / 8) / gw2 >= 1;
   }
-  if (!gen2 && op->N > (int64_t)PO_GW * PO_TPB) return LO_ERR_LAUNCH;  // caller runs the streaming engine
+  if (!gen2 && (wide || op->N > (int64_t)PO_GW * PO_TPB)) return LO_ERR_LAUNCH;  // caller runs the streaming engine
   const int gw = gen2 ? gw2 : PO_GW;
   PoArgs a;
   a.C = Csrc;
@@ -838,8 +862,10 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   {
   ResidentLaunch guard(st);
   if (gen2) {
-    dim3 grid2(2 * nwg), block2(P4_TPB);
-#define LO_GO(R_, G_) hipLaunchKernelGGL((k_pc_onchip4<R_, G_>), grid2, block2, 0, st, a)
+    dim3 grid2(wpc * nwg), block2(P4_TPB);
+#define LO_GO(R_, G_)                                                                      \
+  if (wide) hipLaunchKernelGGL((k_pc_onchip4<R_, G_, 8>), grid2, block2, dyn_lds, st, a);  \
+  else hipLaunchKernelGGL((k_pc_onchip4<R_, G_, 4>), grid2, block2, 0, st, a)
 #define LO_GO_R(R_)                      \
   switch (gw) {                          \
     case 1: LO_GO(R_, 1); break;         \

@@ -196,6 +196,30 @@ def test_small_members_take_small_groups(N):
     assert torch.equal(L8, L) and torch.equal(piv8, piv)
 
 
+def test_pivoted_cholesky_ranks_17_to_32_stay_resident_and_bit_exact():
+    """`max_preconditioner_size` 17 .. 32: the L rows of a workgroup take 128 KB of LDS (one workgroup per CU) and the
+    factorisation stays operator-resident; pivots, permutation and factor bit-identical to the oracle for every group
+    size, ragged N, padded root ranks, and rank > numerical rank (whole-batch early stop)."""
+    from linear_operator_amd import _hip
+
+    rnd = random.Random(21)
+    shapes = [(3, 256, 32, 17), (40, 1000, 20, 24), (5, 2048, 32, 32), (2, 4099, 8, 31), (33, 8192, 32, 20),
+              (2, 12000, 16, 32), (1, 20000, 32, 17), (2, 1537, 3, 20), (300, 1024, 32, 32)]
+    for case, (B, N, R, rank) in enumerate(shapes):
+        C = cases.lowrank_diag(9800 + case, B, N, R, 1)[0]
+        _hip.prof_enable(True)
+        L, piv = K.pivoted_cholesky(K.lowrank_diag_descriptor(dev(C), None), rank)
+        torch.cuda.synchronize()
+        prof = _hip.prof_report()
+        _hip.prof_enable(False)
+        Lo, pivo = orc.pivoted_cholesky(orc.LowRankRowSource(C), rank)
+        tag = f"B={B} N={N} R={R} rank={rank}"
+        assert "pc_onchip" in prof, (tag, sorted(prof))
+        assert np.array_equal(host(piv), pivo), tag
+        assert host(L).shape == Lo.shape and np.array_equal(host(L), Lo), tag
+    del rnd
+
+
 @pytest.mark.parametrize("N,c", [(40000, 1), (65536, 1), (50000, 3)])
 def test_large_members_take_groups_of_64(N, c):
     """32768 < N <= 65536: the root-form resident CG runs a member on 64 workgroups (lane-parallel two-hop all-reduce)
