@@ -306,6 +306,31 @@ int lo_minres_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user, 
                   lo_matvec_cb precond_cb, void* precond_user, const lo_minres_params* prm, const float* rhs,
                   const float* shifts, float* x, void* ws, size_t ws_bytes, lo_minres_info* info, void* stream);
 
+/* ---- linear_cg in fp64 (linear_operator/utils/linear_cg.py:98-359 with float64 operands) ---------------------- */
+/* north_star's path is fp32; this entry exists so that the reference's own fp64 recipes run unmodified (every case of
+ * its test/utils/test_linear_cg.py:27-160 builds float64 operands).  Plain streaming formulation, same masking,
+ * stopping rule and CG-coefficient tridiagonals as lo_cg_solve_f32.
+ *   A         [B, N, N] dense fp64 operator (+ diag [B, N] or NULL), or NULL with (matvec, matvec_user): the closure
+ *             is called once per product on [B, N, c] device buffers, must enqueue on `stream`
+ *   precond_cb  opaque preconditioner closure or NULL (identity)
+ *   rhs, x0 (or NULL), x  [B, N, c];  t_mat [n_tridiag, B, T, T] out, T = max_tridiag_iter, zero-filled by the call
+ * SYNCHRONOUS (one control read-back per iteration).  No batch-global stop hook over ranks.                        */
+typedef int (*lo_matvec_cb_f64)(void* user, const double* v, double* y, int64_t B, int64_t N, int64_t c, void* stream);
+typedef struct lo_cg_params_f64 {
+  int64_t c;
+  int32_t n_tridiag, max_iter, max_tridiag_iter, floor_max_iter; /* as lo_cg_params */
+  double tolerance, eps, stop_updating_after;
+} lo_cg_params_f64;
+typedef struct lo_cg_info_f64 {
+  int32_t iterations, matvecs, tolerance_reached, nan_detected, skipped, last_tridiag_iter; /* as lo_cg_info */
+  double mean_residual;
+} lo_cg_info_f64;
+size_t lo_cg_f64_workspace_bytes(int64_t B, int64_t N, const lo_cg_params_f64* prm);
+int lo_cg_solve_f64(const double* A, const double* diag, lo_matvec_cb_f64 matvec, void* matvec_user,
+                    lo_matvec_cb_f64 precond_cb, void* precond_user, const lo_cg_params_f64* prm, int64_t B, int64_t N,
+                    const double* rhs, const double* x0, double* x, double* t_mat, void* ws, size_t ws_bytes,
+                    lo_cg_info_f64* info, void* stream);
+
 /* ---- measurement aid (no reference counterpart) ------------------------------------------------ */
 /* Opt-in HIP-event timing of every kernel launch of the library, recorded on the launch stream.
  * lo_prof_report writes "name count total_ms" lines into buf (returns the byte count) and resets.

@@ -19,7 +19,7 @@ _lib = None
 LO_OP_LOWRANK_DIAG, LO_OP_DENSE_DIAG, LO_OP_KRON_DIAG, LO_OP_CALLBACK, LO_OP_SUM = 0, 1, 2, 3, 4
 LO_MAX_TERMS = 4
 LO_DIAG_NONE, LO_DIAG_FULL, LO_DIAG_CONST = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 LO_ERR_UNSUPPORTED = -4
 _ERR = {-1: "bad argument", -2: "HIP launch/runtime failure", -3: "workspace too small", -4: "unsupported shape"}
@@ -28,6 +28,7 @@ EXPORTS = [
     "lo_abi_version", "lo_target_arch",
     "lo_matvec_workspace_bytes", "lo_matvec_f32",
     "lo_cg_workspace_bytes", "lo_cg_solve_f32", "lo_cg_set_onchip",
+    "lo_cg_f64_workspace_bytes", "lo_cg_solve_f64",
     "lo_pivoted_cholesky_workspace_bytes", "lo_pivoted_cholesky_f32",
     "lo_pivoted_cholesky_cb_workspace_bytes", "lo_pivoted_cholesky_cb_f32",
     "lo_precond_build_workspace_bytes", "lo_precond_build_f32", "lo_precond_build_strided_f32",
@@ -78,6 +79,18 @@ class CgInfo(C.Structure):
                 ("mean_residual", C.c_float), ("reserved", C.c_float)]
 
 
+class CgParamsF64(C.Structure):
+    _fields_ = [("c", C.c_int64), ("n_tridiag", C.c_int32), ("max_iter", C.c_int32), ("max_tridiag_iter", C.c_int32),
+                ("floor_max_iter", C.c_int32), ("tolerance", C.c_double), ("eps", C.c_double),
+                ("stop_updating_after", C.c_double)]
+
+
+class CgInfoF64(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("matvecs", C.c_int32), ("tolerance_reached", C.c_int32),
+                ("nan_detected", C.c_int32), ("skipped", C.c_int32), ("last_tridiag_iter", C.c_int32),
+                ("mean_residual", C.c_double)]
+
+
 class MinresParams(C.Structure):
     _fields_ = [("c", C.c_int64), ("n_shifts", C.c_int32), ("max_iter", C.c_int32), ("has_value", C.c_int32),
                 ("shifts_per_member", C.c_int32), ("value", C.c_float), ("tolerance", C.c_float), ("eps", C.c_float),
@@ -126,6 +139,12 @@ def load():
     lib.lo_cg_solve_f32.argtypes = [P(OpDesc), MATVEC_CB, C.c_void_p, P(PrecondDesc), MATVEC_CB, C.c_void_p,
                                     P(CgParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz,
                                     P(CgInfo), C.c_void_p]
+    lib.lo_cg_f64_workspace_bytes.restype = sz
+    lib.lo_cg_f64_workspace_bytes.argtypes = [C.c_int64, C.c_int64, P(CgParamsF64)]
+    lib.lo_cg_solve_f64.restype = C.c_int
+    lib.lo_cg_solve_f64.argtypes = [C.c_void_p, C.c_void_p, MATVEC_CB, C.c_void_p, MATVEC_CB, C.c_void_p,
+                                    P(CgParamsF64), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, sz, P(CgInfoF64), C.c_void_p]
     lib.lo_minres_workspace_bytes.restype = sz
     lib.lo_minres_workspace_bytes.argtypes = [P(OpDesc), P(PrecondDesc), P(MinresParams)]
     lib.lo_minres_f32.restype = C.c_int
@@ -245,8 +264,9 @@ def check(rc: int, what: str):
         raise HipExtensionError(f"liblo_amd {what} failed: {_ERR.get(rc, rc)}")
 
 
-def require_hip(*tensors: Optional[torch.Tensor]):
-    """Every tensor must be a HIP fp32 tensor; anything else is an error (no CPU path exists)."""
+def require_hip(*tensors: Optional[torch.Tensor], dtype=torch.float32):
+    """Every tensor must be a HIP tensor of `dtype` (fp32 everywhere but the fp64 linear_cg entry); anything else is an
+    error (no CPU path exists)."""
     for t in tensors:
         if t is None:
             continue
@@ -255,8 +275,10 @@ def require_hip(*tensors: Optional[torch.Tensor]):
                 "linear_operator_amd's iterative solvers run only on MI355X device tensors (got a CPU tensor); "
                 "there is no CPU fallback -- move the operator / right-hand side to 'cuda'."
             )
-        if t.dtype != torch.float32:
-            raise HipExtensionError(f"liblo_amd kernels are fp32; got {t.dtype}")
+        if t.dtype != dtype:
+            raise HipExtensionError(
+                f"liblo_amd kernels are fp32 (linear_cg on dense tensors / closures also fp64); got {t.dtype} where "
+                f"{dtype} was expected")
 
 
 def ptr(t: Optional[torch.Tensor]):

@@ -358,6 +358,70 @@ def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optio
                     bool(info.nan_detected), bool(info.skipped), float(info.mean_residual))
 
 
+def cg_solve_f64(A: Optional[torch.Tensor], diag: Optional[torch.Tensor], rhs: torch.Tensor, *,
+                 x0: Optional[torch.Tensor] = None, matvec_closure: Optional[Callable] = None,
+                 precond_closure: Optional[Callable] = None, n_tridiag: int = 0, max_iter: int = 1000,
+                 max_tridiag_iter: int = 20, tolerance: float = 1.0, eps: float = 1e-10,
+                 stop_updating_after: float = 1e-10, floor_max_iter: int = 0) -> CGResult:
+    """lo_cg_solve_f64: the reference's linear_cg (utils/linear_cg.py:98-359) with float64 operands -- what every case
+    of the reference's test/utils/test_linear_cg.py runs.  `A` [*batch, N, N] (+ `diag` [*batch, N]) is multiplied by
+    the library's fp64 kernel; otherwise `matvec_closure` is called back once per product.  `precond_closure`: any
+    callable or None."""
+    lib = _hip.load()
+    _hip.require_hip(rhs, x0, A, diag, dtype=torch.float64)
+    N, c = rhs.shape[-2:]
+    rhs3 = _flat(rhs, 2)
+    B = rhs3.shape[0]
+    dev = rhs.device
+    bshape = tuple(rhs.shape[:-2])
+    x03 = None if x0 is None else _flat(x0.expand_as(rhs), 2)
+    A3 = d2 = None
+    if A is not None:
+        A3 = A.expand(*bshape, N, N).reshape(B, N, N).contiguous()
+        d2 = None if diag is None else diag.expand(*bshape, N).reshape(B, N).contiguous()
+    elif matvec_closure is None:
+        raise ValueError("need a dense fp64 operator or a matvec closure")
+
+    def wrap(fn):
+        err = []
+
+        def cb(user, v_ptr, y_ptr, B_, N_, c_, stream):
+            try:
+                v = _hip.as_tensor(v_ptr, (B_, N_, c_), dev, "<f8")
+                y = _hip.as_tensor(y_ptr, (B_, N_, c_), dev, "<f8")
+                y.copy_(fn(v.reshape(*bshape, N_, c_)).reshape(B_, N_, c_))
+                return 0
+            except BaseException as e:  # noqa: BLE001 -- must not unwind through C
+                err.append(e)
+                return 1
+
+        return _hip.MATVEC_CB(cb), err
+
+    mv_cb, mv_err = wrap(matvec_closure) if A3 is None else (_hip.MATVEC_CB(), [])
+    pc_cb, pc_err = wrap(precond_closure) if precond_closure is not None else (_hip.MATVEC_CB(), [])
+    prm = _hip.CgParamsF64()
+    prm.c, prm.n_tridiag, prm.max_iter, prm.max_tridiag_iter = c, n_tridiag, max_iter, max_tridiag_iter
+    prm.floor_max_iter = floor_max_iter
+    prm.tolerance, prm.eps, prm.stop_updating_after = tolerance, eps, stop_updating_after
+    ws = _hip.workspace(lib.lo_cg_f64_workspace_bytes(B, N, C.byref(prm)), dev)
+    x = torch.empty_like(rhs3)
+    t_mat = None
+    if n_tridiag:
+        t_mat = torch.empty(n_tridiag, B, max_tridiag_iter, max_tridiag_iter, dtype=torch.float64, device=dev)
+    info = _hip.CgInfoF64()
+    rc = lib.lo_cg_solve_f64(_hip.ptr(A3), _hip.ptr(d2), mv_cb, None, pc_cb, None, C.byref(prm), B, N, _hip.ptr(rhs3),
+                             _hip.ptr(x03), _hip.ptr(x), _hip.ptr(t_mat), _hip.ptr(ws), ws.numel(), C.byref(info),
+                             _hip.stream_ptr(dev))
+    for e in (mv_err + pc_err):
+        raise e
+    _hip.check(rc, "lo_cg_solve_f64")
+    if t_mat is not None:
+        m = info.last_tridiag_iter + 1
+        t_mat = t_mat[:, :, :m, :m].contiguous()
+    return CGResult(x.reshape(rhs.shape), t_mat, info.iterations, info.matvecs, bool(info.tolerance_reached),
+                    bool(info.nan_detected), bool(info.skipped), float(info.mean_residual))
+
+
 def precond_apply(pre: WoodburyPreconditioner, r: torch.Tensor) -> torch.Tensor:
     lib = _hip.load()
     _hip.require_hip(r)
@@ -626,8 +690,14 @@ def _uv(left_vecs: torch.Tensor, right_vecs: torch.Tensor, batch_shape):
     N, D = left_vecs.shape[-2:]
     U = left_vecs.expand(*bs, N, D).contiguous().reshape(-1, N, D)
     V = right_vecs.expand(*bs, N, D).contiguous().reshape(-1, N, D)
-    _hip.require_hip(U, V)
+    _hip.require_hip(U, V, dtype=U.dtype if U.dtype == torch.float64 else torch.float32)
     return U, V, bs
+
+
+def _is_f64(*ts):
+    """fp64 operands of the backward contractions (the pull-backs of an fp64 linear_cg solve): plain library GEMMs /
+    reductions on the device -- the hand-written contraction kernels are fp32."""
+    return all(t.is_cuda and t.dtype == torch.float64 for t in ts)
 
 
 def bilinear_dense(left_vecs: torch.Tensor, right_vecs: torch.Tensor, batch_shape=()):
@@ -635,6 +705,8 @@ def bilinear_dense(left_vecs: torch.Tensor, right_vecs: torch.Tensor, batch_shap
     lib = _hip.load()
     U, V, bs = _uv(left_vecs, right_vecs, batch_shape)
     B, N, D = U.shape
+    if _is_f64(U, V):
+        return torch.matmul(U, V.mT).reshape(*bs, N, N)
     out = torch.empty(B, N, N, dtype=torch.float32, device=U.device)
     _hip.check(lib.lo_bilinear_dense_f32(_hip.ptr(U), _hip.ptr(V), B, N, D, _hip.ptr(out), _hip.stream_ptr(U.device)),
                "lo_bilinear_dense_f32")
@@ -648,6 +720,9 @@ def bilinear_diag(left_vecs: torch.Tensor, right_vecs: torch.Tensor, batch_shape
     U, V, bs = _uv(left_vecs, right_vecs, batch_shape)
     B, N, D = U.shape
     dev = U.device
+    if _is_f64(U, V):
+        rd = (U * V).sum(-1)
+        return rd.sum(-1).reshape(*bs, 1) if constant else rd.reshape(*bs, N)
     out = torch.empty(B if constant else B * N, dtype=torch.float32, device=dev)
     ws = _hip.workspace(4 * B * N + 256, dev) if constant else None
     _hip.check(lib.lo_bilinear_diag_f32(_hip.ptr(U), _hip.ptr(V), B, N, D, 1 if constant else 0, _hip.ptr(out),
@@ -664,6 +739,11 @@ def bilinear_root(root: torch.Tensor, left_vecs: torch.Tensor, right_vecs: torch
     B, N, D = U.shape
     R = root.shape[-1]
     Cm = root.expand(*bs, N, R).contiguous().reshape(B, N, R)
+    if _is_f64(U, V, Cm):
+        out = U @ (V.mT @ Cm) + V @ (U.mT @ Cm)
+        if with_rowdot:
+            return out.reshape(*bs, N, R), (U * V).sum(-1).reshape(*bs, N)
+        return out.reshape(*bs, N, R)
     _hip.require_hip(Cm)
     dev = U.device
     # the kernel keeps a D x R tile on chip (D R <= 2048): wider problems go in column chunks, the derivative is a sum

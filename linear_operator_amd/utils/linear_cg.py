@@ -11,7 +11,8 @@ How the closure is executed:
     iteration, vector updates / inner products / stopping rule stay in the kernels);
   * `preconditioner`: the Woodbury closure AddedDiagLinearOperator._preconditioner returns is recognised and
     applied natively; any other callable is called back.
-There is no CPU implementation: tensors must be fp32 HIP tensors.
+There is no CPU implementation: tensors must be HIP tensors, fp32 (every engine) or fp64 (csrc/lo_cg_f64.hip: dense
+tensors and closures, what the reference's own test/utils/test_linear_cg.py runs).
 """
 from __future__ import annotations
 
@@ -109,24 +110,39 @@ def linear_cg(
             f"Running CG on a {rhs.shape} RHS for {n_iter} iterations (tol={tolerance}). Output: {rhs.shape}."
         )
 
-    desc = _lower_matmul_closure(matmul_closure, batch_shape)
-    closure = None
-    if desc is None:
-        closure = matmul_closure.matmul if torch.is_tensor(matmul_closure) else matmul_closure
-    woodbury, precond_closure = None, None
-    if preconditioner is not None:
-        woodbury = getattr(preconditioner, "woodbury", None)
-        if woodbury is not None and tuple(woodbury.Q.shape[:-2]) != (max(1, batch_shape.numel()),):
-            woodbury = None
-        if woodbury is None:
-            precond_closure = preconditioner
+    if rhs.dtype == torch.float64:
+        # the reference's fp64 recipes (test/utils/test_linear_cg.py): a dense tensor is multiplied by the library's
+        # fp64 kernel, any other closure (and any preconditioner) is called back; no Woodbury / resident engines
+        if _active_stop_reduce() is not None:
+            raise NotImplementedError("the batch-global stopping rule over ranks is fp32 only")
+        dense = matmul_closure if torch.is_tensor(matmul_closure) and matmul_closure.dim() >= 2 else None
+        res = K.cg_solve_f64(
+            dense, None, rhs, x0=initial_guess,
+            matvec_closure=None if dense is not None else (
+                matmul_closure.matmul if torch.is_tensor(matmul_closure) else matmul_closure),
+            precond_closure=preconditioner, n_tridiag=n_tridiag, max_iter=n_iter, max_tridiag_iter=n_tridiag_iter,
+            tolerance=float(tolerance), eps=float(eps), stop_updating_after=float(stop_updating_after),
+            floor_max_iter=max_iter,
+        )
+    else:
+        desc = _lower_matmul_closure(matmul_closure, batch_shape)
+        closure = None
+        if desc is None:
+            closure = matmul_closure.matmul if torch.is_tensor(matmul_closure) else matmul_closure
+        woodbury, precond_closure = None, None
+        if preconditioner is not None:
+            woodbury = getattr(preconditioner, "woodbury", None)
+            if woodbury is not None and tuple(woodbury.Q.shape[:-2]) != (max(1, batch_shape.numel()),):
+                woodbury = None
+            if woodbury is None:
+                precond_closure = preconditioner
 
-    res = K.cg_solve(
-        desc, rhs, x0=initial_guess, precond=woodbury, matvec_closure=closure, precond_closure=precond_closure,
-        n_tridiag=n_tridiag, max_iter=n_iter, max_tridiag_iter=n_tridiag_iter, tolerance=float(tolerance),
-        eps=float(eps), stop_updating_after=float(stop_updating_after), floor_max_iter=max_iter,
-        stop_reduce=_active_stop_reduce(),
-    )
+        res = K.cg_solve(
+            desc, rhs, x0=initial_guess, precond=woodbury, matvec_closure=closure, precond_closure=precond_closure,
+            n_tridiag=n_tridiag, max_iter=n_iter, max_tridiag_iter=n_tridiag_iter, tolerance=float(tolerance),
+            eps=float(eps), stop_updating_after=float(stop_updating_after), floor_max_iter=max_iter,
+            stop_reduce=_active_stop_reduce(),
+        )
     if res.nan_detected:  # :199-200
         raise RuntimeError("NaNs encountered when trying to perform matrix-vector multiplication")
     if not res.tolerance_reached and res.iterations > 0:  # :337-347

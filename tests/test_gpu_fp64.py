@@ -1,0 +1,170 @@
+"""fp64 linear_cg (csrc/lo_cg_f64.hip) on the recipes of the reference's own test/utils/test_linear_cg.py:27-160 --
+float64 operands, N = 100 / 10, vector / matrix / batched right-hand sides, initial guesses, CG-coefficient
+tridiagonals -- against the golden vectors the REAL reference produced for exactly these inputs
+(tests/golden/make_golden.py g1_linear_cg) and against the oracle.  Tolerances: 1e-9 relative on solutions, 1e-7 on the
+tridiagonals (the reference's own acceptance is atol 1e-3 / rtol 1e-4)."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from conftest import load_golden, rel_err
+from oracle import lo_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+from linear_operator_amd.utils import linear_cg  # noqa: E402
+from linear_operator_amd.utils.warnings import NumericalWarning  # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+class Counting:
+    def __init__(self, fn):
+        self.fn, self.calls = fn, 0
+
+    def __call__(self, v):
+        self.calls += 1
+        return self.fn(v)
+
+
+def run(closure, rhs, **kw):
+    with warnings.catch_warnings(record=True) as ws:
+        warnings.simplefilter("always")
+        out = linear_cg(closure, rhs, **kw)
+    return out, any(issubclass(w.category, NumericalWarning) for w in ws)
+
+
+def test_fp64_n100_vector_matrix_and_initial_guess_match_the_reference():
+    g = load_golden("g1_cg_fp64_n100")
+    M = cases.spd_test_matrix(101, 100)
+    b_vec, b_mat = cases.randn(102, 100), cases.randn(103, 100, 50)
+    x0_vec, x0_mat = cases.randn(104, 100), cases.randn(105, 100, 50)
+    Md = dev(M)
+    runs = [(b_vec, None, "x_vec"), (b_vec, x0_vec, "x_vec_init"), (b_mat, None, "x_mat"), (b_mat, x0_mat, "x_mat_init")]
+    for i, (b, x0, key) in enumerate(runs):
+        kw = dict(max_iter=100)
+        if x0 is not None:
+            kw["initial_guess"] = dev(x0)
+        x, warned = run(Md, dev(b), **kw)                      # dense tensor: the library's fp64 matvec
+        assert x.dtype == torch.float64 and x.shape == g[key].shape
+        assert rel_err(host(x), g[key]) < 1e-9, key
+        assert warned == bool(g["warned"][i])
+        cnt = Counting(Md.matmul)                              # closure: one callback per product, as the reference
+        xc, _ = run(cnt, dev(b), **kw)
+        assert cnt.calls == int(g["matvecs"][i]), key
+        assert rel_err(host(xc), g[key]) < 1e-9, key
+    # the reference test's own acceptance (test_linear_cg.py:47)
+    x, _ = run(Md, dev(b_mat), max_iter=100)
+    assert np.allclose(host(x), np.linalg.solve(M, b_mat), atol=1e-3, rtol=1e-4)
+
+
+def test_fp64_tridiagonals_match_the_reference():
+    g = load_golden("g1_cg_fp64_n10_tridiag")
+    M = cases.spd_test_matrix(111, 10)
+    b = cases.randn(112, 10, 50)
+    cnt = Counting(dev(M).matmul)
+    (x, t), warned = run(cnt, dev(b), n_tridiag=5, max_tridiag_iter=10, max_iter=10, tolerance=0, eps=1e-15)
+    assert cnt.calls == int(g["matvecs"]) and warned == bool(g["warned"])
+    assert t.shape == g["t_mat"].shape and t.dtype == torch.float64
+    assert rel_err(host(x), g["x"]) < 1e-9 and rel_err(host(t), g["t_mat"]) < 1e-7
+    eigs = np.linalg.eigvalsh(M)  # test_linear_cg.py:92-95
+    for i in range(5):
+        assert np.allclose(eigs, np.linalg.eigvalsh(host(t)[i]), atol=1e-3, rtol=1e-4)
+    (x2, t2), _ = run(dev(M), dev(b), n_tridiag=5, max_tridiag_iter=10, max_iter=10, tolerance=0, eps=1e-15)
+    assert rel_err(host(x2), g["x"]) < 1e-9 and rel_err(host(t2), g["t_mat"]) < 1e-7
+
+
+def test_fp64_batched_and_batched_tridiagonals_match_the_reference():
+    g = load_golden("g1_cg_fp64_batch")
+    M = cases.spd_test_matrix(121, 100, batch=(5,))
+    b = cases.randn(122, 5, 100, 50)
+    cnt = Counting(dev(M).matmul)
+    x, _ = run(cnt, dev(b), max_iter=100)
+    assert cnt.calls == int(g["matvecs"]) and rel_err(host(x), g["x"]) < 1e-9
+    x, _ = run(dev(M), dev(b), max_iter=100)
+    assert rel_err(host(x), g["x"]) < 1e-9
+    g = load_golden("g1_cg_fp64_batch_tridiag")
+    M = cases.spd_test_matrix(131, 10, batch=(5,))
+    b = cases.randn(132, 5, 10, 10)
+    for closure in (dev(M), dev(M).matmul):
+        (x, t), _ = run(closure, dev(b), n_tridiag=8, max_iter=10, max_tridiag_iter=10, tolerance=0, eps=1e-30)
+        assert t.shape == g["t_mat"].shape
+        assert rel_err(host(x), g["x"]) < 1e-9 and rel_err(host(t), g["t_mat"]) < 1e-7
+
+
+def test_fp64_preconditioner_closure_zero_column_and_skip_against_the_oracle():
+    """A Jacobi preconditioner closure, a zero right-hand-side column (masked, :178-181), the early exit when every
+    column has converged at the initial guess (:207-208), an unbatched operator against a batched right-hand side."""
+    M = cases.spd_test_matrix(141, 60)
+    b = cases.randn(142, 3, 60, 4)
+    b[1, :, 2] = 0.0
+    dinv = 1.0 / np.diag(M)
+    x_o, t_o, info = orc.linear_cg(lambda v: M @ v, b, n_tridiag=2, max_iter=60, max_tridiag_iter=12, tolerance=1e-8,
+                                   preconditioner=lambda r: r * dinv[:, None])
+    dd = dev(dinv)
+    cnt = Counting(dev(M).matmul)
+    (x, t), _ = run(cnt, dev(b), n_tridiag=2, max_iter=60, max_tridiag_iter=12, tolerance=1e-8,
+                    preconditioner=lambda r: r * dd[:, None])
+    assert cnt.calls == info.matvecs
+    assert rel_err(host(x), x_o) < 1e-9 and t.shape == t_o.shape and rel_err(host(t), t_o) < 1e-7
+    assert np.all(host(x)[1, :, 2] == 0.0)
+    # exact initial guess: no iteration at all
+    xs = np.linalg.solve(M, b)
+    cnt = Counting(dev(M).matmul)
+    x, _ = run(cnt, dev(b), initial_guess=dev(xs), max_iter=60)
+    assert cnt.calls == 1 and rel_err(host(x), xs) < 1e-12
+
+
+def test_fp64_operators_solve_and_differentiate_through_linear_cg():
+    """fp64 operators reach the fp64 engine through the operator API (`_solve` -> utils.linear_cg with the bound
+    `_matmul` as closure); the pull-backs of the solves run as library GEMMs.  Against torch autograd of the dense
+    fp64 solve; tolerance 1e-3 relative: the reference's `eps = 1e-10` masks alpha once p^T A p < 1e-10, so its CG
+    (and this one) stalls at a relative residual of ~1e-5 whatever the tolerance asks."""
+    import linear_operator_amd as lo
+    from linear_operator_amd.operators import (AddedDiagLinearOperator, DenseLinearOperator, DiagLinearOperator,
+                                               LowRankRootLinearOperator)
+
+    N = 200
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    X = torch.randn(N, N, generator=g, device="cuda", dtype=torch.float64)
+    M0 = X @ X.T / N + torch.eye(N, device="cuda", dtype=torch.float64)
+    C0 = torch.randn(N, 6, generator=g, device="cuda", dtype=torch.float64)
+    d0 = torch.rand(N, generator=g, device="cuda", dtype=torch.float64) + 0.5
+    b = torch.randn(N, 3, generator=g, device="cuda", dtype=torch.float64)
+
+    def check(build, dense, leaves0):
+        leaves = [t.clone().requires_grad_(True) for t in leaves0]
+        with lo.settings.max_cholesky_size(0), lo.settings.cg_tolerance(1e-12), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            iq = build(*leaves).inv_quad(b)
+            iq.sum().backward()
+        ref_leaves = [t.clone().requires_grad_(True) for t in leaves0]
+        ref = (b * torch.linalg.solve(dense(*ref_leaves), b)).sum()
+        ref.backward()
+        assert iq.dtype == torch.float64
+        assert abs(iq.sum().item() - ref.item()) < 1e-6 * abs(ref.item())
+        for a, r in zip(leaves, ref_leaves):
+            assert a.grad.dtype == torch.float64
+            assert (a.grad - r.grad).abs().max().item() < 1e-3 * r.grad.abs().max().item()
+
+    check(lambda m: DenseLinearOperator(m), lambda m: m, [M0])
+    check(lambda c, d: AddedDiagLinearOperator(LowRankRootLinearOperator(c), DiagLinearOperator(d)),
+          lambda c, d: c @ c.T + torch.diag(d), [C0, d0])
+
+
+def test_fp64_is_limited_to_linear_cg_and_says_so():
+    from linear_operator_amd import _hip, kernels as K
+
+    C = torch.randn(2, 300, 4, device="cuda", dtype=torch.float64)
+    with pytest.raises(_hip.HipExtensionError):
+        K.lowrank_diag_descriptor(C, None)
