@@ -388,6 +388,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
   __shared__ __attribute__((aligned(16))) float f_s[RC * FLD];
   __shared__ __attribute__((aligned(16))) float ef_s[RC * FLD];
   __shared__ float x_s[R4_ROWS], d_s[R4_ROWS], dinv_s[R4_ROWS];
+  __shared__ float4 stage_s[R4_WAVES * 64 * (RC / 4)];  // per-wave transposition window of the member load
   const int wg = blockIdx.x;
   const int xcd = wg % 8, jx = wg / 8;
   const int groups_per_xcd = (gridDim.x / 8) / GW;
@@ -419,37 +420,96 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
   const int nv = max(0, min(a.RW, a.N - row0));
   const bool pre = a.F != nullptr;
   int64_t b = grp;
+  if (a.stagger_phases > 1 && groups_per_xcd >= a.stagger_phases) {
+    // All groups do the same work per member, so without this they stay in step: every workgroup of the chip loads its
+    // 128 KB of C at the same moment (HBM-bound, 15 us) and nobody touches HBM while iterating.  Phases: the two
+    // workgroups of a CU (local groups lg and lg + groups_per_xcd / 2) half a period apart.
+    const int P = a.stagger_phases, lg = jx / GW, hp = P / 2;
+    const int phase = ((lg / (groups_per_xcd / 2)) * hp + (lg % hp)) % P;
+    const long long t0 = wall_clock64();
+    const long long wait = (long long)phase * a.stagger_ticks;
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+  }
   while (b < a.B) {
     const bool stamp = a.dbg && b == a.dbg_member && wig == 0 && t == 0;
     if (stamp) a.dbg[0] = wall_clock64();
     float Cr[R4_NR][RC];
     int tl = t;
     asm volatile("" : "+v"(tl));
+    // Every load of the member is issued before anything waits (vmcnt counts in order: one early use would serialise
+    // the rows): branch-free, the padding rows read a clamped valid row and are zeroed afterwards.
+    const bool d_any = a.d_mode != LO_DIAG_NONE, d_full = a.d_mode == LO_DIAG_FULL;
+    const bool di_full = a.dinv_mode == LO_DIAG_FULL;
+    float dq[R4_NR], diq[R4_NR];
+    // C: a wave fetches its 64 consecutive rows as 64 * RC / 4 CONSECUTIVE 16-byte chunks (lane l takes chunk 64 i + l:
+    // whole cache lines per instruction instead of 16 bytes out of 64 different lines), parks them in its own LDS
+    // window (chunk slot XOR-swizzled by the row) and reads its row back -- no barrier, the window belongs to the wave
+    constexpr int CH = RC / 4;
+    const int wv = tl >> 6, ln = tl & 63;
+#pragma unroll
+    for (int q = 0; q < R4_NR; ++q) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int g = 64 * i + ln;  // chunk of the wave's block
+        const int rw = g / CH, ck = g % CH;
+        const size_t grow_c = (size_t)b * a.N + min(row0 + R4_TPB * q + 64 * wv + rw, a.N - 1);
+        const float4 c4 = *reinterpret_cast<const float4*>(a.C + grow_c * RC + 4 * ck);
+        Cr[q][4 * i] = c4.x; Cr[q][4 * i + 1] = c4.y; Cr[q][4 * i + 2] = c4.z; Cr[q][4 * i + 3] = c4.w;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < R4_NR; ++q) {
       const int lr = tl + R4_TPB * q;
-      const size_t grow = (size_t)b * a.N + row0 + lr;
-      float dq = 0.f, diq = 0.f;
-      if (lr < nv) {
-        const float4* cp = reinterpret_cast<const float4*>(a.C + grow * RC);
-#pragma unroll
-        for (int i = 0; i < RC / 4; ++i) {
-          const float4 c4 = cp[i];
-          Cr[q][4 * i] = c4.x; Cr[q][4 * i + 1] = c4.y; Cr[q][4 * i + 2] = c4.z; Cr[q][4 * i + 3] = c4.w;
-        }
-        dq = (a.d_mode == LO_DIAG_FULL) ? a.d[grow] : (a.d_mode == LO_DIAG_CONST ? a.d[b] : 0.f);
-        diq = pre ? ((a.dinv_mode == LO_DIAG_FULL) ? a.dinv[grow] : a.dinv[b]) : 1.0f;
-      } else {
-#pragma unroll
-        for (int i = 0; i < RC; ++i) Cr[q][i] = 0.f;
-      }
-      d_s[lr] = dq;
-      dinv_s[lr] = diq;
+      const size_t grow = (size_t)b * a.N + min(row0 + lr, a.N - 1);
+      const float* dp = d_any ? (d_full ? a.d + grow : a.d + b) : a.C;
+      const float* ip = pre ? (di_full ? a.dinv + grow : a.dinv + b) : a.C;
+      dq[q] = *dp;
+      diq[q] = *ip;
     }
-    for (int e = tl; e < RC * RC; e += R4_TPB) {  // F, EF -> LDS (zero without a preconditioner)
-      const int i = e / RC, j = e % RC;
-      f_s[i * FLD + j] = pre ? a.F[((size_t)b * RC + i) * RC + j] : 0.f;
-      ef_s[i * FLD + j] = pre ? a.EF[((size_t)b * RC + i) * RC + j] : 0.f;
+    constexpr int NF = (RC * RC + R4_TPB - 1) / R4_TPB;  // F, EF -> LDS (zero without a preconditioner)
+    float fv[NF], ev[NF];
+    {
+      const float* Fp = pre ? a.F + (size_t)b * RC * RC : a.C;
+      const float* Ep = pre ? a.EF + (size_t)b * RC * RC : a.C;
+#pragma unroll
+      for (int u = 0; u < NF; ++u) {
+        const int e = min(tl + R4_TPB * u, RC * RC - 1);
+        fv[u] = Fp[e];
+        ev[u] = Ep[e];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < R4_NR; ++q) {
+      const int lr = tl + R4_TPB * q;
+      const bool valid = lr < nv;
+      float4* win = stage_s + wv * (64 * CH);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int g = 64 * i + ln;
+        const int rw = g / CH, ck = g % CH;
+        win[rw * CH + (ck ^ ((rw ^ (rw >> 3)) & (CH - 1)))] =
+            make_float4(Cr[q][4 * i], Cr[q][4 * i + 1], Cr[q][4 * i + 2], Cr[q][4 * i + 3]);
+      }
+      __builtin_amdgcn_wave_barrier();  // (LDS operations of a wave execute in order; this pins the compiler's order)
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const float4 c4 = win[ln * CH + (i ^ ((ln ^ (ln >> 3)) & (CH - 1)))];
+        Cr[q][4 * i] = c4.x; Cr[q][4 * i + 1] = c4.y; Cr[q][4 * i + 2] = c4.z; Cr[q][4 * i + 3] = c4.w;
+      }
+#pragma unroll
+      for (int i = 0; i < RC; ++i) Cr[q][i] = valid ? Cr[q][i] : 0.f;
+      __builtin_amdgcn_wave_barrier();  // the next row set reuses the window
+      d_s[lr] = (valid && d_any) ? dq[q] : 0.f;
+      dinv_s[lr] = valid ? (pre ? diq[q] : 1.0f) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int e = tl + R4_TPB * u;
+      if (e < RC * RC) {
+        const int i = e / RC, j = e % RC;
+        f_s[i * FLD + j] = pre ? fv[u] : 0.f;
+        ef_s[i * FLD + j] = pre ? ev[u] : 0.f;
+      }
     }
     __syncthreads();
     if (stamp) a.dbg[1] = wall_clock64();
@@ -464,9 +524,12 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
       int tc = t;
       asm volatile("" : "+v"(tc));
 #pragma unroll
+      for (int q = 0; q < R4_NR; ++q)  // (all four loads in flight together: clamped address, selected below)
+        r[q] = a.rhs[((size_t)b * a.N + min(row0 + tc + R4_TPB * q, a.N - 1)) * nc + col];
+#pragma unroll
       for (int q = 0; q < R4_NR; ++q) {
         const int lr = tc + R4_TPB * q;
-        r[q] = (lr < nv) ? a.rhs[((size_t)b * a.N + row0 + lr) * nc + col] : 0.f;
+        r[q] = (lr < nv) ? r[q] : 0.f;
         p[q] = 0.f;
         x_s[lr] = 0.f;
         sc[0] = fmaf(r[q], r[q], sc[0]);

@@ -465,21 +465,24 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
     float Cr[P4_NR][RC];
     float dg[P4_NR];
     int pos[P4_NR];
+    // all loads of the member first (vmcnt counts in order: a use inside the loop would serialise the four rows);
+    // branch-free: the padding rows read a clamped valid row and are zeroed below
+#pragma unroll
+    for (int q = 0; q < P4_NR; ++q) {
+      const float4* cp = reinterpret_cast<const float4*>(
+          a.C + ((size_t)b * a.N + min(row0 + tl + P4_TPB * q, a.N - 1)) * RC);
+#pragma unroll
+      for (int i = 0; i < RC / 4; ++i) {
+        const float4 c4 = cp[i];
+        Cr[q][4 * i] = c4.x; Cr[q][4 * i + 1] = c4.y; Cr[q][4 * i + 2] = c4.z; Cr[q][4 * i + 3] = c4.w;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < P4_NR; ++q) {
       const int lr = tl + P4_TPB * q;
       const bool valid = lr < nv;
-      if (valid) {
-        const float4* cp = reinterpret_cast<const float4*>(a.C + ((size_t)b * a.N + row0 + lr) * RC);
 #pragma unroll
-        for (int i = 0; i < RC / 4; ++i) {
-          const float4 c4 = cp[i];
-          Cr[q][4 * i] = c4.x; Cr[q][4 * i + 1] = c4.y; Cr[q][4 * i + 2] = c4.z; Cr[q][4 * i + 3] = c4.w;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < RC; ++i) Cr[q][i] = 0.f;
-      }
+      for (int i = 0; i < RC; ++i) Cr[q][i] = valid ? Cr[q][i] : 0.f;
       float acc = Cr[q][0] * Cr[q][0];  // (root ** 2).sum(-1), sequential in r
 #pragma unroll
       for (int r = 1; r < RC; ++r) acc = acc + Cr[q][r] * Cr[q][r];
