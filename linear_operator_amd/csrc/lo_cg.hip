@@ -716,7 +716,6 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
                        !(getenv("LO_OC_GEN1") && oc_gen1_ok);
   if (oc_ok) {
     OnchipArgs a;
-    a.stagger_phases = 0; a.stagger_ticks = 0;
     a.C = pl.Apad; a.d = op->d;
     a.d_mode = op->diag_mode;
     if (oc_nopre) {
@@ -782,12 +781,6 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       a.EF = oc_nopre ? nullptr : pre->EF;
       a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
       a.dbg = oc_dbg ? d.oc_dbg : nullptr;
-      {
-        const char* sp = getenv("LO_OC_STAGGER");
-        const char* su = getenv("LO_OC_STAGGER_US");
-        a.stagger_phases = sp ? atoi(sp) : 0;
-        a.stagger_ticks = su ? atoi(su) * 100 : 0;
-      }
       rc = onchip5_launch(pl.R4, a, oc_nwg, st);  // (d.oc_gbuf was cleared together with the control block)
       if (rc == LO_OK) serial_done = true;
       else if (rc == LO_ERR_UNSUPPORTED) rc = LO_OK;  // (does not fit: the Q-form kernels below)

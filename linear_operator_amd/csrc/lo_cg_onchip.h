@@ -39,9 +39,6 @@ struct OnchipArgs {
   int allow_l2_handoff;  // 1: use the verified same-XCD L2 hand-off when the placement check passes
   long long* dbg;  // optional timestamps (wall_clock64) of member dbg_member / its workgroup 0, or nullptr
   int dbg_member;
-  // third generation: groups start their first member in `stagger_phases` phases, `stagger_ticks` (100 MHz) apart, so
-  // that the member loads of some groups overlap the iterations of the others (0 / 1: all at once)
-  int stagger_phases, stagger_ticks;
 };
 
 int onchip_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st);

@@ -420,16 +420,6 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
   const int nv = max(0, min(a.RW, a.N - row0));
   const bool pre = a.F != nullptr;
   int64_t b = grp;
-  if (a.stagger_phases > 1 && groups_per_xcd >= a.stagger_phases) {
-    // All groups do the same work per member, so without this they stay in step: every workgroup of the chip loads its
-    // 128 KB of C at the same moment (HBM-bound, 15 us) and nobody touches HBM while iterating.  Phases: the two
-    // workgroups of a CU (local groups lg and lg + groups_per_xcd / 2) half a period apart.
-    const int P = a.stagger_phases, lg = jx / GW, hp = P / 2;
-    const int phase = ((lg / (groups_per_xcd / 2)) * hp + (lg % hp)) % P;
-    const long long t0 = wall_clock64();
-    const long long wait = (long long)phase * a.stagger_ticks;
-    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-  }
   while (b < a.B) {
     const bool stamp = a.dbg && b == a.dbg_member && wig == 0 && t == 0;
     if (stamp) a.dbg[0] = wall_clock64();

@@ -465,15 +465,21 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
     float Cr[P4_NR][RC];
     float dg[P4_NR];
     int pos[P4_NR];
-    // all loads of the member first (vmcnt counts in order: a use inside the loop would serialise the four rows);
-    // branch-free: the padding rows read a clamped valid row and are zeroed below
+    // All loads of the member are in flight before anything waits (vmcnt counts in order: a use inside the loop would
+    // serialise the four row sets).  A wave fetches its 64 consecutive rows as 64 * RC / 4 CONSECUTIVE 16-byte chunks
+    // (whole cache lines per instruction instead of 16 bytes out of 64 lines), parks them in its own window of the
+    // (not yet used) L rows, chunk slot XOR-swizzled by the row, and reads its row back; padding rows read a clamped
+    // valid row and are zeroed.
+    constexpr int CH = RC / 4;
+    const int wv = tl >> 6, ln = tl & 63;
 #pragma unroll
     for (int q = 0; q < P4_NR; ++q) {
-      const float4* cp = reinterpret_cast<const float4*>(
-          a.C + ((size_t)b * a.N + min(row0 + tl + P4_TPB * q, a.N - 1)) * RC);
 #pragma unroll
-      for (int i = 0; i < RC / 4; ++i) {
-        const float4 c4 = cp[i];
+      for (int i = 0; i < CH; ++i) {
+        const int g = 64 * i + ln;
+        const int rw = g / CH, ck = g % CH;
+        const size_t grow = (size_t)b * a.N + min(row0 + P4_TPB * q + 64 * wv + rw, a.N - 1);
+        const float4 c4 = *reinterpret_cast<const float4*>(a.C + grow * RC + 4 * ck);
         Cr[q][4 * i] = c4.x; Cr[q][4 * i + 1] = c4.y; Cr[q][4 * i + 2] = c4.z; Cr[q][4 * i + 3] = c4.w;
       }
     }
@@ -481,13 +487,33 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
     for (int q = 0; q < P4_NR; ++q) {
       const int lr = tl + P4_TPB * q;
       const bool valid = lr < nv;
+      float4* win = l_s + wv * (64 * CH);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int g = 64 * i + ln;
+        const int rw = g / CH, ck = g % CH;
+        win[rw * CH + (ck ^ ((rw ^ (rw >> 3)) & (CH - 1)))] =
+            make_float4(Cr[q][4 * i], Cr[q][4 * i + 1], Cr[q][4 * i + 2], Cr[q][4 * i + 3]);
+      }
+      __builtin_amdgcn_wave_barrier();  // (LDS operations of a wave execute in order; this pins the compiler's order)
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const float4 c4 = win[ln * CH + (i ^ ((ln ^ (ln >> 3)) & (CH - 1)))];
+        Cr[q][4 * i] = c4.x; Cr[q][4 * i + 1] = c4.y; Cr[q][4 * i + 2] = c4.z; Cr[q][4 * i + 3] = c4.w;
+      }
 #pragma unroll
       for (int i = 0; i < RC; ++i) Cr[q][i] = valid ? Cr[q][i] : 0.f;
+      __builtin_amdgcn_wave_barrier();  // the next row set reuses the window
       float acc = Cr[q][0] * Cr[q][0];  // (root ** 2).sum(-1), sequential in r
 #pragma unroll
       for (int r = 1; r < RC; ++r) acc = acc + Cr[q][r] * Cr[q][r];
       dg[q] = valid ? acc : 0.f;
       pos[q] = valid ? row0 + lr : PO_INVALID;
+    }
+    __syncthreads();  // the windows are done: the L rows can be cleared
+#pragma unroll
+    for (int q = 0; q < P4_NR; ++q) {
+      const int lr = tl + P4_TPB * q;
 #pragma unroll
       for (int i = 0; i < LQ; ++i) l_s[l_slot<LQ>(lr, i)] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
