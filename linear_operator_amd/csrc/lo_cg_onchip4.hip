@@ -380,6 +380,8 @@ struct alignas(16) R5Post {
   float alpha, beta, rn, pad;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int RC, int GW, bool MC>
 __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipArgs a) {
   constexpr int FLD = RC + 4;  // LDS row stride of F / EF (16-byte aligned rows, conflict-free float4 reads per lane)
@@ -423,7 +425,9 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
   while (b < a.B) {
     const bool stamp = a.dbg && b == a.dbg_member && wig == 0 && t == 0;
     if (stamp) a.dbg[0] = wall_clock64();
-    float Cr[R4_NR][RC];
+    // the C rows of the thread as register PAIRS: the three passes over them are v_pk_fma_f32 (two columns per
+    // instruction; the kernel is bound by vector-ALU issue)
+    f32x2 Cr[R4_NR][RC / 2];
     int tl = t;
     asm volatile("" : "+v"(tl));
     // Every load of the member is issued before anything waits (vmcnt counts in order: one early use would serialise
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
         const int rw = g / CH, ck = g % CH;
         const size_t grow_c = (size_t)b * a.N + min(row0 + R4_TPB * q + 64 * wv + rw, a.N - 1);
         const float4 c4 = *reinterpret_cast<const float4*>(a.C + grow_c * RC + 4 * ck);
-        Cr[q][4 * i] = c4.x; Cr[q][4 * i + 1] = c4.y; Cr[q][4 * i + 2] = c4.z; Cr[q][4 * i + 3] = c4.w;
+        Cr[q][2 * i] = f32x2{c4.x, c4.y}; Cr[q][2 * i + 1] = f32x2{c4.z, c4.w};
       }
     }
 #pragma unroll
@@ -478,16 +482,16 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
         const int g = 64 * i + ln;
         const int rw = g / CH, ck = g % CH;
         win[rw * CH + (ck ^ ((rw ^ (rw >> 3)) & (CH - 1)))] =
-            make_float4(Cr[q][4 * i], Cr[q][4 * i + 1], Cr[q][4 * i + 2], Cr[q][4 * i + 3]);
+            make_float4(Cr[q][2 * i].x, Cr[q][2 * i].y, Cr[q][2 * i + 1].x, Cr[q][2 * i + 1].y);
       }
       __builtin_amdgcn_wave_barrier();  // (LDS operations of a wave execute in order; this pins the compiler's order)
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
         const float4 c4 = win[ln * CH + (i ^ ((ln ^ (ln >> 3)) & (CH - 1)))];
-        Cr[q][4 * i] = c4.x; Cr[q][4 * i + 1] = c4.y; Cr[q][4 * i + 2] = c4.z; Cr[q][4 * i + 3] = c4.w;
+        Cr[q][2 * i] = f32x2{c4.x, c4.y}; Cr[q][2 * i + 1] = f32x2{c4.z, c4.w};
       }
 #pragma unroll
-      for (int i = 0; i < RC; ++i) Cr[q][i] = valid ? Cr[q][i] : 0.f;
+      for (int i = 0; i < RC / 2; ++i) Cr[q][i] = valid ? Cr[q][i] : f32x2{0.f, 0.f};
       __builtin_amdgcn_wave_barrier();  // the next row set reuses the window
       d_s[lr] = (valid && d_any) ? dq[q] : 0.f;
       dinv_s[lr] = valid ? (pre ? diq[q] : 1.0f) : 0.f;
@@ -553,14 +557,16 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
         }
         long long cr0 = 0;
         if (g.dbg && t == 0) cr0 = wall_clock64();
-        r4_allreduce<GW, RC>(
-            sh,
-            [&](int c) {
-              float v = Cr[0][c] * rd[0];
+        f32x2 wp[RC / 2];  // column partials of w, two columns per instruction
 #pragma unroll
-              for (int q = 1; q < R4_NR; ++q) v = fmaf(Cr[q][c], rd[q], v);
-              return v;
-            },
+        for (int j = 0; j < RC / 2; ++j) {
+          f32x2 v = Cr[0][j] * f32x2{rd[0], rd[0]};
+#pragma unroll
+          for (int q = 1; q < R4_NR; ++q) v = __builtin_elementwise_fma(Cr[q][j], f32x2{rd[q], rd[q]}, v);
+          wp[j] = v;
+        }
+        r4_allreduce<GW, RC>(
+            sh, [&](int c) { return (c & 1) ? wp[c >> 1].y : wp[c >> 1].x; },
             sc, 3, g);
         if (g.dbg && t == 0) g.dbg[9] += wall_clock64() - cr0;  // partials of w + reduce-scatter + group all-reduce
         long long cp0 = 0;
@@ -643,25 +649,25 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
         const R5Post& mine = post[t >> 6];
         last_alpha = al;
         // p = beta p + (r - C v) / d  (:268, :46);  x += alpha p (:31);  r -= alpha (C t + d p) (:264)
-        float cv[R4_NR], y[R4_NR];
+        f32x2 cv2[R4_NR], y2[R4_NR];
 #pragma unroll
-        for (int q = 0; q < R4_NR; ++q) { cv[q] = 0.f; y[q] = 0.f; }
+        for (int q = 0; q < R4_NR; ++q) { cv2[q] = f32x2{0.f, 0.f}; y2[q] = f32x2{0.f, 0.f}; }
 #pragma unroll
         for (int i = 0; i < RC; i += 4) {
           const float4 v4 = *reinterpret_cast<const float4*>(&mine.v[i]);
           const float4 t4 = *reinterpret_cast<const float4*>(&mine.t[i]);
+          const f32x2 va{v4.x, v4.y}, vb{v4.z, v4.w}, ta{t4.x, t4.y}, tb{t4.z, t4.w};
 #pragma unroll
           for (int q = 0; q < R4_NR; ++q) {
-            cv[q] = fmaf(Cr[q][i], v4.x, cv[q]);
-            cv[q] = fmaf(Cr[q][i + 1], v4.y, cv[q]);
-            cv[q] = fmaf(Cr[q][i + 2], v4.z, cv[q]);
-            cv[q] = fmaf(Cr[q][i + 3], v4.w, cv[q]);
-            y[q] = fmaf(Cr[q][i], t4.x, y[q]);
-            y[q] = fmaf(Cr[q][i + 1], t4.y, y[q]);
-            y[q] = fmaf(Cr[q][i + 2], t4.z, y[q]);
-            y[q] = fmaf(Cr[q][i + 3], t4.w, y[q]);
+            cv2[q] = __builtin_elementwise_fma(Cr[q][i / 2], va, cv2[q]);
+            cv2[q] = __builtin_elementwise_fma(Cr[q][i / 2 + 1], vb, cv2[q]);
+            y2[q] = __builtin_elementwise_fma(Cr[q][i / 2], ta, y2[q]);
+            y2[q] = __builtin_elementwise_fma(Cr[q][i / 2 + 1], tb, y2[q]);
           }
         }
+        float cv[R4_NR], y[R4_NR];
+#pragma unroll
+        for (int q = 0; q < R4_NR; ++q) { cv[q] = cv2[q].x + cv2[q].y; y[q] = y2[q].x + y2[q].y; }
 #pragma unroll
         for (int q = 0; q < R4_NR; ++q) {
           const int lr = t + R4_TPB * q;
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
           if (a.z) {
             float cvq = 0.f;
 #pragma unroll
-            for (int i = 0; i < RC; ++i) cvq = fmaf(Cr[q][i], post[t >> 6].v[i], cvq);
+            for (int i = 0; i < RC; ++i) cvq = fmaf((i & 1) ? Cr[q][i >> 1].y : Cr[q][i >> 1].x, post[t >> 6].v[i], cvq);
             a.z[o] = (r[q] - cvq) * dinv_s[lr];
           }
         }
