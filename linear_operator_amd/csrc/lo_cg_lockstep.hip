@@ -288,6 +288,38 @@ __global__ __launch_bounds__(NW * 64, 2) void k_cg_lockstep(OnchipArgs a) {
     if (b != b_loaded) {
       // ---- operator rows of a new member: C -> LDS (coalesced, swizzled), d, 1/d -> LDS, Q -> registers ----
       __syncthreads();  // (previous item's readers of c_s / d_s are done)
+      // Q (registers) and d, 1/d are requested BEFORE the C rows: everything is in flight together and the first wait
+      // (vmcnt counts in order) is the one in front of the first LDS stores of C -- three round trips per member
+      // instead of eight
+      constexpr int ND = LS_ROWS / LS_TPB;
+      const bool d_any = a.d_mode != LO_DIAG_NONE, d_full = a.d_mode == LO_DIAG_FULL;
+      float dq[ND], diq[ND];
+#pragma unroll
+      for (int j = 0; j < ND; ++j) {
+        const size_t grow = (size_t)b * a.N + min(row0 + j * LS_TPB + tl, a.N - 1);
+        const float* dp = d_any ? (d_full ? a.d + grow : a.d + b) : a.C;
+        const float* ip = PRE ? ((a.dinv_mode == LO_DIAG_FULL) ? a.dinv + grow : a.dinv + b) : a.C;
+        dq[j] = *dp;
+        diq[j] = *ip;
+      }
+      if constexpr (PRE) {
+        const int RK = a.RK;  // floats per row of Q (<= 16)
+#pragma unroll
+        for (int blk = 0; blk < LS_NBLK; ++blk) {
+          const int lrb = lrow0 + blk * 16 + nl;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (lrb < nv && 4 * kl < RK) {
+            const float4 q4 = *reinterpret_cast<const float4*>(a.Q + (brow + lrb) * RK + 4 * kl);
+            v = f32x4{q4.x, q4.y, q4.z, q4.w};
+          }
+          qb[blk] = v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int lra = lrow0 + blk * 16 + 4 * kl + i;
+            qa[blk][i] = (lra < nv && nl < RK) ? a.Q[(brow + lra) * RK + nl] : 0.f;
+          }
+        }
+      }
       {
         const int SPG = a.RCg / 4;   // 16-byte slots per row in HBM (<= SPR: narrower roots are zero-padded here)
         const float4* csrc = reinterpret_cast<const float4*>(a.C + brow * a.RCg);
@@ -307,33 +339,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_cg_lockstep(OnchipArgs a) {
           }
         }
 #pragma unroll
-        for (int j = 0; j < LS_ROWS / LS_TPB; ++j) {
+        for (int j = 0; j < ND; ++j) {
           const int lr = j * LS_TPB + tl;
-          float dq = 0.f, diq = 0.f;
-          if (lr < nv) {
-            dq = (a.d_mode == LO_DIAG_FULL) ? a.d[brow + lr] : (a.d_mode == LO_DIAG_CONST ? a.d[b] : 0.f);
-            diq = PRE ? ((a.dinv_mode == LO_DIAG_FULL) ? a.dinv[brow + lr] : a.dinv[b]) : 1.0f;
-          }
-          d_s[lr] = dq;
-          dinv_s[lr] = diq;
-        }
-      }
-      if constexpr (PRE) {
-        const int RK = a.RK;  // floats per row of Q (<= 16)
-#pragma unroll
-        for (int blk = 0; blk < LS_NBLK; ++blk) {
-          const int lrb = lrow0 + blk * 16 + nl;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (lrb < nv && 4 * kl < RK) {
-            const float4 q4 = *reinterpret_cast<const float4*>(a.Q + (brow + lrb) * RK + 4 * kl);
-            v = f32x4{q4.x, q4.y, q4.z, q4.w};
-          }
-          qb[blk] = v;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int lra = lrow0 + blk * 16 + 4 * kl + i;
-            qa[blk][i] = (lra < nv && nl < RK) ? a.Q[(brow + lra) * RK + nl] : 0.f;
-          }
+          const bool valid = lr < nv;
+          d_s[lr] = (valid && d_any) ? dq[j] : 0.f;
+          dinv_s[lr] = valid ? (PRE ? diq[j] : 1.0f) : 0.f;
         }
       }
       __syncthreads();
