@@ -629,37 +629,40 @@ __global__ __launch_bounds__(kThreads) void k_lz_finish(LzDev d, int k) {
 
 // q_mat [kstore, B, N, P] (working order, :69-76) -> [P, B, N, k] (returned order, lanczos.py:154): LDS-tiled
 // transpose, reads contiguous along P (and rows), writes contiguous along (row, k).  One workgroup = 32 rows of a member.
+// Tile [k][kLzTr][P + 1] with ONE extra float per vector j: kLzTr (P + 1) is a multiple of the 64 banks for P = 16, and
+// the write-out walks j fastest.
 constexpr int kLzTr = 32;
+__host__ __device__ constexpr int lz_tile_js(int P) { return kLzTr * (P + 1) + 1; }
 
 __global__ __launch_bounds__(kThreads) void k_lz_permute(const float* __restrict__ qin, float* __restrict__ qout,
                                                           int k, int64_t B, int N, int P) {
-  extern __shared__ float tile[];  // [k][kLzTr][P + 1]
+  extern __shared__ float tile[];  // [k][kLzTr][P + 1] (+ 1 per j)
   const int64_t b = blockIdx.y;
   const int n0 = blockIdx.x * kLzTr, nr = min(kLzTr, N - n0);
-  const int ld = P + 1;
+  const int ld = P + 1, js = lz_tile_js(P);
   for (int e = threadIdx.x; e < k * nr * P; e += kThreads) {
     const int j = e / (nr * P), rem = e % (nr * P);  // rem = row * P + p: contiguous in qin
-    tile[(j * kLzTr + rem / P) * ld + rem % P] = qin[(((size_t)j * B + b) * N + n0) * P + rem];
+    tile[j * js + (rem / P) * ld + rem % P] = qin[(((size_t)j * B + b) * N + n0) * P + rem];
   }
   __syncthreads();
   for (int e = threadIdx.x; e < P * nr * k; e += kThreads) {
     const int p = e / (nr * k), rem = e % (nr * k);  // rem = row * k + j: contiguous in qout
-    qout[(((size_t)p * B + b) * N + n0) * k + rem] = tile[((rem % k) * kLzTr + rem / k) * ld + p];
+    qout[(((size_t)p * B + b) * N + n0) * k + rem] = tile[(rem % k) * js + (rem / k) * ld + p];
   }
 }
 
 // the same with 16-byte global accesses (P % 4 == 0 and k % 4 == 0: four consecutive outputs share a row)
 __global__ __launch_bounds__(kThreads) void k_lz_permute4(const float* __restrict__ qin, float* __restrict__ qout,
                                                            int k, int64_t B, int N, int P) {
-  extern __shared__ float tile[];  // [k][kLzTr][P + 1]
+  extern __shared__ float tile[];  // [k][kLzTr][P + 1] (+ 1 per j)
   const int64_t b = blockIdx.y;
   const int n0 = blockIdx.x * kLzTr, nr = min(kLzTr, N - n0);
-  const int ld = P + 1;
+  const int ld = P + 1, js = lz_tile_js(P);
   const int nin = nr * P / 4;
   for (int e = threadIdx.x; e < k * nin; e += kThreads) {
     const int j = e / nin, rem = 4 * (e % nin);  // rem = row * P + p
     const float4 v = *reinterpret_cast<const float4*>(qin + (((size_t)j * B + b) * N + n0) * P + rem);
-    float* t = tile + (j * kLzTr + rem / P) * ld + rem % P;
+    float* t = tile + j * js + (rem / P) * ld + rem % P;
     t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
   }
   __syncthreads();
@@ -667,8 +670,8 @@ __global__ __launch_bounds__(kThreads) void k_lz_permute4(const float* __restric
   for (int e = threadIdx.x; e < P * nout; e += kThreads) {
     const int p = e / nout, rem = 4 * (e % nout);  // rem = row * k + j, j % 4 == 0
     const int row = rem / k, j = rem % k;
-    const float* t = tile + (j * kLzTr + row) * ld + p;
-    const float4 v = make_float4(t[0], t[(size_t)kLzTr * ld], t[(size_t)2 * kLzTr * ld], t[(size_t)3 * kLzTr * ld]);
+    const float* t = tile + j * js + row * ld + p;
+    const float4 v = make_float4(t[0], t[js], t[2 * js], t[3 * js]);
     *reinterpret_cast<float4*>(qout + (((size_t)p * B + b) * N + n0) * k + rem) = v;
   }
 }
@@ -747,7 +750,7 @@ int lo_root_from_lanczos_f32(const float* q, const float* evecs, const float* ev
 
 int lo_lanczos_permute_f32(const float* q_in, int32_t k, int64_t B, int64_t N, int64_t P, float* q_out, void* stream) {
   if (!q_in || !q_out || k < 1 || B < 1 || N < 1 || P < 1 || B > 65535) return LO_ERR_BADARG;
-  const size_t lds = sizeof(float) * (size_t)k * kLzTr * (P + 1);
+  const size_t lds = sizeof(float) * (size_t)k * lz_tile_js((int)P);
   if (lds > 64 * 1024) return LO_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)((N + kLzTr - 1) / kLzTr), (unsigned)B);
