@@ -576,14 +576,15 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
           float mv = 0.f;  // lanes 0-31: (F w)_j, lanes 32-63: (E F w)_j
           if (pre && j < RC) {
             const float* row = (lane < 32 ? f_s : ef_s) + j * FLD;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < RC; q += 4) {
               const float4 m4 = *reinterpret_cast<const float4*>(row + q);
               const float4 w4 = *reinterpret_cast<const float4*>(&sh.res[q]);
-              a0 = fmaf(m4.x, w4.x, a0); a1 = fmaf(m4.y, w4.y, a1); a2 = fmaf(m4.z, w4.z, a2); a3 = fmaf(m4.w, w4.w, a3);
+              a01 = __builtin_elementwise_fma(f32x2{m4.x, m4.y}, f32x2{w4.x, w4.y}, a01);
+              a23 = __builtin_elementwise_fma(f32x2{m4.z, m4.w}, f32x2{w4.z, w4.w}, a23);
             }
-            mv = (a0 + a1) + (a2 + a3);
+            mv = (a01.x + a01.y) + (a23.x + a23.y);
           }
           // v_permlane32_swap of a value with itself: first result = the lower-half lane's value in both halves,
           // second = the upper-half lane's: every lane gets (v_j, (E v)_j) with one instruction
@@ -595,11 +596,13 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
           const float zj = wj - evj;                          // (C^T z)_j
           // five independent sums (their butterflies interleave); |C^T p_new|^2 from the expansion so that it does not
           // wait for beta: |zc + beta t|^2 = |zc|^2 + 2 beta zc.t + beta^2 |t|^2
-          const float wv = wave_sum_fast(own ? wj * vj : 0.f);
-          const float vev = wave_sum_fast(own ? vj * evj : 0.f);
-          const float vt = wave_sum_fast(own ? vj * t_old : 0.f);
-          const float zz = wave_sum_fast(own ? zj * zj : 0.f);
-          const float zt = wave_sum_fast(own ? zj * t_old : 0.f);
+          // (w, v, E v and C^T p_old are replicated in the two half-waves: each half sums its own 32 lanes)
+          const bool live = j < RC;
+          const float wv = lanes32_sum(live ? wj * vj : 0.f);
+          const float vev = lanes32_sum(live ? vj * evj : 0.f);
+          const float vt = lanes32_sum(live ? vj * t_old : 0.f);
+          const float zz = lanes32_sum(live ? zj * zj : 0.f);
+          const float zt = lanes32_sum(live ? zj * t_old : 0.f);
           const float rzn = pre ? s2 - wv : s1;              // residual_inner_prod :215 / :35-36
           float rnn = __builtin_amdgcn_sqrtf(s1);            // :298 / :204
           if (k >= 0) {                                      // closes iteration k: beta, residual norm, records

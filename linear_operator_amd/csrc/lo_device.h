@@ -58,6 +58,11 @@ __device__ __forceinline__ float wave_sum_fast(float v) {
   v = bfly_add<16>(v); v = bfly_add<32>(v);
   return v;
 }
+__device__ __forceinline__ float lanes32_sum(float v) {  // sum over each half-wave (lanes 0-31 / 32-63)
+  v = bfly_add<1>(v); v = bfly_add<2>(v); v = bfly_add<4>(v); v = bfly_add<8>(v);
+  v = bfly_add<16>(v);
+  return v;
+}
 __device__ __forceinline__ float lanes16_sum(float v) {
   v = bfly_add<1>(v); v = bfly_add<2>(v); v = bfly_add<4>(v); v = bfly_add<8>(v);
   return v;
