@@ -102,6 +102,7 @@ struct CgDev {
   unsigned long long* ls_gbuf;  // granules of the column-lockstep kernel (lo_cg_lockstep.hip) or nullptr
   unsigned long long* pf_gbuf;  // granules of the fused preconditioner apply (lo_precond_fused.hip) or nullptr
   int* pf_ctr;                  // one member hand-out counter per launch of that kernel (max_iter + 1 ints)
+  unsigned long long* pf_gran;  // [B] tagged residual norms of the fused control step
   int* oc_err;
   float* oc_resid;
   int* oc_init_conv;
@@ -534,7 +535,8 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   const bool pf_shape = pre && precond_fused_eligible(B, N, c, padded_rank_k(pre->k), sp.S);
   dd.pf_gbuf = pf_shape ? ar.take<unsigned long long>(precond_fused_gbuf_bytes() / sizeof(unsigned long long)) : nullptr;
   // (decided by the shape, not by the pointer: the sizing pass runs on a null arena)
-  dd.pf_ctr = pf_shape ? ar.take<int>((size_t)std::max(1, (int)prm->max_iter) + 1) : nullptr;
+  dd.pf_ctr = pf_shape ? ar.take<int>(2 * ((size_t)std::max(1, (int)prm->max_iter) + 1)) : nullptr;  // hand-out | done
+  dd.pf_gran = pf_shape ? ar.take<unsigned long long>((size_t)B) : nullptr;
   dd.oc_zero_q = nullptr;
   dd.oc_ones = nullptr;
   if (!pre && !precond && oc_shape) {
@@ -903,7 +905,8 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   bool p_done = false;  // the fused apply of the previous iteration already wrote this iteration's p
   if (pf_on) {  // granules and hand-out counters of the fused apply: cleared once per solve (tags are unique per launch)
     LO_HIP_CHECK(hipMemsetAsync(d.pf_gbuf, 0, precond_fused_gbuf_bytes(), st));
-    LO_HIP_CHECK(hipMemsetAsync(d.pf_ctr, 0, sizeof(int) * ((size_t)std::max(1, (int)prm->max_iter) + 1), st));
+    LO_HIP_CHECK(hipMemsetAsync(d.pf_ctr, 0, sizeof(int) * 2 * ((size_t)std::max(1, (int)prm->max_iter) + 1), st));
+    LO_HIP_CHECK(hipMemsetAsync(d.pf_gran, 0, sizeof(unsigned long long) * (size_t)B, st));
   }
   // One iteration's launches on stream `ls`.  dyn: the kernels that need the iteration index read it from the control
   // block (the same launch sequence is then valid for every later iteration: it is captured once and replayed as a
@@ -925,15 +928,27 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       if (rcb) return rcb;
     }
     bool pre_done = false;
+    bool ctrl_done = false;  // the fused apply also took the iteration's control step
     if (pre && pf_on) {
+      PfCtrl cf;
+      cf.on = (d.n_tridiag == 0 && kk > 0 && !getenv("LO_NO_FUSED_CTRL")) ? 1 : 0;
+      cf.rhs_is_zero = d.rhs_is_zero; cf.rz = d.rz; cf.beta = d.beta; cf.resid_norm = d.resid_norm;
+      cf.has_conv = d.has_conv; cf.stop_after = d.stop_after; cf.tol = d.tol;
+      cf.kfloor = std::min(10, d.max_iter - 1);
+      cf.done = d.pf_ctr + (std::max(1, (int)prm->max_iter) + 1);
+      cf.ctrl = d.ctrl;
+      cf.gran = d.pf_gran;
       // single pass over Q: r / x update, Q^T r, group all-reduce, z = r/d - Q u, p = z + beta p (lo_precond_fused.hip)
       rcb = precond_fused_rupdate(Qp, pre->dinv, pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL, d.r, d.Ap, d.p, d.x,
                                   d.z, d.pAp_part, d.S_dot, d.rz, d.has_conv, d.eps, d.alpha, d.rr_part, d.rz_part, sp.S,
                                   B, N, d.pf_gbuf, d.oc_err, d.pf_ctr, kk, dyn ? &d.ctrl->iterations : nullptr,
-                                  (int)prm->max_iter, stop, oc_nwg, ls);
+                                  (int)prm->max_iter, stop, oc_nwg, &cf, ls);
       if (rcb == LO_ERR_UNSUPPORTED) pf_on = false;  // (does not fit this device: the two-launch path from now on)
       else if (rcb) return rcb;
-      else pre_done = p_done = true;
+      else {
+        pre_done = p_done = true;
+        ctrl_done = cf.on != 0;
+      }
     }
     if (!pre_done) p_done = false;  // (the two-launch path below leaves the p update to the next iteration's first step)
     if (pre_done) {
@@ -956,6 +971,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
         if (rcb) return rcb;
       }
     }
+    if (ctrl_done) return LO_OK;
     const int karg = dyn ? -1 : kk;
     LO_PROF_BEGIN("cg_ctrl", ls);
     if (ctrl_G == 1) {

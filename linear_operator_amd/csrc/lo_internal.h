@@ -227,12 +227,26 @@ extern bool g_onchip_disabled;  // lo_cg_set_onchip(0): streaming engines only (
 // ---- single-pass Woodbury apply fused with the CG r / x update (lo_precond_fused.hip) --------------
 bool precond_fused_eligible(int64_t B, int64_t N, int64_t c, int ldq, int S);
 size_t precond_fused_gbuf_bytes();
+// the iteration's control step folded into the fused apply (single column, no tridiagonal, k >= 1)
+struct PfCtrl {
+  int on;
+  const int* rhs_is_zero;  // [B]
+  float* rz;               // [B] residual_inner_prod out
+  float* beta;             // [B]
+  float* resid_norm;       // [B]
+  int* has_conv;           // [B]
+  float stop_after, tol;
+  int kfloor;              // min(10, max_iter - 1)
+  int* done;               // base of one zeroed counter per launch of the solve
+  unsigned long long* gran; // [B] tagged residual norms of the current launch (zeroed once per solve)
+  CgCtrl* ctrl;
+};
 // (also writes the next iteration's p = z + beta p; z itself is not stored)
 int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, float* r, const float* Ap, float* p,
                           float* x, float* z, const float* pAp_part, int S_dot, const float* rz, const int* has_conv,
                           float eps, float* alpha_out, float* rr_part, float* rz_part, int S, int64_t B, int64_t N,
                           unsigned long long* gbuf, int* err, int* next_member, int launch, const int* iter_ptr,
-                          int max_launch, const int* stop, int ncu, hipStream_t st);
+                          int max_launch, const int* stop, int ncu, const PfCtrl* cf, hipStream_t st);
 
 // ---- operator-resident pivoted Cholesky (lo_pivchol_onchip.hip) ----------------------------------
 bool pc_onchip_eligible(const lo_op_desc* op, int max_rank);

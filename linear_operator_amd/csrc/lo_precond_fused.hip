@@ -51,6 +51,10 @@ struct PfArgs {
   int allow_l2_handoff;
   unsigned tag_base;  // tags of this launch start above it: the granules of earlier launches of the solve never match
   const int* iter_ptr;  // replayed as a graph node: the launch index is read from the control block (else nullptr)
+  // the control step of the iteration (k_cg_scal + k_cg_ctrl of lo_cg.hip) folded into this launch: the group that
+  // finishes a member records its scalars, the group that finishes the LAST member takes the batch-global decision
+  PfCtrl cf;
+  int launch;  // iteration index k of this launch (iter_ptr: read on the device)
 };
 
 // (pf_publish / pf_collect: the lane-parallel reduce-scatter all-reduce for groups of up to 64 workgroups, lo_group_reduce.h)
@@ -85,6 +89,8 @@ __global__ __launch_bounds__(R4_TPB, OCC) void k_precond_fused(PfArgs a) {
     const int launch = *a.iter_ptr;
     a.tag_base = (unsigned)launch * (unsigned)(a.B + 2);
     a.next_member += launch;
+    a.launch = launch;
+    if (a.cf.on) a.cf.done += launch;
   }
   g.tag = a.tag_base;
   g.err = a.err;
@@ -206,6 +212,25 @@ __global__ __launch_bounds__(R4_TPB, OCC) void k_precond_fused(PfArgs a) {
     const float rzo = rzo_s;
     const float beta = (rzo < a.eps) ? 0.f : srz / rzo;  // the control step's rule (:39-42) on the same numbers
     const int64_t bnext = (int64_t)sh.res[18];
+    int cf_old = -1;
+    if (a.cf.on && wig == 0 && t == 0) {
+      // control step of this member (cg_scal_body of lo_cg.hip for one column, no tridiagonal): beta (:39-42), residual
+      // norm (:298-299), has_converged (:300).  rz / has_conv of the member were read by every workgroup of the group
+      // before the exchange above completed.  Issued HERE, before the p stores: the fence only waits for the r / x
+      // stores (sent before the exchange), and the counter's answer is not needed until the p stores are out.
+      float rn = sqrtf(srr);
+      if (a.cf.rhs_is_zero[b]) rn = 0.f;
+      a.cf.rz[b] = srz;
+      a.cf.beta[b] = beta;
+      a.cf.resid_norm[b] = rn;
+      a.cf.has_conv[b] = rn < a.cf.stop_after;
+      // No fence (a device-scope release writes the XCD's L2 back: +13 us per launch): the norm travels to the group
+      // that closes the launch inside a tagged 8-byte granule, like the hand-offs; the plain stores above are for the
+      // NEXT launch.
+      __hip_atomic_store(a.cf.gran + b, ((unsigned long long)(unsigned)(a.launch + 1) << 32) | __float_as_uint(rn),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cf_old = atomicAdd(a.cf.done, 1);
+    }
     float zv[NV];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -227,6 +252,32 @@ __global__ __launch_bounds__(R4_TPB, OCC) void k_precond_fused(PfArgs a) {
     if (wig == 0 && t < a.S) {  // the control step sums S partials per member: the totals go to slot 0
       a.rr_part[(size_t)b * a.S + t] = (t == 0) ? srr : 0.f;
       a.rz_part[(size_t)b * a.S + t] = (t == 0) ? srz : 0.f;
+    }
+    if (a.cf.on && wig == 0 && t < 64) {
+      const int last = __builtin_amdgcn_readfirstlane((cf_old == (int)a.B - 1) ? 1 : 0);
+      if (last) {  // every member of the batch is recorded: the batch-global decisions (cg_ctrl_body), fixed order
+        float ls = 0.f;
+        const unsigned want = (unsigned)(a.launch + 1);
+        for (int64_t i = t; i < a.B; i += 64) {
+          unsigned long long gq;
+          unsigned spin = 0;
+          do {  // (the counter said every member was issued; its granule may still be on its way)
+            gq = __hip_atomic_load(a.cf.gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((unsigned)(gq >> 32) != want && ++spin < R4_MAXSPIN);
+          if ((unsigned)(gq >> 32) != want) atomicExch(a.err, 1);
+          ls += __uint_as_float((unsigned)(gq & 0xffffffffull));
+        }
+        const float mean = wave_sum_fast(ls) / (float)a.B;
+        if (t == 0) {
+          const int k = a.launch;
+          a.cf.ctrl->iterations = k + 1;
+          a.cf.ctrl->mean_resid = mean;
+          if (k >= a.cf.kfloor && mean < a.cf.tol) {  // :302-306 (no tridiagonal columns on this path)
+            a.cf.ctrl->tol_reached = 1;
+            a.cf.ctrl->stop = 1;
+          }
+        }
+      }
     }
     __syncthreads();  // (sh.res / alpha_s / rzo_s are reused by the next member)
     b = bnext;
@@ -267,8 +318,15 @@ int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, floa
                           float* x, float* z, const float* pAp_part, int S_dot, const float* rz, const int* has_conv,
                           float eps, float* alpha_out, float* rr_part, float* rz_part, int S, int64_t B, int64_t N,
                           unsigned long long* gbuf, int* err, int* next_member, int launch, const int* iter_ptr,
-                          int max_launch, const int* stop, int ncu, hipStream_t st) {
+                          int max_launch, const int* stop, int ncu, const PfCtrl* cf, hipStream_t st) {
   PfArgs a;
+  a.launch = launch;
+  if (cf) {
+    a.cf = *cf;
+    if (a.cf.on && !iter_ptr) a.cf.done += launch;
+  } else {
+    a.cf.on = 0;
+  }
   a.Q = Q; a.dinv = dinv; a.dinv_mode = dinv_mode; a.r = r; a.Ap = Ap; a.p = p; a.x = x; a.z = z;
   a.pAp_part = pAp_part; a.S_dot = S_dot; a.rz = rz; a.has_conv = has_conv; a.eps = eps; a.alpha_out = alpha_out;
   a.rr_part = rr_part; a.rz_part = rz_part; a.S = S; a.B = B; a.N = (int)N;

@@ -739,6 +739,15 @@ def test_fused_preconditioner_apply_matches_two_pass_path(kind, N, monkeypatch):
     assert max_rel_err_cols(host(res.x), host(ref.x)) < 1e-4
     res2 = K.cg_solve(desc, dev(rhs), **kw)
     assert torch.equal(res.x, res2.x) and res2.iterations == res.iterations
+    # the iteration's control step (beta, residual norms, has_converged, the batch-global stop rule) rides in the same
+    # launch from the second iteration on: no control kernel in the profile but the first one, and exactly the
+    # iterations, flags and solution of the separate control kernels
+    assert prof.get("cg_ctrl", (0, 0))[0] <= 1, prof.get("cg_ctrl")
+    monkeypatch.setenv("LO_NO_FUSED_CTRL", "1")
+    sep = K.cg_solve(desc, dev(rhs), **kw)
+    monkeypatch.delenv("LO_NO_FUSED_CTRL")
+    assert sep.iterations == res.iterations and sep.tolerance_reached == res.tolerance_reached
+    assert torch.equal(sep.x, res.x) and abs(sep.mean_residual - res.mean_residual) <= 1e-6 * abs(sep.mean_residual)
 
 
 def test_onchip_cg_many_columns_hand_over():
