@@ -558,16 +558,13 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
         if (pos[q] != PO_INVALID && pos[q] >= m && pos[q] == gj) {
           sh.part[0] = __float_as_uint(gv);
           sh.part[1] = (unsigned)gj;
+          // (one thread writes the whole payload: 16-byte LDS stores -- PO_HDR and RC are multiples of 4)
+          float4* dst = reinterpret_cast<float4*>(&sh.part[PO_HDR]);
 #pragma unroll
-          for (int r = 0; r < RC; ++r) sh.part[PO_HDR + r] = __float_as_uint(Cr[q][r]);
+          for (int r = 0; r < RC / 4; ++r)
+            dst[r] = make_float4(Cr[q][4 * r], Cr[q][4 * r + 1], Cr[q][4 * r + 2], Cr[q][4 * r + 3]);
           const int lr = t + P4_TPB * q;
-          for (int j4 = 0; 4 * j4 < m; ++j4) {
-            const float4 l4 = l_s[l_slot<LQ>(lr, j4)];
-            sh.part[PO_HDR + RC + 4 * j4] = __float_as_uint(l4.x);
-            sh.part[PO_HDR + RC + 4 * j4 + 1] = __float_as_uint(l4.y);
-            sh.part[PO_HDR + RC + 4 * j4 + 2] = __float_as_uint(l4.z);
-            sh.part[PO_HDR + RC + 4 * j4 + 3] = __float_as_uint(l4.w);
-          }
+          for (int j4 = 0; 4 * j4 < m; ++j4) dst[RC / 4 + j4] = l_s[l_slot<LQ>(lr, j4)];
         }
       }
       if (t == 0) {
