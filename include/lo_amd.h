@@ -331,6 +331,26 @@ int lo_cg_solve_f64(const double* A, const double* diag, lo_matvec_cb_f64 matvec
                     const double* rhs, const double* x0, double* x, double* t_mat, void* ws, size_t ws_bytes,
                     lo_cg_info_f64* info, void* stream);
 
+/* ---- shifted MINRES in fp64 (linear_operator/utils/minres.py:10-282 with float64 operands) ---------------------- */
+/* As lo_cg_solve_f64: the reference's own test/utils/test_minres.py:17-80 builds float64 operands.  Same recurrences
+ * and stop test as lo_minres_f32 (every 10th iteration: mean ||update|| / ||solution|| < tolerance).
+ *   A / diag / matvec / precond_cb  as lo_cg_solve_f64
+ *   rhs [B, N, c];  shifts [Q] (or [Q, B] with shifts_per_member);  x [Q, B, N, c] out (scaled back, zero columns 0) */
+typedef struct lo_minres_params_f64 {
+  int64_t c;
+  int32_t n_shifts, max_iter, has_value, shifts_per_member; /* as lo_minres_params */
+  double value, tolerance, eps;
+} lo_minres_params_f64;
+typedef struct lo_minres_info_f64 {
+  int32_t iterations, matvecs, converged, pad;
+  double conv;
+} lo_minres_info_f64;
+size_t lo_minres_f64_workspace_bytes(int64_t B, int64_t N, const lo_minres_params_f64* prm);
+int lo_minres_f64(const double* A, const double* diag, lo_matvec_cb_f64 matvec, void* matvec_user,
+                  lo_matvec_cb_f64 precond_cb, void* precond_user, const lo_minres_params_f64* prm, int64_t B, int64_t N,
+                  const double* rhs, const double* shifts, double* x, void* ws, size_t ws_bytes,
+                  lo_minres_info_f64* info, void* stream);
+
 /* ---- measurement aid (no reference counterpart) ------------------------------------------------ */
 /* Opt-in HIP-event timing of every kernel launch of the library, recorded on the launch stream.
  * lo_prof_report writes "name count total_ms" lines into buf (returns the byte count) and resets.

@@ -19,7 +19,7 @@ _lib = None
 LO_OP_LOWRANK_DIAG, LO_OP_DENSE_DIAG, LO_OP_KRON_DIAG, LO_OP_CALLBACK, LO_OP_SUM = 0, 1, 2, 3, 4
 LO_MAX_TERMS = 4
 LO_DIAG_NONE, LO_DIAG_FULL, LO_DIAG_CONST = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 LO_ERR_UNSUPPORTED = -4
 _ERR = {-1: "bad argument", -2: "HIP launch/runtime failure", -3: "workspace too small", -4: "unsupported shape"}
@@ -28,7 +28,7 @@ EXPORTS = [
     "lo_abi_version", "lo_target_arch",
     "lo_matvec_workspace_bytes", "lo_matvec_f32",
     "lo_cg_workspace_bytes", "lo_cg_solve_f32", "lo_cg_set_onchip",
-    "lo_cg_f64_workspace_bytes", "lo_cg_solve_f64",
+    "lo_cg_f64_workspace_bytes", "lo_cg_solve_f64", "lo_minres_f64_workspace_bytes", "lo_minres_f64",
     "lo_pivoted_cholesky_workspace_bytes", "lo_pivoted_cholesky_f32",
     "lo_pivoted_cholesky_cb_workspace_bytes", "lo_pivoted_cholesky_cb_f32",
     "lo_precond_build_workspace_bytes", "lo_precond_build_f32", "lo_precond_build_strided_f32",
@@ -91,6 +91,16 @@ class CgInfoF64(C.Structure):
                 ("mean_residual", C.c_double)]
 
 
+class MinresParamsF64(C.Structure):
+    _fields_ = [("c", C.c_int64), ("n_shifts", C.c_int32), ("max_iter", C.c_int32), ("has_value", C.c_int32),
+                ("shifts_per_member", C.c_int32), ("value", C.c_double), ("tolerance", C.c_double), ("eps", C.c_double)]
+
+
+class MinresInfoF64(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("matvecs", C.c_int32), ("converged", C.c_int32), ("pad", C.c_int32),
+                ("conv", C.c_double)]
+
+
 class MinresParams(C.Structure):
     _fields_ = [("c", C.c_int64), ("n_shifts", C.c_int32), ("max_iter", C.c_int32), ("has_value", C.c_int32),
                 ("shifts_per_member", C.c_int32), ("value", C.c_float), ("tolerance", C.c_float), ("eps", C.c_float),
@@ -145,6 +155,12 @@ def load():
     lib.lo_cg_solve_f64.argtypes = [C.c_void_p, C.c_void_p, MATVEC_CB, C.c_void_p, MATVEC_CB, C.c_void_p,
                                     P(CgParamsF64), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, sz, P(CgInfoF64), C.c_void_p]
+    lib.lo_minres_f64_workspace_bytes.restype = sz
+    lib.lo_minres_f64_workspace_bytes.argtypes = [C.c_int64, C.c_int64, P(MinresParamsF64)]
+    lib.lo_minres_f64.restype = C.c_int
+    lib.lo_minres_f64.argtypes = [C.c_void_p, C.c_void_p, MATVEC_CB, C.c_void_p, MATVEC_CB, C.c_void_p,
+                                  P(MinresParamsF64), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, sz, P(MinresInfoF64), C.c_void_p]
     lib.lo_minres_workspace_bytes.restype = sz
     lib.lo_minres_workspace_bytes.argtypes = [P(OpDesc), P(PrecondDesc), P(MinresParams)]
     lib.lo_minres_f32.restype = C.c_int

@@ -291,6 +291,27 @@ __global__ __launch_bounds__(kThreads) void k64_final(const double* __restrict__
   out[e] = x[e] * rn[b * c + j];
 }
 
+// shared with lo_minres_f64.hip
+int f64_dots(const double* a, const double* b1, double* out1, const double* a2, const double* b2, double* out2,
+             int64_t B, int64_t N, int64_t c, hipStream_t st) {
+  hipLaunchKernelGGL(k64_dots, dim3((unsigned)c, (unsigned)B), dim3(kThreads), 0, st, a, b1, out1, a2, b2, out2, (int)N,
+                     (int)c);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+int f64_dense_mv(const double* A, const double* d, const double* v, double* y, int64_t B, int64_t N, int64_t c,
+                 hipStream_t st) {
+  hipLaunchKernelGGL(k64_dense_mv, dim3((unsigned)((N + 3) / 4), (unsigned)B), dim3(kThreads), 0, st, A, d, v, y, (int)N,
+                     (int)c);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+int f64_copy(const double* a, double* o, size_t total, hipStream_t st) {
+  hipLaunchKernelGGL(k64_copy, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, a, o, total);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
 struct Lay64 {
   double *u, *r, *z, *p, *Ap, *x;
   double *nsq, *rn, *rr, *pAp, *rz_a, *rz_b, *alpha, *beta, *prev_arec, *prev_beta;

@@ -224,6 +224,14 @@ struct ResidentLaunch {
 extern thread_local bool tls_graph_capture;  // a CG iteration is being captured: no cross-stream event traffic
 extern bool g_onchip_disabled;  // lo_cg_set_onchip(0): streaming engines only (tests compare the two)
 
+// ---- fp64 helpers (lo_cg_f64.hip), shared by the fp64 CG and MINRES engines ---------------------------------------
+// out1[b, j] = sum_i a[b, i, j] b1[b, i, j] (and out2 from (a2, b2) when a2 != nullptr)
+int f64_dots(const double* a, const double* b1, double* out1, const double* a2, const double* b2, double* out2,
+             int64_t B, int64_t N, int64_t c, hipStream_t st);
+int f64_dense_mv(const double* A, const double* d, const double* v, double* y, int64_t B, int64_t N, int64_t c,
+                 hipStream_t st);
+int f64_copy(const double* a, double* o, size_t total, hipStream_t st);
+
 // ---- single-pass Woodbury apply fused with the CG r / x update (lo_precond_fused.hip) --------------
 bool precond_fused_eligible(int64_t B, int64_t N, int64_t c, int ldq, int S);
 size_t precond_fused_gbuf_bytes();

@@ -267,6 +267,63 @@ def minres_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, shifts: 
                         float(info.conv))
 
 
+def minres_solve_f64(A: Optional[torch.Tensor], rhs: torch.Tensor, shifts: torch.Tensor, *,
+                     value: Optional[float] = None, matvec_closure: Optional[Callable] = None,
+                     precond_closure: Optional[Callable] = None, max_iter: int = 1000, tolerance: float = 1e-4,
+                     eps: float = 1e-25) -> MinresResult:
+    """lo_minres_f64: the reference's shifted MINRES (utils/minres.py:10-207) with float64 operands -- what the
+    reference's test/utils/test_minres.py runs.  `A` [*batch, N, N] is multiplied by the library's fp64 kernel, any
+    other operator is called back once per product; `precond_closure`: any callable or None."""
+    lib = _hip.load()
+    _hip.require_hip(rhs, A, dtype=torch.float64)
+    N, c = rhs.shape[-2:]
+    rhs3 = _flat(rhs, 2)
+    B = rhs3.shape[0]
+    dev = rhs.device
+    bshape = tuple(rhs.shape[:-2])
+    Q = shifts.shape[0]
+    per_member = shifts.dim() > 1
+    sh = shifts.to(device=dev, dtype=torch.float64)
+    sh = (sh.expand(Q, *bshape).reshape(Q, B) if per_member else sh.reshape(Q)).contiguous()
+    A3 = None
+    if A is not None:
+        A3 = A.expand(*bshape, N, N).reshape(B, N, N).contiguous()
+    elif matvec_closure is None:
+        raise ValueError("need a dense fp64 operator or a matvec closure")
+
+    def wrap(fn):
+        err = []
+
+        def cb(user, v_ptr, y_ptr, B_, N_, c_, stream):
+            try:
+                v = _hip.as_tensor(v_ptr, (B_, N_, c_), dev, "<f8")
+                y = _hip.as_tensor(y_ptr, (B_, N_, c_), dev, "<f8")
+                y.copy_(fn(v.reshape(*bshape, N_, c_)).reshape(B_, N_, c_))
+                return 0
+            except BaseException as e:  # noqa: BLE001 -- must not unwind through C
+                err.append(e)
+                return 1
+
+        return _hip.MATVEC_CB(cb), err
+
+    mv_cb, mv_err = wrap(matvec_closure) if A3 is None else (_hip.MATVEC_CB(), [])
+    pc_cb, pc_err = wrap(precond_closure) if precond_closure is not None else (_hip.MATVEC_CB(), [])
+    prm = _hip.MinresParamsF64()
+    prm.c, prm.n_shifts, prm.max_iter = c, Q, max_iter
+    prm.has_value, prm.value = (0, 1.0) if value is None else (1, float(value))
+    prm.shifts_per_member, prm.tolerance, prm.eps = int(per_member), tolerance, eps
+    ws = _hip.workspace(lib.lo_minres_f64_workspace_bytes(B, N, C.byref(prm)), dev)
+    x = torch.empty(Q, *rhs3.shape, dtype=torch.float64, device=dev)
+    info = _hip.MinresInfoF64()
+    rc = lib.lo_minres_f64(_hip.ptr(A3), None, mv_cb, None, pc_cb, None, C.byref(prm), B, N, _hip.ptr(rhs3),
+                           _hip.ptr(sh), _hip.ptr(x), _hip.ptr(ws), ws.numel(), C.byref(info), _hip.stream_ptr(dev))
+    for e in (mv_err + pc_err):
+        raise e
+    _hip.check(rc, "lo_minres_f64")
+    return MinresResult(x.reshape(Q, *rhs.shape), info.iterations, info.matvecs, bool(info.converged),
+                        float(info.conv))
+
+
 def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optional[torch.Tensor] = None,
              precond: Optional[WoodburyPreconditioner] = None, matvec_closure: Optional[Callable] = None,
              precond_closure: Optional[Callable] = None, closure_batch_shape=None, n_tridiag: int = 0,

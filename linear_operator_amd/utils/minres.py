@@ -1,8 +1,8 @@
 """minres with the reference's signature and semantics (linear_operator/utils/minres.py:10-207), executed by
 liblo_amd's shifted-MINRES engine (csrc/lo_minres.hip).  Closure handling is the one of utils/linear_cg.py: operator
 `_matmul`s that lower to a kernel descriptor run entirely on the device, other callables are called back for the
-product only; the Woodbury preconditioner closure of AddedDiagLinearOperator is applied natively.  fp32 HIP tensors
-only -- there is no CPU implementation."""
+product only; the Woodbury preconditioner closure of AddedDiagLinearOperator is applied natively.  HIP tensors only --
+there is no CPU implementation; float64 operands (the reference's own test recipes) take csrc/lo_minres_f64.hip."""
 from __future__ import annotations
 
 import torch
@@ -37,6 +37,25 @@ def minres(matmul_closure, rhs, eps=1e-25, shifts=None, value=None, max_iter=Non
     batch_shape = torch.broadcast_shapes(op_batch, rhs.shape[:-2])
     rhs_b = rhs.expand(*batch_shape, *rhs.shape[-2:]).contiguous()
 
+    sh = shifts.reshape(1) if shifts.dim() == 0 else shifts
+    if rhs.dtype == torch.float64:
+        # the reference's fp64 recipes (test/utils/test_minres.py): dense tensors on the library's fp64 kernel, any
+        # other closure / preconditioner called back (csrc/lo_minres_f64.hip)
+        dense = matmul_closure if torch.is_tensor(matmul_closure) and matmul_closure.dim() >= 2 else None
+        res = K.minres_solve_f64(
+            dense, rhs_b, sh, value=value,
+            matvec_closure=None if dense is not None else (
+                matmul_closure.matmul if torch.is_tensor(matmul_closure) else matmul_closure),
+            precond_closure=preconditioner, max_iter=max_iter, tolerance=float(settings.minres_tolerance.value()),
+            eps=float(eps),
+        )
+        solution = res.x
+        if squeeze:
+            solution = solution.squeeze(-1)
+        if shifts.numel() == 1:
+            solution = solution.squeeze(0)
+        return solution
+
     desc = _lower_matmul_closure(matmul_closure, batch_shape)
     closure = None
     if desc is None:
@@ -48,7 +67,6 @@ def minres(matmul_closure, rhs, eps=1e-25, shifts=None, value=None, max_iter=Non
             woodbury = None
         if woodbury is None:
             precond_closure = preconditioner
-    sh = shifts.reshape(1) if shifts.dim() == 0 else shifts
     if settings.verbose_linalg.on():
         settings.verbose_linalg.logger.debug(
             f"Running MINRES on a {rhs.shape} RHS for {max_iter} iterations "

@@ -864,8 +864,31 @@ def g20_kronecker_structured_diag():
     save("g20_kron_structured_diag", checksum=cases.checksum(K1, K2, rhs, W, d1, d2, c1, c2), **out)
 
 
+def g21_minres_fp64():
+    """The reference's own test/utils/test_minres.py:17-80 recipes: float64 operands, value = -1, minres_tolerance
+    1e-6, vector / matrix / batched right-hand sides, with and without the shifts [0, 1, 2], batched and unbatched
+    matrices."""
+    from linear_operator.utils.minres import minres
+
+    sh = np.array([0.0, 1.0, 2.0])
+    out = {"sh": sh}
+    inputs = []
+    runs = [("vec", (20,), (), None), ("vec_shifts", (5,), (), sh), ("mat", (20, 5), (), None),
+            ("bmat", (3, 20, 5), (), None), ("bmat_bop", (3, 20, 5), (3,), None), ("mat_bop", (20, 5), (3,), None),
+            ("mat_shifts", (20, 5), (), sh), ("bmat_bop_shifts", (3, 20, 5), (3,), sh), ("mat_bop_shifts", (20, 5), (3,), sh)]
+    for i, (tag, rshape, mbatch, shifts) in enumerate(runs):
+        size = rshape[-2] if len(rshape) > 1 else rshape[-1]
+        M = cases.spd_test_matrix(2100 + i, size, batch=mbatch)
+        b = cases.randn(2150 + i, *rshape)
+        inputs += [M, b]
+        with settings.minres_tolerance(1e-6):
+            x = minres(T(M), rhs=T(b), value=-1, shifts=None if shifts is None else T(shifts))
+        out[f"x_{tag}"] = x
+    save("g21_minres_fp64", checksum=cases.checksum(*inputs), **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g20", "g19", "g18", "g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g21", "g20", "g19", "g18", "g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
@@ -874,7 +897,7 @@ if __name__ == "__main__":
                      ("g14", g14_sqrt_inv_matmul), ("g15", g15_lanczos_consumers_backward),
                      ("g16", g16_sum_operators), ("g17", g17_low_rank_root_added_diag_backward),
                      ("g18", g18_low_rank_root_added_diag_wide_root), ("g19", g19_kronecker_three_factors),
-                     ("g20", g20_kronecker_structured_diag)):
+                     ("g20", g20_kronecker_structured_diag), ("g21", g21_minres_fp64)):
         if name in todo:
             fn()
     print("done")

@@ -162,7 +162,25 @@ def test_fp64_operators_solve_and_differentiate_through_linear_cg():
           lambda c, d: c @ c.T + torch.diag(d), [C0, d0])
 
 
-def test_fp64_is_limited_to_linear_cg_and_says_so():
+def test_fp64_minres_matches_the_reference_recipes():
+    """The reference's own test/utils/test_minres.py:17-80 (float64, value = -1, minres_tolerance 1e-6, shifts, batched
+    and unbatched matrices and right-hand sides) on csrc/lo_minres_f64.hip, against the goldens the real reference
+    produced (g21) -- dense tensors on the library's fp64 matvec and the same matrices as closures."""
+    import linear_operator_amd as lo
+    from linear_operator_amd.utils.minres import minres
+    from test_oracle_vs_golden import minres64_inputs
+
+    g = load_golden("g21_minres_fp64")
+    for tag, M, b, sh in minres64_inputs():
+        sh_t = None if sh is None else dev(sh)
+        for closure in (dev(M), dev(M).matmul):
+            with lo.settings.minres_tolerance(1e-6):
+                x = minres(closure, rhs=dev(b), value=-1, shifts=sh_t)
+            assert x.dtype == torch.float64 and tuple(x.shape) == g[f"x_{tag}"].shape, tag
+            assert rel_err(host(x), g[f"x_{tag}"]) < 1e-9, tag
+
+
+def test_fp64_is_limited_to_the_two_solvers_and_says_so():
     from linear_operator_amd import _hip, kernels as K
 
     C = torch.randn(2, 300, 4, device="cuda", dtype=torch.float64)

@@ -687,3 +687,38 @@ def test_g20_kronecker_structured_diagonal():
             x = ir[:, None] * (q @ ((q.T @ (ir[:, None] * rhs[i].astype(np.float64))) / (lam + 1)[:, None]))
             assert max_rel_err_cols(x, g[f"{tag}_x_exact"][i]) < 1e-10
             assert abs(np.log1p(lam).sum() - 2 * np.log(ir).sum() - g[f"{tag}_ld_exact"][i]) < 1e-9
+
+
+_MINRES64_RUNS = [("vec", (20,), (), False), ("vec_shifts", (5,), (), True), ("mat", (20, 5), (), False),
+                  ("bmat", (3, 20, 5), (), False), ("bmat_bop", (3, 20, 5), (3,), False), ("mat_bop", (20, 5), (3,), False),
+                  ("mat_shifts", (20, 5), (), True), ("bmat_bop_shifts", (3, 20, 5), (3,), True),
+                  ("mat_bop_shifts", (20, 5), (3,), True)]
+
+
+def minres64_inputs():
+    """(tag, matrix, rhs, shifts-or-None) of the reference's test/utils/test_minres.py recipes, as make_golden.py g21."""
+    out = []
+    for i, (tag, rshape, mbatch, with_shifts) in enumerate(_MINRES64_RUNS):
+        size = rshape[-2] if len(rshape) > 1 else rshape[-1]
+        M = cases.spd_test_matrix(2100 + i, size, batch=mbatch)
+        b = cases.randn(2150 + i, *rshape)
+        out.append((tag, M, b, np.array([0.0, 1.0, 2.0]) if with_shifts else None))
+    return out
+
+
+def test_g21_minres_fp64_reference_recipes():
+    g = load_golden("g21_minres_fp64")
+    runs = minres64_inputs()
+    _check_inputs(g, *[a for _, M, b, _ in runs for a in (M, b)])
+    for tag, M, b, sh in runs:
+        rhs = b if b.ndim > 1 else b[:, None]
+        rb = np.broadcast_to(rhs, np.broadcast_shapes(M.shape[:-2], rhs.shape[:-2]) + rhs.shape[-2:]).copy()
+        x, info = orc.minres(lambda v: M @ v, rb, shifts=sh, value=-1.0, tolerance=1e-6)
+        if b.ndim == 1:
+            x = x[..., 0]
+        assert x.shape == g[f"x_{tag}"].shape, tag
+        assert rel_err(x, g[f"x_{tag}"]) < 1e-9, tag
+        # the reference test's own acceptance (test_minres.py:37-46)
+        A = -M if sh is None else -(M - sh.reshape(-1, *([1] * M.ndim)) * np.eye(M.shape[-1]))
+        exact = np.linalg.solve(A, rb)
+        assert np.allclose(x if b.ndim > 1 else x[..., None], exact, atol=1e-3, rtol=1e-4), tag
