@@ -1,0 +1,53 @@
+"""Randomised shapes through the operator-resident kernels (pivoted Cholesky ranks 1 .. 32 bit-exact against the oracle,
+root-form / lockstep CG against the exact fp64 Woodbury solution) for a given number of minutes.  Not part of the test
+suite: run on the GPU box after kernel changes (`python tools/fuzz_resident.py --minutes 5 --seed 1`)."""
+import argparse, os, random, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import cases  # noqa: E402
+from oracle import lo_oracle as orc  # noqa: E402
+from linear_operator_amd import kernels as K  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--minutes", type=float, default=3.0)
+ap.add_argument("--seed", type=int, default=0)
+args = ap.parse_args()
+rnd = random.Random(args.seed)
+t_end = time.time() + 60 * args.minutes
+n_pc = n_cg = 0
+while time.time() < t_end:
+    B = rnd.choice([1, 2, 3, 9, 40, 130])
+    N = rnd.choice([256, 300, 777, 1024, 1025, 2048, 3000, 4096, 5000, 8192, 9001, 16384, 20000, 32768])
+    R = rnd.choice([1, 2, 5, 8, 11, 16, 24, 32])
+    rank = rnd.randint(1, 32)
+    if B * N * R > 6e7:
+        continue
+    C = cases.lowrank_diag(rnd.randrange(1 << 30), B, N, R, 1)[0]
+    Cd = torch.from_numpy(C).cuda()
+    L, piv = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cd, None), rank)
+    Lo, pivo = orc.pivoted_cholesky(orc.LowRankRowSource(C), rank)
+    assert np.array_equal(piv.cpu().numpy(), pivo) and np.array_equal(L.cpu().numpy(), Lo), ("pc", B, N, R, rank)
+    n_pc += 1
+    c = rnd.choice([1, 1, 2, 5, 16, 17, 33])
+    k = rnd.choice([0, 1, 7, 15, 16])
+    ntri = rnd.choice([0, min(c, 16)])
+    g = torch.Generator(device="cuda"); g.manual_seed(rnd.randrange(1 << 30))
+    d = torch.rand(B, N, generator=g, device="cuda") + 0.5
+    rhs = torch.randn(B, N, c, generator=g, device="cuda")
+    pre = None
+    if k:
+        Lr, perm = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cd, None), k, contiguous=False)
+        pre = K.precond_build(Lr, d, False, root=Cd, perm=perm) if rnd.random() < 0.6 else K.precond_build(Lr, d, False)
+    res = K.cg_solve(K.lowrank_diag_descriptor(Cd, d), rhs, precond=pre, n_tridiag=ntri, tolerance=1e-5, max_iter=400)
+    C64, d64, r64 = Cd.double(), d.double(), rhs.double()
+    Cs = C64 / d64.unsqueeze(-1)
+    cap = torch.eye(R, device="cuda", dtype=torch.float64) + C64.mT @ Cs
+    exact = r64 / d64.unsqueeze(-1) - Cs @ torch.linalg.solve(cap, Cs.mT @ r64)
+    err = ((res.x.double() - exact).norm(dim=-2) / exact.norm(dim=-2)).max().item()
+    # (unpreconditioned / rank-1 preconditioned solves stop on the residual: the error bound carries the condition number)
+    assert err < (1e-4 if k >= 7 else 5e-3) and not res.nan_detected, ("cg", B, N, R, c, k, ntri, res.iterations, err)
+    assert ntri == 0 or bool(torch.isfinite(res.t_mat).all()), ("tri", B, N, R, c, k)
+    n_cg += 1
+print(f"fuzz ok: {n_pc} factorisations, {n_cg} solves, seed {args.seed}")
