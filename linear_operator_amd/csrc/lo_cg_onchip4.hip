@@ -526,14 +526,13 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
         r[q] = (lr < nv) ? r[q] : 0.f;
         p[q] = 0.f;
         x_s[lr] = 0.f;
-        sc[0] = fmaf(r[q], r[q], sc[0]);
       }
-      r4_allreduce_scalars<GW>(sh, sc, 1, g);
-      float nrm = sqrtf(sh.res[0]);                          // rhs.norm(2, dim=-2)          :177
-      const bool rhs_zero = nrm < a.eps;                     // :178
-      if (rhs_zero) nrm = 1.0f;                              // :179
-#pragma unroll
-      for (int q = 0; q < R4_NR; ++q) r[q] = r[q] / nrm;     // :182
+      // The norm of the right-hand side rides on the FIRST reduction (its s1 = sum r^2 is the squared norm): that
+      // reduction runs on the raw column and its results are scaled afterwards -- w by 1 / norm, s1 and s2 by
+      // 1 / norm^2 -- instead of a separate all-reduce in front of it (1.4 us per member and column).  Same range as the
+      // norm itself: sum r^2 has to be finite in fp32.
+      float nrm = 1.0f, inv0 = 1.0f;
+      bool rhs_zero = false;
       // first-wave state of the recurrences (uniform scalars replicated in the lanes; t_old = C^T p_old in lane j < RC)
       float t_old = 0.f, tt_old = 0.f, dpp = 0.f, rz = 0.f, alpha = 0.f, beta = 0.f, rn = 0.f;
       bool conv = false;
@@ -588,11 +587,21 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
           }
           // v_permlane32_swap of a value with itself: first result = the lower-half lane's value in both halves,
           // second = the upper-half lane's: every lane gets (v_j, (E v)_j) with one instruction
+          float sc1 = 1.0f, sc2 = 1.0f;  // scaling of the raw first reduction (k < 0), 1 afterwards
+          if (k < 0) {
+            nrm = sqrtf(sh.res[RC]);                         // rhs.norm(2, dim=-2)          :177
+            rhs_zero = nrm < a.eps;                          // :178
+            if (rhs_zero) nrm = 1.0f;                        // :179
+            inv0 = 1.0f / nrm;
+            sc1 = inv0;
+            sc2 = inv0 * inv0;
+          }
+          mv *= sc1;
           const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mv), __float_as_uint(mv), false, false);
           const float vj = __uint_as_float(sw[0]), evj = __uint_as_float(sw[1]);
-          const float wj = (j < RC) ? sh.res[j] : 0.f;
+          const float wj = (j < RC) ? sh.res[j] * sc1 : 0.f;
           const bool own = lane < 32 && j < RC;
-          const float s1 = sh.res[RC], s2 = sh.res[RC + 1], rp = sh.res[RC + 2];
+          const float s1 = sh.res[RC] * sc2, s2 = sh.res[RC + 1] * sc2, rp = sh.res[RC + 2];
           const float zj = wj - evj;                          // (C^T z)_j
           // five independent sums (their butterflies interleave); |C^T p_new|^2 from the expansion so that it does not
           // wait for beta: |zc + beta t|^2 = |zc|^2 + 2 beta zc.t + beta^2 |t|^2
@@ -640,6 +649,8 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
         if (g.dbg && t == 0) g.dbg[10] += wall_clock64() - cp0;  // small algebra
       };
       reduce_and_post(-1);
+#pragma unroll
+      for (int q = 0; q < R4_NR; ++q) r[q] = r[q] / nrm;     // :182 (the reduction above saw the raw column)
       if (stamp && col == cfirst) {
         a.dbg[2] = wall_clock64();
         g.dbg = a.dbg;
