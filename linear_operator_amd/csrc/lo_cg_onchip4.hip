@@ -510,10 +510,17 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
 
     const int nc = MC ? a.c : 1;
     const int cfirst = MC ? a.col0 : 0, clast = MC ? a.col0 + a.ncols : 1;
+    int64_t b_next = a.B;  // set by the member's last reduction
+    int drawn = 0;
+    // the hand-out counter is read one phase ahead of the reduction that carries it: the atomic's round trip hides
+    // behind the vector updates instead of delaying the publication of the group's first workgroup
+    auto draw = [&](int k, int col) {
+      if (k == a.iters - 1 && col == clast - 1 && wig == 0 && t == 0) drawn = atomicAdd(a.next_member, 1);
+    };
     for (int col = cfirst; col < clast; ++col) {
       const size_t bc = (size_t)b * nc + col;
       float r[R4_NR], p[R4_NR];
-      float sc[3];
+      float sc[4];
       sc[0] = 0.f;
       int tc = t;
       asm volatile("" : "+v"(tc));
@@ -564,9 +571,17 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
           for (int q = 1; q < R4_NR; ++q) v = __builtin_elementwise_fma(Cr[q][j], f32x2{rd[q], rd[q]}, v);
           wp[j] = v;
         }
-        r4_allreduce<GW, RC>(
-            sh, [&](int c) { return (c & 1) ? wp[c >> 1].y : wp[c >> 1].x; },
-            sc, 3, g);
+        // the member's LAST reduction also carries the next member of the group (dynamic hand-out: drawn by the
+        // group's first workgroup, exact below 2^24) -- no all-reduce of its own at the end of the member
+        const bool draws = (k == a.iters - 1) && (col == clast - 1);
+        sc[3] = (draws && wig == 0 && t == 0) ? (float)(ngroups + drawn) : 0.f;  // (requested ahead, see draw())
+        const auto gen = [&](int c) { return (c & 1) ? wp[c >> 1].y : wp[c >> 1].x; };
+        if (draws) {  // (two call sites: the scalar count stays a compile-time constant in the common one)
+          r4_allreduce<GW, RC>(sh, gen, sc, 4, g);
+          b_next = (int64_t)sh.res[RC + 3];
+        } else {
+          r4_allreduce<GW, RC>(sh, gen, sc, 3, g);
+        }
         if (g.dbg && t == 0) g.dbg[9] += wall_clock64() - cr0;  // partials of w + reduce-scatter + group all-reduce
         long long cp0 = 0;
         if (g.dbg && t == 0) cp0 = wall_clock64();
@@ -648,6 +663,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
         }
         if (g.dbg && t == 0) g.dbg[10] += wall_clock64() - cp0;  // small algebra
       };
+      draw(-1, col);
       reduce_and_post(-1);
 #pragma unroll
       for (int q = 0; q < R4_NR; ++q) r[q] = r[q] / nrm;     // :182 (the reduction above saw the raw column)
@@ -659,6 +675,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
       for (int k = 0; k < a.iters; ++k) {
         long long c0 = 0;
         if (g.dbg && t == 0) c0 = wall_clock64();
+        draw(k, col);
         const float al = alpha, be = beta;  // (identical in every wave: formed from the same all-reduced values)
         const R5Post& mine = post[t >> 6];
         last_alpha = al;
@@ -726,12 +743,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
       __syncthreads();
     }  // columns
     if (stamp) a.dbg[4] = wall_clock64();
-    if (t < R4_WAVES) sh.red[t][0] = 0.f;
-    __syncthreads();
-    if (wig == 0 && t == 0) sh.red[0][0] = (float)(ngroups + atomicAdd(a.next_member, 1));
-    r4_group_sum<GW>(sh, 1, g);
-    b = (int64_t)sh.res[0];
-    __syncthreads();
+    b = b_next;
   }
 }
 
