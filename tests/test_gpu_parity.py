@@ -750,6 +750,25 @@ def test_fused_preconditioner_apply_matches_two_pass_path(kind, N, monkeypatch):
     assert torch.equal(sep.x, res.x) and abs(sep.mean_residual - res.mean_residual) <= 1e-6 * abs(sep.mean_residual)
 
 
+def test_streaming_iteration_replayed_as_a_graph_gives_the_same_solve(monkeypatch):
+    """`LO_CG_GRAPH=1` (opt-in: measured slower on this stack) captures one streaming iteration -- Kronecker matvec,
+    fused preconditioner apply with the folded control step -- and replays it with the iteration index read from the
+    control block: same iterations, flags and bits as the plain launches."""
+    n = 96
+    K1, K2, sig, rhs = cases.kron_factors(5750, 3, n, n, 1)
+    d_t = dev(sig[:, 0])
+    desc = K.kron_diag_descriptor(dev(K1), dev(K2), d_t, const_diag=True)
+    L, _ = K.pivoted_cholesky(desc, 15)
+    pre = K.precond_build(L, d_t, True)
+    kw = dict(precond=pre, tolerance=1e-3, max_iter=400)
+    ref = K.cg_solve(desc, dev(rhs), **kw)
+    monkeypatch.setenv("LO_CG_GRAPH", "1")
+    res = K.cg_solve(desc, dev(rhs), **kw)
+    monkeypatch.delenv("LO_CG_GRAPH")
+    assert res.iterations == ref.iterations and res.tolerance_reached == ref.tolerance_reached
+    assert torch.equal(res.x, ref.x)
+
+
 def test_onchip_cg_many_columns_hand_over():
     """Columns + tridiagonals + a tolerance the guaranteed iterations do not reach: the streaming loop continues from
     the resident kernel's per-column state."""
