@@ -191,7 +191,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_cg_lockstep(OnchipArgs a) {
   constexpr int OFF_U = NH * 256;               // payload: W | U | three scalars per column
   constexpr int OFF_S = OFF_U + (PRE ? 256 : 0);
   constexpr int NV = OFF_S + 3 * LS_NC;
-  static_assert(NV <= LS_NVP, "payload");
+  constexpr int NVX = NV + 1;  // + the next work item of the dynamic hand-out (non-zero in an item's last reduction only)
+  static_assert(NVX <= LS_NVP, "payload");
   __shared__ __attribute__((aligned(16))) float c_s[LS_ROWS * RC];
   __shared__ __attribute__((aligned(16))) float d_s[LS_ROWS];
   __shared__ __attribute__((aligned(16))) float dinv_s[LS_ROWS];
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_cg_lockstep(OnchipArgs a) {
   const int ngroups = groups_per_xcd * 8;
   if (jx / GW >= groups_per_xcd) return;
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), kk = lane >> 4, n = lane & 15;
+  if (t < NP) part[t][NV] = 0.f;  // the hand-out slot of the payload (first barrier: the placement check below)
   LsGroup g;
   g.gslot = a.gbuf + (size_t)grp * 2 * (GW + 1) * LS_NVP;
   g.wig = wig;
@@ -378,6 +380,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_cg_lockstep(OnchipArgs a) {
     }
     // two-stage cross-wave sum of a payload held in (accw, accu, three per-column scalars), then the group all-reduce
     long long* tdbg = nullptr;  // phase timers of the stamped work item (iteration loop only)
+    float draw_f = 0.f;         // thread 0 of the group's first workgroup: the next work item, in the item's last reduction
     auto allreduce = [&](float s0, float s1, float s2) {
       long long c0 = 0;
       if (DBG && tdbg) c0 = wall_clock64();
@@ -421,7 +424,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_cg_lockstep(OnchipArgs a) {
         tdbg[8] += c1 - c0;  // cross-wave stage (incl. waiting for the slowest wave)
         c0 = c1;
       }
-      ls_group_sum<GW, NP, LS_TPB>(part, res, NV, g);
+      if (t == 0) part[0][NV] = draw_f;  // (part[1 ..][NV] stay zero)
+      ls_group_sum<GW, NP, LS_TPB>(part, res, NVX, g);
       if (DBG && tdbg) tdbg[9] += wall_clock64() - c0;  // publish + poll + sum
     };
 
@@ -492,7 +496,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_cg_lockstep(OnchipArgs a) {
       allreduce(s0, s1, s2);
     };
 
-    reduce();
+    int64_t item_next = nitems;
+    if (a.iters == 0) {  // (no iteration follows: this is the item's last reduction)
+      if (t == 0 && wig == 0) draw_f = (float)(ngroups + atomicAdd(a.next_member, 1));
+      reduce();
+      item_next = (int64_t)res[NV];
+      draw_f = 0.f;
+    } else {
+      reduce();
+    }
     float rz, beta = 0.f, alpha = 0.f, dpp = 0.f, rn;
     f32x4 tb[NH], gd = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -520,6 +532,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_cg_lockstep(OnchipArgs a) {
     for (int k = 0; k < a.iters; ++k) {
       long long c0 = 0;
       if (DBG && tdbg) c0 = wall_clock64();
+      const bool last_it = k == a.iters - 1;
+      int drawn = 0;  // (the counter is read at the top of the last iteration: its round trip hides behind the products)
+      if (last_it && t == 0 && wig == 0) drawn = atomicAdd(a.next_member, 1);
       // ---- search direction: p = z + beta p with z = r/d - Q u formed on the fly (:268, :46); the small
       //      recurrences for C^T p, Q^T D p and sum d p^2 ----
       {
@@ -623,7 +638,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_cg_lockstep(OnchipArgs a) {
         tdbg[6] += c1 - c0;  // alpha, x and r updates
         c0 = c1;
       }
+      if (last_it && t == 0 && wig == 0) draw_f = (float)(ngroups + drawn);
       reduce();
+      if (last_it) {
+        item_next = (int64_t)res[NV];
+        draw_f = 0.f;
+      }
       {
         float uu = 0.f;
         if constexpr (PRE) {
@@ -695,16 +715,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_cg_lockstep(OnchipArgs a) {
       a.has_conv[bc] = conv ? 1 : 0;
     }
     if (stamp) a.dbg[4] = wall_clock64();
-    // next work item: drawn by the group's first workgroup, handed to the others through the all-reduce path
-    // (one contributor, the rest add zeros: exact for indices < 2^24)
-    __syncthreads();
-    if (t == 0) {
-      part[0][0] = (wig == 0) ? (float)(ngroups + atomicAdd(a.next_member, 1)) : 0.f;
-#pragma unroll
-      for (int q = 1; q < NP; ++q) part[q][0] = 0.f;
-    }
-    ls_group_sum<GW, NP, LS_TPB>(part, res, 1, g);
-    item = (int64_t)res[0];
+    // next work item: drawn by the group's first workgroup one phase ahead and carried by the item's last reduction
+    // (one contributor, the rest add zeros: exact for indices < 2^24) -- no all-reduce of its own
+    item = item_next;
     __syncthreads();
   }
 }
