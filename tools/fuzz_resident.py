@@ -28,7 +28,10 @@ while time.time() < t_end:
     Cd = torch.from_numpy(C).cuda()
     L, piv = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cd, None), rank)
     Lo, pivo = orc.pivoted_cholesky(orc.LowRankRowSource(C), rank)
-    assert np.array_equal(piv.cpu().numpy(), pivo) and np.array_equal(L.cpu().numpy(), Lo), ("pc", B, N, R, rank)
+    # (equal_nan: a rank-deficient member whose remaining diagonal went negative gets a NaN column from sqrt(max) in
+    #  the reference, the oracle and the kernel alike -- seen at B=130 N=32768 R=11 rank=32)
+    assert np.array_equal(piv.cpu().numpy(), pivo) and np.array_equal(L.cpu().numpy(), Lo, equal_nan=True), \
+        ("pc", B, N, R, rank)
     n_pc += 1
     c = rnd.choice([1, 1, 2, 5, 16, 17, 33])
     k = rnd.choice([0, 1, 7, 15, 16])
