@@ -220,6 +220,22 @@ def test_pivoted_cholesky_ranks_17_to_32_stay_resident_and_bit_exact():
     del rnd
 
 
+def test_pivoted_cholesky_nan_column_of_an_exhausted_member():
+    """A rank-deficient member (R = 11 < rank 32) whose remaining diagonal has gone negative by rounding: the reference
+    takes sqrt(max) of a negative number and that member's column is NaN from then on, while the batch continues
+    because other members are still above the tolerance.  The kernel (groups of 32, 128 KB of L rows per workgroup)
+    reproduces it: same pivots, NaNs in the same places, every other entry bit-identical.  (Found by
+    tools/fuzz_resident.py, seed 99.)"""
+    B, N, R, rank = 130, 32768, 11, 32
+    C = cases.lowrank_diag(693751327, B, N, R, 1)[0]
+    L, piv = K.pivoted_cholesky(K.lowrank_diag_descriptor(dev(C), None), rank)
+    with np.errstate(invalid="ignore"):
+        Lo, pivo = orc.pivoted_cholesky(orc.LowRankRowSource(C), rank)
+    assert np.isnan(Lo).any(), "the case no longer exercises the NaN column"
+    assert np.array_equal(host(piv), pivo)
+    assert np.array_equal(np.isnan(host(L)), np.isnan(Lo)) and np.array_equal(host(L), Lo, equal_nan=True)
+
+
 @pytest.mark.parametrize("N,c", [(40000, 1), (65536, 1), (50000, 3)])
 def test_large_members_take_groups_of_64(N, c):
     """32768 < N <= 65536: the root-form resident CG runs a member on 64 workgroups (lane-parallel two-hop all-reduce)
