@@ -81,9 +81,26 @@ def algorithmic_bytes(name, k_eff):
     return 0
 
 
-def cpu_baseline(seconds_budget=12.0):
-    """The numpy oracle (kind 'port') on a bounded sample of the same workload, host cores."""
+def woodbury_fp64_rel_err(Cm, d, rhs, x, chunk=64):
+    """max_b ||x_b - x*_b|| / ||x*_b|| with x* = (D + C C^T)^-1 rhs by the Woodbury identity in fp64 (checker only)."""
+    worst = 0.0
+    for b0 in range(0, Cm.shape[0], chunk):
+        C64, d64 = Cm[b0:b0 + chunk].double(), d[b0:b0 + chunk].double().unsqueeze(-1)
+        r64 = rhs[b0:b0 + chunk].double()
+        Cd = C64 / d64
+        cap = torch.eye(C64.shape[-1], device=Cm.device, dtype=torch.float64) + C64.mT @ Cd
+        xs = r64 / d64 - Cd @ torch.linalg.solve(cap, C64.mT @ (r64 / d64))
+        err = (x[b0:b0 + chunk].double() - xs).flatten(1).norm(dim=1) / xs.flatten(1).norm(dim=1)
+        worst = max(worst, float(err.max().item()))
+    return worst
+
+
+def cpu_baseline(seconds_budget=12.0, device=None):
+    """The numpy oracle (kind 'port') on a bounded sample of the same workload, host cores.  The same leg also holds the
+    parity sample of the line (`parity_sample`): the HIP path against the oracle on IDENTICAL inputs -- solve rel-err,
+    logdet rel-err with identical probes and preconditioner (BASELINE.json's metric names it), pivots."""
     import cases
+    import numpy as np
     from oracle import lo_oracle as orc
 
     try:
@@ -94,10 +111,10 @@ def cpu_baseline(seconds_budget=12.0):
         threads = os.cpu_count() or 1
     Bs = 8
     Cs, ds, rs = cases.lowrank_diag(4242, Bs, N, R, C_COLS)
-    L, _ = orc.pivoted_cholesky(orc.LowRankRowSource(Cs), RANK_K)
+    L, piv = orc.pivoted_cholesky(orc.LowRankRowSource(Cs), RANK_K)
     pre = orc.Preconditioner(L, ds)
     mm = lambda v: orc.matvec_lowrank_diag(Cs, ds, v)  # noqa: E731
-    orc.linear_cg(mm, rs, tolerance=TOL, preconditioner=pre.apply)  # warm up
+    x_ref, _, _ = orc.linear_cg(mm, rs, tolerance=TOL, preconditioner=pre.apply)  # warm up
     t0 = time.perf_counter()
     reps, mv = 0, 0
     while time.perf_counter() - t0 < seconds_budget:
@@ -105,9 +122,39 @@ def cpu_baseline(seconds_budget=12.0):
         mv += Bs * info.matvecs
         reps += 1
     dt = time.perf_counter() - t0
-    return {"value": mv / dt, "unit": "member-matvecs/s", "cores": int(threads), "kind": "port",
-            "sample": f"{reps} x oracle linear_cg on {Bs} of the {B_PER_GPU} members (same N={N}, R={R}, c={C_COLS}, "
-                      f"rank-{RANK_K} preconditioner, tol {TOL}); reference counts {11 + 1} products per solve"}
+    out = {"value": mv / dt, "unit": "member-matvecs/s", "cores": int(threads), "kind": "port",
+           "sample": f"{reps} x oracle linear_cg on {Bs} of the {B_PER_GPU} members (same N={N}, R={R}, c={C_COLS}, "
+                     f"rank-{RANK_K} preconditioner, tol {TOL}); reference counts {11 + 1} products per solve"}
+    if device is not None:  # ---- parity sample: the HIP path on the oracle's very inputs ----
+        Pn = 16
+        Ct, dt_, rt = (torch.from_numpy(a).to(device) for a in (Cs, ds, rs))
+        desc = K.lowrank_diag_descriptor(Ct, dt_)
+        Lh, ph = K.pivoted_cholesky(desc, RANK_K, contiguous=False)
+        pivots_equal = bool(np.array_equal(ph.cpu().numpy()[:, :RANK_K], np.asarray(piv)[:, :RANK_K]))
+        pre_h = K.precond_build(Lh, dt_, constant_diag=False, root=desc.A0, perm=ph)
+        xh = K.cg_solve(desc, rt, precond=pre_h, tolerance=TOL).x.cpu().numpy()
+        num = np.linalg.norm((xh - x_ref).reshape(Bs, -1), axis=1)
+        solve_err = float((num / np.linalg.norm(x_ref.reshape(Bs, -1), axis=1)).max())
+        rng = np.random.Generator(np.random.PCG64(99))
+        Z = rng.standard_normal((Bs, N, Pn)).astype(np.float32)
+        Z /= np.linalg.norm(Z, axis=-2, keepdims=True)
+        full = np.concatenate([Z, rs], axis=-1)
+        xo, to, _ = orc.linear_cg(mm, full, n_tridiag=Pn, tolerance=TOL, preconditioner=pre.apply)
+        ev, evec = orc.lanczos_tridiag_to_diag(to)
+        ld_ref = orc.slq_logdet(N, ev, evec) + pre.logdet
+        rh = K.cg_solve(desc, torch.from_numpy(full).to(device), precond=pre_h, n_tridiag=Pn, tolerance=TOL)
+        _, _, ldh = K.tridiag_eigh_slq(rh.t_mat, N)
+        ld_h = (ldh + pre_h.logdet.reshape(-1)).cpu().numpy()
+        ld_exact = orc.woodbury_logdet(Cs.astype(np.float64), ds.astype(np.float64))
+        out["parity_sample"] = {
+            "members": Bs, "pivots_equal": pivots_equal, "solve_rel_err_vs_oracle": solve_err,
+            "logdet_rel_err_vs_oracle": float(np.max(np.abs(ld_h - ld_ref) / np.abs(ld_ref))),
+            "logdet_rel_err_slq_vs_exact_fp64": float(np.max(np.abs(ld_h - ld_exact) / np.abs(ld_exact))),
+            "note": "HIP path vs the numpy oracle on identical inputs: identical right-hand side, identical 16 probes, "
+                    "identical rank-15 preconditioner (pivots compared exactly); logdet = SLQ on the CG tridiagonals "
+                    "+ logdet P.  The last figure is the estimator's own error against the fp64 closed form "
+                    "(16 probes), not a parity figure"}
+    return out
 
 
 def _time(fn, reps):
@@ -396,6 +443,79 @@ def strong_scaling(args, device, dist, rank, world):
     }
 
 
+def self_launch(n, argv):
+    """Re-exec this script under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free
+    port); rank 0's JSON line goes to our stdout.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def _gather_rank_ms(dist, elapsed_ms, device):
+    """Per-rank step times (ms) on every rank."""
+    t = torch.tensor([elapsed_ms], device=device, dtype=torch.float64)
+    allt = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(allt, t)
+    return [float(x.item()) for x in allt]
+
+
+def stub_run(args, rank, world):
+    """LO_BENCH_STUB=1: the launcher, the rank plumbing, barrier + max-over-ranks timing and the JSON contract with a
+    stubbed solver on the gloo backend -- runs without a GPU.  Never a measurement: metric and data say `stub`."""
+    import torch.distributed as dist
+
+    if world > 1 or os.environ.get("LO_BENCH_FORCE_DIST"):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == args.gpus
+    else:
+        dist = None
+    dev = torch.device("cpu")
+    x = torch.full((4, 8, 1), float(rank))
+    buf = torch.empty(world * 4, 8, 1)
+
+    def step():
+        time.sleep(0.002 * (1 + rank))  # uneven ranks: the MAX must win
+        if dist is not None:
+            dist.all_gather_into_tensor(buf, x)
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
+    if dist is not None:
+        rank_ms = _gather_rank_ms(dist, rank_ms[0], dev)
+        ok = bool(torch.equal(buf[:, 0, 0].reshape(world, 4)[:, 0], torch.arange(world, dtype=torch.float32)))
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ok = True
+    ms = max(rank_ms)
+    return {"metric": "stub", "value": world * 4 * 11 / (ms * 1e-3), "unit": "member-matvecs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "stub", "config": {"workload": "stub (launcher check, no GPU)"},
+            "rccl_ranks": world, "per_rank_ms": rank_ms, "gather_ok": ok}
+
+
 def main():
     # stdout carries exactly ONE JSON line: everything else that libraries print to fd 1 (RCCL prints a version banner
     # on process-group setup) is sent to stderr for the whole run; the JSON goes to the saved descriptor at the end.
@@ -418,8 +538,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU under torch.distributed.run,
+        # the driver's own convention) instead of dying -- the scaling run must not be lost to a launch convention
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if os.environ.get("LO_BENCH_STUB"):  # launcher / JSON-contract check without a GPU (tests/test_distributed_cpu.py)
+        out = stub_run(args, rank, world)
+        if rank == 0:
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        os.close(real_stdout)
+        return
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: no HIP device {local_rank} (visible devices: "
+                         f"{torch.cuda.device_count() if torch.cuda.is_available() else 0}); bench.py has no CPU path")
     dist = None
     use_dist = world > 1 or bool(os.environ.get("LO_BENCH_FORCE_DIST"))  # the env var exercises the RCCL path at N=1
     if use_dist:
@@ -434,6 +569,8 @@ def main():
         # below) and a 16 MB per-rank all-gather does not need more
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     _hip.load()
@@ -490,10 +627,19 @@ def main():
         res = step()
     fence()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
+    allgather_ms = None
     if use_dist:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        per_rank_ms = _gather_rank_ms(dist, per_rank_ms[0], device)
+        elapsed = max(per_rank_ms) * 1e-3 * args.steps  # the MAX over the ranks is the job's time
+        # the collective on its own (blocking, nothing to hide behind): what one all-gather of the solutions costs
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        tg = time.perf_counter()
+        for i in range(5):
+            dist.all_gather_into_tensor(gather_bufs[i % 2], res.x)
+        torch.cuda.synchronize(device)
+        allgather_ms = (time.perf_counter() - tg) / 5 * 1e3
     matvecs_per_solve = res.matvecs
     total_members = world * B_PER_GPU
     value = total_members * matvecs_per_solve * args.steps / elapsed
@@ -511,6 +657,24 @@ def main():
         t = torch.tensor([e2e], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         e2e = float(t.item())
+
+    # ---- accuracy of the timed solve: max_b ||x - x*|| / ||x*|| against the fp64 Woodbury closed form (the exact
+    # solution of the same systems; torch fp64 library ops as the CHECKER, outside every timed region) ----
+    solve_rel_err = woodbury_fp64_rel_err(Cm, d, rhs, res.x)
+    # ---- BASELINE cfg4 / cfg5 at their full batch over the same ranks (strong scaling), same invocation ----
+    strong = {}
+    if use_dist and world > 1 and not os.environ.get("LO_BENCH_NO_STRONG"):
+        import types
+
+        del pre
+        torch.cuda.empty_cache()
+        for wl in ("cfg4", "cfg5"):
+            a2 = types.SimpleNamespace(workload=wl, steps=2, warmup=1, chunk_members=args.chunk_members)
+            line = strong_scaling(a2, device, dist, rank, world)
+            if line is not None:
+                strong[f"{wl}_strong_scaling"] = {k: line[k] for k in ("value", "unit", "ms_per_step", "scaling", "config")}
+            torch.cuda.empty_cache()
+        pre = build_precond(desc, d)
 
     out = None
     if rank == 0:
@@ -605,11 +769,20 @@ def main():
             "end_to_end_ms": e2e * 1e3,
             "kernels": kernels,
             "final_mean_residual": res.mean_residual,
+            "solve_rel_err": solve_rel_err,
+            "solve_rel_err_note": "max over the 512 members of ||x - x*|| / ||x*||, x* = fp64 Woodbury closed form of the "
+                                  "same systems (north_star bar 1e-4); logdet rel-err with identical probes: "
+                                  "cpu_baseline.parity_sample",
+            "rccl_ranks": world if use_dist else 0,
+            "per_rank_ms": per_rank_ms,
+            "allgather_ms": allgather_ms,
         }
         if world == 1 and not args.no_extras:
             out["other_configs"], out["rooflines"] = other_configs(device)
+        if strong:
+            out["other_configs"] = strong
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(device=device)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -152,3 +152,40 @@ def test_factory_sharding_and_global_rule_plumbing_gloo_world2(tmp_path, B):
     C, d, rhs = cases.lowrank_diag(778, B, 96, 4, 2)
     full, _, _ = orc.linear_cg(lambda v: orc.matvec_lowrank_diag(C, d, v), rhs, tolerance=1e-4)
     assert got["x"].shape == full.shape and np.allclose(got["x"], full, rtol=1e-5, atol=1e-6)
+
+
+def _run_bench_stub(extra_env, argv):
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(LO_BENCH_STUB="1", **extra_env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout  # exactly ONE JSON line on stdout (the driver's contract)
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start its own 2-rank job (the round-2
+    script exited instead): stubbed solver on gloo, so the launcher, the rank plumbing, the barrier + MAX-over-ranks
+    timing and the JSON contract run here without a GPU."""
+    out = _run_bench_stub({}, ["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert len(out["per_rank_ms"]) == 2 and out["gather_ok"]
+    assert out["ms_per_step"] == max(out["per_rank_ms"])  # the slowest rank is the job's time
+    assert out["per_rank_ms"][1] > out["per_rank_ms"][0] * 0.9  # (rank 1 sleeps twice as long per step)
+    assert out["data"] == "stub" and out["metric"] == "stub"  # a stub line can never pass for a measurement
+
+
+def test_bench_single_rank_contract_and_world_size_mismatch():
+    out = _run_bench_stub({}, ["--steps", "2", "--warmup", "1"])
+    assert out["n_gpus"] == 1 and len(out["per_rank_ms"]) == 1
+    import subprocess
+
+    env = dict(os.environ, LO_BENCH_STUB="1", WORLD_SIZE="1", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr  # a launcher that started the wrong number of ranks
