@@ -168,6 +168,52 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
                     const float* x0, float* x, float* t_mat, void* ws, size_t ws_bytes, lo_cg_info* info,
                     void* stream);
 
+/* ---- fused end-to-end solve: ONE resident launch ------------------------------------------------- */
+/* A.solve(rhs) of AddedDiag(LowRankRoot(C), Diag | ConstantDiag) end to end, the operator read from HBM once:
+ *   PivotedCholesky.forward   (functions/_pivoted_cholesky.py:14-105; `rank` pivots of C C^T)
+ *   -> AddedDiagLinearOperator._init_cache (operators/added_diag_linear_operator.py:144-184; in ROOT FORM, see
+ *      lo_precond_desc.F / EF: L = C M is never written to memory)
+ *   -> linear_cg              (utils/linear_cg.py:98-359; the iterations of the reference's floor, :302-308)
+ * per member inside one kernel (csrc/lo_solve_fused_impl.h).  The two BATCH-GLOBAL decisions of the reference cannot
+ * be taken inside (members are in flight at different times); they are checked after the launch and reported in
+ * `info->status`:
+ *   LO_FUSED_OK          x holds the reference's result (every member took all `rank` pivots on its own error and the
+ *                        stopping rule held at the floor) -- also when nan_detected / skipped are set
+ *   LO_FUSED_EARLY_STOP  some member's own pivot error reached error_tol (or NaN) before `rank` pivots: the shared
+ *                        pivot count (_pivoted_cholesky.py:57) needs the three-launch path
+ *   LO_FUSED_CONTINUE    the tolerance was not met at the floor: CG has to continue (three-launch path)
+ *   LO_FUSED_TIMEOUT     a group exchange timed out (co-residency lost)
+ * In the last three cases x is NOT valid and the caller redoes the solve with lo_pivoted_cholesky_f32 +
+ * lo_precond_root_form_f32 / lo_precond_build_f32 + lo_cg_solve_f32.
+ *   op       LO_OP_LOWRANK_DIAG, R in {8, 16, 32}, 256 <= N <= 8192, diag FULL or CONST
+ *   rank     pivots (settings.max_preconditioner_size, 1..16), error_tol = settings.preconditioner_tolerance
+ *   prm      as lo_cg_solve_f32 (n_tridiag == 0, no stop_reduce, c <= 8)
+ *   x        [B, N, c] out
+ *   F, EF, E [B, R, R] out, dinv [B, N] | [B] out, logdet_p [B] out: the root-form preconditioner for later solves
+ *            (any may be NULL); swaps [B, rank] int32 out: position exchanged with position m at pivot m -- the
+ *            reference's permutation is the identity with these exchanges applied in order (lo_solve_fused_perm)
+ * SYNCHRONOUS (one read-back of the status block).  lo_solve_fused_supported: 1 if the shape is taken.            */
+#define LO_FUSED_OK 0
+#define LO_FUSED_EARLY_STOP 1
+#define LO_FUSED_CONTINUE 2
+#define LO_FUSED_TIMEOUT 3
+typedef struct lo_fused_info {
+  int32_t status;            /* LO_FUSED_*                                                         */
+  int32_t iterations;        /* as lo_cg_info                                                      */
+  int32_t matvecs;
+  int32_t tolerance_reached;
+  int32_t nan_detected;
+  int32_t skipped;
+  int32_t rank;              /* pivots taken (= rank when status is LO_FUSED_OK)                   */
+  float mean_residual;
+} lo_fused_info;
+int lo_solve_fused_supported(const lo_op_desc* op, int32_t rank, const lo_cg_params* prm);
+size_t lo_solve_fused_workspace_bytes(const lo_op_desc* op, int32_t rank, const lo_cg_params* prm);
+int lo_solve_fused_f32(const lo_op_desc* op, int32_t rank, float error_tol, const lo_cg_params* prm, const float* rhs,
+                       float* x, float* F, float* EF, float* E, float* dinv, float* logdet_p, int32_t* swaps,
+                       void* ws, size_t ws_bytes, lo_fused_info* info, void* stream);
+int lo_solve_fused_perm(const int32_t* swaps, int64_t B, int64_t N, int32_t rank, int64_t* perm, void* stream);
+
 /* Development / test switch: 0 forces the streaming (multi-kernel) engine, 1 (default) allows the operator-resident
  * fast path (csrc/lo_cg_onchip.hip) for low-rank + Woodbury-preconditioned single-column solves.  Same results
  * up to summation order. */

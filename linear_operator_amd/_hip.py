@@ -19,15 +19,17 @@ _lib = None
 LO_OP_LOWRANK_DIAG, LO_OP_DENSE_DIAG, LO_OP_KRON_DIAG, LO_OP_CALLBACK, LO_OP_SUM = 0, 1, 2, 3, 4
 LO_MAX_TERMS = 4
 LO_DIAG_NONE, LO_DIAG_FULL, LO_DIAG_CONST = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 LO_ERR_UNSUPPORTED = -4
+LO_FUSED_OK, LO_FUSED_EARLY_STOP, LO_FUSED_CONTINUE, LO_FUSED_TIMEOUT = 0, 1, 2, 3
 _ERR = {-1: "bad argument", -2: "HIP launch/runtime failure", -3: "workspace too small", -4: "unsupported shape"}
 
 EXPORTS = [
     "lo_abi_version", "lo_target_arch",
     "lo_matvec_workspace_bytes", "lo_matvec_f32",
     "lo_cg_workspace_bytes", "lo_cg_solve_f32", "lo_cg_set_onchip",
+    "lo_solve_fused_supported", "lo_solve_fused_workspace_bytes", "lo_solve_fused_f32", "lo_solve_fused_perm",
     "lo_cg_f64_workspace_bytes", "lo_cg_solve_f64", "lo_minres_f64_workspace_bytes", "lo_minres_f64",
     "lo_pivoted_cholesky_workspace_bytes", "lo_pivoted_cholesky_f32",
     "lo_pivoted_cholesky_cb_workspace_bytes", "lo_pivoted_cholesky_cb_f32",
@@ -77,6 +79,12 @@ class CgInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("matvecs", C.c_int32), ("tolerance_reached", C.c_int32),
                 ("nan_detected", C.c_int32), ("skipped", C.c_int32), ("last_tridiag_iter", C.c_int32),
                 ("mean_residual", C.c_float), ("reserved", C.c_float)]
+
+
+class FusedInfo(C.Structure):
+    _fields_ = [("status", C.c_int32), ("iterations", C.c_int32), ("matvecs", C.c_int32),
+                ("tolerance_reached", C.c_int32), ("nan_detected", C.c_int32), ("skipped", C.c_int32),
+                ("rank", C.c_int32), ("mean_residual", C.c_float)]
 
 
 class CgParamsF64(C.Structure):
@@ -149,6 +157,16 @@ def load():
     lib.lo_cg_solve_f32.argtypes = [P(OpDesc), MATVEC_CB, C.c_void_p, P(PrecondDesc), MATVEC_CB, C.c_void_p,
                                     P(CgParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz,
                                     P(CgInfo), C.c_void_p]
+    lib.lo_solve_fused_supported.restype = C.c_int
+    lib.lo_solve_fused_supported.argtypes = [P(OpDesc), C.c_int32, P(CgParams)]
+    lib.lo_solve_fused_workspace_bytes.restype = sz
+    lib.lo_solve_fused_workspace_bytes.argtypes = [P(OpDesc), C.c_int32, P(CgParams)]
+    lib.lo_solve_fused_f32.restype = C.c_int
+    lib.lo_solve_fused_f32.argtypes = [P(OpDesc), C.c_int32, C.c_float, P(CgParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz,
+                                       P(FusedInfo), C.c_void_p]
+    lib.lo_solve_fused_perm.restype = C.c_int
+    lib.lo_solve_fused_perm.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     lib.lo_cg_f64_workspace_bytes.restype = sz
     lib.lo_cg_f64_workspace_bytes.argtypes = [C.c_int64, C.c_int64, P(CgParamsF64)]
     lib.lo_cg_solve_f64.restype = C.c_int

@@ -26,6 +26,7 @@
 namespace lo {
 
 bool g_onchip_disabled = false;
+int g_onchip_fused_timeouts = 0;
 static thread_local bool tls_no_fused_precond = false;  // set while a solve is redone after a timed-out hand-off
 
 // hipGraph of one CG iteration: captured on a private side stream, replayed on the caller's stream.

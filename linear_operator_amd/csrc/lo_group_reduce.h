@@ -31,14 +31,17 @@ __device__ __forceinline__ int q_slot(int r, int q) {
 // The components come from a generator so that only n/2 temporaries are ever live (component j and j + n/2 are
 // formed right before their first halving step).
 template <int n, class Gen>
-__device__ __forceinline__ float r4_wave_rs(Gen gen) {
-  const int lane = threadIdx.x & 63;
+__device__ __forceinline__ float r4_wave_rs_t(Gen gen, const int lane) {
   constexpr int h0 = n / 2;
   float w[h0];
 #pragma unroll
   for (int j = 0; j < h0; ++j) w[j] = halve_pair<32>(gen(j), gen(j + h0), lane);
   halving_steps<h0, 16, h0>(w, lane);
   return w[0];
+}
+template <int n, class Gen>
+__device__ __forceinline__ float r4_wave_rs(Gen gen) {
+  return r4_wave_rs_t<n>(gen, (int)(threadIdx.x & 63));
 }
 
 struct R4Group {
@@ -123,14 +126,15 @@ __device__ __forceinline__ void pf_collect(R4Shared& sh, int cnt, R4Group& g, co
 // Second half of an all-reduce: sh.red[w][0..cnt) hold the wave partials.  Thread t < cnt sums them (fixed
 // order), publishes the granule, polls the same component of every workgroup of the group and sums those in fixed
 // order -> sh.res[t], bitwise identical in all workgroups.  Ends with a barrier.
+// (the _t variants take the thread index from the caller: a kernel with several phases passes a per-phase opaque copy
+// so that the addresses derived from it are not hoisted to the kernel entry and kept live -- or spilled -- throughout)
 template <int GW>
-__device__ __forceinline__ void r4_group_sum(R4Shared& sh, int cnt, R4Group& g) {
+__device__ __forceinline__ void r4_group_sum_t(R4Shared& sh, int cnt, R4Group& g, const int t) {
   if constexpr (GW == 64) {  // (cnt <= 64: one owner workgroup per entry; granule layout [2][GW + 1][R4_SLOT])
     const PfSlots ps = pf_publish<64>(sh, cnt, g);
     pf_collect<64>(sh, cnt, g, ps);
     return;
   }
-  const int t = threadIdx.x;
   const unsigned tag = ++g.tag;
   long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
   const bool stamp = g.dbg && t == 0;
@@ -215,18 +219,28 @@ __device__ __forceinline__ void r4_group_sum(R4Shared& sh, int cnt, R4Group& g) 
   __syncthreads();
 }
 
+template <int GW>
+__device__ __forceinline__ void r4_group_sum(R4Shared& sh, int cnt, R4Group& g) {
+  r4_group_sum_t<GW>(sh, cnt, g, (int)threadIdx.x);
+}
+
 // all-reduce of n generated components + ns scalars over the whole group -> sh.res[0 .. n + ns)
 template <int GW, int n, class Gen>
-__device__ __forceinline__ void r4_allreduce(R4Shared& sh, Gen gen, const float* scal, int ns, R4Group& g) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+__device__ __forceinline__ void r4_allreduce_t(R4Shared& sh, Gen gen, const float* scal, int ns, R4Group& g,
+                                               const int t) {
+  const int lane = t & 63, wave = t >> 6;
   constexpr int sh_bits = (n == 32) ? 1 : (n == 16) ? 2 : (n == 8) ? 3 : 4;
-  const float mine = r4_wave_rs<n>(gen);
+  const float mine = r4_wave_rs_t<n>(gen, lane);
   if ((lane & ((1 << sh_bits) - 1)) == 0) sh.red[wave][lane >> sh_bits] = mine;
   for (int j = 0; j < ns; ++j) {
     const float sv = wave_sum_fast(scal[j]);
     if (lane == 0) sh.red[wave][n + j] = sv;
   }
-  r4_group_sum<GW>(sh, n + ns, g);
+  r4_group_sum_t<GW>(sh, n + ns, g, t);
+}
+template <int GW, int n, class Gen>
+__device__ __forceinline__ void r4_allreduce(R4Shared& sh, Gen gen, const float* scal, int ns, R4Group& g) {
+  r4_allreduce_t<GW, n>(sh, gen, scal, ns, g, (int)threadIdx.x);
 }
 
 template <int GW>

@@ -55,13 +55,13 @@ def global_stopping_rule(group=None, reducer: Optional[Callable] = None):
     execute exactly the iterations the unsharded run executes.  Outside it ("option B") each shard applies the rule to
     its own members -- identical whenever CG ends at its iteration floors.  `reducer`: custom callable(list[3]) ->
     list[3] (tests)."""
-    prev = getattr(_local, "stop_reduce", None)
+    prev, prev_group = getattr(_local, "stop_reduce", None), getattr(_local, "group", None)
     _local.stop_reduce = reducer if reducer is not None else StopReduce(group)
     _local.group = group
     try:
         yield _local.stop_reduce
     finally:
-        _local.stop_reduce = prev
+        _local.stop_reduce, _local.group = prev, prev_group
 
 
 def global_max_int(value: int) -> int:

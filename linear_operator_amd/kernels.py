@@ -152,6 +152,7 @@ class WoodburyPreconditioner:
     EF: Optional[torch.Tensor] = None
     E: Optional[torch.Tensor] = None
     source: Optional[tuple] = None  # (L, d) the preconditioner was built from (to build Q later)
+    rebuild: Optional[Callable] = None  # root form from the fused solve (no L exists): () -> the full preconditioner
 
     @property
     def rf_ld(self) -> int:
@@ -160,9 +161,14 @@ class WoodburyPreconditioner:
     def ensure_q(self) -> "WoodburyPreconditioner":
         """Build the generic (Q, dinv) form if this preconditioner only carries the root form."""
         if self.Q is None:
-            L, d = self.source
-            full = precond_build(L, d, self.constant_diag)
-            self.Q, self.dinv = full.Q, full.dinv
+            if self.source is not None:
+                L, d = self.source
+                full = precond_build(L, d, self.constant_diag)
+            elif self.rebuild is not None:
+                full = self.rebuild().ensure_q()
+            else:
+                raise _hip.HipExtensionError("root-form-only preconditioner without its factor: Q cannot be built")
+            self.Q, self.dinv, self.k = full.Q, full.dinv, full.k
         return self
 
     def c_struct(self) -> _hip.PrecondDesc:
@@ -172,7 +178,8 @@ class WoodburyPreconditioner:
         s.Q = None if self.Q is None else self.Q.data_ptr()
         s.dinv = self.dinv.data_ptr()
         if self.F is not None:
-            s.F, s.EF, s.E, s.rf_ld = self.F.data_ptr(), self.EF.data_ptr(), self.E.data_ptr(), self.rf_ld
+            s.F, s.EF, s.rf_ld = self.F.data_ptr(), self.EF.data_ptr(), self.rf_ld
+            s.E = None if self.E is None else self.E.data_ptr()
         return s
 
 
@@ -413,6 +420,89 @@ def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optio
         t_mat = t_mat[:, :, :m, :m].contiguous()
     return CGResult(x.reshape(rhs.shape), t_mat, info.iterations, info.matvecs, bool(info.tolerance_reached),
                     bool(info.nan_detected), bool(info.skipped), float(info.mean_residual))
+
+
+@dataclass
+class FusedSolveResult:
+    """Outcome of the one-launch end-to-end solve: the linear_cg result, the root-form preconditioner it built on the
+    way (for later solves with the same operator) and the recorded pivots."""
+
+    cg: CGResult
+    precond: WoodburyPreconditioner  # root form only (Q is None); `source` is None: L was never materialised
+    swaps: torch.Tensor  # [B, rank] int32: position exchanged with position m at pivot m
+    rank: int
+
+    def permutation(self, N: int) -> torch.Tensor:
+        """The reference's permutation [B, N] int64 (_pivoted_cholesky.py:47-48, :67-70) from the recorded exchanges."""
+        lib = _hip.load()
+        B = self.swaps.shape[0]
+        perm = torch.empty(B, N, dtype=torch.int64, device=self.swaps.device)
+        _hip.check(lib.lo_solve_fused_perm(_hip.ptr(self.swaps), B, N, self.rank, _hip.ptr(perm),
+                                           _hip.stream_ptr(perm.device)), "lo_solve_fused_perm")
+        return perm
+
+
+def _cg_params(c, n_tridiag, max_iter, max_tridiag_iter, tolerance, eps, stop_updating_after, floor_max_iter):
+    prm = _hip.CgParams()
+    prm.c, prm.n_tridiag, prm.max_iter, prm.max_tridiag_iter = c, n_tridiag, max_iter, max_tridiag_iter
+    prm.floor_max_iter = floor_max_iter
+    prm.tolerance, prm.eps, prm.stop_updating_after = tolerance, eps, stop_updating_after
+    return prm
+
+
+def solve_fused_supported(desc: Optional[OperatorDescriptor], c: int, rank: int, max_iter: int = 1000,
+                          floor_max_iter: int = 0) -> bool:
+    """True if lo_solve_fused_f32 takes this operator / right-hand side shape (see include/lo_amd.h)."""
+    if desc is None or desc.kind != _hip.LO_OP_LOWRANK_DIAG or desc.A0 is None or not desc.A0.is_cuda:
+        return False
+    prm = _cg_params(c, 0, max_iter, min(20, max_iter), 1.0, 1e-10, 1e-10, floor_max_iter)
+    s = desc.c_struct()
+    return bool(_hip.load().lo_solve_fused_supported(C.byref(s), int(rank), C.byref(prm)))
+
+
+def solve_fused(desc: OperatorDescriptor, rhs: torch.Tensor, rank: int, error_tol: float = 1e-3, *,
+                max_iter: int = 1000, tolerance: float = 1.0, eps: float = 1e-10, stop_updating_after: float = 1e-10,
+                floor_max_iter: int = 0) -> Optional[FusedSolveResult]:
+    """lo_solve_fused_f32: pivoted Cholesky (rank pivots) -> root-form preconditioner -> preconditioned CG of
+    AddedDiag(LowRankRoot, Diag) in ONE resident launch, the operator read once.  Returns None when the result would
+    not be the reference's (a member's own pivot error reached the tolerance before `rank` pivots, the CG tolerance was
+    not met at the iteration floor, or a group exchange timed out): the caller then takes the three-launch path."""
+    lib = _hip.load()
+    _hip.require_hip(rhs)
+    N, c = rhs.shape[-2:]
+    rhs3 = _flat(rhs, 2)
+    B = rhs3.shape[0]
+    if desc.B != B or desc.N != N:
+        raise RuntimeError(f"solve_fused: rhs {tuple(rhs.shape)} does not match operator batch {desc.B}, N {desc.N}")
+    dev = rhs.device
+    rank = min(int(rank), N)
+    prm = _cg_params(c, 0, max_iter, min(20, max_iter), tolerance, eps, stop_updating_after, floor_max_iter)
+    s = desc.c_struct()
+    if not lib.lo_solve_fused_supported(C.byref(s), rank, C.byref(prm)):
+        return None
+    R = desc.R
+    const = desc.diag_mode == _hip.LO_DIAG_CONST
+    x = torch.empty_like(rhs3)
+    F = torch.empty(B, R, R, dtype=torch.float32, device=dev)
+    EF, E = torch.empty_like(F), torch.empty_like(F)
+    dinv = torch.empty(B if const else (B, N), dtype=torch.float32, device=dev)
+    logdet = torch.empty(B, dtype=torch.float32, device=dev)
+    swaps = torch.empty(B, rank, dtype=torch.int32, device=dev)
+    ws = _hip.workspace(lib.lo_solve_fused_workspace_bytes(C.byref(s), rank, C.byref(prm)), dev)
+    info = _hip.FusedInfo()
+    rc = lib.lo_solve_fused_f32(C.byref(s), rank, float(error_tol), C.byref(prm), _hip.ptr(rhs3), _hip.ptr(x),
+                                _hip.ptr(F), _hip.ptr(EF), _hip.ptr(E), _hip.ptr(dinv), _hip.ptr(logdet),
+                                _hip.ptr(swaps), _hip.ptr(ws), ws.numel(), C.byref(info), _hip.stream_ptr(dev))
+    if rc == _hip.LO_ERR_UNSUPPORTED:
+        return None
+    _hip.check(rc, "lo_solve_fused_f32")
+    if info.status != _hip.LO_FUSED_OK:
+        return None
+    pre = WoodburyPreconditioner(None, dinv, rank, const, logdet.reshape(desc.batch_shape) if desc.batch_shape else logdet,
+                                 F, EF, E)
+    cg = CGResult(x.reshape(rhs.shape), None, info.iterations, info.matvecs, bool(info.tolerance_reached),
+                  bool(info.nan_detected), bool(info.skipped), float(info.mean_residual))
+    return FusedSolveResult(cg, pre, swaps, rank)
 
 
 def cg_solve_f64(A: Optional[torch.Tensor], diag: Optional[torch.Tensor], rhs: torch.Tensor, *,

@@ -38,6 +38,69 @@ class WoodburyPreconditionClosure:
         return z.squeeze(-1) if is_vec else z
 
 
+class LazyWoodburyPreconditionClosure:
+    """What `_solve_preconditioner` hands to `_solve` when the operator qualifies for the ONE-LAUNCH end-to-end solve
+    (csrc/lo_solve_fused_impl.h): the same closure as `_preconditioner()[0]`, but nothing is factorised yet.
+    `utils.linear_cg` recognises it (attribute `lazy_fused`) and, when its `matmul_closure` is the `_matmul` of the very
+    operator this closure belongs to, runs pivoted Cholesky -> root-form preconditioner -> CG in one resident kernel and
+    hands the root form back through `adopt` (memoised for later solves with the same tensors).  Any other use --
+    calling it, asking for `.woodbury`, a CG call the fused kernel does not take -- materialises the ordinary
+    preconditioner first, so the object is a drop-in for the reference's closure (added_diag_linear_operator.py:135-140).
+    """
+
+    lazy_fused = True
+
+    def __init__(self, owner, desc, rank, tol, memo_key, memo_tensors):
+        self._owner, self.desc, self.rank, self.tol = owner, desc, int(rank), float(tol)
+        self._memo_key, self._memo_tensors = memo_key, memo_tensors
+        self.batch_shape = torch.Size(owner.batch_shape)
+        self._real = None
+        self._done = False
+
+    @property
+    def pending(self) -> bool:
+        return not self._done
+
+    def same_operator(self, desc) -> bool:
+        """True if `desc` (lowered from linear_cg's matmul_closure) is this closure's operator: same tensors."""
+        mine = self.desc
+        return (desc is not None and desc.kind == mine.kind and desc.diag_mode == mine.diag_mode
+                and desc.A0 is not None and desc.d is not None and (desc.B, desc.N, desc.R) == (mine.B, mine.N, mine.R)
+                and desc.A0.data_ptr() == mine.A0.data_ptr() and desc.d.data_ptr() == mine.d.data_ptr())
+
+    def materialize(self):
+        """The ordinary closure (three-launch build through `_preconditioner`), or None (NaN in the factor: the
+        reference continues without a preconditioner, :126-131)."""
+        if not self._done:
+            self._real, self._done = self._owner._preconditioner()[0], True
+        return self._real
+
+    def adopt(self, woodbury):
+        """Root-form preconditioner the fused solve built on the way: becomes this closure's preconditioner and is
+        memoised under the operator's tensors for later solves (a later call that needs Q or L rebuilds in full)."""
+        woodbury.rebuild = lambda: self._rebuild_full()
+        self._real = WoodburyPreconditionClosure(woodbury, self.batch_shape)
+        self._done = True
+        if PRECONDITIONER_MEMO_SIZE > 0 and self._memo_key is not None:
+            _rootform_memo.insert(0, (self._memo_key, self._memo_tensors, woodbury))
+            del _rootform_memo[PRECONDITIONER_MEMO_SIZE:]
+
+    def _rebuild_full(self):
+        closure = self._owner._preconditioner()[0]
+        if closure is None:
+            raise K._hip.HipExtensionError("the preconditioner could not be rebuilt (NaN in the pivoted Cholesky factor)")
+        return closure.woodbury
+
+    @property
+    def woodbury(self):
+        real = self.materialize()
+        return None if real is None else real.woodbury
+
+    def __call__(self, tensor: Tensor) -> Tensor:
+        real = self.materialize()
+        return tensor.clone() if real is None else real(tensor)
+
+
 # Memo of the last preconditioners, keyed on the operator's tensors (address, version counter, layout) and the settings
 # that shape the factorisation.  The reference caches the preconditioner on the operator OBJECT, but its autograd
 # Functions rebuild the operator from its tensors (functions/_solve.py:40), so a solve followed by a logdet, or the
@@ -45,6 +108,9 @@ class WoodburyPreconditionClosure:
 # (so an address cannot be reused by other data) and any in-place update bumps the version counter.
 PRECONDITIONER_MEMO_SIZE = 2
 _precond_memo: "list[tuple]" = []
+# root-form-only preconditioners the fused end-to-end solve produced (no L, no Q): enough for later SOLVES with the
+# same tensors; `_preconditioner()` (probe sampling, logdet terms) ignores them and builds in full
+_rootform_memo: "list[tuple]" = []
 
 
 def _memo_key(tensors, extra):
@@ -52,12 +118,20 @@ def _memo_key(tensors, extra):
     Writes through `.data` do not bump the version counter -- call clear_preconditioner_memo() after such updates."""
     if any(t.is_inference() for t in tensors):
         return None
+    # a preconditioner built under distributed.global_stopping_rule carries the rank ALL shards agreed on (a collective
+    # ran while it was built): it must not be confused with one built outside the context or under another group, and
+    # every rank has to take the same hit / miss decision -- no memo at all inside the context
+    from .. import distributed
+
+    if distributed.active_stop_reduce() is not None:
+        return None
     return tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype) for t in tensors) + extra
 
 
 def clear_preconditioner_memo():
     """Drop the memoised preconditioners (and the references to the tensors they were built from)."""
     _precond_memo.clear()
+    _rootform_memo.clear()
 
 
 class AddedDiagLinearOperator(SumLinearOperator):
@@ -126,6 +200,37 @@ class AddedDiagLinearOperator(SumLinearOperator):
         return self.__class__(self._linear_op + other, self._diag_tensor)
 
     # ------------------------------------------------------------------ preconditioner (reference :95-184)
+    def _precond_memo_key(self):
+        tensors = self.representation()
+        return tensors, _memo_key(tensors, (settings.max_preconditioner_size.value(),
+                                            settings.preconditioner_tolerance.value(), type(self._linear_op),
+                                            type(self._diag_tensor)))
+
+    def _solve_preconditioner(self):
+        """`_preconditioner()[0]` (reference _linear_operator.py:805), deferred when the solve can run as ONE resident
+        launch (LazyWoodburyPreconditionClosure): low-rank root of 8 / 16 / 32 columns plus a diagonal, fp32 on the
+        device, nothing memoised for these tensors yet, no batch-global stopping rule over ranks."""
+        if (self.preconditioner_override is not None or self._q_cache is not None
+                or settings.max_preconditioner_size.value() == 0
+                or self.size(-1) < settings.min_preconditioning_size.value()):
+            return super()._solve_preconditioner()
+        from .. import distributed
+
+        if distributed.active_stop_reduce() is not None or self.device.type != "cuda" or self.dtype != torch.float32:
+            return super()._solve_preconditioner()
+        tensors, key = self._precond_memo_key()
+        if key is not None:
+            if any(entry[0] == key for entry in _precond_memo):
+                return super()._solve_preconditioner()
+            for entry in _rootform_memo:
+                if entry[0] == key:
+                    return WoodburyPreconditionClosure(entry[2], self.batch_shape)
+        desc = self._kernel_descriptor()
+        rank = min(settings.max_preconditioner_size.value(), self.size(-1))
+        if desc is None or not K.solve_fused_supported(desc, 1, rank, settings.max_cg_iterations.value()):
+            return super()._solve_preconditioner()
+        return LazyWoodburyPreconditionClosure(self, desc, rank, settings.preconditioner_tolerance.value(), key, tensors)
+
     def _preconditioner(self):
         if self.preconditioner_override is not None:
             return self.preconditioner_override(self)
@@ -133,9 +238,7 @@ class AddedDiagLinearOperator(SumLinearOperator):
             return None, None, None
         if self._q_cache is None:
             max_iter = settings.max_preconditioner_size.value()
-            tensors = self.representation()
-            key = _memo_key(tensors, (max_iter, settings.preconditioner_tolerance.value(), type(self._linear_op),
-                                      type(self._diag_tensor)))
+            tensors, key = self._precond_memo_key()
             for entry in (_precond_memo if key is not None else ()):
                 if entry[0] == key:
                     (self._piv_chol_self, self._piv_chol_perm, self._woodbury, self._q_cache,
@@ -167,6 +270,11 @@ class AddedDiagLinearOperator(SumLinearOperator):
         desc = self._linear_op._kernel_descriptor()
         if desc is None or desc.diag_mode != 0 or self.device.type != "cuda" or self.dtype != torch.float32:
             L, perm = self._linear_op.pivoted_cholesky(rank=max_iter, return_pivots=True)
+            from .. import distributed
+
+            m_global = distributed.global_max_int(L.shape[-1])  # (shared rank over all shards, as on the lowered path)
+            if m_global > L.shape[-1]:
+                L, perm = self._linear_op.pivoted_cholesky(rank=m_global, error_tol=0.0, return_pivots=True)
             self._piv_chol_perm = perm  # (the backward pass of the preconditioner terms needs the pivots here too)
             # detached: the rest of the cache is built by kernels outside autograd and the factor's derivative is
             # chained by hand (functions/_inv_quad_logdet._add_preconditioner_terms), exactly as on the lowered path
@@ -216,4 +324,4 @@ class AddedDiagLinearOperator(SumLinearOperator):
         return rebuilt._linear_op + rebuilt._diag_tensor
 
 
-__all__ = ["AddedDiagLinearOperator", "WoodburyPreconditionClosure"]
+__all__ = ["AddedDiagLinearOperator", "WoodburyPreconditionClosure", "LazyWoodburyPreconditionClosure"]

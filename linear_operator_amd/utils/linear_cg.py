@@ -129,15 +129,31 @@ def linear_cg(
         closure = None
         if desc is None:
             closure = matmul_closure.matmul if torch.is_tensor(matmul_closure) else matmul_closure
+        res = None
+        if getattr(preconditioner, "lazy_fused", False) and preconditioner.pending:
+            # AddedDiagLinearOperator._solve_preconditioner deferred the factorisation: when this call is what the
+            # one-launch kernel computes (the closure's own operator, no tridiagonals, zero initial guess, the rule of
+            # this process only) pivoted Cholesky, root-form preconditioner and CG run in ONE resident launch
+            lazy = preconditioner
+            if (n_tridiag == 0 and initial_guess is None and _active_stop_reduce() is None
+                    and lazy.same_operator(desc) and rhs.is_cuda):
+                fused = K.solve_fused(desc, rhs, lazy.rank, lazy.tol, max_iter=n_iter, tolerance=float(tolerance),
+                                      eps=float(eps), stop_updating_after=float(stop_updating_after),
+                                      floor_max_iter=max_iter)
+                if fused is not None:
+                    lazy.adopt(fused.precond)
+                    res = fused.cg
+            if res is None:
+                preconditioner = lazy.materialize()  # the ordinary three-launch build (or None: NaN in the factor)
         woodbury, precond_closure = None, None
-        if preconditioner is not None:
+        if preconditioner is not None and res is None:
             woodbury = getattr(preconditioner, "woodbury", None)
-            if woodbury is not None and tuple(woodbury.Q.shape[:-2]) != (max(1, batch_shape.numel()),):
+            if woodbury is not None and int(woodbury.dinv.shape[0]) != max(1, batch_shape.numel()):
                 woodbury = None
             if woodbury is None:
                 precond_closure = preconditioner
 
-        res = K.cg_solve(
+        res = res if res is not None else K.cg_solve(
             desc, rhs, x0=initial_guess, precond=woodbury, matvec_closure=closure, precond_closure=precond_closure,
             n_tridiag=n_tridiag, max_iter=n_iter, max_tridiag_iter=n_tridiag_iter, tolerance=float(tolerance),
             eps=float(eps), stop_updating_after=float(stop_updating_after), floor_max_iter=max_iter,

@@ -163,12 +163,22 @@ def test_hip_kernels_under_an_rccl_process_group_with_a_collective_in_flight():
         assert torch.equal(bufs[1], ref.x)
         # the batch-global stopping rule through a real RCCL all_reduce (world 1: same decision as the local rule)
         A = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C[:8])), DiagLinearOperator(dev(d[:8])))
+        from linear_operator_amd.operators.added_diag_linear_operator import clear_preconditioner_memo
+
         with settings.cg_tolerance(1e-4):
-            x_local = A.solve(dev(rhs[:8]))
+            x_fused = A.solve(dev(rhs[:8]))  # local rule: the one-launch end-to-end solve
+            clear_preconditioner_memo()
+            os.environ["LO_NO_FUSED_SOLVE"] = "1"  # local rule on the three-launch path: what the global rule runs on
+            try:
+                x_local = A.solve(dev(rhs[:8]))
+            finally:
+                del os.environ["LO_NO_FUSED_SOLVE"]
+            clear_preconditioner_memo()
             with D.global_stopping_rule() as red:
                 x_glob = A.solve(dev(rhs[:8]))
             assert isinstance(red, D.StopReduce) and red.calls >= 1
         assert torch.equal(x_local, x_glob)
+        assert max_rel_err_cols(x_fused.cpu().numpy(), x_glob.cpu().numpy()) < 2e-5
         # factory sharding: only the local slice is built, gathered result = full result
         built = []
 
