@@ -36,7 +36,7 @@ from linear_operator_amd import kernels as K  # noqa: E402
 B_PER_GPU, N, R, C_COLS, RANK_K = 512, 8192, 32, 1, 15
 TOL = 1e-4
 ITERS_FLOOR = 11  # linear_cg.py:303 -- the iterations the operator-resident kernel runs in one launch
-PROFILE_DIR = "r02"  # profiles/<dir>/ holds the rocprofv3 summaries of this command (tools/profile_round.sh)
+PROFILE_DIR = "r03"  # profiles/<dir>/ holds the rocprofv3 summaries of this command (tools/profile_round.sh)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0  # the guide's measured float4-copy rate: the ceiling a streaming kernel can reach
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (v_mfma_f32_16x16x4_f32 / 32x32x2, MI355X_MICROARCH.md)
@@ -219,9 +219,30 @@ def other_configs(device):
     Cm = torch.randn(64, N, R, generator=g, device=device) / (R ** 0.5)
     d = torch.rand(64, N, generator=g, device=device) + 0.5
     rhs = torch.randn(64, N, 1, generator=g, device=device)
+    from linear_operator_amd import settings as lo_settings
+    from linear_operator_amd.operators import AddedDiagLinearOperator, DiagLinearOperator, LowRankRootLinearOperator
+    from linear_operator_amd.operators.added_diag_linear_operator import clear_preconditioner_memo
+
+    A2 = AddedDiagLinearOperator(LowRankRootLinearOperator(Cm), DiagLinearOperator(d))
+
+    def cfg2_solve():  # the public path, nothing memoised: one resident launch (lo_solve_fused_f32)
+        clear_preconditioner_memo()
+        return A2.solve(rhs)
+
+    with lo_settings.cg_tolerance(TOL):
+        t, x2 = _time(cfg2_solve, 5)
+    res["cfg2_B64_solve_end_to_end"] = {"ms": t * 1e3, "solves_per_s": 64 / t, "path": "A.solve(rhs), operator API",
+                                        "solve_rel_err": woodbury_fp64_rel_err(Cm, d, rhs, x2)}
+    with lo_settings.cg_tolerance(TOL):
+        prof = _profiled(cfg2_solve)
+    clear_preconditioner_memo()
+    if "solve_fused" in prof:
+        roofs.append(_roof("k_solve_fused<32,8,false>", "cfg2: 64 members, pivoted Cholesky + root form + 11 CG iterations "
+                           "in one launch", prof["solve_fused"], "hbm", 4 * 64 * (N * (R + 3) + 3 * R * R + N),
+                           "compulsory bytes per launch: C, d, rhs in; x, 1/d, F, EF, E out.  64 members = one round of "
+                           "the 64 resident groups: the launch time is the latency of ONE member's chain of 15 pivot "
+                           "exchanges and 12 CG all-reduces"))
     desc = K.lowrank_diag_descriptor(Cm, d)
-    t, _ = _time(lambda: K.cg_solve(desc, rhs, precond=build_precond(desc, d, need_q=False), tolerance=TOL), 5)
-    res["cfg2_B64_solve_end_to_end"] = {"ms": t * 1e3, "solves_per_s": 64 / t}
     # cfg3: batch 512, 16 probes + 1 rhs, CG with tridiagonals + SLQ logdet (preconditioner build included)
     Cm = torch.randn(B_PER_GPU, N, R, generator=g, device=device) / (R ** 0.5)
     d = torch.rand(B_PER_GPU, N, generator=g, device=device) + 0.5
@@ -645,14 +666,41 @@ def main():
     value = total_members * matvecs_per_solve * args.steps / elapsed
 
     # ---- end-to-end solves/s (pivoted Cholesky + preconditioner build + CG), local rank ----
+    # Through the PUBLIC path: A.solve(rhs) of AddedDiagLinearOperator(LowRankRootLinearOperator(C), DiagLinearOperator(d))
+    # -> Solve Function -> _solve_preconditioner -> utils.linear_cg, nothing memoised (the memo is cleared before every
+    # solve: a new operator every time, as in a training loop).  This is the one-launch kernel lo_solve_fused_f32.
+    from linear_operator_amd import settings as lo_settings
+    from linear_operator_amd.operators import AddedDiagLinearOperator, DiagLinearOperator, LowRankRootLinearOperator
+    from linear_operator_amd.operators.added_diag_linear_operator import clear_preconditioner_memo
+
+    A_op = AddedDiagLinearOperator(LowRankRootLinearOperator(Cm), DiagLinearOperator(d))
+
+    def e2e_api():
+        clear_preconditioner_memo()
+        return A_op.solve(rhs)
+
+    def e2e_three_launch():  # the same work as three resident launches (round 2's path), kernel-level calls
+        p2 = build_precond(desc, d, need_q=False)
+        return K.cg_solve(desc, rhs, precond=p2, tolerance=TOL)
+
+    with lo_settings.cg_tolerance(TOL):
+        for _ in range(2):
+            x_e2e = e2e_api()
+        fence()
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            x_e2e = e2e_api()
+        fence()
+        e2e = (time.perf_counter() - t1) / reps
+    e2e_three_launch()
     fence()
     t1 = time.perf_counter()
-    reps = 3
-    for _ in range(reps):
-        p2 = build_precond(desc, d, need_q=False)  # (the resident kernel needs the root form only)
-        K.cg_solve(desc, rhs, precond=p2, tolerance=TOL)
+    for _ in range(3):
+        e2e_three_launch()
     fence()
-    e2e = (time.perf_counter() - t1) / reps
+    e2e3 = (time.perf_counter() - t1) / 3
+    clear_preconditioner_memo()
     if use_dist:
         t = torch.tensor([e2e], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -767,6 +815,11 @@ def main():
                                   "equivalent_GBs": mv_alg / mv_s / 1e9, "north_star_budget_us": 122.0, "note": mv_note},
             "solves_per_sec_end_to_end": total_members / e2e,
             "end_to_end_ms": e2e * 1e3,
+            "end_to_end_path": "A.solve(rhs) through the operator API, preconditioner memo cleared before every solve: "
+                               "pivoted Cholesky + root-form preconditioner + CG in ONE resident launch "
+                               "(lo_solve_fused_f32)",
+            "end_to_end_solve_rel_err": woodbury_fp64_rel_err(Cm, d, rhs, x_e2e),
+            "end_to_end_three_launch_ms": e2e3 * 1e3,
             "kernels": kernels,
             "final_mean_residual": res.mean_residual,
             "solve_rel_err": solve_rel_err,
@@ -777,8 +830,24 @@ def main():
             "per_rank_ms": per_rank_ms,
             "allgather_ms": allgather_ms,
         }
+        # the one-launch end-to-end kernel at the headline shape: live HIP-event time, compulsory bytes per launch
+        with lo_settings.cg_tolerance(TOL):
+            prof_e = _profiled(e2e_api)
+        clear_preconditioner_memo()
+        fused_roof = None
+        if "solve_fused" in prof_e:
+            fused_roof = _roof("k_solve_fused<32,8,false>", "headline shape end to end: 512 members, rank-15 pivoted "
+                               "Cholesky + root-form preconditioner + 11 CG iterations in ONE launch", prof_e["solve_fused"],
+                               "hbm", 4 * B_PER_GPU * (N * (R + 3) + 3 * R * R + N),
+                               "compulsory bytes per launch: C, d, rhs in; x, 1/d, F, EF, E out (L is never written).  "
+                               "Bound by the latency chain of 15 pivot exchanges + 12 CG all-reduces per member at two "
+                               "waves per SIMD (C in 128 VGPRs per lane), not by HBM",
+                               _committed_traffic("traffic_fused.json"))
+            out["end_to_end_kernel"] = fused_roof
         if world == 1 and not args.no_extras:
             out["other_configs"], out["rooflines"] = other_configs(device)
+            if fused_roof is not None:
+                out["rooflines"].insert(0, fused_roof)
         if strong:
             out["other_configs"] = strong
         if world == 1 and not args.no_cpu_baseline:

@@ -94,10 +94,17 @@ struct FuLayout {
 
 static constexpr int kFuMaxWgs = 1024;  // two workgroups per CU on up to 512 CUs
 
-static void fu_layout(int64_t B, int rank, int iters, int64_t c, Arena& ar, FuLayout* l) {
-  l->pgbuf = ar.take<unsigned long long>((size_t)kFuMaxWgs * 2 * FU_SLOT);
-  l->egbuf = ar.take<unsigned long long>((size_t)kFuMaxWgs * FU_ESLOT);
-  l->cgbuf = ar.take<unsigned long long>((size_t)kFuMaxWgs * 2 * R4_SLOT);
+// pinned host landing zone of the status block (a copy to pageable memory is staged and slow); one per host thread
+static FusedCtrl* pinned_ctrl() {
+  static thread_local FusedCtrl* p = nullptr;
+  if (!p && hipHostMalloc(reinterpret_cast<void**>(&p), sizeof(FusedCtrl), hipHostMallocDefault) != hipSuccess) p = nullptr;
+  return p;
+}
+
+static void fu_layout(int64_t B, int rank, int iters, int64_t c, int nwgs, Arena& ar, FuLayout* l) {
+  l->pgbuf = ar.take<unsigned long long>((size_t)nwgs * 2 * FU_SLOT);
+  l->egbuf = ar.take<unsigned long long>((size_t)nwgs * FU_ESLOT);
+  l->cgbuf = ar.take<unsigned long long>((size_t)nwgs * 2 * R4_SLOT);
   l->ints = ar.take<int>(8);
   l->zero_bytes = (size_t)(reinterpret_cast<char*>(l->ints + 8) - reinterpret_cast<char*>(l->pgbuf));
   l->err_rec = ar.take<float>((size_t)rank * B);
@@ -143,7 +150,7 @@ size_t lo_solve_fused_workspace_bytes(const lo_op_desc* op, int32_t rank, const 
   if (!op || !prm) return 0;
   Arena ar(nullptr, 0);
   FuLayout l;
-  fu_layout(op->B, rank, fused_iters(prm), prm->c, ar, &l);
+  fu_layout(op->B, rank, fused_iters(prm), prm->c, kFuMaxWgs, ar, &l);
   return ar.off + 1024;
 }
 
@@ -155,11 +162,11 @@ int lo_solve_fused_f32(const lo_op_desc* op, int32_t rank, float error_tol, cons
   hipStream_t st = (hipStream_t)stream;
   const int64_t B = op->B, N = op->N;
   const int iters = fused_iters(prm);
+  const int nwg = onchip_num_workgroups();
   Arena ar(ws, ws_bytes);
   FuLayout l;
-  fu_layout(B, rank, iters, prm->c, ar, &l);
+  fu_layout(B, rank, iters, prm->c, 2 * nwg, ar, &l);
   if (!ar.ok) return LO_ERR_WORKSPACE;
-  const int nwg = onchip_num_workgroups();
   FusedArgs a;
   a.C = op->A0; a.d = op->d; a.d_mode = op->diag_mode;
   a.rhs = rhs; a.xout = x; a.c = (int)prm->c;
@@ -190,15 +197,16 @@ int lo_solve_fused_f32(const lo_op_desc* op, int32_t rank, float error_tol, cons
                      B * prm->c, iters, fmi, prm->tolerance);
   LO_LAUNCH_CHECK();
   FusedCtrl h;
-  LO_HIP_CHECK(hipMemcpyAsync(&h, l.ctrl, sizeof(h), hipMemcpyDeviceToHost, st));
+  FusedCtrl* hp = pinned_ctrl();
+  LO_HIP_CHECK(hipMemcpyAsync(hp ? hp : &h, l.ctrl, sizeof(h), hipMemcpyDeviceToHost, st));
   LO_HIP_CHECK(hipStreamSynchronize(st));
+  if (hp) h = *hp;
   if (debug) {
     long long ts[16];
     LO_HIP_CHECK(hipMemcpy(ts, l.dbg, sizeof(ts), hipMemcpyDeviceToHost));
-    fprintf(stderr, "  E: scale+tile-mfma %lld, sums+publish+M %lld, fetch %lld | algebra: T,G %lld, chol+Y %lld, F,EF,store %lld\n",
-            ts[8] - ts[2], ts[9] - ts[8], ts[10] - ts[9], ts[11] - ts[3], ts[12] - ts[11], ts[4] - ts[12]);
-    fprintf(stderr, "solve_fused member %d (100 MHz ticks): load %lld pivots %lld E %lld algebra %lld CG %lld\n",
-            a.dbg_member, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4]);
+    fprintf(stderr, "solve_fused member %d (100 MHz ticks): load %lld E-partials %lld pivots %lld E-totals+M %lld algebra %lld "
+            "(T,G %lld chol+Y %lld F,EF %lld) CG %lld\n", a.dbg_member, ts[1] - ts[0], ts[8] - ts[1], ts[2] - ts[8],
+            ts[3] - ts[2], ts[4] - ts[3], ts[11] - ts[3], ts[12] - ts[11], ts[4] - ts[12], ts[5] - ts[4]);
   }
   info->status = h.status;
   info->iterations = h.iterations;

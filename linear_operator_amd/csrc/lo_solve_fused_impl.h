@@ -344,17 +344,122 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
         dg[q] = valid ? acc : 0.f;
         pos[q] = valid ? row0 + lr : FU_INVALID;
       }
-      __syncthreads();  // the windows are done: the L rows can be cleared
-#pragma unroll
-      for (int q = 0; q < R4_NR; ++q) {
-        const int lr = tl + R4_TPB * q;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) l_s[fu_l_slot(lr, i)] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      __syncthreads();  // the windows are done: region A is free for the row tile of the E phase
     }
     if (stamp) a.dbg[1] = wall_clock64();
+    // ================================ 2. E = C^T D^-1 C: partials ================================
+    // (before the pivots: region A is still free for the row tile, and the partials have the whole pivot phase to
+    // travel -- they are fetched afterwards without waiting)
+    // fp32 arithmetic for the row scales (IEEE division and square root, logf): the fp64 versions of the three-launch
+    // path cost ~1.5 us per member here; the partial sums of log d are still accumulated in fp64
+    float sq[R4_NR];  // 1 / sqrt(d) (CONST: 1, E is divided by sigma afterwards)
+    float dinvq[R4_NR];
+    double lsum = 0.0;
+    int te = t0;
+    asm volatile("" : "+v"(te));
+#pragma unroll
+    for (int q = 0; q < R4_NR; ++q) {
+      const int lr = te + R4_TPB * q;
+      const bool valid = lr < nv;
+      const float di = 1.0f / dq[q];
+      sq[q] = !valid ? 0.f : (d_full ? sqrtf(di) : 1.0f);
+      if (valid && d_full) lsum += (double)logf(dq[q]);
+      dq[q] = valid ? dq[q] : 0.f;
+      dinvq[q] = valid ? di : 0.f;
+      // (the diagonal and its inverse move to their CG slots only after the E phase: region A holds the row tile now)
+      if (a.dinv && valid && d_full) a.dinv[(size_t)b * a.N + row0 + lr] = di;
+    }
+    unsigned etg;
+    {
+      float* const tile = reinterpret_cast<float*>(regA);                       // [256][33]
+      double* const red = reinterpret_cast<double*>(regA + 256 * 33 * 4 + 64);  // [4][64][12]  (8-byte aligned)
+      const int wave_e = te >> 6, lane_e = te & 63;
+      const int aa = lane_e & 15, kk = lane_e >> 4;
+      double acc[NB][4];
+#pragma unroll
+      for (int bk = 0; bk < NB; ++bk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[bk][r] = 0.0;
+#pragma unroll
+      for (int q = 0; q < R4_NR; ++q) {
+        // every wave stages ITS OWN 64 rows (row set q) and multiplies them: no workgroup barrier
+        float* my = tile + te * 33;
+#pragma unroll
+        for (int i = 0; i < RC / 2; ++i) {
+          my[2 * i] = Cr[q][i].x * sq[q];
+          my[2 * i + 1] = Cr[q][i].y * sq[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // two 32-row tiles per row set: fp32 inside a tile, fp64 across tiles
+          fu_f32x4 t00 = {0.f, 0.f, 0.f, 0.f}, t01 = t00, t11 = t00;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int row = 64 * wave_e + 32 * h + 4 * e + kk;
+            const float w0 = (aa < RC) ? tile[row * 33 + aa] : 0.f;
+            t00 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, w0, t00, 0, 0, 0);
+            if constexpr (NB == 3) {
+              const float w1 = tile[row * 33 + aa + 16];
+              t01 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, w1, t01, 0, 0, 0);
+              t11 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, w1, t11, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[0][r] += (double)t00[r];
+            if constexpr (NB == 3) {
+              acc[1][r] += (double)t01[r];
+              acc[2][r] += (double)t11[r];
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();  // the next row set reuses the wave's tile rows
+      }
+#pragma unroll
+      for (int bk = 0; bk < NB; ++bk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[te * 12 + 4 * bk + r] = acc[bk][r];
+      const double lw = wave_sum_d(lsum);
+      if (lane_e == 0) red[4 * 64 * 12 + wave_e] = lw;
+      __syncthreads();
+      // entry e = 12 lane + 4 block + r of the workgroup partial: summed over the waves, published, fetched from every
+      // workgroup of the group and summed in fixed order (fp64) -> identical bits in all workgroups
+      const unsigned tg = ++etag;
+      etg = tg;
+      constexpr int NE = 64 * 12;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int e = te + R4_TPB * s;
+        const double v = (red[e] + red[NE + e]) + (red[2 * NE + e] + red[3 * NE + e]);
+        const bool used = (NB == 3) || ((e % 12) < 4);
+        if (used) {
+          const unsigned long long mine = ((unsigned long long)tg << 32) | (unsigned long long)__float_as_uint((float)v);
+          __hip_atomic_store(eslot + (size_t)wig * FU_ESLOT + e, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (te < 2) {  // sum log d of the workgroup as a (hi, lo) pair of floats
+        const double ls = (red[4 * NE] + red[4 * NE + 1]) + (red[4 * NE + 2] + red[4 * NE + 3]);
+        const float hi = (float)ls;
+        const float lo = (float)(ls - (double)hi);
+        const unsigned long long mine =
+            ((unsigned long long)tg << 32) | (unsigned long long)__float_as_uint(te == 0 ? hi : lo);
+        __hip_atomic_store(eslot + (size_t)wig * FU_ESLOT + NE + te, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();  // tile / red are dead: the L rows can be cleared
+    {
+      int tz = t0;
+      asm volatile("" : "+v"(tz));
+#pragma unroll
+      for (int q = 0; q < R4_NR; ++q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l_s[fu_l_slot(tz + R4_TPB * q, i)] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (stamp) a.dbg[8] = wall_clock64();
 
-    // ================================ 2. pivots ================================
+
+    // ================================ 3. pivots ================================
     bool early = false;  // this member's own error fell to the tolerance (or went NaN) before `rank` pivots
     float orig = 0.f;
     int tp = t0;  // (opaque per phase: LDS addresses derived from it are not hoisted out of the MEMBER loop, where they
@@ -506,104 +611,17 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
     __syncthreads();  // L rows and the exchange block are dead from here on (region A / B change hands)
     if (stamp) a.dbg[2] = wall_clock64();
 
-    // ================================ 3. E = C^T D^-1 C ================================
-    // fp32 arithmetic for the row scales (IEEE division and square root, logf): the fp64 versions of the three-launch
-    // path cost ~1.5 us per member here; the partial sums of log d are still accumulated in fp64
-    float sq[R4_NR];  // 1 / sqrt(d) (CONST: 1, E is divided by sigma afterwards)
-    float dinvq[R4_NR];
-    double lsum = 0.0;
-    int te = t0;
-    asm volatile("" : "+v"(te));
-#pragma unroll
-    for (int q = 0; q < R4_NR; ++q) {
-      const int lr = te + R4_TPB * q;
-      const bool valid = lr < nv;
-      const float di = 1.0f / dq[q];
-      sq[q] = !valid ? 0.f : (d_full ? sqrtf(di) : 1.0f);
-      if (valid && d_full) lsum += (double)logf(dq[q]);
-      dq[q] = valid ? dq[q] : 0.f;
-      dinvq[q] = valid ? di : 0.f;
-      // (the diagonal and its inverse move to their CG slots only after the E phase: region A holds the row tile now)
-      if (a.dinv && valid && d_full) a.dinv[(size_t)b * a.N + row0 + lr] = di;
-    }
+    // ================================ 4. E: totals, and the root-form recurrence ================================
     {
-      float* const tile = reinterpret_cast<float*>(regA);                       // [256][33]
-      double* const red = reinterpret_cast<double*>(regA + 256 * 33 * 4 + 64);  // [4][64][12]  (8-byte aligned)
+      int te = t0;
+      asm volatile("" : "+v"(te));
       const int wave_e = te >> 6, lane_e = te & 63;
-      const int aa = lane_e & 15, kk = lane_e >> 4;
-      double acc[NB][4];
-#pragma unroll
-      for (int bk = 0; bk < NB; ++bk)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[bk][r] = 0.0;
-#pragma unroll
-      for (int q = 0; q < R4_NR; ++q) {
-        // every wave stages ITS OWN 64 rows (row set q) and multiplies them: no workgroup barrier
-        float* my = tile + te * 33;
-#pragma unroll
-        for (int i = 0; i < RC / 2; ++i) {
-          my[2 * i] = Cr[q][i].x * sq[q];
-          my[2 * i + 1] = Cr[q][i].y * sq[q];
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {  // two 32-row tiles per row set: fp32 inside a tile, fp64 across tiles
-          fu_f32x4 t00 = {0.f, 0.f, 0.f, 0.f}, t01 = t00, t11 = t00;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int row = 64 * wave_e + 32 * h + 4 * e + kk;
-            const float w0 = (aa < RC) ? tile[row * 33 + aa] : 0.f;
-            t00 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, w0, t00, 0, 0, 0);
-            if constexpr (NB == 3) {
-              const float w1 = tile[row * 33 + aa + 16];
-              t01 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, w1, t01, 0, 0, 0);
-              t11 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, w1, t11, 0, 0, 0);
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            acc[0][r] += (double)t00[r];
-            if constexpr (NB == 3) {
-              acc[1][r] += (double)t01[r];
-              acc[2][r] += (double)t11[r];
-            }
-          }
-        }
-        __builtin_amdgcn_wave_barrier();  // the next row set reuses the wave's tile rows
-      }
-#pragma unroll
-      for (int bk = 0; bk < NB; ++bk)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[te * 12 + 4 * bk + r] = acc[bk][r];
-      if (stamp) a.dbg[8] = wall_clock64();
-      const double lw = wave_sum_d(lsum);
-      if (lane_e == 0) red[4 * 64 * 12 + wave_e] = lw;
-      __syncthreads();
-      // entry e = 12 lane + 4 block + r of the workgroup partial: summed over the waves, published, fetched from every
-      // workgroup of the group and summed in fixed order (fp64) -> identical bits in all workgroups
-      const unsigned tg = ++etag;
+      const unsigned tg = etg;
       constexpr int NE = 64 * 12;
-      double tot[3];
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int e = te + R4_TPB * s;
-        const double v = (red[e] + red[NE + e]) + (red[2 * NE + e] + red[3 * NE + e]);
-        const bool used = (NB == 3) || ((e % 12) < 4);
-        if (used) {
-          const unsigned long long mine = ((unsigned long long)tg << 32) | (unsigned long long)__float_as_uint((float)v);
-          __hip_atomic_store(eslot + (size_t)wig * FU_ESLOT + e, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      if (te < 2) {  // sum log d of the workgroup as a (hi, lo) pair of floats
-        const double ls = (red[4 * NE] + red[4 * NE + 1]) + (red[4 * NE + 2] + red[4 * NE + 3]);
-        const float hi = (float)ls;
-        const float lo = (float)(ls - (double)hi);
-        const unsigned long long mine =
-            ((unsigned long long)tg << 32) | (unsigned long long)__float_as_uint(te == 0 ? hi : lo);
-        __hip_atomic_store(eslot + (size_t)wig * FU_ESLOT + NE + te, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      // While the partials travel: the root-form recurrence (first wave, lane r < RC holds row r of M in registers;
-      // compile-time loops, the pivot rows' L entries are wave-uniform LDS broadcasts)
+      double tot[4];
+      const int idx = te - 64;  // waves 1-3 fetch (192 threads x 4 entries); the first wave computes M meanwhile
+      // the root-form recurrence (first wave, lane r < RC holds row r of M in registers; compile-time loops, the pivot
+      // rows' L entries are wave-uniform LDS broadcasts) while the other waves start fetching
       //   M[r][j] = (C[pi_j][r] - sum_{i<j} M[r][i] L[pi_j][i]) / L[pi_j][j],   L = C M
       if (wave_e == 0) {
         // 1 / L[pi_j][j] for all j at once (lane j), then broadcast; the substitution is column-oriented: finishing
@@ -627,7 +645,6 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
           for (int j = 0; j < FU_MAXRANK; ++j) Mm[lane_e][j] = mr[j];  // (columns >= rank are zero: G is padded with I)
         }
       }
-      if (stamp) a.dbg[9] = wall_clock64();
       auto fetch_sum = [&](int e) -> double {
         double s = 0.0;
         FuWait wt{a.err, 0};
@@ -650,29 +667,28 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
         return s;
       };
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int e = te + R4_TPB * s;
-        const bool used = (NB == 3) || ((e % 12) < 4);
+      for (int s = 0; s < 4; ++s) {
+        const int e = idx + 192 * s;
+        const bool used = idx >= 0 && ((NB == 3) || ((e % 12) < 4));
         tot[s] = used ? fetch_sum(e) : 0.0;
       }
       double logd = 0.0;
-      if (te == 0) logd = fetch_sum(NE) + fetch_sum(NE + 1);
+      if (idx == 0) logd = fetch_sum(NE) + fetch_sum(NE + 1);
       if (stamp) a.dbg[10] = wall_clock64();
-      __syncthreads();  // tile / red are dead: region A becomes the fp64 matrices of the algebra
       double(*const Em)[FU_LD] = reinterpret_cast<double(*)[FU_LD]>(regA);
       const double sigma = d_full ? 1.0 : (double)a.d[b];
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int e = te + R4_TPB * s;
+      for (int s = 0; s < 4; ++s) {
+        const int e = (idx < 0 ? 0 : idx) + 192 * s;
         const int l2 = e / 12, bk = (e % 12) / 4, r = e % 4;
         const int gi = 4 * (l2 >> 4) + r + (bk == 2 ? 16 : 0), gj = (l2 & 15) + (bk >= 1 ? 16 : 0);
-        const bool used = (NB == 3) || (bk == 0);
+        const bool used = idx >= 0 && ((NB == 3) || (bk == 0));
         if (used && gi < RC && gj < RC) {
           Em[gi][gj] = tot[s] / sigma;
           if (bk == 1) Em[gj][gi] = tot[s] / sigma;  // E10 = E01^T
         }
       }
-      if (te == 0) {
+      if (idx == 0) {
         // logdet P = logdet(I + M^T E M) + sum log d  (added_diag_linear_operator.py:168-184); the first term is added
         // after the Cholesky factorisation below
         Em[RC][0] = d_full ? logd : (double)a.N * log(sigma);
@@ -681,7 +697,8 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
     }
     if (stamp) a.dbg[3] = wall_clock64();
 
-    // ================================ 4. the small algebra (k_pb_rootform) ================================
+
+    // ================================ 5. the small algebra (k_pb_rootform) ================================
     // fp64; every inner loop has a compile-time trip count (M is padded to 16 columns with zeros, G with the identity),
     // the 16 x 16 Cholesky factorisation and the forward substitution run in registers of the first wave with
     // v_readlane broadcasts: the chains of dependent LDS round trips of a runtime-bounded version cost 27 us per member
@@ -779,7 +796,7 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
           for (int q2 = 0; q2 < RC; ++q2) ef = fma(Em[r][q2], Fm[q2][c2], ef);
           fv[u] = (float)Fm[r][c2];
           ev[u] = (float)ef;
-          if (wig == 0) {
+          if (pr % GW == wig) {  // (every workgroup holds the same bits: each stores its share)
             if (a.F) a.F[(size_t)b * RC * RC + pr] = fv[u];
             if (a.EF) a.EF[(size_t)b * RC * RC + pr] = ev[u];
             if (a.E) a.E[(size_t)b * RC * RC + pr] = (float)Em[r][c2];
@@ -810,7 +827,7 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
     }
     if (stamp) a.dbg[4] = wall_clock64();
 
-    // ================================ 5. CG (k_cg_onchip5) ================================
+    // ================================ 6. CG (k_cg_onchip5) ================================
     int64_t b_next = a.B;
     {
     // (compiled with the contraction default of lo_cg_onchip4.hip -- only the load and pivot blocks switch it off --

@@ -483,11 +483,11 @@ def solve_fused(desc: OperatorDescriptor, rhs: torch.Tensor, rank: int, error_to
     R = desc.R
     const = desc.diag_mode == _hip.LO_DIAG_CONST
     x = torch.empty_like(rhs3)
-    F = torch.empty(B, R, R, dtype=torch.float32, device=dev)
-    EF, E = torch.empty_like(F), torch.empty_like(F)
+    small = torch.empty(B * (3 * R * R + 1 + rank), dtype=torch.float32, device=dev)  # one allocation: F | EF | E | logdet | swaps
+    F, EF, E = (small[i * B * R * R:(i + 1) * B * R * R].view(B, R, R) for i in range(3))
+    logdet = small[3 * B * R * R:3 * B * R * R + B]
+    swaps = small[3 * B * R * R + B:].view(torch.int32).view(B, rank)
     dinv = torch.empty(B if const else (B, N), dtype=torch.float32, device=dev)
-    logdet = torch.empty(B, dtype=torch.float32, device=dev)
-    swaps = torch.empty(B, rank, dtype=torch.int32, device=dev)
     ws = _hip.workspace(lib.lo_solve_fused_workspace_bytes(C.byref(s), rank, C.byref(prm)), dev)
     info = _hip.FusedInfo()
     rc = lib.lo_solve_fused_f32(C.byref(s), rank, float(error_tol), C.byref(prm), _hip.ptr(rhs3), _hip.ptr(x),

@@ -134,10 +134,16 @@ class LinearOperator(object):
     # ------------------------------------------------------------------ shape / dtype
     @property
     def shape(self) -> torch.Size:
-        return self._size()
+        # the size of an operator never changes after construction (its tensors may be updated in place, never
+        # reshaped): computed once per object -- `_size` of a sum is a torch.broadcast_shapes call (~15 us) and the solve
+        # path asks for the shape a dozen times
+        s = self.__dict__.get("_shape_memo")
+        if s is None:
+            s = self.__dict__["_shape_memo"] = self._size()
+        return s
 
     def size(self, dim: Optional[int] = None):
-        s = self._size()
+        s = self.shape
         return s if dim is None else s[dim]
 
     def dim(self) -> int:

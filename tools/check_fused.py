@@ -45,3 +45,11 @@ dx = (again.x - rf.cg.x).abs().max().item()
 print("fused x vs root-form CG kernel with the fused launch's own preconditioner: bit-equal", torch.equal(again.x, rf.cg.x), "max abs diff", dx)
 rf2 = fused()
 print("fused twice bit-equal", torch.equal(rf2.cg.x, rf.cg.x))
+K._hip.prof_enable(True)
+for _ in range(5): fused()
+torch.cuda.synchronize()
+print("prof fused:", {k: round(v[1] / v[0] * 1e3, 1) for k, v in K._hip.prof_report().items()}, "us per launch")
+for _ in range(5): three()
+torch.cuda.synchronize()
+print("prof three:", {k: round(v[1] / v[0] * 1e3, 1) for k, v in K._hip.prof_report().items()}, "us per launch")
+K._hip.prof_enable(False)
