@@ -27,6 +27,13 @@ namespace lo {
 
 bool g_onchip_disabled = false;
 int g_onchip_fused_timeouts = 0;
+void onchip_note_timeout() {
+  if (getenv("LO_OC_TEST_FALLBACK")) return;
+  if (!g_onchip_disabled)
+    fprintf(stderr, "liblo_amd: a resident kernel lost its co-residency (hand-off timeout): resident kernels are switched "
+                    "off for this process (lo_cg_set_onchip(1) re-arms them)\n");
+  g_onchip_disabled = true;
+}
 static thread_local bool tls_no_fused_precond = false;  // set while a solve is redone after a timed-out hand-off
 
 // hipGraph of one CG iteration: captured on a private side stream, replayed on the caller's stream.
@@ -847,6 +854,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
         x_written = xout_ok;
       } else {  // a group hand-off timed out: redo everything with the streaming engine
         fprintf(stderr, "liblo_amd: operator-resident CG timed out, falling back to the streaming engine\n");
+        onchip_note_timeout();
         LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, sizeof(CgCtrl), st));
         memset(&h, 0, sizeof(h));
       }

@@ -224,6 +224,10 @@ struct ResidentLaunch {
 extern thread_local bool tls_graph_capture;  // a CG iteration is being captured: no cross-stream event traffic
 extern bool g_onchip_disabled;  // lo_cg_set_onchip(0): streaming engines only (tests compare the two)
 extern int g_onchip_fused_timeouts;  // group exchanges of the fused solve that timed out in this process
+// A REAL hand-off timeout (co-residency lost: another process / kernel holds part of the CUs) latches the resident
+// kernels off for the rest of the process -- every later solve would pay the ~0.5 s spin again before falling back.
+// lo_cg_set_onchip(1) re-arms them.  The injected timeout of the tests (LO_OC_TEST_FALLBACK) does not latch.
+void onchip_note_timeout();
 
 // ---- fp64 helpers (lo_cg_f64.hip), shared by the fp64 CG and MINRES engines ---------------------------------------
 // out1[b, j] = sum_i a[b, i, j] b1[b, i, j] (and out2 from (a2, b2) when a2 != nullptr)

@@ -924,7 +924,10 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
             ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4], ts[5], ts[6]);
     fprintf(stderr, "  update split: winner+row fetch %lld, C.C chain %lld, L.L chain %lld\n", ts[7], ts[8], ts[9]);
   }
-  if (h[0]) return LO_ERR_LAUNCH;
+  if (h[0]) {
+    onchip_note_timeout();
+    return LO_ERR_LAUNCH;
+  }
   *rank_out = h[1];
   return LO_OK;
 }

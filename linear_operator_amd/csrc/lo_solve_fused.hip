@@ -219,6 +219,7 @@ int lo_solve_fused_f32(const lo_op_desc* op, int32_t rank, float error_tol, cons
   if (h.status == LO_FUSED_TIMEOUT) {
     fprintf(stderr, "liblo_amd: fused solve timed out in a group exchange, the caller falls back to the three-launch path\n");
     g_onchip_fused_timeouts++;
+    onchip_note_timeout();
   }
   return LO_OK;
 }

@@ -16,6 +16,12 @@ from .. import settings
 def _solve(linear_op, rhs):
     """Cholesky for N <= max_cholesky_size (or fast solves switched off), else `linear_op._solve` with the
     preconditioner built from the detached operator (reference :17-22)."""
+    if getattr(linear_op, "_has_closed_form_solve", False):
+        # operators whose `_solve` is a closed form (Woodbury for LowRankRoot + Diag, per-factor eigendecomposition for
+        # Kronecker + constant diagonal) go straight to it, whatever their size -- as the reference's own `solve` of
+        # those classes does (low_rank_root_added_diag_linear_operator.py:152, :62-90): no O(N^3) dense Cholesky below
+        # max_cholesky_size, no preconditioner build
+        return linear_op._solve(rhs)
     small = linear_op.size(-1) <= settings.max_cholesky_size.value()
     if small or settings.fast_computations.solves.off():
         return linear_op.cholesky()._cholesky_solve(rhs)

@@ -1,72 +1,84 @@
-"""SqrtInvMatmul Function (reference: linear_operator/functions/_sqrt_inv_matmul.py:10-140): A^{-1/2} rhs or
-lhs A^{-1/2} rhs (+ the inverse quadratic form of lhs) by contour integral quadrature -- shifted MINRES on the device
-(csrc/lo_minres.hip) -- forward and backward (`_bilinear_derivative` kernels, csrc/lo_bilinear.hip)."""
+"""SqrtInvMatmul Function: `A^{-1/2} R` or `L A^{-1/2} R` (plus the inverse quadratic form of L) by contour integral
+quadrature -- shifted MINRES on the device (csrc/lo_minres.hip) -- with its derivative (reference behaviour:
+linear_operator/functions/_sqrt_inv_matmul.py:10-140).
+
+With the quadrature `A^{-1/2} ~= sum_q w_q (A + t_q I)^{-1}` (utils/contour_integral_quad.py) and the shifted solves
+`S_q(X) = (A + t_q I)^{-1} X`:
+
+    forward    H = sum_q w_q S_q(R);   out = H  or  L H;   quad_b = -sum_rows (A^{-1} L^T) o L^T   (as the reference signs it)
+    d out/dR   sum_q w_q S_q(L^T G)          (no L: sum_q w_q S_q(G), one more quadrature call with the SAME shifts)
+    d out/dL   (sum_q w_q S_q(R) G^T)^T  + 2 (quad term)
+    d out/dA   every term has the shape -<U, dA V> with U, V shifted solves: the pairs (U_q, V_q) of all nodes are
+               folded into the column dimension and handed to `_bilinear_derivative` ONCE, symmetrised
+               (functions/_solve._symmetric_operator_grads: the helper Solve / InvQuad use for the same purpose).
+One quadrature call serves both blocks when a left factor is given: the columns `[R | L^T]` are solved together and
+sliced, there is no separate code path per argument pattern.
+"""
 from __future__ import annotations
 
 import torch
 from torch.autograd import Function
 
 from .. import settings, utils
+from ._solve import _symmetric_operator_grads
+
+
+def _nodes_into_columns(t):
+    """[Q, *batch, N, c] -> [*batch, N, Q c]: the quadrature nodes become extra columns of one contraction."""
+    return t.movedim(0, -2).reshape(*t.shape[1:-1], t.shape[0] * t.shape[-1]).contiguous()
 
 
 class SqrtInvMatmul(Function):
     @staticmethod
     def forward(ctx, representation_tree, rhs, lhs, *matrix_args):
-        ctx.representation_tree = representation_tree
-        ctx.linear_op = representation_tree(*matrix_args)
-        nq = settings.num_contour_quadrature.value()
-        if lhs is not None:  # :23-35
-            terms = torch.cat([rhs, lhs.mT], dim=-1)
-            solves, weights, no_shift_solves, shifts = utils.contour_integral_quad(
-                ctx.linear_op, terms, inverse=True, num_contour_quadrature=nq)
-            rhs_solves, lhs_solves = solves.split([rhs.size(-1), lhs.size(-2)], dim=-1)
-            lhs_no_shift_solves = no_shift_solves[..., -lhs.size(-2):]
-            sqrt_inv_matmul_res = lhs @ (rhs_solves * weights).sum(0)
-            inv_quad_res = (lhs_no_shift_solves.mT * lhs).sum(dim=-1).mul_(-1)
-        else:  # :36-47
-            rhs_solves, weights, _, shifts = utils.contour_integral_quad(
-                ctx.linear_op, rhs, inverse=True, num_contour_quadrature=nq)
-            sqrt_inv_matmul_res = (rhs_solves * weights).sum(0)
-            lhs_solves = None
-            lhs_no_shift_solves = None
-            inv_quad_res = torch.zeros(ctx.linear_op.batch_shape, dtype=rhs.dtype, device=rhs.device)
-        ctx.save_for_backward(rhs, lhs, rhs_solves, lhs_solves, weights, shifts, lhs_no_shift_solves, *matrix_args)
-        return sqrt_inv_matmul_res, inv_quad_res
+        linear_op = representation_tree(*matrix_args)
+        ctx.linear_op, ctx.has_lhs = linear_op, lhs is not None
+        n_rhs = rhs.size(-1)
+        block = torch.cat((rhs, lhs.mT), dim=-1) if ctx.has_lhs else rhs
+        solves, weights, plain, shifts = utils.contour_integral_quad(
+            linear_op, block, inverse=True, num_contour_quadrature=settings.num_contour_quadrature.value())
+        rhs_solves = solves[..., :n_rhs]  # S_q(R) for every node q
+        half = (rhs_solves * weights).sum(0)  # A^{-1/2} R
+        if ctx.has_lhs:
+            lhs_solves, lhs_plain = solves[..., n_rhs:], plain[..., n_rhs:]
+            out = lhs @ half
+            quad = (lhs_plain.mT * lhs).sum(dim=-1).neg_()
+        else:
+            lhs_solves = lhs_plain = None
+            out = half
+            quad = torch.zeros(linear_op.batch_shape, dtype=rhs.dtype, device=rhs.device)
+        ctx.save_for_backward(rhs, lhs, rhs_solves, lhs_solves, lhs_plain, weights, shifts, *matrix_args)
+        return out, quad
 
     @staticmethod
-    def backward(ctx, sqrt_inv_matmul_grad, inv_quad_grad):  # :53-140
-        rhs, lhs, rhs_solves, lhs_solves, weights, shifts, lhs_no_shift_solves, *matrix_args = ctx.saved_tensors
-        rhs_grad = None
-        lhs_grad = None
-        if lhs is not None:
-            weighted_rhs_solves_mul_grad = rhs_solves.mul(weights) @ sqrt_inv_matmul_grad.mT
-            neg_inv_quad_solves_mul_grad = lhs_no_shift_solves.mul(inv_quad_grad.unsqueeze(-2)).mul(-1)
-            if ctx.needs_input_grad[2]:
-                lhs_grad = weighted_rhs_solves_mul_grad.mT.sum(0)
-                lhs_grad = lhs_grad.add(neg_inv_quad_solves_mul_grad.mT, alpha=2)
-            if ctx.needs_input_grad[1]:
-                rhs_grad = (lhs_solves @ sqrt_inv_matmul_grad).mul(weights).sum(0)
-            terms1 = torch.cat([lhs_no_shift_solves.unsqueeze(0), lhs_solves], 0)
-            terms2 = torch.cat([neg_inv_quad_solves_mul_grad.unsqueeze(0), weighted_rhs_solves_mul_grad], 0)
+    def backward(ctx, grad_out, grad_quad):
+        rhs, lhs, rhs_solves, lhs_solves, lhs_plain, weights, shifts, *matrix_args = ctx.saved_tensors
+        want_rhs, want_lhs, want_args = ctx.needs_input_grad[1], ctx.needs_input_grad[2], any(ctx.needs_input_grad[3:])
+        d_rhs = d_lhs = None
+        if ctx.has_lhs:
+            through_out = (rhs_solves * weights) @ grad_out.mT  # w_q S_q(R) G^T, one block per node
+            through_quad = lhs_plain * grad_quad.unsqueeze(-2).neg()
+            if want_lhs:
+                d_lhs = through_out.sum(0).mT + 2.0 * through_quad.mT
+            if want_rhs:
+                d_rhs = ((lhs_solves @ grad_out) * weights).sum(0)
+            # operator pairs: (A^-1 L^T, quad term) for the quadratic form, (S_q(L^T), w_q S_q(R) G^T) for every node
+            u_side = torch.cat((lhs_plain.unsqueeze(0), lhs_solves), dim=0)
+            v_side = torch.cat((through_quad.unsqueeze(0), through_out), dim=0)
         else:
-            grad_solves, _, _, _ = utils.contour_integral_quad(
-                ctx.linear_op, sqrt_inv_matmul_grad.contiguous(), inverse=True, weights=weights, shifts=shifts,
+            g_solves, _, _, _ = utils.contour_integral_quad(
+                ctx.linear_op, grad_out.contiguous(), inverse=True, weights=weights, shifts=shifts,
                 num_contour_quadrature=settings.num_contour_quadrature.value())
-            grad_solves_mul_weights = grad_solves.mul(weights)
-            if ctx.needs_input_grad[1]:
-                rhs_grad = grad_solves_mul_weights.sum(0)
-            terms1 = grad_solves_mul_weights
-            terms2 = rhs_solves
-        matrix_arg_grads = [None] * len(matrix_args)
-        if any(ctx.needs_input_grad[3:]):
-            # the quadrature dimension rides in the column dimension of the contraction: sum_q sum_d u v^T
-            def fold(t):
-                return t.movedim(0, -2).reshape(*t.shape[1:-1], t.shape[0] * t.shape[-1])
-
-            left = torch.cat([fold(terms1), fold(terms2)], -1)
-            right = torch.cat([fold(terms2), fold(terms1)], -1).mul_(0.5)
-            matrix_arg_grads = ctx.linear_op._bilinear_derivative(left.contiguous(), right.contiguous())
-        return (None, rhs_grad, lhs_grad, *matrix_arg_grads)
+            u_side = g_solves * weights  # w_q S_q(G)
+            v_side = rhs_solves
+            if want_rhs:
+                d_rhs = u_side.sum(0)
+        d_args = (None,) * len(matrix_args)
+        if want_args:
+            # sum_q <U_q, dA V_q>, symmetrised; the shared helper computes -sym(<left, dA right>), hence the sign
+            d_args = tuple(_symmetric_operator_grads(ctx.linear_op, _nodes_into_columns(u_side),
+                                                     _nodes_into_columns(v_side).neg_()))
+        return (None, d_rhs, d_lhs, *d_args)
 
 
 __all__ = ["SqrtInvMatmul"]

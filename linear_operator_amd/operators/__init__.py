@@ -10,11 +10,12 @@ from .linear_operator_representation_tree import LinearOperatorRepresentationTre
 from .low_rank_root_added_diag_linear_operator import LowRankRootAddedDiagLinearOperator
 from .root_linear_operator import LowRankRootLinearOperator, RootLinearOperator
 from .sum_linear_operator import PsdSumLinearOperator, SumLinearOperator
+from .triangular_linear_operator import TriangularLinearOperator
 
 __all__ = [
     "LowRankRootAddedDiagLinearOperator", "KroneckerProductAddedDiagLinearOperator",
     "LinearOperator", "to_dense", "to_linear_operator", "AddedDiagLinearOperator", "DenseLinearOperator",
     "DiagLinearOperator", "ConstantDiagLinearOperator", "IdentityLinearOperator", "KroneckerProductLinearOperator", "KroneckerProductDiagLinearOperator",
     "LinearOperatorRepresentationTree", "RootLinearOperator", "LowRankRootLinearOperator", "SumLinearOperator",
-    "PsdSumLinearOperator",
+    "PsdSumLinearOperator", "TriangularLinearOperator",
 ]

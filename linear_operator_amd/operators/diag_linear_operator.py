@@ -8,11 +8,17 @@ from torch import Tensor
 
 from .. import kernels as K
 from ._linear_operator import LinearOperator
+from .triangular_linear_operator import TriangularLinearOperator
 
 
-class DiagLinearOperator(LinearOperator):
+class DiagLinearOperator(TriangularLinearOperator):
+    """(a diagonal matrix is triangular: class identity as in the reference, diag_linear_operator.py:16 -- every
+    method of the triangular base is overridden below with its elementwise form)"""
+
+    upper = False
+
     def __init__(self, diag: Tensor):
-        super().__init__(diag)
+        LinearOperator.__init__(self, diag)  # (not the triangular constructor: there is no dense factor)
         self._diag = diag
 
     def __add__(self, other):  # reference :27-35
@@ -76,6 +82,9 @@ class DiagLinearOperator(LinearOperator):
     def solve(self, right_tensor: Tensor, left_tensor=None) -> Tensor:
         res = self.inverse()._matmul(right_tensor)
         return left_tensor @ res if left_tensor is not None else res
+
+    def _cholesky_solve(self, rhs: Tensor, upper: bool = False) -> Tensor:  # (D D^T)^-1 rhs, reference :47-48
+        return rhs / self._diag.unsqueeze(-1).pow(2)
 
     def zero_mean_mvn_samples(self, num_samples: int) -> Tensor:  # reference :273-277
         base = torch.randn(num_samples, *self._diag.shape, dtype=self.dtype, device=self.device)

@@ -94,6 +94,10 @@ class KroneckerProductAddedDiagLinearOperator(AddedDiagLinearOperator):
         ir, inv, q_t, q = self._sym_cache
         return ir * q._matmul(inv * q_t._matmul(ir * rhs))
 
+    @property
+    def _has_closed_form_solve(self) -> bool:  # functions/_solve._solve: eigendecomposition forms at every size
+        return bool(self._diag_is_constant or self._structured())
+
     def _solve(self, rhs: Tensor, preconditioner=None, num_tridiag: int = 0):
         if not self._diag_is_constant and self._structured():
             return self._solve_structured(rhs)

@@ -111,12 +111,16 @@ class KroneckerProductLinearOperator(LinearOperator):
         if best[0] > self._kMaxGroup:
             return None
         j = best[1]
+        # the regrouped dense factors are memoised per operator object, keyed on the factor tensors' storage AND version
+        # counters: an in-place update of a factor (optimizer step on a reused operator) rebuilds the groups instead of
+        # silently multiplying with stale ones
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) if not t.is_inference() else None for t in ts)
         cache = getattr(self, "_groups_cache", None)
-        if cache is None:
+        if cache is None or None in key or cache[0] != key:
             with torch.no_grad():
-                cache = (_dense_kron(ts[:j]), _dense_kron(ts[j:]), j)
+                cache = (key, (_dense_kron(ts[:j]), _dense_kron(ts[j:]), j))
             self._groups_cache = cache
-        return cache
+        return cache[1]
 
     def _kernel_descriptor(self, batch_shape=None):
         groups = self._two_groups()

@@ -23,6 +23,8 @@ from .root_linear_operator import LowRankRootLinearOperator
 
 
 class LowRankRootAddedDiagLinearOperator(AddedDiagLinearOperator):
+    _has_closed_form_solve = True  # functions/_solve._solve: Woodbury at every size (reference :62-90, :152)
+
     def __init__(self, *linear_ops, preconditioner_override=None):
         if len(linear_ops) > 2:
             raise RuntimeError("An AddedDiagLinearOperator can only have two components")

@@ -887,8 +887,44 @@ def g21_minres_fp64():
     save("g21_minres_fp64", checksum=cases.checksum(*inputs), **out)
 
 
+def g22_kronecker_iteration_pinned():
+    """cfg4 with the ITERATION COUNT pinned: AddedDiag(Kron(K1, K2), ConstantDiag).solve first at cg_tolerance 1e-3 (the
+    stop-rule run: `its` iterations), then again with cg_tolerance 0 and max_cg_iterations = its -- the very same
+    iterates, no stop decision involved -- so that a kernel path can be compared column by column at 1e-4 after
+    exactly the reference's iterations (linear_cg.py:302-308 never fires).  Two sizes: 48 (x) 48 (N = 2304) and
+    128 (x) 128 (N = 16384: the matrix-core Kronecker GEMMs and the single-pass preconditioner apply)."""
+    print("G22 Kronecker solve, iteration-pinned")
+    out, inputs = {}, []
+    for tag, seed, n in (("n48", 421, 48), ("n128", 2201, 128)):
+        K1, K2, sig, rhs = cases.kron_factors(seed, 2, n, n, 1)
+        N = n * n
+        A = AddedDiagLinearOperator(KroneckerProductLinearOperator(T(K1), T(K2)), ConstantDiagLinearOperator(T(sig), N))
+        with settings.cg_tolerance(1e-3):
+            x_tol, spy, w = _with_spy(lambda: A.solve(T(rhs)))
+        its = int(spy.records[0]["matvecs"]) - 1
+        A2 = AddedDiagLinearOperator(KroneckerProductLinearOperator(T(K1), T(K2)), ConstantDiagLinearOperator(T(sig), N))
+        with settings.cg_tolerance(0.0), settings.max_cg_iterations(its):
+            x_pin, spy2, w2 = _with_spy(lambda: A2.solve(T(rhs)))
+        assert int(spy2.records[0]["matvecs"]) - 1 == its
+        # exact solution by the per-factor eigendecomposition in fp64: (K1 (x) K2 + s I)^-1 b
+        xs = []
+        for i in range(2):
+            l1, q1 = np.linalg.eigh(K1[i].astype(np.float64))
+            l2, q2 = np.linalg.eigh(K2[i].astype(np.float64))
+            Bm = rhs[i, :, 0].astype(np.float64).reshape(n, n)
+            Y = q1.T @ Bm @ q2
+            Y = Y / (np.outer(l1, l2) + float(sig[i, 0]))
+            xs.append((q1 @ Y @ q2.T).reshape(N, 1))
+        out.update({f"x_tol_{tag}": x_tol, f"x_pinned_{tag}": x_pin, f"iterations_{tag}": its,
+                    f"x_exact_{tag}": np.stack(xs).astype(np.float32), f"warned_pinned_{tag}": w2})
+        inputs += [K1, K2, sig, rhs]
+        d1 = float((x_pin - x_tol).norm() / x_tol.norm())
+        print(f"  {tag}: {its} iterations, |x_pinned - x_tol| / |x_tol| = {d1:.2e}")
+    save("g22_kron_iteration_pinned", checksum=cases.checksum(*inputs), **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g21", "g20", "g19", "g18", "g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g22", "g21", "g20", "g19", "g18", "g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
@@ -897,7 +933,8 @@ if __name__ == "__main__":
                      ("g14", g14_sqrt_inv_matmul), ("g15", g15_lanczos_consumers_backward),
                      ("g16", g16_sum_operators), ("g17", g17_low_rank_root_added_diag_backward),
                      ("g18", g18_low_rank_root_added_diag_wide_root), ("g19", g19_kronecker_three_factors),
-                     ("g20", g20_kronecker_structured_diag), ("g21", g21_minres_fp64)):
+                     ("g20", g20_kronecker_structured_diag), ("g21", g21_minres_fp64),
+                     ("g22", g22_kronecker_iteration_pinned)):
         if name in todo:
             fn()
     print("done")

@@ -203,3 +203,53 @@ def test_kronecker_added_diag_routing_and_closed_form_plumbing_cpu():
         a1.solve(T(rhs))  # the solve needs the Kronecker matvec kernel: no silent ATen route
     with pytest.raises(_hip.HipExtensionError):
         lo.utils.minres(T(np.eye(8, dtype=np.float32)).matmul, torch.randn(8, 1))
+
+
+def test_install_as_linear_operator_makes_the_package_a_drop_in():
+    """`linear_operator_amd.install_as("linear_operator")`: GPyTorch-style imports resolve to this package, and the
+    solver seam of the reference (rebinding `linear_operator.utils.linear_cg`, as
+    linear_operator/test/linear_operator_test_case.py:555-556 does with mock.patch) is the seam `_solve` goes through.
+    Runs in a subprocess: the alias must not leak into the other tests' sys.modules."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        from unittest import mock
+        import torch
+        import linear_operator_amd
+        assert "linear_operator" not in sys.modules
+        linear_operator_amd.install_as("linear_operator")
+        import linear_operator
+        from linear_operator import settings, operators, utils
+        from linear_operator.operators import (AddedDiagLinearOperator, ConstantDiagLinearOperator, DiagLinearOperator,
+                                               LowRankRootLinearOperator, TriangularLinearOperator)
+        from linear_operator.operators.added_diag_linear_operator import AddedDiagLinearOperator as A2
+        from linear_operator.utils.lanczos import lanczos_tridiag
+        from linear_operator.utils.warnings import NumericalWarning
+        import linear_operator.functions._inv_quad_logdet
+        assert linear_operator is linear_operator_amd and A2 is AddedDiagLinearOperator
+        assert linear_operator.utils is linear_operator_amd.utils
+        assert issubclass(ConstantDiagLinearOperator, DiagLinearOperator) and issubclass(DiagLinearOperator, TriangularLinearOperator)
+        A = AddedDiagLinearOperator(LowRankRootLinearOperator(torch.randn(3, 40, 4)), DiagLinearOperator(torch.rand(3, 40) + 1))
+        rhs = torch.randn(3, 40, 2)
+        assert torch.allclose(torch.matmul(A, rhs), A.to_dense() @ rhs, atol=1e-4)      # __torch_function__ dispatch
+        fake = mock.MagicMock(return_value=torch.zeros_like(rhs))
+        with mock.patch("linear_operator.utils.linear_cg", new=fake), settings.max_cholesky_size(0):
+            out = A.solve(rhs)                                                             # CG seam reached by name
+        assert fake.call_count == 1 and torch.equal(out, torch.zeros_like(rhs))
+        assert fake.call_args.args[0].__self__.__class__ is AddedDiagLinearOperator        # bound _matmul of the operator
+        with settings.cg_tolerance(0.25):
+            assert linear_operator_amd.settings.cg_tolerance.value() == 0.25               # one settings object
+        try:
+            linear_operator_amd.install_as("json")
+        except ImportError:
+            pass
+        else:
+            raise AssertionError("shadowing an imported package must be refused")
+        print("OK")
+    """ % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stderr[-3000:]

@@ -722,3 +722,20 @@ def test_g21_minres_fp64_reference_recipes():
         A = -M if sh is None else -(M - sh.reshape(-1, *([1] * M.ndim)) * np.eye(M.shape[-1]))
         exact = np.linalg.solve(A, rb)
         assert np.allclose(x if b.ndim > 1 else x[..., None], exact, atol=1e-3, rtol=1e-4), tag
+
+
+@pytest.mark.parametrize("tag,seed,n", [("n48", 421, 48), ("n128", 2201, 128)])
+def test_solve_kron_iteration_pinned(tag, seed, n):
+    """g22: the reference's Kronecker CG run for EXACTLY its own iteration count (cg_tolerance 0, max_cg_iterations =
+    the count of the tolerance-1e-3 run): no stop decision is involved, so the comparison is column by column at the
+    north_star bar 1e-4 -- the +-3-iteration test above pins the stop rule, this one pins the arithmetic."""
+    g = load_golden("g22_kron_iteration_pinned")
+    K1, K2, sig, rhs = cases.kron_factors(seed, 2, n, n, 1)
+    N = n * n
+    its = int(g[f"iterations_{tag}"])
+    assert np.array_equal(g[f"x_pinned_{tag}"], g[f"x_tol_{tag}"])  # same iterates: pinning changes nothing in the reference
+    d = np.broadcast_to(sig, (2, N)).copy()
+    x, info, pre = orc.solve(lambda v: orc.matvec_kron_diag(K1, K2, d, v), orc.KronRowSource(K1, K2), d, rhs,
+                             tolerance=0.0, max_iter=its)
+    assert info.iterations == its
+    assert max_rel_err_cols(x, g[f"x_pinned_{tag}"]) < 1e-4
