@@ -27,6 +27,30 @@ namespace lo {
 
 bool g_onchip_disabled = false;
 int g_onchip_fused_timeouts = 0;
+void* pinned_status_block() {
+  static thread_local void* p = nullptr;
+  if (!p) {
+    if (hipHostMalloc(&p, 256, hipHostMallocCoherent) != hipSuccess) p = nullptr;
+    else memset(p, 0, 256);
+  }
+  return p;
+}
+// Wait for the kernel that mirrors its decision into the pinned block: the block's last word carries a per-call ticket
+// written AFTER the payload (system-scope fence in between), so the host can spin on it for a few microseconds instead
+// of paying the wake-up latency of hipStreamSynchronize (~15 us on this stack); falls back to the stream
+// synchronisation after ~200 us (long solves, other work queued on the stream in front of ours).
+static unsigned next_ticket() {
+  static thread_local unsigned t = 0;
+  return ++t == 0 ? ++t : t;
+}
+static int wait_ticket(volatile unsigned* word, unsigned ticket, hipStream_t st) {
+  for (int spin = 0; spin < 40000; ++spin) {
+    if (*word == ticket) return LO_OK;
+    __builtin_ia32_pause();
+  }
+  LO_HIP_CHECK(hipStreamSynchronize(st));
+  return (*word == ticket) ? LO_OK : LO_ERR_LAUNCH;
+}
 void onchip_note_timeout() {
   if (getenv("LO_OC_TEST_FALLBACK")) return;
   if (!g_onchip_disabled)
@@ -411,7 +435,8 @@ __global__ __launch_bounds__(kThreads) void k_oc_tridiag(CgDev d, const float* _
 }
 
 __global__ __launch_bounds__(kThreads) void k_cg_ctrl_onchip(CgDev d, const float* __restrict__ resid_rec,
-                                                              const int* __restrict__ init_conv, int iters, int ktri) {
+                                                              const int* __restrict__ init_conv, int iters, int ktri,
+                                                              CgCtrl* __restrict__ mirror, unsigned ticket) {
   __shared__ float red[kThreads];
   float lsum = 0.f, lnan = 0.f, lnotconv = 0.f;
   const int64_t n = d.B * d.c;
@@ -449,6 +474,12 @@ __global__ __launch_bounds__(kThreads) void k_cg_ctrl_onchip(CgDev d, const floa
     } else if (k >= min(10, d.max_iter - 1) && mean < d.tol) {  // (k >= min(n_tridiag_iter, max_iter-1) by construction)
       d.ctrl->tol_reached = 1;
       d.ctrl->stop = 1;
+    }
+    // the host reads the decision from pinned memory right after the stream drains: no device-to-host copy command
+    if (mirror) {
+      *mirror = *d.ctrl;
+      __threadfence_system();
+      __hip_atomic_store(reinterpret_cast<unsigned*>(mirror) + 63, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -823,11 +854,22 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
         LO_HIP_CHECK(hipMemsetAsync(d.oc_maxoff, 0, sizeof(int) * (prm->max_tridiag_iter + 1), st));
         hipLaunchKernelGGL(k_oc_maxoff, dim3(tri_grid), block, 0, st, d, d.oc_ab, ktri);
       }
-      hipLaunchKernelGGL(k_cg_ctrl_onchip, dim3(1), block, 0, st, d, d.oc_resid, d.oc_init_conv, a.iters, ktri);
+      // (with tridiagonals k_oc_tridiag follows and does not touch the control block: the mirror is final either way)
+      CgCtrl* mirror = static_cast<CgCtrl*>(pinned_status_block());
+      const unsigned ticket = next_ticket();
+      hipLaunchKernelGGL(k_cg_ctrl_onchip, dim3(1), block, 0, st, d, d.oc_resid, d.oc_init_conv, a.iters, ktri, mirror,
+                         ticket);
       if (ktri) hipLaunchKernelGGL(k_oc_tridiag, dim3(tri_grid), block, 0, st, d, d.oc_ab, ktri);
       LO_LAUNCH_CHECK();
-      LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
-      LO_HIP_CHECK(hipStreamSynchronize(st));
+      if (mirror) {
+        // (with tridiagonals k_oc_tridiag is still queued behind the control kernel: drain the stream as before)
+        if (ktri) LO_HIP_CHECK(hipStreamSynchronize(st));
+        else if (wait_ticket(reinterpret_cast<volatile unsigned*>(mirror) + 63, ticket, st)) return LO_ERR_LAUNCH;
+        memcpy(&h, mirror, sizeof(CgCtrl));
+      } else {
+        LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
+        LO_HIP_CHECK(hipStreamSynchronize(st));
+      }
       const int oc_err = h.oc_err;
       if (oc_err == 0) {
         rc = global_check();
@@ -897,8 +939,10 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   const bool opaque = (op->kind == LO_OP_CALLBACK) || (precond_cb != nullptr);
   const int chunk = (opaque || global_rule) ? 1 : 4;
   auto poll = [&]() -> int {
-    LO_HIP_CHECK(hipMemcpyAsync(&h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
+    void* hp = pinned_status_block();
+    LO_HIP_CHECK(hipMemcpyAsync(hp ? hp : &h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
     LO_HIP_CHECK(hipStreamSynchronize(st));
+    if (hp) memcpy(&h, hp, sizeof(CgCtrl));
     return LO_OK;
   };
   if (opaque || prm->max_iter == 0) {  // closures cannot see the stop word: look before the first product

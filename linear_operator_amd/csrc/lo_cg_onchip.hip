@@ -455,9 +455,16 @@ ResidentLaunch::~ResidentLaunch() { g_res_mu.unlock(); }
 
 int onchip_num_workgroups() {
   int dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  int cus = prop.multiProcessorCount;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  // (hipGetDeviceProperties fills a ~1.5 KB structure and costs tens of microseconds: asked once per device)
+  static int cu_count[64] = {0};
+  if (dev < 0 || dev >= 64) return 0;
+  if (cu_count[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cu_count[dev] = n;
+  }
+  int cus = cu_count[dev];
   // LO_OC_RESERVE_CUS=<n>: leave n CUs' worth of workgroup slots unused so that a concurrently running collective
   // (RCCL's all-gather kernel on its own stream) finds room WITHOUT displacing workgroups of a resident group -- a
   // displaced workgroup stalls its whole group until the other kernel ends.  The spare slots end up scattered over the

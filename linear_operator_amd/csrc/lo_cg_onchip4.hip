@@ -334,7 +334,7 @@ static int onchip4_go(const OnchipArgs& a, int nwg, hipStream_t st) {
   // the spin-waiting groups need ALL workgroups resident: two per CU
   int per_cu = 0;
   const bool half = getenv("LO_OC_HALF") != nullptr;  // debugging: one workgroup per CU
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_onchip4<RC, RK, GW, MC>, R4_TPB, 0) != hipSuccess ||
+  if (LO_OCCUPANCY_CACHED(per_cu, (k_cg_onchip4<RC, RK, GW, MC>), R4_TPB, 0) != hipSuccess ||
       per_cu < (half ? 1 : 2))
     return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("cg_onchip", st);
@@ -754,7 +754,7 @@ bool onchip5_eligible(int RC, int64_t N, int64_t c) {
 template <int RC, int GW, bool MC>
 static int onchip5_go(const OnchipArgs& a, int nwg, hipStream_t st) {
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_onchip5<RC, GW, MC>, R4_TPB, 0) != hipSuccess ||
+  if (LO_OCCUPANCY_CACHED(per_cu, (k_cg_onchip5<RC, GW, MC>), R4_TPB, 0) != hipSuccess ||
       per_cu < 2)
     return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("cg_onchip", st);

@@ -228,6 +228,24 @@ extern int g_onchip_fused_timeouts;  // group exchanges of the fused solve that 
 // kernels off for the rest of the process -- every later solve would pay the ~0.5 s spin again before falling back.
 // lo_cg_set_onchip(1) re-arms them.  The injected timeout of the tests (LO_OC_TEST_FALLBACK) does not latch.
 void onchip_note_timeout();
+// Pinned host landing zone for the small status read-backs of the synchronous entry points (a device-to-host copy into
+// pageable memory is staged through an internal buffer and costs tens of microseconds more): one 256-byte block per
+// host thread, allocated on first use; nullptr if pinned memory is unavailable (callers then copy to their stack).
+void* pinned_status_block();
+// hipOccupancyMaxActiveBlocksPerMultiprocessor costs microseconds per call and its answer for a given kernel, block
+// size and dynamic LDS size never changes within a process: asked once per call site (one site per instantiation)
+#define LO_OCCUPANCY_CACHED(out_int, kernel, tpb, dyn_lds)                                                   \
+  ([&]() -> hipError_t {                                                                                     \
+    static int cached = -1;                                                                                  \
+    static hipError_t cached_err = hipSuccess;                                                               \
+    if (cached < 0) {                                                                                        \
+      int v = 0;                                                                                             \
+      cached_err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, tpb, dyn_lds);                   \
+      cached = (cached_err == hipSuccess) ? v : 0;                                                           \
+    }                                                                                                        \
+    (out_int) = cached;                                                                                      \
+    return cached_err;                                                                                       \
+  }())
 
 // ---- fp64 helpers (lo_cg_f64.hip), shared by the fp64 CG and MINRES engines ---------------------------------------
 // out1[b, j] = sum_i a[b, i, j] b1[b, i, j] (and out2 from (a2, b2) when a2 != nullptr)

@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #pragma clang fp contract(off)
 
 #include "lo_device.h"
@@ -915,8 +916,12 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   int h[2];
-  LO_HIP_CHECK(hipMemcpyAsync(h, l.err, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-  LO_HIP_CHECK(hipStreamSynchronize(st));
+  {
+    void* hp = pinned_status_block();
+    LO_HIP_CHECK(hipMemcpyAsync(hp ? hp : h, l.err, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    LO_HIP_CHECK(hipStreamSynchronize(st));
+    if (hp) memcpy(h, hp, sizeof(h));
+  }
   if (debug) {
     long long ts[12];
     LO_HIP_CHECK(hipMemcpy(ts, l.dbg, sizeof(ts), hipMemcpyDeviceToHost));

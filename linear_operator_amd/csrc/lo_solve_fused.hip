@@ -94,12 +94,7 @@ struct FuLayout {
 
 static constexpr int kFuMaxWgs = 1024;  // two workgroups per CU on up to 512 CUs
 
-// pinned host landing zone of the status block (a copy to pageable memory is staged and slow); one per host thread
-static FusedCtrl* pinned_ctrl() {
-  static thread_local FusedCtrl* p = nullptr;
-  if (!p && hipHostMalloc(reinterpret_cast<void**>(&p), sizeof(FusedCtrl), hipHostMallocDefault) != hipSuccess) p = nullptr;
-  return p;
-}
+static FusedCtrl* pinned_ctrl() { return static_cast<FusedCtrl*>(pinned_status_block()); }
 
 static void fu_layout(int64_t B, int rank, int iters, int64_t c, int nwgs, Arena& ar, FuLayout* l) {
   l->pgbuf = ar.take<unsigned long long>((size_t)nwgs * 2 * FU_SLOT);
@@ -193,14 +188,18 @@ int lo_solve_fused_f32(const lo_op_desc* op, int32_t rank, float error_tol, cons
   else if (op->R == 8) rc = fused_launch_r8(a, nwg, st);
   if (rc) return rc;
   const int fmi = prm->floor_max_iter > 0 ? prm->floor_max_iter : prm->max_iter;
-  hipLaunchKernelGGL(k_fused_ctrl, dim3(1), dim3(kThreads), 0, st, l.ctrl, l.resid_rec, l.init_conv, l.ints + 1, l.ints,
-                     B * prm->c, iters, fmi, prm->tolerance);
-  LO_LAUNCH_CHECK();
   FusedCtrl h;
-  FusedCtrl* hp = pinned_ctrl();
-  LO_HIP_CHECK(hipMemcpyAsync(hp ? hp : &h, l.ctrl, sizeof(h), hipMemcpyDeviceToHost, st));
-  LO_HIP_CHECK(hipStreamSynchronize(st));
-  if (hp) h = *hp;
+  FusedCtrl* hp = pinned_ctrl();  // the decision lands in pinned host memory: no device-to-host copy command
+  hipLaunchKernelGGL(k_fused_ctrl, dim3(1), dim3(kThreads), 0, st, hp ? hp : l.ctrl, l.resid_rec, l.init_conv, l.ints + 1,
+                     l.ints, B * prm->c, iters, fmi, prm->tolerance);
+  LO_LAUNCH_CHECK();
+  if (hp) {
+    LO_HIP_CHECK(hipStreamSynchronize(st));
+    h = *hp;
+  } else {
+    LO_HIP_CHECK(hipMemcpyAsync(&h, l.ctrl, sizeof(h), hipMemcpyDeviceToHost, st));
+    LO_HIP_CHECK(hipStreamSynchronize(st));
+  }
   if (debug) {
     long long ts[16];
     LO_HIP_CHECK(hipMemcpy(ts, l.dbg, sizeof(ts), hipMemcpyDeviceToHost));

@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
 template <int RC, int GW, bool MC>
 static int fused_go(const FusedArgs& a, int nwg, hipStream_t st) {
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_fused<RC, GW, MC>, R4_TPB, 0) != hipSuccess ||
+  if (LO_OCCUPANCY_CACHED(per_cu, (k_solve_fused<RC, GW, MC>), R4_TPB, 0) != hipSuccess ||
       per_cu < 2 || (2 * nwg / 8) / GW < 1)
     return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("solve_fused", st);
