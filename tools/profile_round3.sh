@@ -1,0 +1,57 @@
+#!/bin/bash
+# Round 3 profiles (runs on the MI355X box through gpurun): rocprofv3 kernel-trace stats of the bench, of the end-to-end
+# solve (fused one-launch kernel) and of the per-config microbenchmarks; separate PMC passes (FETCH_SIZE, WRITE_SIZE;
+# kernel-trace only) for the headline kernel and the fused kernel, the traffic*.json files bench.py cites, wave-cycle
+# counters of the fused kernel, and the bench line itself.  Output: gpurun_out/prof3/ (copied to profiles/r03/).
+set -u
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof3
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+B="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras"
+stats() {  # name, command...
+  local name=$1; shift
+  rm -rf /tmp/p_$name
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$name -- "$@" > $OUT/${name}_under_rocprof.log 2>&1
+  cp "$(find /tmp/p_$name -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_$name.csv
+}
+stats bench $B
+stats e2e python $R/tools/mb_e2e.py
+stats iql python $R/tools/mb_iql_pieces.py
+stats cfg45 python $R/tools/mb_cfg45.py
+stats lanczos python $R/tools/mb_lanczos.py
+pmc() {  # name, counter, command...
+  local name=$1 ctr=$2; shift 2
+  rm -rf /tmp/q_${name}_$ctr
+  timeout 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/q_${name}_$ctr -- "$@" > /dev/null 2>&1
+  python $R/tools/pmc_summary.py /tmp/q_${name}_$ctr
+}
+{ pmc bench FETCH_SIZE $B; pmc bench WRITE_SIZE $B; } > $OUT/pmc_fetch_write_bench.txt
+{ pmc e2e FETCH_SIZE python $R/tools/mb_e2e.py; pmc e2e WRITE_SIZE python $R/tools/mb_e2e.py; } > $OUT/pmc_fetch_write_e2e.txt
+python - "$OUT" <<'PY'
+import json, re, sys
+out = sys.argv[1]
+def grab(path, counter, kernel):
+    for line in open(path):
+        if line.startswith(counter) and kernel in line:
+            return float(re.search(r"avg=\s*([0-9.]+)", line).group(1))
+    return None
+for fname, src, prof_name, kern, label in (
+        ("traffic.json", "pmc_fetch_write_bench.txt", "cg_onchip", "k_cg_onchip5<32, 8, false>", "k_cg_onchip5<32,8,false>"),
+        ("traffic_fused.json", "pmc_fetch_write_e2e.txt", "solve_fused", "k_solve_fused<32, 8, false>", "k_solve_fused<32,8,false>")):
+    f, w = grab(f"{out}/{src}", "FETCH_SIZE", kern), grab(f"{out}/{src}", "WRITE_SIZE", kern)
+    if f is not None and w is not None:
+        json.dump({"prof_name": prof_name, "kernel": label, "FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w,
+                   "fetch_correction": 2.0, "traffic_bytes_per_launch": (2.0 * f + w) * 1024,
+                   "source": f"{src} (rocprofv3 --pmc, separate passes)"}, open(f"{out}/{fname}", "w"), indent=1)
+PY
+# where the wave cycles of the fused kernel go (one pass per counter)
+: > $OUT/pmc_wave_cycles_e2e.txt
+for c in SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 VALUBusy; do
+  rm -rf /tmp/p_w
+  timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/p_w -- python $R/tools/mb_e2e.py > /dev/null 2>&1
+  python $R/tools/pmc_summary.py /tmp/p_w k_solve_fused >> $OUT/pmc_wave_cycles_e2e.txt
+  python $R/tools/pmc_summary.py /tmp/p_w k_cg_onchip5 >> $OUT/pmc_wave_cycles_e2e.txt
+done
+cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err
+ls -la $OUT
