@@ -450,6 +450,9 @@ def _cg_params(c, n_tridiag, max_iter, max_tridiag_iter, tolerance, eps, stop_up
     return prm
 
 
+_fused_ws_bytes: dict = {}  # workspace size of lo_solve_fused_f32 per (B, rank, c, max_iter, floor): a pure function
+
+
 def solve_fused_supported(desc: Optional[OperatorDescriptor], c: int, rank: int, max_iter: int = 1000,
                           floor_max_iter: int = 0) -> bool:
     """True if lo_solve_fused_f32 takes this operator / right-hand side shape (see include/lo_amd.h)."""
@@ -477,9 +480,7 @@ def solve_fused(desc: OperatorDescriptor, rhs: torch.Tensor, rank: int, error_to
     dev = rhs.device
     rank = min(int(rank), N)
     prm = _cg_params(c, 0, max_iter, min(20, max_iter), tolerance, eps, stop_updating_after, floor_max_iter)
-    s = desc.c_struct()
-    if not lib.lo_solve_fused_supported(C.byref(s), rank, C.byref(prm)):
-        return None
+    s = desc.c_struct()  # (shapes the kernel does not take come back as LO_ERR_UNSUPPORTED from the call itself)
     R = desc.R
     const = desc.diag_mode == _hip.LO_DIAG_CONST
     x = torch.empty_like(rhs3)
@@ -488,7 +489,11 @@ def solve_fused(desc: OperatorDescriptor, rhs: torch.Tensor, rank: int, error_to
     logdet = small[3 * B * R * R:3 * B * R * R + B]
     swaps = small[3 * B * R * R + B:].view(torch.int32).view(B, rank)
     dinv = torch.empty(B if const else (B, N), dtype=torch.float32, device=dev)
-    ws = _hip.workspace(lib.lo_solve_fused_workspace_bytes(C.byref(s), rank, C.byref(prm)), dev)
+    wkey = (B, rank, c, max_iter, floor_max_iter)
+    nbytes = _fused_ws_bytes.get(wkey)
+    if nbytes is None:
+        nbytes = _fused_ws_bytes[wkey] = lib.lo_solve_fused_workspace_bytes(C.byref(s), rank, C.byref(prm))
+    ws = _hip.workspace(nbytes, dev)
     info = _hip.FusedInfo()
     rc = lib.lo_solve_fused_f32(C.byref(s), rank, float(error_tol), C.byref(prm), _hip.ptr(rhs3), _hip.ptr(x),
                                 _hip.ptr(F), _hip.ptr(EF), _hip.ptr(E), _hip.ptr(dinv), _hip.ptr(logdet),
