@@ -100,6 +100,16 @@ typedef struct lo_precond_desc {
   const float* E;        /* [B, rf_ld, rf_ld] = C^T D^-1 C                                          */
   int32_t rf_ld;         /* row stride of F / EF / E = padded root rank (8, 16 or 32); 0 = absent   */
   int32_t reserved2;
+  /* Optional KRONECKER ROOT FORM of the same preconditioner (lo_precond_kron_root_f32), valid when the operator is
+   * LO_OP_KRON_DIAG with a constant diagonal and L is the pivoted Cholesky factor of K1 (x) K2 with k <= 16 pivots.
+   * Row pi of K1 (x) K2 is the Kronecker product of row pi / n2 of K1 and row pi % n2 of K2, and every column of L
+   * is a combination of the pivot rows (L = KP M, KP[(i1, i2), m] = kron_a[i1][m] * kron_b[i2][m]), hence
+   *   P^-1 r = (r - KP F KP^T (r o dinv)) o dinv,   F = (KP[pivots, :] + KP^T D^-1 KP)^-1  (k x k).
+   * The single-column CG iteration of large N (csrc/lo_precond_fused.hip) then forms the rows of KP on the fly from
+   * 16 (n1 + n2) floats per member instead of streaming the 16 N floats of Q.  NULL = not available (Q is used).  */
+  const float* kron_a;   /* [B, n1, 16]: kron_a[i1][m] = K1[pi_m / n2, i1], columns >= k zero       */
+  const float* kron_b;   /* [B, n2, 16]: kron_b[i2][m] = K2[pi_m % n2, i2]                          */
+  const float* kron_F;   /* [B, 16, 16], symmetric, zero padded                                     */
 } lo_precond_desc;
 
 /* Batch-sharded solves (one process per GPU, SURVEY.md section 8(e) "option A"): the reference's stopping rule is the
@@ -265,6 +275,16 @@ int lo_precond_root_form_f32(const float* C, int32_t R, const float* d, int32_t 
                              int64_t ld_member, int64_t ld_row, int64_t ld_col, const int64_t* perm, int64_t B,
                              int64_t N, int32_t k, int32_t rf_ld, float* F, float* EF, float* E, float* dinv,
                              float* logdet_p, void* ws, size_t ws_bytes, void* stream);
+/* Kronecker root form of the pivoted-Cholesky preconditioner (see lo_precond_desc.kron_*): op = LO_OP_KRON_DIAG with
+ * LO_DIAG_CONST, L / perm as lo_precond_root_form_f32 (k <= 16 pivots).  Gathers the pivot rows of the two factors
+ * (kron_a [B, n1, 16], kron_b [B, n2, 16]), forms E = KP^T KP / sigma as the Hadamard product of the two small Gram
+ * matrices and runs the fp64 algebra of the root form: F [B, 16, 16].  kappa [B]: the factor by which the fp32 rounding
+ * of KP^T (r / d) is amplified in P^-1 r, sqrt(sum_m (F E F)_mm E_mm) -- a few units for well separated pivots, large
+ * when the pivot rows are nearly dependent (the caller then keeps the Q form).                                     */
+size_t lo_precond_kron_root_workspace_bytes(int64_t B);
+int lo_precond_kron_root_f32(const lo_op_desc* op, const float* L, int64_t ld_member, int64_t ld_row, int64_t ld_col,
+                             const int64_t* perm, int32_t k, float* kron_a, float* kron_b, float* kron_F,
+                             float* kappa, void* ws, size_t ws_bytes, void* stream);
 /* z = P^{-1} r  (precondition_closure, added_diag_linear_operator.py:135-140) */
 size_t lo_precond_apply_workspace_bytes(int64_t B, int64_t N, int32_t k, int64_t c);
 int lo_precond_apply_f32(const lo_precond_desc* pre, const float* r, float* z, int64_t B, int64_t N, int64_t c, void* ws,

@@ -955,6 +955,12 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   // large-N single-column solves: the preconditioner apply fused with the r / x update, Q read once per iteration
   bool pf_on = pre && pre->Q && d.pf_gbuf && !tls_no_fused_precond && oc_nwg >= 64 &&
                precond_fused_eligible(B, N, c, preR4, sp.S);
+  // Kronecker operator with a constant diagonal: the rows of the preconditioner's tall matrix are formed on the fly from
+  // the pivot rows of the two factors (lo_precond_desc.kron_*): 7 instead of 23 floats of traffic per row and iteration
+  PfKron kron{nullptr, nullptr, nullptr, 0, 0};
+  const bool pf_kron = pf_on && op->kind == LO_OP_KRON_DIAG && op->diag_mode == LO_DIAG_CONST && pre->constant_diag &&
+                       pre->kron_a && pre->kron_b && pre->kron_F && pre->k <= 16 && !getenv("LO_NO_KRON_ROOT");
+  if (pf_kron) kron = PfKron{pre->kron_a, pre->kron_b, pre->kron_F, (int)op->R, (int)op->n2};
   bool p_done = false;  // the fused apply of the previous iteration already wrote this iteration's p
   if (pf_on) {  // granules and hand-out counters of the fused apply: cleared once per solve (tags are unique per launch)
     LO_HIP_CHECK(hipMemsetAsync(d.pf_gbuf, 0, precond_fused_gbuf_bytes(), st));
@@ -995,7 +1001,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       rcb = precond_fused_rupdate(Qp, pre->dinv, pre->constant_diag ? LO_DIAG_CONST : LO_DIAG_FULL, d.r, d.Ap, d.p, d.x,
                                   d.z, d.pAp_part, d.S_dot, d.rz, d.has_conv, d.eps, d.alpha, d.rr_part, d.rz_part, sp.S,
                                   B, N, d.pf_gbuf, d.oc_err, d.pf_ctr, kk, dyn ? &d.ctrl->iterations : nullptr,
-                                  (int)prm->max_iter, stop, oc_nwg, &cf, ls);
+                                  (int)prm->max_iter, stop, oc_nwg, &cf, pf_kron ? &kron : nullptr, ls);
       if (rcb == LO_ERR_UNSUPPORTED) pf_on = false;  // (does not fit this device: the two-launch path from now on)
       else if (rcb) return rcb;
       else {

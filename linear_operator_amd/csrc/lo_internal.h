@@ -257,6 +257,7 @@ int f64_copy(const double* a, double* o, size_t total, hipStream_t st);
 
 // ---- single-pass Woodbury apply fused with the CG r / x update (lo_precond_fused.hip) --------------
 bool precond_fused_eligible(int64_t B, int64_t N, int64_t c, int ldq, int S);
+bool precond_fused_kron_eligible(int64_t n1, int64_t n2);  // factor sizes the Kronecker root-form kernel takes
 size_t precond_fused_gbuf_bytes();
 // the iteration's control step folded into the fused apply (single column, no tridiagonal, k >= 1)
 struct PfCtrl {
@@ -272,12 +273,20 @@ struct PfCtrl {
   unsigned long long* gran; // [B] tagged residual norms of the current launch (zeroed once per solve)
   CgCtrl* ctrl;
 };
+// Kronecker root form of the preconditioner (lo_precond_desc.kron_*): rows of "Q" formed on the fly (nullptr = Q form)
+struct PfKron {
+  const float* a;
+  const float* b;
+  const float* F;
+  int n1, n2;
+};
 // (also writes the next iteration's p = z + beta p; z itself is not stored)
 int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, float* r, const float* Ap, float* p,
                           float* x, float* z, const float* pAp_part, int S_dot, const float* rz, const int* has_conv,
                           float eps, float* alpha_out, float* rr_part, float* rz_part, int S, int64_t B, int64_t N,
                           unsigned long long* gbuf, int* err, int* next_member, int launch, const int* iter_ptr,
-                          int max_launch, const int* stop, int ncu, const PfCtrl* cf, hipStream_t st);
+                          int max_launch, const int* stop, int ncu, const PfCtrl* cf, const PfKron* kr,
+                          hipStream_t st);
 
 // ---- operator-resident pivoted Cholesky (lo_pivchol_onchip.hip) ----------------------------------
 bool pc_onchip_eligible(const lo_op_desc* op, int max_rank);

@@ -606,7 +606,9 @@ __global__ __launch_bounds__(kThreads) void k_pb_rootform(const double* __restri
                                                      const long long* __restrict__ perm, int N, int k, int S, int ld,
                                                      float* __restrict__ F, float* __restrict__ EF,
                                                      float* __restrict__ Eo, float* __restrict__ logdet,
-                                                     float* __restrict__ dinv_const) {
+                                                     float* __restrict__ dinv_const,
+                                                     const float* __restrict__ Cpiv = nullptr,
+                                                     float* __restrict__ kappa = nullptr) {
   __shared__ double E[kPbMaxK][kPbMaxK + 1];
   __shared__ double M[kPbMaxK][kPbMaxK + 1];   // [R][k]
   __shared__ double T[kPbMaxK][kPbMaxK + 1];   // scratch: E M, then Y = M Lg^-T
@@ -630,7 +632,8 @@ __global__ __launch_bounds__(kThreads) void k_pb_rootform(const double* __restri
   __syncthreads();
   for (int pr = lane; pr < k * R; pr += NT) {
     const int j = pr / R, a = pr % R;
-    T[j][a] = (double)Cb[(size_t)piv[j] * R + a];
+    // (Cpiv: the k pivot rows handed over explicitly, [B, R, R] -- the Kronecker root form has no tall C in memory)
+    T[j][a] = Cpiv ? (double)Cpiv[((size_t)b * R + j) * R + a] : (double)Cb[(size_t)piv[j] * R + a];
   }
   for (int pr = lane; pr < k * k; pr += NT) {
     const int j = pr / k, i = pr % k;
@@ -702,6 +705,23 @@ __global__ __launch_bounds__(kThreads) void k_pb_rootform(const double* __restri
     EFb[pr] = (float)ef;
     Eb[pr] = (float)e;
   }
+  if (kappa) {  // sqrt(sum_m (F E F)_mm E_mm): amplification of the fp32 rounding of C^T (r/d) in P^-1 r (lo_amd.h)
+    if (lane < R) {
+      double t = 0.0;
+      for (int q = 0; q < R; ++q) {
+        double ef = 0.0;
+        for (int c2 = 0; c2 < R; ++c2) ef += E[q][c2] * Fm[c2][lane];
+        t += Fm[lane][q] * ef;
+      }
+      T[lane][0] = t * E[lane][lane];
+    }
+    __syncthreads();
+    if (lane == 0) {
+      double t = 0.0;
+      for (int m = 0; m < R; ++m) t += T[m][0];
+      kappa[b] = (float)sqrt(fabs(t));
+    }
+  }
   if (lane == 0) {
     double ldt = 0.0;
     for (int j = 0; j < k; ++j) ldt += log(fabs(G[j][j]));
@@ -718,6 +738,54 @@ __global__ __launch_bounds__(kThreads) void k_pb_rootform(const double* __restri
   }
 }
 
+
+// ---- Kronecker root form (lo_precond_desc.kron_*) --------------------------------------------------------------------
+// Row pi of K1 (x) K2 (what the pivoted Cholesky fetched, _pivoted_cholesky.py:81 through kronecker_product...py:34-45)
+// is K1[pi / n2, :] (x) K2[pi % n2, :].  One workgroup per member gathers the k <= 16 pivot rows of both factors
+// (transposed and zero padded to 16: a quad of lanes reads the 16 values of a row index as one 64-byte line), the
+// Gram matrix KP^T KP = (A^T A) o (B^T B) in fp64 and the start of the recurrence of k_pb_rootform (unit vectors).
+__global__ __launch_bounds__(kThreads) void k_pb_kron_gather(const float* __restrict__ K1, const float* __restrict__ K2,
+                                                             int n1, int n2, const long long* __restrict__ perm, int N,
+                                                             int k, float* __restrict__ ka, float* __restrict__ kb,
+                                                             double* __restrict__ gpart, float* __restrict__ Cpiv) {
+  __shared__ int p1[16], p2[16];
+  const int64_t b = blockIdx.x;
+  const int t = threadIdx.x;
+  if (t < 16) {
+    const long long pv = t < k ? perm[(size_t)b * N + t] : 0;
+    p1[t] = (int)(pv / n2);
+    p2[t] = (int)(pv % n2);
+  }
+  __syncthreads();
+  const float* K1b = K1 + (size_t)b * n1 * n1;
+  const float* K2b = K2 + (size_t)b * n2 * n2;
+  for (int e = t; e < n1 * 16; e += kThreads) {
+    const int i = e >> 4, m = e & 15;
+    ka[(size_t)b * n1 * 16 + e] = m < k ? K1b[(size_t)p1[m] * n1 + i] : 0.f;
+  }
+  for (int e = t; e < n2 * 16; e += kThreads) {
+    const int i = e >> 4, m = e & 15;
+    kb[(size_t)b * n2 * 16 + e] = m < k ? K2b[(size_t)p2[m] * n2 + i] : 0.f;
+  }
+  {  // one pair (m, n) per thread (kThreads == 256)
+    const int m = t >> 4, n = t & 15;
+    double g1 = 0.0, g2 = 0.0;
+    float cp = 0.f;
+    if (m < k && n < k) {
+      const float* ra = K1b + (size_t)p1[m] * n1;
+      const float* rb = K1b + (size_t)p1[n] * n1;
+      for (int i = 0; i < n1; ++i) g1 += (double)ra[i] * (double)rb[i];
+      ra = K2b + (size_t)p2[m] * n2;
+      rb = K2b + (size_t)p2[n] * n2;
+      for (int i = 0; i < n2; ++i) g2 += (double)ra[i] * (double)rb[i];
+      // column m of K IS column m of KP: the recurrence of k_pb_rootform starts from the unit vectors
+      // (M[:, j] = (e_j - sum_{i<j} M[:, i] L[pi_j, i]) / L[pi_j, j], i.e. M = Lp^-T with Lp = L[pivots, :])
+      cp = (m == n) ? 1.0f : 0.0f;
+    }
+    gpart[(size_t)b * 256 + t] = g1 * g2;
+    Cpiv[(size_t)b * 256 + t] = cp;
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Wide preconditioners, 32 < k <= 128 (settings.max_preconditioner_size beyond the register-resident algebra above).
@@ -1081,6 +1149,44 @@ int lo_precond_root_form_f32(const float* C, int32_t R, const float* d, int32_t 
   LO_PROF_BEGIN("pb_rootform", st);
   hipLaunchKernelGGL(k_pb_rootform, dim3((unsigned)B), dim3(kThreads), 0, st, gpart, logd, C, (int)R, d, diag_mode, L, ls,
                      (const long long*)perm, (int)N, (int)k, sp.S, (int)rf_ld, F, EF, E, logdet_p, dinv);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+size_t lo_precond_kron_root_workspace_bytes(int64_t B) {
+  Arena ar(nullptr, 0);
+  ar.take<double>((size_t)B * 256);
+  ar.take<double>((size_t)B);
+  ar.take<float>((size_t)B * 256 * 3);
+  ar.take<float>((size_t)B * 2);
+  return ar.off + 1024;
+}
+
+int lo_precond_kron_root_f32(const lo_op_desc* op, const float* L, int64_t ld_member, int64_t ld_row, int64_t ld_col,
+                             const int64_t* perm, int32_t k, float* kron_a, float* kron_b, float* kron_F, float* kappa,
+                             void* ws, size_t ws_bytes, void* stream) {
+  if (!op || !L || !perm || !kron_a || !kron_b || !kron_F || !kappa || !ws) return LO_ERR_BADARG;
+  if (op->kind != LO_OP_KRON_DIAG || op->diag_mode != LO_DIAG_CONST || !op->A0 || !op->A1 || !op->d)
+    return LO_ERR_UNSUPPORTED;
+  if (k < 1 || k > 16 || op->R < 1 || op->n2 < 1 || op->R * op->n2 != op->N) return LO_ERR_UNSUPPORTED;
+  static_assert(kThreads == 256, "k_pb_kron_gather: one (m, n) pair per thread");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t B = op->B;
+  Arena ar(ws, ws_bytes);
+  double* gpart = ar.take<double>((size_t)B * 256);
+  double* logd = ar.take<double>((size_t)B);
+  float* scratch = ar.take<float>((size_t)B * 256 * 3);  // pivot rows of KP, EF, E
+  float* small = ar.take<float>((size_t)B * 2);          // logdet, 1 / sigma (both already known from the Q form)
+  if (!ar.ok) return LO_ERR_WORKSPACE;
+  float* Cpiv = scratch;
+  LO_PROF_BEGIN("pb_kron_root", st);
+  hipLaunchKernelGGL(k_pb_kron_gather, dim3((unsigned)B), dim3(kThreads), 0, st, op->A0, op->A1, (int)op->R, (int)op->n2,
+                     (const long long*)perm, (int)op->N, (int)k, kron_a, kron_b, gpart, Cpiv);
+  const LStride ls{ld_member, ld_row, ld_col};
+  hipLaunchKernelGGL(k_pb_rootform, dim3((unsigned)B), dim3(kThreads), 0, st, gpart, logd, (const float*)nullptr, 16,
+                     op->d, (int)LO_DIAG_CONST, L, ls, (const long long*)perm, (int)op->N, (int)k, 1, 16, kron_F,
+                     scratch + (size_t)B * 256, scratch + (size_t)B * 512, small, small + B, (const float*)Cpiv, kappa);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;

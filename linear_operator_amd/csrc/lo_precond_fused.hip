@@ -15,6 +15,15 @@
 // The kernel also knows the new r.z after the exchange, hence beta: it writes the next search direction
 // p <- z + beta p instead of z, and the separate p-update pass of the streaming loop disappears.
 //   bound: HBM -- 4 N (16 + 8) bytes per member and iteration (Q once; r, Ap, p, x, dinv in; r, x, p out).
+//
+// k_precond_fused_kron (round 3): the same iteration step for the KRONECKER ROOT FORM (lo_precond_desc.kron_*).  The
+// preconditioner of K1 (x) K2 + sigma I is P = KP (KP[pivots, :])^-1 KP^T + sigma I, where column m of KP is the
+// Kronecker product of pivot row a_m of K1 and pivot row b_m of K2, so
+//   z = r / sigma - KP F KP^T r / sigma^2,   F = (KP[pivots, :] + KP^T KP / sigma)^-1   (16 x 16),
+//   (KP^T v)_m = sum_i1 a_m[i1] sum_i2 b_m[i2] v[i1, i2],   (KP u)[i1, i2] = sum_m a_m[i1] (b_m[i2] u_m):
+// a thread owns rows with ONE second-factor index i2 (its 16 values b_.[i2] sit in registers) and takes the 16 values
+// a_.[i1] of each of its four rows from a 64-byte line most lanes of the wave share.  Nothing tall is read besides the
+// CG vectors: 4 N 7 bytes per member and iteration instead of 4 N 23.
 #include <algorithm>
 #include <stdlib.h>
 
@@ -55,6 +64,12 @@ struct PfArgs {
   // finishes a member records its scalars, the group that finishes the LAST member takes the batch-global decision
   PfCtrl cf;
   int launch;  // iteration index k of this launch (iter_ptr: read on the device)
+  // Kronecker root form (k_precond_fused_kron): kron_a [B, n1, 16], kron_b [B, n2, 16], kron_F [B, 16, 16]; Q unused
+  const float* ka;
+  const float* kb;
+  const float* kF;
+  int n1, n2;
+  float inv_n2;
 };
 
 // (pf_publish / pf_collect: the lane-parallel reduce-scatter all-reduce for groups of up to 64 workgroups, lo_group_reduce.h)
@@ -284,6 +299,224 @@ __global__ __launch_bounds__(R4_TPB, OCC) void k_precond_fused(PfArgs a) {
   }
 }
 
+// read-only data behind a wave-uniform address: the constant address space lets the compiler use the scalar cache
+// (a plain global pointer may alias the kernel's stores, which rules scalar loads out)
+typedef const float __attribute__((address_space(4)))* cfloat_ptr;
+__device__ __forceinline__ cfloat_ptr as_const_space(const float* p) { return (cfloat_ptr)(uintptr_t)p; }
+
+// Kronecker root form (see the header of this file).  Same group structure, member hand-out, control step and tags as
+// k_precond_fused.  Thread t owns the rows row0 + t + 256 q (q < NRK) of its workgroup: n2 divides 256, so they share
+// the second-factor index i2 (16 values b_.[i2] in registers), and n2 >= 64 with row0 a multiple of 256 makes the
+// first-factor index i1 uniform over a wave: the 16 values a_.[i1] of a row come through the scalar cache into SGPRs.
+// NRK = 4 or 16 rows per thread (16: a member of 65536 rows is a group of 16 workgroups instead of 64 -- a quarter
+// of the hand-offs, and the 28 bytes per row of a workgroup's share are enough to keep its loads streaming).
+template <int GW, int OCC, int NRK>
+__global__ __launch_bounds__(R4_TPB, OCC) void k_precond_fused_kron(PfArgs a) {
+  if (a.stop && *a.stop) return;
+  __shared__ R4Shared sh;
+  __shared__ float alpha_s, rzo_s;
+  __shared__ __attribute__((aligned(16))) float kf_s[256];
+  const int wg = blockIdx.x;
+  const int xcd = wg % 8, jx = wg / 8;
+  const int groups_per_xcd = (gridDim.x / 8) / GW;
+  const int grp = xcd * groups_per_xcd + jx / GW;
+  const int wig = jx % GW;
+  const int ngroups = groups_per_xcd * 8;
+  if (jx / GW >= groups_per_xcd) return;
+  const int t = threadIdx.x;
+  R4Group g;
+  g.gslot = a.gbuf + (size_t)grp * 2 * (GW + 1) * R4_SLOT;
+  g.wig = wig;
+  g.dbg = nullptr;
+  if (a.iter_ptr) {
+    const int launch = *a.iter_ptr;
+    a.tag_base = (unsigned)launch * (unsigned)(a.B + 2);
+    a.next_member += launch;
+    a.launch = launch;
+    if (a.cf.on) a.cf.done += launch;
+  }
+  g.tag = a.tag_base;
+  g.err = a.err;
+  g.same_xcd = false;
+  {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
+    if (t < 64) {
+      sh.red[0][0] = (float)xcc;
+      sh.red[0][1] = (float)(xcc * xcc);
+    }
+    if (t < 2 * (R4_WAVES - 1)) sh.red[1 + t / 2][t % 2] = 0.f;
+    const PfSlots ps = pf_publish<GW>(sh, 2, g);
+    pf_collect<GW>(sh, 2, g, ps);
+    const float fx = (float)xcc;
+    g.same_xcd = (sh.res[0] == GW * fx) && (sh.res[1] == GW * fx * fx) && (a.allow_l2_handoff != 0);
+    __syncthreads();
+  }
+  const int row0 = wig * a.RW;  // multiple of 256 (precond_fused_rupdate)
+  const int nv = max(0, min(a.RW, a.N - row0));
+  const int lane = t & 63, wave = t >> 6;
+  // first-factor index of the wave's rows at q = 0 and its step per q; the second-factor index of the thread
+  const int nw0 = row0 + 64 * wave;  // (n2 >= 64 divides 256: the wave's 64 rows share i1)
+  const int i1w = __builtin_amdgcn_readfirstlane(min(nw0, a.N - 1) / a.n2);
+  const int i1step = R4_TPB / a.n2;
+  const int i2 = (nw0 + lane) % a.n2;
+  const int i1max = a.n1 - 1;
+  int64_t b = grp;
+  while (b < a.B) {
+    float rv[NRK], apv[NRK];
+    const size_t mb = (size_t)b * a.N + row0;
+    const float* kab = a.ka + (size_t)b * a.n1 * 16;
+    const float4* kb4 = reinterpret_cast<const float4*>(a.kb) + ((size_t)b * a.n2 + i2) * 4;
+    float bm[16];
+    {
+      const float4 b0 = kb4[0], b1 = kb4[1], b2 = kb4[2], b3 = kb4[3];
+      bm[0] = b0.x; bm[1] = b0.y; bm[2] = b0.z; bm[3] = b0.w; bm[4] = b1.x; bm[5] = b1.y; bm[6] = b1.z; bm[7] = b1.w;
+      bm[8] = b2.x; bm[9] = b2.y; bm[10] = b2.z; bm[11] = b2.w; bm[12] = b3.x; bm[13] = b3.y; bm[14] = b3.z; bm[15] = b3.w;
+    }
+    kf_s[t] = a.kF[(size_t)b * 256 + t];  // (R4_TPB == 256 entries; the barrier behind the alpha block covers it)
+    const float dc = a.dinv[b];
+#pragma unroll
+    for (int q = 0; q < NRK; ++q) {
+      const int lr = t + R4_TPB * q;
+      const bool ok = lr < nv;
+      rv[q] = ok ? a.r[mb + lr] : 0.f;
+      apv[q] = ok ? a.Ap[mb + lr] : 0.f;
+    }
+    if (t < 64) {  // masked alpha from the matvec's p.Ap partials (linear_cg.py:250-260), while the loads are in flight
+      float pAp = 0.f;
+      for (int s = t; s < a.S_dot; s += 64) pAp += a.pAp_part[(size_t)b * a.S_dot + s];
+      pAp = wave_sum_fast(pAp);
+      const float rzo = a.rz[b];
+      float al = (pAp < a.eps) ? 0.f : rzo / pAp;
+      if (a.has_conv[b]) al = 0.f;
+      if (t == 0) {
+        rzo_s = rzo;
+        alpha_s = al;
+        if (wig == 0) a.alpha_out[b] = al;
+      }
+    }
+    __syncthreads();
+    const float al = alpha_s;
+    float sc0 = 0.f;
+    float wm[16];  // sum over the thread's rows of a_m[i1] r[i1, i2]; times b_m[i2] / sigma below
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wm[m] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NRK; ++q) {
+      rv[q] = fmaf(-al, apv[q], rv[q]);  // r -= alpha Ap     :264
+      sc0 = fmaf(rv[q], rv[q], sc0);
+      const cfloat_ptr ar = as_const_space(kab + (size_t)min(i1w + q * i1step, i1max) * 16);  // wave-uniform: s_load
+#pragma unroll
+      for (int m = 0; m < 16; ++m) wm[m] = fmaf(ar[m], rv[q], wm[m]);
+    }
+    {
+      // lane l: wave sum of component l >> 2 of w = KP^T (r / sigma)
+      const float mine = r4_wave_rs_t<16>([&](int c) { return wm[c] * (bm[c] * dc); }, lane);
+      if ((lane & 3) == 0) sh.red[wave][lane >> 2] = mine;
+      const float s0 = wave_sum_fast(sc0);
+      if (lane == 0) {
+        sh.red[wave][16] = s0;
+        sh.red[wave][17] = s0 * dc;  // sum r^2 / d (constant diagonal)
+        // the next member rides on the same all-reduce: drawn by the group's first workgroup (exact below 2^24)
+        sh.red[wave][18] = (wig == 0 && wave == 0) ? (float)(ngroups + atomicAdd(a.next_member, 1)) : 0.f;
+      }
+    }
+    const PfSlots ps = pf_publish<GW>(sh, 19, g);
+    // while the partial sums travel: store r, update x
+    float pv[NRK];
+#pragma unroll
+    for (int q = 0; q < NRK; ++q) {
+      const int lr = t + R4_TPB * q;
+      pv[q] = 0.f;
+      if (lr < nv) {
+        pv[q] = a.p[mb + lr];
+        a.r[mb + lr] = rv[q];
+        a.x[mb + lr] = fmaf(al, pv[q], a.x[mb + lr]);  // x += alpha p      :31
+      }
+    }
+    pf_collect<GW>(sh, 19, g, ps);
+    // u = F w (every lane: all 16 entries, F rows from LDS as broadcast reads), r.z = sum r^2/d - w.u
+    float cm[16];  // b_m[i2] u_m / sigma
+    float uu = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const float* row = kf_s + m * 16;
+      float s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) {
+        const float4 f4 = *reinterpret_cast<const float4*>(row + j);
+        const float4 w4 = *reinterpret_cast<const float4*>(&sh.res[j]);
+        s2 = fmaf(f4.x, w4.x, s2); s2 = fmaf(f4.y, w4.y, s2); s2 = fmaf(f4.z, w4.z, s2); s2 = fmaf(f4.w, w4.w, s2);
+      }
+      uu = fmaf(sh.res[m], s2, uu);
+      cm[m] = bm[m] * (s2 * dc);
+    }
+    const float srr = sh.res[16], srz = sh.res[17] - uu;
+    const float rzo = rzo_s;
+    const float beta = (rzo < a.eps) ? 0.f : srz / rzo;  // the control step's rule (:39-42) on the same numbers
+    // (uniform by construction; readfirstlane tells the compiler, so that the a_.[i1] loads stay scalar)
+    const int64_t bnext = (int64_t)__builtin_amdgcn_readfirstlane((int)sh.res[18]);
+    int cf_old = -1;
+    if (a.cf.on && wig == 0 && t == 0) {  // control step of this member: see k_precond_fused
+      float rn = sqrtf(srr);
+      if (a.cf.rhs_is_zero[b]) rn = 0.f;
+      a.cf.rz[b] = srz;
+      a.cf.beta[b] = beta;
+      a.cf.resid_norm[b] = rn;
+      a.cf.has_conv[b] = rn < a.cf.stop_after;
+      __hip_atomic_store(a.cf.gran + b, ((unsigned long long)(unsigned)(a.launch + 1) << 32) | __float_as_uint(rn),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cf_old = atomicAdd(a.cf.done, 1);
+    }
+#pragma unroll
+    for (int q = 0; q < NRK; ++q) {
+      const int lr = t + R4_TPB * q;
+      const cfloat_ptr ar = as_const_space(kab + (size_t)min(i1w + q * i1step, i1max) * 16);
+      float zq = 0.f;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) zq = fmaf(ar[m], cm[m], zq);
+      // z = r/sigma - KP F KP^T r / sigma^2 goes straight into p <- z + beta p (:46)
+      if (lr < nv) a.p[mb + lr] = fmaf(pv[q], beta, fmaf(rv[q], dc, -zq));
+    }
+    if (wig == 0 && t < a.S) {  // the control step sums S partials per member: the totals go to slot 0
+      a.rr_part[(size_t)b * a.S + t] = (t == 0) ? srr : 0.f;
+      a.rz_part[(size_t)b * a.S + t] = (t == 0) ? srz : 0.f;
+    }
+    if (a.cf.on && wig == 0 && t < 64) {
+      const int last = __builtin_amdgcn_readfirstlane((cf_old == (int)a.B - 1) ? 1 : 0);
+      if (last) {  // every member of the batch is recorded: the batch-global decisions (cg_ctrl_body), fixed order
+        float ls = 0.f;
+        const unsigned want = (unsigned)(a.launch + 1);
+        for (int64_t i = t; i < a.B; i += 64) {
+          unsigned long long gq;
+          unsigned spin = 0;
+          do {
+            gq = __hip_atomic_load(a.cf.gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((unsigned)(gq >> 32) != want && ++spin < R4_MAXSPIN);
+          if ((unsigned)(gq >> 32) != want) atomicExch(a.err, 1);
+          ls += __uint_as_float((unsigned)(gq & 0xffffffffull));
+        }
+        const float mean = wave_sum_fast(ls) / (float)a.B;
+        if (t == 0) {
+          const int k = a.launch;
+          a.cf.ctrl->iterations = k + 1;
+          a.cf.ctrl->mean_resid = mean;
+          if (k >= a.cf.kfloor && mean < a.cf.tol) {  // :302-306 (no tridiagonal columns on this path)
+            a.cf.ctrl->tol_reached = 1;
+            a.cf.ctrl->stop = 1;
+          }
+        }
+      }
+    }
+    __syncthreads();  // (sh.res / alpha_s / rzo_s / kf_s are reused by the next member)
+    b = bnext;
+  }
+}
+
+// second-factor sizes the kernel takes: n2 divides 256 (a thread's rows share i2) and n2 >= 64 (a wave's rows share i1)
+bool precond_fused_kron_eligible(int64_t n1, int64_t n2) {
+  return n1 >= 1 && (n2 == 64 || n2 == 128 || n2 == 256) && n1 * n2 < (1 << 24) && !getenv("LO_NO_KRON_ROOT");
+}
+
 static int pf_group_size(int64_t N) { return N <= 16 * (int64_t)R4_ROWS ? 16 : (N <= 32 * (int64_t)R4_ROWS ? 32 : 64); }
 
 bool precond_fused_eligible(int64_t B, int64_t N, int64_t c, int ldq, int S) {
@@ -293,18 +526,22 @@ bool precond_fused_eligible(int64_t B, int64_t N, int64_t c, int ldq, int S) {
 
 size_t precond_fused_gbuf_bytes() { return (size_t)64 * 2 * 65 * R4_SLOT * sizeof(unsigned long long) + 256; }
 
-template <int GW, int OCC>
+template <int GW, int OCC, int NRK>  // NRK = 0: the Q form; 4 / 16: Kronecker root form with NRK rows per thread
 static int pf_go(PfArgs& a, int ncu, hipStream_t st) {
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_precond_fused<GW, OCC>, R4_TPB, 0) != hipSuccess ||
-      per_cu < 1)
-    return LO_ERR_UNSUPPORTED;
+  constexpr bool KR = NRK > 0;
+  constexpr int NK = KR ? NRK : 4;
+  const hipError_t oe =
+      KR ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_precond_fused_kron<GW, OCC, NK>, R4_TPB, 0)
+         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_precond_fused<GW, OCC>, R4_TPB, 0);
+  if (oe != hipSuccess || per_cu < 1) return LO_ERR_UNSUPPORTED;
   per_cu = std::min(per_cu, OCC);
   const int nwg = per_cu * ncu;
   if ((nwg / 8) < GW) return LO_ERR_UNSUPPORTED;
-  LO_PROF_BEGIN("precond_fused", st);
+  LO_PROF_BEGIN(KR ? "precond_fused_kron" : "precond_fused", st);
   ResidentLaunch guard(st);
-  hipLaunchKernelGGL((k_precond_fused<GW, OCC>), dim3(nwg), dim3(R4_TPB), 0, st, a);
+  if (KR) hipLaunchKernelGGL((k_precond_fused_kron<GW, OCC, NK>), dim3(nwg), dim3(R4_TPB), 0, st, a);
+  else hipLaunchKernelGGL((k_precond_fused<GW, OCC>), dim3(nwg), dim3(R4_TPB), 0, st, a);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
@@ -318,8 +555,14 @@ int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, floa
                           float* x, float* z, const float* pAp_part, int S_dot, const float* rz, const int* has_conv,
                           float eps, float* alpha_out, float* rr_part, float* rz_part, int S, int64_t B, int64_t N,
                           unsigned long long* gbuf, int* err, int* next_member, int launch, const int* iter_ptr,
-                          int max_launch, const int* stop, int ncu, const PfCtrl* cf, hipStream_t st) {
+                          int max_launch, const int* stop, int ncu, const PfCtrl* cf, const PfKron* kr,
+                          hipStream_t st) {
   PfArgs a;
+  const bool kron = kr && kr->a && kr->b && kr->F && dinv_mode == LO_DIAG_CONST &&
+                    precond_fused_kron_eligible(kr->n1, kr->n2);
+  a.ka = kron ? kr->a : nullptr; a.kb = kron ? kr->b : nullptr; a.kF = kron ? kr->F : nullptr;
+  a.n1 = kron ? kr->n1 : 0; a.n2 = kron ? kr->n2 : 1;
+  a.inv_n2 = 1.0f / (float)a.n2;
   a.launch = launch;
   if (cf) {
     a.cf = *cf;
@@ -330,8 +573,13 @@ int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, floa
   a.Q = Q; a.dinv = dinv; a.dinv_mode = dinv_mode; a.r = r; a.Ap = Ap; a.p = p; a.x = x; a.z = z;
   a.pAp_part = pAp_part; a.S_dot = S_dot; a.rz = rz; a.has_conv = has_conv; a.eps = eps; a.alpha_out = alpha_out;
   a.rr_part = rr_part; a.rz_part = rz_part; a.S = S; a.B = B; a.N = (int)N;
-  const int GW = pf_group_size(N);
+  int GW = pf_group_size(N);
   a.RW = (int)((N + GW - 1) / GW);
+  // Kronecker root form: 16 rows per thread (groups of 16 workgroups of 4096 rows) once the batch fills the device that
+  // way, else 4; a workgroup's first row is a multiple of 256 (wave-uniform first-factor index)
+  const bool kron16 = kron && N > 8 * (int64_t)4096 && B * ((N + 4095) / 4096) >= 512 && !getenv("LO_KRON_NR4");
+  if (kron16) GW = 16;
+  if (kron) a.RW = (int)(((N + (int64_t)GW * 256 - 1) / ((int64_t)GW * 256)) * 256);
   a.gbuf = gbuf; a.err = err; a.next_member = next_member; a.stop = stop;
   a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
   // next_member: base of the per-launch counters; launch: index of this launch (iter_ptr: read on the device instead)
@@ -341,9 +589,15 @@ int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, floa
   a.iter_ptr = iter_ptr;
   if (!iter_ptr) a.next_member = next_member + launch;
   // four workgroups per CU (110 VGPRs): cfg4 153 us per call against 188 us with two or three
-  if (GW == 16) return pf_go<16, 4>(a, ncu, st);
-  if (GW == 32) return pf_go<32, 4>(a, ncu, st);
-  return pf_go<64, 4>(a, ncu, st);
+  if (kron16) return pf_go<16, 4, 16>(a, ncu, st);
+  if (kron) {
+    if (GW == 16) return pf_go<16, 4, 4>(a, ncu, st);
+    if (GW == 32) return pf_go<32, 4, 4>(a, ncu, st);
+    return pf_go<64, 4, 4>(a, ncu, st);
+  }
+  if (GW == 16) return pf_go<16, 4, 0>(a, ncu, st);
+  if (GW == 32) return pf_go<32, 4, 0>(a, ncu, st);
+  return pf_go<64, 4, 0>(a, ncu, st);
 }
 
 }  // namespace lo

@@ -152,6 +152,10 @@ class WoodburyPreconditioner:
     EF: Optional[torch.Tensor] = None
     E: Optional[torch.Tensor] = None
     source: Optional[tuple] = None  # (L, d) the preconditioner was built from (to build Q later)
+    # Kronecker root form (lo_precond_desc.kron_*): (kron_a [B, n1, 16], kron_b [B, n2, 16], kron_F [B, 16, 16]) of a
+    # Kronecker operator with a constant diagonal -- the single-column CG of large N forms the rows of the tall matrix
+    # on the fly instead of streaming Q
+    kron: Optional[tuple] = None
     rebuild: Optional[Callable] = None  # root form from the fused solve (no L exists): () -> the full preconditioner
 
     @property
@@ -180,6 +184,8 @@ class WoodburyPreconditioner:
         if self.F is not None:
             s.F, s.EF, s.rf_ld = self.F.data_ptr(), self.EF.data_ptr(), self.rf_ld
             s.E = None if self.E is None else self.E.data_ptr()
+        if self.kron is not None:
+            s.kron_a, s.kron_b, s.kron_F = (t.data_ptr() for t in self.kron)
         return s
 
 
@@ -684,6 +690,34 @@ def _root_form(lib, root, perm, L3, d, constant_diag, B, N, k, dev) -> WoodburyP
     return WoodburyPreconditioner(None, dinv, k, constant_diag, logdet, F, EF, E)
 
 
+# the Kronecker root form multiplies the fp32 rounding of KP^T (r/d) by `kappa` (lo_amd.h); beyond this bound the
+# pivot rows are too close to dependent for 1e-4 solves and the orthonormal Q form is kept
+KRON_ROOT_MAX_KAPPA = 200.0
+
+
+def _kron_root(lib, desc: "OperatorDescriptor", perm, L3, k, dev) -> Optional[tuple]:
+    """lo_precond_kron_root_f32 for a Kronecker operator with a constant diagonal (descriptor with the diagonal
+    attached); None when some member's pivot rows are too ill conditioned (one read-back of B floats)."""
+    B, n1, n2 = desc.B, desc.R, desc.n2
+    ka = torch.empty(B, n1, 16, dtype=torch.float32, device=dev)
+    kb = torch.empty(B, n2, 16, dtype=torch.float32, device=dev)
+    kF = torch.empty(B, 16, 16, dtype=torch.float32, device=dev)
+    kappa = torch.empty(B, dtype=torch.float32, device=dev)
+    p2 = _flat(perm, 1)
+    ws = _hip.workspace(lib.lo_precond_kron_root_workspace_bytes(B), dev)
+    sm, sr, sc = L3.stride()
+    if B == 1:
+        sm = 0
+    s = desc.c_struct()
+    _hip.check(lib.lo_precond_kron_root_f32(C.byref(s), _hip.ptr(L3), sm, sr, sc, _hip.ptr(p2), k, _hip.ptr(ka),
+                                            _hip.ptr(kb), _hip.ptr(kF), _hip.ptr(kappa), _hip.ptr(ws), ws.numel(),
+                                            _hip.stream_ptr(dev)), "lo_precond_kron_root_f32")
+    worst = float(kappa.max())
+    if not (worst < KRON_ROOT_MAX_KAPPA):  # (also NaN)
+        return None
+    return ka, kb, kF
+
+
 def padded_rank(k: int) -> int:
     rq, p = (k + 3) // 4, 1
     while p < rq:
@@ -692,12 +726,15 @@ def padded_rank(k: int) -> int:
 
 
 def precond_build(L: torch.Tensor, d: torch.Tensor, constant_diag: bool, root: Optional[torch.Tensor] = None,
-                  perm: Optional[torch.Tensor] = None, need_q: bool = True) -> WoodburyPreconditioner:
+                  perm: Optional[torch.Tensor] = None, need_q: bool = True,
+                  kron: Optional["OperatorDescriptor"] = None) -> WoodburyPreconditioner:
     """lo_precond_build_f32: AddedDiagLinearOperator._init_cache* (added_diag_linear_operator.py:144-184).
     L [*batch, N, k]; d [*batch, N] (or [*batch] when constant_diag).
     root, perm: the root C [*batch, N, R <= 32] of the low-rank operator L was factored from and the permutation
     pivoted_cholesky returned -- adds the ROOT FORM (lo_precond_root_form_f32) the operator-resident CG kernels
-    prefer (one all-reduce per iteration, no second tall matrix); need_q=False then skips the generic Q."""
+    prefer (one all-reduce per iteration, no second tall matrix); need_q=False then skips the generic Q.
+    kron, perm: the descriptor (LO_OP_KRON_DIAG, constant diagonal) of the Kronecker operator L was factored from --
+    adds the Kronecker root form (lo_precond_kron_root_f32) for the single-column CG of 8192 <= N <= 65536."""
     lib = _hip.load()
     _hip.require_hip(L, d)
     N, k = L.shape[-2:]
@@ -735,7 +772,12 @@ def precond_build(L: torch.Tensor, d: torch.Tensor, constant_diag: bool, root: O
                                                 _hip.ptr(dinv), _hip.ptr(logdet), _hip.ptr(ws), ws.numel(),
                                                 _hip.stream_ptr(dev)),
                "lo_precond_build_strided_f32")
-    return WoodburyPreconditioner(Q, dinv, k, constant_diag, logdet.reshape(L.shape[:-2]))
+    out = WoodburyPreconditioner(Q, dinv, k, constant_diag, logdet.reshape(L.shape[:-2]))
+    if (kron is not None and perm is not None and constant_diag and kron.kind == _hip.LO_OP_KRON_DIAG
+            and kron.diag_mode == _hip.LO_DIAG_CONST and kron.B == B and kron.N == N and 1 <= k <= 16
+            and 8192 <= N <= 65536):
+        out.kron = _kron_root(lib, kron, perm, L3, k, dev)
+    return out
 
 
 def tridiag_eigh_slq(t_mat: torch.Tensor, n: int, want_evecs: bool = False, want_logdet: bool = True):

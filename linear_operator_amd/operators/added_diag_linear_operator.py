@@ -313,7 +313,15 @@ class AddedDiagLinearOperator(SumLinearOperator):
             root = root.detach().expand(*batch_shape, *root.shape[-2:])
             self._woodbury = K.precond_build(L, d_arg.to(torch.float32), self._constant_diag, root=root, perm=perm)
         else:
-            self._woodbury = K.precond_build(L, d_arg.to(torch.float32), self._constant_diag)
+            # a Kronecker operator (two dense groups) with a constant diagonal also gets the Kronecker root form: the
+            # single-column CG of large N then forms the rows of the preconditioner's tall matrix on the fly
+            kron = None
+            if self._constant_diag and perm is not None:
+                base = self._linear_op._kernel_descriptor()
+                if (base is not None and base.kind == K._hip.LO_OP_KRON_DIAG and base.diag_mode == K._hip.LO_DIAG_NONE
+                        and tuple(base.batch_shape) == tuple(batch_shape)):
+                    kron = K._with_diag(base, d_arg.to(torch.float32), True)
+            self._woodbury = K.precond_build(L, d_arg.to(torch.float32), self._constant_diag, perm=perm, kron=kron)
         self._q_cache = self._woodbury.Q[..., : self._woodbury.k].reshape(*batch_shape, n, self._woodbury.k)
         logdet = self._woodbury.logdet
         self._precond_logdet_cache = logdet.view(*batch_shape) if len(batch_shape) else logdet.squeeze()  # :172,:184

@@ -25,4 +25,4 @@ with settings.cg_tolerance(1e-4):
     pr = cProfile.Profile(); pr.enable()
     for _ in range(200): api()
     pr.disable()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
