@@ -308,8 +308,8 @@ __device__ __forceinline__ cfloat_ptr as_const_space(const float* p) { return (c
 // k_precond_fused.  Thread t owns the rows row0 + t + 256 q (q < NRK) of its workgroup: n2 divides 256, so they share
 // the second-factor index i2 (16 values b_.[i2] in registers), and n2 >= 64 with row0 a multiple of 256 makes the
 // first-factor index i1 uniform over a wave: the 16 values a_.[i1] of a row come through the scalar cache into SGPRs.
-// NRK = 4 or 16 rows per thread (16: a member of 65536 rows is a group of 16 workgroups instead of 64 -- a quarter
-// of the hand-offs, and the 28 bytes per row of a workgroup's share are enough to keep its loads streaming).
+// NRK = 4 or 8 rows per thread (8: a member of 65536 rows is a group of 32 workgroups instead of 64 -- half the
+// hand-offs for the same bytes).
 template <int GW, int OCC, int NRK>
 __global__ __launch_bounds__(R4_TPB, OCC) void k_precond_fused_kron(PfArgs a) {
   if (a.stop && *a.stop) return;
@@ -526,7 +526,7 @@ bool precond_fused_eligible(int64_t B, int64_t N, int64_t c, int ldq, int S) {
 
 size_t precond_fused_gbuf_bytes() { return (size_t)64 * 2 * 65 * R4_SLOT * sizeof(unsigned long long) + 256; }
 
-template <int GW, int OCC, int NRK>  // NRK = 0: the Q form; 4 / 16: Kronecker root form with NRK rows per thread
+template <int GW, int OCC, int NRK>  // NRK = 0: the Q form; 4 / 8: Kronecker root form with NRK rows per thread
 static int pf_go(PfArgs& a, int ncu, hipStream_t st) {
   int per_cu = 0;
   constexpr bool KR = NRK > 0;
@@ -575,10 +575,11 @@ int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, floa
   a.rr_part = rr_part; a.rz_part = rz_part; a.S = S; a.B = B; a.N = (int)N;
   int GW = pf_group_size(N);
   a.RW = (int)((N + GW - 1) / GW);
-  // Kronecker root form: 16 rows per thread (groups of 16 workgroups of 4096 rows) once the batch fills the device that
-  // way, else 4; a workgroup's first row is a multiple of 256 (wave-uniform first-factor index)
-  const bool kron16 = kron && N > 8 * (int64_t)4096 && B * ((N + 4095) / 4096) >= 512 && !getenv("LO_KRON_NR4");
-  if (kron16) GW = 16;
+  // Kronecker root form: 8 rows per thread (groups of 16 / 32 workgroups of 2048 rows) once the batch fills the device
+  // that way, else 4 (cfg4 shard: 74.7 us with 4 rows, 61.7 with 8, 62.2 with 16); a workgroup's first row is a
+  // multiple of 256 (wave-uniform first-factor index)
+  const bool kron8 = kron && N > 8 * (int64_t)2048 && B * ((N + 2047) / 2048) >= 1024 && !getenv("LO_KRON_NR4");
+  if (kron8) GW = N <= 16 * (int64_t)2048 ? 16 : 32;
   if (kron) a.RW = (int)(((N + (int64_t)GW * 256 - 1) / ((int64_t)GW * 256)) * 256);
   a.gbuf = gbuf; a.err = err; a.next_member = next_member; a.stop = stop;
   a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
@@ -589,7 +590,7 @@ int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, floa
   a.iter_ptr = iter_ptr;
   if (!iter_ptr) a.next_member = next_member + launch;
   // four workgroups per CU (110 VGPRs): cfg4 153 us per call against 188 us with two or three
-  if (kron16) return pf_go<16, 4, 16>(a, ncu, st);
+  if (kron8) return GW == 16 ? pf_go<16, 4, 8>(a, ncu, st) : pf_go<32, 4, 8>(a, ncu, st);
   if (kron) {
     if (GW == 16) return pf_go<16, 4, 4>(a, ncu, st);
     if (GW == 32) return pf_go<32, 4, 4>(a, ncu, st);
