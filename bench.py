@@ -327,13 +327,31 @@ def other_configs(device):
     rhs = torch.randn(128, n * n, 1, generator=g, device=device)
     desc = K.kron_diag_descriptor(K1, K2, sig, const_diag=True)
 
+    kd = desc.without_diag()  # the preconditioner factors the Kronecker part (added_diag_linear_operator.py:125)
+
     def kron():
-        L, _ = K.pivoted_cholesky(desc, RANK_K, contiguous=False)  # [B, m, N] rows read in place by the build
-        return K.cg_solve(desc, rhs, precond=K.precond_build(L, sig, True), tolerance=1e-3)
+        L, perm = K.pivoted_cholesky(kd, RANK_K, contiguous=False)  # [B, m, N] rows read in place by the build
+        # (perm + the operator: the build adds the Kronecker root form, what AddedDiagLinearOperator._init_cache passes)
+        return K.cg_solve(desc, rhs, precond=K.precond_build(L, sig, True, perm=perm, kron=desc), tolerance=1e-3)
 
     t, r = _time(kron, 1)
     res["cfg4_shard_B128_kron_solve"] = {"ms": t * 1e3, "solves_per_s": 128 / t, "iterations": r.iterations}
     prof = _profiled(kron)
+    if "kron_fused" in prof:
+        roofs.append(_roof("k_kron_fused<8,4>", "cfg4 shard: 128 members, BOTH 256^3 GEMMs of a Kronecker matvec in one "
+                           "launch", prof["kron_fused"], "mfma", 4.0 * 128 * n * n * n,
+                           "fp32 matrix cores (v_mfma_f32_32x32x2_f32), 2 x 2 n^3 flop per member; the intermediate "
+                           "V K2^T stays in the accumulators and is the second GEMM's B operand as it lies (DESIGN 4.8); "
+                           "compulsory HBM bytes per launch 134 MB (K1, K2, v in, y out)",
+                           _committed_traffic("traffic_cfg45.json", "kron_fused")))
+    if "precond_fused_kron" in prof:
+        roofs.append(_roof("k_precond_fused_kron<32,4,8>", "cfg4 shard: 128 members x 65536 rows, one CG iteration's "
+                           "Woodbury apply in Kronecker root form + r / x / p updates", prof["precond_fused_kron"], "hbm",
+                           4 * 128 * n * n * 7,
+                           "4 N 7 bytes per member and iteration: r, Ap, p, x in; r, x, p out -- the rows of the "
+                           "preconditioner's tall matrix are formed on the fly from the pivot rows of the two factors "
+                           "(DESIGN 4.7); bound by one group hand-off per member at four rounds of 32 groups",
+                           _committed_traffic("traffic_cfg45.json", "precond_fused_kron")))
     if "kron_gemm_mfma" in prof:
         roofs.append(_roof("k_kron_nt_mfma", "cfg4 shard: 128 members, one of the two 256^3 GEMMs of a Kronecker matvec",
                            prof["kron_gemm_mfma"], "mfma", 2.0 * 128 * n * n * n,
@@ -397,9 +415,11 @@ def strong_scaling(args, device, dist, rank, world):
         rhs = torch.randn(chunk, n * n, 1, generator=g, device=device)
         desc = K.kron_diag_descriptor(K1, K2, sig, const_diag=True)
 
+        kd = desc.without_diag()
+
         def solve_chunk():
-            L, _ = K.pivoted_cholesky(desc, RANK_K, contiguous=False)
-            return K.cg_solve(desc, rhs, precond=K.precond_build(L, sig, True), tolerance=1e-3)
+            L, perm = K.pivoted_cholesky(kd, RANK_K, contiguous=False)
+            return K.cg_solve(desc, rhs, precond=K.precond_build(L, sig, True, perm=perm, kron=desc), tolerance=1e-3)
 
         cols, what = 1, "KroneckerProduct(256x256, 256x256) + 1e-2 I, N = 65536, 1 rhs column, tolerance 1e-3"
     else:

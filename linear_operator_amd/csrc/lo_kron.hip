@@ -263,6 +263,219 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 }
 
+// ---- both GEMMs of the Kronecker matvec in ONE kernel (round 3) -----------------------------------------------------
+// Y = K1 (V K2^T) + d o V for V [n1, n2], n1 = 128 or 256.  A workgroup owns 128 columns j of Y (wave w: 32 of them) and
+// ALL n1 rows, so the intermediate T = V K2^T never leaves the register file:
+//   stage 1   T[i, j] = sum_l V[i, l] K2[j, l]     wave w: n1 x 32 block = n1 / 32 accumulator tiles of 32 x 32
+//   stage 2   Y[m, j] = sum_i K1[m, i] T[i, j]     T is the B operand STRAIGHT FROM THE ACCUMULATORS:
+// register r of an accumulator tile holds T[32 ib + 8 (r / 4) + 4 h + r % 4][j] in lane (j, h) -- exactly the
+// (k = h, n = j) layout of a 32x32x2 B operand whose two contraction indices are i and i + 4; the A operand supplies
+// K1[m][i + 4 h] to match (four consecutive registers = a float4 of K1 at column 32 ib + 8 (r / 4) + 4 h).  The order of
+// the contraction is free, the values are the same products.  V / K1 (n1 x 64 slabs) and K2 (128 x 64) pass through
+// LDS as in k_kron_nt_mfma; the slab after next is fetched into registers behind the matrix-core stream.
+// Per member: V, K1 read by n2 / 128 workgroups of one XCD (L2), K2 and Y once -- the 2 x n1 n2 floats of the
+// intermediate (67 MB per launch at cfg4, a third of the two-launch traffic) and one launch are gone.
+struct KfArgs {
+  const float* K1;  // [B][n1][n1]
+  const float* K2;  // [B][n2][n2]
+  const float* v;   // [B][n1][n2]
+  float* y;
+  const float* diag;
+  int diag_mode;
+  float* dot_part;  // [B][tiles of 128 x 128] or nullptr (layout of kron_S_dot)
+  int n2, B;
+};
+
+constexpr int KF_LDE = KM_BN + 4;  // row stride of the epilogue's staging tile (128 rows x 128 columns)
+template <int NI, int NS>  // n1 = 32 NI; n2 = 64 NS (NS = 0: any multiple of 128, slab loop not unrolled)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_kron_fused(
+    KfArgs g, const int* __restrict__ stop) {
+  if (stop && *stop) return;
+  constexpr int N1 = 32 * NI;
+  constexpr int NU = N1 / 16;  // float4 per thread and slab of V / K1
+  static_assert(N1 * KM_LD >= 128 * KF_LDE || NI == 4, "the epilogue stages 128 rows of Y in the V / K1 slab buffer");
+  __shared__ float a_s[(N1 * KM_LD > 128 * KF_LDE) ? N1 * KM_LD : 128 * KF_LDE];
+  __shared__ float b_s[KM_BN * KM_LD];
+  __shared__ float dot_s[4][2];
+  const int n2 = NS ? 64 * NS : g.n2, nblk = n2 / KM_BN;
+  const int id = blockIdx.x, xcd = id & 7, rest = id >> 3;
+  const int blk = rest % nblk, z = (rest / nblk) * 8 + xcd;
+  if (z >= g.B) return;
+  const float* V = g.v + (size_t)z * N1 * n2;
+  const float* K2 = g.K2 + (size_t)z * n2 * n2 + (size_t)blk * KM_BN * n2;
+  const float* K1 = g.K1 + (size_t)z * N1 * N1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  const int sr = threadIdx.x >> 4, sq = threadIdx.x & 15;
+  // staging registers: NAMED, not arrays (the compiler demotes loop-carried float4 arrays to LDS / scratch, which puts
+  // a wait right behind the loads: see k_kron_nt_mfma)
+  float4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, ra8, ra9, ra10, ra11, ra12, ra13, ra14, ra15;
+  float4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
+  ra8 = ra9 = ra10 = ra11 = ra12 = ra13 = ra14 = ra15 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define KF_LD4(p_) (*reinterpret_cast<const float4*>(p_))
+#define KF_ST4(p_, v_) (*reinterpret_cast<float4*>(p_) = (v_))
+  // rows sr + 16 u of a slab: p_ = address of row sr, ld_ = row stride of the source
+#define KF_LOAD_A(p_, ld_)                                                                                       \
+  ra0 = KF_LD4(p_); ra1 = KF_LD4((p_) + (size_t)16 * (ld_)); ra2 = KF_LD4((p_) + (size_t)32 * (ld_));            \
+  ra3 = KF_LD4((p_) + (size_t)48 * (ld_)); ra4 = KF_LD4((p_) + (size_t)64 * (ld_));                              \
+  ra5 = KF_LD4((p_) + (size_t)80 * (ld_)); ra6 = KF_LD4((p_) + (size_t)96 * (ld_));                              \
+  ra7 = KF_LD4((p_) + (size_t)112 * (ld_));                                                                      \
+  if constexpr (NU == 16) {                                                                                      \
+    ra8 = KF_LD4((p_) + (size_t)128 * (ld_)); ra9 = KF_LD4((p_) + (size_t)144 * (ld_));                          \
+    ra10 = KF_LD4((p_) + (size_t)160 * (ld_)); ra11 = KF_LD4((p_) + (size_t)176 * (ld_));                        \
+    ra12 = KF_LD4((p_) + (size_t)192 * (ld_)); ra13 = KF_LD4((p_) + (size_t)208 * (ld_));                        \
+    ra14 = KF_LD4((p_) + (size_t)224 * (ld_)); ra15 = KF_LD4((p_) + (size_t)240 * (ld_));                        \
+  }
+#define KF_LOAD_B(p_, ld_)                                                                                       \
+  rb0 = KF_LD4(p_); rb1 = KF_LD4((p_) + (size_t)16 * (ld_)); rb2 = KF_LD4((p_) + (size_t)32 * (ld_));            \
+  rb3 = KF_LD4((p_) + (size_t)48 * (ld_)); rb4 = KF_LD4((p_) + (size_t)64 * (ld_));                              \
+  rb5 = KF_LD4((p_) + (size_t)80 * (ld_)); rb6 = KF_LD4((p_) + (size_t)96 * (ld_));                              \
+  rb7 = KF_LD4((p_) + (size_t)112 * (ld_));
+#define KF_STORE_A()                                                                                             \
+  KF_ST4(al, ra0); KF_ST4(al + 16 * KM_LD, ra1); KF_ST4(al + 32 * KM_LD, ra2); KF_ST4(al + 48 * KM_LD, ra3);      \
+  KF_ST4(al + 64 * KM_LD, ra4); KF_ST4(al + 80 * KM_LD, ra5); KF_ST4(al + 96 * KM_LD, ra6);                      \
+  KF_ST4(al + 112 * KM_LD, ra7);                                                                                 \
+  if constexpr (NU == 16) {                                                                                      \
+    KF_ST4(al + 128 * KM_LD, ra8); KF_ST4(al + 144 * KM_LD, ra9); KF_ST4(al + 160 * KM_LD, ra10);                \
+    KF_ST4(al + 176 * KM_LD, ra11); KF_ST4(al + 192 * KM_LD, ra12); KF_ST4(al + 208 * KM_LD, ra13);              \
+    KF_ST4(al + 224 * KM_LD, ra14); KF_ST4(al + 240 * KM_LD, ra15);                                              \
+  }
+#define KF_STORE_B()                                                                                             \
+  KF_ST4(bl, rb0); KF_ST4(bl + 16 * KM_LD, rb1); KF_ST4(bl + 32 * KM_LD, rb2); KF_ST4(bl + 48 * KM_LD, rb3);      \
+  KF_ST4(bl + 64 * KM_LD, rb4); KF_ST4(bl + 80 * KM_LD, rb5); KF_ST4(bl + 96 * KM_LD, rb6);                      \
+  KF_ST4(bl + 112 * KM_LD, rb7);
+  f32x16 T[NI], Y[NI];
+#pragma unroll
+  for (int ib = 0; ib < NI; ++ib)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      T[ib][e] = 0.f;
+      Y[ib][e] = 0.f;
+    }
+  {
+    const float* vg = V + (size_t)sr * n2 + 4 * sq;
+    const float* kg = K2 + (size_t)sr * n2 + 4 * sq;
+    KF_LOAD_A(vg, n2)
+    KF_LOAD_B(kg, n2)
+  }
+  float* al = &a_s[sr * KM_LD + 4 * sq];
+  float* bl = &b_s[sr * KM_LD + 4 * sq];
+  // ---- stage 1: T = V K2[j block]^T, contraction over l in slabs of 64 ----
+#pragma unroll
+  for (int l0 = 0; l0 < n2; l0 += KM_BK) {
+    __syncthreads();
+    KF_STORE_A()
+    KF_STORE_B()
+    __syncthreads();
+    if (l0 + KM_BK < n2) {
+      const float* vg = V + (size_t)sr * n2 + l0 + KM_BK + 4 * sq;
+      const float* kg = K2 + (size_t)sr * n2 + l0 + KM_BK + 4 * sq;
+      KF_LOAD_A(vg, n2)
+      KF_LOAD_B(kg, n2)
+    } else {  // the first K1 slab of stage 2 travels behind the last slab's products
+      const float* kg = K1 + (size_t)sr * N1 + 4 * sq;
+      KF_LOAD_A(kg, N1)
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (the scheduler would otherwise sink the loads below the matrix-core stream)
+    const float* a0 = &a_s[li * KM_LD + 32 * h];
+    const float* b0 = &b_s[(32 * wave + li) * KM_LD + 32 * h];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float4 av[NI];
+#pragma unroll
+      for (int ib = 0; ib < NI; ++ib) av[ib] = KF_LD4(a0 + ib * 32 * KM_LD + 4 * q);
+      const float4 bv = KF_LD4(b0 + 4 * q);
+#define KF_STEP(c_)                                                                     \
+  _Pragma("unroll") for (int ib = 0; ib < NI; ++ib)                                     \
+      T[ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ib].c_, bv.c_, T[ib], 0, 0, 0);
+      KF_STEP(x) KF_STEP(y) KF_STEP(z) KF_STEP(w)
+#undef KF_STEP
+    }
+  }
+  // ---- stage 2: Y = K1 T, contraction over i in slabs of 64 (two accumulator tiles of T per slab) ----
+#pragma unroll
+  for (int s = 0; s < NI / 2; ++s) {
+    __syncthreads();
+    KF_STORE_A()
+    __syncthreads();
+    if (s + 1 < NI / 2) {
+      const float* kg = K1 + (size_t)sr * N1 + 64 * (s + 1) + 4 * sq;
+      KF_LOAD_A(kg, N1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ibl = 0; ibl < 2; ++ibl) {
+      const f32x16& Tt = T[2 * s + ibl];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float4 av[NI];
+        const float* a0 = &a_s[li * KM_LD + 32 * ibl + 8 * g4 + 4 * h];
+#pragma unroll
+        for (int mb = 0; mb < NI; ++mb) av[mb] = KF_LD4(a0 + mb * 32 * KM_LD);
+#define KF_STEP(c_, e_)                                                                       \
+  _Pragma("unroll") for (int mb = 0; mb < NI; ++mb)                                           \
+      Y[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb].c_, Tt[4 * g4 + e_], Y[mb], 0, 0, 0);
+        KF_STEP(x, 0) KF_STEP(y, 1) KF_STEP(z, 2) KF_STEP(w, 3)
+#undef KF_STEP
+      }
+    }
+  }
+#undef KF_LD4
+#undef KF_ST4
+#undef KF_LOAD_A
+#undef KF_LOAD_B
+#undef KF_STORE_A
+#undef KF_STORE_B
+  // ---- epilogue: 128 rows of Y at a time through LDS (the slab buffer is free), so that v is read and y written as
+  //      whole 512-byte row segments; + d o v, dot partials per 128 x 128 tile (the layout the two-launch path writes) ----
+  float* Yg = g.y + (size_t)z * N1 * n2;
+  const float dconst = (g.diag_mode == LO_DIAG_CONST) ? g.diag[z] : 0.f;
+  const int col0 = blk * KM_BN;
+  const int er = threadIdx.x >> 5, ec = threadIdx.x & 31;  // float4 (row er + 8 u, columns 4 ec ..) of the staged tile
+#pragma unroll
+  for (int half = 0; half < NI / 4; ++half) {
+    __syncthreads();
+#pragma unroll
+    for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        a_s[(32 * mq + km_row(e, lane)) * KF_LDE + 32 * wave + li] = Y[4 * half + mq][e];
+    __syncthreads();
+    float dacc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int rl = er + 8 * u;
+      float4 yv = *reinterpret_cast<const float4*>(&a_s[rl * KF_LDE + 4 * ec]);
+      const size_t o = (size_t)(128 * half + rl) * n2 + col0 + 4 * ec;
+      if (g.diag_mode != LO_DIAG_NONE) {
+        const float4 vin = *reinterpret_cast<const float4*>(V + o);
+        float4 dv = make_float4(dconst, dconst, dconst, dconst);
+        if (g.diag_mode == LO_DIAG_FULL) dv = *reinterpret_cast<const float4*>(g.diag + (size_t)z * N1 * n2 + o);
+        yv.x = fmaf(dv.x, vin.x, yv.x); yv.y = fmaf(dv.y, vin.y, yv.y);
+        yv.z = fmaf(dv.z, vin.z, yv.z); yv.w = fmaf(dv.w, vin.w, yv.w);
+        dacc = fmaf(vin.x, yv.x, dacc); dacc = fmaf(vin.y, yv.y, dacc);
+        dacc = fmaf(vin.z, yv.z, dacc); dacc = fmaf(vin.w, yv.w, dacc);
+      }
+      *reinterpret_cast<float4*>(Yg + o) = yv;
+    }
+    if (g.dot_part) {
+      dacc = wave_sum(dacc);
+      if (lane == 0) dot_s[wave][half] = dacc;
+    }
+  }
+  if (g.dot_part) {
+    __syncthreads();
+    if (threadIdx.x < NI / 4) {
+      const int rt = threadIdx.x;
+      g.dot_part[(size_t)z * (NI / 4) * nblk + rt * nblk + blk] =
+          (dot_s[0][rt] + dot_s[1][rt]) + (dot_s[2][rt] + dot_s[3][rt]);
+    }
+  }
+}
+
+bool kron_fused_ok(int n1, int n2) {
+  return (n1 == 128 || n1 == 256) && n2 % 128 == 0 && n2 >= 128 && !getenv("LO_NO_KRON_FUSED");
+}
+
 static bool km_aligned(int n1, int n2) { return n1 % 128 == 0 && n2 % 128 == 0; }
 // (factor sizes that are multiples of 4 and at least 64: tiles beyond the matrices are guarded; smaller or odd sizes
 //  stay on the strided VALU GEMM)
@@ -282,6 +495,23 @@ static void km_launch(const KmArgs& g, int64_t Z, bool guard, const int* stop, h
 // y = (K1 (x) K2) v + diag o v and (optionally) the dot partials sum v o y, c == 1, matrix cores
 int kron_matvec_mfma(const float* K1, const float* K2, const float* diag, int diag_mode, const float* v, float* tmp,
                      float* y, float* dot_part, int64_t B, int n1, int n2, const int* stop, hipStream_t st) {
+  // both GEMMs in one launch, the intermediate stays in the accumulators -- once the batch offers a workgroup to at least
+  // a third of the CUs (a small batch is spread wider by the 128 x 128 tiles of the two-launch path: 5 members of
+  // 256 (x) 128: 40 us against 60)
+  if (kron_fused_ok(n1, n2) && B * (n2 / KM_BN) >= 96) {
+    KfArgs f;
+    f.K1 = K1; f.K2 = K2; f.v = v; f.y = y; f.diag = diag; f.diag_mode = diag ? diag_mode : LO_DIAG_NONE;
+    f.dot_part = dot_part; f.n2 = n2; f.B = (int)B;
+    const dim3 grid((unsigned)(((B + 7) / 8) * 8) * (unsigned)(n2 / KM_BN));
+    LO_PROF_BEGIN("kron_fused", st);
+    if (n1 == 256 && n2 == 256) hipLaunchKernelGGL((k_kron_fused<8, 4>), grid, dim3(kThreads), 0, st, f, stop);
+    else if (n1 == 256) hipLaunchKernelGGL((k_kron_fused<8, 0>), grid, dim3(kThreads), 0, st, f, stop);
+    else if (n2 == 128) hipLaunchKernelGGL((k_kron_fused<4, 2>), grid, dim3(kThreads), 0, st, f, stop);
+    else hipLaunchKernelGGL((k_kron_fused<4, 0>), grid, dim3(kThreads), 0, st, f, stop);
+    LO_PROF_END(st);
+    LO_LAUNCH_CHECK();
+    return LO_OK;
+  }
   KmArgs g;
   g.B = (int)B;
   g.a_div = 1;

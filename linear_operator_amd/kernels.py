@@ -156,6 +156,7 @@ class WoodburyPreconditioner:
     # Kronecker operator with a constant diagonal -- the single-column CG of large N forms the rows of the tall matrix
     # on the fly instead of streaming Q
     kron: Optional[tuple] = None
+    kron_kappa: Optional[float] = None  # worst rounding amplification of the Kronecker root form over the batch
     rebuild: Optional[Callable] = None  # root form from the fused solve (no L exists): () -> the full preconditioner
 
     @property
@@ -695,9 +696,10 @@ def _root_form(lib, root, perm, L3, d, constant_diag, B, N, k, dev) -> WoodburyP
 KRON_ROOT_MAX_KAPPA = 200.0
 
 
-def _kron_root(lib, desc: "OperatorDescriptor", perm, L3, k, dev) -> Optional[tuple]:
+def _kron_root(lib, desc: "OperatorDescriptor", perm, L3, k, dev):
     """lo_precond_kron_root_f32 for a Kronecker operator with a constant diagonal (descriptor with the diagonal
-    attached); None when some member's pivot rows are too ill conditioned (one read-back of B floats)."""
+    attached) -> ((kron_a, kron_b, kron_F) or None when some member's pivot rows are too ill conditioned, worst kappa);
+    one read-back of B floats."""
     B, n1, n2 = desc.B, desc.R, desc.n2
     ka = torch.empty(B, n1, 16, dtype=torch.float32, device=dev)
     kb = torch.empty(B, n2, 16, dtype=torch.float32, device=dev)
@@ -714,8 +716,8 @@ def _kron_root(lib, desc: "OperatorDescriptor", perm, L3, k, dev) -> Optional[tu
                                             _hip.stream_ptr(dev)), "lo_precond_kron_root_f32")
     worst = float(kappa.max())
     if not (worst < KRON_ROOT_MAX_KAPPA):  # (also NaN)
-        return None
-    return ka, kb, kF
+        return None, worst
+    return (ka, kb, kF), worst
 
 
 def padded_rank(k: int) -> int:
@@ -776,7 +778,7 @@ def precond_build(L: torch.Tensor, d: torch.Tensor, constant_diag: bool, root: O
     if (kron is not None and perm is not None and constant_diag and kron.kind == _hip.LO_OP_KRON_DIAG
             and kron.diag_mode == _hip.LO_DIAG_CONST and kron.B == B and kron.N == N and 1 <= k <= 16
             and 8192 <= N <= 65536):
-        out.kron = _kron_root(lib, kron, perm, L3, k, dev)
+        out.kron, out.kron_kappa = _kron_root(lib, kron, perm, L3, k, dev)
     return out
 
 

@@ -22,7 +22,7 @@ pre_q = K.precond_build(L, sig, True)
 K.KRON_ROOT_MAX_KAPPA = float(os.environ.get("KR_MAXK", K.KRON_ROOT_MAX_KAPPA))
 pre_k = K.precond_build(L, sig, True, perm=perm, kron=desc)
 lib = _hip.load()
-print("kron root available:", pre_k.kron is not None)
+print("kron root available:", pre_k.kron is not None, "worst kappa", pre_k.kron_kappa)
 def run(pre):
     return K.cg_solve(desc, rhs, precond=pre, tolerance=float(os.environ.get("KR_TOL", 1e-3)))
 out = {}

@@ -22,8 +22,8 @@ if which in ("cfg4", "both"):
     K1 = X1 @ X1.mT + 0.1 * torch.eye(n, device=dev); K2 = X2 @ X2.mT + 0.1 * torch.eye(n, device=dev)
     sig = torch.full((B,), 1e-2, device=dev); rhs = torch.randn(B, n * n, 1, generator=g, device=dev)
     desc = K.kron_diag_descriptor(K1, K2, sig, const_diag=True)
-    t, (L, _) = timeit(lambda: K.pivoted_cholesky(desc, 15), 1); print(f"cfg4/GPU shard B={B}: pivoted cholesky {t*1e3:.2f} ms, rank {L.shape[-1]}")
-    pre = K.precond_build(L, sig, True)
+    t, (L, perm) = timeit(lambda: K.pivoted_cholesky(desc.without_diag(), 15), 1); print(f"cfg4/GPU shard B={B}: pivoted cholesky {t*1e3:.2f} ms, rank {L.shape[-1]}")
+    pre = K.precond_build(L, sig, True, perm=perm, kron=desc)  # (+ the Kronecker root form)
     t, res = timeit(lambda: K.cg_solve(desc, rhs, precond=pre, tolerance=1e-3), 1)
     print(f"  CG: {t*1e3:.1f} ms, iterations {res.iterations}, {B*res.matvecs/t/1e3:.1f} k member-matvecs/s, mean resid {res.mean_residual:.2e}")
     prof(lambda: K.cg_solve(desc, rhs, precond=pre, tolerance=1e-3))
