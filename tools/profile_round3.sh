@@ -28,6 +28,8 @@ pmc() {  # name, counter, command...
 }
 { pmc bench FETCH_SIZE $B; pmc bench WRITE_SIZE $B; } > $OUT/pmc_fetch_write_bench.txt
 { pmc e2e FETCH_SIZE python $R/tools/mb_e2e.py; pmc e2e WRITE_SIZE python $R/tools/mb_e2e.py; } > $OUT/pmc_fetch_write_e2e.txt
+{ pmc cfg45 FETCH_SIZE python $R/tools/mb_cfg45.py; pmc cfg45 WRITE_SIZE python $R/tools/mb_cfg45.py; } > $OUT/pmc_fetch_write_cfg45.txt
+{ pmc lockstep FETCH_SIZE python $R/tools/mb_lockstep.py; pmc lockstep WRITE_SIZE python $R/tools/mb_lockstep.py; } > $OUT/pmc_fetch_write_lockstep.txt
 python - "$OUT" <<'PY'
 import json, re, sys
 out = sys.argv[1]
@@ -44,6 +46,24 @@ for fname, src, prof_name, kern, label in (
         json.dump({"prof_name": prof_name, "kernel": label, "FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w,
                    "fetch_correction": 2.0, "traffic_bytes_per_launch": (2.0 * f + w) * 1024,
                    "source": f"{src} (rocprofv3 --pmc, separate passes)"}, open(f"{out}/{fname}", "w"), indent=1)
+f, w = (grab(f"{out}/pmc_fetch_write_lockstep.txt", c, "k_cg_lockstep") for c in ("FETCH_SIZE", "WRITE_SIZE"))
+if f is not None and w is not None:
+    json.dump({"prof_name": "cg_lockstep", "kernel": "k_cg_lockstep<32,true,8>", "FETCH_SIZE_KB_avg": f,
+               "WRITE_SIZE_KB_avg": w, "fetch_correction": 2.0, "traffic_bytes_per_launch": (2.0 * f + w) * 1024,
+               "source": "pmc_fetch_write_lockstep.txt (rocprofv3 --pmc, separate passes, tools/mb_lockstep.py)"},
+              open(f"{out}/traffic_lockstep.json", "w"), indent=1)
+others = {}
+for name, kern in (("kron_fused", "k_kron_fused"), ("precond_fused_kron", "k_precond_fused_kron"),
+                   ("precond_fused", "k_precond_fused<"), ("dense_mv_mfma", "k_dense_mv_mfma16"),
+                   ("kron_gemm_mfma", "k_kron_nt_mfma<true")):
+    f = grab(f"{out}/pmc_fetch_write_cfg45.txt", "FETCH_SIZE", kern)
+    w = grab(f"{out}/pmc_fetch_write_cfg45.txt", "WRITE_SIZE", kern)
+    if f is not None and w is not None:
+        others[name] = {"kernel": kern, "FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w, "fetch_correction": 2.0,
+                        "traffic_bytes_per_launch": (2.0 * f + w) * 1024}
+if others:
+    json.dump({"source": "pmc_fetch_write_cfg45.txt (rocprofv3 --pmc, separate passes, tools/mb_cfg45.py)",
+               "kernels": others}, open(f"{out}/traffic_cfg45.json", "w"), indent=1)
 PY
 # where the wave cycles of the fused kernel go (one pass per counter)
 : > $OUT/pmc_wave_cycles_e2e.txt
@@ -54,4 +74,6 @@ for c in SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIV
   python $R/tools/pmc_summary.py /tmp/p_w k_cg_onchip5 >> $OUT/pmc_wave_cycles_e2e.txt
 done
 cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 600 python bench.py --workload cfg4 --steps 2 --warmup 1 > $OUT/bench_cfg4_strong.json 2>> $OUT/bench.err
+timeout 600 python bench.py --workload cfg5 --steps 1 --warmup 1 > $OUT/bench_cfg5_strong.json 2>> $OUT/bench.err
 ls -la $OUT
