@@ -38,6 +38,14 @@ class WoodburyPreconditionClosure:
         return z.squeeze(-1) if is_vec else z
 
 
+def _rebuild_full_preconditioner(owner):
+    """The full (L, Q) preconditioner of `owner` for a root-form-only one that has to grow a Q (ensure_q)."""
+    closure = owner._preconditioner()[0]
+    if closure is None:
+        raise K._hip.HipExtensionError("the preconditioner could not be rebuilt (NaN in the pivoted Cholesky factor)")
+    return closure.woodbury
+
+
 class LazyWoodburyPreconditionClosure:
     """What `_solve_preconditioner` hands to `_solve` when the operator qualifies for the ONE-LAUNCH end-to-end solve
     (csrc/lo_solve_fused_impl.h): the same closure as `_preconditioner()[0]`, but nothing is factorised yet.
@@ -61,6 +69,13 @@ class LazyWoodburyPreconditionClosure:
     def pending(self) -> bool:
         return not self._done
 
+    def owns(self, matmul_closure, batch_shape) -> bool:
+        """True if `matmul_closure` is the (unpatched) bound `_matmul` of the operator this closure belongs to and the
+        right-hand side carries the operator's own batch shape: the stored descriptor is the closure's lowering."""
+        return (getattr(matmul_closure, "__self__", None) is self._owner
+                and getattr(matmul_closure, "__func__", None) is type(self._owner)._matmul
+                and batch_shape == self.batch_shape)
+
     def same_operator(self, desc) -> bool:
         """True if `desc` (lowered from linear_cg's matmul_closure) is this closure's operator: same tensors."""
         mine = self.desc
@@ -78,18 +93,16 @@ class LazyWoodburyPreconditionClosure:
     def adopt(self, woodbury):
         """Root-form preconditioner the fused solve built on the way: becomes this closure's preconditioner and is
         memoised under the operator's tensors for later solves (a later call that needs Q or L rebuilds in full)."""
-        woodbury.rebuild = lambda: self._rebuild_full()
+        # (the rebuild hook references the OPERATOR, not this closure: closure -> woodbury -> hook -> closure would be a
+        # reference cycle, and the device tensors of every solve would wait for the cyclic collector -- the caching
+        # allocator then has to hipMalloc fresh blocks: + 130 us per solve of 64 members)
+        owner = self._owner
+        woodbury.rebuild = lambda: _rebuild_full_preconditioner(owner)
         self._real = WoodburyPreconditionClosure(woodbury, self.batch_shape)
         self._done = True
         if PRECONDITIONER_MEMO_SIZE > 0 and self._memo_key is not None:
             _rootform_memo.insert(0, (self._memo_key, self._memo_tensors, woodbury))
             del _rootform_memo[PRECONDITIONER_MEMO_SIZE:]
-
-    def _rebuild_full(self):
-        closure = self._owner._preconditioner()[0]
-        if closure is None:
-            raise K._hip.HipExtensionError("the preconditioner could not be rebuilt (NaN in the pivoted Cholesky factor)")
-        return closure.woodbury
 
     @property
     def woodbury(self):

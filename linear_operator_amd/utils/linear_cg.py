@@ -95,10 +95,13 @@ def linear_cg(
         op_batch = matmul_closure.shape[:-2]
     else:
         op_batch = getattr(getattr(matmul_closure, "__self__", None), "batch_shape", torch.Size())
-    try:
-        full_batch = torch.broadcast_shapes(batch_shape, op_batch)
-    except RuntimeError:
+    if op_batch == batch_shape:
         full_batch = batch_shape
+    else:
+        try:
+            full_batch = torch.broadcast_shapes(batch_shape, op_batch)
+        except RuntimeError:
+            full_batch = batch_shape
     if full_batch != batch_shape:
         rhs = rhs.expand(*full_batch, *rhs.shape[-2:])
         if initial_guess is not None:
@@ -125,18 +128,21 @@ def linear_cg(
             floor_max_iter=max_iter,
         )
     else:
-        desc = _lower_matmul_closure(matmul_closure, batch_shape)
+        lazy = preconditioner if getattr(preconditioner, "lazy_fused", False) and preconditioner.pending else None
+        if lazy is not None and lazy.owns(matmul_closure, batch_shape):
+            desc = lazy.desc  # (the closure is the `_matmul` of the operator the lazy closure was lowered from)
+        else:
+            desc = _lower_matmul_closure(matmul_closure, batch_shape)
         closure = None
         if desc is None:
             closure = matmul_closure.matmul if torch.is_tensor(matmul_closure) else matmul_closure
         res = None
-        if getattr(preconditioner, "lazy_fused", False) and preconditioner.pending:
+        if lazy is not None:
             # AddedDiagLinearOperator._solve_preconditioner deferred the factorisation: when this call is what the
             # one-launch kernel computes (the closure's own operator, no tridiagonals, zero initial guess, the rule of
             # this process only) pivoted Cholesky, root-form preconditioner and CG run in ONE resident launch
-            lazy = preconditioner
             if (n_tridiag == 0 and initial_guess is None and _active_stop_reduce() is None
-                    and lazy.same_operator(desc) and rhs.is_cuda):
+                    and (desc is lazy.desc or lazy.same_operator(desc)) and rhs.is_cuda):
                 fused = K.solve_fused(desc, rhs, lazy.rank, lazy.tol, max_iter=n_iter, tolerance=float(tolerance),
                                       eps=float(eps), stop_updating_after=float(stop_updating_after),
                                       floor_max_iter=max_iter)
