@@ -91,7 +91,10 @@ def woodbury_fp64_rel_err(Cm, d, rhs, x, chunk=64):
         cap = torch.eye(C64.shape[-1], device=Cm.device, dtype=torch.float64) + C64.mT @ Cd
         xs = r64 / d64 - Cd @ torch.linalg.solve(cap, C64.mT @ (r64 / d64))
         err = (x[b0:b0 + chunk].double() - xs).flatten(1).norm(dim=1) / xs.flatten(1).norm(dim=1)
-        worst = max(worst, float(err.max().item()))
+        e = float(err.max().item())
+        if e != e:  # NaN must not hide behind max()
+            return float("nan")
+        worst = max(worst, e)
     return worst
 
 
