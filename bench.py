@@ -160,35 +160,26 @@ def cpu_baseline(seconds_budget=12.0, device=None):
     return out
 
 
-class _no_gc:
-    """Timed regions run with the cyclic collector off (and a collection in front): a generation-2 pass of this
-    process walks ~1e6 objects for 35 ms -- 80 headline steps -- and where it falls depends on the allocation count up
-    to that point (seen: the first timed repetition of the 64-member solve, 36.9 ms instead of 0.29)."""
+def _gc_off():
+    """Every timed region of this process runs with the cyclic collector off, switched off ONCE before the first
+    warm-up: a generation-2 pass walks ~1e6 objects for 35 ms -- 80 headline steps -- and where it falls depends on the
+    allocation count up to that point (seen: the first timed repetition of the 64-member solve, 36.9 ms instead of
+    0.29); collecting right in front of a timed region is no alternative, the GPU's clocks drop during the pause and
+    the following repetitions run 3 - 5 % slow."""
+    import gc
 
-    def __enter__(self):
-        import gc
-
-        gc.collect()
-        self._was = gc.isenabled()
-        gc.disable()
-
-    def __exit__(self, *exc):
-        import gc
-
-        if self._was:
-            gc.enable()
+    gc.collect()
+    gc.disable()
 
 
 def _time(fn, reps):
     fn()
     torch.cuda.synchronize()
-    with _no_gc():
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            out = fn()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    return dt / reps, out
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps, out
 
 
 def _profiled(fn):
@@ -482,12 +473,11 @@ def strong_scaling(args, device, dist, rank, world):
     for _ in range(args.warmup):
         res = step()
     fence()
-    with _no_gc():
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            res = step()
-        fence()
-        elapsed = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -640,6 +630,7 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     _hip.load()
+    _gc_off()
 
     if args.workload != "headline":
         out = strong_scaling(args, device, dist if use_dist else None, rank, world)
@@ -688,12 +679,11 @@ def main():
     for _ in range(args.warmup):
         res = step()
     fence()
-    with _no_gc():
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            res = step()
-        fence()
-        elapsed = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
     per_rank_ms = [elapsed / args.steps * 1e3]
     allgather_ms = None
     if use_dist:
@@ -734,20 +724,18 @@ def main():
             x_e2e = e2e_api()
         fence()
         reps = 5
-        with _no_gc():
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                x_e2e = e2e_api()
-            fence()
-            e2e = (time.perf_counter() - t1) / reps
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            x_e2e = e2e_api()
+        fence()
+        e2e = (time.perf_counter() - t1) / reps
     e2e_three_launch()
     fence()
-    with _no_gc():
-        t1 = time.perf_counter()
-        for _ in range(3):
-            e2e_three_launch()
-        fence()
-        e2e3 = (time.perf_counter() - t1) / 3
+    t1 = time.perf_counter()
+    for _ in range(3):
+        e2e_three_launch()
+    fence()
+    e2e3 = (time.perf_counter() - t1) / 3
     clear_preconditioner_memo()
     if use_dist:
         t = torch.tensor([e2e], device=device, dtype=torch.float64)
