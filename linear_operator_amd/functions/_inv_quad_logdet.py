@@ -5,6 +5,8 @@ eigendecomposition + quadrature is one kernel on the device (csrc/lo_eig.hip) in
 device -> host -> device round trip (utils/lanczos.py:179-189)."""
 from __future__ import annotations
 
+import warnings
+
 import torch
 from torch.autograd import Function
 
@@ -133,10 +135,26 @@ class InvQuadLogdet(Function):
         matrix_shape, batch_shape = linear_op.matrix_shape, linear_op.batch_shape
 
         if probe_vectors is None or probe_vector_norms is None:  # reference :78-110
-            if settings.deterministic_probes.on():
-                raise NotImplementedError("deterministic_probes is deprecated in the reference and not implemented")
             num_random_probes = settings.num_trace_samples.value()
-            probe_vectors = _zero_mean_mvn_samples_columns(precond_lt, num_random_probes)  # [*batch, N, P]
+            if settings.deterministic_probes.on():  # reference :80-105 (deprecated there, kept for drop-in use)
+                # the same base samples every call, coloured by a (Lanczos) root of the preconditioner
+                if precond_lt.size()[-2:] == torch.Size([1, 1]):
+                    covar_root = precond_lt.to_dense().sqrt()
+                else:
+                    covar_root = precond_lt.root_decomposition().root
+                warnings.warn(
+                    "The deterministic probes feature is now deprecated. "
+                    "See https://github.com/cornellius-gp/linear_operator/pull/1836.",
+                    DeprecationWarning,
+                )
+                base_samples = settings.deterministic_probes.probe_vectors
+                if base_samples is None or covar_root.size(-1) != base_samples.size(-2):
+                    base_samples = torch.randn(*precond_lt.batch_shape, covar_root.size(-1), num_random_probes,
+                                               dtype=precond_lt.dtype, device=precond_lt.device)
+                    settings.deterministic_probes.probe_vectors = base_samples
+                probe_vectors = covar_root.matmul(base_samples)  # [*batch, N, P]
+            else:
+                probe_vectors = _zero_mean_mvn_samples_columns(precond_lt, num_random_probes)  # [*batch, N, P]
             probe_vector_norms = torch.linalg.vector_norm(probe_vectors, ord=2, dim=-2, keepdim=True)
             probe_vectors = probe_vectors.div(probe_vector_norms)
 

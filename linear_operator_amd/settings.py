@@ -162,10 +162,17 @@ class debug(_feature_flag):
 
 
 class deterministic_probes(_feature_flag):
-    """Deprecated in the reference (settings.py:245-262); kept as an off-by-default flag, not implemented."""
+    """The same base samples for the log-determinant probes of every call (reference settings.py:245-262, deprecated
+    there): InvQuadLogdet colours them with a root of the preconditioner.  The base samples are cached HERE, in global
+    scope, and dropped whenever the flag's state changes -- one model per context, as in the reference."""
 
     _default = False
     probe_vectors = None
+
+    @classmethod
+    def _set_state(cls, state):
+        super()._set_state(state)
+        cls.probe_vectors = None
 
 
 class max_cg_iterations(_value_context):

@@ -74,6 +74,30 @@ def test_inv_quad_logdet_probe_seam_and_logdet():
     assert np.allclose(host(ld2), g["logdet_exact"], rtol=0.1, atol=2.0)
 
 
+def test_inv_quad_logdet_deterministic_probes():
+    """settings.deterministic_probes (reference functions/_inv_quad_logdet.py:80-105, settings.py:245-262): the base
+    samples are drawn once and cached on the setting, coloured by a Lanczos root of the preconditioner; two calls give
+    the SAME estimate, leaving the context drops the cache, the reference's DeprecationWarning is raised."""
+    g = load_golden("g4_iql_lowrank")
+    C, d, rhs = cases.lowrank_diag(411, 3, 2048, 16, 1)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C)), DiagLinearOperator(dev(d)))
+    assert settings.deterministic_probes.probe_vectors is None
+    with settings.cg_tolerance(1e-4), settings.num_trace_samples(32), settings.deterministic_probes(True):
+        with pytest.warns(DeprecationWarning, match="deterministic probes"):
+            iq1, ld1 = A.inv_quad_logdet(dev(rhs), logdet=True)
+        base = settings.deterministic_probes.probe_vectors
+        assert base is not None and base.shape[-1] == 32 and base.shape[:-2] == (3,)
+        with pytest.warns(DeprecationWarning):
+            iq2, ld2 = A.inv_quad_logdet(dev(rhs), logdet=True)
+        assert settings.deterministic_probes.probe_vectors is base
+    assert settings.deterministic_probes.probe_vectors is None  # the cache lives as long as the context
+    assert np.allclose(host(iq1), g["inv_quad"], rtol=1e-4)
+    # same base samples; the Lanczos root of the preconditioner is recomputed per call from a random start vector (as
+    # in the reference, whose precond_lt is rebuilt by the Function), so the two estimates agree to a few percent only
+    assert np.allclose(host(ld1), host(ld2), rtol=0.1, atol=1.0)
+    assert np.allclose(host(ld1), g["logdet_exact"], rtol=0.1, atol=2.0)
+
+
 def test_kron_and_dense_operator_api():
     g = load_golden("g4_solve_kron")
     K1, K2, sig, rhs = cases.kron_factors(421, 2, 48, 48, 1)
