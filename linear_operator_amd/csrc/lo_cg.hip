@@ -755,6 +755,14 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   // (the dynamic member hand-out passes indices through fp32 granules: exact below 2^24)
   const bool oc_gen2 = oc_ok && ls_cols < c && onchip4_eligible(pl.R4, ocR4, N, c - ls_cols) &&
                        !(getenv("LO_OC_GEN1") && oc_gen1_ok);
+  // Result-only first pass ("lean"): the resident kernels that take it (third-generation serial columns, lockstep) write
+  // the scaled result but not x / r / p / z of a possible continuation -- 4 of the 5 vectors they used to store.  All
+  // BASELINE shapes stop at the floor; when the rule does not hold there, the same launches are repeated with the state
+  // (deterministic kernels: the continuation starts from the very numbers the first pass computed).
+  bool lean = !global_rule && !getenv("LO_OC_KEEP_STATE") &&
+              (ls_cols == c || (!getenv("LO_OC_GEN2") && oc_root_ok));  // (every column on a kernel with that mode)
+  for (int oc_pass = 0; oc_pass < 2; ++oc_pass) {
+  bool oc_redo = false;
   if (oc_ok) {
     OnchipArgs a;
     a.C = pl.Apad; a.d = op->d;
@@ -775,6 +783,9 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.iters = kfloor0 + 1;
     a.eps = prm->eps; a.stop_after = prm->stop_updating_after;
     a.x = d.x; a.r = d.r; a.p = d.p; a.z = d.z;
+    auto lean_state = [&](bool on) {  // (kernels without the result-only mode get the state pointers back)
+      a.x = on ? nullptr : d.x; a.r = on ? nullptr : d.r; a.p = on ? nullptr : d.p; a.z = on ? nullptr : d.z;
+    };
     a.rhs_norm = d.rhs_norm; a.rz = d.rz; a.alpha = d.alpha; a.beta = d.beta; a.resid_norm = d.resid_norm;
     a.rhs_is_zero = d.rhs_is_zero; a.has_conv = d.has_conv;
     a.resid_rec = d.oc_resid; a.init_conv = d.oc_init_conv; a.err = d.oc_err;
@@ -794,6 +805,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     if (ls_cols) {  // third generation: columns [0, ls_cols)
       a.ncols = ls_cols;
       a.xout = x;
+      lean_state(lean);
       a.gbuf = d.ls_gbuf; a.next_member = d.oc_err + 2;
       a.dbg = ls_dbg ? d.oc_dbg : nullptr;
       LO_HIP_CHECK(hipMemsetAsync(d.ls_gbuf, 0, lockstep_gbuf_bytes(32, 16), st));
@@ -818,6 +830,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       a.RW = (int)((N + a.GW - 1) / a.GW);
       a.col0 = ls_cols; a.ncols = c - ls_cols;
       a.xout = x;
+      lean_state(lean);
       a.F = oc_nopre ? nullptr : pre->F;
       a.EF = oc_nopre ? nullptr : pre->EF;
       a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
@@ -828,6 +841,13 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     }
     if (rc == LO_OK && ls_cols < c && !serial_done && pre && !pre->Q) rc = LO_ERR_UNSUPPORTED;  // (root form only)
     if (rc == LO_OK && ls_cols < c && !serial_done) {  // second (first) generation: columns [ls_cols, c)
+      if (lean) {  // (the root-form kernel did not fit after all; these kernels have no result-only mode: start over)
+        lean = false;
+        oc_redo = true;
+      }
+    }
+    if (rc == LO_OK && ls_cols < c && !serial_done && !oc_redo) {
+      lean_state(false);
       const bool gen2 = onchip4_eligible(pl.R4, ocR4, N, c - ls_cols) && !(getenv("LO_OC_GEN1") && oc_gen1_ok);
       a.GW = gen2 ? onchip4_group_size(N) : 8;
       a.RW = (int)((N + a.GW - 1) / a.GW);
@@ -847,7 +867,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     }
     (void)oc_gen2;
     if (rc && rc != LO_ERR_UNSUPPORTED) return rc;
-    if (rc == LO_OK) {  // (LO_ERR_UNSUPPORTED: no resident kernel fits this device / shape -> streaming engine)
+    if (rc == LO_OK && !oc_redo) {  // (LO_ERR_UNSUPPORTED: no resident kernel fits this device / shape -> streaming engine)
       const int ktri = prm->n_tridiag ? std::min(a.iters, (int)prm->max_tridiag_iter) : 0;
       const unsigned tri_grid = (unsigned)(((size_t)B * std::max(1, (int)prm->n_tridiag) + kThreads - 1) / kThreads);
       if (ktri) {
@@ -891,7 +911,13 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
         fprintf(stderr, "onchip member0 (100 MHz ticks): load %lld init %lld iters %lld store %lld | wg-wait %lld publish %lld poll %lld\n",
                 ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5], ts[6], ts[7]);
       }
-      if (oc_err == 0) {
+      if (oc_err == 0 && lean && !h.stop) {
+        // the stop rule does not hold at the floor and the state was not written: the same launches once more, in full
+        // (a root-form-only preconditioner cannot continue on the streaming engine anyway: the caller builds Q first)
+        if (pre && !pre->Q) return LO_ERR_UNSUPPORTED;
+        lean = false;
+        oc_redo = true;
+      } else if (oc_err == 0) {
         k_start = a.iters;
         x_written = xout_ok;
       } else {  // a group hand-off timed out: redo everything with the streaming engine
@@ -902,6 +928,13 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       }
     }
   }
+  if (!oc_redo) break;
+  {  // second pass: control block and granules as at the start of the solve
+    const size_t span = (size_t)(reinterpret_cast<char*>(d.oc_gbuf) - reinterpret_cast<char*>(d.ctrl)) + onchip_gbuf_bytes(66);
+    LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, span, st));
+    memset(&h, 0, sizeof(h));
+  }
+  }  // oc_pass
   // a root-form-only preconditioner cannot feed the streaming engine (initial run, redo after a timeout, or the
   // continuation beyond the resident iterations): the caller builds the Q form and calls again
   if (pre && !pre->Q && (k_start == 0 || !h.stop)) return LO_ERR_UNSUPPORTED;

@@ -696,11 +696,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_cg_lockstep(OnchipArgs a) {
           const int lr = lrow0 + blk * 16 + 4 * kq + i;
           if (cok && lr < nv) {
             const size_t o = (brow + lr) * ldc + cbase + nq;
-            a.x[o] = x[blk][i];
             if (a.xout) a.xout[o] = x[blk][i] * nrm;  // final when the stop rule holds at the floor (:335)
-            a.r[o] = r[blk][i];
-            a.p[o] = p[blk][i];
-            if (a.z) a.z[o] = z[i];
+            if (a.x) {  // (nullptr: result only, see k_cg_onchip5)
+              a.x[o] = x[blk][i];
+              a.r[o] = r[blk][i];
+              a.p[o] = p[blk][i];
+              if (a.z) a.z[o] = z[i];
+            }
           }
         }
       }

@@ -719,11 +719,15 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
         if (tw + R4_TPB * q < nv) {
           const size_t o = ((size_t)b * a.N + row0 + tw + R4_TPB * q) * nc + col;
           const int lr = t + R4_TPB * q;
-          a.x[o] = x_s[lr];
+          // (a.x == nullptr: the caller expects the stop rule to hold at the floor and wants the result only; if it
+          //  does not hold, the launch is repeated WITH the continuation state -- lo_cg.hip)
           if (a.xout) a.xout[o] = x_s[lr] * nrm;             // :335
-          a.r[o] = r[q];
-          a.p[o] = p[q];
-          if (a.z) {
+          if (a.x) {
+            a.x[o] = x_s[lr];
+            a.r[o] = r[q];
+            a.p[o] = p[q];
+          }
+          if (a.x && a.z) {
             float cvq = 0.f;
 #pragma unroll
             for (int i = 0; i < RC; ++i) cvq = fmaf((i & 1) ? Cr[q][i >> 1].y : Cr[q][i >> 1].x, post[t >> 6].v[i], cvq);

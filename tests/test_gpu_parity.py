@@ -4,6 +4,8 @@ Bars: integer results (pivots / permutations / iteration counts at the floors) b
 within 1e-4 relative per column (north_star); logdet within 1e-4 rel + the documented eigensolver noise
 floor.  Run with `pytest -m gpu` on an MI355X.
 """
+import warnings
+
 import numpy as np
 import pytest
 import torch
@@ -1025,3 +1027,35 @@ def test_wide_preconditioner_rank_above_32(k):
         A = Kd.astype(np.float64) + np.stack([np.diag(v) for v in d.astype(np.float64)])
         assert max_rel_err_cols(host(res.x), np.linalg.solve(A, rhs.astype(np.float64))) < 1e-4
         assert res.iterations <= res0.iterations
+
+
+@pytest.mark.parametrize("c,nt", [(1, 0), (17, 16), (3, 0)])
+def test_result_only_first_pass_and_its_repeat_with_state(c, nt, monkeypatch):
+    """The resident CG kernels first run result-only (no x / r / p / z of a possible continuation).  (i) At the floor
+    the result is bit-identical to a run that writes the state (LO_OC_KEEP_STATE=1).  (ii) With a tolerance the floor
+    cannot meet the launches are repeated with the state and the streaming engine continues from it: again
+    bit-identical to the run that wrote the state in its first pass, same iteration count."""
+    C, d, rhs = cases.lowrank_diag(9100 + c, 12, 8192, 32, c)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    pre = _default_precond(desc, dev(d), False)
+    for tol, max_iter in ((1e-4, 1000), (1e-9, 40)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            monkeypatch.delenv("LO_OC_KEEP_STATE", raising=False)
+            K._hip.prof_enable(True)
+            a = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=tol, n_tridiag=nt, max_iter=max_iter)
+            torch.cuda.synchronize()
+            prof = K._hip.prof_report()
+            K._hip.prof_enable(False)
+            monkeypatch.setenv("LO_OC_KEEP_STATE", "1")
+            b = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=tol, n_tridiag=nt, max_iter=max_iter)
+        resident = prof.get("cg_onchip", (0, 0))[0] + prof.get("cg_lockstep", (0, 0))[0]
+        assert resident >= 1, sorted(prof)
+        assert a.iterations == b.iterations and a.tolerance_reached == b.tolerance_reached
+        if tol == 1e-9:
+            assert a.iterations > (21 if nt else 11)  # the streaming engine continued
+            launches = (1 if c != 17 else 2)
+            assert resident == 2 * launches, (resident, sorted(prof))  # result-only pass + the repeat with the state
+        assert torch.equal(a.x, b.x)
+        if nt:
+            assert torch.equal(a.t_mat, b.t_mat)
