@@ -184,6 +184,7 @@ struct alignas(16) FuPost {
 
 typedef float fu_f32x2 __attribute__((ext_vector_type(2)));
 typedef float fu_f32x4 __attribute__((ext_vector_type(4)));
+typedef double fu_f64x4 __attribute__((ext_vector_type(4)));
 
 // LDS map (bytes); region A is a union over the phases
 //   A  [0, 65536):       pivots: L rows (1024 x 16 floats, swizzled 16-byte slots; first the per-wave load windows)
@@ -712,24 +713,42 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
       int ta = t0;
       asm volatile("" : "+v"(ta));
       const int wave_a = ta >> 6, lane_a = ta & 63;
+      // The four matrix products of this phase run on v_mfma_f64_16x16x4_f64 (lane l supplies A[l % 16][l / 16] and
+      // B[l / 16][l % 16] of a step, register r of the result is D[4 r + l / 16][l % 16]): one 16 x 16 tile per wave, the
+      // operands one double per lane and step from LDS -- the vector-ALU version spent two 8-byte LDS reads on every
+      // multiply-add (256 per thread for E F alone) and was bound by LDS bandwidth with two workgroups per CU.
+      constexpr int NTL = (RC + 15) / 16;  // 16-row tiles of an RC x RC matrix
+      const int mn = lane_a & 15, kq = lane_a >> 4;
+      if (wave_a < NTL) {  // T = E M  [RC][16]
+        const int ri = 16 * wave_a + mn;
+        fu_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int u = 0; u < (RC * KP + NT - 1) / NT; ++u) {  // T = E M  [RC][16]
-        const int pr = ta + NT * u;
-        if (pr < RC * KP) {
-          const int r = pr / KP, j = pr % KP;
-          double s = 0.0;
-#pragma unroll 8
-          for (int c2 = 0; c2 < RC; ++c2) s = fma(Em[r][c2], Mm[c2][j], s);
-          Tm[r][j] = s;
+        for (int k0 = 0; k0 < 16 * NTL; k0 += 4) {
+          const int kk = k0 + kq;
+          const double av = (ri < RC && kk < RC) ? Em[ri][kk] : 0.0;
+          const double bv = (kk < RC) ? Mm[kk][mn] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ro = 16 * wave_a + 4 * r + kq;
+          if (ro < RC) Tm[ro][mn] = acc[r];
         }
       }
       __syncthreads();
-      {  // G = I + M^T T  [16][16], one entry per thread
-        const int i = ta / KP, j = ta % KP;
-        double s = (i == j) ? 1.0 : 0.0;
-#pragma unroll 8
-        for (int r = 0; r < RC; ++r) s = fma(Mm[r][i], Tm[r][j], s);
-        Gm[i][j] = s;
+      if (wave_a == 0) {  // G = I + M^T T  [16][16]
+        fu_f64x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = (4 * r + kq == mn) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k0 = 0; k0 < 16 * NTL; k0 += 4) {
+          const int kk = k0 + kq;
+          const double av = (kk < RC) ? Mm[kk][mn] : 0.0;  // A[i = mn][k] = M[k][i]
+          const double bv = (kk < RC) ? Tm[kk][mn] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Gm[4 * r + kq][mn] = acc[r];
       }
       __syncthreads();
       double ldt = 0.0;
@@ -771,15 +790,39 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
       }
       __syncthreads();
       if (stamp) a.dbg[12] = wall_clock64();
+      double(*const EFm)[FU_LD] = Gm;  // (G is dead after the factorisation: its block takes E F)
+      if (wave_a < NTL * NTL) {  // F = Y Y^T  [RC][RC], tile (ti, tj) on wave ti NTL + tj
+        const int ti = wave_a / NTL, tj = wave_a % NTL;
+        const int ri = 16 * ti + mn, cj = 16 * tj + mn;
+        fu_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int u = 0; u < (RC * RC + NT - 1) / NT; ++u) {  // F = Y Y^T
-        const int pr = ta + NT * u;
-        if (pr < RC * RC) {
-          const int r = pr / RC, c2 = pr % RC;
-          double sf = 0.0;
+        for (int k0 = 0; k0 < KP; k0 += 4) {
+          const double av = (ri < RC) ? Tm[ri][k0 + kq] : 0.0;
+          const double bv = (cj < RC) ? Tm[cj][k0 + kq] : 0.0;  // B[k][j] = Y[j][k]
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
 #pragma unroll
-          for (int j = 0; j < KP; ++j) sf = fma(Tm[r][j], Tm[c2][j], sf);
-          Fm[r][c2] = sf;
+        for (int r = 0; r < 4; ++r) {
+          const int ro = 16 * ti + 4 * r + kq;
+          if (ro < RC && cj < RC) Fm[ro][cj] = acc[r];
+        }
+      }
+      __syncthreads();
+      if (wave_a < NTL * NTL) {  // E F  [RC][RC]
+        const int ti = wave_a / NTL, tj = wave_a % NTL;
+        const int ri = 16 * ti + mn, cj = 16 * tj + mn;
+        fu_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k0 = 0; k0 < 16 * NTL; k0 += 4) {
+          const int kk = k0 + kq;
+          const double av = (ri < RC && kk < RC) ? Em[ri][kk] : 0.0;
+          const double bv = (kk < RC && cj < RC) ? Fm[kk][cj] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ro = 16 * ti + 4 * r + kq;
+          if (ro < RC && cj < RC) EFm[ro][cj] = acc[r];
         }
       }
       __syncthreads();
@@ -791,11 +834,8 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
         ev[u] = 0.f;
         if (pr < RC * RC) {
           const int r = pr / RC, c2 = pr % RC;
-          double ef = 0.0;
-#pragma unroll 8
-          for (int q2 = 0; q2 < RC; ++q2) ef = fma(Em[r][q2], Fm[q2][c2], ef);
           fv[u] = (float)Fm[r][c2];
-          ev[u] = (float)ef;
+          ev[u] = (float)EFm[r][c2];
           if (pr % GW == wig) {  // (every workgroup holds the same bits: each stores its share)
             if (a.F) a.F[(size_t)b * RC * RC + pr] = fv[u];
             if (a.EF) a.EF[(size_t)b * RC * RC + pr] = ev[u];
