@@ -754,38 +754,32 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
       double ldt = 0.0;
       if (stamp) a.dbg[11] = wall_clock64();
       if (wave_a == 0) {
-        const int li = lane_a & 15;  // lane i holds row i of G (the other lanes replicate: harmless)
+        // Lanes 0-15 hold the rows of G, lanes 16 .. 16 + RC - 1 the rows of M: the right-looking Cholesky
+        // factorisation G = Lg Lg^T and the forward substitution Y = M Lg^-T are the SAME column operations (column j is
+        // scaled by 1 / Lg[j][j], every later column c loses column j times Lg[c][j] -- lane c's entry, one broadcast
+        // for both), so one loop does both.
+        const int li = lane_a & 15;
+        const int mr_ = lane_a - 16;
+        const bool is_g = lane_a < 16, is_m = mr_ >= 0 && mr_ < RC;
         double gr[KP];
 #pragma unroll
-        for (int c2 = 0; c2 < KP; ++c2) gr[c2] = Gm[li][c2];
+        for (int c2 = 0; c2 < KP; ++c2) gr[c2] = is_g ? Gm[li][c2] : (is_m ? Mm[mr_][c2] : 0.0);
         double myinv = 1.0;
 #pragma unroll
-        for (int j = 0; j < KP; ++j) {  // right-looking Cholesky, G = Lg Lg^T
+        for (int j = 0; j < KP; ++j) {
           const double inv = fu_rsqrt(fu_readlane_d(gr[j], j));  // 1 / Lg[j][j]
-          const double lj = gr[j] * inv;                           // Lg[i][j] for i >= j
+          const double lj = gr[j] * inv;                           // Lg[i][j] (G rows) / Y[r][j] (M rows)
           gr[j] = lj;
-          myinv = (li == j) ? inv : myinv;
+          myinv = (lane_a == j) ? inv : myinv;
 #pragma unroll
           for (int c2 = j + 1; c2 < KP; ++c2) gr[c2] = fma(-lj, fu_readlane_d(lj, c2), gr[c2]);
         }
-        const double mylog = -log(myinv);  // log Lg[j][j] in lane j
+        const double mylog = -log(myinv);  // log Lg[j][j] in lane j < 16
 #pragma unroll
         for (int j = 0; j < KP; ++j) ldt += fu_readlane_d(mylog, j);
-        // Y = M Lg^-T: row r of Y solves Lg y = M[r, :]^T; lane r holds the row, Lg[k][j] = lane k's gr[j]; column-
-        // oriented substitution (independent updates of the later entries)
-        const int rr = lane_a & 31;
-        double y[KP];
+        if (is_m) {
 #pragma unroll
-        for (int j = 0; j < KP; ++j) y[j] = (rr < RC) ? Mm[rr][j] : 0.0;
-#pragma unroll
-        for (int j = 0; j < KP; ++j) {
-          y[j] = y[j] * fu_readlane_d(myinv, j);
-#pragma unroll
-          for (int k2 = j + 1; k2 < KP; ++k2) y[k2] = fma(-fu_readlane_d(gr[j], k2), y[j], y[k2]);
-        }
-        if (lane_a < RC) {
-#pragma unroll
-          for (int j = 0; j < KP; ++j) Tm[lane_a][j] = y[j];
+          for (int j = 0; j < KP; ++j) Tm[mr_][j] = gr[j];
         }
       }
       __syncthreads();
