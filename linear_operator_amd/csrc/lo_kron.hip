@@ -271,8 +271,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 // register r of an accumulator tile holds T[32 ib + 8 (r / 4) + 4 h + r % 4][j] in lane (j, h) -- exactly the
 // (k = h, n = j) layout of a 32x32x2 B operand whose two contraction indices are i and i + 4; the A operand supplies
 // K1[m][i + 4 h] to match (four consecutive registers = a float4 of K1 at column 32 ib + 8 (r / 4) + 4 h).  The order of
-// the contraction is free, the values are the same products.  V / K1 (n1 x 64 slabs) and K2 (128 x 64) pass through
-// LDS as in k_kron_nt_mfma; the slab after next is fetched into registers behind the matrix-core stream.
+// the contraction is free, the values are the same products.  V / K1 (n1 x 32 slabs) and K2 (128 x 32) pass through
+// double-buffered LDS; the slab after next is fetched into registers behind the matrix-core stream.
 // Per member: V, K1 read by n2 / 128 workgroups of one XCD (L2), K2 and Y once -- the 2 x n1 n2 floats of the
 // intermediate (67 MB per launch at cfg4, a third of the two-launch traffic) and one launch are gone.
 struct KfArgs {
@@ -287,15 +287,18 @@ struct KfArgs {
 };
 
 constexpr int KF_LDE = KM_BN + 4;  // row stride of the epilogue's staging tile (128 rows x 128 columns)
-template <int NI, int NS>  // n1 = 32 NI; n2 = 64 NS (NS = 0: any multiple of 128, slab loop not unrolled)
+// Slabs of 32 contraction indices in TWO LDS buffers: the slab after next is on its way from HBM into registers and the
+// next slab moves from registers into the idle buffer while the matrix cores work on the current one -- one barrier per
+// slab (a first version with 64-wide slabs in one buffer needed barrier - store - barrier: 85.8 vs 82.3 us).
+template <int NI, int NS>  // n1 = 32 NI; n2 = 64 NS (NS = 0: any multiple of 128)
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_kron_fused(
     KfArgs g, const int* __restrict__ stop) {
   if (stop && *stop) return;
   constexpr int N1 = 32 * NI;
-  constexpr int NU = N1 / 16;  // float4 per thread and slab of V / K1
-  static_assert(N1 * KM_LD >= 128 * KF_LDE || NI == 4, "the epilogue stages 128 rows of Y in the V / K1 slab buffer");
-  __shared__ float a_s[(N1 * KM_LD > 128 * KF_LDE) ? N1 * KM_LD : 128 * KF_LDE];
-  __shared__ float b_s[KM_BN * KM_LD];
+  constexpr int LDD = 36;  // row stride of a 32-wide slab (floats): conflict-free ds_read_b128 / ds_write_b128
+  constexpr int SA = N1 * LDD, SB = KM_BN * LDD;
+  constexpr int SMEM = (2 * SA + 2 * SB > 128 * KF_LDE) ? 2 * SA + 2 * SB : 128 * KF_LDE;
+  __shared__ __attribute__((aligned(16))) float sm[SMEM];  // A0 | A1 | B0 | B1; the epilogue's staging tile afterwards
   __shared__ float dot_s[4][2];
   const int n2 = NS ? 64 * NS : g.n2, nblk = n2 / KM_BN;
   const int id = blockIdx.x, xcd = id & 7, rest = id >> 3;
@@ -305,44 +308,48 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   const float* K2 = g.K2 + (size_t)z * n2 * n2 + (size_t)blk * KM_BN * n2;
   const float* K1 = g.K1 + (size_t)z * N1 * N1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-  const int sr = threadIdx.x >> 4, sq = threadIdx.x & 15;
-  // staging registers: NAMED, not arrays (the compiler demotes loop-carried float4 arrays to LDS / scratch, which puts
-  // a wait right behind the loads: see k_kron_nt_mfma)
-  float4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, ra8, ra9, ra10, ra11, ra12, ra13, ra14, ra15;
-  float4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
-  ra8 = ra9 = ra10 = ra11 = ra12 = ra13 = ra14 = ra15 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int sr = threadIdx.x >> 3, sq = threadIdx.x & 7;  // staging: float4 (row sr + 32 u, columns 4 sq ..) of a slab
+  const int S1 = n2 / 32;  // slabs of stage 1; stage 2 has NI more (one accumulator tile of T each)
+  float4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3;  // (named: see k_kron_nt_mfma)
+  ra4 = ra5 = ra6 = ra7 = make_float4(0.f, 0.f, 0.f, 0.f);
+  rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define KF_LD4(p_) (*reinterpret_cast<const float4*>(p_))
 #define KF_ST4(p_, v_) (*reinterpret_cast<float4*>(p_) = (v_))
-  // rows sr + 16 u of a slab: p_ = address of row sr, ld_ = row stride of the source
-#define KF_LOAD_A(p_, ld_)                                                                                       \
-  ra0 = KF_LD4(p_); ra1 = KF_LD4((p_) + (size_t)16 * (ld_)); ra2 = KF_LD4((p_) + (size_t)32 * (ld_));            \
-  ra3 = KF_LD4((p_) + (size_t)48 * (ld_)); ra4 = KF_LD4((p_) + (size_t)64 * (ld_));                              \
-  ra5 = KF_LD4((p_) + (size_t)80 * (ld_)); ra6 = KF_LD4((p_) + (size_t)96 * (ld_));                              \
-  ra7 = KF_LD4((p_) + (size_t)112 * (ld_));                                                                      \
-  if constexpr (NU == 16) {                                                                                      \
-    ra8 = KF_LD4((p_) + (size_t)128 * (ld_)); ra9 = KF_LD4((p_) + (size_t)144 * (ld_));                          \
-    ra10 = KF_LD4((p_) + (size_t)160 * (ld_)); ra11 = KF_LD4((p_) + (size_t)176 * (ld_));                        \
-    ra12 = KF_LD4((p_) + (size_t)192 * (ld_)); ra13 = KF_LD4((p_) + (size_t)208 * (ld_));                        \
-    ra14 = KF_LD4((p_) + (size_t)224 * (ld_)); ra15 = KF_LD4((p_) + (size_t)240 * (ld_));                        \
+#define KF2_LOAD_A(p_, ld_)                                                                              \
+  ra0 = KF_LD4(p_); ra1 = KF_LD4((p_) + (size_t)32 * (ld_)); ra2 = KF_LD4((p_) + (size_t)64 * (ld_));    \
+  ra3 = KF_LD4((p_) + (size_t)96 * (ld_));                                                               \
+  if constexpr (NI == 8) {                                                                               \
+    ra4 = KF_LD4((p_) + (size_t)128 * (ld_)); ra5 = KF_LD4((p_) + (size_t)160 * (ld_));                  \
+    ra6 = KF_LD4((p_) + (size_t)192 * (ld_)); ra7 = KF_LD4((p_) + (size_t)224 * (ld_));                  \
   }
-#define KF_LOAD_B(p_, ld_)                                                                                       \
-  rb0 = KF_LD4(p_); rb1 = KF_LD4((p_) + (size_t)16 * (ld_)); rb2 = KF_LD4((p_) + (size_t)32 * (ld_));            \
-  rb3 = KF_LD4((p_) + (size_t)48 * (ld_)); rb4 = KF_LD4((p_) + (size_t)64 * (ld_));                              \
-  rb5 = KF_LD4((p_) + (size_t)80 * (ld_)); rb6 = KF_LD4((p_) + (size_t)96 * (ld_));                              \
-  rb7 = KF_LD4((p_) + (size_t)112 * (ld_));
-#define KF_STORE_A()                                                                                             \
-  KF_ST4(al, ra0); KF_ST4(al + 16 * KM_LD, ra1); KF_ST4(al + 32 * KM_LD, ra2); KF_ST4(al + 48 * KM_LD, ra3);      \
-  KF_ST4(al + 64 * KM_LD, ra4); KF_ST4(al + 80 * KM_LD, ra5); KF_ST4(al + 96 * KM_LD, ra6);                      \
-  KF_ST4(al + 112 * KM_LD, ra7);                                                                                 \
-  if constexpr (NU == 16) {                                                                                      \
-    KF_ST4(al + 128 * KM_LD, ra8); KF_ST4(al + 144 * KM_LD, ra9); KF_ST4(al + 160 * KM_LD, ra10);                \
-    KF_ST4(al + 176 * KM_LD, ra11); KF_ST4(al + 192 * KM_LD, ra12); KF_ST4(al + 208 * KM_LD, ra13);              \
-    KF_ST4(al + 224 * KM_LD, ra14); KF_ST4(al + 240 * KM_LD, ra15);                                              \
+#define KF2_LOAD_B(p_, ld_)                                                                              \
+  rb0 = KF_LD4(p_); rb1 = KF_LD4((p_) + (size_t)32 * (ld_)); rb2 = KF_LD4((p_) + (size_t)64 * (ld_));    \
+  rb3 = KF_LD4((p_) + (size_t)96 * (ld_));
+  // slab s_ of the whole sequence -> registers (s_ < S1: V and K2 columns 32 s_ ..; else K1 columns 32 (s_ - S1) ..)
+#define KF2_LOAD(s_)                                                                                     \
+  if ((s_) < S1) {                                                                                       \
+    const float* vg_ = V + (size_t)sr * n2 + 32 * (s_) + 4 * sq;                                         \
+    const float* kg_ = K2 + (size_t)sr * n2 + 32 * (s_) + 4 * sq;                                        \
+    KF2_LOAD_A(vg_, n2)                                                                                  \
+    KF2_LOAD_B(kg_, n2)                                                                                  \
+  } else {                                                                                               \
+    const float* kg_ = K1 + (size_t)sr * N1 + 32 * ((s_) - S1) + 4 * sq;                                 \
+    KF2_LOAD_A(kg_, N1)                                                                                  \
   }
-#define KF_STORE_B()                                                                                             \
-  KF_ST4(bl, rb0); KF_ST4(bl + 16 * KM_LD, rb1); KF_ST4(bl + 32 * KM_LD, rb2); KF_ST4(bl + 48 * KM_LD, rb3);      \
-  KF_ST4(bl + 64 * KM_LD, rb4); KF_ST4(bl + 80 * KM_LD, rb5); KF_ST4(bl + 96 * KM_LD, rb6);                      \
-  KF_ST4(bl + 112 * KM_LD, rb7);
+  // registers -> buffer (s_ & 1); stage-2 slabs have no B part
+#define KF2_STORE(s_)                                                                                    \
+  {                                                                                                      \
+    float* al_ = sm + ((s_) & 1) * SA + sr * LDD + 4 * sq;                                               \
+    KF_ST4(al_, ra0); KF_ST4(al_ + 32 * LDD, ra1); KF_ST4(al_ + 64 * LDD, ra2); KF_ST4(al_ + 96 * LDD, ra3); \
+    if constexpr (NI == 8) {                                                                             \
+      KF_ST4(al_ + 128 * LDD, ra4); KF_ST4(al_ + 160 * LDD, ra5); KF_ST4(al_ + 192 * LDD, ra6);          \
+      KF_ST4(al_ + 224 * LDD, ra7);                                                                      \
+    }                                                                                                    \
+    if ((s_) < S1) {                                                                                     \
+      float* bl_ = sm + 2 * SA + ((s_) & 1) * SB + sr * LDD + 4 * sq;                                    \
+      KF_ST4(bl_, rb0); KF_ST4(bl_ + 32 * LDD, rb1); KF_ST4(bl_ + 64 * LDD, rb2); KF_ST4(bl_ + 96 * LDD, rb3); \
+    }                                                                                                    \
+  }
   f32x16 T[NI], Y[NI];
 #pragma unroll
   for (int ib = 0; ib < NI; ++ib)
@@ -351,38 +358,23 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       T[ib][e] = 0.f;
       Y[ib][e] = 0.f;
     }
-  {
-    const float* vg = V + (size_t)sr * n2 + 4 * sq;
-    const float* kg = K2 + (size_t)sr * n2 + 4 * sq;
-    KF_LOAD_A(vg, n2)
-    KF_LOAD_B(kg, n2)
-  }
-  float* al = &a_s[sr * KM_LD + 4 * sq];
-  float* bl = &b_s[sr * KM_LD + 4 * sq];
-  // ---- stage 1: T = V K2[j block]^T, contraction over l in slabs of 64 ----
+  KF2_LOAD(0)
+  KF2_STORE(0)
+  KF2_LOAD(1)
+  // ---- stage 1: T = V K2[j block]^T ----
 #pragma unroll
-  for (int l0 = 0; l0 < n2; l0 += KM_BK) {
-    __syncthreads();
-    KF_STORE_A()
-    KF_STORE_B()
-    __syncthreads();
-    if (l0 + KM_BK < n2) {
-      const float* vg = V + (size_t)sr * n2 + l0 + KM_BK + 4 * sq;
-      const float* kg = K2 + (size_t)sr * n2 + l0 + KM_BK + 4 * sq;
-      KF_LOAD_A(vg, n2)
-      KF_LOAD_B(kg, n2)
-    } else {  // the first K1 slab of stage 2 travels behind the last slab's products
-      const float* kg = K1 + (size_t)sr * N1 + 4 * sq;
-      KF_LOAD_A(kg, N1)
-    }
+  for (int s = 0; s < (NS ? 2 * NS : S1); ++s) {
+    __syncthreads();  // buffer s & 1 complete; everybody is done with the other one
+    KF2_STORE(s + 1)  // (always exists: the first stage-2 slab follows the last stage-1 slab)
+    KF2_LOAD(s + 2)
     __builtin_amdgcn_sched_barrier(0);  // (the scheduler would otherwise sink the loads below the matrix-core stream)
-    const float* a0 = &a_s[li * KM_LD + 32 * h];
-    const float* b0 = &b_s[(32 * wave + li) * KM_LD + 32 * h];
+    const float* a0 = sm + (s & 1) * SA + li * LDD + 16 * h;
+    const float* b0 = sm + 2 * SA + (s & 1) * SB + (32 * wave + li) * LDD + 16 * h;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 4; ++q) {
       float4 av[NI];
 #pragma unroll
-      for (int ib = 0; ib < NI; ++ib) av[ib] = KF_LD4(a0 + ib * 32 * KM_LD + 4 * q);
+      for (int ib = 0; ib < NI; ++ib) av[ib] = KF_LD4(a0 + ib * 32 * LDD + 4 * q);
       const float4 bv = KF_LD4(b0 + 4 * q);
 #define KF_STEP(c_)                                                                     \
   _Pragma("unroll") for (int ib = 0; ib < NI; ++ib)                                     \
@@ -391,46 +383,40 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #undef KF_STEP
     }
   }
-  // ---- stage 2: Y = K1 T, contraction over i in slabs of 64 (two accumulator tiles of T per slab) ----
+  // ---- stage 2: Y = K1 T, slab s2 = accumulator tile s2 of T (B operand as it lies, see above) ----
 #pragma unroll
-  for (int s = 0; s < NI / 2; ++s) {
+  for (int s2 = 0; s2 < NI; ++s2) {
+    const int s = S1 + s2;
     __syncthreads();
-    KF_STORE_A()
-    __syncthreads();
-    if (s + 1 < NI / 2) {
-      const float* kg = K1 + (size_t)sr * N1 + 64 * (s + 1) + 4 * sq;
-      KF_LOAD_A(kg, N1)
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    if (s2 + 1 < NI) KF2_STORE(s + 1)
+    if (s2 + 2 < NI) { KF2_LOAD(s + 2) }
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x16& Tt = T[s2];
+    const float* abase = sm + (s & 1) * SA + li * LDD + 4 * h;
 #pragma unroll
-    for (int ibl = 0; ibl < 2; ++ibl) {
-      const f32x16& Tt = T[2 * s + ibl];
+    for (int g4 = 0; g4 < 4; ++g4) {
+      float4 av[NI];
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        float4 av[NI];
-        const float* a0 = &a_s[li * KM_LD + 32 * ibl + 8 * g4 + 4 * h];
-#pragma unroll
-        for (int mb = 0; mb < NI; ++mb) av[mb] = KF_LD4(a0 + mb * 32 * KM_LD);
+      for (int mb = 0; mb < NI; ++mb) av[mb] = KF_LD4(abase + mb * 32 * LDD + 8 * g4);
 #define KF_STEP(c_, e_)                                                                       \
   _Pragma("unroll") for (int mb = 0; mb < NI; ++mb)                                           \
       Y[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb].c_, Tt[4 * g4 + e_], Y[mb], 0, 0, 0);
-        KF_STEP(x, 0) KF_STEP(y, 1) KF_STEP(z, 2) KF_STEP(w, 3)
+      KF_STEP(x, 0) KF_STEP(y, 1) KF_STEP(z, 2) KF_STEP(w, 3)
 #undef KF_STEP
-      }
     }
   }
+#undef KF2_LOAD
+#undef KF2_STORE
+#undef KF2_LOAD_A
+#undef KF2_LOAD_B
 #undef KF_LD4
 #undef KF_ST4
-#undef KF_LOAD_A
-#undef KF_LOAD_B
-#undef KF_STORE_A
-#undef KF_STORE_B
-  // ---- epilogue: 128 rows of Y at a time through LDS (the slab buffer is free), so that v is read and y written as
+  // ---- epilogue: 128 rows of Y at a time through LDS (the slab buffers are free), so that v is read and y written as
   //      whole 512-byte row segments; + d o v, dot partials per 128 x 128 tile (the layout the two-launch path writes) ----
   float* Yg = g.y + (size_t)z * N1 * n2;
   const float dconst = (g.diag_mode == LO_DIAG_CONST) ? g.diag[z] : 0.f;
   const int col0 = blk * KM_BN;
-  const int er = threadIdx.x >> 5, ec = threadIdx.x & 31;  // float4 (row er + 8 u, columns 4 ec ..) of the staged tile
+  const int er = threadIdx.x >> 5, ec = threadIdx.x & 31;
 #pragma unroll
   for (int half = 0; half < NI / 4; ++half) {
     __syncthreads();
@@ -438,13 +424,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     for (int mq = 0; mq < 4; ++mq)
 #pragma unroll
       for (int e = 0; e < 16; ++e)
-        a_s[(32 * mq + km_row(e, lane)) * KF_LDE + 32 * wave + li] = Y[4 * half + mq][e];
+        sm[(32 * mq + km_row(e, lane)) * KF_LDE + 32 * wave + li] = Y[4 * half + mq][e];
     __syncthreads();
     float dacc = 0.f;
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int rl = er + 8 * u;
-      float4 yv = *reinterpret_cast<const float4*>(&a_s[rl * KF_LDE + 4 * ec]);
+      float4 yv = *reinterpret_cast<const float4*>(&sm[rl * KF_LDE + 4 * ec]);
       const size_t o = (size_t)(128 * half + rl) * n2 + col0 + 4 * ec;
       if (g.diag_mode != LO_DIAG_NONE) {
         const float4 vin = *reinterpret_cast<const float4*>(V + o);
