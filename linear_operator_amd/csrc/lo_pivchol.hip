@@ -325,8 +325,17 @@ __global__ __launch_bounds__(kThreads) void k_pc_update(PcDev d, int m) {
     if (live) {
       float v = rowv;
       if (m > 0) {
-        float acc = upd[0] * Lb[i];
-        for (int jj = 1; jj < m; ++jj) acc = acc + upd[jj] * Lb[(size_t)jj * N + i];  // :83-89
+        // :83-89, products and sums in the reference's order; the loads of up to sixteen earlier columns are issued
+        // together (a load per trip, each waited for before the next, made the update a chain of HBM latencies)
+        float acc = 0.f;
+        for (int j8 = 0; j8 < m; j8 += 16) {
+          float lv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) lv[u] = (j8 + u < m) ? Lb[(size_t)(j8 + u) * N + i] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (j8 + u < m) acc = (j8 + u == 0) ? upd[0] * lv[0] : acc + upd[j8 + u] * lv[u];
+        }
         v = rowv - acc;
       }
       v = v / piv;                                   // :91
