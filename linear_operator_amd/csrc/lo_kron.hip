@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   KF2_STORE(0)
   KF2_LOAD(1)
   // ---- stage 1: T = V K2[j block]^T ----
-#pragma unroll
+#pragma unroll NS ? 2 * NS : 1  // (fully unrolled when the factor size is a template argument)
   for (int s = 0; s < (NS ? 2 * NS : S1); ++s) {
     __syncthreads();  // buffer s & 1 complete; everybody is done with the other one
     KF2_STORE(s + 1)  // (always exists: the first stage-2 slab follows the last stage-1 slab)
