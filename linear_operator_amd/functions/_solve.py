@@ -16,13 +16,17 @@ from .. import settings
 def _solve(linear_op, rhs):
     """Cholesky for N <= max_cholesky_size (or fast solves switched off), else `linear_op._solve` with the
     preconditioner built from the detached operator (reference :17-22)."""
+    small = linear_op.size(-1) <= settings.max_cholesky_size.value()
     if getattr(linear_op, "_has_closed_form_solve", False):
         # operators whose `_solve` is a closed form (Woodbury for LowRankRoot + Diag, per-factor eigendecomposition for
-        # Kronecker + constant diagonal) go straight to it, whatever their size -- as the reference's own `solve` of
-        # those classes does (low_rank_root_added_diag_linear_operator.py:152, :62-90): no O(N^3) dense Cholesky below
-        # max_cholesky_size, no preconditioner build
-        return linear_op._solve(rhs)
-    small = linear_op.size(-1) <= settings.max_cholesky_size.value()
+        # Kronecker + constant diagonal) go straight to it -- as the reference's own `solve` of those classes does
+        # (low_rank_root_added_diag_linear_operator.py:152, :62-90): no O(N^3) dense Cholesky, no preconditioner build.
+        # The closed forms run in liblo_amd (fp32 HIP tensors); a SMALL operator that is not one keeps the exact
+        # Cholesky branch below (CPU tensors, fp64: the plumbing case), a large one has no other route and raises there.
+        on_device = (linear_op.dtype == torch.float32 and linear_op.device.type == "cuda"
+                     and rhs.dtype == torch.float32 and rhs.is_cuda)
+        if on_device or not small:
+            return linear_op._solve(rhs)
     if small or settings.fast_computations.solves.off():
         return linear_op.cholesky()._cholesky_solve(rhs)
     with torch.no_grad():

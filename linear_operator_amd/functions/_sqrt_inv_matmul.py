@@ -77,7 +77,7 @@ class SqrtInvMatmul(Function):
         if want_args:
             # sum_q <U_q, dA V_q>, symmetrised; the shared helper computes -sym(<left, dA right>), hence the sign
             d_args = tuple(_symmetric_operator_grads(ctx.linear_op, _nodes_into_columns(u_side),
-                                                     _nodes_into_columns(v_side).neg_()))
+                                                     _nodes_into_columns(v_side).neg()))  # (out of place: the reshape may be a view of a saved tensor)
         return (None, d_rhs, d_lhs, *d_args)
 
 

@@ -86,6 +86,22 @@ class DiagLinearOperator(TriangularLinearOperator):
     def _cholesky_solve(self, rhs: Tensor, upper: bool = False) -> Tensor:  # (D D^T)^-1 rhs, reference :47-48
         return rhs / self._diag.unsqueeze(-1).pow(2)
 
+    def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
+        """Elementwise: sum_n rhs^2 / d and sum_n log d; vector right-hand sides are one column; terms that were not
+        asked for are EMPTY tensors (reference :161-191)."""
+        empty = torch.empty(0, dtype=self.dtype, device=self.device)
+        inv_quad_term = empty
+        if inv_quad_rhs is not None:
+            if inv_quad_rhs.dim() == 1 or inv_quad_rhs.dim() == self._diag.dim():
+                # [*batch, N]: one column, already reduced
+                inv_quad_term = (inv_quad_rhs * inv_quad_rhs / self._diag).sum(-1)
+            else:
+                inv_quad_term = (inv_quad_rhs * inv_quad_rhs / self._diag.unsqueeze(-1)).sum(-2)
+                if reduce_inv_quad:
+                    inv_quad_term = inv_quad_term.sum(-1)
+        logdet_term = self._diag.log().sum(-1) if logdet else empty
+        return inv_quad_term, logdet_term
+
     def zero_mean_mvn_samples(self, num_samples: int) -> Tensor:  # reference :273-277
         base = torch.randn(num_samples, *self._diag.shape, dtype=self.dtype, device=self.device)
         return base * self._diag.sqrt()

@@ -68,9 +68,18 @@ class TriangularLinearOperator(LinearOperator, _TriangularLinearOperatorBase):
         return self.solve(rhs)
 
     def _cholesky_solve(self, rhs: Tensor, upper: bool = False) -> Tensor:
-        """(T T^H)^-1 rhs (lower factor) or (T^H T)^-1 rhs (upper factor): two substitutions (reference :72-91)."""
-        w = torch.linalg.solve_triangular(self._tensor if not self.upper else self._tensor.mT, rhs, upper=False)
-        return torch.linalg.solve_triangular(self._tensor.mT if not self.upper else self._tensor, w, upper=True)
+        """(T T^H)^-1 rhs for `upper=False`, (T^H T)^-1 rhs for `upper=True`: two substitutions with this factor and
+        its transpose; the ARGUMENT selects the product, as in the reference (:72-89)."""
+        is_vec = rhs.dim() == 1
+        cols = rhs.unsqueeze(-1) if is_vec else rhs
+        t, t_is_upper = self._tensor, self.upper
+        if upper:  # (T^H T)^-1 = T^-1 T^-H
+            w = torch.linalg.solve_triangular(t.mT, cols, upper=not t_is_upper)
+            res = torch.linalg.solve_triangular(t, w, upper=t_is_upper)
+        else:  # (T T^H)^-1 = T^-H T^-1
+            w = torch.linalg.solve_triangular(t, cols, upper=t_is_upper)
+            res = torch.linalg.solve_triangular(t.mT, w, upper=not t_is_upper)
+        return res.squeeze(-1) if is_vec else res
 
     def inverse(self) -> "TriangularLinearOperator":
         eye = torch.eye(self._tensor.size(-1), dtype=self._tensor.dtype, device=self._tensor.device)
@@ -80,12 +89,22 @@ class TriangularLinearOperator(LinearOperator, _TriangularLinearOperatorBase):
         return self._diagonal().abs().log().sum(-1)
 
     def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
-        inv_quad_term = None
+        """Substitution for the quadratic form, the diagonal for the log-determinant (NaN for a negative determinant);
+        a term that was not asked for comes back as an EMPTY tensor, never `None` (reference :181-204)."""
+        empty = torch.empty(0, dtype=self.dtype, device=self.device)
+        inv_quad_term = empty
         if inv_quad_rhs is not None:
-            inv_quad_term = (inv_quad_rhs * self.solve(inv_quad_rhs)).sum(-2)
-            if reduce_inv_quad and inv_quad_term.dim() > len(self.batch_shape):
+            cols = inv_quad_rhs.unsqueeze(-1) if inv_quad_rhs.dim() == 1 else inv_quad_rhs
+            inv_quad_term = (cols * self.solve(cols)).sum(-2)
+            if reduce_inv_quad or inv_quad_rhs.dim() == 1:
                 inv_quad_term = inv_quad_term.sum(-1)
-        return inv_quad_term, (self.logdet() if logdet else None)
+        logdet_term = empty
+        if logdet:
+            diag = self._diagonal()
+            logdet_term = diag.abs().log().sum(-1)
+            negative = torch.sign(diag).prod(-1) < 0
+            logdet_term = torch.where(negative, torch.full_like(logdet_term, float("nan")), logdet_term)
+        return inv_quad_term, logdet_term
 
 
 __all__ = ["TriangularLinearOperator"]

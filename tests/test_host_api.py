@@ -253,3 +253,62 @@ def test_install_as_linear_operator_makes_the_package_a_drop_in():
     """ % ROOT)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stderr[-3000:]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_small_closed_form_operators_keep_the_exact_branch_on_cpu(dtype):
+    """`LowRankRoot + Diag` and `Kronecker + ConstantDiag` below `max_cholesky_size` on CPU / in fp64 are the
+    plumbing case of the reference (functions/_solve.py:17-18): dense Cholesky, not the HIP closed forms."""
+    g = torch.Generator().manual_seed(11)
+    k1 = torch.randn(3, 3, generator=g, dtype=dtype)
+    k2 = torch.randn(4, 4, generator=g, dtype=dtype)
+    k1, k2 = k1 @ k1.T + torch.eye(3, dtype=dtype), k2 @ k2.T + torch.eye(4, dtype=dtype)
+    a = lo.operators.KroneckerProductLinearOperator(lo.operators.DenseLinearOperator(k1), lo.operators.DenseLinearOperator(k2)) \
+        + lo.operators.ConstantDiagLinearOperator(torch.tensor([0.5], dtype=dtype), 12)
+    assert type(a).__name__ == "KroneckerProductAddedDiagLinearOperator"
+    rhs = torch.randn(12, 2, generator=g, dtype=dtype)
+    tol = 1e-4 if dtype == torch.float32 else 1e-10
+    assert (a.to_dense() @ a.solve(rhs) - rhs).abs().max() < tol
+    c, d = torch.randn(20, 3, generator=g, dtype=dtype), torch.rand(20, generator=g, dtype=dtype) + 0.5
+    b = lo.operators.LowRankRootLinearOperator(c) + lo.operators.DiagLinearOperator(d)
+    assert type(b).__name__ == "LowRankRootAddedDiagLinearOperator"
+    rhs = torch.randn(20, 2, generator=g, dtype=dtype)
+    assert (b.to_dense() @ b.solve(rhs) - rhs).abs().max() < tol
+    assert (b.to_dense() @ b.solve(rhs[:, 0]) - rhs[:, 0]).abs().max() < tol  # vector right-hand side
+
+
+def test_diag_and_triangular_inv_quad_logdet_follow_the_reference():
+    """vector right-hand sides, empty tensors for terms that were not asked for
+    (reference diag_linear_operator.py:161-191, triangular_linear_operator.py:181-204), `upper` of `_cholesky_solve`
+    (triangular_linear_operator.py:72-89)."""
+    g = torch.Generator().manual_seed(12)
+    d = torch.rand(2, 9, generator=g) + 0.5
+    D = lo.operators.DiagLinearOperator(d)
+    v, m = torch.randn(2, 9, generator=g), torch.randn(2, 9, 3, generator=g)
+    iq, ld = lo.operators.DiagLinearOperator(d[0]).inv_quad_logdet(v[0], logdet=True)
+    assert torch.allclose(iq, (v[0] ** 2 / d[0]).sum()) and torch.allclose(ld, d[0].log().sum())
+    iq, ld = D.inv_quad_logdet(m, logdet=False, reduce_inv_quad=False)
+    assert iq.shape == (2, 3) and ld.numel() == 0 and torch.allclose(iq, (m ** 2 / d.unsqueeze(-1)).sum(-2))
+    iq, ld = D.inv_quad_logdet(None, logdet=True)
+    assert iq.numel() == 0 and torch.allclose(ld, d.log().sum(-1))
+    cd = lo.operators.ConstantDiagLinearOperator(torch.tensor([2.0]), 5)
+    iq, ld = cd.inv_quad_logdet(torch.ones(5), logdet=True)
+    assert torch.allclose(iq, torch.tensor(2.5)) and torch.allclose(ld, torch.tensor(5 * np.log(2.0), dtype=torch.float32))
+    k = torch.randn(6, 6, generator=g, dtype=torch.float64)
+    k = k @ k.T + torch.eye(6, dtype=torch.float64)
+    low = torch.linalg.cholesky(k)
+    r = torch.randn(6, 2, generator=g, dtype=torch.float64)
+    T = lo.operators.TriangularLinearOperator(low)
+    U = lo.operators.TriangularLinearOperator(low.mT.contiguous(), upper=True)
+    want = torch.linalg.solve(k, r)
+    assert torch.allclose(T._cholesky_solve(r), want) and torch.allclose(U._cholesky_solve(r, upper=True), want)
+    assert torch.allclose(T._cholesky_solve(r[:, 0]), want[:, 0])
+    iq, ld = T.inv_quad_logdet(r[:, 0], logdet=True)
+    assert iq.dim() == 0 and torch.allclose(iq, (r[:, 0] * torch.linalg.solve_triangular(low, r[:, :1], upper=False)[:, 0]).sum())
+    assert torch.allclose(ld, low.diagonal().log().sum())
+    iq, ld = T.inv_quad_logdet(r, logdet=False)
+    assert ld.numel() == 0 and iq.dim() == 0
+    neg = lo.operators.TriangularLinearOperator(-low)
+    assert torch.isnan(neg.inv_quad_logdet(None, logdet=True)[1]) == (6 % 2 == 1)
+    neg5 = lo.operators.TriangularLinearOperator(-low[:5, :5])
+    assert torch.isnan(neg5.inv_quad_logdet(None, logdet=True)[1])
