@@ -516,6 +516,14 @@ def self_launch(n, argv):
     return subprocess.call(cmd, env=env)
 
 
+def _step_stats(laps):
+    """min / median / p95 / max of per-step host times in ms."""
+    a = sorted(laps)
+    n = len(a)
+    return {"steps": n, "min_ms": a[0] * 1e3, "median_ms": a[n // 2] * 1e3, "p95_ms": a[min(n - 1, int(0.95 * n))] * 1e3,
+            "max_ms": a[-1] * 1e3, "mean_ms": sum(a) / n * 1e3}
+
+
 def _gather_rank_ms(dist, elapsed_ms, device):
     """Per-rank step times (ms) on every rank."""
     t = torch.tensor([elapsed_ms], device=device, dtype=torch.float64)
@@ -587,6 +595,10 @@ def main():
     ap.add_argument("--workload", choices=["headline", "cfg4", "cfg5"], default="headline",
                     help="headline (default, weak scaling, the driver's contract) or BASELINE cfg4 / cfg5 at their "
                          "full batch split over the ranks (strong scaling)")
+    ap.add_argument("--min-seconds", type=float, default=3.0,
+                    help="after the timed K steps: keep stepping (each step timed on its own) for about this much wall "
+                         "time -- per-step min / median / max for the JSON line, and a GPU that an external "
+                         "utilisation sampler sees busy.  0 = off.  `value` / `ms_per_step` come from the K steps only")
     ap.add_argument("--chunk-members", type=int, default=128,
                     help="cfg5: members resident at a time per rank (1 GiB each)")
     args = ap.parse_args()
@@ -679,11 +691,14 @@ def main():
     for _ in range(args.warmup):
         res = step()
     fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    stamps = [0.0] * (args.steps + 1)
+    t0 = stamps[0] = time.perf_counter()
+    for i in range(args.steps):
         res = step()
+        stamps[i + 1] = time.perf_counter()  # (linear_cg returns when the solve's status block has arrived)
     fence()
     elapsed = time.perf_counter() - t0
+    step_stats = _step_stats([stamps[i + 1] - stamps[i] for i in range(args.steps)])
     per_rank_ms = [elapsed / args.steps * 1e3]
     allgather_ms = None
     if use_dist:
@@ -697,6 +712,19 @@ def main():
             dist.all_gather_into_tensor(gather_bufs[i % 2], res.x)
         torch.cuda.synchronize(device)
         allgather_ms = (time.perf_counter() - tg) / 5 * 1e3
+    # soak: the same step again and again, every step timed on its own (host clock around a synchronous solve); the
+    # count follows from the job's measured step time, so every rank runs the same number of steps (and gathers)
+    soak = None
+    if args.min_seconds > 0:
+        n_soak = max(1, min(200000, int(args.min_seconds / (elapsed / args.steps))))
+        laps = [0.0] * n_soak
+        for i in range(n_soak):
+            ta = time.perf_counter()
+            res = step()
+            laps[i] = time.perf_counter() - ta
+        fence()
+        soak = _step_stats(laps)
+        soak["seconds"] = round(sum(laps), 3)
     matvecs_per_solve = res.matvecs
     total_members = world * B_PER_GPU
     value = total_members * matvecs_per_solve * args.steps / elapsed
@@ -796,9 +824,10 @@ def main():
         kernels = {k: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2),
                        "alg_GBs": round(algorithmic_bytes(k, RANK_K) / (v[1] / v[0] * 1e-3) / 1e9, 1)}
                    for k, v in sorted(prof.items())}
-        triad_gbs = None  # measured HBM ceiling of this box (report beside the spec peak)
+        triad_gbs = copy_gbs = None  # measured HBM ceilings of this box (report beside the spec peak)
         try:
-            triad_gbs = round(_hip.hbm_triad_gbs(device), 1)
+            triad_gbs = round(_hip.hbm_stream_gbs(device, "triad"), 1)
+            copy_gbs = round(_hip.hbm_stream_gbs(device, "copy"), 1)
         except Exception:  # noqa: BLE001
             pass
         # HBM bytes per launch from rocprofv3 PMC passes: they cannot be collected from inside this process, so the
@@ -820,6 +849,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "step_ms": step_stats,
+            "soak": soak,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -839,8 +870,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
-                         "triad_this_box": triad_gbs,
+                         "achievable_peak": copy_gbs or HBM_ACHIEVABLE_GBS,
+                         "frac_of_achievable": achieved / (copy_gbs or HBM_ACHIEVABLE_GBS),
+                         "triad_this_box": triad_gbs, "copy_this_box": copy_gbs,
+                         "achievable_peak_source": "copy_this_box when measured (1 GiB float4 copy of this run), else "
+                                                   "the MI355X guide's 6.29 TB/s",
                          "algorithmic_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6, "launches_timed": cnt,
                          "note": ("per-launch compulsory bytes (C, d, 1/d, rhs in, x out, root-form preconditioner "
                                   "matrices; the kernel keeps the operator on chip for all 11 iterations) / launch time.  "

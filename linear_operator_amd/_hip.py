@@ -43,7 +43,7 @@ EXPORTS = [
     "lo_bilinear_dense_f32", "lo_bilinear_diag_f32", "lo_bilinear_root_workspace_bytes", "lo_bilinear_root_f32",
     "lo_bilinear_kron_workspace_bytes", "lo_bilinear_kron_f32",
     "lo_minres_workspace_bytes", "lo_minres_f32",
-    "lo_prof_enable", "lo_prof_report", "lo_hbm_triad_f32",
+    "lo_prof_enable", "lo_prof_report", "lo_hbm_triad_f32", "lo_hbm_copy_f32", "lo_hbm_stream_dev",
 ]
 
 
@@ -264,6 +264,11 @@ def load():
                                          C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p]
     lib.lo_hbm_triad_f32.restype = C.c_int
     lib.lo_hbm_triad_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, sz, C.c_void_p]
+    lib.lo_hbm_copy_f32.restype = C.c_int
+    lib.lo_hbm_copy_f32.argtypes = [C.c_void_p, C.c_void_p, sz, C.c_void_p]
+    lib.lo_hbm_stream_dev.restype = C.c_int
+    lib.lo_hbm_stream_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, sz,
+                                      C.c_void_p]
     _lib = lib
     return lib
 
@@ -283,22 +288,40 @@ def prof_report() -> dict:
     return out
 
 
-def hbm_triad_gbs(device, n_floats: int = 1 << 28, reps: int = 10) -> float:
-    """Achievable HBM rate of this box: a = b + s c over three n-float arrays (1 GiB each by default), GB/s."""
+def hbm_stream_gbs(device, mode: str = "triad", n_floats: int = 1 << 28, reps: int = 10, unroll=None, nt=None) -> float:
+    """Achievable HBM rate of this box in GB/s: `triad` a = b + s c (12 bytes per element), `copy` a = b (8 bytes),
+    `read` (8 bytes), over n-float arrays (1 GiB each by default: far beyond the 256 MiB Infinity Cache).  `unroll` /
+    `nt` select a variant of the sweep aid instead of the library's default shape."""
     import torch
     lib = load()
     a, b, c = (torch.empty(n_floats, dtype=torch.float32, device=device) for _ in range(3))
     b.fill_(1.0)
     c.fill_(2.0)
     st = stream_ptr(device)
-    check(lib.lo_hbm_triad_f32(ptr(a), ptr(b), ptr(c), 0.5, n_floats, st), "lo_hbm_triad_f32")
+    code = {"triad": 0, "copy": 1, "read": 2}[mode]
+    nbytes = {"triad": 12, "copy": 8, "read": 8}[mode]
+
+    def launch():
+        if unroll is not None:
+            return lib.lo_hbm_stream_dev(code, unroll, 1 if nt else 0, ptr(a), ptr(b), ptr(c), 0.5, n_floats, st)
+        if mode == "triad":
+            return lib.lo_hbm_triad_f32(ptr(a), ptr(b), ptr(c), 0.5, n_floats, st)
+        if mode == "copy":
+            return lib.lo_hbm_copy_f32(ptr(a), ptr(b), n_floats, st)
+        return lib.lo_hbm_stream_dev(2, 4, 1, ptr(a), ptr(b), ptr(c), 0.5, n_floats, st)
+
+    check(launch(), "lo_hbm_stream")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        lib.lo_hbm_triad_f32(ptr(a), ptr(b), ptr(c), 0.5, n_floats, st)
+        launch()
     e1.record()
     torch.cuda.synchronize(device)
-    return 3 * 4 * n_floats * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return nbytes * n_floats * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def hbm_triad_gbs(device, n_floats: int = 1 << 28, reps: int = 10) -> float:
+    return hbm_stream_gbs(device, "triad", n_floats, reps)
 
 
 def check(rc: int, what: str):
