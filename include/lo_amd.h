@@ -171,12 +171,55 @@ int lo_matvec_f32(const lo_op_desc* op, const float* v, float* y, int64_t c, voi
  *   rhs       [B,N,c]      x0  [B,N,c] or NULL (zeros)        x  [B,N,c] out
  *   t_mat     [n_tridiag, B, T, T] out, T = max_tridiag_iter, zero-filled by the call; the caller crops
  *             to [: last_tridiag_iter+1]^2 (linear_cg.py:353-357)
- * SYNCHRONOUS: polls the device stop flag between launch chunks and returns with `info` filled.  */
+ * SYNCHRONOUS for the caller's purposes: returns with `info` filled and x / t_mat complete on `stream`.  When the solve
+ * ends inside the resident launches, the status block arrives through pinned host memory (a ticket the control kernel
+ * writes last) and the call returns without a hipStreamSynchronize: work the caller queued on `stream` BEFORE the call
+ * is complete, but the stream's tail event may not have retired yet -- order later work by the stream, not by the
+ * host.  Otherwise polls the device stop flag between launch chunks.                                       */
 size_t lo_cg_workspace_bytes(const lo_op_desc* op, const lo_precond_desc* pre, const lo_cg_params* prm);
 int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user, const lo_precond_desc* pre,
                     lo_matvec_cb precond_cb, void* precond_user, const lo_cg_params* prm, const float* rhs,
                     const float* x0, float* x, float* t_mat, void* ws, size_t ws_bytes, lo_cg_info* info,
                     void* stream);
+
+/* ---- engine selection of lo_cg_solve_f32 as a PURE function ------------------------------------------------------ */
+/* Which kernels lo_cg_solve_f32 will run for these arguments: decided from the shapes, the null-ness of the pointers in
+ * `pre`, the parameters and the number of compute units -- no device memory is read and nothing is launched, so the
+ * selection matrix is testable on a machine without a GPU (tests/test_host_api.py holds the table).  lo_cg_solve_f32
+ * executes exactly this plan; what is left to run time are the fall-backs after an occupancy query refuses a kernel
+ * (next engine down) or a group hand-off times out (streaming engine).
+ *   cus  compute units to plan for; <= 0: the current device (LO_OC_RESERVE_CUS applied)                             */
+#define LO_ENGINE_NONE 0          /* no serial resident columns                                                 */
+#define LO_ENGINE_RESIDENT_GEN1 1 /* k_cg_onchip  (one row per thread, Q form, one column)                       */
+#define LO_ENGINE_RESIDENT_GEN2 2 /* k_cg_onchip4 (four rows per thread, Q form, columns one after the other)    */
+#define LO_ENGINE_RESIDENT_ROOT 3 /* k_cg_onchip5 (root-form preconditioner, one all-reduce per iteration)       */
+#define LO_STREAM_PRE_NONE 0       /* unpreconditioned update                                                    */
+#define LO_STREAM_PRE_TWO_PASS 1   /* Q^T r, then z = r/d - Q u (two passes over Q)                              */
+#define LO_STREAM_PRE_CLOSURE 2    /* opaque preconditioner closure                                              */
+#define LO_STREAM_PRE_FUSED_Q 3    /* k_precond_fused: one pass over Q, r / x / p updates fused                  */
+#define LO_STREAM_PRE_FUSED_KRON 4 /* k_precond_fused_kron: Kronecker root form, no Q traffic                    */
+typedef struct lo_cg_plan {
+  int32_t resident;             /* 1: the iterations up to the first possible stop run in operator-resident launches */
+  int32_t resident_iterations;  /* how many (first_stop_iteration + 1), 0 if not resident                            */
+  int32_t lockstep_cols;        /* columns [0, lockstep_cols) advance 16 at a time on k_cg_lockstep                  */
+  int32_t lockstep_group;       /* workgroups per member of that kernel                                              */
+  int32_t serial_engine;        /* LO_ENGINE_*: the kernel of the columns [lockstep_cols, c)                         */
+  int32_t serial_group;         /* workgroups per member of that kernel                                              */
+  int32_t lean;                 /* 1: result-only first pass (state written by a repeat only if CG has to continue)  */
+  int32_t needs_q;              /* 1: `pre` carries the root form only and no resident kernel takes the solve:
+                                 * lo_cg_solve_f32 returns LO_ERR_UNSUPPORTED, the caller builds the Q form          */
+  int32_t streaming_precond;    /* LO_STREAM_PRE_*: the preconditioner step of iterations beyond the resident ones
+                                 * (all iterations when resident == 0)                                               */
+  int32_t poll_chunk;           /* streaming iterations enqueued between two reads of the control block              */
+  int32_t first_stop_iteration; /* min(10, max_iter-1), raised to min(max_tridiag_iter, max_iter-1) with tridiagonals
+                                 * (linear_cg.py:302-308)                                                            */
+  int32_t reserved;
+} lo_cg_plan;
+int lo_cg_plan_f32(const lo_op_desc* op, const lo_precond_desc* pre, int has_precond_cb, int has_x0,
+                   const lo_cg_params* prm, int cus, lo_cg_plan* plan);
+/* The plan as the calling thread's last successful lo_cg_solve_f32 EXECUTED it (after run-time fall-backs; `reserved`
+ * = streaming iterations enqueued after the resident phase): the GPU tests compare it with lo_cg_plan_f32.          */
+int lo_cg_last_executed(lo_cg_plan* plan);
 
 /* ---- fused end-to-end solve: ONE resident launch ------------------------------------------------- */
 /* A.solve(rhs) of AddedDiag(LowRankRoot(C), Diag | ConstantDiag) end to end, the operator read from HBM once:

@@ -19,7 +19,7 @@ _lib = None
 LO_OP_LOWRANK_DIAG, LO_OP_DENSE_DIAG, LO_OP_KRON_DIAG, LO_OP_CALLBACK, LO_OP_SUM = 0, 1, 2, 3, 4
 LO_MAX_TERMS = 4
 LO_DIAG_NONE, LO_DIAG_FULL, LO_DIAG_CONST = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 LO_ERR_UNSUPPORTED = -4
 LO_FUSED_OK, LO_FUSED_EARLY_STOP, LO_FUSED_CONTINUE, LO_FUSED_TIMEOUT = 0, 1, 2, 3
@@ -28,7 +28,7 @@ _ERR = {-1: "bad argument", -2: "HIP launch/runtime failure", -3: "workspace too
 EXPORTS = [
     "lo_abi_version", "lo_target_arch",
     "lo_matvec_workspace_bytes", "lo_matvec_f32",
-    "lo_cg_workspace_bytes", "lo_cg_solve_f32", "lo_cg_set_onchip",
+    "lo_cg_workspace_bytes", "lo_cg_solve_f32", "lo_cg_set_onchip", "lo_cg_plan_f32", "lo_cg_last_executed",
     "lo_solve_fused_supported", "lo_solve_fused_workspace_bytes", "lo_solve_fused_f32", "lo_solve_fused_perm",
     "lo_cg_f64_workspace_bytes", "lo_cg_solve_f64", "lo_minres_f64_workspace_bytes", "lo_minres_f64",
     "lo_pivoted_cholesky_workspace_bytes", "lo_pivoted_cholesky_f32",
@@ -81,6 +81,17 @@ class CgInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("matvecs", C.c_int32), ("tolerance_reached", C.c_int32),
                 ("nan_detected", C.c_int32), ("skipped", C.c_int32), ("last_tridiag_iter", C.c_int32),
                 ("mean_residual", C.c_float), ("reserved", C.c_float)]
+
+
+class CgPlan(C.Structure):
+    """lo_cg_plan (include/lo_amd.h): the engine selection of lo_cg_solve_f32."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "resident", "resident_iterations", "lockstep_cols", "lockstep_group", "serial_engine", "serial_group", "lean",
+        "needs_q", "streaming_precond", "poll_chunk", "first_stop_iteration", "reserved")]
+
+
+ENGINE_NAMES = {0: "none", 1: "gen1", 2: "gen2", 3: "root"}
+STREAM_PRE_NAMES = {0: "none", 1: "two_pass", 2: "closure", 3: "fused_q", 4: "fused_kron"}
 
 
 class FusedInfo(C.Structure):
@@ -159,6 +170,10 @@ def load():
     lib.lo_cg_solve_f32.argtypes = [P(OpDesc), MATVEC_CB, C.c_void_p, P(PrecondDesc), MATVEC_CB, C.c_void_p,
                                     P(CgParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz,
                                     P(CgInfo), C.c_void_p]
+    lib.lo_cg_plan_f32.restype = C.c_int
+    lib.lo_cg_plan_f32.argtypes = [P(OpDesc), P(PrecondDesc), C.c_int, C.c_int, P(CgParams), C.c_int, P(CgPlan)]
+    lib.lo_cg_last_executed.restype = C.c_int
+    lib.lo_cg_last_executed.argtypes = [P(CgPlan)]
     lib.lo_solve_fused_supported.restype = C.c_int
     lib.lo_solve_fused_supported.argtypes = [P(OpDesc), C.c_int32, P(CgParams)]
     lib.lo_solve_fused_workspace_bytes.restype = sz

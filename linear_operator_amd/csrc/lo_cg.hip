@@ -58,6 +58,7 @@ void onchip_note_timeout() {
                     "off for this process (lo_cg_set_onchip(1) re-arms them)\n");
   g_onchip_disabled = true;
 }
+static thread_local lo_cg_plan tls_last_exec = {};    // what the last lo_cg_solve_f32 of this thread actually launched
 static thread_local bool tls_no_fused_precond = false;  // set while a solve is redone after a timed-out hand-off
 
 // hipGraph of one CG iteration: captured on a private side stream, replayed on the caller's stream.
@@ -514,6 +515,105 @@ static int padded_rank_k(int k) {
   return 4 * p;
 }
 
+// ---- engine selection: a PURE function of the shapes, the pointers' null-ness, the parameters and the number of
+// workgroup slots (no device memory is read, nothing is launched).  lo_cg_solve_f32 executes this plan; the only
+// decisions left to run time are the fall-backs after an occupancy query refuses a kernel or a hand-off times out.
+// Exported as lo_cg_plan_f32 so that the selection matrix has a table-driven test (tests/test_host_api.py).
+static int padded_rank_c(int64_t R) {  // floats per row of the root as the skinny kernels read it (lo_matvec.hip)
+  int64_t rq = (R + 3) / 4, p = 1;
+  while (p < rq) p <<= 1;
+  return (int)(4 * p);
+}
+
+struct CgShape {  // what cg_layout allocates for the resident paths (it sizes the workspace from the same predicates)
+  bool oc_shape, has_ab, has_ls_gbuf, has_zero_q, pf_shape;
+};
+
+static CgShape cg_shape(const lo_op_desc* op, const lo_precond_desc* pre, bool pre_cb, const lo_cg_params* prm) {
+  const int64_t B = op->B, N = op->N, c = prm->c;
+  CgShape s;
+  s.oc_shape = op->kind == LO_OP_LOWRANK_DIAG && c <= 64 && N >= 256 && N <= 65536;
+  s.has_ab = s.oc_shape && prm->n_tridiag > 0;
+  s.has_ls_gbuf = s.oc_shape && c >= kLockstepMinCols && N <= 8192;
+  s.has_zero_q = !pre && !pre_cb && s.oc_shape;
+  const Split sp = choose_split(B, N, 256);
+  s.pf_shape = pre && precond_fused_eligible(B, N, c, padded_rank_k(pre->k), sp.S);
+  return s;
+}
+
+static void cg_plan(const lo_op_desc* op, const lo_precond_desc* pre, bool pre_cb, bool has_x0, const lo_cg_params* prm,
+                    int oc_nwg, lo_cg_plan* out) {
+  memset(out, 0, sizeof(*out));
+  const int64_t B = op->B, N = op->N;
+  const int c = (int)prm->c;
+  const CgShape sh = cg_shape(op, pre, pre_cb, prm);
+  const int fmi = prm->floor_max_iter > 0 ? prm->floor_max_iter : prm->max_iter;  // (linear_cg.py:303-305)
+  int kfloor0 = std::min(10, fmi - 1);
+  if (prm->n_tridiag) kfloor0 = std::max(kfloor0, std::min(prm->max_tridiag_iter, fmi - 1));  // first possible stop
+  out->first_stop_iteration = kfloor0;
+  const bool global_rule = prm->stop_reduce != nullptr;
+  const bool pre_root = pre && pre->F && pre->EF && pre->rf_ld > 0;
+  const int RC = op->kind == LO_OP_LOWRANK_DIAG ? padded_rank_c(op->R) : 0;
+  const int preR4 = pre ? padded_rank_k(pre->k) : 0;
+  // no preconditioner (N < min_preconditioning_size in the host API): the resident kernels run with Q = 0 and
+  // 1/d = 1, i.e. z = r and r.z = ||r||^2, which is the reference's unpreconditioned update (linear_cg.py:49-95)
+  const bool oc_nopre = !pre && !pre_cb && sh.has_zero_q;
+  const int ocR4 = oc_nopre ? 4 : preR4;
+  // (the first generation handles one column without tridiagonals; the second loops over the columns; the third
+  // advances 16 columns together on the matrix cores; the root-form kernel needs F / EF of the operator's own root)
+  const bool oc_gen1_ok = !oc_nopre && prm->n_tridiag == 0 && c == 1 && onchip_eligible(RC, preR4, N, c);
+  const bool oc_base = (op->kind == LO_OP_LOWRANK_DIAG) && RC <= kMaxRank && (pre || oc_nopre) && !pre_cb && !has_x0 &&
+                       prm->max_iter >= 11 && prm->max_iter > kfloor0 && oc_nwg >= 64 && !g_onchip_disabled &&
+                       (prm->n_tridiag == 0 || sh.has_ab) && B < (1 << 24) - 1024;
+  // column split: full chunks of 16 (and a last chunk of at least kLockstepMinCols) -> lockstep kernel, the rest serial
+  int ls_cols = 0;
+  if (oc_base && sh.has_ls_gbuf && !getenv("LO_OC_NO_LOCKSTEP") && (!pre || pre->Q) &&
+      lockstep_eligible(RC, pre ? preR4 : 0, pre != nullptr, N, c)) {
+    const int full = (c / 16) * 16, rem = c - full;
+    ls_cols = full + (rem >= kLockstepMinCols ? rem : 0);
+  }
+  const bool root_match = oc_nopre || (pre_root && pre->rf_ld == RC);
+  const bool oc_root_ok = ls_cols < c && !getenv("LO_OC_GEN2") && onchip5_eligible(RC, N, c - ls_cols) && root_match;
+  const bool gen2_ok = ls_cols < c && onchip4_eligible(RC, ocR4, N, c - ls_cols) && (!pre || pre->Q);
+  const bool gen1_ok = ls_cols < c && oc_gen1_ok && pre && pre->Q;
+  const bool oc_ok = oc_base && (ls_cols == c || oc_root_ok || gen2_ok || gen1_ok);
+  out->streaming_precond = pre_cb ? LO_STREAM_PRE_CLOSURE : (pre ? LO_STREAM_PRE_TWO_PASS : LO_STREAM_PRE_NONE);
+  if (pre && pre->Q && sh.pf_shape && !tls_no_fused_precond && oc_nwg >= 64) {
+    const bool kron = op->kind == LO_OP_KRON_DIAG && op->diag_mode == LO_DIAG_CONST && pre->constant_diag && pre->kron_a &&
+                      pre->kron_b && pre->kron_F && pre->k <= 16 && !getenv("LO_NO_KRON_ROOT");
+    out->streaming_precond = kron ? LO_STREAM_PRE_FUSED_KRON : LO_STREAM_PRE_FUSED_Q;
+  }
+  const bool opaque = (op->kind == LO_OP_CALLBACK) || pre_cb;
+  out->poll_chunk = (opaque || global_rule) ? 1 : 4;
+  // a root-form-only preconditioner cannot feed the streaming engine: without a resident kernel the caller is told to
+  // build the Q form (LO_ERR_UNSUPPORTED)
+  out->needs_q = (pre && !pre->Q && !(oc_ok && (ls_cols == c || oc_root_ok))) ? 1 : 0;
+  if (!oc_ok) return;
+  out->resident = 1;
+  out->resident_iterations = kfloor0 + 1;
+  out->lockstep_cols = ls_cols;
+  out->lockstep_group = ls_cols ? lockstep_group_size(N) : 0;
+  if (ls_cols < c) {
+    if (oc_root_ok) {
+      out->serial_engine = LO_ENGINE_RESIDENT_ROOT;
+      out->serial_group = (getenv("LO_OC_GW8") && N <= 32768) ? onchip4_group_size(N) : onchip5_group_size(N);
+    } else if (gen2_ok && !(getenv("LO_OC_GEN1") && gen1_ok)) {
+      out->serial_engine = LO_ENGINE_RESIDENT_GEN2;
+      out->serial_group = onchip4_group_size(N);
+    } else {
+      out->serial_engine = LO_ENGINE_RESIDENT_GEN1;
+      out->serial_group = 8;
+    }
+  }
+  // Result-only first pass ("lean"): the resident kernels that take it (root-form serial columns, lockstep) write the
+  // scaled result but not x / r / p / z of a possible continuation -- 4 of the 5 vectors they used to store.  All
+  // BASELINE shapes stop at the floor; when the rule does not hold there, the same launches are repeated with the state
+  // (deterministic kernels: the continuation starts from the very numbers the first pass computed).
+  out->lean = (!global_rule && !getenv("LO_OC_KEEP_STATE") && (ls_cols == c || out->serial_engine == LO_ENGINE_RESIDENT_ROOT))
+                  ? 1 : 0;
+}
+
+
 static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool pre_cb, const lo_cg_params* prm,
                         void* ws, size_t ws_bytes, CgDev* d, MatvecPlan* pl, lo_matvec_cb mv_cb, void* mv_user,
                         const float** Qpad, float** upart, hipStream_t st, int* rc_out, bool init) {
@@ -561,24 +661,25 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   int oc_iters = std::min(10, fmi0 - 1);
   if (prm->n_tridiag) oc_iters = std::max(oc_iters, std::min(prm->max_tridiag_iter, fmi0 - 1));
   oc_iters = std::max(1, oc_iters + 1);
-  const bool oc_shape = op->kind == LO_OP_LOWRANK_DIAG && c <= 64 && N >= 256 && N <= 65536;
+  const CgShape shp = cg_shape(op, pre, pre_cb, prm);  // (the predicates cg_plan decides on)
+  const bool oc_shape = shp.oc_shape;
   const size_t oc_n = oc_shape ? (size_t)B * c : 1;
   dd.oc_resid = ar.take<float>(oc_n * oc_iters);
   dd.oc_init_conv = ar.take<int>(oc_n);
-  dd.oc_ab = (oc_shape && prm->n_tridiag) ? ar.take<float>(2 * oc_n * oc_iters) : nullptr;
+  dd.oc_ab = shp.has_ab ? ar.take<float>(2 * oc_n * oc_iters) : nullptr;
   dd.oc_maxoff = ar.take<int>((size_t)std::max(1, (int)prm->max_tridiag_iter) + 1);
   dd.oc_dbg = ar.take<long long>(16);
-  dd.ls_gbuf = (oc_shape && c >= kLockstepMinCols && N <= 8192)
+  dd.ls_gbuf = shp.has_ls_gbuf
                    ? ar.take<unsigned long long>(lockstep_gbuf_bytes(32, 16) / sizeof(unsigned long long))
                    : nullptr;
-  const bool pf_shape = pre && precond_fused_eligible(B, N, c, padded_rank_k(pre->k), sp.S);
+  const bool pf_shape = shp.pf_shape;
   dd.pf_gbuf = pf_shape ? ar.take<unsigned long long>(precond_fused_gbuf_bytes() / sizeof(unsigned long long)) : nullptr;
   // (decided by the shape, not by the pointer: the sizing pass runs on a null arena)
   dd.pf_ctr = pf_shape ? ar.take<int>(2 * ((size_t)std::max(1, (int)prm->max_iter) + 1)) : nullptr;  // hand-out | done
   dd.pf_gran = pf_shape ? ar.take<unsigned long long>((size_t)B) : nullptr;
   dd.oc_zero_q = nullptr;
   dd.oc_ones = nullptr;
-  if (!pre && !precond && oc_shape) {
+  if (shp.has_zero_q) {
     dd.oc_zero_q = ar.take<float>((size_t)B * N * 4);
     dd.oc_ones = ar.take<float>((size_t)B);
   }
@@ -728,39 +829,20 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     }
     return LO_OK;
   };
-  int kfloor0 = std::min(10, fmi - 1);
-  if (prm->n_tridiag) kfloor0 = std::max(kfloor0, std::min(prm->max_tridiag_iter, fmi - 1));  // first stop
   const int oc_nwg = onchip_num_workgroups();
-  // no preconditioner (N < min_preconditioning_size in the host API): the resident kernel runs with Q = 0 and
-  // 1/d = 1, i.e. z = r and r.z = ||r||^2, which is the reference's unpreconditioned update (linear_cg.py:49-95)
+  // ---- the plan (pure: cg_plan above; lo_cg_plan_f32 reports the same decisions to the tests) ----
+  lo_cg_plan plan;
+  cg_plan(op, pre, precond_cb != nullptr, x0 != nullptr, prm, oc_nwg, &plan);
+  const int kfloor0 = plan.first_stop_iteration;
   const bool oc_nopre = !pre && !precond_cb && d.oc_zero_q != nullptr;
   const int ocR4 = oc_nopre ? 4 : preR4;
-  // (the first generation handles one column without tridiagonals; the second loops over the columns; the third
-  // advances 16 columns together on the matrix cores)
-  const bool oc_gen1_ok = !oc_nopre && prm->n_tridiag == 0 && c == 1 && onchip_eligible(pl.R4, preR4, N, c);
-  const bool oc_base = (op->kind == LO_OP_LOWRANK_DIAG) && (pre || oc_nopre) && !precond_cb && !x0 &&
-                       prm->max_iter >= 11 && prm->max_iter > kfloor0 && oc_nwg >= 64 && !g_onchip_disabled &&
-                       (prm->n_tridiag == 0 || d.oc_ab != nullptr) && B < (1 << 24) - 1024;
-  // column split: full chunks of 16 (and a last chunk of at least kLockstepMinCols) -> lockstep kernel, the rest serial
-  int ls_cols = 0;
-  if (oc_base && d.ls_gbuf && !getenv("LO_OC_NO_LOCKSTEP") && (!pre || pre->Q) &&
-      lockstep_eligible(pl.R4, pre ? preR4 : 0, pre != nullptr, N, c)) {
-    const int full = (c / 16) * 16, rem = c - full;
-    ls_cols = full + (rem >= kLockstepMinCols ? rem : 0);
-  }
-  const bool oc_root_ok = onchip5_eligible(pl.R4, N, c - ls_cols) && (oc_nopre || (pre_root && pre->rf_ld == pl.R4));
-  const bool oc_ok = oc_base && (ls_cols == c || oc_gen1_ok || oc_root_ok ||
-                                 onchip4_eligible(pl.R4, ocR4, N, c - ls_cols));
-  // second generation (4 rows per thread, lo_cg_onchip4.hip) unless LO_OC_GEN1 asks for the first one
-  // (the dynamic member hand-out passes indices through fp32 granules: exact below 2^24)
-  const bool oc_gen2 = oc_ok && ls_cols < c && onchip4_eligible(pl.R4, ocR4, N, c - ls_cols) &&
-                       !(getenv("LO_OC_GEN1") && oc_gen1_ok);
-  // Result-only first pass ("lean"): the resident kernels that take it (third-generation serial columns, lockstep) write
-  // the scaled result but not x / r / p / z of a possible continuation -- 4 of the 5 vectors they used to store.  All
-  // BASELINE shapes stop at the floor; when the rule does not hold there, the same launches are repeated with the state
-  // (deterministic kernels: the continuation starts from the very numbers the first pass computed).
-  bool lean = !global_rule && !getenv("LO_OC_KEEP_STATE") &&
-              (ls_cols == c || (!getenv("LO_OC_GEN2") && oc_root_ok));  // (every column on a kernel with that mode)
+  const bool oc_gen1_ok = !oc_nopre && prm->n_tridiag == 0 && c == 1 && onchip_eligible(pl.R4, preR4, N, c) && pre && pre->Q;
+  const bool oc_ok = plan.resident != 0;
+  int ls_cols = plan.lockstep_cols;
+  bool lean = plan.lean != 0;
+  lo_cg_plan exec = plan;  // the plan as executed: run-time fall-backs are recorded here (lo_cg_last_executed)
+  exec.resident = 0;
+  exec.serial_engine = LO_ENGINE_NONE;
   for (int oc_pass = 0; oc_pass < 2; ++oc_pass) {
   bool oc_redo = false;
   if (oc_ok) {
@@ -817,12 +899,15 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
         a.RW = (int)((N + 7) / 8);
         rc = lockstep_launch(pl.R4, pre != nullptr, a, std::min(oc_nwg, 256), st);
       }
+      if (rc == LO_OK) exec.lockstep_group = a.GW;
       if (rc == LO_ERR_UNSUPPORTED) {  // (does not fit this device: all columns go to the serial kernels)
         ls_cols = 0;
         rc = (oc_gen1_ok || onchip4_eligible(pl.R4, ocR4, N, c)) ? LO_OK : LO_ERR_UNSUPPORTED;
       }
     }
     bool serial_done = false;
+    // (the plan chose the root-form kernel for the serial columns -- or the lockstep kernel did not fit this device and
+    // its columns come here as well)
     if (rc == LO_OK && ls_cols < c && !getenv("LO_OC_GEN2") && onchip5_eligible(pl.R4, N, c - ls_cols) &&
         (oc_nopre || (pre_root && pre->rf_ld == pl.R4))) {
       // root-form serial-column kernel (one all-reduce per iteration): columns [ls_cols, c)
@@ -836,7 +921,11 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
       a.dbg = oc_dbg ? d.oc_dbg : nullptr;
       rc = onchip5_launch(pl.R4, a, oc_nwg, st);  // (d.oc_gbuf was cleared together with the control block)
-      if (rc == LO_OK) serial_done = true;
+      if (rc == LO_OK) {
+        serial_done = true;
+        exec.serial_engine = LO_ENGINE_RESIDENT_ROOT;
+        exec.serial_group = a.GW;
+      }
       else if (rc == LO_ERR_UNSUPPORTED) rc = LO_OK;  // (does not fit: the Q-form kernels below)
     }
     if (rc == LO_OK && ls_cols < c && !serial_done && pre && !pre->Q) rc = LO_ERR_UNSUPPORTED;  // (root form only)
@@ -858,14 +947,21 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(66), st));  // whole allocation (either generation)
       rc = LO_ERR_UNSUPPORTED;
       if (gen2) rc = onchip4_launch(pl.R4, ocR4, a, oc_nwg, st);
+      if (gen2 && rc == LO_OK) {
+        exec.serial_engine = LO_ENGINE_RESIDENT_GEN2;
+        exec.serial_group = a.GW;
+      }
       xout_ok = gen2 && rc == LO_OK;
       if (rc == LO_ERR_UNSUPPORTED && oc_gen1_ok) {
         a.GW = 8;
         a.RW = (int)((N + 7) / 8);
         rc = onchip_launch(pl.R4, preR4, a, oc_nwg, st);
+        if (rc == LO_OK) {
+          exec.serial_engine = LO_ENGINE_RESIDENT_GEN1;
+          exec.serial_group = 8;
+        }
       }
     }
-    (void)oc_gen2;
     if (rc && rc != LO_ERR_UNSUPPORTED) return rc;
     if (rc == LO_OK && !oc_redo) {  // (LO_ERR_UNSUPPORTED: no resident kernel fits this device / shape -> streaming engine)
       const int ktri = prm->n_tridiag ? std::min(a.iters, (int)prm->max_tridiag_iter) : 0;
@@ -919,6 +1015,9 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
         oc_redo = true;
       } else if (oc_err == 0) {
         k_start = a.iters;
+        exec.resident = 1;
+        exec.lockstep_cols = ls_cols;
+        exec.lean = lean ? 1 : 0;
         x_written = xout_ok;
       } else {  // a group hand-off timed out: redo everything with the streaming engine
         fprintf(stderr, "liblo_amd: operator-resident CG timed out, falling back to the streaming engine\n");
@@ -970,7 +1069,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   int first_poll = kfloor;
   if (prm->n_tridiag) first_poll = std::max(first_poll, std::min(prm->max_tridiag_iter, fmi - 1));
   const bool opaque = (op->kind == LO_OP_CALLBACK) || (precond_cb != nullptr);
-  const int chunk = (opaque || global_rule) ? 1 : 4;
+  const int chunk = plan.poll_chunk;
   auto poll = [&]() -> int {
     void* hp = pinned_status_block();
     LO_HIP_CHECK(hipMemcpyAsync(hp ? hp : &h, d.ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
@@ -986,13 +1085,12 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   int k = k_start;
   int launched = k_start;
   // large-N single-column solves: the preconditioner apply fused with the r / x update, Q read once per iteration
-  bool pf_on = pre && pre->Q && d.pf_gbuf && !tls_no_fused_precond && oc_nwg >= 64 &&
-               precond_fused_eligible(B, N, c, preR4, sp.S);
+  bool pf_on = d.pf_gbuf && (plan.streaming_precond == LO_STREAM_PRE_FUSED_Q ||
+                             plan.streaming_precond == LO_STREAM_PRE_FUSED_KRON);
   // Kronecker operator with a constant diagonal: the rows of the preconditioner's tall matrix are formed on the fly from
   // the pivot rows of the two factors (lo_precond_desc.kron_*): 7 instead of 23 floats of traffic per row and iteration
   PfKron kron{nullptr, nullptr, nullptr, 0, 0};
-  const bool pf_kron = pf_on && op->kind == LO_OP_KRON_DIAG && op->diag_mode == LO_DIAG_CONST && pre->constant_diag &&
-                       pre->kron_a && pre->kron_b && pre->kron_F && pre->k <= 16 && !getenv("LO_NO_KRON_ROOT");
+  const bool pf_kron = pf_on && plan.streaming_precond == LO_STREAM_PRE_FUSED_KRON;
   if (pf_kron) kron = PfKron{pre->kron_a, pre->kron_b, pre->kron_F, (int)op->R, (int)op->n2};
   bool p_done = false;  // the fused apply of the previous iteration already wrote this iteration's p
   if (pf_on) {  // granules and hand-out counters of the fused apply: cleared once per solve (tags are unique per launch)
@@ -1035,7 +1133,10 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
                                   d.z, d.pAp_part, d.S_dot, d.rz, d.has_conv, d.eps, d.alpha, d.rr_part, d.rz_part, sp.S,
                                   B, N, d.pf_gbuf, d.oc_err, d.pf_ctr, kk, dyn ? &d.ctrl->iterations : nullptr,
                                   (int)prm->max_iter, stop, oc_nwg, &cf, pf_kron ? &kron : nullptr, ls);
-      if (rcb == LO_ERR_UNSUPPORTED) pf_on = false;  // (does not fit this device: the two-launch path from now on)
+      if (rcb == LO_ERR_UNSUPPORTED) {  // (does not fit this device: the two-launch path from now on)
+        pf_on = false;
+        exec.streaming_precond = LO_STREAM_PRE_TWO_PASS;
+      }
       else if (rcb) return rcb;
       else {
         pre_done = p_done = true;
@@ -1155,6 +1256,32 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   info->last_tridiag_iter = h.last_tridiag_iter;
   info->mean_residual = h.mean_resid;
   info->reserved = 0.f;
+  if (!exec.resident) {
+    exec.resident_iterations = exec.lockstep_cols = exec.lockstep_group = exec.serial_group = exec.lean = 0;
+    exec.serial_engine = LO_ENGINE_NONE;
+  }
+  exec.reserved = launched - k_start;  // streaming iterations enqueued after the resident phase
+  tls_last_exec = exec;
+  return LO_OK;
+}
+
+// The engine selection of lo_cg_solve_f32 for these arguments (pure; see cg_plan).  cus <= 0: the current device (with
+// LO_OC_RESERVE_CUS applied), else plan for a device with that many compute units.
+int lo_cg_plan_f32(const lo_op_desc* op, const lo_precond_desc* pre, int has_precond_cb, int has_x0,
+                   const lo_cg_params* prm, int cus, lo_cg_plan* plan) {
+  if (!op || !prm || !plan) return LO_ERR_BADARG;
+  if (prm->c < 1 || prm->c > kMaxCols) return LO_ERR_UNSUPPORTED;
+  if (pre && has_precond_cb) return LO_ERR_BADARG;
+  const int nwg = cus > 0 ? (cus / 32) * 32 : onchip_num_workgroups();
+  cg_plan(op, pre, has_precond_cb != 0, has_x0 != 0, prm, nwg, plan);
+  return LO_OK;
+}
+
+// What the calling thread's last successful lo_cg_solve_f32 launched: the plan after its run-time fall-backs
+// (`reserved` = number of streaming iterations enqueued after the resident phase).
+int lo_cg_last_executed(lo_cg_plan* out) {
+  if (!out) return LO_ERR_BADARG;
+  *out = tls_last_exec;
   return LO_OK;
 }
 

@@ -429,6 +429,40 @@ def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optio
                     bool(info.nan_detected), bool(info.skipped), float(info.mean_residual))
 
 
+def _plan_dict(pl) -> dict:
+    return dict(resident=bool(pl.resident), resident_iterations=pl.resident_iterations, lockstep_cols=pl.lockstep_cols,
+                lockstep_group=pl.lockstep_group, serial_engine=_hip.ENGINE_NAMES[pl.serial_engine],
+                serial_group=pl.serial_group, lean=bool(pl.lean), needs_q=bool(pl.needs_q),
+                streaming_precond=_hip.STREAM_PRE_NAMES[pl.streaming_precond], poll_chunk=pl.poll_chunk,
+                first_stop_iteration=pl.first_stop_iteration, streaming_iterations=pl.reserved)
+
+
+def cg_plan(desc: OperatorDescriptor, c: int, *, precond: Optional[WoodburyPreconditioner] = None, has_x0: bool = False,
+            has_precond_closure: bool = False, n_tridiag: int = 0, max_iter: int = 1000, max_tridiag_iter: int = 20,
+            floor_max_iter: int = 0, global_rule: bool = False, cus: int = 0) -> dict:
+    """lo_cg_plan_f32: which engines `cg_solve` will run for these arguments (pure; nothing is launched).  cus = 0:
+    this device."""
+    lib = _hip.load()
+    s = desc.c_struct()
+    pre_s = precond.c_struct() if precond is not None else None
+    prm = _hip.CgParams()
+    prm.c, prm.n_tridiag, prm.max_iter, prm.max_tridiag_iter, prm.floor_max_iter = c, n_tridiag, max_iter, max_tridiag_iter, floor_max_iter
+    prm.tolerance, prm.eps, prm.stop_updating_after = 1.0, 1e-10, 1e-10
+    if global_rule:
+        prm.stop_reduce = _hip.STOP_REDUCE_CB(lambda user, vals: 0)
+    out = _hip.CgPlan()
+    _hip.check(lib.lo_cg_plan_f32(C.byref(s), C.byref(pre_s) if pre_s is not None else None, int(has_precond_closure),
+                                  int(has_x0), C.byref(prm), int(cus), C.byref(out)), "lo_cg_plan_f32")
+    return _plan_dict(out)
+
+
+def cg_last_executed() -> dict:
+    """lo_cg_last_executed: the plan the calling thread's last `cg_solve` actually ran (after run-time fall-backs)."""
+    out = _hip.CgPlan()
+    _hip.check(_hip.load().lo_cg_last_executed(C.byref(out)), "lo_cg_last_executed")
+    return _plan_dict(out)
+
+
 @dataclass
 class FusedSolveResult:
     """Outcome of the one-launch end-to-end solve: the linear_cg result, the root-form preconditioner it built on the

@@ -38,3 +38,21 @@ def max_rel_err_cols(a, b):
     num = np.sqrt(((a - b) ** 2).sum(axis=-2))
     den = np.maximum(np.sqrt((b**2).sum(axis=-2)), 1e-300)
     return float((num / den).max())
+
+
+def tridiag_block_err(t, t64, valid, back_off=0):
+    """CG tridiagonals against the reference's fp64 run of the same recurrence, on the leading block up to which the
+    reference's OWN fp32 run follows its fp64 run entry by entry (golden g23: `*_valid`, criterion
+    |a - b| <= 1e-4 |b| + 1e-6 max |b|): max over (column, member, entry) of |t - t64| / (|t64| + 1e-2 max |t64|)
+    -- 1e-4 here is the generator's criterion.  Returns (worst error, smallest block)."""
+    t = np.asarray(t, dtype=np.float64)
+    t64 = np.asarray(t64, dtype=np.float64)
+    worst, smallest = 0.0, None
+    for i in range(t64.shape[0]):
+        for b in range(t64.shape[1]):
+            k = min(int(valid[i, b]) - back_off, t.shape[-1], t64.shape[-1])
+            assert k >= 1
+            smallest = k if smallest is None else min(smallest, k)
+            blk = t64[i, b, :k, :k]
+            worst = max(worst, float((np.abs(t[i, b, :k, :k] - blk) / (np.abs(blk) + 1e-2 * np.abs(blk).max())).max()))
+    return worst, smallest

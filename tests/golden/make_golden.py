@@ -923,8 +923,134 @@ def g22_kronecker_iteration_pinned():
     save("g22_kron_iteration_pinned", checksum=cases.checksum(*inputs), **out)
 
 
+def _tridiag_valid_len(t32, t64, rtol):
+    """Per (column, member): the largest k such that the leading k x k blocks of the two tridiagonals agree ENTRY BY
+    ENTRY, |a - b| <= rtol |b| + 1e-6 max |b| over the block (the absolute part only forgives off-diagonals that
+    have decayed to rounding level); the block also ends where the fp64 off-diagonal has decayed below 1e-5 of the
+    largest entry: the column has converged, what follows is 0 / 0 in every fp32 run."""
+    nt, B = t64.shape[:2]
+    K = min(t32.shape[-1], t64.shape[-1])
+    out = np.zeros((nt, B), dtype=np.int64)
+    for i in range(nt):
+        for b in range(B):
+            for m in range(1, K + 1):
+                a, c = t32[i, b, :m, :m].astype(np.float64), t64[i, b, :m, :m].astype(np.float64)
+                if m > 1 and abs(c[m - 1, m - 2]) <= 1e-5 * np.abs(c).max():
+                    break  # the fp64 recurrence has decoupled here (column converged): later rows are not defined
+                if np.any(np.abs(a - c) > rtol * np.abs(c) + 1e-6 * np.abs(c).max()):
+                    break
+                out[i, b] = m
+    return out
+
+
+def g23_tridiag_divergence_and_tight_logdet():
+    """(a) For every fp32 golden that carries CG tridiagonals, the SAME reference run in fp64 on the same (fp32-valued)
+    inputs, and the index up to which the reference's own fp32 run follows it (leading block, every entry to 1e-4
+    relative): beyond that index the fp32 recurrence (linear_cg.py:311-332) is rounding noise in the reference
+    itself, up to it a kernel path has to agree entry by entry.
+    (b) Two WELL-CONDITIONED inv_quad_logdet cases with injected probes (spectrum of the preconditioned operator in
+    [1, 4], |logdet| ~ 1e3): there the reference's fp32 result is within 2e-5 of its own fp64 result, so a kernel path
+    can be held to rtol 1e-4 with atol 0 (functions/_inv_quad_logdet.py:112-153, test/functions/test_inv_quad_logdet.py:17-85)."""
+    print("G23 tridiagonal divergence index + tight logdet")
+    out, inputs = {}, []
+    # ---- (a1) g1_cg_fp32_lowrank, tolerance 1, n_tridiag 4 (unpreconditioned, 20 x 20)
+    C, d, rhs = cases.lowrank_diag(141, 4, 512, 8, 5)
+    A32 = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+    A64 = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C).double()), DiagLinearOperator(T(d).double()))
+    (_, t32), _, _ = run_cg(A32._matmul, T(rhs), tolerance=1.0, n_tridiag=4)
+    (x64, t64), n64, _ = run_cg(A64._matmul, T(rhs).double(), tolerance=1.0, n_tridiag=4)
+    out.update(g1_t_mat_f64=t64, g1_x_f64=x64, g1_matvecs_f64=n64,
+               g1_valid=_tridiag_valid_len(t32.numpy(), t64.numpy(), 1e-4))
+    print("  g1 lowrank: valid rows", out["g1_valid"].min(), "..", out["g1_valid"].max(), "of", t64.shape[-1])
+    inputs += [C, d, rhs]
+
+    # ---- (a2) g4_iql_lowrank and g4_iql_dense (preconditioned, injected probes)
+    def iql(make_op, rhs, Z, Zn, dt, tol=1e-4):
+        A = make_op(dt)
+        A._probes = (T(Z).to(dt), T(Zn).to(dt))
+        with settings.cg_tolerance(tol):
+            (iq, ld), spy, w = _with_spy(lambda: A.inv_quad_logdet(T(rhs).to(dt), logdet=True))
+        solves, t_mat = spy.records[0]["out"]
+        return iq, ld, solves, t_mat, spy.records[0]["matvecs"]
+
+    C, d, rhs = cases.lowrank_diag(411, 3, 2048, 16, 1)
+    Z, Zn = cases.probes(412, 3, 2048, 8)
+    mk = lambda dt: _ProbedAddedDiag(LowRankRootLinearOperator(T(C).to(dt)), DiagLinearOperator(T(d).to(dt)))  # noqa: E731
+    _, ld32, _, t32, _ = iql(mk, rhs, Z, Zn, torch.float32)
+    iq64, ld64, s64, t64, n64 = iql(mk, rhs, Z, Zn, torch.float64)
+    out.update(iql_lowrank_t_mat_f64=t64, iql_lowrank_logdet_f64=ld64, iql_lowrank_inv_quad_f64=iq64,
+               iql_lowrank_solves_f64=s64, iql_lowrank_matvecs_f64=n64,
+               iql_lowrank_valid=_tridiag_valid_len(t32.numpy(), t64.numpy(), 1e-4))
+    print("  iql lowrank: valid", out["iql_lowrank_valid"].min(), "..", out["iql_lowrank_valid"].max(),
+          "fp32 logdet", ld32.tolist(), "fp64", ld64.tolist())
+    inputs += [C, d, rhs, Z]
+    Kd, d, rhs = cases.dense_diag(431, 2, 2048, 1)
+    Z, Zn = cases.probes(432, 2, 2048, 4)
+    mk = lambda dt: _ProbedAddedDiag(DenseLinearOperator(T(Kd).to(dt)), DiagLinearOperator(T(d).to(dt)))  # noqa: E731
+    _, ld32, _, t32, _ = iql(mk, rhs, Z, Zn, torch.float32)
+    iq64, ld64, s64, t64, n64 = iql(mk, rhs, Z, Zn, torch.float64)
+    out.update(iql_dense_t_mat_f64=t64, iql_dense_logdet_f64=ld64, iql_dense_inv_quad_f64=iq64,
+               iql_dense_matvecs_f64=n64, iql_dense_valid=_tridiag_valid_len(t32.numpy(), t64.numpy(), 1e-4))
+    print("  iql dense: valid", out["iql_dense_valid"].min(), "..", out["iql_dense_valid"].max(),
+          "fp32 logdet", ld32.tolist(), "fp64", ld64.tolist())
+    inputs += [Kd, d, rhs, Z]
+
+    # ---- (b) well-conditioned logdet: d in [1.5, 2.5), C = 0.05 randn (C C^T has R eigenvalues ~ 0.0025 N)
+    for tag, seed, B, N, R, P in (("wc_nopre", 2301, 3, 1024, 8, 8), ("wc_pre", 2311, 3, 2304, 32, 8)):
+        g = np.random.default_rng(seed)
+        C = (0.05 * g.standard_normal((B, N, R))).astype(np.float32)
+        d = (g.random((B, N)) + 1.5).astype(np.float32)
+        rhs = g.standard_normal((B, N, 1)).astype(np.float32)
+        Z, Zn = cases.probes(seed + 1, B, N, P)
+        mk = lambda dt: _ProbedAddedDiag(LowRankRootLinearOperator(T(C).to(dt)), DiagLinearOperator(T(d).to(dt)))  # noqa: E731
+        iq32, ld32, s32, t32, n32 = iql(mk, rhs, Z, Zn, torch.float32)
+        iq64, ld64, s64, t64, n64 = iql(mk, rhs, Z, Zn, torch.float64)
+        dense = (T(C).double() @ T(C).double().mT) + torch.diag_embed(T(d).double())
+        exact = np.linalg.slogdet(dense.numpy())[1]
+        rel = float(((ld32.double() - ld64).abs() / ld64.abs()).max())
+        print(f"  {tag}: matvecs {n32}/{n64}, t_mat {tuple(t32.shape)}, logdet fp32 {ld32.tolist()} fp64 {ld64.tolist()} "
+              f"exact {exact.tolist()}; fp32 vs fp64 rel {rel:.2e}")
+        assert rel < 2e-5, "not a well-conditioned case: the reference's own fp32 run is off"
+        out.update({f"{tag}_logdet": ld32, f"{tag}_inv_quad": iq32, f"{tag}_solves": s32, f"{tag}_t_mat": t32,
+                    f"{tag}_matvecs": n32, f"{tag}_logdet_f64": ld64, f"{tag}_inv_quad_f64": iq64,
+                    f"{tag}_t_mat_f64": t64, f"{tag}_logdet_exact": exact,
+                    f"{tag}_valid": _tridiag_valid_len(t32.numpy(), t64.numpy(), 1e-4)})
+        inputs += [C, d, rhs, Z]
+    save("g23_tridiag_divergence_tight_logdet", checksum=cases.checksum(*inputs), **out)
+
+
+def g24_kronecker_256_iteration_pinned():
+    """cfg4 at its real factor size, 256 (x) 256 (N = 65536), B = 2, iteration-pinned like g22: the reference at
+    cg_tolerance 1e-3, then tolerance 0 with max_cg_iterations = the count it needed.  Only the pinned iterate, the
+    exact solution and the iteration count are stored (fp32, 2 x 65536 each)."""
+    print("G24 Kronecker 256 (x) 256, iteration-pinned")
+    n, B = 256, 2
+    N = n * n
+    K1, K2, sig, rhs = cases.kron_factors(2401, B, n, n, 1)
+    A = AddedDiagLinearOperator(KroneckerProductLinearOperator(T(K1), T(K2)), ConstantDiagLinearOperator(T(sig), N))
+    with settings.cg_tolerance(1e-3):
+        x_tol, spy, w = _with_spy(lambda: A.solve(T(rhs)))
+    its = int(spy.records[0]["matvecs"]) - 1
+    A2 = AddedDiagLinearOperator(KroneckerProductLinearOperator(T(K1), T(K2)), ConstantDiagLinearOperator(T(sig), N))
+    with settings.cg_tolerance(0.0), settings.max_cg_iterations(its):
+        x_pin, spy2, w2 = _with_spy(lambda: A2.solve(T(rhs)))
+    assert int(spy2.records[0]["matvecs"]) - 1 == its
+    xs = []
+    for i in range(B):
+        l1, q1 = np.linalg.eigh(K1[i].astype(np.float64))
+        l2, q2 = np.linalg.eigh(K2[i].astype(np.float64))
+        Y = q1.T @ rhs[i, :, 0].astype(np.float64).reshape(n, n) @ q2
+        xs.append((q1 @ (Y / (np.outer(l1, l2) + float(sig[i, 0]))) @ q2.T).reshape(N, 1))
+    xe = np.stack(xs)
+    err_pin = float(np.abs(x_pin.numpy() - xe).max() / np.abs(xe).max())
+    print(f"  {its} iterations; |x_pinned - x_tol| / |x_tol| = {float((x_pin - x_tol).norm() / x_tol.norm()):.2e}; "
+          f"pinned vs exact (max-norm) {err_pin:.2e}")
+    save("g24_kron256_iteration_pinned", x_pinned=x_pin, iterations=its, warned_pinned=w2,
+         x_exact=xe.astype(np.float32), checksum=cases.checksum(K1, K2, sig, rhs))
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g22", "g21", "g20", "g19", "g18", "g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g24", "g23", "g22", "g21", "g20", "g19", "g18", "g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
@@ -934,7 +1060,8 @@ if __name__ == "__main__":
                      ("g16", g16_sum_operators), ("g17", g17_low_rank_root_added_diag_backward),
                      ("g18", g18_low_rank_root_added_diag_wide_root), ("g19", g19_kronecker_three_factors),
                      ("g20", g20_kronecker_structured_diag), ("g21", g21_minres_fp64),
-                     ("g22", g22_kronecker_iteration_pinned)):
+                     ("g22", g22_kronecker_iteration_pinned), ("g23", g23_tridiag_divergence_and_tight_logdet),
+                     ("g24", g24_kronecker_256_iteration_pinned)):
         if name in todo:
             fn()
     print("done")

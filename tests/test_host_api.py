@@ -312,3 +312,93 @@ def test_diag_and_triangular_inv_quad_logdet_follow_the_reference():
     assert torch.isnan(neg.inv_quad_logdet(None, logdet=True)[1]) == (6 % 2 == 1)
     neg5 = lo.operators.TriangularLinearOperator(-low[:5, :5])
     assert torch.isnan(neg5.inv_quad_logdet(None, logdet=True)[1])
+
+
+# ---------------------------------------------------------------- engine selection of lo_cg_solve_f32
+def _plan(kind, N, R=32, c=1, k=15, pre="root+q", nt=0, B=512, x0=False, closure=False, max_iter=1000, cus=256, n2=0,
+          kron_root=False, global_rule=False, diag_mode=_hip.LO_DIAG_FULL, const_pre=False):
+    """lo_cg_plan_f32 on a descriptor with placeholder (non-null) pointers: the plan reads shapes and null-ness only."""
+    lib = _hip.load()
+    FAKE = 0x1000
+    op = _hip.OpDesc()
+    op.kind, op.diag_mode, op.B, op.N, op.R, op.n2 = kind, diag_mode, B, N, R, n2
+    op.A0, op.A1, op.d = FAKE, (FAKE if kind == _hip.LO_OP_KRON_DIAG else None), FAKE
+    pd = None
+    if pre and not closure:
+        pd = _hip.PrecondDesc()
+        pd.k, pd.ldq, pd.constant_diag, pd.dinv = k, 4 * (1 << max(0, ((k + 3) // 4 - 1).bit_length())), int(const_pre), FAKE
+        pd.Q = FAKE if "q" in pre else None
+        if "root" in pre:
+            rf = 8 if R <= 8 else (16 if R <= 16 else 32)
+            pd.F, pd.EF, pd.E, pd.rf_ld = FAKE, FAKE, FAKE, rf
+        if kron_root:
+            pd.kron_a, pd.kron_b, pd.kron_F = FAKE, FAKE, FAKE
+    prm = _hip.CgParams()
+    prm.c, prm.n_tridiag, prm.max_iter, prm.max_tridiag_iter, prm.floor_max_iter = c, nt, max_iter, 20, 0
+    prm.tolerance, prm.eps, prm.stop_updating_after = 1e-4, 1e-10, 1e-10
+    if global_rule:
+        prm.stop_reduce = _hip.STOP_REDUCE_CB(lambda user, vals: 0)
+    out = _hip.CgPlan()
+    rc = lib.lo_cg_plan_f32(ctypes.byref(op), ctypes.byref(pd) if pd is not None else None, int(closure), int(x0),
+                            ctypes.byref(prm), cus, ctypes.byref(out))
+    assert rc == 0, rc
+    return dict(resident=out.resident, iters=out.resident_iterations, ls=out.lockstep_cols, ls_gw=out.lockstep_group,
+                serial=_hip.ENGINE_NAMES[out.serial_engine], gw=out.serial_group, lean=out.lean, needs_q=out.needs_q,
+                stream=_hip.STREAM_PRE_NAMES[out.streaming_precond], chunk=out.poll_chunk, first_stop=out.first_stop_iteration)
+
+
+LOW, DENSE, KRON, CB = _hip.LO_OP_LOWRANK_DIAG, _hip.LO_OP_DENSE_DIAG, _hip.LO_OP_KRON_DIAG, _hip.LO_OP_CALLBACK
+ENGINE_TABLE = [
+    # (label, arguments of _plan, expected subset of the plan)
+    ("headline: cfg3 operator, one column", dict(kind=LOW, N=8192), dict(resident=1, iters=11, ls=0, serial="root", gw=8, lean=1, needs_q=0)),
+    ("cfg2", dict(kind=LOW, N=8192, B=64), dict(resident=1, serial="root", gw=8, lean=1)),
+    ("cfg3: 16 probes + rhs", dict(kind=LOW, N=8192, c=17, nt=16), dict(resident=1, iters=21, ls=16, ls_gw=8, serial="root", lean=1)),
+    ("16 probes only", dict(kind=LOW, N=8192, c=16, nt=16), dict(resident=1, ls=16, serial="none", lean=1)),
+    ("20 columns: chunks of 16 + 4", dict(kind=LOW, N=8192, c=20), dict(ls=20, serial="none")),
+    ("19 columns: 16 lockstep + 3 serial", dict(kind=LOW, N=8192, c=19), dict(ls=16, serial="root")),
+    ("Q form only, one column", dict(kind=LOW, N=8192, pre="q"), dict(resident=1, serial="gen2", gw=8, lean=0)),
+    ("Q form only, 17 columns", dict(kind=LOW, N=8192, c=17, nt=16, pre="q"), dict(resident=1, ls=16, serial="gen2", lean=0)),
+    ("root form only", dict(kind=LOW, N=8192, pre="root"), dict(resident=1, serial="root", needs_q=0, lean=1)),
+    ("root form only, 17 columns: no lockstep without Q", dict(kind=LOW, N=8192, c=17, nt=16, pre="root"),
+     dict(resident=1, ls=0, serial="root", lean=1, needs_q=0)),
+    ("root form only beyond the resident kernels", dict(kind=LOW, N=100000, pre="root"), dict(resident=0, needs_q=1)),
+    ("small members take small groups", dict(kind=LOW, N=1024), dict(resident=1, serial="root", gw=1)),
+    ("N = 3000", dict(kind=LOW, N=3000, c=5, nt=4), dict(resident=1, ls=5, ls_gw=4, serial="none")),
+    ("N = 16384", dict(kind=LOW, N=16384), dict(resident=1, serial="root", gw=16)),
+    ("N = 16384, 17 columns: lockstep stops at 8192", dict(kind=LOW, N=16384, c=17, nt=16), dict(resident=1, ls=0, serial="root", gw=16)),
+    ("N = 65536: groups of 64", dict(kind=LOW, N=65536), dict(resident=1, serial="root", gw=64)),
+    ("N = 40000, Q form only: streaming, fused apply", dict(kind=LOW, N=40000, pre="q"), dict(resident=0, stream="fused_q", chunk=4)),
+    ("N = 100000: streaming two-pass", dict(kind=LOW, N=100000), dict(resident=0, stream="two_pass")),
+    ("N < 256", dict(kind=LOW, N=200, pre=None), dict(resident=0, stream="none")),
+    ("no preconditioner", dict(kind=LOW, N=1500, pre=None), dict(resident=1, serial="root", gw=2, lean=1, stream="none")),
+    ("no preconditioner, 9 columns", dict(kind=LOW, N=1500, pre=None, c=9), dict(resident=1, ls=9, serial="none")),
+    ("rank-20 root is padded to 32", dict(kind=LOW, N=5000, R=20, c=20, nt=16), dict(resident=1, ls=20)),
+    ("rank-8 root", dict(kind=LOW, N=2048, R=8, c=6), dict(resident=1, ls=6, ls_gw=2)),
+    ("initial guess", dict(kind=LOW, N=8192, x0=True), dict(resident=0, stream="fused_q")),
+    ("preconditioner closure", dict(kind=LOW, N=8192, closure=True), dict(resident=0, stream="closure", chunk=1)),
+    ("max_iter below the floor", dict(kind=LOW, N=8192, max_iter=5), dict(resident=0, first_stop=4)),
+    ("more than 64 columns", dict(kind=LOW, N=8192, c=70), dict(resident=0)),
+    ("too few compute units", dict(kind=LOW, N=8192, cus=32), dict(resident=0)),
+    ("batch-global stop rule over ranks", dict(kind=LOW, N=8192, global_rule=True), dict(resident=1, lean=0, chunk=1)),
+    ("preconditioner rank 40: beyond the resident kernels", dict(kind=LOW, N=8192, k=40, pre="q"), dict(resident=0, stream="two_pass")),
+    ("cfg4: Kronecker root form", dict(kind=KRON, N=65536, R=256, n2=256, B=128, kron_root=True, pre="q", const_pre=True,
+                                       diag_mode=_hip.LO_DIAG_CONST), dict(resident=0, stream="fused_kron", chunk=4)),
+    ("cfg4 without the Kronecker root form", dict(kind=KRON, N=65536, R=256, n2=256, B=128, pre="q", const_pre=True,
+                                                  diag_mode=_hip.LO_DIAG_CONST), dict(resident=0, stream="fused_q")),
+    ("Kronecker, three columns", dict(kind=KRON, N=65536, R=256, n2=256, B=128, c=3, pre="q"), dict(stream="two_pass")),
+    ("Kronecker 48 x 48: below the fused apply", dict(kind=KRON, N=2304, R=48, n2=48, B=2, pre="q"), dict(stream="two_pass")),
+    ("cfg5: dense, 17 columns", dict(kind=DENSE, N=16384, c=17, nt=16, B=8, pre="q"), dict(resident=0, stream="two_pass", first_stop=20)),
+    ("dense, one column, N = 16384: fused apply", dict(kind=DENSE, N=16384, B=8, pre="q"), dict(stream="fused_q")),
+    ("dense, unpreconditioned", dict(kind=DENSE, N=1000, B=1, pre=None), dict(resident=0, stream="none")),
+    ("closure operator", dict(kind=CB, N=8192, pre=None), dict(resident=0, chunk=1)),
+]
+
+
+@pytest.mark.parametrize("label,args,want", ENGINE_TABLE, ids=[t[0] for t in ENGINE_TABLE])
+def test_cg_engine_selection_table(label, args, want):
+    """Which engine `lo_cg_solve_f32` takes for which (kind, N, R, c, k, n_tridiag, preconditioner form, device size):
+    `lo_cg_plan_f32` is the pure function the solver executes (csrc/lo_cg.hip: cg_plan), so an eligibility edit that moves
+    a shape to a slower path shows up here, on a machine without a GPU."""
+    got = _plan(**args)
+    bad = {k: (got[k], v) for k, v in want.items() if got[k] != v}
+    assert not bad, f"{label}: (got, want) {bad}\nfull plan: {got}"

@@ -739,3 +739,76 @@ def test_solve_kron_iteration_pinned(tag, seed, n):
                              tolerance=0.0, max_iter=its)
     assert info.iterations == its
     assert max_rel_err_cols(x, g[f"x_pinned_{tag}"]) < 1e-4
+
+
+# ---------------------------------------------------------------- G23 / G24 (round 4: VERDICT r3 "parity soft spots")
+def _wc_case(tag):
+    seed, B, N, R, P = {"wc_nopre": (2301, 3, 1024, 8, 8), "wc_pre": (2311, 3, 2304, 32, 8)}[tag]
+    g = np.random.default_rng(seed)
+    C = (0.05 * g.standard_normal((B, N, R))).astype(np.float32)
+    d = (g.random((B, N)) + 1.5).astype(np.float32)
+    rhs = g.standard_normal((B, N, 1)).astype(np.float32)
+    Z, _ = cases.probes(seed + 1, B, N, P)
+    return C, d, rhs, Z, N
+
+
+def test_g23_tridiagonals_up_to_the_reference_divergence_index():
+    """The FULL fp32 tridiagonals, not a 2 x 2 corner: on the block where the reference's own fp32 run follows its fp64
+    run to 1e-4 (golden g23; that index is SHARP: the column has converged there and the next coefficient is a ratio
+    of rounding noise, off by > 1e-2) the oracle -- another valid fp32 rounding sequence of the same recurrence,
+    linear_cg.py:311-332 -- follows the fp64 run to 3e-4 up to one row before the reference's divergence index."""
+    from conftest import tridiag_block_err
+
+    g = load_golden("g23_tridiag_divergence_tight_logdet")
+    C, d, rhs = cases.lowrank_diag(141, 4, 512, 8, 5)
+    _, t_mat, info = orc.linear_cg(lambda v: orc.matvec_lowrank_diag(C, d, v), rhs, tolerance=1.0, n_tridiag=4)
+    assert info.matvecs == int(g["g1_matvecs_f64"]) == 22 and t_mat.shape == g["g1_t_mat_f64"].shape
+    err, k = tridiag_block_err(t_mat, g["g1_t_mat_f64"], g["g1_valid"], back_off=1)
+    assert k >= 9 and err < 3e-4, (err, k)
+    C, d, rhs = cases.lowrank_diag(411, 3, 2048, 16, 1)
+    Z, _ = cases.probes(412, 3, 2048, 8)
+    _, _, _, t_mat, _, _ = orc.inv_quad_logdet(lambda v: orc.matvec_lowrank_diag(C, d, v), orc.LowRankRowSource(C), d,
+                                               rhs, Z, tolerance=1e-4)
+    err, k = tridiag_block_err(t_mat, g["iql_lowrank_t_mat_f64"], g["iql_lowrank_valid"])
+    assert k == 2 and err < 1e-4, (err, k)  # (the fp64 recurrence decouples after two rows: converged)
+    Kd, d, rhs = cases.dense_diag(431, 2, 2048, 1)
+    Z, _ = cases.probes(432, 2, 2048, 4)
+    iq, ld, _, t_mat, _, _ = orc.inv_quad_logdet(lambda v: orc.matvec_dense_diag(Kd, d, v), orc.DenseRowSource(Kd), d,
+                                                 rhs, Z, tolerance=1e-4)
+    err, k = tridiag_block_err(t_mat, g["iql_dense_t_mat_f64"], g["iql_dense_valid"], back_off=1)
+    assert k >= 14 and err < 3e-4, (err, k)
+    assert np.allclose(ld, g["iql_dense_logdet_f64"], rtol=1e-4, atol=0)  # against the reference's fp64 value
+    assert np.allclose(iq[..., 0], g["iql_dense_inv_quad_f64"], rtol=1e-4, atol=0)
+
+
+@pytest.mark.parametrize("tag", ["wc_nopre", "wc_pre"])
+def test_g23_logdet_rtol_1e4_atol_0_on_well_conditioned_operators(tag):
+    """north_star's logdet bar with NO absolute slack: injected probes, spectrum of P^-1 A in [1, 4], |logdet| ~ 1e3 --
+    the reference's own fp32 and fp64 runs agree to 3e-7 there (make_golden.py g23), so 1e-4 relative is a real bar."""
+    from conftest import tridiag_block_err
+
+    g = load_golden("g23_tridiag_divergence_tight_logdet")
+    C, d, rhs, Z, N = _wc_case(tag)
+    iq, ld, solves, t_mat, info, pre = orc.inv_quad_logdet(
+        lambda v: orc.matvec_lowrank_diag(C, d, v), orc.LowRankRowSource(C), d, rhs, Z, tolerance=1e-4)
+    assert info.matvecs == int(g[f"{tag}_matvecs"]) == 22 and (pre is not None) == (tag == "wc_pre")
+    assert np.allclose(ld, g[f"{tag}_logdet"], rtol=1e-4, atol=0)
+    assert np.allclose(ld, g[f"{tag}_logdet_f64"], rtol=1e-4, atol=0)
+    assert np.allclose(iq[..., 0], g[f"{tag}_inv_quad"], rtol=1e-4, atol=0)
+    assert max_rel_err_cols(solves, g[f"{tag}_solves"]) < 1e-5
+    err, k = tridiag_block_err(t_mat, g[f"{tag}_t_mat_f64"], g[f"{tag}_valid"], back_off=1)
+    assert err < 3e-4 and k >= 4, (err, k)
+
+
+def test_g24_kronecker_256_iteration_pinned():
+    """cfg4 at its real factor size (256 (x) 256, N = 65536), the reference's iterate after exactly its 137 iterations:
+    the oracle reproduces it per column to 1e-4."""
+    g = load_golden("g24_kron256_iteration_pinned")
+    K1, K2, sig, rhs = cases.kron_factors(2401, 2, 256, 256, 1)
+    _check_inputs(g, K1, K2, sig, rhs)
+    its = int(g["iterations"])
+    d = np.broadcast_to(sig, (2, 65536)).copy()
+    x, info, pre = orc.solve(lambda v: orc.matvec_kron_diag(K1, K2, d, v), orc.KronRowSource(K1, K2), d, rhs,
+                             tolerance=0.0, max_iter=its)
+    assert info.iterations == its == 137
+    assert max_rel_err_cols(x, g["x_pinned"]) < 1e-4
