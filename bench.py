@@ -687,6 +687,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    # ---- validation BEFORE the timed region: one solve checked against the fp64 Woodbury closed form of the same systems
+    # (the exact solution; torch fp64 library ops as the CHECKER).  The kernels are bitwise reproducible, so this is the
+    # very result every timed step computes (asserted after the timed region).
+    res_check = K.cg_solve(desc, rhs, precond=pre, tolerance=TOL)
+    solve_rel_err = woodbury_fp64_rel_err(Cm, d, rhs, res_check.x)
+    x_check = res_check.x.clone()
     res = None
     for _ in range(args.warmup):
         res = step()
@@ -772,7 +778,8 @@ def main():
 
     # ---- accuracy of the timed solve: max_b ||x - x*|| / ||x*|| against the fp64 Woodbury closed form (the exact
     # solution of the same systems; torch fp64 library ops as the CHECKER, outside every timed region) ----
-    solve_rel_err = woodbury_fp64_rel_err(Cm, d, rhs, res.x)
+    timed_equals_checked = bool(torch.equal(res.x, x_check))  # the validated solve IS the timed one, bit for bit
+    del x_check
     # ---- BASELINE cfg4 / cfg5 at their full batch over the same ranks (strong scaling), same invocation ----
     strong = {}
     if use_dist and world > 1 and not os.environ.get("LO_BENCH_NO_STRONG"):
@@ -893,6 +900,7 @@ def main():
             "kernels": kernels,
             "final_mean_residual": res.mean_residual,
             "solve_rel_err": solve_rel_err,
+            "timed_result_bitwise_equals_checked_result": timed_equals_checked,
             "solve_rel_err_note": "max over the 512 members of ||x - x*|| / ||x*||, x* = fp64 Woodbury closed form of the "
                                   "same systems (north_star bar 1e-4); logdet rel-err with identical probes: "
                                   "cpu_baseline.parity_sample",

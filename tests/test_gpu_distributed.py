@@ -308,3 +308,135 @@ def test_two_host_threads_solving_on_two_streams_do_not_starve_each_other():
     assert not errs, errs
     assert bad == [0, 0]
     assert dt < 2.0, f"40 solves + 40 factorisations took {dt:.2f} s: resident kernels timed out against each other"
+
+
+# ---------------------------------------------------------------- two PROCESSES on the one GPU
+_TWO_PROC_WORKER = r'''
+import os, sys, json
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["LO_ROOT"]); sys.path.insert(0, os.path.join(os.environ["LO_ROOT"], "tests", "golden"))
+import cases
+from linear_operator_amd import distributed as D, kernels as K, settings
+from linear_operator_amd.operators import (AddedDiagLinearOperator, ConstantDiagLinearOperator, DiagLinearOperator,
+                                           KroneckerProductLinearOperator, LowRankRootLinearOperator)
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)                      # both ranks share the one GPU: RCCL refuses that, gloo carries the collectives
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+out = {}
+# (1) resident kernels of two processes at the same time: low-rank + diag, 96 members, sharded 48 / 48
+B, N, R = 96, 8192, 32
+C, d, rhs = cases.lowrank_diag(7101, B, N, R, 1)
+def lowrank(lo, hi):
+    return (AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C[lo:hi])), DiagLinearOperator(dev(d[lo:hi]))), dev(rhs[lo:hi]))
+with settings.cg_tolerance(1e-4):
+    dist.barrier()
+    xs = []
+    for rep in range(6):                      # repeated: the two processes' launches overlap in time
+        xs.append(D.sharded_solve_from_factory(lowrank, B, global_rule=True).cpu())
+    out["lowrank_repeatable"] = all(torch.equal(xs[0], x) for x in xs[1:])
+    torch.save(xs[0], os.path.join(os.environ["LO_OUT"], f"x_lowrank_{rank}.pt"))
+    out["lowrank_engine"] = K.cg_last_executed()
+# (2) the batch-global stopping rule far beyond the floor: Kronecker, members of very different difficulty
+Bk, n = 6, 32
+K1, K2, sig, rk = cases.kron_factors(2101, Bk, n, n, 1, sigma=1e-2)
+rk[:3] *= 1e-3
+def kron(lo, hi):
+    return (AddedDiagLinearOperator(KroneckerProductLinearOperator(dev(K1[lo:hi]), dev(K2[lo:hi])),
+                                    ConstantDiagLinearOperator(dev(sig[lo:hi]), n * n)), dev(rk[lo:hi]))
+its = []
+real = K.cg_solve
+def spy(*a, **kw):
+    r = real(*a, **kw); its.append(r.iterations); return r
+K.cg_solve = spy
+with settings.cg_tolerance(1e-3):
+    xk = D.sharded_solve_from_factory(kron, Bk, global_rule=True).cpu()
+K.cg_solve = real
+out["kron_iterations"] = its
+torch.save(xk, os.path.join(os.environ["LO_OUT"], f"x_kron_{rank}.pt"))
+json.dump(out, open(os.path.join(os.environ["LO_OUT"], f"out_{rank}.json"), "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_processes_share_one_gpu_with_the_global_rule(tmp_path):
+    """Two PROCESSES on this one GPU, each running the real HIP path of `sharded_solve_from_factory` on its shard with
+    `global_rule=True` (gloo carries the 3-double all-reduce and the final all-gather: RCCL refuses two ranks on one
+    device).  (1) Resident kernels launched by two processes at the same time must not starve each other into their
+    hand-off timeouts -- or, if the device cannot co-schedule them, the latch-off path must engage and the results must
+    still be right: either way the gathered solution is bit-identical to the unsharded HIP run of this process.
+    (2) The batch-global stopping rule: both processes execute exactly the unsharded iteration count."""
+    import json
+    import subprocess
+    import sys
+    import time
+
+    from conftest import ROOT
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LO_ROOT=ROOT, LO_OUT=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _TWO_PROC_WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    t0 = time.time()
+    logs = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(se)
+        assert p.returncode == 0, se[-3000:]
+    elapsed = time.time() - t0
+    outs = [json.load(open(tmp_path / f"out_{r}.json")) for r in range(2)]
+    # ---- unsharded HIP runs in this process
+    B, N, R = 96, 8192, 32
+    C, d, rhs = cases.lowrank_diag(7101, B, N, R, 1)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C)), DiagLinearOperator(dev(d)))
+    with settings.cg_tolerance(1e-4):
+        with D.global_stopping_rule(reducer=lambda v: v):  # the same engines as the sharded run (one rank: identity)
+            x_ref = A.solve(dev(rhs)).cpu()
+        x_plain = A.solve(dev(rhs)).cpu()  # the default path (one-launch kernel)
+    assert max_rel_err_cols(x_ref.numpy(), x_plain.numpy()) < 1e-5
+    for r in range(2):
+        x = torch.load(tmp_path / f"x_lowrank_{r}.pt")
+        assert outs[r]["lowrank_repeatable"]
+        assert outs[r]["lowrank_engine"]["resident"] and not outs[r]["lowrank_engine"]["lean"]
+        assert torch.equal(x, x_ref), f"rank {r}: sharded two-process result differs from the unsharded run"
+    timeouts = sum("timed out" in lg for lg in logs)
+    # co-scheduled resident kernels either both make progress (no timeout) or the latch engages ONCE per process
+    assert all(lg.count("timed out") <= 1 for lg in logs), logs
+    assert elapsed < 300, f"two processes took {elapsed:.0f} s: resident launches starve each other"
+    # ---- (2) batch-global rule
+    Bk, n = 6, 32
+    K1, K2, sig, rk = cases.kron_factors(2101, Bk, n, n, 1, sigma=1e-2)
+    rk[:3] *= 1e-3
+    Ak = AddedDiagLinearOperator(KroneckerProductLinearOperator(dev(K1), dev(K2)), ConstantDiagLinearOperator(dev(sig), n * n))
+    its = []
+    real = K.cg_solve
+
+    def spy(*a, **kw):
+        res = real(*a, **kw)
+        its.append(res.iterations)
+        return res
+
+    K.cg_solve = spy
+    try:
+        with settings.cg_tolerance(1e-3):
+            xk_ref = Ak.solve(dev(rk)).cpu()
+    finally:
+        K.cg_solve = real
+    assert outs[0]["kron_iterations"] == outs[1]["kron_iterations"] == its, (outs[0]["kron_iterations"], its)
+    for r in range(2):
+        xk = torch.load(tmp_path / f"x_kron_{r}.pt")
+        assert max_rel_err_cols(xk.numpy(), xk_ref.numpy()) < 1e-4
+    print(f"two processes on one GPU: {elapsed:.1f} s, hand-off timeouts seen: {timeouts}; engines {outs[0]['lowrank_engine']}")
