@@ -861,7 +861,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.rhs = rhs; a.B = B; a.N = (int)N;
     a.c = c; a.ab_rec = prm->n_tridiag ? d.oc_ab : nullptr;
     a.col0 = 0; a.ncols = c; a.RK = pre ? preR4 : 0; a.RCg = pl.R4;
-    a.F = nullptr; a.EF = nullptr;
+    a.F = nullptr; a.EF = nullptr; a.E = nullptr;
     a.iters = kfloor0 + 1;
     a.eps = prm->eps; a.stop_after = prm->stop_updating_after;
     a.x = d.x; a.r = d.r; a.p = d.p; a.z = d.z;
@@ -918,6 +918,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       lean_state(lean);
       a.F = oc_nopre ? nullptr : pre->F;
       a.EF = oc_nopre ? nullptr : pre->EF;
+      a.E = oc_nopre ? nullptr : pre->E;
       a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
       a.dbg = oc_dbg ? d.oc_dbg : nullptr;
       rc = onchip5_launch(pl.R4, a, oc_nwg, st);  // (d.oc_gbuf was cleared together with the control block)

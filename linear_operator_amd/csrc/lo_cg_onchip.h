@@ -19,6 +19,7 @@ struct OnchipArgs {
   int RCg;            // floats per row of C in HBM (third generation: 8, 16 or 32)
   const float* F;     // root-form preconditioner (lo_precond_desc.F / EF), [B, RC, RC] each, or nullptr
   const float* EF;
+  const float* E;     // C^T D^-1 C [B, RC, RC] (lo_precond_desc.E) or nullptr: enables the w-recurrence mode of k_cg_onchip5
   float* ab_rec;      // [iters, B, c, 2] masked alpha / beta per iteration (second generation, n_tridiag > 0) or nullptr
   int64_t B;
   int N, RW;          // rows per workgroup

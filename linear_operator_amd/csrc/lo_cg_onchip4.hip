@@ -377,18 +377,29 @@ int onchip4_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st)
 struct alignas(16) R5Post {
   float v[32];
   float t[32];
+  float w[32];  // (w-recurrence mode: this wave's copy of w = C^T (r / d) for the broadcast reads of the next F w)
   float alpha, beta, rn, pad;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int RC, int GW, bool MC>
+// MODE 0: one column, three passes over C per iteration.  MODE 1 ("MC"): several columns and / or recorded alpha, beta.
+// MODE 2 ("WR"): one column, no tridiagonals, w = C^T D^-1 r carried by RECURRENCE -- r' = r - alpha (C t + d o p) with
+// t = C^T p gives  w' = w - alpha (E t + t),  E = C^T D^-1 C  (tests/proto/proto_w_recurrence.py): the third pass over the
+// rows of C and 32 of the 35 values of the per-iteration all-reduce disappear; the rows still deliver the three scalars
+// {sum r^2, sum r^2 / d, sum r o p}.  Identical in exact arithmetic; solutions as close to the fp64 iteration as the
+// three-pass form (1.5e-6 vs 1.7e-6 at the headline spectrum), but the CG COEFFICIENTS of the converging iterations
+// follow the fp64 ones to 1e-3 instead of 5e-6 -- so the mode is never used when tridiagonals are recorded.
+template <int RC, int GW, int MODE>
 __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipArgs a) {
+  constexpr bool MC = MODE == 1;
+  constexpr bool WR = MODE == 2;
   constexpr int FLD = RC + 4;  // LDS row stride of F / EF (16-byte aligned rows, conflict-free float4 reads per lane)
   __shared__ R4Shared sh;
   __shared__ R5Post post[R4_WAVES];
   __shared__ __attribute__((aligned(16))) float f_s[RC * FLD];
   __shared__ __attribute__((aligned(16))) float ef_s[RC * FLD];
+  __shared__ __attribute__((aligned(16))) float e_s[WR ? RC * FLD : 4];
   __shared__ float x_s[R4_ROWS], d_s[R4_ROWS], dinv_s[R4_ROWS];
   __shared__ float4 stage_s[R4_WAVES * 64 * (RC / 4)];  // per-wave transposition window of the member load
   const int wg = blockIdx.x;
@@ -461,15 +472,17 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
       diq[q] = *ip;
     }
     constexpr int NF = (RC * RC + R4_TPB - 1) / R4_TPB;  // F, EF -> LDS (zero without a preconditioner)
-    float fv[NF], ev[NF];
+    float fv[NF], ev[NF], e0v[WR ? NF : 1];
     {
       const float* Fp = pre ? a.F + (size_t)b * RC * RC : a.C;
       const float* Ep = pre ? a.EF + (size_t)b * RC * RC : a.C;
+      const float* E0p = (WR && pre) ? a.E + (size_t)b * RC * RC : a.C;
 #pragma unroll
       for (int u = 0; u < NF; ++u) {
         const int e = min(tl + R4_TPB * u, RC * RC - 1);
         fv[u] = Fp[e];
         ev[u] = Ep[e];
+        if (WR) e0v[u] = E0p[e];
       }
     }
 #pragma unroll
@@ -503,6 +516,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
         const int i = e / RC, j = e % RC;
         f_s[i * FLD + j] = pre ? fv[u] : 0.f;
         ef_s[i * FLD + j] = pre ? ev[u] : 0.f;
+        if (WR) e_s[i * FLD + j] = pre ? e0v[u] : 0.f;
       }
     }
     __syncthreads();
@@ -542,6 +556,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
       bool rhs_zero = false;
       // first-wave state of the recurrences (uniform scalars replicated in the lanes; t_old = C^T p_old in lane j < RC)
       float t_old = 0.f, tt_old = 0.f, dpp = 0.f, rz = 0.f, alpha = 0.f, beta = 0.f, rn = 0.f;
+      float w_reg = 0.f;  // (WR: w_j in lane j of both halves, carried by the recurrence)
       bool conv = false;
       // one reduction: w = C^T (r / d), s1, s2, rp; then (first wave) the small algebra; k = -1 marks the initial one
       auto reduce_and_post = [&](int k) {
@@ -563,24 +578,35 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
         }
         long long cr0 = 0;
         if (g.dbg && t == 0) cr0 = wall_clock64();
-        f32x2 wp[RC / 2];  // column partials of w, two columns per instruction
-#pragma unroll
-        for (int j = 0; j < RC / 2; ++j) {
-          f32x2 v = Cr[0][j] * f32x2{rd[0], rd[0]};
-#pragma unroll
-          for (int q = 1; q < R4_NR; ++q) v = __builtin_elementwise_fma(Cr[q][j], f32x2{rd[q], rd[q]}, v);
-          wp[j] = v;
-        }
         // the member's LAST reduction also carries the next member of the group (dynamic hand-out: drawn by the
         // group's first workgroup, exact below 2^24) -- no all-reduce of its own at the end of the member
         const bool draws = (k == a.iters - 1) && (col == clast - 1);
         sc[3] = (draws && wig == 0 && t == 0) ? (float)(ngroups + drawn) : 0.f;  // (requested ahead, see draw())
-        const auto gen = [&](int c) { return (c & 1) ? wp[c >> 1].y : wp[c >> 1].x; };
-        if (draws) {  // (two call sites: the scalar count stays a compile-time constant in the common one)
-          r4_allreduce<GW, RC>(sh, gen, sc, 4, g);
-          b_next = (int64_t)sh.res[RC + 3];
+        const bool wrec = WR && k >= 0;  // w comes from the recurrence: only the scalars are reduced
+        const int so = wrec ? 0 : RC;    // where the scalars start in sh.res
+        if (wrec) {
+          if (draws) {  // (two call sites: the scalar count stays a compile-time constant in the common one)
+            r4_allreduce_scalars4<GW, 4>(sh, sc, g);
+            b_next = (int64_t)sh.res[3];
+          } else {
+            r4_allreduce_scalars4<GW, 3>(sh, sc, g);
+          }
         } else {
-          r4_allreduce<GW, RC>(sh, gen, sc, 3, g);
+          f32x2 wp[RC / 2];  // column partials of w, two columns per instruction
+#pragma unroll
+          for (int j = 0; j < RC / 2; ++j) {
+            f32x2 v = Cr[0][j] * f32x2{rd[0], rd[0]};
+#pragma unroll
+            for (int q = 1; q < R4_NR; ++q) v = __builtin_elementwise_fma(Cr[q][j], f32x2{rd[q], rd[q]}, v);
+            wp[j] = v;
+          }
+          const auto gen = [&](int c) { return (c & 1) ? wp[c >> 1].y : wp[c >> 1].x; };
+          if (draws) {
+            r4_allreduce<GW, RC>(sh, gen, sc, 4, g);
+            b_next = (int64_t)sh.res[RC + 3];
+          } else {
+            r4_allreduce<GW, RC>(sh, gen, sc, 3, g);
+          }
         }
         if (g.dbg && t == 0) g.dbg[9] += wall_clock64() - cr0;  // partials of w + reduce-scatter + group all-reduce
         long long cp0 = 0;
@@ -590,11 +616,12 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
           float mv = 0.f;  // lanes 0-31: (F w)_j, lanes 32-63: (E F w)_j
           if (pre && j < RC) {
             const float* row = (lane < 32 ? f_s : ef_s) + j * FLD;
+            const float* wsrc = wrec ? post[t >> 6].w : sh.res;  // (this wave's own copy / the all-reduce's result)
             f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < RC; q += 4) {
               const float4 m4 = *reinterpret_cast<const float4*>(row + q);
-              const float4 w4 = *reinterpret_cast<const float4*>(&sh.res[q]);
+              const float4 w4 = *reinterpret_cast<const float4*>(&wsrc[q]);
               a01 = __builtin_elementwise_fma(f32x2{m4.x, m4.y}, f32x2{w4.x, w4.y}, a01);
               a23 = __builtin_elementwise_fma(f32x2{m4.z, m4.w}, f32x2{w4.z, w4.w}, a23);
             }
@@ -604,7 +631,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
           // second = the upper-half lane's: every lane gets (v_j, (E v)_j) with one instruction
           float sc1 = 1.0f, sc2 = 1.0f;  // scaling of the raw first reduction (k < 0), 1 afterwards
           if (k < 0) {
-            nrm = sqrtf(sh.res[RC]);                         // rhs.norm(2, dim=-2)          :177
+            nrm = sqrtf(sh.res[so]);                         // rhs.norm(2, dim=-2)          :177
             rhs_zero = nrm < a.eps;                          // :178
             if (rhs_zero) nrm = 1.0f;                        // :179
             inv0 = 1.0f / nrm;
@@ -614,9 +641,9 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
           mv *= sc1;
           const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mv), __float_as_uint(mv), false, false);
           const float vj = __uint_as_float(sw[0]), evj = __uint_as_float(sw[1]);
-          const float wj = (j < RC) ? sh.res[j] * sc1 : 0.f;
+          const float wj = wrec ? w_reg : ((j < RC) ? sh.res[j] * sc1 : 0.f);
           const bool own = lane < 32 && j < RC;
-          const float s1 = sh.res[RC] * sc2, s2 = sh.res[RC + 1] * sc2, rp = sh.res[RC + 2];
+          const float s1 = sh.res[so] * sc2, s2 = sh.res[so + 1] * sc2, rp = sh.res[so + 2];
           const float zj = wj - evj;                          // (C^T z)_j
           // five independent sums (their butterflies interleave); |C^T p_new|^2 from the expansion so that it does not
           // wait for beta: |zc + beta t|^2 = |zc|^2 + 2 beta zc.t + beta^2 |t|^2
@@ -659,6 +686,30 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
           if (own) {
             mine.v[j] = vj;
             mine.t[j] = t_old;
+          }
+          if (WR) {
+            // w of the NEXT reduction by recurrence: r' = r - alpha (C t + d o p)  =>  w' = w - alpha (E t + t).
+            // (E t)_j: each half-wave sums half of row j of E against the t this wave has just written (LDS operations of
+            // a wave execute in order), the halves are joined by one v_permlane32_swap
+            __builtin_amdgcn_wave_barrier();
+            float et = 0.f;
+            if (pre && j < RC) {
+              const int q0 = (lane < 32) ? 0 : RC / 2;
+              const float* row = e_s + j * FLD + q0;
+              f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+              for (int q = 0; q < RC / 2; q += 4) {
+                const float4 m4 = *reinterpret_cast<const float4*>(row + q);
+                const float4 t4 = *reinterpret_cast<const float4*>(&mine.t[q0 + q]);
+                a01 = __builtin_elementwise_fma(f32x2{m4.x, m4.y}, f32x2{t4.x, t4.y}, a01);
+                a23 = __builtin_elementwise_fma(f32x2{m4.z, m4.w}, f32x2{t4.z, t4.w}, a23);
+              }
+              et = (a01.x + a01.y) + (a23.x + a23.y);
+            }
+            const auto se = __builtin_amdgcn_permlane32_swap(__float_as_uint(et), __float_as_uint(et), false, false);
+            const float etj = __uint_as_float(se[0]) + __uint_as_float(se[1]);
+            w_reg = fmaf(-alpha, etj + t_old, wj);
+            if (own) mine.w[j] = w_reg;
           }
         }
         if (g.dbg && t == 0) g.dbg[10] += wall_clock64() - cp0;  // small algebra
@@ -755,15 +806,15 @@ bool onchip5_eligible(int RC, int64_t N, int64_t c) {
   return (RC == 8 || RC == 16 || RC == 32) && c >= 1 && c <= 64 && N >= 256 && N <= (int64_t)64 * R4_ROWS;
 }
 
-template <int RC, int GW, bool MC>
+template <int RC, int GW, int MODE>
 static int onchip5_go(const OnchipArgs& a, int nwg, hipStream_t st) {
   int per_cu = 0;
-  if (LO_OCCUPANCY_CACHED(per_cu, (k_cg_onchip5<RC, GW, MC>), R4_TPB, 0) != hipSuccess ||
+  if (LO_OCCUPANCY_CACHED(per_cu, (k_cg_onchip5<RC, GW, MODE>), R4_TPB, 0) != hipSuccess ||
       per_cu < 2)
     return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("cg_onchip", st);
   ResidentLaunch guard(st);
-  hipLaunchKernelGGL((k_cg_onchip5<RC, GW, MC>), dim3(2 * nwg), dim3(R4_TPB), 0, st, a);
+  hipLaunchKernelGGL((k_cg_onchip5<RC, GW, MODE>), dim3(2 * nwg), dim3(R4_TPB), 0, st, a);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
@@ -772,7 +823,16 @@ static int onchip5_go(const OnchipArgs& a, int nwg, hipStream_t st) {
 // a.F / a.EF [B, RC, RC] (or nullptr: no preconditioner).  Same launch geometry as onchip4_launch.
 int onchip5_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st) {
   const bool mc = a.c > 1 || a.ab_rec != nullptr;
-#define LO_O5_G(C_, G_) (mc ? onchip5_go<C_, G_, true>(a, nwg, st) : onchip5_go<C_, G_, false>(a, nwg, st))
+  // one column without recorded coefficients and the preconditioner's E = C^T D^-1 C at hand: w by recurrence
+  // (LO_OC_NO_WREC restores the three-pass iteration; the tests compare the two)
+  // ONLY for the result-only first pass (a.x == nullptr): the recurrence is as accurate as the three-pass iteration
+  // while CG converges, but on ill-conditioned systems (diagonals ~1e-3: E ~ 1e5) w stagnates at 1e-4 of its start --
+  // such solves miss the stop rule at the floor (evaluated on sum r^2 of the ACTUAL rows), and their repeat with the
+  // continuation state runs the three-pass iteration.
+  const bool wr = !mc && a.F && a.EF && a.E && !a.x && !getenv("LO_OC_NO_WREC");
+#define LO_O5_G(C_, G_)                                \
+  (mc ? onchip5_go<C_, G_, 1>(a, nwg, st)              \
+      : (wr ? onchip5_go<C_, G_, 2>(a, nwg, st) : onchip5_go<C_, G_, 0>(a, nwg, st)))
 #define LO_O5(C_)                                                                                    \
   switch (a.GW) {                                                                                    \
     case 1: return LO_O5_G(C_, 1);                                                                   \

@@ -243,6 +243,20 @@ __device__ __forceinline__ void r4_allreduce(R4Shared& sh, Gen gen, const float*
   r4_allreduce_t<GW, n>(sh, gen, scal, ns, g, (int)threadIdx.x);
 }
 
+// the same with a compile-time count (the butterflies of the NS scalars interleave)
+template <int GW, int NS>
+__device__ __forceinline__ void r4_allreduce_scalars4(R4Shared& sh, const float* scal, R4Group& g) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  float sv[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) sv[j] = wave_sum_fast(scal[j]);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) sh.red[wave][j] = sv[j];
+  }
+  r4_group_sum<GW>(sh, NS, g);
+}
+
 template <int GW>
 __device__ __forceinline__ void r4_allreduce_scalars(R4Shared& sh, const float* scal, int ns, R4Group& g) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;

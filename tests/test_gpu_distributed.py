@@ -411,7 +411,16 @@ def test_two_processes_share_one_gpu_with_the_global_rule(tmp_path):
         x = torch.load(tmp_path / f"x_lowrank_{r}.pt")
         assert outs[r]["lowrank_repeatable"]
         assert outs[r]["lowrank_engine"]["resident"] and not outs[r]["lowrank_engine"]["lean"]
-        assert torch.equal(x, x_ref), f"rank {r}: sharded two-process result differs from the unsharded run"
+        # (a shard of 48 and the batch of 96 split their reductions differently in the streaming build kernels: equal up
+        # to summation order; the SAME shard solved alone in this process must agree bit for bit -- below)
+        assert max_rel_err_cols(x.numpy(), x_ref.numpy()) < 2e-6
+    x_two = torch.load(tmp_path / "x_lowrank_0.pt")
+    assert torch.equal(x_two, torch.load(tmp_path / "x_lowrank_1.pt"))
+    for lo, hi in ((0, 48), (48, 96)):  # each rank's shard, solved alone here: what running next to another process changed
+        As = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C[lo:hi])), DiagLinearOperator(dev(d[lo:hi])))
+        with settings.cg_tolerance(1e-4), D.global_stopping_rule(reducer=lambda v: v):
+            xs = As.solve(dev(rhs[lo:hi])).cpu()
+        assert torch.equal(xs, x_two[lo:hi]), f"shard [{lo}, {hi}): two concurrent processes changed the result"
     timeouts = sum("timed out" in lg for lg in logs)
     # co-scheduled resident kernels either both make progress (no timeout) or the latch engages ONCE per process
     assert all(lg.count("timed out") <= 1 for lg in logs), logs

@@ -251,3 +251,76 @@ def test_the_plan_is_what_the_solver_executes(kind, N, R, c, nt, form):
         assert res.iterations == plan["resident_iterations"] + ran["streaming_iterations"] or ran["streaming_iterations"] > 0
     else:
         assert ran["streaming_iterations"] >= res.iterations
+
+
+# ---------------------------------------------------------------- w by recurrence (k_cg_onchip5 MODE 2)
+def _woodbury_exact(C, d, rhs):
+    C64, d64, r64 = (torch.from_numpy(a).double().cuda() for a in (C, d, rhs))
+    Cd = C64 / d64.unsqueeze(-1)
+    cap = torch.eye(C64.shape[-1], dtype=torch.float64, device="cuda") + C64.mT @ Cd
+    return (r64 / d64.unsqueeze(-1) - Cd @ torch.linalg.solve(cap, C64.mT @ (r64 / d64.unsqueeze(-1)))).cpu().numpy()
+
+
+@pytest.mark.parametrize("N,R,B,dscale,doff,cscale", [
+    (8192, 32, 40, 1.0, 0.5, 1.0),      # the headline spectrum
+    (8192, 32, 24, 0.1, 0.01, 1.0),     # small diagonals
+    (2048, 32, 24, 0.01, 0.001, 1.0),
+    (4096, 16, 24, 1.0, 0.05, 1.0),
+    (5000, 8, 24, 1.0, 0.5, 1.0),       # rank <= pivots: P = A
+    (8192, 32, 24, 1.0, 0.5, 10.0),     # strong low-rank part
+    (16384, 32, 12, 1.0, 0.5, 1.0),     # groups of 16
+    (1024, 32, 24, 10.0, 0.5, 1.0),     # a group of one
+    (40000, 32, 6, 1.0, 0.5, 1.0),      # groups of 64
+])
+def test_w_recurrence_mode_against_three_pass_oracle_and_exact_solution(N, R, B, dscale, doff, cscale, monkeypatch):
+    """Single-column solves without tridiagonals carry w = C^T D^-1 r by recurrence (k_cg_onchip5 MODE 2; numerics
+    prototype tests/proto/proto_w_recurrence.py).  Same iteration count as the three-pass iteration (LO_OC_NO_WREC) and the
+    oracle; solution within 1e-4 per column of the oracle's (north_star's bar) and as close to the EXACT solution (fp64
+    Woodbury) as the three-pass iteration is, within a factor of 3."""
+    C, d, rhs = cases.lowrank_diag(8800 + R, B, N, R, 1)
+    C = (C * cscale).astype(np.float32)
+    d = ((d - 0.5) * dscale + doff).astype(np.float32)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    L, perm = K.pivoted_cholesky(desc, 15)
+    pre = K.precond_build(L, dev(d), constant_diag=False, root=desc.A0, perm=perm)
+    assert pre.E is not None
+    K._hip.prof_enable(True)
+    res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+    torch.cuda.synchronize()
+    prof = K._hip.prof_report()
+    K._hip.prof_enable(False)
+    assert "cg_onchip" in prof and K.cg_last_executed()["serial_engine"] == "root"
+    monkeypatch.setenv("LO_OC_NO_WREC", "1")
+    ref = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+    monkeypatch.delenv("LO_OC_NO_WREC")
+    assert res.iterations == ref.iterations and res.tolerance_reached == ref.tolerance_reached
+    if K.cg_last_executed()["streaming_iterations"] == 0:  # (stop at the floor: the w-recurrence result stands)
+        assert not torch.equal(res.x, ref.x), "the two modes gave identical bits: the switch does not switch"
+    exact = _woodbury_exact(C, d, rhs)
+    e_wr, e_3p = max_rel_err_cols(host(res.x), exact), max_rel_err_cols(host(ref.x), exact)
+    # (the ill-conditioned cases miss the stop rule at the floor: the w-recurrence pass is discarded, the three-pass kernel
+    #  repeats it and CG continues -- the very same bits as the reference run; their distance from the EXACT solution is
+    #  tolerance x condition number, for both)
+    assert e_wr < 3 * e_3p + 1e-6 and (e_wr < 1e-4 or e_wr == e_3p), (e_wr, e_3p)
+    sub = slice(0, 3)
+    Lo, _ = orc.pivoted_cholesky(orc.LowRankRowSource(C[sub]), 15)
+    xo, _, info = orc.linear_cg(lambda v: orc.matvec_lowrank_diag(C[sub], d[sub], v), rhs[sub], tolerance=1e-4,
+                                preconditioner=orc.Preconditioner(Lo, d[sub]).apply)
+    assert max_rel_err_cols(host(res.x)[sub], xo) < (1e-4 if e_3p < 1e-5 else 2e-3)
+    res2 = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+    assert torch.equal(res.x, res2.x)  # bitwise reproducible
+
+
+def test_w_recurrence_mode_continues_on_the_streaming_engine_when_the_floor_is_not_enough():
+    """Tolerance far below what 11 iterations reach with a weak (rank-2) preconditioner: the result-only first pass (w by
+    recurrence) misses the stop rule, is repeated by the three-pass kernel WITH the state, and the streaming engine
+    continues from its x / r / p / z."""
+    B, N, R = 12, 8192, 32
+    C, d, rhs = cases.lowrank_diag(8899, B, N, R, 1)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    L, perm = K.pivoted_cholesky(desc, 2)
+    pre = K.precond_build(L, dev(d), constant_diag=False, root=desc.A0, perm=perm)
+    res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-6, max_iter=200)
+    ran = K.cg_last_executed()
+    assert ran["resident"] and ran["streaming_iterations"] > 0 and res.tolerance_reached
+    assert max_rel_err_cols(host(res.x), _woodbury_exact(C, d, rhs)) < 1e-4
