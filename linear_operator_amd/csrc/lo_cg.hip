@@ -871,7 +871,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.rhs_norm = d.rhs_norm; a.rz = d.rz; a.alpha = d.alpha; a.beta = d.beta; a.resid_norm = d.resid_norm;
     a.rhs_is_zero = d.rhs_is_zero; a.has_conv = d.has_conv;
     a.resid_rec = d.oc_resid; a.init_conv = d.oc_init_conv; a.err = d.oc_err;
-    a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
+    a.allow_l2_handoff = onchip_l2_handoff_allowed();
     a.prefetch = getenv("LO_OC_NO_PREFETCH") ? 0 : 1;
     // LO_OC_DEBUG=<member index to time> (serial-column kernels), LO_LS_DEBUG=<member> (lockstep kernel)
     const bool ls_dbg = getenv("LO_LS_DEBUG") != nullptr && B >= 8;

@@ -28,6 +28,8 @@
 #include <stdlib.h>
 
 #include "lo_device.h"
+#include <string.h>
+
 #include "lo_internal.h"
 #include "lo_cg_onchip.h"
 
@@ -452,6 +454,24 @@ ResidentLaunch::ResidentLaunch(hipStream_t st) {
 }
 
 ResidentLaunch::~ResidentLaunch() { g_res_mu.unlock(); }
+
+// The same-XCD hand-off publishes granules with WORKGROUP-scope stores that other workgroups of the XCD read through the
+// shared L2: outside the HIP memory model, correct only where a CU's vector L1 is write-through into the XCD's L2.  That
+// holds on gfx950 (verified on MI355X: tools/fuzz_resident.py, the GPU test suite) -- so the path is OPT-IN per
+// verified architecture string; anywhere else (and with LO_OC_NO_L2_HANDOFF) every granule is an agent-scope store.
+// Cost of the agent-scope stores on MI355X: profiles/r04/l2_handoff_cost.txt.
+int onchip_l2_handoff_allowed() {
+  if (getenv("LO_OC_NO_L2_HANDOFF")) return 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  static int verified[64] = {0};  // 0 unknown, 1 yes, 2 no
+  if (verified[dev] == 0) {
+    hipDeviceProp_t prop;
+    verified[dev] = 2;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) verified[dev] = 1;
+  }
+  return verified[dev] == 1 ? 1 : 0;
+}
 
 int onchip_num_workgroups() {
   int dev = 0;

@@ -583,13 +583,23 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
         const bool draws = (k == a.iters - 1) && (col == clast - 1);
         sc[3] = (draws && wig == 0 && t == 0) ? (float)(ngroups + drawn) : 0.f;  // (requested ahead, see draw())
         const bool wrec = WR && k >= 0;  // w comes from the recurrence: only the scalars are reduced
-        const int so = wrec ? 0 : RC;    // where the scalars start in sh.res
+        float tot[4] = {0.f, 0.f, 0.f, 0.f};  // the reduced scalars s1 | s2 | rp | (hand-out)
         if (wrec) {
-          if (draws) {  // (two call sites: the scalar count stays a compile-time constant in the common one)
-            r4_allreduce_scalars4<GW, 4>(sh, sc, g);
-            b_next = (int64_t)sh.res[3];
+          if constexpr (GW <= 16) {  // one barrier, the totals come back in registers
+            if (draws) {  // (two call sites: the scalar count stays a compile-time constant in the common one)
+              r4_allreduce_small<GW, 4>(sh, sc, tot, g);
+              b_next = (int64_t)tot[3];
+            } else {
+              r4_allreduce_small<GW, 3>(sh, sc, tot, g);
+            }
           } else {
-            r4_allreduce_scalars4<GW, 3>(sh, sc, g);
+            if (draws) {
+              r4_allreduce_scalars4<GW, 4>(sh, sc, g);
+              b_next = (int64_t)sh.res[3];
+            } else {
+              r4_allreduce_scalars4<GW, 3>(sh, sc, g);
+            }
+            tot[0] = sh.res[0]; tot[1] = sh.res[1]; tot[2] = sh.res[2];
           }
         } else {
           f32x2 wp[RC / 2];  // column partials of w, two columns per instruction
@@ -607,6 +617,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
           } else {
             r4_allreduce<GW, RC>(sh, gen, sc, 3, g);
           }
+          tot[0] = sh.res[RC]; tot[1] = sh.res[RC + 1]; tot[2] = sh.res[RC + 2];
         }
         if (g.dbg && t == 0) g.dbg[9] += wall_clock64() - cr0;  // partials of w + reduce-scatter + group all-reduce
         long long cp0 = 0;
@@ -631,7 +642,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
           // second = the upper-half lane's: every lane gets (v_j, (E v)_j) with one instruction
           float sc1 = 1.0f, sc2 = 1.0f;  // scaling of the raw first reduction (k < 0), 1 afterwards
           if (k < 0) {
-            nrm = sqrtf(sh.res[so]);                         // rhs.norm(2, dim=-2)          :177
+            nrm = sqrtf(tot[0]);                             // rhs.norm(2, dim=-2)          :177
             rhs_zero = nrm < a.eps;                          // :178
             if (rhs_zero) nrm = 1.0f;                        // :179
             inv0 = 1.0f / nrm;
@@ -643,7 +654,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
           const float vj = __uint_as_float(sw[0]), evj = __uint_as_float(sw[1]);
           const float wj = wrec ? w_reg : ((j < RC) ? sh.res[j] * sc1 : 0.f);
           const bool own = lane < 32 && j < RC;
-          const float s1 = sh.res[so] * sc2, s2 = sh.res[so + 1] * sc2, rp = sh.res[so + 2];
+          const float s1 = tot[0] * sc2, s2 = tot[1] * sc2, rp = tot[2];
           const float zj = wj - evj;                          // (C^T z)_j
           // five independent sums (their butterflies interleave); |C^T p_new|^2 from the expansion so that it does not
           // wait for beta: |zc + beta t|^2 = |zc|^2 + 2 beta zc.t + beta^2 |t|^2

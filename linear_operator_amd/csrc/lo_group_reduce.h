@@ -243,6 +243,56 @@ __device__ __forceinline__ void r4_allreduce(R4Shared& sh, Gen gen, const float*
   r4_allreduce_t<GW, n>(sh, gen, scal, ns, g, (int)threadIdx.x);
 }
 
+// All-reduce of NS <= 4 scalars over a group of GW <= 16 workgroups with ONE barrier and no LDS round trip for the
+// result: every wave sums the four wave partials itself (LDS broadcast reads), the first wave publishes the workgroup's
+// granules, and EVERY wave polls the group's GW x NS granules with one granule per lane (lane = 4 w + j) and sums over
+// the workgroups with the fixed xor butterflies over the lane bits 2.. -- the same tree in every wave of every
+// workgroup, so the totals are bitwise identical everywhere.  The totals come back in registers (wave-uniform), the
+// second barrier and the sh.res write / read of r4_group_sum are gone.  The wave partials are double-buffered by the
+// phase parity (sh.red[wave][4 parity + j]): a wave can only write parity p again after the barrier of the phase in
+// between, which every wave passes after it has read its values of parity p.
+template <int GW, int NS>
+__device__ __forceinline__ void r4_allreduce_small_t(R4Shared& sh, const float* scal, float* out, R4Group& g,
+                                                     const int t) {
+  static_assert(GW <= 16 && NS <= 4, "one granule per lane");
+  const int lane = t & 63, wave = t >> 6;
+  const unsigned tag = ++g.tag;
+  const int par = (int)(tag & 1u);
+  float sv[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) sv[j] = wave_sum_fast(scal[j]);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) sh.red[wave][4 * par + j] = sv[j];
+  }
+  __syncthreads();
+  const int j = lane & 3, w = lane >> 2;
+  float s = 0.f;
+  if (j < NS) {
+#pragma unroll
+    for (int q = 0; q < R4_WAVES; ++q) s += sh.red[q][4 * par + j];  // fixed order, the same bits in every wave
+  }
+  float v = 0.f;
+  if constexpr (GW == 1) {
+    v = (w == 0) ? s : 0.f;  // a group of one: nothing to publish or to wait for
+  } else {
+    unsigned long long* slot = g.gslot + (size_t)par * GW * R4_SLOT;
+    if (wave == 0 && lane < NS) pf_store(g, tag, slot + (size_t)g.wig * R4_SLOT + lane, s);
+    v = pf_wait(g, tag, slot + (size_t)w * R4_SLOT + j, w < GW && j < NS);
+  }
+  if constexpr (GW > 1) v = bfly_add<4>(v);
+  if constexpr (GW > 2) v = bfly_add<8>(v);
+  if constexpr (GW > 4) v = bfly_add<16>(v);
+  if constexpr (GW > 8) v = bfly_add<32>(v);
+#pragma unroll
+  for (int q = 0; q < NS; ++q) out[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), q));
+}
+
+template <int GW, int NS>
+__device__ __forceinline__ void r4_allreduce_small(R4Shared& sh, const float* scal, float* out, R4Group& g) {
+  r4_allreduce_small_t<GW, NS>(sh, scal, out, g, (int)threadIdx.x);
+}
+
 // the same with a compile-time count (the butterflies of the NS scalars interleave)
 template <int GW, int NS>
 __device__ __forceinline__ void r4_allreduce_scalars4(R4Shared& sh, const float* scal, R4Group& g) {

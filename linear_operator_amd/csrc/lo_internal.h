@@ -207,6 +207,7 @@ struct OnchipArgs;
 size_t onchip_gbuf_bytes(int ngroups);
 bool onchip_eligible(int RC, int RK, int64_t N, int64_t c);
 int onchip_num_workgroups();
+int onchip_l2_handoff_allowed();  // same-XCD plain-store hand-off: verified architectures only (lo_cg_onchip.hip)
 bool onchip4_eligible(int RC, int RK, int64_t N, int64_t c);  // lo_cg_onchip4.hip
 int onchip4_group_size(int64_t N);
 int onchip5_group_size(int64_t N);

@@ -877,7 +877,7 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   a.swaps = l.swaps;
   a.gbuf = l.gbuf;
   a.err = l.err;
-  a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
+  a.allow_l2_handoff = onchip_l2_handoff_allowed();
   const bool debug = getenv("LO_OC_DEBUG") != nullptr;
   a.dbg = debug ? l.dbg : nullptr;
   if (debug) LO_HIP_CHECK(hipMemsetAsync(l.dbg, 0, 12 * sizeof(long long), st));

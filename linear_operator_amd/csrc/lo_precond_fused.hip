@@ -582,7 +582,7 @@ int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, floa
   if (kron8) GW = N <= 16 * (int64_t)2048 ? 16 : 32;
   if (kron) a.RW = (int)(((N + (int64_t)GW * 256 - 1) / ((int64_t)GW * 256)) * 256);
   a.gbuf = gbuf; a.err = err; a.next_member = next_member; a.stop = stop;
-  a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
+  a.allow_l2_handoff = onchip_l2_handoff_allowed();
   // next_member: base of the per-launch counters; launch: index of this launch (iter_ptr: read on the device instead)
   const unsigned long long base = (unsigned long long)launch * (unsigned long long)(B + 2);
   if ((unsigned long long)(max_launch + 1) * (unsigned long long)(B + 2) >= 0xffff0000ull) return LO_ERR_UNSUPPORTED;

@@ -134,6 +134,9 @@ int lo_solve_fused_supported(const lo_op_desc* op, int32_t rank, const lo_cg_par
   if (rank < 1 || rank > FU_MAXRANK || rank > op->N) return 0;
   if (op->N < 256 || op->N > (int64_t)8 * R4_ROWS || op->B < 1 || op->B >= (1 << 24) - 1024) return 0;
   if (prm->c < 1 || prm->c > 8 || prm->n_tridiag != 0 || prm->stop_reduce) return 0;
+  // (debug switch of the w-recurrence: the single-column instantiation of this kernel always carries w by recurrence,
+  //  like k_cg_onchip5 MODE 2 -- with the switch set, single-column solves take the three-launch path)
+  if (prm->c == 1 && getenv("LO_OC_NO_WREC")) return 0;
   const int fmi = prm->floor_max_iter > 0 ? prm->floor_max_iter : prm->max_iter;
   if (prm->max_iter < 11 || fmi < 11) return 0;
   const int nwg = onchip_num_workgroups();
@@ -175,7 +178,7 @@ int lo_solve_fused_f32(const lo_op_desc* op, int32_t rank, float error_tol, cons
   a.resid_rec = l.resid_rec; a.init_conv = l.init_conv;
   a.err = l.ints; a.flags = l.ints + 1; a.next_member = l.ints + 2;
   a.pgbuf = l.pgbuf; a.egbuf = l.egbuf; a.cgbuf = l.cgbuf;
-  a.allow_l2_handoff = getenv("LO_OC_NO_L2_HANDOFF") ? 0 : 1;
+  a.allow_l2_handoff = onchip_l2_handoff_allowed();
   const bool debug = getenv("LO_FU_DEBUG") != nullptr && B >= 8;
   a.dbg = debug ? l.dbg : nullptr;
   a.dbg_member = debug ? atoi(getenv("LO_FU_DEBUG")) : 0;

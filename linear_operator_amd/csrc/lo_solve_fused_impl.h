@@ -180,6 +180,7 @@ __device__ __forceinline__ void fu_gather(FuPShared<GW>& sh, int cnt, unsigned l
 struct alignas(16) FuPost {
   float v[32];
   float t[32];
+  float w[32];  // (single column: this wave's copy of w = C^T (r / d), carried by recurrence -- k_cg_onchip5 MODE 2)
 };
 
 typedef float fu_f32x2 __attribute__((ext_vector_type(2)));
@@ -190,7 +191,7 @@ typedef double fu_f64x4 __attribute__((ext_vector_type(4)));
 //   A  [0, 65536):       pivots: L rows (1024 x 16 floats, swizzled 16-byte slots; first the per-wave load windows)
 //                        E:      row tile [256][33] floats | cross-wave partials double [4][64][12]
 //                        algebra: E, T, G, Fm double [32][33]
-//                        CG:     x_s, d_s, dinv_s [1024] floats | f_s, ef_s [RC][RC + 4] floats
+//                        CG:     x_s, d_s, dinv_s [1024] floats | f_s, ef_s, e_s [RC][RC + 4] floats
 //   B  union { FuPShared<GW> (pivots) ; R4Shared + FuPost[4] (CG) }
 //   M  double [32][17]  (E phase -> algebra)
 //   H  float [16][48]   pivot history: row m = the winner's C row (32) | its L entries 0..m-1, piv at m (pivots -> M)
@@ -241,6 +242,8 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
   float* const dinv_s = d_s + R4_ROWS;
   float* const f_s = dinv_s + R4_ROWS;
   float* const ef_s = f_s + RC * FLD;
+  float* const e_s = ef_s + RC * FLD;
+  constexpr bool WR = !MC;  // one column: w by recurrence, exactly as k_cg_onchip5 MODE 2 (same bits)
 
   const int wg = blockIdx.x;
   const int xcd = wg % 8, jx = wg / 8;  // block b runs on XCD b % 8: keep a group behind one L2 (speed only)
@@ -820,20 +823,22 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
         }
       }
       __syncthreads();
-      float fv[(RC * RC + NT - 1) / NT], ev[(RC * RC + NT - 1) / NT];
+      float fv[(RC * RC + NT - 1) / NT], ev[(RC * RC + NT - 1) / NT], e0v[(RC * RC + NT - 1) / NT];
 #pragma unroll
       for (int u = 0; u < (RC * RC + NT - 1) / NT; ++u) {
         const int pr = ta + NT * u;
         fv[u] = 0.f;
         ev[u] = 0.f;
+        e0v[u] = 0.f;
         if (pr < RC * RC) {
           const int r = pr / RC, c2 = pr % RC;
           fv[u] = (float)Fm[r][c2];
           ev[u] = (float)EFm[r][c2];
+          e0v[u] = (float)Em[r][c2];
           if (pr % GW == wig) {  // (every workgroup holds the same bits: each stores its share)
             if (a.F) a.F[(size_t)b * RC * RC + pr] = fv[u];
             if (a.EF) a.EF[(size_t)b * RC * RC + pr] = ev[u];
-            if (a.E) a.E[(size_t)b * RC * RC + pr] = (float)Em[r][c2];
+            if (a.E) a.E[(size_t)b * RC * RC + pr] = e0v[u];
           }
         }
       }
@@ -849,6 +854,7 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
         if (pr < RC * RC) {
           f_s[(pr / RC) * FLD + pr % RC] = fv[u];
           ef_s[(pr / RC) * FLD + pr % RC] = ev[u];
+          if (WR) e_s[(pr / RC) * FLD + pr % RC] = e0v[u];
         }
       }
 #pragma unroll
@@ -895,6 +901,7 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
       float nrm = 1.0f, inv0 = 1.0f;
       bool rhs_zero = false;
       float t_old = 0.f, tt_old = 0.f, dpp = 0.f, rz = 0.f, alpha = 0.f, beta = 0.f, rn = 0.f;
+      float w_reg = 0.f;  // (WR: w_j in lane j of both halves, carried by the recurrence)
       bool conv = false;
       // one reduction: w = C^T (r / d), s1, s2, rp; then (every wave) the small algebra; k = -1 marks the initial one
       auto reduce_and_post = [&](int k) {
@@ -908,33 +915,46 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
           sc[1] = fmaf(rd[q], r[q], sc[1]);
           sc[2] = fmaf(r[q], p[q], sc[2]);
         }
-        fu_f32x2 wp[RC / 2];
-#pragma unroll
-        for (int j = 0; j < RC / 2; ++j) {
-          fu_f32x2 v = Cr[0][j] * fu_f32x2{rd[0], rd[0]};
-#pragma unroll
-          for (int q = 1; q < R4_NR; ++q) v = __builtin_elementwise_fma(Cr[q][j], fu_f32x2{rd[q], rd[q]}, v);
-          wp[j] = v;
-        }
         const bool draws = (k == a.iters - 1) && (col == clast - 1);
         sc[3] = (draws && wig == 0 && tg == 0) ? (float)(ngroups + drawn) : 0.f;
-        const auto gen = [&](int c) { return (c & 1) ? wp[c >> 1].y : wp[c >> 1].x; };
-        if (draws) {
-          r4_allreduce_t<GW, RC>(sh, gen, sc, 4, g, tg);
-          b_next = (int64_t)sh.res[RC + 3];
+        const bool wrec = WR && k >= 0;  // w comes from the recurrence: only the scalars are reduced
+        float tot[4] = {0.f, 0.f, 0.f, 0.f};
+        if (wrec) {
+          if (draws) {
+            r4_allreduce_small_t<GW, 4>(sh, sc, tot, g, tg);
+            b_next = (int64_t)tot[3];
+          } else {
+            r4_allreduce_small_t<GW, 3>(sh, sc, tot, g, tg);
+          }
         } else {
-          r4_allreduce_t<GW, RC>(sh, gen, sc, 3, g, tg);
+          fu_f32x2 wp[RC / 2];
+#pragma unroll
+          for (int j = 0; j < RC / 2; ++j) {
+            fu_f32x2 v = Cr[0][j] * fu_f32x2{rd[0], rd[0]};
+#pragma unroll
+            for (int q = 1; q < R4_NR; ++q) v = __builtin_elementwise_fma(Cr[q][j], fu_f32x2{rd[q], rd[q]}, v);
+            wp[j] = v;
+          }
+          const auto gen = [&](int c) { return (c & 1) ? wp[c >> 1].y : wp[c >> 1].x; };
+          if (draws) {
+            r4_allreduce_t<GW, RC>(sh, gen, sc, 4, g, tg);
+            b_next = (int64_t)sh.res[RC + 3];
+          } else {
+            r4_allreduce_t<GW, RC>(sh, gen, sc, 3, g, tg);
+          }
+          tot[0] = sh.res[RC]; tot[1] = sh.res[RC + 1]; tot[2] = sh.res[RC + 2];
         }
         {
           const int j = lane_c & 31;
           float mv = 0.f;  // lanes 0-31: (F w)_j, lanes 32-63: (E F w)_j
           if (j < RC) {
             const float* row = (lane_c < 32 ? f_s : ef_s) + j * FLD;
+            const float* wsrc = wrec ? post[tg >> 6].w : sh.res;
             fu_f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < RC; q += 4) {
               const float4 m4 = *reinterpret_cast<const float4*>(row + q);
-              const float4 w4 = *reinterpret_cast<const float4*>(&sh.res[q]);
+              const float4 w4 = *reinterpret_cast<const float4*>(&wsrc[q]);
               a01 = __builtin_elementwise_fma(fu_f32x2{m4.x, m4.y}, fu_f32x2{w4.x, w4.y}, a01);
               a23 = __builtin_elementwise_fma(fu_f32x2{m4.z, m4.w}, fu_f32x2{w4.z, w4.w}, a23);
             }
@@ -942,7 +962,7 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
           }
           float sc1 = 1.0f, sc2 = 1.0f;
           if (k < 0) {
-            nrm = sqrtf(sh.res[RC]);                         // rhs.norm(2, dim=-2)          :177
+            nrm = sqrtf(tot[0]);                             // rhs.norm(2, dim=-2)          :177
             rhs_zero = nrm < a.eps;                          // :178
             if (rhs_zero) nrm = 1.0f;                        // :179
             inv0 = 1.0f / nrm;
@@ -952,9 +972,9 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
           mv *= sc1;
           const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mv), __float_as_uint(mv), false, false);
           const float vj = __uint_as_float(sw[0]), evj = __uint_as_float(sw[1]);
-          const float wj = (j < RC) ? sh.res[j] * sc1 : 0.f;
+          const float wj = wrec ? w_reg : ((j < RC) ? sh.res[j] * sc1 : 0.f);
           const bool own = lane_c < 32 && j < RC;
-          const float s1 = sh.res[RC] * sc2, s2 = sh.res[RC + 1] * sc2, rp = sh.res[RC + 2];
+          const float s1 = tot[0] * sc2, s2 = tot[1] * sc2, rp = tot[2];
           const float zj = wj - evj;                          // (C^T z)_j
           const bool live = j < RC;
           const float wv = lanes32_sum(live ? wj * vj : 0.f);
@@ -988,6 +1008,27 @@ __global__ __launch_bounds__(R4_TPB, 2) void k_solve_fused(FusedArgs a) {
           if (own) {
             mine.v[j] = vj;
             mine.t[j] = t_old;
+          }
+          if (WR) {  // w' = w - alpha (E t + t): see k_cg_onchip5 (lo_cg_onchip4.hip), operation for operation
+            __builtin_amdgcn_wave_barrier();
+            float et = 0.f;
+            if (j < RC) {
+              const int q0 = (lane_c < 32) ? 0 : RC / 2;
+              const float* row = e_s + j * FLD + q0;
+              fu_f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+              for (int q = 0; q < RC / 2; q += 4) {
+                const float4 m4 = *reinterpret_cast<const float4*>(row + q);
+                const float4 t4 = *reinterpret_cast<const float4*>(&mine.t[q0 + q]);
+                a01 = __builtin_elementwise_fma(fu_f32x2{m4.x, m4.y}, fu_f32x2{t4.x, t4.y}, a01);
+                a23 = __builtin_elementwise_fma(fu_f32x2{m4.z, m4.w}, fu_f32x2{t4.z, t4.w}, a23);
+              }
+              et = (a01.x + a01.y) + (a23.x + a23.y);
+            }
+            const auto se = __builtin_amdgcn_permlane32_swap(__float_as_uint(et), __float_as_uint(et), false, false);
+            const float etj = __uint_as_float(se[0]) + __uint_as_float(se[1]);
+            w_reg = fmaf(-alpha, etj + t_old, wj);
+            if (own) mine.w[j] = w_reg;
           }
         }
       };

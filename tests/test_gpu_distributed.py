@@ -168,11 +168,14 @@ def test_hip_kernels_under_an_rccl_process_group_with_a_collective_in_flight():
         with settings.cg_tolerance(1e-4):
             x_fused = A.solve(dev(rhs[:8]))  # local rule: the one-launch end-to-end solve
             clear_preconditioner_memo()
-            os.environ["LO_NO_FUSED_SOLVE"] = "1"  # local rule on the three-launch path: what the global rule runs on
+            # local rule on the three-launch path with the three-pass iteration: what the global rule runs on (the
+            # result-only pass of the local rule would carry w by recurrence -- another rounding sequence)
+            os.environ["LO_NO_FUSED_SOLVE"] = "1"
+            os.environ["LO_OC_NO_WREC"] = "1"
             try:
                 x_local = A.solve(dev(rhs[:8]))
             finally:
-                del os.environ["LO_NO_FUSED_SOLVE"]
+                del os.environ["LO_NO_FUSED_SOLVE"], os.environ["LO_OC_NO_WREC"]
             clear_preconditioner_memo()
             with D.global_stopping_rule() as red:
                 x_glob = A.solve(dev(rhs[:8]))

@@ -290,11 +290,14 @@ def test_w_recurrence_mode_against_three_pass_oracle_and_exact_solution(N, R, B,
     prof = K._hip.prof_report()
     K._hip.prof_enable(False)
     assert "cg_onchip" in prof and K.cg_last_executed()["serial_engine"] == "root"
+    ran_lean = K.cg_last_executed()["lean"]  # the result-only (w-recurrence) pass met the stop rule and stands
     monkeypatch.setenv("LO_OC_NO_WREC", "1")
     ref = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
     monkeypatch.delenv("LO_OC_NO_WREC")
     assert res.iterations == ref.iterations and res.tolerance_reached == ref.tolerance_reached
-    if K.cg_last_executed()["streaming_iterations"] == 0:  # (stop at the floor: the w-recurrence result stands)
+    if ran_lean and R > 15:
+        # (stop at the floor: the w-recurrence result stands.  A root of rank <= 15 is reproduced exactly by the pivots:
+        #  P = A, CG converges in its first step -- before the recurrence has been used at all)
         assert not torch.equal(res.x, ref.x), "the two modes gave identical bits: the switch does not switch"
     exact = _woodbury_exact(C, d, rhs)
     e_wr, e_3p = max_rel_err_cols(host(res.x), exact), max_rel_err_cols(host(ref.x), exact)
