@@ -238,7 +238,7 @@ int lo_cg_last_executed(lo_cg_plan* plan);
  *   LO_FUSED_TIMEOUT     a group exchange timed out (co-residency lost)
  * In the last three cases x is NOT valid and the caller redoes the solve with lo_pivoted_cholesky_f32 +
  * lo_precond_root_form_f32 / lo_precond_build_f32 + lo_cg_solve_f32.
- *   op       LO_OP_LOWRANK_DIAG, R in {8, 16, 32}, 256 <= N <= 8192, diag FULL or CONST
+ *   op       LO_OP_LOWRANK_DIAG, R in {8, 16, 32}, 256 <= N <= 16384, diag FULL or CONST
  *   rank     pivots (settings.max_preconditioner_size, 1..16), error_tol = settings.preconditioner_tolerance
  *   prm      as lo_cg_solve_f32 (n_tridiag == 0, no stop_reduce, c <= 8)
  *   x        [B, N, c] out

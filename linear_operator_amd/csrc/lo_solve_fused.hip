@@ -132,7 +132,9 @@ int lo_solve_fused_supported(const lo_op_desc* op, int32_t rank, const lo_cg_par
   if (op->kind != LO_OP_LOWRANK_DIAG || (op->diag_mode != LO_DIAG_FULL && op->diag_mode != LO_DIAG_CONST)) return 0;
   if (!(op->R == 8 || op->R == 16 || op->R == 32)) return 0;
   if (rank < 1 || rank > FU_MAXRANK || rank > op->N) return 0;
-  if (op->N < 256 || op->N > (int64_t)8 * R4_ROWS || op->B < 1 || op->B >= (1 << 24) - 1024) return 0;
+  // (groups of 1 .. 16 workgroups: up to 16384 rows; groups of 32 spill at the 256-VGPR budget)
+  if (op->N < 256 || op->N > (int64_t)16 * R4_ROWS || op->B < 1 || op->B >= (1 << 24) - 1024) return 0;
+  if (op->N > (int64_t)8 * R4_ROWS && getenv("LO_FUSED_NO_GW16")) return 0;
   if (prm->c < 1 || prm->c > 8 || prm->n_tridiag != 0 || prm->stop_reduce) return 0;
   // (debug switch of the w-recurrence: the single-column instantiation of this kernel always carries w by recurrence,
   //  like k_cg_onchip5 MODE 2 -- with the switch set, single-column solves take the three-launch path)

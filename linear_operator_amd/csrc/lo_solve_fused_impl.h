@@ -1107,8 +1107,9 @@ static int fused_launch_rc(const FusedArgs& a, int nwg, hipStream_t st) {
     case 2: return LO_FU_G(2);
     case 4: return LO_FU_G(4);
     case 8: return LO_FU_G(8);
-    // (groups of 16 / 32 workgroups -- N > 8192 -- spill at the 256-VGPR budget in the pivot and CG loops: those
-    // members take the three-launch path)
+    case 16: return LO_FU_G(16);
+    // (round 4: groups of 16 -- N <= 16384 -- compile with 4 cold spilled registers since the single-column CG carries w
+    //  by recurrence; groups of 32 still spill in the pivot loop: those members take the three-launch path)
     default: return LO_ERR_UNSUPPORTED;
   }
 #undef LO_FU_G

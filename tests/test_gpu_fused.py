@@ -46,9 +46,10 @@ def _oracle_solve(C, d, rhs, rank=15, tol=1e-4):
 
 
 @pytest.mark.parametrize("N,R,B,c", [(8192, 32, 70, 1), (2048, 16, 20, 2), (1000, 8, 37, 1), (5000, 32, 9, 3),
-                                     (4096, 32, 130, 1), (300, 16, 600, 1), (8192, 16, 9, 1), (7000, 8, 11, 4)])
+                                     (4096, 32, 130, 1), (300, 16, 600, 1), (8192, 16, 9, 1), (7000, 8, 11, 4),
+                                     (16384, 32, 40, 1), (12000, 32, 7, 2), (9000, 16, 5, 1)])
 def test_fused_solve_matches_oracle_pivots_and_solution(N, R, B, c):
-    """Members larger / smaller than a workgroup multiple, every group size (1, 2, 4, 8 workgroups), 1-4 columns:
+    """Members larger / smaller than a workgroup multiple, every group size (1, 2, 4, 8, 16 workgroups), 1-4 columns:
     pivots bit-exact vs the oracle, solution within 1e-4 per column, logdet P of the root form, iteration floor."""
     C, d, rhs = cases.lowrank_diag(7100 + R + N, B, N, R, c)
     if R == 8:  # a rank-8 root exhausts after 8 pivots (the batch-global rule stops early): factor a rank-12 request
@@ -140,12 +141,13 @@ def test_fused_solve_declines_what_it_cannot_decide(monkeypatch):
     assert K.solve_fused(desc, dev(rhs), 15, 1e-3, tolerance=TOL) is None
     monkeypatch.delenv("LO_OC_TEST_FALLBACK")
     assert K.solve_fused(desc, dev(rhs), 15, 1e-3, tolerance=TOL) is not None
-    # shapes outside the kernel: ranks above 16, roots that are not 8 / 16 / 32 wide, members above 8192 rows
+    # shapes outside the kernel: ranks above 16, roots that are not 8 / 16 / 32 wide, members above 16384 rows
     assert not K.solve_fused_supported(desc, 1, 17) and not K.solve_fused_supported(desc, 9, 15)
     C2 = cases.lowrank_diag(7402, 2, 2048, 20, 1)[0]
     assert not K.solve_fused_supported(K.lowrank_diag_descriptor(dev(C2), dev(d[:2])), 1, 15)
-    C3, d3, _ = cases.lowrank_diag(7403, 2, 9000, 16, 1)
+    C3, d3, _ = cases.lowrank_diag(7403, 2, 17000, 16, 1)
     assert not K.solve_fused_supported(K.lowrank_diag_descriptor(dev(C3), dev(d3)), 1, 15)
+    assert K.solve_fused_supported(K.lowrank_diag_descriptor(dev(C3[:, :9000]), dev(d3[:, :9000])), 1, 15)  # (round 4)
     # NaN in the root: flagged, never a silent result
     Cn = C.copy()
     Cn[2, 17, 3] = np.nan
