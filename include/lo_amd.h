@@ -341,7 +341,8 @@ int lo_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matv
                            int64_t P, int32_t max_iter, float tol, float* q_mat, float* t_mat, int32_t* iters_out,
                            void* ws, size_t ws_bytes, void* stream);
 /* q_mat [k, B, N, P] (first k of the stored vectors, working order) -> [P, B, N, k], the layout lanczos.py:154
- * returns (permute(-1, batch, -2, 0).contiguous()).  LO_ERR_UNSUPPORTED when k * 32 * (P + 1) floats exceed 64 KiB
+ * returns (permute(-1, batch, -2, 0).contiguous()).  Since round 4 the host mirror returns the permuted VIEW and the
+ * consumers on the path read the native layout (lo_root_from_lanczos_native_f32): this copy is made on request only.  LO_ERR_UNSUPPORTED when k * 32 * (P + 1) floats exceed 64 KiB
  * of LDS (the host then permutes with torch).                                                       */
 int lo_lanczos_permute_f32(const float* q_in, int32_t k, int64_t B, int64_t N, int64_t P, float* q_out, void* stream);
 /* Epilogue of RootDecomposition.forward (functions/_root_decomposition.py:73-85) for PB = probes x batch members:
@@ -349,6 +350,12 @@ int lo_lanczos_permute_f32(const float* q_in, int32_t k, int64_t B, int64_t N, i
  * [PB, k, k], evals [PB, k]; any of the three outputs may be NULL.  k <= 32, else LO_ERR_UNSUPPORTED.      */
 int lo_root_from_lanczos_f32(const float* q, const float* evecs, const float* evals, int64_t PB, int64_t N, int32_t k,
                              float* qv, float* root, float* inverse, void* stream);
+
+/* The same epilogue on the basis in the layout lo_lanczos_tridiag_f32 WRITES it: q_native [k, B, N, P] (the first k stored
+ * vectors) with evecs [P, B, k, k], evals [P, B, k]; outputs [P, B, N, k].  The [P, B, N, k] copy of lanczos.py:154 is
+ * then never made.  LO_ERR_UNSUPPORTED: k > 32 or P (k k + 1 + k + (256 / P) k) floats beyond 64 KiB of LDS.           */
+int lo_root_from_lanczos_native_f32(const float* q_native, const float* evecs, const float* evals, int64_t B, int64_t N,
+                                    int64_t P, int32_t k, float* qv, float* root, float* inverse, void* stream);
 
 /* ---- lanczos_tridiag_to_diag + StochasticLQ.to_dense (lanczos.py:167-189, stochastic_lq.py:45-82) */
 /* t_mat [M, T, T] (M = P*B tridiagonals, only the three diagonals are read) ->

@@ -38,7 +38,7 @@ EXPORTS = [
     "lo_precond_root_form_workspace_bytes", "lo_precond_root_form_f32",
     "lo_precond_kron_root_workspace_bytes", "lo_precond_kron_root_f32",
     "lo_lanczos_workspace_bytes", "lo_lanczos_tridiag_f32", "lo_lanczos_permute_f32",
-    "lo_root_from_lanczos_f32",
+    "lo_root_from_lanczos_f32", "lo_root_from_lanczos_native_f32",
     "lo_tridiag_eigh_slq_workspace_bytes", "lo_tridiag_eigh_slq_f32",
     "lo_bilinear_dense_f32", "lo_bilinear_diag_f32", "lo_bilinear_root_workspace_bytes", "lo_bilinear_root_f32",
     "lo_bilinear_kron_workspace_bytes", "lo_bilinear_kron_f32",
@@ -170,6 +170,9 @@ def load():
     lib.lo_cg_solve_f32.argtypes = [P(OpDesc), MATVEC_CB, C.c_void_p, P(PrecondDesc), MATVEC_CB, C.c_void_p,
                                     P(CgParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, sz,
                                     P(CgInfo), C.c_void_p]
+    lib.lo_root_from_lanczos_native_f32.restype = C.c_int
+    lib.lo_root_from_lanczos_native_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.lo_cg_plan_f32.restype = C.c_int
     lib.lo_cg_plan_f32.argtypes = [P(OpDesc), P(PrecondDesc), C.c_int, C.c_int, P(CgParams), C.c_int, P(CgPlan)]
     lib.lo_cg_last_executed.restype = C.c_int

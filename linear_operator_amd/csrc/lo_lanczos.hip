@@ -707,11 +707,99 @@ __global__ __launch_bounds__(kThreads) void k_lz_root(const float* __restrict__ 
   }
 }
 
+// The same epilogue reading the Lanczos basis in the layout the step kernels WRITE it -- q_native [k, B, N, P] (vector a
+// of probe p of member b: q[((a B + b) N + n) P + p]) -- so that the [P, B, N, k] copy of lanczos.py:154 is never made
+// (k_lz_permute4 cost 0.9 - 2.2 ms per call at the cfg3 shape).  A workgroup takes TR rows x all P probes of a member:
+// thread (row, p) gathers its k coefficients with P-contiguous loads (a wave instruction reads whole lines), multiplies
+// by V_p (LDS, per-probe stride k k + 1: the 16 probes of a wave hit different banks) and the results leave through an
+// LDS tile as TR k contiguous floats per probe.
+template <int KM>
+__global__ __launch_bounds__(kThreads) void k_lz_root_native(const float* __restrict__ q, const float* __restrict__ evecs,
+                                                              const float* __restrict__ evals, int64_t B, int N, int P,
+                                                              int k, int TR, float* __restrict__ qv,
+                                                              float* __restrict__ root, float* __restrict__ inverse) {
+  extern __shared__ float lz_sm[];
+  const int vld = k * k + 1;
+  float* v_s = lz_sm;                     // [P][k k + 1]
+  float* s_s = v_s + (size_t)P * vld;     // [P][k]  sqrt(lambda)
+  float* tile = s_s + (size_t)P * k;      // [P][TR][k]
+  const int64_t b = blockIdx.y;
+  const int r0 = blockIdx.x * TR;
+  for (int e = threadIdx.x; e < P * k * k; e += kThreads) {
+    const int pp = e / (k * k), ij = e % (k * k);
+    v_s[pp * vld + ij] = evecs[((size_t)pp * B + b) * k * k + ij];
+  }
+  for (int e = threadIdx.x; e < P * k; e += kThreads) s_s[e] = sqrtf(evals[((size_t)(e / k) * B + b) * k + e % k]);
+  const int e0 = threadIdx.x;
+  const int p = e0 % P, row = e0 / P;
+  const bool live = e0 < TR * P && r0 + row < N;
+  float x[KM];
+#pragma unroll
+  for (int a = 0; a < KM; ++a)
+    x[a] = (live && a < k) ? q[(((size_t)a * B + b) * N + r0 + row) * P + p] : 0.f;
+  __syncthreads();
+  float acc[KM];
+#pragma unroll
+  for (int j = 0; j < KM; ++j) acc[j] = 0.f;
+  if (live) {
+    const float* vp = v_s + p * vld;
+#pragma unroll
+    for (int a = 0; a < KM; ++a) {
+      if (a < k) {  // (uniform)
+        const float xa = x[a];
+#pragma unroll
+        for (int j = 0; j < KM; ++j)
+          if (j < k) acc[j] = fmaf(xa, vp[a * k + j], acc[j]);
+      }
+    }
+  }
+  const int nrow = min(TR, N - r0);
+  for (int which = 0; which < 3; ++which) {
+    float* out = which == 0 ? qv : (which == 1 ? root : inverse);
+    if (!out) continue;
+    __syncthreads();
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < KM; ++j)
+        if (j < k) {
+          const float sj = s_s[p * k + j];
+          tile[((size_t)p * TR + row) * k + j] = which == 0 ? acc[j] : (which == 1 ? acc[j] * sj : acc[j] / sj);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < P * nrow * k; e += kThreads) {
+      const int pp = e / (nrow * k), rem = e % (nrow * k);
+      out[(((size_t)pp * B + b) * N + r0) * k + rem] = tile[(size_t)pp * TR * k + rem];
+    }
+  }
+}
+
 }  // namespace lo
 
 using namespace lo;
 
 extern "C" {
+
+int lo_root_from_lanczos_native_f32(const float* q_native, const float* evecs, const float* evals, int64_t B, int64_t N,
+                                    int64_t P, int32_t k, float* qv, float* root, float* inverse, void* stream) {
+  if (!q_native || !evecs || !evals || B < 1 || N < 1 || P < 1 || k < 1 || B > 65535) return LO_ERR_BADARG;
+  if (k > 32 || P > kThreads) return LO_ERR_UNSUPPORTED;
+  const int TR = kThreads / (int)P;
+  const size_t lds = sizeof(float) * ((size_t)P * (k * k + 1) + (size_t)P * k + (size_t)P * TR * k);
+  if (lds > 64 * 1024) return LO_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((N + TR - 1) / TR), (unsigned)B);
+  LO_PROF_BEGIN("lz_root", st);
+  if (k <= 16)
+    hipLaunchKernelGGL((k_lz_root_native<16>), grid, dim3(kThreads), lds, st, q_native, evecs, evals, B, (int)N, (int)P,
+                       (int)k, TR, qv, root, inverse);
+  else
+    hipLaunchKernelGGL((k_lz_root_native<32>), grid, dim3(kThreads), lds, st, q_native, evecs, evals, B, (int)N, (int)P,
+                       (int)k, TR, qv, root, inverse);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
 
 static void lz_layout(const lo_op_desc* op, int64_t P, int max_iter, Arena& ar, LzDev* d, Split* spo) {
   Split sp = choose_split(op->B, op->N, 256, 64);  // (the fused step keeps a member's dot partials in 64 slots)

@@ -838,9 +838,11 @@ def tridiag_eigh_slq(t_mat: torch.Tensor, n: int, want_evecs: bool = False, want
 
 
 def lanczos_tridiag(desc: Optional[OperatorDescriptor], init_vecs: torch.Tensor, max_iter: int, tol: float = 1e-5,
-                    matvec_closure: Optional[Callable] = None):
+                    matvec_closure: Optional[Callable] = None, contiguous: bool = False):
     """lo_lanczos_tridiag_f32: utils/lanczos.py:9-164.  init_vecs [*batch, N, P].
-    Returns (q_mat [P,*batch,N,k'], t_mat [P,*batch,k',k']) in the reference's output layout (:151-161)."""
+    Returns (q_mat [P,*batch,N,k'], t_mat [P,*batch,k',k']) with the reference's output shapes (:151-161); q_mat is a
+    strided view of the basis as the kernels wrote it unless `contiguous=True` asks for the reference's memory layout
+    (one more pass over the basis: lo_lanczos_permute_f32)."""
     lib = _hip.load()
     _hip.require_hip(init_vecs)
     N, P = init_vecs.shape[-2:]
@@ -872,16 +874,47 @@ def lanczos_tridiag(desc: Optional[OperatorDescriptor], init_vecs: torch.Tensor,
     k = iters.value
     nb = len(batch)
     t = t[:k, :k].reshape(k, k, *batch, P)
-    q_out = torch.empty(P, *batch, N, k, dtype=torch.float32, device=dev)
-    rc = lib.lo_lanczos_permute_f32(_hip.ptr(q), k, B, N, P, _hip.ptr(q_out), _hip.stream_ptr(dev))  # lanczos.py:154
-    if rc == _hip.LO_ERR_UNSUPPORTED:
-        q_out = q[:k].reshape(k, *batch, N, P).permute(-1, *range(1, 1 + nb), -2, 0).contiguous()
+    if contiguous:
+        q_out = torch.empty(P, *batch, N, k, dtype=torch.float32, device=dev)
+        rc = lib.lo_lanczos_permute_f32(_hip.ptr(q), k, B, N, P, _hip.ptr(q_out), _hip.stream_ptr(dev))  # lanczos.py:154
+        if rc == _hip.LO_ERR_UNSUPPORTED:
+            q_out = q[:k].reshape(k, *batch, N, P).permute(-1, *range(1, 1 + nb), -2, 0).contiguous()
+        else:
+            _hip.check(rc, "lo_lanczos_permute_f32")
     else:
-        _hip.check(rc, "lo_lanczos_permute_f32")
+        # the reference's q_mat [P, *batch, N, k] (lanczos.py:154) as a VIEW of the basis in the layout the step kernels
+        # write it ([k, B, N, P]): same shape, same values, no 5 GB copy at the cfg3 shape.  The consumers on the path
+        # (root_from_lanczos below) read this layout directly; anything else sees an ordinary strided tensor.
+        q_out = q[:k].reshape(k, *batch, N, P).permute(-1, *range(1, 1 + nb), -2, 0)
     t_out = t.permute(-1, *range(2, 2 + nb), 0, 1).contiguous()  # :156
     if P == 1:  # squeeze_(0) (:159-161) only acts on a size-1 leading dim
         q_out, t_out = q_out[0], t_out[0]
     return q_out, t_out
+
+
+def _native_lanczos_layout(q_mat: torch.Tensor):
+    """(P, B) if q_mat [P, *batch, N, k] is the permuted view `lanczos_tridiag` returns of a basis stored [k, B, N, P]
+    (element (p, b, n, a) at ((a B + b) N + n) P + p from its first element), else None.  Size-1 dimensions carry no
+    information (the callers unsqueeze / squeeze them)."""
+    if q_mat.dim() < 3:
+        return None
+    N, k = q_mat.shape[-2:]
+    lead = list(q_mat.shape[:-2])
+    P = lead[0]
+    B = 1
+    for s in lead[1:]:
+        B *= s
+    want = [1]  # stride of the probe dimension
+    acc = N * P
+    batch_strides = []
+    for s in reversed(lead[1:]):
+        batch_strides.append(acc)
+        acc *= s
+    want += list(reversed(batch_strides)) + [P, B * N * P]
+    for size, have, exp in zip(q_mat.shape, q_mat.stride(), want):
+        if size > 1 and have != exp:
+            return None
+    return P, B
 
 
 def root_from_lanczos(q_mat: torch.Tensor, evecs: torch.Tensor, evals: torch.Tensor, want_root: bool = True,
@@ -897,6 +930,22 @@ def root_from_lanczos(q_mat: torch.Tensor, evecs: torch.Tensor, evals: torch.Ten
         s = evals.sqrt().unsqueeze(-2)
         return qv, (qv * s if want_root else None), (qv / s if want_inverse else None)
     _hip.require_hip(q_mat, evecs, evals)
+    native = _native_lanczos_layout(q_mat)
+    if native is not None:
+        P, B = native
+        dev = q_mat.device
+        v4 = evecs.contiguous().reshape(P * B, k, k)
+        e4 = evals.contiguous().reshape(P * B, k)
+        qv = torch.empty(P * B, N, k, dtype=torch.float32, device=dev)
+        root = torch.empty_like(qv) if want_root else None
+        inv = torch.empty_like(qv) if want_inverse else None
+        rc = lib.lo_root_from_lanczos_native_f32(_hip.ptr(q_mat), _hip.ptr(v4), _hip.ptr(e4), B, N, P, k, _hip.ptr(qv),
+                                                 _hip.ptr(root), _hip.ptr(inv), _hip.stream_ptr(dev))
+        if rc == 0:
+            shp = (*lead, N, k)
+            return qv.reshape(shp), (None if root is None else root.reshape(shp)), (None if inv is None else inv.reshape(shp))
+        if rc != _hip.LO_ERR_UNSUPPORTED:
+            _hip.check(rc, "lo_root_from_lanczos_native_f32")
     q3 = q_mat.contiguous().reshape(-1, N, k)
     PB = q3.shape[0]
     v3 = evecs.contiguous().reshape(PB, k, k)

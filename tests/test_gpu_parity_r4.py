@@ -327,3 +327,34 @@ def test_w_recurrence_mode_continues_on_the_streaming_engine_when_the_floor_is_n
     ran = K.cg_last_executed()
     assert ran["resident"] and ran["streaming_iterations"] > 0 and res.tolerance_reached
     assert max_rel_err_cols(host(res.x), _woodbury_exact(C, d, rhs)) < 1e-4
+
+
+# ---------------------------------------------------------------- Lanczos basis without the layout copy
+@pytest.mark.parametrize("B,N,P,k", [(6, 3000, 16, 20), (3, 1000, 4, 12), (2, 700, 1, 9), (5, 2048, 8, 32)])
+def test_lanczos_basis_view_and_native_root_epilogue(B, N, P, k):
+    """`lanczos_tridiag` returns q_mat [P, B, N, k] as a VIEW of the basis in the step kernels' layout [k, B, N, P]
+    (no 5 GB copy at the cfg3 shape); `root_from_lanczos` reads that layout directly.  Same values as the reference
+    layout (lo_lanczos_permute_f32), bit-identical epilogue outputs."""
+    C, d, _ = cases.lowrank_diag(9900 + P, B, N, 16, 1)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    V = dev(cases.randn(9901, B, N, P, dtype=np.float32))
+    q_view, t_view = K.lanczos_tridiag(desc, V, k)
+    q_cont, t_cont = K.lanczos_tridiag(desc, V, k, contiguous=True)
+    assert q_view.shape == q_cont.shape and not q_view.is_contiguous() and q_cont.is_contiguous()
+    assert torch.equal(q_view, q_cont) and torch.equal(t_view, t_cont)
+    if P == 1:
+        q_view, q_cont, t_view = q_view.unsqueeze(0), q_cont.unsqueeze(0), t_view.unsqueeze(0)
+    assert (K._native_lanczos_layout(q_view) is not None) and K._native_lanczos_layout(q_cont) is None
+    from linear_operator_amd.utils.lanczos import lanczos_tridiag_to_diag
+    evals, evecs = lanczos_tridiag_to_diag(t_view + 1e-3 * torch.eye(t_view.shape[-1], device="cuda"))
+    K._hip.prof_enable(True)
+    a = K.root_from_lanczos(q_view, evecs, evals, want_root=True, want_inverse=True)
+    torch.cuda.synchronize()
+    prof = K._hip.prof_report()
+    K._hip.prof_enable(False)
+    assert list(prof) == ["lz_root"], sorted(prof)  # (one launch, no copy kernel in front of it)
+    b = K.root_from_lanczos(q_cont, evecs, evals, want_root=True, want_inverse=True)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and torch.equal(x, y)
+    ref = (q_cont.double() @ evecs.double())
+    assert float((a[0].double() - ref).abs().max()) < 1e-5
