@@ -786,7 +786,8 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     const size_t span = oc_possible ? (size_t)(reinterpret_cast<char*>(d.oc_gbuf) - reinterpret_cast<char*>(d.ctrl)) +
                                           onchip_gbuf_bytes(66)
                                     : sizeof(CgCtrl);
-    LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, span, st));
+    rc = zero_span(d.ctrl, span, st);
+    if (rc) return rc;
   }
   if (prm->n_tridiag)
     LO_HIP_CHECK(hipMemsetAsync(t_mat, 0, sizeof(float) * (size_t)prm->n_tridiag * B * d.T * d.T, st));

@@ -165,6 +165,8 @@ struct PlanGuard {
 };
 // y += a (elementwise, n floats)
 int vec_axpy1(float* y, const float* a, size_t n, const int* stop, hipStream_t st);
+// clears `bytes` at p (16-byte aligned) with one kernel launch (control blocks / hand-off granules of a resident launch)
+int zero_span(void* p, size_t bytes, hipStream_t st);
 size_t matvec_plan_bytes(const lo_op_desc* op, int64_t c, Split sp);
 int matvec_plan_init(MatvecPlan* pl, const lo_op_desc* op, lo_matvec_cb cb, void* cb_user, int64_t c, Split sp,
                      Arena* ar, hipStream_t st);

@@ -184,7 +184,10 @@ int lo_solve_fused_f32(const lo_op_desc* op, int32_t rank, float error_tol, cons
   const bool debug = getenv("LO_FU_DEBUG") != nullptr && B >= 8;
   a.dbg = debug ? l.dbg : nullptr;
   a.dbg_member = debug ? atoi(getenv("LO_FU_DEBUG")) : 0;
-  LO_HIP_CHECK(hipMemsetAsync(l.pgbuf, 0, l.zero_bytes, st));
+  {
+    const int zrc = zero_span(l.pgbuf, l.zero_bytes, st);  // (one launch instead of the runtime's fill kernels)
+    if (zrc) return zrc;
+  }
   if (debug) LO_HIP_CHECK(hipMemsetAsync(l.dbg, 0, 16 * sizeof(long long), st));
   if (getenv("LO_OC_TEST_FALLBACK")) LO_HIP_CHECK(hipMemsetAsync(l.ints, 1, 1, st));  // as if an exchange had timed out
   int rc = LO_ERR_UNSUPPORTED;

@@ -5,6 +5,8 @@
 #include <algorithm>
 
 #include "lo_device.h"
+#include <stdint.h>
+
 #include "lo_internal.h"
 
 namespace lo {
@@ -98,6 +100,32 @@ __global__ __launch_bounds__(kThreads) void k_axpy1(float* __restrict__ y, const
     reinterpret_cast<float4*>(y)[i] = yv;
   }
   for (size_t i = 4 * n4 + (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) y[i] += a[i];
+}
+
+// Clears a small control region (control block + hand-off granules of a resident launch) with ONE kernel launch:
+// hipMemsetAsync of such a span became five __amd_rocclr_fillBufferAligned launches per solve on ROCm 7
+// (profiles/r04/kernel_stats_bench.csv of the first build: 8.5 us of fill kernels in front of every 340 us solve).
+// p: 16-byte aligned; bytes: any (the tail is cleared bytewise).
+__global__ __launch_bounds__(kThreads) void k_zero_span(uint4* __restrict__ p, size_t n16, unsigned char* __restrict__ tail,
+                                                         int ntail) {
+  const size_t stride = (size_t)gridDim.x * kThreads;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+int zero_span(void* p, size_t bytes, hipStream_t st) {
+  if (!bytes) return LO_OK;
+  if ((reinterpret_cast<uintptr_t>(p) & 15u) != 0) {  // (never on an Arena allocation: the library path of last resort)
+    LO_HIP_CHECK(hipMemsetAsync(p, 0, bytes, st));
+    return LO_OK;
+  }
+  const size_t n16 = bytes / 16;
+  const int ntail = (int)(bytes - 16 * n16);
+  const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>((n16 + kThreads - 1) / kThreads, 512));
+  hipLaunchKernelGGL(k_zero_span, dim3(grid), dim3(kThreads), 0, st, reinterpret_cast<uint4*>(p), n16,
+                     reinterpret_cast<unsigned char*>(p) + 16 * n16, ntail);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
 }
 
 // y += a: the accumulation step of a SumLinearOperator matvec (sum_linear_operator.py:47-51)
