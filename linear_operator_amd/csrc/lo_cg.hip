@@ -14,6 +14,7 @@
 //   precond    z = P^-1 r ; rz_part = sum r o z                 (:268, :35-36 fused)
 //   ctrl       beta (:34-42), residual norms (:298-300), stop rule (:302-308), tridiag (:311-332)
 #include <algorithm>
+#include <chrono>
 #include <cstddef>
 #include <cmath>
 #include <cstdlib>
@@ -44,9 +45,15 @@ static unsigned next_ticket() {
   return ++t == 0 ? ++t : t;
 }
 static int wait_ticket(volatile unsigned* word, unsigned ticket, hipStream_t st) {
-  for (int spin = 0; spin < 40000; ++spin) {
+  // (time-bounded: ~2 ms of spinning covers every resident launch of the BASELINE shapes; the iteration count of a fixed
+  //  spin loop depends on what `pause` costs on the host CPU)
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int spin = 0;; ++spin) {
     if (*word == ticket) return LO_OK;
     __builtin_ia32_pause();
+    if ((spin & 1023) == 1023 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3)
+      break;
   }
   LO_HIP_CHECK(hipStreamSynchronize(st));
   return (*word == ticket) ? LO_OK : LO_ERR_LAUNCH;
@@ -132,6 +139,8 @@ struct CgDev {
   CgCtrl* ctrl;
   float* ctrl_part;  // [3, kCtrlMaxG] per-workgroup partials of the control step
   unsigned long long* oc_gbuf;
+  unsigned long long* oc_close; // [B] closing granules of k_cg_onchip5 + one counter word behind them (right after oc_gbuf:
+                                // cleared with the control block by the same launch)
   unsigned long long* ls_gbuf;  // granules of the column-lockstep kernel (lo_cg_lockstep.hip) or nullptr
   unsigned long long* pf_gbuf;  // granules of the fused preconditioner apply (lo_precond_fused.hip) or nullptr
   int* pf_ctr;                  // one member hand-out counter per launch of that kernel (max_iter + 1 ints)
@@ -627,6 +636,7 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   dd.ctrl = ar.take<CgCtrl>(1);
   // (granule buffer of the serial resident kernels right behind the control block: ONE memset clears both)
   dd.oc_gbuf = ar.take<unsigned long long>(onchip_gbuf_bytes(66) / sizeof(unsigned long long));
+  dd.oc_close = ar.take<unsigned long long>((size_t)B + 2);
   dd.x = ar.take<float>(nv);
   dd.r = ar.take<float>(nv);
   dd.p = ar.take<float>(nv);
@@ -783,8 +793,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
 
   {  // control block (+ the granule buffer behind it when a resident kernel may run)
     const bool oc_possible = op->kind == LO_OP_LOWRANK_DIAG && !g_onchip_disabled;
-    const size_t span = oc_possible ? (size_t)(reinterpret_cast<char*>(d.oc_gbuf) - reinterpret_cast<char*>(d.ctrl)) +
-                                          onchip_gbuf_bytes(66)
+    const size_t span = oc_possible ? (size_t)(reinterpret_cast<char*>(d.oc_close + B + 2) - reinterpret_cast<char*>(d.ctrl))
                                     : sizeof(CgCtrl);
     rc = zero_span(d.ctrl, span, st);
     if (rc) return rc;
@@ -863,6 +872,10 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.c = c; a.ab_rec = prm->n_tridiag ? d.oc_ab : nullptr;
     a.col0 = 0; a.ncols = c; a.RK = pre ? preR4 : 0; a.RCg = pl.R4;
     a.F = nullptr; a.EF = nullptr; a.E = nullptr;
+    a.close_gran = nullptr; a.close_count = nullptr; a.close_ctrl = nullptr; a.close_mirror = nullptr;
+    a.close_ticket = 0; a.close_tol = 0.f; a.close_floor_ok = 0;
+    bool close_in_kernel = false;
+    unsigned close_ticket = 0;
     a.iters = kfloor0 + 1;
     a.eps = prm->eps; a.stop_after = prm->stop_updating_after;
     a.x = d.x; a.r = d.r; a.p = d.p; a.z = d.z;
@@ -922,7 +935,24 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       a.E = oc_nopre ? nullptr : pre->E;
       a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
       a.dbg = oc_dbg ? d.oc_dbg : nullptr;
+      // one column, no tridiagonals, no lockstep launch in front: the kernel closes the solve itself (stop rule, NaN /
+      // skip conditions, mirror + ticket) -- no separate control launch
+      close_in_kernel = c == 1 && ls_cols == 0 && prm->n_tridiag == 0 && !oc_dbg && !getenv("LO_OC_NO_INKERNEL_CLOSE") &&
+                        pinned_status_block() != nullptr;
+      if (close_in_kernel) {
+        a.close_gran = d.oc_close;
+        a.close_count = reinterpret_cast<int*>(d.oc_close + B);
+        a.close_ctrl = d.ctrl;
+        a.close_mirror = static_cast<CgCtrl*>(pinned_status_block());
+        a.close_ticket = close_ticket = next_ticket();
+        a.close_tol = d.tol;
+        a.close_floor_ok = (a.iters - 1 >= std::min(10, d.max_iter - 1)) ? 1 : 0;
+      }
       rc = onchip5_launch(pl.R4, a, oc_nwg, st);  // (d.oc_gbuf was cleared together with the control block)
+      if (rc != LO_OK) {
+        close_in_kernel = false;
+        a.close_gran = nullptr;
+      }
       if (rc == LO_OK) {
         serial_done = true;
         exec.serial_engine = LO_ENGINE_RESIDENT_ROOT;
@@ -974,9 +1004,10 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       }
       // (with tridiagonals k_oc_tridiag follows and does not touch the control block: the mirror is final either way)
       CgCtrl* mirror = static_cast<CgCtrl*>(pinned_status_block());
-      const unsigned ticket = next_ticket();
-      hipLaunchKernelGGL(k_cg_ctrl_onchip, dim3(1), block, 0, st, d, d.oc_resid, d.oc_init_conv, a.iters, ktri, mirror,
-                         ticket);
+      const unsigned ticket = close_in_kernel ? close_ticket : next_ticket();
+      if (!close_in_kernel)
+        hipLaunchKernelGGL(k_cg_ctrl_onchip, dim3(1), block, 0, st, d, d.oc_resid, d.oc_init_conv, a.iters, ktri, mirror,
+                           ticket);
       if (ktri) hipLaunchKernelGGL(k_oc_tridiag, dim3(tri_grid), block, 0, st, d, d.oc_ab, ktri);
       LO_LAUNCH_CHECK();
       if (mirror) {
@@ -1031,8 +1062,9 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   }
   if (!oc_redo) break;
   {  // second pass: control block and granules as at the start of the solve
-    const size_t span = (size_t)(reinterpret_cast<char*>(d.oc_gbuf) - reinterpret_cast<char*>(d.ctrl)) + onchip_gbuf_bytes(66);
-    LO_HIP_CHECK(hipMemsetAsync(d.ctrl, 0, span, st));
+    const size_t span = (size_t)(reinterpret_cast<char*>(d.oc_close + B + 2) - reinterpret_cast<char*>(d.ctrl));
+    rc = zero_span(d.ctrl, span, st);
+    if (rc) return rc;
     memset(&h, 0, sizeof(h));
   }
   }  // oc_pass

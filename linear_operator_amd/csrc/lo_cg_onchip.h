@@ -6,6 +6,8 @@
 
 namespace lo {
 
+struct CgCtrl;
+
 struct OnchipArgs {
   const float* C;     // [B, N, RC]   (padded rank RC)
   const float* Q;     // [B, N, RK]
@@ -38,6 +40,17 @@ struct OnchipArgs {
   int* next_member;   // second generation: shared counter of the dynamic member hand-out (zeroed by the host)
   int prefetch;          // first generation only: pull the next member's rows into L2 while iterating
   int allow_l2_handoff;  // 1: use the verified same-XCD L2 hand-off when the placement check passes
+  // In-kernel closing step of k_cg_onchip5 (one column, no tridiagonals, this launch is the whole resident phase): every
+  // member leaves {final residual norm | tag + flags} as one 8-byte granule, the workgroup that finishes last evaluates the
+  // stop rule / NaN / skip conditions of k_cg_ctrl_onchip over them and mirrors the control block to the host -- the
+  // separate control launch (4 us + a dependent-launch gap) disappears.  close_gran == nullptr: the host launches it.
+  unsigned long long* close_gran;  // [B], zeroed together with the control block
+  int* close_count;                // groups that have finished, zeroed together with the control block
+  struct CgCtrl* close_ctrl;       // device control block
+  struct CgCtrl* close_mirror;     // pinned host copy (or nullptr)
+  unsigned close_ticket;
+  float close_tol;                 // tolerance (< 0: the host decides -- batch-global rule over ranks)
+  int close_floor_ok;              // iters - 1 >= min(10, max_iter - 1)
   long long* dbg;  // optional timestamps (wall_clock64) of member dbg_member / its workgroup 0, or nullptr
   int dbg_member;
 };

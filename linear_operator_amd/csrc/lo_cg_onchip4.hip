@@ -557,6 +557,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
       // first-wave state of the recurrences (uniform scalars replicated in the lanes; t_old = C^T p_old in lane j < RC)
       float t_old = 0.f, tt_old = 0.f, dpp = 0.f, rz = 0.f, alpha = 0.f, beta = 0.f, rn = 0.f;
       float w_reg = 0.f;  // (WR: w_j in lane j of both halves, carried by the recurrence)
+      unsigned close_flags = 0u;  // bit 0: converged before the first iteration, bit 1: NaN after the first product
       bool conv = false;
       // one reduction: w = C^T (r / d), s1, s2, rp; then (first wave) the small algebra; k = -1 marks the initial one
       auto reduce_and_post = [&](int k) {
@@ -682,7 +683,9 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
             beta = 0.f;
             rn = rnn;
             if (wig == 0 && t == 0) a.init_conv[bc] = (rn < a.stop_after) ? 1 : 0;  // :204-205
+            close_flags = (rn < a.stop_after) ? 1u : 0u;
           }
+          if (k == 0 && rnn != rnn) close_flags |= 2u;  // (NaN after the first product, linear_cg.py:199-200)
           conv = rn < a.stop_after;                          // :300
           rz = rzn;
           const float dzz = pre ? fmaf(-2.f, wv, s2) + vev : s2;
@@ -805,11 +808,75 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
         a.beta[bc] = beta;
         a.resid_norm[bc] = rn;
         a.has_conv[bc] = conv ? 1 : 0;
+        if (!MC && a.close_gran) {  // this member's line of the closing step: one never-torn 8-byte store
+          const unsigned long long gr =
+              ((unsigned long long)(0x80000000u | close_flags) << 32) | (unsigned long long)__float_as_uint(rn);
+          __hip_atomic_store(a.close_gran + b, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       __syncthreads();
     }  // columns
     if (stamp) a.dbg[4] = wall_clock64();
     b = b_next;
+  }
+  // ---- closing step: the first workgroup of the group that finishes LAST does what k_cg_ctrl_onchip does ----
+  if (!MC && a.close_gran && wig == 0) {
+    __shared__ int closer_s;
+    __shared__ float red_s[R4_TPB];
+    if (t == 0) closer_s = (atomicAdd(a.close_count, 1) == ngroups - 1) ? 1 : 0;
+    __syncthreads();
+    if (closer_s) {
+      // (the other groups' granules were stored before their counter increments, but nothing orders the two for us:
+      //  every granule is polled until its tag is there -- no fence anywhere)
+      float lsum = 0.f, lnan = 0.f, lnotconv = 0.f;
+      unsigned spin = 0;
+      bool lost = false;
+      for (int64_t i = t; i < a.B && !lost; i += R4_TPB) {
+        unsigned long long gr;
+        for (;;) {
+          gr = __hip_atomic_load(a.close_gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)(gr >> 32) & 0x80000000u) break;
+          if (++spin > R4_MAXSPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            lost = true;  // a group gave up (hand-off timeout): its members never arrive -- the host redoes the solve
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (lost) break;
+        const float rn = __uint_as_float((unsigned)(gr & 0xffffffffull));
+        const unsigned fl = (unsigned)(gr >> 32);
+        lsum += rn;
+        if (rn != rn || (fl & 2u)) lnan = 1.f;
+        if (!(fl & 1u)) lnotconv = 1.f;
+      }
+      if (lost) atomicExch(a.err, 1);
+      const float mean = block_sum256(lsum, red_s) / (float)a.B;   // (the summation order of k_cg_ctrl_onchip)
+      const float anynan = block_sum256(lnan, red_s);
+      const float notconv = block_sum256(lnotconv, red_s);
+      if (t == 0) {
+        CgCtrl* c = a.close_ctrl;
+        c->iterations = a.iters;
+        c->mean_resid = mean;
+        if (anynan > 0.f) {
+          c->nan_detected = 1;
+          c->stop = 1;
+        } else if (notconv == 0.f) {                 // every column converged before the first iteration (:207-208)
+          c->skipped = 1;
+          c->iterations = 0;
+          c->stop = 1;
+        } else if (a.close_floor_ok && mean < a.close_tol) {
+          c->tol_reached = 1;
+          c->stop = 1;
+        }
+        c->oc_err = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.close_mirror) {
+          *a.close_mirror = *c;
+          __threadfence_system();
+          __hip_atomic_store(reinterpret_cast<unsigned*>(a.close_mirror) + 63, a.close_ticket, __ATOMIC_RELEASE,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
   }
 }
 
