@@ -98,36 +98,56 @@ def woodbury_fp64_rel_err(Cm, d, rhs, x, chunk=64):
     return worst
 
 
-def cpu_baseline(seconds_budget=12.0, device=None):
-    """The numpy oracle (kind 'port') on a bounded sample of the same workload, host cores.  The same leg also holds the
-    parity sample of the line (`parity_sample`): the HIP path against the oracle on IDENTICAL inputs -- solve rel-err,
-    logdet rel-err with identical probes and preconditioner (BASELINE.json's metric names it), pivots."""
+def cpu_baseline(seconds_budget=10.0, device=None):
+    """The CPU restatement of the path (kind 'port') timed on the host cores on a bounded sample of the same workload:
+    the C oracle (oracle/lo_oracle_c.c: linear_cg with the rank-15 pivoted-Cholesky preconditioner, OpenMP over the
+    members, every core) on 128 of the 512 members; the numpy oracle's rate on 8 members beside it.  The same leg also
+    holds the parity sample of the line (`parity_sample`): the HIP path against the numpy oracle on IDENTICAL inputs --
+    solve rel-err, logdet rel-err with identical probes and preconditioner (BASELINE.json's metric names it), pivots."""
     import cases
     import numpy as np
     from oracle import lo_oracle as orc
+    from oracle import lo_oracle_c as occ
 
-    try:
-        from threadpoolctl import threadpool_info
-
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:  # noqa: BLE001
-        threads = os.cpu_count() or 1
+    Bc = 128
+    Cc, dc, rc_ = cases.lowrank_diag(4242, Bc, N, R, C_COLS)
     Bs = 8
-    Cs, ds, rs = cases.lowrank_diag(4242, Bs, N, R, C_COLS)
+    Cs, ds, rs = Cc[:Bs], dc[:Bs], rc_[:Bs]
+    # ---- C oracle, all cores ----
+    op_c = occ.lowrank_diag(Cc, dc)
+    Lc, piv_c = occ.pivoted_cholesky(occ.lowrank_diag(Cc), RANK_K)
+    pre_c = occ.Preconditioner(Lc, dc)
+    x_c, _, info_c = occ.linear_cg(op_c, rc_, pre=pre_c, tolerance=TOL)  # warm up
+    t0 = time.perf_counter()
+    reps_c, mv_c = 0, 0
+    while time.perf_counter() - t0 < seconds_budget:
+        _, _, info_c = occ.linear_cg(op_c, rc_, pre=pre_c, tolerance=TOL)
+        mv_c += Bc * info_c.matvecs
+        reps_c += 1
+    dt_c = time.perf_counter() - t0
+    # ---- numpy oracle (the restatement the parity tests use), a few seconds ----
     L, piv = orc.pivoted_cholesky(orc.LowRankRowSource(Cs), RANK_K)
     pre = orc.Preconditioner(L, ds)
     mm = lambda v: orc.matvec_lowrank_diag(Cs, ds, v)  # noqa: E731
     x_ref, _, _ = orc.linear_cg(mm, rs, tolerance=TOL, preconditioner=pre.apply)  # warm up
     t0 = time.perf_counter()
     reps, mv = 0, 0
-    while time.perf_counter() - t0 < seconds_budget:
+    while time.perf_counter() - t0 < 3.0:
         _, _, info = orc.linear_cg(mm, rs, tolerance=TOL, preconditioner=pre.apply)
         mv += Bs * info.matvecs
         reps += 1
     dt = time.perf_counter() - t0
-    out = {"value": mv / dt, "unit": "member-matvecs/s", "cores": int(threads), "kind": "port",
-           "sample": f"{reps} x oracle linear_cg on {Bs} of the {B_PER_GPU} members (same N={N}, R={R}, c={C_COLS}, "
-                     f"rank-{RANK_K} preconditioner, tol {TOL}); reference counts {11 + 1} products per solve"}
+    c_vs_numpy = float(np.max(np.linalg.norm((x_c[:Bs] - x_ref).reshape(Bs, -1), axis=1) /
+                              np.linalg.norm(x_ref.reshape(Bs, -1), axis=1)))
+    out = {"value": mv_c / dt_c, "unit": "member-matvecs/s", "cores": occ.num_threads(), "kind": "port",
+           "sample": f"{reps_c} x C oracle (oracle/lo_oracle_c.c, OpenMP over members) linear_cg on {Bc} of the "
+                     f"{B_PER_GPU} members (same N={N}, R={R}, c={C_COLS}, rank-{RANK_K} pivoted-Cholesky preconditioner, "
+                     f"tol {TOL}) in {dt_c:.1f} s; the reference counts {11 + 1} products per solve (it also spends one "
+                     "on A x0)",
+           "numpy_oracle_value": mv / dt,
+           "numpy_oracle_sample": f"{reps} x numpy oracle linear_cg on {Bs} members in {dt:.1f} s",
+           "c_vs_numpy_oracle_solve_rel_err": c_vs_numpy,
+           "c_vs_numpy_oracle_pivots_equal": bool(np.array_equal(piv_c[:Bs], np.asarray(piv)))}
     if device is not None:  # ---- parity sample: the HIP path on the oracle's very inputs ----
         Pn = 16
         Ct, dt_, rt = (torch.from_numpy(a).to(device) for a in (Cs, ds, rs))
