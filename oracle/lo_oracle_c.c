@@ -27,12 +27,25 @@
 #include <omp.h>
 #endif
 
+/* Threads a parallel region over `work` independent members uses: never more than the members, never more than the
+ * limit the host wrapper derived from the CPUs this process may actually run on (affinity mask / cgroup quota -- the
+ * container of a GPU box may see 128 cores and own a few; 128 spinning OpenMP threads on them ran 100x slower). */
+static int g_thread_limit = 0;
+int lo_cpu_set_num_threads(int n) {
+  g_thread_limit = n > 0 ? n : 0;
+  return LO_OK;
+}
 int lo_cpu_num_threads(void) {
 #if defined(_OPENMP)
-  return omp_get_max_threads();
+  const int m = omp_get_max_threads();
+  return (g_thread_limit > 0 && g_thread_limit < m) ? g_thread_limit : m;
 #else
   return 1;
 #endif
+}
+static int nthr(int64_t work) {
+  const int t = lo_cpu_num_threads();
+  return (int)(work < t ? (work < 1 ? 1 : work) : t);
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -160,7 +173,7 @@ int lo_cpu_matvec_f32(const lo_op_desc* op, const float* v, float* y, int64_t c)
   const int64_t B = op->B, N = op->N;
   const size_t nt = op_tmp_floats(op, c);
   int bad = 0;
-#pragma omp parallel
+#pragma omp parallel num_threads(nthr(B))
   {
     float* tmp = (float*)malloc(sizeof(float) * nt);
     if (!tmp) {
@@ -226,7 +239,7 @@ int lo_cpu_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float er
     return LO_ERR_WORKSPACE;
   }
   memset(L_rows, 0, sizeof(float) * (size_t)B * max_rank * N); /* :36-42 */
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthr(B))
   for (int64_t b = 0; b < B; ++b) {
     float mx = -INFINITY, l1 = 0.f;
     for (int64_t i = 0; i < N; ++i) {
@@ -251,7 +264,7 @@ int lo_cpu_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float er
       }
       if (m >= rank || anynan || !(emax > error_tol)) break;
     }
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthr(B))
     for (int64_t b = 0; b < B; ++b) {
       int64_t* pi = perm + (size_t)b * N;
       float* dg = diag + (size_t)b * N;
@@ -311,7 +324,7 @@ int lo_cpu_precond_build_f32(const float* L, const float* d, int32_t diag_mode, 
   if (!L || !d || !Q || !dinv || !logdet_p || B < 1 || N < 1 || k < 1 || k > 256) return LO_ERR_BADARG;
   if (diag_mode != LO_DIAG_FULL && diag_mode != LO_DIAG_CONST) return LO_ERR_BADARG;
   int bad = 0;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthr(B))
   for (int64_t b = 0; b < B; ++b) {
     double* G = (double*)calloc((size_t)k * k, sizeof(double));
     double* X = (double*)calloc((size_t)k * k, sizeof(double));
@@ -397,7 +410,7 @@ static void precond_apply_member(const lo_precond_desc* pre, int64_t b, int64_t 
 int lo_cpu_precond_apply_f32(const lo_precond_desc* pre, const float* r, float* z, int64_t B, int64_t N, int64_t c) {
   if (!pre || !pre->Q || !pre->dinv || !r || !z || pre->k < 1) return LO_ERR_BADARG;
   int bad = 0;
-#pragma omp parallel
+#pragma omp parallel num_threads(nthr(B))
   {
     float* u = (float*)malloc(sizeof(float) * (size_t)pre->k * c);
     if (!u) {
@@ -443,7 +456,7 @@ static int cg_precond(const cg_ctx* cx, const float* r, float* z) {
 
 /* out[b, j] = sum_i a[b, i, j] * bb[b, i, j] */
 static void col_dots(const float* a, const float* bb, float* out, int64_t B, int64_t N, int64_t c) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nthr(B))
   for (int64_t b = 0; b < B; ++b) {
     const float* ab = a + (size_t)b * N * c;
     const float* bp = bb + (size_t)b * N * c;
@@ -492,7 +505,7 @@ int lo_cpu_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_
     rhs_is_zero[i] = nrm < eps;
     rhs_norm[i] = rhs_is_zero[i] ? 1.0f : nrm;
   }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nthr(B))
   for (int64_t b = 0; b < B; ++b)
     for (int64_t i = 0; i < N; ++i)
       for (int64_t j = 0; j < c; ++j) {
@@ -543,7 +556,7 @@ int lo_cpu_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_
         alpha[i] = (a < eps) ? 0.f : rz[i] / a;
         if (has_conv[i]) alpha[i] = 0.f;
       }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nthr(B))
       for (int64_t b = 0; b < B; ++b)
         for (int64_t i = 0; i < N; ++i)
           for (int64_t j = 0; j < c; ++j) {
@@ -560,7 +573,7 @@ int lo_cpu_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_
         rz[i] = dots[i];
         beta[i] = (old < eps) ? 0.f : rz[i] / old;
       }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nthr(B))
       for (int64_t b = 0; b < B; ++b)
         for (int64_t i = 0; i < N; ++i)
           for (int64_t j = 0; j < c; ++j) {
@@ -614,7 +627,7 @@ int lo_cpu_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_
       for (size_t i = 0; i < ns; ++i) sum += rn[i];
       info->mean_residual = sum / (float)ns;
     }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nthr(B))
     for (int64_t b = 0; b < B; ++b)
       for (int64_t i = 0; i < N; ++i)
         for (int64_t j = 0; j < c; ++j) {

@@ -62,10 +62,38 @@ def build(force: bool = False) -> str:
     return LIB
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually run on: the affinity mask, cut by the cgroup quota if there is one (the container
+    of a GPU box can see every core of the host and own a handful)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def load():
     global _lib
     if _lib is None:
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # (idle OpenMP threads must not spin on shared cores)
         lib = C.CDLL(build())
+        lib.lo_cpu_set_num_threads.restype = C.c_int
+        lib.lo_cpu_set_num_threads.argtypes = [C.c_int]
+        lib.lo_cpu_set_num_threads(int(os.environ.get("LO_ORACLE_THREADS", usable_cpus())))
         P = C.POINTER
         lib.lo_cpu_num_threads.restype = C.c_int
         lib.lo_cpu_matvec_f32.restype = C.c_int
