@@ -65,6 +65,33 @@ void onchip_note_timeout() {
                     "off for this process (lo_cg_set_onchip(1) re-arms them)\n");
   g_onchip_disabled = true;
 }
+// The result-only ("lean") first pass is speculative: when the stop rule does not hold at the floor the launches are
+// repeated with the continuation state.  An operator that missed is likely to miss again on its next solve (same tensors,
+// same settings): remember up to 16 such (operator, shape, tolerance) signatures per thread and start those solves with
+// the state-writing pass right away; a solve that then DOES stop at the floor clears its entry.
+struct LeanMiss {
+  const void* a0;
+  const void* d;
+  int64_t B, N, c;
+  float tol;
+  int valid;
+};
+static thread_local LeanMiss tls_lean_miss[16] = {};
+static thread_local int tls_lean_miss_next = 0;
+static int lean_miss_find(const lo_op_desc* op, const lo_cg_params* prm) {
+  for (int i = 0; i < 16; ++i) {
+    const LeanMiss& m = tls_lean_miss[i];
+    if (m.valid && m.a0 == op->A0 && m.d == op->d && m.B == op->B && m.N == op->N && m.c == prm->c &&
+        m.tol == prm->tolerance)
+      return i;
+  }
+  return -1;
+}
+static void lean_miss_note(const lo_op_desc* op, const lo_cg_params* prm) {
+  if (lean_miss_find(op, prm) >= 0) return;
+  tls_lean_miss[tls_lean_miss_next] = LeanMiss{op->A0, op->d, op->B, op->N, prm->c, prm->tolerance, 1};
+  tls_lean_miss_next = (tls_lean_miss_next + 1) % 16;
+}
 static thread_local lo_cg_plan tls_last_exec = {};    // what the last lo_cg_solve_f32 of this thread actually launched
 static thread_local bool tls_no_fused_precond = false;  // set while a solve is redone after a timed-out hand-off
 
@@ -850,6 +877,9 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   const bool oc_ok = plan.resident != 0;
   int ls_cols = plan.lockstep_cols;
   bool lean = plan.lean != 0;
+  const int miss_slot = lean ? lean_miss_find(op, prm) : -1;
+  const bool lean_skipped = miss_slot >= 0 && pre && pre->Q && !getenv("LO_OC_NO_LEAN_MEMO");
+  if (lean_skipped) lean = false;  // this operator missed the floor last time: write the state in the first pass
   lo_cg_plan exec = plan;  // the plan as executed: run-time fall-backs are recorded here (lo_cg_last_executed)
   exec.resident = 0;
   exec.serial_engine = LO_ENGINE_NONE;
@@ -1043,11 +1073,13 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       if (oc_err == 0 && lean && !h.stop) {
         // the stop rule does not hold at the floor and the state was not written: the same launches once more, in full
         // (a root-form-only preconditioner cannot continue on the streaming engine anyway: the caller builds Q first)
+        lean_miss_note(op, prm);
         if (pre && !pre->Q) return LO_ERR_UNSUPPORTED;
         lean = false;
         oc_redo = true;
       } else if (oc_err == 0) {
         k_start = a.iters;
+        if (lean_skipped && h.stop) tls_lean_miss[miss_slot].valid = 0;  // (it stops at the floor now: speculate again)
         exec.resident = 1;
         exec.lockstep_cols = ls_cols;
         exec.lean = lean ? 1 : 0;
@@ -1322,6 +1354,7 @@ int lo_cg_last_executed(lo_cg_plan* out) {
 // development / test switch: force the streaming engine (0) or allow the operator-resident fast path (1)
 int lo_cg_set_onchip(int enable) {
   g_onchip_disabled = (enable == 0);
+  for (int i = 0; i < 16; ++i) tls_lean_miss[i].valid = 0;  // (also forgets which operators missed their result-only pass)
   return LO_OK;
 }
 

@@ -37,6 +37,41 @@ def _default_preconditioner(x):
     return x.clone()
 
 
+# ---- the one-launch solve is speculative: a launch whose batch-global decisions do not hold (a member stops pivoting
+# early, the tolerance is not met at the 11-iteration floor, lo_amd.h: LO_FUSED_EARLY_STOP / _CONTINUE) is discarded and the
+# three-launch path redoes everything.  A system that missed is likely to miss again (the same operator in the next
+# solve, the next step of a training loop): remember the miss and skip the speculation for the next few solves of the
+# same operator / settings, then try again.
+_FUSED_MISSES: dict = {}
+_FUSED_SKIP_AFTER_MISS = 8
+
+
+def _fused_key(desc, rhs, rank, pc_tol, tolerance, n_iter):
+    d = getattr(desc, "d", None)
+    return (desc.A0.data_ptr(), 0 if d is None else d.data_ptr(), desc.B, desc.N, desc.R, int(rhs.shape[-1]), int(rank),
+            float(pc_tol), float(tolerance), int(n_iter))
+
+
+def _fused_worth_trying(key) -> bool:
+    left = _FUSED_MISSES.get(key)
+    if left is None:
+        return True
+    if left <= 0:
+        del _FUSED_MISSES[key]  # (a retry: conditions may have changed)
+        return True
+    _FUSED_MISSES[key] = left - 1
+    return False
+
+
+def _fused_note(key, hit: bool):
+    if hit:
+        _FUSED_MISSES.pop(key, None)
+        return
+    if len(_FUSED_MISSES) >= 64:
+        _FUSED_MISSES.pop(next(iter(_FUSED_MISSES)))
+    _FUSED_MISSES[key] = _FUSED_SKIP_AFTER_MISS
+
+
 def _lower_matmul_closure(matmul_closure, batch_shape):
     """Return an OperatorDescriptor for closures we can run natively, else None."""
     if torch.is_tensor(matmul_closure):
@@ -143,12 +178,15 @@ def linear_cg(
             # this process only) pivoted Cholesky, root-form preconditioner and CG run in ONE resident launch
             if (n_tridiag == 0 and initial_guess is None and _active_stop_reduce() is None
                     and (desc is lazy.desc or lazy.same_operator(desc)) and rhs.is_cuda):
-                fused = K.solve_fused(desc, rhs, lazy.rank, lazy.tol, max_iter=n_iter, tolerance=float(tolerance),
-                                      eps=float(eps), stop_updating_after=float(stop_updating_after),
-                                      floor_max_iter=max_iter)
-                if fused is not None:
-                    lazy.adopt(fused.precond)
-                    res = fused.cg
+                key = _fused_key(desc, rhs, lazy.rank, lazy.tol, tolerance, n_iter)
+                if _fused_worth_trying(key):
+                    fused = K.solve_fused(desc, rhs, lazy.rank, lazy.tol, max_iter=n_iter, tolerance=float(tolerance),
+                                          eps=float(eps), stop_updating_after=float(stop_updating_after),
+                                          floor_max_iter=max_iter)
+                    _fused_note(key, fused is not None)
+                    if fused is not None:
+                        lazy.adopt(fused.precond)
+                        res = fused.cg
             if res is None:
                 preconditioner = lazy.materialize()  # the ordinary three-launch build (or None: NaN in the factor)
         woodbury, precond_closure = None, None

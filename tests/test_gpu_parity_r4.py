@@ -358,3 +358,54 @@ def test_lanczos_basis_view_and_native_root_epilogue(B, N, P, k):
         assert x.shape == y.shape and torch.equal(x, y)
     ref = (q_cont.double() @ evecs.double())
     assert float((a[0].double() - ref).abs().max()) < 1e-5
+
+
+def test_speculation_misses_are_remembered(monkeypatch):
+    """(i) a solve whose result-only first pass misses the stop rule at the floor starts its NEXT solve with
+    the state-writing pass (one resident launch instead of two); a solve that stops at the floor again clears the entry.
+    (ii) The one-launch `A.solve` that had to be redone by the three-launch path is not tried again for the next solves
+    of the same operator."""
+    B, N, R = 12, 8192, 32
+    C, d, rhs = cases.lowrank_diag(8899, B, N, R, 1)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    L, perm = K.pivoted_cholesky(desc, 2)
+    pre = K.precond_build(L, dev(d), constant_diag=False, root=desc.A0, perm=perm)
+
+    def launches(tol):
+        K._hip.prof_enable(True)
+        res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=tol, max_iter=200)
+        torch.cuda.synchronize()
+        prof = K._hip.prof_report()
+        K._hip.prof_enable(False)
+        return res, prof["cg_onchip"][0]
+
+    K.set_onchip_cg(True)     # (forgets earlier misses: the memo is keyed on the operator's device pointers)
+    r1, n1 = launches(1e-6)   # weak preconditioner, tolerance beyond the floor: result-only pass + repeat with the state
+    r2, n2 = launches(1e-6)   # remembered: the state-writing pass at once
+    assert (n1, n2) == (2, 1) and r1.iterations == r2.iterations and torch.equal(r1.x, r2.x)
+    r3, n3 = launches(1.0)    # another tolerance is another signature: speculation as usual, holds at the floor
+    assert n3 == 1 and r3.iterations == 11 and K.cg_last_executed()["lean"]
+    # (ii) the operator API: a hard system (rank-2 preconditioner cannot meet 1e-6 at the floor)
+    import sys
+
+    import linear_operator_amd.utils  # noqa: F401
+    lcg = sys.modules["linear_operator_amd.utils.linear_cg"]  # (the attribute of the same name is the function)
+    from linear_operator_amd.operators.added_diag_linear_operator import clear_preconditioner_memo
+
+    lcg._FUSED_MISSES.clear()
+    calls = []
+    real = K.solve_fused
+    monkeypatch.setattr(K, "solve_fused", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    import warnings
+    with settings.cg_tolerance(1e-7), settings.max_preconditioner_size(2), settings.max_cg_iterations(60), \
+            warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xs = []
+        C_t, d_t, rhs_t = desc.A0.reshape(B, N, R), dev(d), dev(rhs)  # (the operator's tensors persist, as in a training loop)
+        for _ in range(3):
+            clear_preconditioner_memo()
+            A = AddedDiagLinearOperator(LowRankRootLinearOperator(C_t), DiagLinearOperator(d_t))
+            xs.append(A.solve(rhs_t))
+    assert len(calls) == 1, f"the one-launch solve was speculated {len(calls)} times for an operator that had missed"
+    assert torch.equal(xs[0], xs[1]) and torch.equal(xs[1], xs[2])
+    lcg._FUSED_MISSES.clear()
