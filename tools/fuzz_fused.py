@@ -9,7 +9,7 @@ t_end = time.time() + float(os.environ.get("FUZZ_SECONDS", 120))
 n = bad = fallbacks = 0
 while time.time() < t_end:
     B = rng.choice([1, 2, 7, 33, 64, 65, 130, 300])
-    N = rng.choice([256, 300, 1000, 1024, 1025, 2048, 3000, 4096, 4097, 6000, 8192])
+    N = rng.choice([256, 300, 1000, 1024, 1025, 2048, 3000, 4096, 4097, 6000, 8192, 9000, 12000, 16384])
     R = rng.choice([8, 16, 32]); c = rng.randint(1, 4)
     if B * N * R > 5e7: continue
     const = rng.random() < 0.3
