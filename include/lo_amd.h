@@ -294,6 +294,18 @@ int lo_pivoted_cholesky_cb_f32(int64_t B, int64_t N, const float* diag, lo_rowfe
                                int32_t max_rank, float error_tol, float* L_rows, int64_t* perm, int32_t* rank_out,
                                void* ws, size_t ws_bytes, void* stream);
 
+/* The same in float64 (round 4): PivotedCholesky.forward is dtype-generic in the reference.  Same streaming engine and
+ * operation order; the descriptor's A0 / A1 are read as `const double*` (kinds LOWRANK / DENSE / KRON / SUM of those; d is
+ * ignored), L_rows [B, max_rank, N] double.  No operator-resident fast path.                                          */
+typedef int (*lo_rowfetch_cb_f64)(void* user, const int64_t* piv, double* rows, int64_t B, int64_t N, void* stream);
+size_t lo_pivoted_cholesky_f64_workspace_bytes(const lo_op_desc* op, int32_t max_rank);
+int lo_pivoted_cholesky_f64(const lo_op_desc* op, int32_t max_rank, double error_tol, double* L_rows, int64_t* perm,
+                            int32_t* rank_out, void* ws, size_t ws_bytes, void* stream);
+size_t lo_pivoted_cholesky_cb_f64_workspace_bytes(int64_t B, int64_t N, int32_t max_rank);
+int lo_pivoted_cholesky_cb_f64(int64_t B, int64_t N, const double* diag, lo_rowfetch_cb_f64 row_cb, void* row_user,
+                               int32_t max_rank, double error_tol, double* L_rows, int64_t* perm, int32_t* rank_out,
+                               void* ws, size_t ws_bytes, void* stream);
+
 /* ---- AddedDiagLinearOperator._init_cache* (added_diag_linear_operator.py:144-184) ------------- */
 /* From L [B,N,k] and the diagonal builds Q [B,N,k] (the reference's _q_cache, up to the sign/rotation
  * freedom of a thin QR, which Q Q^T is invariant to), dinv and logdet_p [B].

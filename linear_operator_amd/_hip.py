@@ -33,6 +33,8 @@ EXPORTS = [
     "lo_cg_f64_workspace_bytes", "lo_cg_solve_f64", "lo_minres_f64_workspace_bytes", "lo_minres_f64",
     "lo_pivoted_cholesky_workspace_bytes", "lo_pivoted_cholesky_f32",
     "lo_pivoted_cholesky_cb_workspace_bytes", "lo_pivoted_cholesky_cb_f32",
+    "lo_pivoted_cholesky_f64_workspace_bytes", "lo_pivoted_cholesky_f64",
+    "lo_pivoted_cholesky_cb_f64_workspace_bytes", "lo_pivoted_cholesky_cb_f64",
     "lo_precond_build_workspace_bytes", "lo_precond_build_f32", "lo_precond_build_strided_f32",
     "lo_precond_apply_workspace_bytes", "lo_precond_apply_f32",
     "lo_precond_root_form_workspace_bytes", "lo_precond_root_form_f32",
@@ -173,6 +175,17 @@ def load():
     lib.lo_root_from_lanczos_native_f32.restype = C.c_int
     lib.lo_root_from_lanczos_native_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.lo_pivoted_cholesky_f64_workspace_bytes.restype = sz
+    lib.lo_pivoted_cholesky_f64_workspace_bytes.argtypes = [P(OpDesc), C.c_int32]
+    lib.lo_pivoted_cholesky_f64.restype = C.c_int
+    lib.lo_pivoted_cholesky_f64.argtypes = [P(OpDesc), C.c_int32, C.c_double, C.c_void_p, C.c_void_p, P(C.c_int32),
+                                            C.c_void_p, sz, C.c_void_p]
+    lib.lo_pivoted_cholesky_cb_f64_workspace_bytes.restype = sz
+    lib.lo_pivoted_cholesky_cb_f64_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
+    lib.lo_pivoted_cholesky_cb_f64.restype = C.c_int
+    lib.lo_pivoted_cholesky_cb_f64.argtypes = [C.c_int64, C.c_int64, C.c_void_p, ROWFETCH_CB, C.c_void_p, C.c_int32,
+                                               C.c_double, C.c_void_p, C.c_void_p, P(C.c_int32), C.c_void_p, sz,
+                                               C.c_void_p]
     lib.lo_cg_plan_f32.restype = C.c_int
     lib.lo_cg_plan_f32.argtypes = [P(OpDesc), P(PrecondDesc), C.c_int, C.c_int, P(CgParams), C.c_int, P(CgPlan)]
     lib.lo_cg_last_executed.restype = C.c_int

@@ -29,7 +29,9 @@ class PivotedCholesky(Function):
         else:
             # no descriptor: the reference's generic accesses -- matrix._diagonal() (:39) and one row per pivot through
             # LinearOperator.__getitem__ (:81) -- feed the same kernels; nothing is densified
-            diag = matrix._diagonal().to(torch.float32).contiguous()
+            # (float64 operators keep their dtype -- the reference is dtype-generic: lo_pivoted_cholesky_cb_f64)
+            diag = matrix._diagonal()
+            diag = (diag if diag.dtype == torch.float64 else diag.to(torch.float32)).contiguous()
             L, perm = K.pivoted_cholesky_generic(diag, matrix._get_rows, max_iter, float(error_tol))
         ctx.mark_non_differentiable(perm)
         ctx.representation_tree = representation_tree

@@ -662,21 +662,22 @@ def pivoted_cholesky_generic(diag: torch.Tensor, row_fetch: Callable, rank: int,
     host synchronisation; pivot search, Schur update and the stopping rule run in the same kernels as for lowered
     operators.  Returns (L [*batch, N, m], permutation [*batch, N])."""
     lib = _hip.load()
-    _hip.require_hip(diag)
+    f64 = diag.dtype == torch.float64  # (round 4: the reference is dtype-generic; same kernels instantiated for double)
+    _hip.require_hip(diag, dtype=diag.dtype if f64 else torch.float32)
     dev = diag.device
     bs = tuple(diag.shape[:-1])
     N = diag.shape[-1]
     d2 = _flat(diag, 1)
     B = d2.shape[0]
     max_rank = min(int(rank), N)
-    L_rows = torch.empty(B, max_rank, N, dtype=torch.float32, device=dev)
+    L_rows = torch.empty(B, max_rank, N, dtype=diag.dtype, device=dev)
     perm = torch.empty(B, N, dtype=torch.int64, device=dev)
     err = []
 
     def cb(user, piv_ptr, rows_ptr, B_, N_, stream):
         try:
             piv = _hip.as_tensor(piv_ptr, (B_,), dev, "<i8")
-            rows = _hip.as_tensor(rows_ptr, (B_, N_), dev)
+            rows = _hip.as_tensor(rows_ptr, (B_, N_), dev, "<f8" if f64 else "<f4")
             rows.copy_(row_fetch(piv.reshape(bs)).reshape(B_, N_))
             return 0
         except BaseException as e:  # noqa: BLE001 -- must not unwind through C
@@ -684,13 +685,18 @@ def pivoted_cholesky_generic(diag: torch.Tensor, row_fetch: Callable, rank: int,
             return 1
 
     c_cb = _hip.ROWFETCH_CB(cb)
-    ws = _hip.workspace(lib.lo_pivoted_cholesky_cb_workspace_bytes(B, N, max_rank), dev)
     m = C.c_int32(0)
-    rc = lib.lo_pivoted_cholesky_cb_f32(B, N, _hip.ptr(d2), c_cb, None, max_rank, float(error_tol), _hip.ptr(L_rows),
-                                        _hip.ptr(perm), C.byref(m), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev))
+    if f64:
+        ws = _hip.workspace(lib.lo_pivoted_cholesky_cb_f64_workspace_bytes(B, N, max_rank), dev)
+        rc = lib.lo_pivoted_cholesky_cb_f64(B, N, _hip.ptr(d2), c_cb, None, max_rank, float(error_tol), _hip.ptr(L_rows),
+                                            _hip.ptr(perm), C.byref(m), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev))
+    else:
+        ws = _hip.workspace(lib.lo_pivoted_cholesky_cb_workspace_bytes(B, N, max_rank), dev)
+        rc = lib.lo_pivoted_cholesky_cb_f32(B, N, _hip.ptr(d2), c_cb, None, max_rank, float(error_tol), _hip.ptr(L_rows),
+                                            _hip.ptr(perm), C.byref(m), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev))
     if err:
         raise err[0]
-    _hip.check(rc, "lo_pivoted_cholesky_cb_f32")
+    _hip.check(rc, "lo_pivoted_cholesky_cb_f64" if f64 else "lo_pivoted_cholesky_cb_f32")
     L = L_rows[:, : m.value, :].mT
     if contiguous:
         L = L.contiguous()

@@ -38,6 +38,25 @@ class WoodburyPreconditionClosure:
         return z.squeeze(-1) if is_vec else z
 
 
+class DensePreconditionClosure:
+    """The same closure for float64 operators, evaluated as the reference does (two GEMMs and an elementwise scaling on
+    the device, :135-140): Q [*batch, N, k] and the noise are float64 tensors; `woodbury` is None, so `linear_cg`
+    (lo_cg_solve_f64) calls it back per iteration."""
+
+    woodbury = None
+
+    def __init__(self, q, noise, constant_diag):
+        self.q, self.constant_diag = q, bool(constant_diag)
+        self.noise = noise.unsqueeze(-1)  # [*batch, N | 1, 1]
+
+    def __call__(self, tensor: Tensor) -> Tensor:
+        is_vec = tensor.dim() == 1
+        t = tensor.unsqueeze(-1) if is_vec else tensor
+        qqt = self.q @ (self.q.mT @ t)
+        z = (t - qqt) / self.noise if self.constant_diag else t / self.noise - qqt
+        return z.squeeze(-1) if is_vec else z
+
+
 def _rebuild_full_preconditioner(owner):
     """The full (L, Q) preconditioner of `owner` for a root-form-only one that has to grow a Q (ensure_q)."""
     closure = owner._preconditioner()[0]
@@ -272,7 +291,10 @@ class AddedDiagLinearOperator(SumLinearOperator):
                                                         self._q_cache, self._precond_logdet_cache, self._constant_diag,
                                                         self._noise)))
                 del _precond_memo[PRECONDITIONER_MEMO_SIZE:]
-        closure = WoodburyPreconditionClosure(self._woodbury, self.batch_shape)
+        if self._woodbury is None:  # float64: z = r / d - Q (Q^T r) or (r - Q Q^T r) / sigma with library GEMMs (:135-140)
+            closure = DensePreconditionClosure(self._q_cache, self._noise, self._constant_diag)
+        else:
+            closure = WoodburyPreconditionClosure(self._woodbury, self.batch_shape)
         closure.piv_chol, closure.piv_perm = self._piv_chol_self, getattr(self, "_piv_chol_perm", None)
         return closure, self._precond_lt, self._precond_logdet_cache
 
@@ -315,8 +337,29 @@ class AddedDiagLinearOperator(SumLinearOperator):
         first = noise[..., :1]
         self._constant_diag = bool(torch.equal(noise, first.expand_as(noise)))
         self._noise = first if self._constant_diag else noise
+        if L.is_cuda and L.dtype == torch.float64:
+            # float64 operators (round 4): the factor comes from the float64 instantiation of the pivoted-Cholesky
+            # kernels; the thin QR of _init_cache* is the LAPACK call the reference itself makes (:161-184), on the
+            # device, and the apply is two library GEMMs -- not a performance path (no Woodbury descriptor: linear_cg in
+            # float64 takes the closure)
+            self._woodbury = None
+            k = L.shape[-1]
+            eye = torch.eye(k, dtype=L.dtype, device=L.device).expand(*batch_shape, k, k)
+            if self._constant_diag:
+                sig = first.unsqueeze(-1)  # [*batch, 1, 1]
+                Q, Rm = torch.linalg.qr(torch.cat((L, sig.sqrt() * eye), dim=-2))
+                self._q_cache = Q[..., :n, :]
+                logdet = Rm.diagonal(dim1=-1, dim2=-2).abs().log().sum(-1).mul(2) + (n - k) * sig[..., 0, 0].log()
+            else:
+                sq = noise.unsqueeze(-1).sqrt()
+                Q, Rm = torch.linalg.qr(torch.cat((L / sq, eye), dim=-2))
+                self._q_cache = Q[..., :n, :] / sq
+                logdet = Rm.diagonal(dim1=-1, dim2=-2).abs().log().sum(-1).mul(2) + noise.log().sum(-1)
+            self._precond_logdet_cache = logdet.view(*batch_shape) if len(batch_shape) else logdet.squeeze()
+            self._precond_lt = PsdSumLinearOperator(RootLinearOperator(L), self._diag_tensor)  # :159
+            return
         if not (L.is_cuda and L.dtype == torch.float32):
-            raise K._hip.HipExtensionError("the preconditioner cache is built by liblo_amd: fp32 HIP tensors only")
+            raise K._hip.HipExtensionError("the preconditioner cache is built by liblo_amd: fp32 / fp64 HIP tensors only")
         d_arg = first[..., 0].contiguous() if self._constant_diag else noise.contiguous()
         # for a low-rank root the kernels also get the root form of the preconditioner (F = M (I + M^T E M)^-1 M^T with
         # L = C M): the operator-resident CG then needs one all-reduce per iteration and no second tall matrix

@@ -1049,8 +1049,40 @@ def g24_kronecker_256_iteration_pinned():
          x_exact=xe.astype(np.float32), checksum=cases.checksum(K1, K2, sig, rhs))
 
 
+def g25_fp64_preconditioned_path():
+    """The preconditioned path in float64 (the reference is dtype-generic; GPyTorch users often run in double):
+    pivoted Cholesky of a low-rank root and of a dense matrix, `A.solve` and `inv_quad_logdet` with injected probes of
+    AddedDiag(LowRankRoot, Diag) above `min_preconditioning_size` (N = 2048)."""
+    print("G25 float64: pivoted Cholesky, preconditioned solve, inv_quad_logdet")
+    C, d, rhs = cases.lowrank_diag(2501, 2, 2048, 16, 2, dtype=np.float64)
+    Z, Zn = cases.probes(2502, 2, 2048, 6, dtype=np.float64)
+    Lr, pr = LowRankRootLinearOperator(T(C)).pivoted_cholesky(15, return_pivots=True)
+    Kd, _, _ = cases.dense_diag(2503, 2, 300, 1, dtype=np.float64)
+    Ld, pd_ = DenseLinearOperator(T(Kd)).pivoted_cholesky(10, return_pivots=True)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+    with settings.cg_tolerance(1e-8):
+        x, spy, w = _with_spy(lambda: A.solve(T(rhs)))
+    Ap = _ProbedAddedDiag(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+    Ap._probes = (T(Z), T(Zn))
+    with settings.cg_tolerance(1e-8):
+        (iq, ld), spy2, w2 = _with_spy(lambda: Ap.inv_quad_logdet(T(rhs), logdet=True))
+    _, _, logdet_p = Ap._preconditioner()
+    dense = (T(C) @ T(C).mT) + torch.diag_embed(T(d))
+    # constant diagonal
+    dc = np.full_like(d, 0.7)
+    Ac = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), ConstantDiagLinearOperator(T(dc[:, :1].copy()), 2048))
+    with settings.cg_tolerance(1e-8):
+        xc, spyc, wc = _with_spy(lambda: Ac.solve(T(rhs)))
+    save("g25_fp64_preconditioned", L_root=Lr, piv_root=pr, L_dense=Ld, piv_dense=pd_, x=x,
+         matvecs=spy.records[0]["matvecs"], inv_quad=iq, logdet=ld, iql_matvecs=spy2.records[0]["matvecs"],
+         logdet_p=logdet_p, logdet_exact=np.linalg.slogdet(dense.numpy())[1], x_exact=np.linalg.solve(dense.numpy(), rhs),
+         x_const=xc, matvecs_const=spyc.records[0]["matvecs"], checksum=cases.checksum(C, d, rhs, Z, Kd))
+    print(f"  solve matvecs {spy.records[0]['matvecs']}, iql matvecs {spy2.records[0]['matvecs']}, const {spyc.records[0]['matvecs']}; "
+          f"logdet {ld.tolist()} exact {np.linalg.slogdet(dense.numpy())[1].tolist()}")
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g24", "g23", "g22", "g21", "g20", "g19", "g18", "g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g25", "g24", "g23", "g22", "g21", "g20", "g19", "g18", "g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
@@ -1061,7 +1093,7 @@ if __name__ == "__main__":
                      ("g18", g18_low_rank_root_added_diag_wide_root), ("g19", g19_kronecker_three_factors),
                      ("g20", g20_kronecker_structured_diag), ("g21", g21_minres_fp64),
                      ("g22", g22_kronecker_iteration_pinned), ("g23", g23_tridiag_divergence_and_tight_logdet),
-                     ("g24", g24_kronecker_256_iteration_pinned)):
+                     ("g24", g24_kronecker_256_iteration_pinned), ("g25", g25_fp64_preconditioned_path)):
         if name in todo:
             fn()
     print("done")

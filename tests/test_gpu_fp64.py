@@ -186,3 +186,52 @@ def test_fp64_is_limited_to_the_two_solvers_and_says_so():
     C = torch.randn(2, 300, 4, device="cuda", dtype=torch.float64)
     with pytest.raises(_hip.HipExtensionError):
         K.lowrank_diag_descriptor(C, None)
+
+
+def test_float64_preconditioned_path_against_the_reference_golden():
+    """Round 4: float64 operators above `min_preconditioning_size` -- pivoted Cholesky on the float64 instantiation of the
+    streaming kernels (pivots bit for bit against the real reference, golden g25), the QR preconditioner the reference
+    builds (LAPACK on the device), `A.solve` and `inv_quad_logdet` with injected probes on lo_cg_solve_f64."""
+    import cases
+    import linear_operator_amd as lo
+    from linear_operator_amd.operators import (AddedDiagLinearOperator, ConstantDiagLinearOperator, DenseLinearOperator,
+                                               DiagLinearOperator, LowRankRootLinearOperator)
+
+    g = load_golden("g25_fp64_preconditioned")
+    C, d, rhs = cases.lowrank_diag(2501, 2, 2048, 16, 2, dtype=np.float64)
+    Z, Zn = cases.probes(2502, 2, 2048, 6, dtype=np.float64)
+    Kd, _, _ = cases.dense_diag(2503, 2, 300, 1, dtype=np.float64)
+    L, piv = LowRankRootLinearOperator(dev(C)).pivoted_cholesky(15, return_pivots=True)
+    assert L.dtype == torch.float64 and np.array_equal(host(piv), g["piv_root"])
+    assert np.allclose(host(L), g["L_root"], rtol=1e-9, atol=1e-11)
+    Ld, pd_ = DenseLinearOperator(dev(Kd)).pivoted_cholesky(10, return_pivots=True)
+    assert np.array_equal(host(pd_), g["piv_dense"]) and np.allclose(host(Ld), g["L_dense"], rtol=1e-9, atol=1e-11)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C)), DiagLinearOperator(dev(d)))
+    with lo.settings.cg_tolerance(1e-8):
+        x = A.solve(dev(rhs))
+    assert x.dtype == torch.float64 and rel_err(host(x), g["x"]) < 1e-9 and rel_err(host(x), g["x_exact"]) < 1e-7
+
+    class Probed(AddedDiagLinearOperator):
+        _probes = None
+
+        def _probe_vectors_and_norms(self):
+            return self._probes
+
+    Ap = Probed(LowRankRootLinearOperator(dev(C)), DiagLinearOperator(dev(d)))
+    Ap._probes = (dev(Z), dev(Zn))
+    with lo.settings.cg_tolerance(1e-8):
+        iq, ld = Ap.inv_quad_logdet(dev(rhs), logdet=True)
+    assert np.allclose(host(iq), g["inv_quad"], rtol=1e-9) and np.allclose(host(ld), g["logdet"], rtol=1e-7, atol=1e-7)
+    Ac = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C)),
+                                 ConstantDiagLinearOperator(dev(np.full((2, 1), 0.7)), 2048))
+    with lo.settings.cg_tolerance(1e-8):
+        xc = Ac.solve(dev(rhs))
+    assert rel_err(host(xc), g["x_const"]) < 1e-9
+    # gradients through the float64 solve (library GEMM pull-backs)
+    Cg, dg = dev(C).requires_grad_(True), dev(d).requires_grad_(True)
+    Ag = AddedDiagLinearOperator(LowRankRootLinearOperator(Cg), DiagLinearOperator(dg))
+    with lo.settings.cg_tolerance(1e-10):
+        Ag.solve(dev(rhs)).sum().backward()
+    dense = (Cg.detach() @ Cg.detach().mT + torch.diag_embed(dg.detach())).requires_grad_(True)
+    torch.linalg.solve(dense, dev(rhs)).sum().backward()
+    assert torch.allclose(dg.grad, dense.grad.diagonal(dim1=-1, dim2=-2), rtol=1e-6, atol=1e-9)

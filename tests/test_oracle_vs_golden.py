@@ -812,3 +812,25 @@ def test_g24_kronecker_256_iteration_pinned():
                              tolerance=0.0, max_iter=its)
     assert info.iterations == its == 137
     assert max_rel_err_cols(x, g["x_pinned"]) < 1e-4
+
+
+def test_g25_float64_preconditioned_path():
+    """The dtype-generic part of the path in float64 (golden g25 from the real reference): pivots bit for bit, the factor
+    and the preconditioned solve / inv_quad_logdet to float64 accuracy."""
+    g = load_golden("g25_fp64_preconditioned")
+    C, d, rhs = cases.lowrank_diag(2501, 2, 2048, 16, 2, dtype=np.float64)
+    Z, _ = cases.probes(2502, 2, 2048, 6, dtype=np.float64)
+    Kd, _, _ = cases.dense_diag(2503, 2, 300, 1, dtype=np.float64)
+    _check_inputs(g, C, d, rhs, Z, Kd)
+    L, piv = orc.pivoted_cholesky(orc.LowRankRowSource(C), 15)
+    assert L.dtype == np.float64 and np.array_equal(piv, g["piv_root"]) and np.allclose(L, g["L_root"], rtol=1e-9, atol=1e-11)
+    Ld, pd_ = orc.pivoted_cholesky(orc.DenseRowSource(Kd), 10)
+    assert np.array_equal(pd_, g["piv_dense"]) and np.allclose(Ld, g["L_dense"], rtol=1e-9, atol=1e-11)
+    x, info, pre = orc.solve(lambda v: orc.matvec_lowrank_diag(C, d, v), orc.LowRankRowSource(C), d, rhs, tolerance=1e-8)
+    assert info.matvecs == int(g["matvecs"]) and max_rel_err_cols(x, g["x"]) < 1e-9
+    assert max_rel_err_cols(x, g["x_exact"]) < 1e-7
+    iq, ld, _, _, info2, pre2 = orc.inv_quad_logdet(lambda v: orc.matvec_lowrank_diag(C, d, v), orc.LowRankRowSource(C), d,
+                                                   rhs, Z, tolerance=1e-8)
+    assert info2.matvecs == int(g["iql_matvecs"])
+    assert np.allclose(pre2.logdet, g["logdet_p"], rtol=1e-10) and np.allclose(iq.sum(-1), g["inv_quad"], rtol=1e-9)
+    assert np.allclose(ld, g["logdet"], rtol=1e-7, atol=1e-7)
