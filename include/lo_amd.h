@@ -479,6 +479,18 @@ int lo_minres_f64(const double* A, const double* diag, lo_matvec_cb_f64 matvec, 
                   const double* rhs, const double* shifts, double* x, void* ws, size_t ws_bytes,
                   lo_minres_info_f64* info, void* stream);
 
+/* lanczos_tridiag (utils/lanczos.py:9-164) with float64 operands: the reference is dtype-generic and its
+ * root_decomposition / Lanczos callers may hand it doubles.  Streaming formulation (csrc/lo_lanczos_f64.hip).
+ *   A [B,N,N] (+ diag [B,N]) or matvec   the operator, as lo_cg_solve_f64
+ *   init_vecs [B,N,P]                     start block (normalised per column inside, :81)
+ *   q_mat [max_iter,B,N,P], t_mat [max_iter,max_iter,B,P]   working order, as lo_lanczos_tridiag_f32; the first
+ *   *iters_out vectors / rows+columns are the result (:151)
+ * Reads two integers back per step (the reference's re-orthogonalisation and stopping tests), so it synchronises.  */
+size_t lo_lanczos_f64_workspace_bytes(int64_t B, int64_t N, int64_t P, int32_t max_iter);
+int lo_lanczos_tridiag_f64(const double* A, const double* diag, lo_matvec_cb_f64 matvec, void* matvec_user,
+                           const double* init_vecs, int64_t B, int64_t N, int64_t P, int32_t max_iter, double tol,
+                           double* q_mat, double* t_mat, int32_t* iters_out, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- measurement aid (no reference counterpart) ------------------------------------------------ */
 /* Opt-in HIP-event timing of every kernel launch of the library, recorded on the launch stream.
  * lo_prof_report writes "name count total_ms" lines into buf (returns the byte count) and resets.

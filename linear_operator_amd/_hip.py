@@ -19,7 +19,7 @@ _lib = None
 LO_OP_LOWRANK_DIAG, LO_OP_DENSE_DIAG, LO_OP_KRON_DIAG, LO_OP_CALLBACK, LO_OP_SUM = 0, 1, 2, 3, 4
 LO_MAX_TERMS = 4
 LO_DIAG_NONE, LO_DIAG_FULL, LO_DIAG_CONST = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 LO_ERR_UNSUPPORTED = -4
 LO_FUSED_OK, LO_FUSED_EARLY_STOP, LO_FUSED_CONTINUE, LO_FUSED_TIMEOUT = 0, 1, 2, 3
@@ -41,6 +41,7 @@ EXPORTS = [
     "lo_precond_kron_root_workspace_bytes", "lo_precond_kron_root_f32",
     "lo_lanczos_workspace_bytes", "lo_lanczos_tridiag_f32", "lo_lanczos_permute_f32",
     "lo_root_from_lanczos_f32", "lo_root_from_lanczos_native_f32",
+    "lo_lanczos_f64_workspace_bytes", "lo_lanczos_tridiag_f64",
     "lo_tridiag_eigh_slq_workspace_bytes", "lo_tridiag_eigh_slq_f32",
     "lo_bilinear_dense_f32", "lo_bilinear_diag_f32", "lo_bilinear_root_workspace_bytes", "lo_bilinear_root_f32",
     "lo_bilinear_kron_workspace_bytes", "lo_bilinear_kron_f32",
@@ -206,6 +207,12 @@ def load():
     lib.lo_cg_solve_f64.argtypes = [C.c_void_p, C.c_void_p, MATVEC_CB, C.c_void_p, MATVEC_CB, C.c_void_p,
                                     P(CgParamsF64), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, sz, P(CgInfoF64), C.c_void_p]
+    lib.lo_lanczos_f64_workspace_bytes.restype = sz
+    lib.lo_lanczos_f64_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int32]
+    lib.lo_lanczos_tridiag_f64.restype = C.c_int
+    lib.lo_lanczos_tridiag_f64.argtypes = [C.c_void_p, C.c_void_p, MATVEC_CB, C.c_void_p, C.c_void_p, C.c_int64,
+                                           C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p,
+                                           P(C.c_int32), C.c_void_p, C.c_size_t, C.c_void_p]
     lib.lo_minres_f64_workspace_bytes.restype = sz
     lib.lo_minres_f64_workspace_bytes.argtypes = [C.c_int64, C.c_int64, P(MinresParamsF64)]
     lib.lo_minres_f64.restype = C.c_int

@@ -898,6 +898,58 @@ def lanczos_tridiag(desc: Optional[OperatorDescriptor], init_vecs: torch.Tensor,
     return q_out, t_out
 
 
+def lanczos_tridiag_f64(A: Optional[torch.Tensor], diag: Optional[torch.Tensor], init_vecs: torch.Tensor,
+                        max_iter: int, tol: float = 1e-5, matvec_closure: Optional[Callable] = None):
+    """lo_lanczos_tridiag_f64: utils/lanczos.py:9-164 with float64 operands (the reference is dtype-generic).  `A`
+    [*batch, N, N] (+ `diag` [*batch, N]) is multiplied by the library's fp64 kernel, otherwise `matvec_closure` is
+    called back once per step.  Same return shapes as `lanczos_tridiag`; q_mat is the permuted view of the basis."""
+    lib = _hip.load()
+    _hip.require_hip(init_vecs, A, diag, dtype=torch.float64)
+    N, P = init_vecs.shape[-2:]
+    batch = tuple(init_vecs.shape[:-2])
+    v3 = _flat(init_vecs, 2)
+    B = v3.shape[0]
+    dev = init_vecs.device
+    A3 = d2 = None
+    err = []
+    cb = _hip.MATVEC_CB()
+    if A is not None:
+        A3 = A.expand(*batch, N, N).reshape(B, N, N).contiguous()
+        d2 = None if diag is None else diag.expand(*batch, N).reshape(B, N).contiguous()
+    elif matvec_closure is None:
+        raise ValueError("need a dense fp64 operator or a matvec closure")
+    else:
+        def _cb(user, v_ptr, y_ptr, B_, N_, c_, stream):
+            try:
+                v = _hip.as_tensor(v_ptr, (B_, N_, c_), dev, "<f8")
+                y = _hip.as_tensor(y_ptr, (B_, N_, c_), dev, "<f8")
+                y.copy_(matvec_closure(v.reshape(*batch, N_, c_)).reshape(B_, N_, c_))
+                return 0
+            except BaseException as e:  # noqa: BLE001 -- must not unwind through C
+                err.append(e)
+                return 1
+
+        cb = _hip.MATVEC_CB(_cb)
+    max_iter = int(max_iter)
+    q = torch.empty(max_iter, B, N, P, dtype=torch.float64, device=dev)
+    t = torch.empty(max_iter, max_iter, B, P, dtype=torch.float64, device=dev)
+    ws = _hip.workspace(lib.lo_lanczos_f64_workspace_bytes(B, N, P, max_iter), dev)
+    iters = C.c_int32(0)
+    rc = lib.lo_lanczos_tridiag_f64(_hip.ptr(A3), _hip.ptr(d2), cb, None, _hip.ptr(v3), B, N, P, max_iter, float(tol),
+                                    _hip.ptr(q), _hip.ptr(t), C.byref(iters), _hip.ptr(ws), ws.numel(),
+                                    _hip.stream_ptr(dev))
+    for e in err:
+        raise e
+    _hip.check(rc, "lo_lanczos_tridiag_f64")
+    k = iters.value
+    nb = len(batch)
+    q_out = q[:k].reshape(k, *batch, N, P).permute(-1, *range(1, 1 + nb), -2, 0)
+    t_out = t[:k, :k].reshape(k, k, *batch, P).permute(-1, *range(2, 2 + nb), 0, 1).contiguous()
+    if P == 1:
+        q_out, t_out = q_out[0], t_out[0]
+    return q_out, t_out
+
+
 def _native_lanczos_layout(q_mat: torch.Tensor):
     """(P, B) if q_mat [P, *batch, N, k] is the permuted view `lanczos_tridiag` returns of a basis stored [k, B, N, P]
     (element (p, b, n, a) at ((a B + b) N + n) P + p from its first element), else None.  Size-1 dimensions carry no

@@ -42,6 +42,11 @@ def lanczos_tridiag(
         settings.verbose_linalg.logger.debug(
             f"Running Lanczos on a {matrix_shape} matrix with a {init_vecs.shape} RHS for {num_iter} iterations."
         )
+    if init_vecs.dtype == torch.float64:  # the reference is dtype-generic; fp64 runs csrc/lo_lanczos_f64.hip
+        if torch.is_tensor(matmul_closure):
+            return K.lanczos_tridiag_f64(matmul_closure, None, init_vecs.contiguous(), num_iter, tol=tol)
+        return K.lanczos_tridiag_f64(None, None, init_vecs.contiguous(), num_iter, tol=tol,
+                                     matvec_closure=matmul_closure)
     desc = _lower_matmul_closure(matmul_closure, init_vecs.shape[:-2])
     closure = None
     if desc is None:

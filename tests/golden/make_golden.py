@@ -1081,8 +1081,37 @@ def g25_fp64_preconditioned_path():
           f"logdet {ld.tolist()} exact {np.linalg.slogdet(dense.numpy())[1].tolist()}")
 
 
+def g26_lanczos_fp64():
+    """lanczos_tridiag and RootDecomposition.forward in float64: the test_lanczos.py:42-48 recipe at N = 100 run to
+    completion, a batched dense operator with three start vectors stopped after 16 steps, and the root / inverse root
+    of AddedDiag(LowRankRoot, Diag) from 14 steps."""
+    from linear_operator.functions._root_decomposition import RootDecomposition
+
+    print("G26 float64 lanczos_tridiag / RootDecomposition")
+    dev = torch.device("cpu")
+    M = cases.spd_test_matrix(2601, 100, dtype=np.float64, jitter=1e-6)
+    v0 = cases.randn(2602, 100, 1, dtype=np.float64)
+    q, t = lanczos_tridiag(T(M).matmul, max_iter=100, dtype=torch.float64, device=dev, matrix_shape=M.shape,
+                           init_vecs=T(v0))
+    Kd, _, _ = cases.dense_diag(2603, 2, 300, 1, dtype=np.float64)
+    V = cases.randn(2604, 2, 300, 3, dtype=np.float64)
+    qb, tb = lanczos_tridiag(T(Kd).matmul, max_iter=16, dtype=torch.float64, device=dev, matrix_shape=Kd.shape[-2:],
+                             batch_shape=torch.Size([2]), init_vecs=T(V))
+    C, d, _ = cases.lowrank_diag(2605, 2, 512, 8, 1, dtype=np.float64)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(T(C)), DiagLinearOperator(T(d)))
+    v1 = cases.randn(2606, 2, 512, 1, dtype=np.float64)
+    tv = cases.randn(2607, 2, 512, 2, dtype=np.float64)
+    root, inv = RootDecomposition.apply(A.representation_tree(), 14, A.dtype, A.device, A.batch_shape, A.matrix_shape,
+                                        True, True, T(v1), *A.representation())
+    dense = T(C) @ T(C).mT + torch.diag_embed(T(d))
+    save("g26_lanczos_fp64", q_near=q, t_near=t, q_batch=qb, t_batch=tb, rrt_tv=root @ (root.mT @ T(tv)),
+         iit_tv=inv @ (inv.mT @ T(tv)), A_tv=dense @ T(tv), Ainv_tv=np.linalg.solve(dense.numpy(), tv),
+         checksum=cases.checksum(M, v0, Kd, V, C, d, v1, tv))
+    print(f"  near {tuple(t.shape)}, batch {tuple(tb.shape)}, root {tuple(root.shape)}")
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g25", "g24", "g23", "g22", "g21", "g20", "g19", "g18", "g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g26", "g25", "g24", "g23", "g22", "g21", "g20", "g19", "g18", "g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
@@ -1093,7 +1122,8 @@ if __name__ == "__main__":
                      ("g18", g18_low_rank_root_added_diag_wide_root), ("g19", g19_kronecker_three_factors),
                      ("g20", g20_kronecker_structured_diag), ("g21", g21_minres_fp64),
                      ("g22", g22_kronecker_iteration_pinned), ("g23", g23_tridiag_divergence_and_tight_logdet),
-                     ("g24", g24_kronecker_256_iteration_pinned), ("g25", g25_fp64_preconditioned_path)):
+                     ("g24", g24_kronecker_256_iteration_pinned), ("g25", g25_fp64_preconditioned_path),
+                     ("g26", g26_lanczos_fp64)):
         if name in todo:
             fn()
     print("done")

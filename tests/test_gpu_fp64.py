@@ -180,6 +180,55 @@ def test_fp64_minres_matches_the_reference_recipes():
             assert rel_err(host(x), g[f"x_{tag}"]) < 1e-9, tag
 
 
+def test_float64_lanczos_and_root_decomposition_against_the_reference_golden():
+    """Round 4: lanczos_tridiag in float64 (csrc/lo_lanczos_f64.hip) against the real reference's outputs (golden g26):
+    dense tensor operator, batched with three start vectors, closure operator, and RootDecomposition's roots."""
+    import cases
+    from linear_operator_amd.functions._root_decomposition import RootDecomposition
+    from linear_operator_amd.operators import AddedDiagLinearOperator, DiagLinearOperator, LowRankRootLinearOperator
+    from linear_operator_amd.utils import lanczos
+
+    g = load_golden("g26_lanczos_fp64")
+    M = cases.spd_test_matrix(2601, 100, dtype=np.float64, jitter=1e-6)
+    v0 = cases.randn(2602, 100, 1, dtype=np.float64)
+    Md = dev(M)
+    for closure in (Md, Md.matmul):  # tensor operand: the library's fp64 matvec; callable: called back per step
+        q, t = lanczos.lanczos_tridiag(closure, max_iter=100, dtype=torch.float64, device=Md.device,
+                                       matrix_shape=M.shape, init_vecs=dev(v0))
+        assert q.dtype == torch.float64 and tuple(q.shape) == g["q_near"].shape and tuple(t.shape) == g["t_near"].shape
+        q, t = host(q), host(t)
+        assert np.allclose(t[:20, :20], g["t_near"][:20, :20], rtol=1e-8, atol=1e-12)
+        assert np.allclose(q @ t @ q.T, M, atol=1e-9)  # test_lanczos.py:35-36 acceptance, at double's accuracy
+        assert np.allclose(q.T @ q, np.eye(q.shape[1]), atol=1e-9)
+    Kd, _, _ = cases.dense_diag(2603, 2, 300, 1, dtype=np.float64)
+    V = cases.randn(2604, 2, 300, 3, dtype=np.float64)
+    qb, tb = lanczos.lanczos_tridiag(dev(Kd), max_iter=16, dtype=torch.float64, device=Md.device,
+                                     matrix_shape=Kd.shape[-2:], batch_shape=torch.Size([2]), init_vecs=dev(V))
+    assert tuple(qb.shape) == g["q_batch"].shape
+    assert np.allclose(host(tb), g["t_batch"], rtol=1e-9, atol=1e-12) and np.allclose(host(qb), g["q_batch"], atol=1e-9)
+    C, d, _ = cases.lowrank_diag(2605, 2, 512, 8, 1, dtype=np.float64)
+    A = AddedDiagLinearOperator(LowRankRootLinearOperator(dev(C)), DiagLinearOperator(dev(d)))
+    v1 = cases.randn(2606, 2, 512, 1, dtype=np.float64)
+    tv = dev(cases.randn(2607, 2, 512, 2, dtype=np.float64))
+    root, inv = RootDecomposition.apply(A.representation_tree(), 14, A.dtype, A.device, A.batch_shape, A.matrix_shape,
+                                        True, True, dev(v1), *A.representation())
+    assert root.dtype == torch.float64
+    assert rel_err(host(root @ (root.mT @ tv)), g["rrt_tv"]) < 1e-8
+    assert rel_err(host(inv @ (inv.mT @ tv)), g["iit_tv"]) < 1e-8
+    # and through the public entry (random start vector: accuracy against the dense matrix, not the golden)
+    from linear_operator_amd.operators import DenseLinearOperator
+
+    with lo_settings().max_cholesky_size(0), lo_settings().max_root_decomposition_size(100):
+        R = DenseLinearOperator(Md).root_decomposition().root.to_dense()
+    assert R.dtype == torch.float64 and rel_err(host(R @ R.mT), M) < 1e-8
+
+
+def lo_settings():
+    import linear_operator_amd as lo
+
+    return lo.settings
+
+
 def test_fp64_is_limited_to_the_two_solvers_and_says_so():
     from linear_operator_amd import _hip, kernels as K
 

@@ -834,3 +834,21 @@ def test_g25_float64_preconditioned_path():
     assert info2.matvecs == int(g["iql_matvecs"])
     assert np.allclose(pre2.logdet, g["logdet_p"], rtol=1e-10) and np.allclose(iq.sum(-1), g["inv_quad"], rtol=1e-9)
     assert np.allclose(ld, g["logdet"], rtol=1e-7, atol=1e-7)
+
+
+# ---------------------------------------------------------------- G26 Lanczos in float64
+def test_lanczos_fp64_against_reference():
+    """In double the recurrence is reproducible to rounding over the whole run, so the oracle is pinned entry by entry
+    (the fp32 golden above can only pin the leading block)."""
+    g = load_golden("g26_lanczos_fp64")
+    M = cases.spd_test_matrix(2601, 100, dtype=np.float64, jitter=1e-6)
+    v0 = cases.randn(2602, 100, 1, dtype=np.float64)
+    q, t = orc.lanczos_tridiag(lambda v: M @ v, 100, v0)
+    assert q.shape == g["q_near"].shape and t.shape == g["t_near"].shape
+    assert np.allclose(t[:20, :20], g["t_near"][:20, :20], rtol=1e-8, atol=1e-12)
+    assert np.allclose(q @ t @ q.T, M, atol=1e-9)
+    Kd, _, _ = cases.dense_diag(2603, 2, 300, 1, dtype=np.float64)
+    V = cases.randn(2604, 2, 300, 3, dtype=np.float64)
+    qb, tb = orc.lanczos_tridiag(lambda v: Kd @ v, 16, V)
+    assert qb.shape == g["q_batch"].shape and tb.shape == g["t_batch"].shape
+    assert np.allclose(tb, g["t_batch"], rtol=1e-9, atol=1e-12) and np.allclose(qb, g["q_batch"], atol=1e-9)
