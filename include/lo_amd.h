@@ -198,6 +198,9 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
 #define LO_STREAM_PRE_CLOSURE 2    /* opaque preconditioner closure                                              */
 #define LO_STREAM_PRE_FUSED_Q 3    /* k_precond_fused: one pass over Q, r / x / p updates fused                  */
 #define LO_STREAM_PRE_FUSED_KRON 4 /* k_precond_fused_kron: Kronecker root form, no Q traffic                    */
+#define LO_STREAM_PRE_FUSED_COLS 5 /* k_cg_step_cols: up to 32 columns, the whole step behind the product (alpha, r / x,
+                                    * Q form of the preconditioner, beta, p, control step) in one launch              */
+#define LO_STREAM_NOPRE_FUSED_COLS 6 /* the same launch without a preconditioner (z = r)                              */
 typedef struct lo_cg_plan {
   int32_t resident;             /* 1: the iterations up to the first possible stop run in operator-resident launches */
   int32_t resident_iterations;  /* how many (first_stop_iteration + 1), 0 if not resident                            */

@@ -94,7 +94,8 @@ class CgPlan(C.Structure):
 
 
 ENGINE_NAMES = {0: "none", 1: "gen1", 2: "gen2", 3: "root"}
-STREAM_PRE_NAMES = {0: "none", 1: "two_pass", 2: "closure", 3: "fused_q", 4: "fused_kron"}
+STREAM_PRE_NAMES = {0: "none", 1: "two_pass", 2: "closure", 3: "fused_q", 4: "fused_kron", 5: "fused_cols",
+                    6: "fused_cols_nopre"}
 
 
 class FusedInfo(C.Structure):

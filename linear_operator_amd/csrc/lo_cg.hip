@@ -172,6 +172,9 @@ struct CgDev {
   unsigned long long* pf_gbuf;  // granules of the fused preconditioner apply (lo_precond_fused.hip) or nullptr
   int* pf_ctr;                  // one member hand-out counter per launch of that kernel (max_iter + 1 ints)
   unsigned long long* pf_gran;  // [B] tagged residual norms of the fused control step
+  unsigned long long* sc_gbuf;  // granules of the multi-column iteration step (lo_cg_step_cols.hip) or nullptr
+  int* sc_ctr;                  // hand-out | done counters of that kernel (max_iter + 1 ints each)
+  unsigned long long* sc_gran;  // [3, B] tagged per-member aggregates of its folded control step
   int* oc_err;
   float* oc_resid;
   int* oc_init_conv;
@@ -562,7 +565,7 @@ static int padded_rank_c(int64_t R) {  // floats per row of the root as the skin
 }
 
 struct CgShape {  // what cg_layout allocates for the resident paths (it sizes the workspace from the same predicates)
-  bool oc_shape, has_ab, has_ls_gbuf, has_zero_q, pf_shape;
+  bool oc_shape, has_ab, has_ls_gbuf, has_zero_q, pf_shape, sc_shape, sc_alloc;
 };
 
 static CgShape cg_shape(const lo_op_desc* op, const lo_precond_desc* pre, bool pre_cb, const lo_cg_params* prm) {
@@ -574,6 +577,10 @@ static CgShape cg_shape(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   s.has_zero_q = !pre && !pre_cb && s.oc_shape;
   const Split sp = choose_split(B, N, 256);
   s.pf_shape = pre && precond_fused_eligible(B, N, c, padded_rank_k(pre->k), sp.S);
+  // every other streaming shape of up to 32 columns and 16384 rows: the whole step behind the product in one launch
+  const int ldq = pre ? padded_rank_k(pre->k) : 0;
+  s.sc_alloc = !s.pf_shape && ldq <= 16 && cg_step_cols_eligible(B, N, c, ldq);  // (the sizing pass assumes a closure)
+  s.sc_shape = s.sc_alloc && !pre_cb;
   return s;
 }
 
@@ -619,6 +626,10 @@ static void cg_plan(const lo_op_desc* op, const lo_precond_desc* pre, bool pre_c
                       pre->kron_b && pre->kron_F && pre->k <= 16 && !getenv("LO_NO_KRON_ROOT");
     out->streaming_precond = kron ? LO_STREAM_PRE_FUSED_KRON : LO_STREAM_PRE_FUSED_Q;
   }
+  if ((out->streaming_precond == LO_STREAM_PRE_TWO_PASS || out->streaming_precond == LO_STREAM_PRE_NONE) && sh.sc_shape &&
+      (!pre || pre->Q) && !tls_no_fused_precond && std::min(512, 2 * oc_nwg) / 8 >= cg_step_cols_group(N) &&
+      cg_step_cols_worthwhile(B, N, c, pre != nullptr))
+    out->streaming_precond = pre ? LO_STREAM_PRE_FUSED_COLS : LO_STREAM_NOPRE_FUSED_COLS;
   const bool opaque = (op->kind == LO_OP_CALLBACK) || pre_cb;
   out->poll_chunk = (opaque || global_rule) ? 1 : 4;
   // a root-form-only preconditioner cannot feed the streaming engine: without a resident kernel the caller is told to
@@ -714,6 +725,9 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   // (decided by the shape, not by the pointer: the sizing pass runs on a null arena)
   dd.pf_ctr = pf_shape ? ar.take<int>(2 * ((size_t)std::max(1, (int)prm->max_iter) + 1)) : nullptr;  // hand-out | done
   dd.pf_gran = pf_shape ? ar.take<unsigned long long>((size_t)B) : nullptr;
+  dd.sc_gbuf = shp.sc_alloc ? ar.take<unsigned long long>(cg_step_cols_gbuf_bytes() / sizeof(unsigned long long)) : nullptr;
+  dd.sc_ctr = shp.sc_alloc ? ar.take<int>(2 * ((size_t)std::max(1, (int)prm->max_iter) + 1)) : nullptr;
+  dd.sc_gran = shp.sc_alloc ? ar.take<unsigned long long>(3 * (size_t)B) : nullptr;
   dd.oc_zero_q = nullptr;
   dd.oc_ones = nullptr;
   if (shp.has_zero_q) {
@@ -1159,6 +1173,16 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   const bool pf_kron = pf_on && plan.streaming_precond == LO_STREAM_PRE_FUSED_KRON;
   if (pf_kron) kron = PfKron{pre->kron_a, pre->kron_b, pre->kron_F, (int)op->R, (int)op->n2};
   bool p_done = false;  // the fused apply of the previous iteration already wrote this iteration's p
+  // up to 32 columns, up to 16384 rows: alpha, r / x, the preconditioner, beta, p and the control step in one launch
+  bool sc_on = d.sc_gbuf && (plan.streaming_precond == LO_STREAM_PRE_FUSED_COLS ||
+                            plan.streaming_precond == LO_STREAM_NOPRE_FUSED_COLS);
+  const bool sc_dbg = sc_on && getenv("LO_SC_DEBUG") != nullptr;
+  if (sc_dbg) LO_HIP_CHECK(hipMemsetAsync(d.oc_dbg, 0, 16 * sizeof(long long), st));
+  if (sc_on) {  // cleared once per solve (tags are unique per launch)
+    LO_HIP_CHECK(hipMemsetAsync(d.sc_gbuf, 0, cg_step_cols_gbuf_bytes(), st));
+    LO_HIP_CHECK(hipMemsetAsync(d.sc_ctr, 0, sizeof(int) * 2 * ((size_t)std::max(1, (int)prm->max_iter) + 1), st));
+    LO_HIP_CHECK(hipMemsetAsync(d.sc_gran, 0, sizeof(unsigned long long) * 3 * (size_t)B, st));
+  }
   if (pf_on) {  // granules and hand-out counters of the fused apply: cleared once per solve (tags are unique per launch)
     LO_HIP_CHECK(hipMemsetAsync(d.pf_gbuf, 0, precond_fused_gbuf_bytes(), st));
     LO_HIP_CHECK(hipMemsetAsync(d.pf_ctr, 0, sizeof(int) * 2 * ((size_t)std::max(1, (int)prm->max_iter) + 1), st));
@@ -1205,6 +1229,31 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       }
       else if (rcb) return rcb;
       else {
+        pre_done = p_done = true;
+        ctrl_done = cf.on != 0;
+      }
+    }
+    if (!pre_done && sc_on) {
+      if (dyn) return LO_ERR_UNSUPPORTED;  // (not replayed as a graph node)
+      ScCtrl cf;
+      cf.on = getenv("LO_NO_FUSED_CTRL") ? 0 : 1;
+      cf.rhs_is_zero = d.rhs_is_zero; cf.beta = d.beta; cf.resid_norm = d.resid_norm;
+      cf.stop_after = d.stop_after; cf.tol = d.tol; cf.max_iter = d.max_iter;
+      cf.n_tridiag = d.n_tridiag; cf.n_tridiag_iter = d.n_tridiag_iter; cf.T = d.T; cf.t_mat = d.t_mat;
+      cf.prev_ar = d.prev_ar; cf.prev_beta = d.prev_beta; cf.check_nan_first = d.check_nan_first;
+      cf.done = d.sc_ctr + (std::max(1, (int)prm->max_iter) + 1);
+      cf.gran = d.sc_gran;
+      cf.ctrl = d.ctrl;
+      rcb = cg_step_cols(pre ? Qp : nullptr, preR4, pre ? pre->dinv : nullptr,
+                         (pre && pre->constant_diag) ? LO_DIAG_CONST : LO_DIAG_FULL, d.r, d.Ap, d.p, d.x, c, d.pAp_part,
+                         d.S_dot, d.rz, d.has_conv, d.eps, d.alpha, d.rr_part, d.rz_part, sp.S, B, N, d.sc_gbuf, d.oc_err,
+                         d.sc_ctr, kk, (int)prm->max_iter, stop, oc_nwg, &cf, sc_dbg ? d.oc_dbg : nullptr, ls);
+      if (rcb == LO_ERR_UNSUPPORTED) {  // (does not fit this device: the multi-launch path from now on)
+        sc_on = false;
+        exec.streaming_precond = pre ? LO_STREAM_PRE_TWO_PASS : LO_STREAM_PRE_NONE;
+      } else if (rcb) {
+        return rcb;
+      } else {
         pre_done = p_done = true;
         ctrl_done = cf.on != 0;
       }
@@ -1288,7 +1337,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     if (at_poll || k == prm->max_iter - 1 || (opaque && k == 0)) {
       rc = poll();
       if (rc) return rc;
-      if (pf_on && h.oc_err) break;  // a hand-off of the fused apply timed out: redo below
+      if ((pf_on || sc_on) && h.oc_err) break;  // a hand-off of the fused apply timed out: redo below
       if (k >= first_poll) {  // (one collective per iteration from the first possible stop on, on every rank)
         rc = global_check();
         if (rc) return rc;
@@ -1300,7 +1349,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     rc = poll();
     if (rc) return rc;
   }
-  if (pf_on && h.oc_err) {  // (co-residency lost -- never seen on a dedicated GPU): the two-launch path for the whole solve
+  if ((pf_on || sc_on) && h.oc_err) {  // (co-residency lost -- never seen on a dedicated GPU): the two-launch path for the whole solve
     fprintf(stderr, "liblo_amd: fused preconditioner apply timed out, redoing the solve with the two-pass kernels\n");
     tls_no_fused_precond = true;
     const int rc2 = lo_cg_solve_f32(op, matvec, matvec_user, pre, precond_cb, precond_user, prm, rhs, x0, x, t_mat, ws,
@@ -1314,6 +1363,14 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     LO_HIP_CHECK(hipStreamSynchronize(st));
   }
 
+  if (sc_dbg) {
+    long long ts[8];
+    LO_HIP_CHECK(hipMemcpy(ts, d.oc_dbg, sizeof(ts), hipMemcpyDeviceToHost));
+    if (ts[5])
+      fprintf(stderr, "cg_step_cols member 0, first workgroup (100 MHz ticks per launch): loads+alpha %.1f update+mfma %.1f "
+              "all-reduce %.1f beta+control %.1f p %.1f\n", (double)ts[0] / ts[5], (double)ts[1] / ts[5], (double)ts[2] / ts[5],
+              (double)ts[3] / ts[5], (double)ts[4] / ts[5]);
+  }
   info->iterations = h.iterations;
   info->matvecs = matvecs + h.iterations;
   info->tolerance_reached = h.tol_reached;

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma16(const float* __res
   float vreg[8];
   float vxreg[2];
   const bool full_rows = ((N & 3) == 0) && (row0 + DM_ROWS <= N);
+  bool slab_fast = true;  // layout of the slab in kreg: 16-byte pieces (aligned fast path) or one float per lane
   auto load_slab = [&](int kb) {
     if (full_rows && kb + DM_KB <= N) {
 #pragma unroll
@@ -195,17 +196,22 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma16(const float* __res
         kreg[u] = *reinterpret_cast<const float4*>(Kb + (size_t)(row0 + r) * N + kb + 4 * q);
       }
     } else {
+      // rows that are not 16-byte aligned (N % 4 != 0) or the ragged edge: one float per lane, consecutive lanes on
+      // consecutive floats of a row -- 256 contiguous bytes per wave instruction whatever the alignment (the 16-byte
+      // stride of four scalar loads per lane streamed at 2.9 TB/s; this order at the rate of the aligned path)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int f = threadIdx.x + kThreads * u;
-        const int r = f >> 5, q = f & 31;
-        const int grow = row0 + r, gk = kb + 4 * q;
-        float t[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = (grow < N && gk + e < N) ? Kb[(size_t)grow * N + gk + e] : 0.f;
-        kreg[u] = make_float4(t[0], t[1], t[2], t[3]);
+      for (int u = 0; u < 32; ++u) {
+        const int e = threadIdx.x + kThreads * u;  // float #e of the [64 rows][128 k] slab
+        const int r = e >> 7, kq = e & 127;
+        const int grow = row0 + r, gk = kb + kq;
+        const float val = (grow < N && gk < N) ? Kb[(size_t)grow * N + gk] : 0.f;
+        if ((u & 3) == 0) kreg[u >> 2].x = val;
+        else if ((u & 3) == 1) kreg[u >> 2].y = val;
+        else if ((u & 3) == 2) kreg[u >> 2].z = val;
+        else kreg[u >> 2].w = val;
       }
     }
+    slab_fast = full_rows && kb + DM_KB <= N;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = threadIdx.x + kThreads * u;  // [128 k][16 cols]
@@ -222,11 +228,20 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma16(const float* __res
     }
   };
   auto store_slab = [&]() {
+    if (slab_fast) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int f = threadIdx.x + kThreads * u;
-      const int r = f >> 5, q = f & 31;
-      *reinterpret_cast<float4*>(&k_s[r * DM_LD + 4 * q]) = kreg[u];
+      for (int u = 0; u < 8; ++u) {
+        const int f = threadIdx.x + kThreads * u;
+        const int r = f >> 5, q = f & 31;
+        *reinterpret_cast<float4*>(&k_s[r * DM_LD + 4 * q]) = kreg[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        const int e = threadIdx.x + kThreads * u;
+        const float4 kq4 = kreg[u >> 2];
+        k_s[(e >> 7) * DM_LD + (e & 127)] = (u & 3) == 0 ? kq4.x : ((u & 3) == 1 ? kq4.y : ((u & 3) == 2 ? kq4.z : kq4.w));
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -474,7 +489,6 @@ static void launch_mv16(int nv, dim3 grid, hipStream_t st, const float* K, const
 // faster (5.8 - 6.0 TB/s against 4.2 / 4.2 / 2.2 TB/s of the VALU kernel at c = 2 / 3 / 4: tools/mb_dense_cols.py)
 bool dense_mfma_ok(int64_t N, int64_t c) { return c >= 2 && N >= 256; }
 int dense_mfma_tiles(int64_t N) { return (int)((N + DM_ROWS - 1) / DM_ROWS); }
-
 int dense_matvec_mfma(const float* K, const float* d, int dd_mode, const float* v, float* y, float* dot_part, int64_t B,
                       int64_t N, int64_t c, float* ypart, const int* stop, hipStream_t st) {
   dim3 grid(dense_mfma_tiles(N), (unsigned)B), block(kThreads);

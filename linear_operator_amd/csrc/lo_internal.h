@@ -291,6 +291,34 @@ int precond_fused_rupdate(const float* Q, const float* dinv, int dinv_mode, floa
                           int max_launch, const int* stop, int ncu, const PfCtrl* cf, const PfKron* kr,
                           hipStream_t st);
 
+// ---- the whole post-product step of a streaming CG iteration for up to 32 columns (lo_cg_step_cols.hip) ----------
+// the iteration's control step (cg_scal_body + cg_ctrl_body of lo_cg.hip) folded into that launch
+struct ScCtrl {
+  int on;
+  const int* rhs_is_zero;  // [B, c]
+  float* beta;             // [B, c]
+  float* resid_norm;       // [B, c]
+  float stop_after, tol;
+  int max_iter;            // the value the stop-rule floors are taken from
+  int n_tridiag, n_tridiag_iter, T;
+  float* t_mat;            // [n_tridiag, B, T, T]
+  float* prev_ar;          // [B, n_tridiag]
+  float* prev_beta;
+  int check_nan_first;
+  int* done;               // base of one zeroed counter per launch of the solve
+  unsigned long long* gran; // [3, B] tagged per-member aggregates of the current launch (zeroed once per solve)
+  CgCtrl* ctrl;
+};
+bool cg_step_cols_eligible(int64_t B, int64_t N, int64_t c, int ldq);  // ldq = 0: no preconditioner
+size_t cg_step_cols_gbuf_bytes();
+int cg_step_cols_group(int64_t N);
+bool cg_step_cols_worthwhile(int64_t B, int64_t N, int64_t c, bool has_pre);
+int cg_step_cols(const float* Q, int ldq, const float* dinv, int dinv_mode, float* r, const float* Ap, float* p, float* x,
+                 int64_t c, const float* pAp_part, int S_dot, float* rz, int* has_conv, float eps, float* alpha_out,
+                 float* rr_part, float* rz_part, int S, int64_t B, int64_t N, unsigned long long* gbuf, int* err,
+                 int* next_member, int launch, int max_launch, const int* stop, int ncu, const ScCtrl* cf,
+                 long long* dbg, hipStream_t st);
+
 // ---- operator-resident pivoted Cholesky (lo_pivchol_onchip.hip) ----------------------------------
 bool pc_onchip_eligible(const lo_op_desc* op, int max_rank);
 size_t pc_onchip_workspace_bytes(const lo_op_desc* op, int max_rank);

@@ -369,8 +369,10 @@ ENGINE_TABLE = [
     ("N = 65536: groups of 64", dict(kind=LOW, N=65536), dict(resident=1, serial="root", gw=64)),
     ("N = 40000, Q form only: streaming, fused apply", dict(kind=LOW, N=40000, pre="q"), dict(resident=0, stream="fused_q", chunk=4)),
     ("N = 100000: streaming two-pass", dict(kind=LOW, N=100000), dict(resident=0, stream="two_pass")),
-    ("N < 256", dict(kind=LOW, N=200, pre=None), dict(resident=0, stream="none")),
+    ("N < 256", dict(kind=LOW, N=200, pre=None), dict(resident=0, stream="fused_cols_nopre")),
     ("no preconditioner", dict(kind=LOW, N=1500, pre=None), dict(resident=1, serial="root", gw=2, lean=1, stream="none")),
+    ("thousands of tiny members keep the multi-launch step", dict(kind=DENSE, N=300, B=1000, c=11, nt=10, pre="q", k=5), dict(stream="two_pass")),
+    ("200 members of 1000 rows, 11 columns", dict(kind=DENSE, N=1000, B=200, c=11, nt=10, pre="q", k=7), dict(stream="fused_cols")),
     ("no preconditioner, 9 columns", dict(kind=LOW, N=1500, pre=None, c=9), dict(resident=1, ls=9, serial="none")),
     ("rank-20 root is padded to 32", dict(kind=LOW, N=5000, R=20, c=20, nt=16), dict(resident=1, ls=20)),
     ("rank-8 root", dict(kind=LOW, N=2048, R=8, c=6), dict(resident=1, ls=6, ls_gw=2)),
@@ -386,10 +388,17 @@ ENGINE_TABLE = [
     ("cfg4 without the Kronecker root form", dict(kind=KRON, N=65536, R=256, n2=256, B=128, pre="q", const_pre=True,
                                                   diag_mode=_hip.LO_DIAG_CONST), dict(resident=0, stream="fused_q")),
     ("Kronecker, three columns", dict(kind=KRON, N=65536, R=256, n2=256, B=128, c=3, pre="q"), dict(stream="two_pass")),
-    ("Kronecker 48 x 48: below the fused apply", dict(kind=KRON, N=2304, R=48, n2=48, B=2, pre="q"), dict(stream="two_pass")),
-    ("cfg5: dense, 17 columns", dict(kind=DENSE, N=16384, c=17, nt=16, B=8, pre="q"), dict(resident=0, stream="two_pass", first_stop=20)),
+    ("Kronecker 128 x 128, three columns: one launch behind the product", dict(kind=KRON, N=16384, R=128, n2=128, B=16, c=3, pre="q"),
+     dict(stream="fused_cols")),
+    ("Kronecker 48 x 48: below the single-column fused apply", dict(kind=KRON, N=2304, R=48, n2=48, B=2, pre="q"), dict(stream="fused_cols")),
+    ("cfg5: dense, 17 columns", dict(kind=DENSE, N=16384, c=17, nt=16, B=8, pre="q"), dict(resident=0, stream="fused_cols", first_stop=20)),
+    ("dense, 17 columns, N = 20000: beyond the groups of 64", dict(kind=DENSE, N=20000, c=17, nt=16, B=2, pre="q"), dict(stream="two_pass")),
+    ("dense, 40 columns", dict(kind=DENSE, N=4000, c=40, B=1, pre="q"), dict(stream="two_pass")),
+    ("dense, 11 columns, N = 4000, too few compute units for groups of 16", dict(kind=DENSE, N=4000, c=11, nt=10, B=1, pre="q", cus=32),
+     dict(stream="two_pass")),
+    ("dense, 11 columns, preconditioner rank 40", dict(kind=DENSE, N=4000, c=11, nt=10, B=1, pre="q", k=40), dict(stream="two_pass")),
     ("dense, one column, N = 16384: fused apply", dict(kind=DENSE, N=16384, B=8, pre="q"), dict(stream="fused_q")),
-    ("dense, unpreconditioned", dict(kind=DENSE, N=1000, B=1, pre=None), dict(resident=0, stream="none")),
+    ("dense, unpreconditioned", dict(kind=DENSE, N=1000, B=1, pre=None), dict(resident=0, stream="fused_cols_nopre")),
     ("closure operator", dict(kind=CB, N=8192, pre=None), dict(resident=0, chunk=1)),
 ]
 
