@@ -1256,6 +1256,9 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       } else {
         pre_done = p_done = true;
         ctrl_done = cf.on != 0;
+        // LO_SC_TEST_FALLBACK=<k>: the error word set behind launch k, as if a hand-off had timed out (host redo path)
+        if (const char* e = getenv("LO_SC_TEST_FALLBACK"))
+          if (atoi(e) == kk) LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 1, 1, ls));
       }
     }
     if (!pre_done) p_done = false;  // (the two-launch path below leaves the p update to the next iteration's first step)
