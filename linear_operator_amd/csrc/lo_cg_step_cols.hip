@@ -23,7 +23,8 @@
 //   freeze :326-327) from three tagged granules per member -- no fence, no second launch.
 //
 // Without a preconditioner (N below settings.min_preconditioning_size) the same kernel runs with z = r (PRE = false:
-// c + 1 values cross the group).  Groups are persistent and take members dynamically (the next member rides on the
+// c + 1 values cross the group).  Members of more than 16384 rows (up to 65536) give a workgroup 2 or 4 row blocks: it
+// walks over them twice and re-reads r and p behind the exchange.  Groups are persistent and take members dynamically (the next member rides on the
 // all-reduce).  Bitwise reproducible: every sum has a fixed order.  A timed-out hand-off sets the error word; the host
 // redoes the solve on the multi-launch path.
 //   bound: HBM / L2 -- 4 c N 7 bytes of vectors + 4 N 16 of Q (read twice, the second time from cache) per member.
@@ -135,7 +136,10 @@ constexpr int SC_OOB = 0x40000000;  // byte offset beyond every descriptor's ran
 // Addressing: one buffer descriptor per member and array (wave-uniform base, the member's byte count as the range), the
 // lane's byte offset in a VGPR, the 16 row steps of a lane as uniform addends.  Rows beyond N and columns beyond c fall
 // outside the descriptor's range -- no per-element predicates, no 64-bit address registers.
-template <int GW, int CT, bool PRE>
+// RB = row blocks of 256 per workgroup: 1 keeps r, p, 1/d of the workgroup's rows in registers across the exchange; 2 / 4
+// (members of up to 65536 rows on groups of at most 64) walk over their blocks twice and re-read r and p behind the exchange
+// (cache hits: the first walk has just written them).
+template <int GW, int CT, bool PRE, int RB>
 __global__ __launch_bounds__(SC_TPB, 2) void k_cg_step_cols(ScArgs a) {
   if (a.stop && *a.stop) return;
   __shared__ ScShared sh;
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(SC_TPB, 2) void k_cg_step_cols(ScArgs a) {
   g.same_xcd = false;  // (agent-scope granules: this kernel exchanges once per member)
   const int c = a.c;
   const int cnt = PRE ? 18 * c + 1 : c + 1;
-  const int rbase = wig * SC_ROWS + 64 * wave;  // first row of the wave
+  const int rbase = wig * SC_ROWS * RB + 64 * wave;  // first row of the wave (block 0)
   const int k_it = a.launch;
   const int vec_bytes = a.N * c * 4;
   // lane offsets (bytes): vectors at (row rbase + 4 kk, column 16 ct + n); Q as the A operand of the two products
@@ -182,30 +186,32 @@ __global__ __launch_bounds__(SC_TPB, 2) void k_cg_step_cols(ScArgs a) {
     if (stamp) c0 = wall_clock64();
     float rv[CT][16], pv[CT][16], apv[CT][16], xv[CT][16];
     float dv[16], qa[16];
-    // ---- loads of the first column tile, the diagonal and Q ----
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int so = (16 * (q >> 2) + (q & 3)) * c * 4;
-      rv[0][q] = sc_ld(rs_r, voff[0] + so);
-      apv[0][q] = sc_ld(rs_ap, voff[0] + so);
-      pv[0][q] = sc_ld(rs_p, voff[0] + so);
-      xv[0][q] = sc_ld(rs_x, voff[0] + so);
-    }
-    if constexpr (PRE) {
-      const __amdgpu_buffer_rsrc_t rs_q =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q) + mrow * a.ldq, 0, a.N * a.ldq * 4, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs_d =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dinv) + mrow, 0, a.N * 4, 0x00020000);
-      const float dconst = (a.dinv_mode == LO_DIAG_FULL) ? 0.f : a.dinv[b];
-#pragma unroll
+    if constexpr (RB == 1) {
+      // ---- loads of the first column tile, the diagonal and Q ----
+  #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int ro = 16 * (q >> 2) + (q & 3);
-        dv[q] = (a.dinv_mode == LO_DIAG_FULL) ? sc_ld(rs_d, voff_d + ro * 4) : dconst;
-        qa[q] = sc_ld(rs_q, voff_qa + ro * a.ldq * 4);
+        const int so = (16 * (q >> 2) + (q & 3)) * c * 4;
+        rv[0][q] = sc_ld(rs_r, voff[0] + so);
+        apv[0][q] = sc_ld(rs_ap, voff[0] + so);
+        pv[0][q] = sc_ld(rs_p, voff[0] + so);
+        xv[0][q] = sc_ld(rs_x, voff[0] + so);
       }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) dv[q] = 1.f, qa[q] = 0.f;
+      if constexpr (PRE) {
+        const __amdgpu_buffer_rsrc_t rs_q =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q) + mrow * a.ldq, 0, a.N * a.ldq * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_d =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dinv) + mrow, 0, a.N * 4, 0x00020000);
+        const float dconst = (a.dinv_mode == LO_DIAG_FULL) ? 0.f : a.dinv[b];
+  #pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int ro = 16 * (q >> 2) + (q & 3);
+          dv[q] = (a.dinv_mode == LO_DIAG_FULL) ? sc_ld(rs_d, voff_d + ro * 4) : dconst;
+          qa[q] = sc_ld(rs_q, voff_qa + ro * a.ldq * 4);
+        }
+      } else {
+  #pragma unroll
+        for (int q = 0; q < 16; ++q) dv[q] = 1.f, qa[q] = 0.f;
+      }
     }
     // ---- alpha of every column from the product's partials (linear_cg.py:250-260), while the loads are in flight ----
     float rzo_t = 0.f;
@@ -246,62 +252,131 @@ __global__ __launch_bounds__(SC_TPB, 2) void k_cg_step_cols(ScArgs a) {
     }
     __syncthreads();
     if (stamp) c1 = wall_clock64();
-    if constexpr (CT == 2) {  // the second tile's r / Ap travel while the first tile is updated
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int so = (16 * (q >> 2) + (q & 3)) * c * 4;
-        rv[1][q] = sc_ld(rs_r, voff[1] + so);
-        apv[1][q] = sc_ld(rs_ap, voff[1] + so);
-      }
-    }
-    // ---- r -= alpha Ap, x += alpha p (:264, :31); the partials of Q^T r, sum r^2, sum r^2 / d ----
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const int col = 16 * ct + n;
-      const float al = sh.alpha[col];
-      if (ct == 1) {
-#pragma unroll
+    if constexpr (RB == 1) {
+      if constexpr (CT == 2) {  // the second tile's r / Ap travel while the first tile is updated
+  #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int so = (16 * (q >> 2) + (q & 3)) * c * 4;
-          pv[ct][q] = sc_ld(rs_p, voff[ct] + so);
-          xv[ct][q] = sc_ld(rs_x, voff[ct] + so);
+          rv[1][q] = sc_ld(rs_r, voff[1] + so);
+          apv[1][q] = sc_ld(rs_ap, voff[1] + so);
         }
       }
-      float s0 = 0.f, s1 = 0.f;
-      sc_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int so = (16 * (q >> 2) + (q & 3)) * c * 4;
-        const float rn = fmaf(-al, apv[ct][q], rv[ct][q]);
-        rv[ct][q] = rn;
-        s0 = fmaf(rn, rn, s0);
-        if constexpr (PRE) {
-          s1 = fmaf(rn * dv[q], rn, s1);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[q], rn, acc, 0, 0, 0);
-        }
-        sc_st(rs_r, voff[ct] + so, rn);
-        sc_st(rs_x, voff[ct] + so, fmaf(al, pv[ct][q], xv[ct][q]));
-      }
-      s0 = bfly_add<32>(bfly_add<16>(s0));
-      if constexpr (PRE) {
-        s1 = bfly_add<32>(bfly_add<16>(s1));
-        if (col < c) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sh.red[wave][(4 * kk + e) * c + col] = acc[e];
-          if (kk == 0) {
-            sh.red[wave][16 * c + col] = s0;
-            sh.red[wave][17 * c + col] = s1;
+      // ---- r -= alpha Ap, x += alpha p (:264, :31); the partials of Q^T r, sum r^2, sum r^2 / d ----
+  #pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int col = 16 * ct + n;
+        const float al = sh.alpha[col];
+        if (ct == 1) {
+  #pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int so = (16 * (q >> 2) + (q & 3)) * c * 4;
+            pv[ct][q] = sc_ld(rs_p, voff[ct] + so);
+            xv[ct][q] = sc_ld(rs_x, voff[ct] + so);
           }
         }
-      } else {
-        if (col < c && kk == 0) sh.red[wave][col] = s0;
+        float s0 = 0.f, s1 = 0.f;
+        sc_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int so = (16 * (q >> 2) + (q & 3)) * c * 4;
+          const float rn = fmaf(-al, apv[ct][q], rv[ct][q]);
+          rv[ct][q] = rn;
+          s0 = fmaf(rn, rn, s0);
+          if constexpr (PRE) {
+            s1 = fmaf(rn * dv[q], rn, s1);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[q], rn, acc, 0, 0, 0);
+          }
+          sc_st(rs_r, voff[ct] + so, rn);
+          sc_st(rs_x, voff[ct] + so, fmaf(al, pv[ct][q], xv[ct][q]));
+        }
+        s0 = bfly_add<32>(bfly_add<16>(s0));
+        if constexpr (PRE) {
+          s1 = bfly_add<32>(bfly_add<16>(s1));
+          if (col < c) {
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) sh.red[wave][(4 * kk + e) * c + col] = acc[e];
+            if (kk == 0) {
+              sh.red[wave][16 * c + col] = s0;
+              sh.red[wave][17 * c + col] = s1;
+            }
+          }
+        } else {
+          if (col < c && kk == 0) sh.red[wave][col] = s0;
+        }
+      }
+    } else {
+      // ---- members of more than 256 GW rows: block after block; the partial sums ride in registers across the blocks ----
+      sc_f32x4 accb[CT];
+      float s0b[CT], s1b[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        accb[ct] = sc_f32x4{0.f, 0.f, 0.f, 0.f};
+        s0b[ct] = 0.f;
+        s1b[ct] = 0.f;
+      }
+      for (int blk = 0; blk < RB; ++blk) {
+        if constexpr (PRE) {
+          const __amdgpu_buffer_rsrc_t rs_q =
+              __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q) + mrow * a.ldq, 0, a.N * a.ldq * 4, 0x00020000);
+          const __amdgpu_buffer_rsrc_t rs_d =
+              __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dinv) + mrow, 0, a.N * 4, 0x00020000);
+          const float dconst = (a.dinv_mode == LO_DIAG_FULL) ? 0.f : a.dinv[b];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int ro = SC_ROWS * blk + 16 * (q >> 2) + (q & 3);
+            dv[q] = (a.dinv_mode == LO_DIAG_FULL) ? sc_ld(rs_d, voff_d + ro * 4) : dconst;
+            qa[q] = sc_ld(rs_q, voff_qa + ro * a.ldq * 4);
+          }
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const float al = sh.alpha[16 * ct + n];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int so = (SC_ROWS * blk + 16 * (q >> 2) + (q & 3)) * c * 4;
+            rv[0][q] = sc_ld(rs_r, voff[ct] + so);
+            apv[0][q] = sc_ld(rs_ap, voff[ct] + so);
+            pv[0][q] = sc_ld(rs_p, voff[ct] + so);
+            xv[0][q] = sc_ld(rs_x, voff[ct] + so);
+          }
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int so = (SC_ROWS * blk + 16 * (q >> 2) + (q & 3)) * c * 4;
+            const float rn = fmaf(-al, apv[0][q], rv[0][q]);
+            s0b[ct] = fmaf(rn, rn, s0b[ct]);
+            if constexpr (PRE) {
+              s1b[ct] = fmaf(rn * dv[q], rn, s1b[ct]);
+              accb[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[q], rn, accb[ct], 0, 0, 0);
+            }
+            sc_st(rs_r, voff[ct] + so, rn);
+            sc_st(rs_x, voff[ct] + so, fmaf(al, pv[0][q], xv[0][q]));
+          }
+        }
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int col = 16 * ct + n;
+        const float s0 = bfly_add<32>(bfly_add<16>(s0b[ct]));
+        if constexpr (PRE) {
+          const float s1 = bfly_add<32>(bfly_add<16>(s1b[ct]));
+          if (col < c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sh.red[wave][(4 * kk + e) * c + col] = accb[ct][e];
+            if (kk == 0) {
+              sh.red[wave][16 * c + col] = s0;
+              sh.red[wave][17 * c + col] = s1;
+            }
+          }
+        } else {
+          if (col < c && kk == 0) sh.red[wave][col] = s0;
+        }
       }
     }
     if (lane == 0)  // the next member rides on the same all-reduce: drawn by the group's first workgroup (exact < 2^24)
       sh.red[wave][cnt - 1] = (wig == 0 && wave == 0) ? (float)(ngroups + atomicAdd(a.next_member, 1)) : 0.f;
     // rows of Q as the A operand of the expanding product (the same lines again: cache hits), issued before the wait
     float qb[16];
-    if constexpr (PRE) {
+    if constexpr (PRE && RB == 1) {
       const __amdgpu_buffer_rsrc_t rs_q =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q) + mrow * a.ldq, 0, a.N * a.ldq * 4, 0x00020000);
 #pragma unroll
@@ -391,27 +466,75 @@ __global__ __launch_bounds__(SC_TPB, 2) void k_cg_step_cols(ScArgs a) {
     }
     if (stamp) c4 = wall_clock64();
     // ---- p <- z + beta p with z = r/d - Q u (:140, :46) ----
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const int col = 16 * ct + n;
-      const float be = sh.beta[col];
-      float ub[4];
-      if constexpr (PRE) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) ub[s] = (col < c) ? sh.res[(4 * s + kk) * c + col] : 0.f;
-      }
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        sc_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (RB == 1) {
+  #pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int col = 16 * ct + n;
+        const float be = sh.beta[col];
+        float ub[4];
         if constexpr (PRE) {
+  #pragma unroll
+          for (int s = 0; s < 4; ++s) ub[s] = (col < c) ? sh.res[(4 * s + kk) * c + col] : 0.f;
+        }
+  #pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          sc_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (PRE) {
+  #pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[4 * rb + s], ub[s], acc, 0, 0, 0);
+          }
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int q = 4 * rb + e;
+            const float z = PRE ? (rv[ct][q] * dv[q] - acc[e]) : rv[ct][q];
+            sc_st(rs_p, voff[ct] + (16 * rb + e) * c * 4, fmaf(pv[ct][q], be, z));
+          }
+        }
+      }
+    } else {
+      for (int blk = 0; blk < RB; ++blk) {
+        if constexpr (PRE) {
+          const __amdgpu_buffer_rsrc_t rs_q =
+              __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q) + mrow * a.ldq, 0, a.N * a.ldq * 4, 0x00020000);
+          const __amdgpu_buffer_rsrc_t rs_d =
+              __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dinv) + mrow, 0, a.N * 4, 0x00020000);
+          const float dconst = (a.dinv_mode == LO_DIAG_FULL) ? 0.f : a.dinv[b];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[4 * rb + s], ub[s], acc, 0, 0, 0);
+          for (int q = 0; q < 16; ++q) {
+            dv[q] = (a.dinv_mode == LO_DIAG_FULL) ? sc_ld(rs_d, voff_d + (SC_ROWS * blk + 16 * (q >> 2) + (q & 3)) * 4) : dconst;
+            qb[q] = (4 * (q & 3) < a.ldq)
+                        ? sc_ld(rs_q, voff_qb + ((SC_ROWS * blk + 16 * (q >> 2)) * a.ldq + 4 * (q & 3)) * 4) : 0.f;
+          }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int q = 4 * rb + e;
-          const float z = PRE ? (rv[ct][q] * dv[q] - acc[e]) : rv[ct][q];
-          sc_st(rs_p, voff[ct] + (16 * rb + e) * c * 4, fmaf(pv[ct][q], be, z));
+        for (int ct = 0; ct < CT; ++ct) {
+          const int col = 16 * ct + n;
+          const float be = sh.beta[col];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int so = (SC_ROWS * blk + 16 * (q >> 2) + (q & 3)) * c * 4;
+            rv[0][q] = sc_ld(rs_r, voff[ct] + so);
+            pv[0][q] = sc_ld(rs_p, voff[ct] + so);
+          }
+          float ub[4];
+          if constexpr (PRE) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ub[s] = (col < c) ? sh.res[(4 * s + kk) * c + col] : 0.f;
+          }
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) {
+            sc_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (PRE) {
+#pragma unroll
+              for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[4 * rb + s], ub[s], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int q = 4 * rb + e;
+              const float z = PRE ? (rv[0][q] * dv[q] - acc[e]) : rv[0][q];
+              sc_st(rs_p, voff[ct] + (SC_ROWS * blk + 16 * rb + e) * c * 4, fmaf(pv[0][q], be, z));
+            }
+          }
         }
       }
     }
@@ -468,56 +591,62 @@ __global__ __launch_bounds__(SC_TPB, 2) void k_cg_step_cols(ScArgs a) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
+static int sc_row_blocks(int64_t N) { return N <= 64 * (int64_t)SC_ROWS ? 1 : (N <= 128 * (int64_t)SC_ROWS ? 2 : 4); }
 int cg_step_cols_group(int64_t N) {  // workgroups per member: the smallest power of two that holds its rows
+  const int64_t rows = (int64_t)SC_ROWS * sc_row_blocks(N);
   int gw = 1;
-  while ((int64_t)gw * SC_ROWS < N) gw <<= 1;
+  while ((int64_t)gw * rows < N) gw <<= 1;
   return gw;
 }
 
 bool cg_step_cols_eligible(int64_t B, int64_t N, int64_t c, int ldq) {
-  return c >= 1 && c <= SC_MAXC && N >= 1 && N <= 64 * (int64_t)SC_ROWS && (ldq == 0 || ldq == 4 || ldq == 8 || ldq == 16) &&
+  return c >= 1 && c <= SC_MAXC && N >= 1 && N <= 256 * (int64_t)SC_ROWS && (ldq == 0 || ldq == 4 || ldq == 8 || ldq == 16) &&
          B >= 1 && B < (1 << 24) - 4096 && !getenv("LO_NO_STEP_COLS");
 }
 
 // Where the one launch pays (tools/check_step_cols.py): a member's step is a chain of latencies (loads, exchange, stores:
-// 25 - 35 us) that a group runs for one member after the other, so thousands of tiny members (N < 512: 1000 x 300 rows
+// 25 - 35 us) that a group runs for one member after the other, while the multi-launch kernels are bandwidth-bound.  So
+// the batch may take at most four rounds of the resident groups; thousands of tiny members (N < 512: 1000 x 300 rows
 // 4.7 vs 4.2 ms) and few-column unpreconditioned solves (16 lanes per load instruction carry c < 4 values) stay on the
 // multi-launch path unless every member has a group of its own.
 bool cg_step_cols_worthwhile(int64_t B, int64_t N, int64_t c, bool has_pre) {
-  const bool own_group = B * cg_step_cols_group(N) <= 512;
-  return own_group || (N >= 512 && (has_pre || c >= 4));
+  const int64_t slots = B * cg_step_cols_group(N);
+  if (slots <= 512) return true;
+  return slots <= 4 * 512 && N >= 512 && (has_pre || c >= 4);
 }
 
 size_t cg_step_cols_gbuf_bytes() {  // 512 workgroup slots + up to 512 total rows, two parities
   return (size_t)2 * (512 + 512) * SC_LD * sizeof(unsigned long long) + 256;
 }
 
-template <int GW, int CT, bool PRE>
+template <int GW, int CT, bool PRE, int RB>
 static int sc_go(ScArgs& a, int ncu, hipStream_t st) {
   int per_cu = 0;
-  const hipError_t oe = LO_OCCUPANCY_CACHED(per_cu, (k_cg_step_cols<GW, CT, PRE>), SC_TPB, 0);
+  const hipError_t oe = LO_OCCUPANCY_CACHED(per_cu, (k_cg_step_cols<GW, CT, PRE, RB>), SC_TPB, 0);
   if (oe != hipSuccess || per_cu < 1) return LO_ERR_UNSUPPORTED;
   per_cu = std::min(per_cu, 2);
   const int nwg = std::min(512, per_cu * ncu);
   if ((nwg / 8) < GW) return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("cg_step_cols", st);
   ResidentLaunch guard(st);
-  hipLaunchKernelGGL((k_cg_step_cols<GW, CT, PRE>), dim3(nwg), dim3(SC_TPB), 0, st, a);
+  hipLaunchKernelGGL((k_cg_step_cols<GW, CT, PRE, RB>), dim3(nwg), dim3(SC_TPB), 0, st, a);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
 }
 
 template <int CT, bool PRE>
-static int sc_go_gw(int GW, ScArgs& a, int ncu, hipStream_t st) {
+static int sc_go_gw(int GW, int RB, ScArgs& a, int ncu, hipStream_t st) {
+  if (RB == 2) return sc_go<64, CT, PRE, 2>(a, ncu, st);  // (more than 16384 rows: always groups of 64)
+  if (RB == 4) return sc_go<64, CT, PRE, 4>(a, ncu, st);
   switch (GW) {
-    case 1: return sc_go<1, CT, PRE>(a, ncu, st);
-    case 2: return sc_go<2, CT, PRE>(a, ncu, st);
-    case 4: return sc_go<4, CT, PRE>(a, ncu, st);
-    case 8: return sc_go<8, CT, PRE>(a, ncu, st);
-    case 16: return sc_go<16, CT, PRE>(a, ncu, st);
-    case 32: return sc_go<32, CT, PRE>(a, ncu, st);
-    default: return sc_go<64, CT, PRE>(a, ncu, st);
+    case 1: return sc_go<1, CT, PRE, 1>(a, ncu, st);
+    case 2: return sc_go<2, CT, PRE, 1>(a, ncu, st);
+    case 4: return sc_go<4, CT, PRE, 1>(a, ncu, st);
+    case 8: return sc_go<8, CT, PRE, 1>(a, ncu, st);
+    case 16: return sc_go<16, CT, PRE, 1>(a, ncu, st);
+    case 32: return sc_go<32, CT, PRE, 1>(a, ncu, st);
+    default: return sc_go<64, CT, PRE, 1>(a, ncu, st);
   }
 }
 
@@ -544,10 +673,10 @@ int cg_step_cols(const float* Q, int ldq, const float* dinv, int dinv_mode, floa
   } else {
     a.cf.on = 0;
   }
-  const int GW = cg_step_cols_group(N);
+  const int GW = cg_step_cols_group(N), RB = sc_row_blocks(N);
   const bool two = c > 16;
-  if (Q) return two ? sc_go_gw<2, true>(GW, a, ncu, st) : sc_go_gw<1, true>(GW, a, ncu, st);
-  return two ? sc_go_gw<2, false>(GW, a, ncu, st) : sc_go_gw<1, false>(GW, a, ncu, st);
+  if (Q) return two ? sc_go_gw<2, true>(GW, RB, a, ncu, st) : sc_go_gw<1, true>(GW, RB, a, ncu, st);
+  return two ? sc_go_gw<2, false>(GW, RB, a, ncu, st) : sc_go_gw<1, false>(GW, RB, a, ncu, st);
 }
 
 }  // namespace lo

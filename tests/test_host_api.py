@@ -392,7 +392,10 @@ ENGINE_TABLE = [
      dict(stream="fused_cols")),
     ("Kronecker 48 x 48: below the single-column fused apply", dict(kind=KRON, N=2304, R=48, n2=48, B=2, pre="q"), dict(stream="fused_cols")),
     ("cfg5: dense, 17 columns", dict(kind=DENSE, N=16384, c=17, nt=16, B=8, pre="q"), dict(resident=0, stream="fused_cols", first_stop=20)),
-    ("dense, 17 columns, N = 20000: beyond the groups of 64", dict(kind=DENSE, N=20000, c=17, nt=16, B=2, pre="q"), dict(stream="two_pass")),
+    ("dense, 17 columns, N = 20000: two row blocks per workgroup", dict(kind=DENSE, N=20000, c=17, nt=16, B=2, pre="q"), dict(stream="fused_cols")),
+    ("dense, 17 columns, N = 70000: beyond the groups of 64", dict(kind=DENSE, N=70000, c=17, nt=16, B=1, pre="q"), dict(stream="two_pass")),
+    ("dense, 17 columns, 40 members of 16384 rows: more than four rounds of the groups", dict(kind=DENSE, N=16384, c=17, nt=16, B=40, pre="q"),
+     dict(stream="two_pass")),
     ("dense, 40 columns", dict(kind=DENSE, N=4000, c=40, B=1, pre="q"), dict(stream="two_pass")),
     ("dense, 11 columns, N = 4000, too few compute units for groups of 16", dict(kind=DENSE, N=4000, c=11, nt=10, B=1, pre="q", cus=32),
      dict(stream="two_pass")),
