@@ -422,6 +422,14 @@ def other_configs(device):
                            prof["dense_mv_mfma"], "hbm", mv_bytes,
                            "4 (N^2 + N + 2 N c) bytes per member: K streamed once for all 17 columns (the committed "
                            "counter profile is of 8 members: twice the bytes)"))
+    if "cg_step_cols" in prof:
+        roofs.append(_roof("k_cg_step_cols<64,2,true,1>", "cfg5 shard: 4 members of 16384 rows, 17 columns: everything of a CG "
+                           "iteration behind the product (alpha, r / x, Q-form preconditioner, beta, p, control step with "
+                           "tridiagonals) in one launch", prof["cg_step_cols"], "hbm", 4 * 4 * Nd * (7 * 17 + 16 + 1),
+                           "4 N (7 c + 16 + 1) bytes per member: r, Ap, p, x in; r, x, p out; Q and 1/d once.  One member per "
+                           "group of 64 workgroups, one exchange: a chain of latencies (loads 10 us, exchange 12 us), not a "
+                           "stream -- it replaced three launches of 145 us (the committed counter profile, traffic_cfg45.json, is of 8 "
+                           "members)"))
     return res, roofs
 
 

@@ -55,7 +55,7 @@ if f is not None and w is not None:
               open(f"{out}/traffic_lockstep.json", "w"), indent=1)
 others = {}
 for name, kern in (("kron_fused", "k_kron_fused"), ("precond_fused_kron", "k_precond_fused_kron"),
-                   ("precond_fused", "k_precond_fused<"), ("dense_mv_mfma", "k_dense_mv_mfma16"),
+                   ("precond_fused", "k_precond_fused<"), ("dense_mv_mfma", "k_dense_mv_mfma16"), ("cg_step_cols", "k_cg_step_cols"),
                    ("kron_gemm_mfma", "k_kron_nt_mfma<true")):
     f = grab(f"{out}/pmc_fetch_write_cfg45.txt", "FETCH_SIZE", kern)
     w = grab(f"{out}/pmc_fetch_write_cfg45.txt", "WRITE_SIZE", kern)
