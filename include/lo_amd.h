@@ -372,6 +372,28 @@ int lo_root_from_lanczos_f32(const float* q, const float* evecs, const float* ev
 int lo_root_from_lanczos_native_f32(const float* q_native, const float* evecs, const float* evals, int64_t B, int64_t N,
                                     int64_t P, int32_t k, float* qv, float* root, float* inverse, void* stream);
 
+/* ---- host glue of InvQuadLogdet as kernels (csrc/lo_probes.hip; round 4, ABI 10) ----------------------------- */
+/* Probe vectors of InvQuadLogdet.forward (functions/_inv_quad_logdet.py:91-110) for the preconditioner P = L L^T + D of an
+ * AddedDiagLinearOperator: z = L e1 + sqrt(d) o e2 (a draw from N(0, P): zero_mean_mvn_samples of the PsdSum,
+ * sum_linear_operator.py:88-91), the column norms (:108), z / norm (:109) written into the FIRST P columns of the
+ * right-hand-side block rhs_out [B, N, P + q], the q inv_quad columns copied behind them (the torch.cat of :131).
+ *   L          element (b, n, j) at L[b * l_sb + n * l_sn + j * l_sk]  (any layout / broadcast batch), k <= 32 columns
+ *   d          [B, N] (LO_DIAG_FULL) or [B] (LO_DIAG_CONST);  e1 [B, k, P], e2 [B, N, P] standard normal draws
+ *   norms      [B, P] out;  ws: lo_probe_vectors_workspace_bytes.  P, q <= 64.  Asynchronous on `stream`.          */
+size_t lo_probe_vectors_workspace_bytes(int64_t B, int64_t N, int64_t P);
+int lo_probe_vectors_f32(const float* L, int64_t l_sb, int64_t l_sn, int64_t l_sk, int32_t k, const float* d,
+                         int32_t diag_mode, const float* e1, const float* e2, const float* inv_quad_rhs, int64_t q,
+                         int64_t B, int64_t N, int64_t P, float* rhs_out, float* norms, void* ws, size_t ws_bytes,
+                         void* stream);
+/* Element-wise part of InvQuadLogdet.backward (:183-213) in one pass.  solves [B, N, P + q]; pp [B, N, ldp] = the
+ * preconditioner applied to the NORMALISED probes (first P columns read); norms [B, P]; g_ld [B] logdet grad;
+ * g_iq [B, q] inv_quad grad (or NULL when q = 0); coef = 1 / P.  Outputs: left, right [B, N, P + q] (the factors of
+ * linear_op._bilinear_derivative: [probe part | inv_quad part]) and pre_left, pre_right [B, N, P] (the factors of the
+ * preconditioner's bilinear derivative, :211-213).                                                                  */
+int lo_iql_backward_factors_f32(const float* solves, const float* pp, int64_t ldp, const float* norms, const float* g_ld,
+                                const float* g_iq, float coef, int64_t B, int64_t N, int64_t P, int64_t q, float* left,
+                                float* right, float* pre_left, float* pre_right, void* stream);
+
 /* ---- lanczos_tridiag_to_diag + StochasticLQ.to_dense (lanczos.py:167-189, stochastic_lq.py:45-82) */
 /* t_mat [M, T, T] (M = P*B tridiagonals, only the three diagonals are read) ->
  *   evals [M, T], evecs [M, T, T] (column j = eigenvector j; negative eigenvalues -> 1 and their

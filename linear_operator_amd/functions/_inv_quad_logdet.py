@@ -93,6 +93,33 @@ def _zero_mean_mvn_samples_columns(precond_lt, num_samples):
     return samples.unsqueeze(-2).transpose(0, -2).squeeze(0).mT.contiguous()
 
 
+def _fused_probe_block(precond_lt, num_samples, inv_quad_rhs, batch_shape):
+    """The right-hand-side block [normalised probes | inv_quad rhs] of `forward` in two kernel launches
+    (`kernels.probe_vectors`, csrc/lo_probes.hip) when the preconditioner is L L^T + D on the device in fp32 -- the draws
+    e1, e2 come from torch's generator in the order `_zero_mean_mvn_samples_columns` takes them.  None: not that case."""
+    from ..operators.diag_linear_operator import DiagLinearOperator
+    from ..operators.root_linear_operator import RootLinearOperator
+    from ..operators.sum_linear_operator import PsdSumLinearOperator
+
+    ops = getattr(precond_lt, "linear_ops", ())
+    if not (isinstance(precond_lt, PsdSumLinearOperator) and len(ops) == 2):
+        return None
+    root = next((o for o in ops if isinstance(o, RootLinearOperator)), None)
+    diag = next((o for o in ops if isinstance(o, DiagLinearOperator)), None)
+    L = root._dense_root() if root is not None else None
+    if L is None or diag is None or not (L.is_cuda and L.dtype == torch.float32):
+        return None
+    batch, n = tuple(batch_shape), precond_lt.size(-1)
+    if L.size(-1) > 32 or num_samples > 64 or tuple(precond_lt.batch_shape) != batch:
+        return None
+    if inv_quad_rhs is not None and not (inv_quad_rhs.is_cuda and inv_quad_rhs.dtype == torch.float32 and
+                                        inv_quad_rhs.size(-1) <= 64 and tuple(inv_quad_rhs.shape[:-2]) == batch):
+        return None
+    e1 = torch.randn(*batch, L.size(-1), num_samples, dtype=L.dtype, device=L.device)
+    e2 = torch.randn(*batch, n, num_samples, dtype=L.dtype, device=L.device)
+    return K.probe_vectors(L, diag._diagonal(), e1, e2, inv_quad_rhs, batch)
+
+
 def _bilinear_derivative_where_needed(precond_lt, precond_args, left, right):
     """precond_lt._bilinear_derivative(left, right) restricted to the components whose tensors take a gradient: the
     pivoted-Cholesky factor of the preconditioner is built outside autograd (its contribution is chained by hand in
@@ -134,6 +161,11 @@ class InvQuadLogdet(Function):
         dtype, device = linear_op.dtype, linear_op.device
         matrix_shape, batch_shape = linear_op.matrix_shape, linear_op.batch_shape
 
+        ctx.is_vector = False
+        if inv_quad and inv_quad_rhs.ndimension() == 1:
+            inv_quad_rhs = inv_quad_rhs.unsqueeze(-1)
+            ctx.is_vector = True
+        rhs = None
         if probe_vectors is None or probe_vector_norms is None:  # reference :78-110
             num_random_probes = settings.num_trace_samples.value()
             if settings.deterministic_probes.on():  # reference :80-105 (deprecated there, kept for drop-in use)
@@ -154,21 +186,23 @@ class InvQuadLogdet(Function):
                     settings.deterministic_probes.probe_vectors = base_samples
                 probe_vectors = covar_root.matmul(base_samples)  # [*batch, N, P]
             else:
-                probe_vectors = _zero_mean_mvn_samples_columns(precond_lt, num_random_probes)  # [*batch, N, P]
-            probe_vector_norms = torch.linalg.vector_norm(probe_vectors, ord=2, dim=-2, keepdim=True)
-            probe_vectors = probe_vectors.div(probe_vector_norms)
+                block = _fused_probe_block(precond_lt, num_random_probes, inv_quad_rhs if inv_quad else None, batch_shape)
+                if block is not None:  # draws, norms, division and the cat of :131 as two launches
+                    rhs, probe_vector_norms = block
+                    probe_vectors = rhs.narrow(-1, 0, num_random_probes)
+                else:
+                    probe_vectors = _zero_mean_mvn_samples_columns(precond_lt, num_random_probes)  # [*batch, N, P]
+            if rhs is None:
+                probe_vector_norms = torch.linalg.vector_norm(probe_vectors, ord=2, dim=-2, keepdim=True)
+                probe_vectors = probe_vectors.div(probe_vector_norms)
 
-        rhs_list = [probe_vectors]
         num_random_probes = probe_vectors.size(-1)
-        num_inv_quad_solves = 0
-        ctx.is_vector = False
-        if inv_quad:
-            if inv_quad_rhs.ndimension() == 1:
-                inv_quad_rhs = inv_quad_rhs.unsqueeze(-1)
-                ctx.is_vector = True
-            rhs_list.append(inv_quad_rhs)
-            num_inv_quad_solves = inv_quad_rhs.size(-1)
-        rhs = torch.cat(rhs_list, -1)
+        num_inv_quad_solves = inv_quad_rhs.size(-1) if inv_quad else 0
+        if rhs is None:
+            rhs = torch.cat([probe_vectors, inv_quad_rhs], -1) if inv_quad else probe_vectors
+            ctx.rhs_block = None
+        else:
+            ctx.rhs_block = rhs  # (backward applies the preconditioner to the block instead of a copy of its first columns)
         solves, t_mat = linear_op._solve(rhs, preconditioner, num_tridiag=num_random_probes)  # reference :133
 
         logdet_term = torch.zeros(batch_shape, dtype=dtype, device=device)
@@ -204,41 +238,54 @@ class InvQuadLogdet(Function):
         linear_op = ctx.representation_tree(*matrix_args)
         precond_lt = ctx.precond_representation_tree(*precond_args)
 
+        g_iq0, g_ld0 = inv_quad_grad_output, logdet_grad_output
         if ctx.inv_quad:
             inv_quad_grad_output = inv_quad_grad_output.unsqueeze(-2)
         logdet_grad_output = logdet_grad_output.unsqueeze(-1).unsqueeze(-1)
 
         # un-normalise the probe-vector solves (:183-186)
         coef = 1.0 / ctx.probe_vectors.size(-1)
-        # (the three per-probe / per-member factors are combined first: one pass over the [*, N, P] solves)
         n_p, n_q = ctx.num_random_probes, (ctx.num_inv_quad_solves if ctx.inv_quad else 0)
-        # left / right factors of the bilinear derivative: [probe part | inv_quad part], filled in place (no torch.cat)
-        left_factors = torch.empty(*solves.shape[:-1], n_p + n_q, dtype=solves.dtype, device=solves.device)
-        right_factors = torch.empty_like(left_factors)
-        probe_vector_solves = left_factors.narrow(-1, 0, n_p)
-        torch.mul(solves.narrow(-1, 0, n_p), ctx.probe_vector_norms.mul(logdet_grad_output).mul(coef),
-                  out=probe_vector_solves)
-
-        # probes were drawn from N(0, P); P^-1 probes are draws from N(0, P^-1)  (:188-193)
-        if ctx.preconditioner is not None:
-            precond_probe_vectors = ctx.preconditioner((ctx.probe_vectors * ctx.probe_vector_norms).contiguous())
+        pre_left = pre_right = None
+        if (solves.is_cuda and solves.dtype == torch.float32 and ctx.preconditioner is not None and n_p <= 64 and n_q <= 64
+                and g_ld0.dim() == solves.dim() - 2
+                and (not ctx.inv_quad or tuple(g_iq0.shape) == (*solves.shape[:-2], n_q))):
+            # one pass (csrc/lo_probes.hip): the preconditioner is applied to the NORMALISED right-hand-side block of the
+            # forward (linear: P^-1 (z / |z|) |z| = P^-1 z, the draws from N(0, P^-1) of :188-193), then the factors of
+            # both bilinear derivatives are formed from the solves and that product together
+            block = getattr(ctx, "rhs_block", None)
+            pp = ctx.preconditioner(block if block is not None else ctx.probe_vectors.contiguous())
+            left_factors, right_factors, pre_left, pre_right = K.iql_backward_factors(
+                solves, pp, ctx.probe_vector_norms, g_ld0, g_iq0 if ctx.inv_quad else None, n_p)
+            neg_inv_quad_solves_times_grad_out = left_factors.narrow(-1, n_p, n_q) if ctx.inv_quad else None
         else:
-            precond_probe_vectors = ctx.probe_vectors * ctx.probe_vector_norms
-        right_factors.narrow(-1, 0, n_p).copy_(precond_probe_vectors)
-        neg_inv_quad_solves_times_grad_out = None
-        if ctx.inv_quad:
-            inv_quad_solves = solves.narrow(-1, n_p, n_q)
-            neg_inv_quad_solves_times_grad_out = left_factors.narrow(-1, n_p, n_q)
-            torch.mul(inv_quad_solves, inv_quad_grad_output.mul(-1), out=neg_inv_quad_solves_times_grad_out)
-            right_factors.narrow(-1, n_p, n_q).copy_(inv_quad_solves)
+            # left / right factors of the bilinear derivative: [probe part | inv_quad part], filled in place (no torch.cat)
+            left_factors = torch.empty(*solves.shape[:-1], n_p + n_q, dtype=solves.dtype, device=solves.device)
+            right_factors = torch.empty_like(left_factors)
+            probe_vector_solves = left_factors.narrow(-1, 0, n_p)
+            torch.mul(solves.narrow(-1, 0, n_p), ctx.probe_vector_norms.mul(logdet_grad_output).mul(coef),
+                      out=probe_vector_solves)
+
+            # probes were drawn from N(0, P); P^-1 probes are draws from N(0, P^-1)  (:188-193)
+            if ctx.preconditioner is not None:
+                precond_probe_vectors = ctx.preconditioner((ctx.probe_vectors * ctx.probe_vector_norms).contiguous())
+            else:
+                precond_probe_vectors = ctx.probe_vectors * ctx.probe_vector_norms
+            right_factors.narrow(-1, 0, n_p).copy_(precond_probe_vectors)
+            neg_inv_quad_solves_times_grad_out = None
+            if ctx.inv_quad:
+                inv_quad_solves = solves.narrow(-1, n_p, n_q)
+                neg_inv_quad_solves_times_grad_out = left_factors.narrow(-1, n_p, n_q)
+                torch.mul(inv_quad_solves, inv_quad_grad_output.mul(-1), out=neg_inv_quad_solves_times_grad_out)
+                right_factors.narrow(-1, n_p, n_q).copy_(inv_quad_solves)
+            pre_left = -precond_probe_vectors * coef
+            pre_right = precond_probe_vectors * logdet_grad_output
         matrix_arg_grads = linear_op._bilinear_derivative(left_factors, right_factors)
 
         # preconditioner gradient (:211-213).  In the reference the preconditioner tensors (L, d) carry an autograd
         # graph back to the operator's tensors (PivotedCholesky.backward, the QR of _init_cache) and logdet P is added
         # outside with its own graph; here the preconditioner is built by kernels outside autograd, so both
         # contributions are chained by hand into the gradients of the operator's tensors.
-        pre_left = -precond_probe_vectors * coef
-        pre_right = precond_probe_vectors * logdet_grad_output
         precond_arg_grads = _bilinear_derivative_where_needed(precond_lt, precond_args, pre_left, pre_right)
         matrix_arg_grads = _add_preconditioner_terms(
             ctx, linear_op, list(matrix_arg_grads), matrix_args, pre_left, pre_right, logdet_grad_output

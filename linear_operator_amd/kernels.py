@@ -629,6 +629,66 @@ def precond_apply(pre: WoodburyPreconditioner, r: torch.Tensor) -> torch.Tensor:
     return z.reshape(r.shape)
 
 
+def probe_vectors(L: torch.Tensor, d: torch.Tensor, e1: torch.Tensor, e2: torch.Tensor,
+                  inv_quad_rhs: Optional[torch.Tensor], batch_shape) -> tuple:
+    """lo_probe_vectors_f32: the probe vectors of InvQuadLogdet.forward (functions/_inv_quad_logdet.py:91-110, :131) for
+    the preconditioner L L^T + Diag(d): z = L e1 + sqrt(d) o e2, normalised, with the inv_quad columns behind them.
+    L [*b, N, k] (any strides, broadcast batch), d [*b, N] or [*b, 1] / [*b] (constant), e1 [*batch, k, P], e2 [*batch, N, P].
+    Returns (rhs [*batch, N, P + q], norms [*batch, 1, P]); the probes are rhs[..., :P]."""
+    lib = _hip.load()
+    bs = tuple(batch_shape)
+    N, P = e2.shape[-2:]
+    k = L.shape[-1]
+    e13, e23 = _flat(e1.expand(*bs, k, P), 2), _flat(e2.expand(*bs, N, P), 2)
+    B = e23.shape[0]
+    _hip.require_hip(L, d, e13, e23, inv_quad_rhs)
+    Lx = L.expand(*bs, N, k)
+    if len(bs) > 1:  # (one batch stride is all the kernel takes: several batch dimensions are flattened by a copy)
+        Lx = Lx.reshape(B, N, k)
+    elif len(bs) == 0:
+        Lx = Lx.unsqueeze(0)
+    const = d.shape[-1] == 1 and N != 1
+    d2 = (d.expand(*bs, 1) if const else d.expand(*bs, N)).contiguous().reshape(B, -1)
+    q = 0 if inv_quad_rhs is None else inv_quad_rhs.shape[-1]
+    iq3 = None if inv_quad_rhs is None else _flat(inv_quad_rhs.expand(*bs, N, q), 2)
+    dev = e2.device
+    out = torch.empty(B, N, P + q, dtype=torch.float32, device=dev)
+    norms = torch.empty(B, P, dtype=torch.float32, device=dev)
+    ws = _hip.workspace(lib.lo_probe_vectors_workspace_bytes(B, N, P), dev)
+    rc = lib.lo_probe_vectors_f32(_hip.ptr(Lx), Lx.stride(0), Lx.stride(1), Lx.stride(2), k, _hip.ptr(d2),
+                                  _hip.LO_DIAG_CONST if const else _hip.LO_DIAG_FULL, _hip.ptr(e13), _hip.ptr(e23),
+                                  _hip.ptr(iq3), q, B, N, P, _hip.ptr(out), _hip.ptr(norms), _hip.ptr(ws), ws.numel(),
+                                  _hip.stream_ptr(dev))
+    _hip.check(rc, "lo_probe_vectors_f32")
+    return out.reshape(*bs, N, P + q), norms.reshape(*bs, 1, P)
+
+
+def iql_backward_factors(solves: torch.Tensor, pp: torch.Tensor, norms: torch.Tensor, g_ld: torch.Tensor,
+                         g_iq: Optional[torch.Tensor], P: int):
+    """lo_iql_backward_factors_f32: the element-wise part of InvQuadLogdet.backward (functions/_inv_quad_logdet.py:183-213)
+    in one pass.  solves [*batch, N, P + q]; pp [*batch, N, >= P] the preconditioner applied to the NORMALISED probes;
+    norms [*batch, 1, P]; g_ld [*batch]; g_iq [*batch, q] or None.  Returns (left, right [*batch, N, P + q], pre_left,
+    pre_right [*batch, N, P])."""
+    lib = _hip.load()
+    bs = solves.shape[:-2]
+    N, c = solves.shape[-2:]
+    q = c - P
+    s3, p3 = _flat(solves, 2), _flat(pp, 2)
+    B = s3.shape[0]
+    n2 = norms.expand(*bs, 1, P).contiguous().reshape(B, P)
+    gl = g_ld.expand(bs).contiguous().reshape(B).to(torch.float32)
+    gq = None if (g_iq is None or q == 0) else g_iq.expand(*bs, q).contiguous().reshape(B, q).to(torch.float32)
+    _hip.require_hip(s3, p3, n2, gl, gq)
+    left, right = torch.empty_like(s3), torch.empty_like(s3)
+    pre_left = torch.empty(B, N, P, dtype=torch.float32, device=s3.device)
+    pre_right = torch.empty_like(pre_left)
+    rc = lib.lo_iql_backward_factors_f32(_hip.ptr(s3), _hip.ptr(p3), p3.shape[-1], _hip.ptr(n2), _hip.ptr(gl), _hip.ptr(gq),
+                                         1.0 / P, B, N, P, q, _hip.ptr(left), _hip.ptr(right), _hip.ptr(pre_left),
+                                         _hip.ptr(pre_right), _hip.stream_ptr(s3.device))
+    _hip.check(rc, "lo_iql_backward_factors_f32")
+    return (left.reshape(*bs, N, c), right.reshape(*bs, N, c), pre_left.reshape(*bs, N, P), pre_right.reshape(*bs, N, P))
+
+
 # ------------------------------------------------------------------------------------------------
 def pivoted_cholesky(desc: OperatorDescriptor, rank: int, error_tol: float = 1e-3, contiguous: bool = True):
     """lo_pivoted_cholesky_f32: PivotedCholesky.forward (functions/_pivoted_cholesky.py:14-105) of the
