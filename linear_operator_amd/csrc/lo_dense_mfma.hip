@@ -162,7 +162,9 @@ constexpr int DM_VLD = 20;  // row stride of the v slab [128 k][16 cols]: the fo
 // Split-K (kchunk < N, gridDim.z slices): a single operator of N = 4000 has 63 row tiles for 256 CUs -- each slice takes a
 // range of K's columns and leaves its raw partial product in ypart [slice][B][N][c]; k_dense_mv_finish adds the slices in
 // fixed order, the diagonal term and the dot partials.
-template <bool DOT, int NV>
+// UNAL: rows that are not 16-byte aligned (N % 4 != 0 or a misaligned base pointer) -- its own instantiation so that the
+// aligned kernel keeps its 112 - 176 VGPRs (three workgroups per CU): with both paths in one body the compiler took 200 - 256.
+template <bool DOT, int NV, bool UNAL>
 __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma16(const float* __restrict__ K, const float* __restrict__ dd,
                                                                int dd_mode, const float* __restrict__ v, int ldv, int c,
                                                                float* __restrict__ y, float* __restrict__ dot_part,
@@ -186,32 +188,48 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma16(const float* __res
   float vreg[8];
   float vxreg[2];
   const bool full_rows = ((N & 3) == 0) && (row0 + DM_ROWS <= N);
-  bool slab_fast = true;  // layout of the slab in kreg: 16-byte pieces (aligned fast path) or one float per lane
   auto load_slab = [&](int kb) {
-    if (full_rows && kb + DM_KB <= N) {
+    if constexpr (!UNAL) {
+      if (full_rows && kb + DM_KB <= N) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int f = threadIdx.x + kThreads * u;
-        const int r = f >> 5, q = f & 31;
-        kreg[u] = *reinterpret_cast<const float4*>(Kb + (size_t)(row0 + r) * N + kb + 4 * q);
+        for (int u = 0; u < 8; ++u) {
+          const int f = threadIdx.x + kThreads * u;
+          const int r = f >> 5, q = f & 31;
+          kreg[u] = *reinterpret_cast<const float4*>(Kb + (size_t)(row0 + r) * N + kb + 4 * q);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int f = threadIdx.x + kThreads * u;
+          const int r = f >> 5, q = f & 31;
+          const int grow = row0 + r, gk = kb + 4 * q;
+          float t[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = (grow < N && gk + e < N) ? Kb[(size_t)grow * N + gk + e] : 0.f;
+          kreg[u] = make_float4(t[0], t[1], t[2], t[3]);
+        }
       }
     } else {
-      // rows that are not 16-byte aligned (N % 4 != 0) or the ragged edge: one float per lane, consecutive lanes on
-      // consecutive floats of a row -- 256 contiguous bytes per wave instruction whatever the alignment (the 16-byte
-      // stride of four scalar loads per lane streamed at 2.9 TB/s; this order at the rate of the aligned path)
+      // one float per lane, consecutive lanes on consecutive floats of a row: 256 contiguous bytes per wave instruction
+      // whatever the alignment of the row (four scalar loads per lane at a 16-byte stride streamed at 2.9 TB/s, this
+      // order at 3.7 - 4.2; 16-byte pieces read from the aligned address below each row and stored to LDS shifted by the
+      // row's misalignment -- four conflicting 4-byte LDS stores per piece -- were SLOWER: 3.0 - 3.2 TB/s)
+      // (buffer loads: the tile's rows as one descriptor, a 32-bit lane offset -- rows beyond N fall outside its range and
+      // read 0; with 64-bit addresses the 32 loads in flight took 64 address registers: 179 - 243 VGPRs)
+      const int tile_rows = min(DM_ROWS, N - row0);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(Kb) + (size_t)row0 * N, 0, tile_rows * N * 4, 0x00020000);
+      const int kq = threadIdx.x & 127;
+      const int voff0 = (kb + kq < N) ? (((int)(threadIdx.x >> 7) * N + kb + kq) * 4) : 0x7f000000;
 #pragma unroll
-      for (int u = 0; u < 32; ++u) {
-        const int e = threadIdx.x + kThreads * u;  // float #e of the [64 rows][128 k] slab
-        const int r = e >> 7, kq = e & 127;
-        const int grow = row0 + r, gk = kb + kq;
-        const float val = (grow < N && gk < N) ? Kb[(size_t)grow * N + gk] : 0.f;
+      for (int u = 0; u < 32; ++u) {  // float #(t + 256 u) of the [64 rows][128 k] slab: row (t >> 7) + 2 u, column t & 127
+        const float val = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff0 + u * 8 * N, 0, 0));
         if ((u & 3) == 0) kreg[u >> 2].x = val;
         else if ((u & 3) == 1) kreg[u >> 2].y = val;
         else if ((u & 3) == 2) kreg[u >> 2].z = val;
         else kreg[u >> 2].w = val;
       }
     }
-    slab_fast = full_rows && kb + DM_KB <= N;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = threadIdx.x + kThreads * u;  // [128 k][16 cols]
@@ -228,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma16(const float* __res
     }
   };
   auto store_slab = [&]() {
-    if (slab_fast) {
+    if constexpr (!UNAL) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int f = threadIdx.x + kThreads * u;
@@ -472,9 +490,27 @@ template <bool DOT>
 static void launch_mv16(int nv, dim3 grid, hipStream_t st, const float* K, const float* d, int dd_mode, const float* v,
                         int ldv, int c, float* y, float* dot_part, int N, int kchunk, float* ypart, const int* stop) {
   dim3 block(kThreads);
+  const bool unal = (N & 3) != 0 || (reinterpret_cast<uintptr_t>(K) & 15) != 0;
+  // Three workgroups fit a CU (45 KB of LDS each); every workgroup streams the same number of bytes and the chip is
+  // HBM-bound, so a grid runs in rounds.  With between three and four workgroups per CU (768 < W <= 1024 on 256 CUs) the
+  // second round of three-per-CU is at most one third full; two per CU finish the same grid in two full rounds.  The
+  // launch then asks for 12 KB of dynamic LDS it does not use, which caps the occupancy at two (tools/mb_dense_occ.py,
+  // interleaved best of four: 4 x 16384^2 778 -> 720 us at 11 columns, 5 x 12288^2 593 -> 550 us; for larger grids the
+  // cap LOSES 2 - 9 % and is not applied).
+  size_t pad_lds = 0;
+  {
+    const int64_t W = (int64_t)grid.x * grid.y * grid.z, cus = std::max(64, onchip_num_workgroups());
+    if (W > 3 * cus && W <= 4 * cus && !getenv("LO_DENSE_OCC3")) pad_lds = 12 * 1024;
+  }
 #define LO_MV16(NV_)                                                                                                   \
-  hipLaunchKernelGGL((k_dense_mv_mfma16<DOT, NV_>), grid, block, 0, st, K, d, dd_mode, v, ldv, c, y, dot_part, ldv, N, \
-                     kchunk, ypart, stop)
+  do {                                                                                                                 \
+    if (unal)                                                                                                          \
+      hipLaunchKernelGGL((k_dense_mv_mfma16<DOT, NV_, true>), grid, block, pad_lds, st, K, d, dd_mode, v, ldv, c, y,   \
+                         dot_part, ldv, N, kchunk, ypart, stop);                                                       \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_dense_mv_mfma16<DOT, NV_, false>), grid, block, pad_lds, st, K, d, dd_mode, v, ldv, c, y,  \
+                         dot_part, ldv, N, kchunk, ypart, stop);                                                       \
+  } while (0)
   switch (nv) {
     case 0: LO_MV16(0); break;
     case 1: LO_MV16(1); break;
