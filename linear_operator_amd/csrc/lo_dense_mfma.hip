@@ -198,6 +198,11 @@ __global__ __launch_bounds__(kThreads) void k_dense_mv_mfma16(const float* __res
           kreg[u] = *reinterpret_cast<const float4*>(Kb + (size_t)(row0 + r) * N + kb + 4 * q);
         }
       } else {
+        // (last slab of a row whose length is not a multiple of the slab: guarded scalar loads; sizes with a ragged last
+        // TILE do not come here -- the launcher gives them the buffer-load instantiation, whose range check makes the
+        // missing rows free, because these loads made the last tile of every member a straggler: 7 x 10000^2 4.7 TB/s
+        // against 5.0 at N = 10001.  __builtin_amdgcn_raw_buffer_load_b128 would keep the 16-byte pieces, but this
+        // compiler lowers it to ONE dword load splat over the four components.)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int f = threadIdx.x + kThreads * u;
@@ -490,7 +495,8 @@ template <bool DOT>
 static void launch_mv16(int nv, dim3 grid, hipStream_t st, const float* K, const float* d, int dd_mode, const float* v,
                         int ldv, int c, float* y, float* dot_part, int N, int kchunk, float* ypart, const int* stop) {
   dim3 block(kThreads);
-  const bool unal = (N & 3) != 0 || (reinterpret_cast<uintptr_t>(K) & 15) != 0;
+  // (N % 64 != 0: a ragged last tile -- or rows that are not 16-byte aligned -- take the buffer-load instantiation)
+  const bool unal = (N & 63) != 0 || (reinterpret_cast<uintptr_t>(K) & 15) != 0;
   // Three workgroups fit a CU (45 KB of LDS each); every workgroup streams the same number of bytes and the chip is
   // HBM-bound, so a grid runs in rounds.  With between three and four workgroups per CU (768 < W <= 1024 on 256 CUs) the
   // second round of three-per-CU is at most one third full; two per CU finish the same grid in two full rounds.  The
