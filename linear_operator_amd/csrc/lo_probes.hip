@@ -20,6 +20,7 @@
 namespace lo {
 
 constexpr int PV_ROWS = 256;  // rows of a member per workgroup
+constexpr int PV_MLP = 8;     // loads a thread keeps in flight in the flat walks (4: 20 - 25 % slower, latency-bound)
 
 // Flat walk over a tile's [rows, ld] elements by 256 threads: element e = t + 256 u sits at (row, col); both advance
 // incrementally (no division in the loop).
@@ -65,18 +66,18 @@ __global__ __launch_bounds__(kThreads) void k_probe_form(const float* __restrict
     const float* src = e2 + ((size_t)b * N + r0) * P;
     const int total = nr * P;
     FlatIdx f(t, P);
-    for (int e0 = t; e0 < total; e0 += 4 * kThreads) {  // four loads in flight per thread
-      float v[4];
-      int at[4];
+    for (int e0 = t; e0 < total; e0 += PV_MLP * kThreads) {  // PV_MLP loads in flight per thread
+      float v[PV_MLP];
+      int at[PV_MLP];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < PV_MLP; ++u) {
         const int e = e0 + u * kThreads;
         v[u] = (e < total) ? src[e] : 0.f;
         at[u] = f.row * ldt + f.col;
         f.next();
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < PV_MLP; ++u)
         if (e0 + u * kThreads < total) tile[at[u]] = v[u];
     }
   }
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(kThreads) void k_probe_form(const float* __restrict
 }
 
 // out[:, :P] /= norm (norm = sqrt of the fixed-order sum of the partials); out[:, P:] = inv_quad_rhs; norms out.
-// Flat, coalesced walk over the tile's [rows, P + q] elements, four loads in flight per thread.
+// Flat, coalesced walk over the tile's [rows, P + q] elements, PV_MLP loads in flight per thread.
 __global__ __launch_bounds__(kThreads) void k_probe_scale(const float* __restrict__ part, int S, int N, int P, int q,
                                                           const float* __restrict__ iq_rhs, float* __restrict__ out,
                                                           float* __restrict__ norms) {
@@ -142,11 +143,11 @@ __global__ __launch_bounds__(kThreads) void k_probe_scale(const float* __restric
   float* ob = out + ((size_t)b * N + r0) * ldo;
   const float* ib = iq_rhs ? iq_rhs + ((size_t)b * N + r0) * q : nullptr;
   FlatIdx f(t, ldo);
-  for (int e0 = t; e0 < total; e0 += 4 * kThreads) {
-    float v[4];
-    int col[4];
+  for (int e0 = t; e0 < total; e0 += PV_MLP * kThreads) {
+    float v[PV_MLP];
+    int col[PV_MLP];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PV_MLP; ++u) {
       const int e = e0 + u * kThreads;
       col[u] = f.col;
       v[u] = 0.f;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(kThreads) void k_probe_scale(const float* __restric
       f.next();
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PV_MLP; ++u) {
       const int e = e0 + u * kThreads;
       if (e < total) ob[e] = (col[u] < P) ? v[u] / nrm_s[col[u]] : v[u];  // probe_vectors.div(probe_vector_norms)   :109
     }
@@ -184,11 +185,11 @@ __global__ __launch_bounds__(kThreads) void k_iql_factors(const float* __restric
   const int total = (r1 - r0) * ldo;
   const size_t base = ((size_t)b * N + r0);
   FlatIdx f(t, ldo);
-  for (int e0 = t; e0 < total; e0 += 4 * kThreads) {
-    float sv[4], pv[4];
-    int row[4], col[4];
+  for (int e0 = t; e0 < total; e0 += PV_MLP * kThreads) {
+    float sv[PV_MLP], pv[PV_MLP];
+    int row[PV_MLP], col[PV_MLP];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PV_MLP; ++u) {
       const int e = e0 + u * kThreads;
       row[u] = f.row;
       col[u] = f.col;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void k_iql_factors(const float* __restric
       f.next();
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PV_MLP; ++u) {
       const int e = e0 + u * kThreads;
       if (e >= total) continue;
       if (col[u] < P) {
