@@ -20,7 +20,7 @@
 namespace lo {
 
 constexpr int PV_ROWS = 256;  // rows of a member per workgroup
-constexpr int PV_MLP = 8;     // loads a thread keeps in flight in the flat walks (4: 20 - 25 % slower, latency-bound)
+constexpr int PV_MLP = 8;     // loads a thread keeps in flight in the flat walks (4 measured the same: not latency-bound)
 
 // Flat walk over a tile's [rows, ld] elements by 256 threads: element e = t + 256 u sits at (row, col); both advance
 // incrementally (no division in the loop).
