@@ -337,7 +337,10 @@ class AddedDiagLinearOperator(SumLinearOperator):
         first = noise[..., :1]
         self._constant_diag = bool(torch.equal(noise, first.expand_as(noise)))
         self._noise = first if self._constant_diag else noise
-        if L.is_cuda and L.dtype == torch.float64:
+        if L.is_cuda and (L.dtype == torch.float64 or (L.dtype == torch.float32 and L.shape[-1] > 128)):
+            # float32 preconditioners of rank > 128 (settings.max_preconditioner_size is unbounded in the reference; the
+            # kernels of lo_precond.hip stop at 128) take the same route: the reference's own thin QR, the apply as two
+            # library GEMMs called back by lo_cg_solve_f32 per iteration.
             # float64 operators (round 4): the factor comes from the float64 instantiation of the pivoted-Cholesky
             # kernels; the thin QR of _init_cache* is the LAPACK call the reference itself makes (:161-184), on the
             # device, and the apply is two library GEMMs -- not a performance path (no Woodbury descriptor: linear_cg in

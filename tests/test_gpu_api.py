@@ -1058,3 +1058,34 @@ def test_host_api_with_max_preconditioner_size_above_32():
         (iq.sum() + ld.sum()).backward()
         assert np.allclose(host(ld), ld64.numpy(), rtol=2e-2)
         assert bool(torch.isfinite(Kt.grad).all()) and bool(torch.isfinite(dt.grad).all())
+
+
+def test_preconditioner_rank_above_128_takes_the_reference_qr_route():
+    """settings.max_preconditioner_size is unbounded in the reference (settings.py:417); the build kernels stop at rank
+    128, beyond it the cache is built as the reference builds it (thin QR on the device, added_diag_linear_operator.py:
+    161-184) and applied as a closure.  Solve and logdet against float64 dense algebra; fewer iterations than rank 15."""
+    from linear_operator_amd import kernels as K
+
+    N = 1500
+    g = torch.Generator(device="cuda").manual_seed(150)
+    x = torch.rand(N, 2, generator=g, device="cuda")
+    Kd = torch.exp(-torch.cdist(x, x) ** 2 / (2 * 0.05 ** 2))  # (short length scale: the pivots do not run out before 150)
+    Kd = ((Kd + Kd.mT) * 0.5).contiguous()
+    d = torch.full((N,), 1e-2, device="cuda")
+    rhs = torch.randn(N, 2, generator=g, device="cuda")
+    want = torch.linalg.solve(Kd.double() + torch.diag(d.double()), rhs.double())
+    counts = {}
+    for rank in (15, 150):
+        A = AddedDiagLinearOperator(DenseLinearOperator(Kd), DiagLinearOperator(d))
+        with settings.max_preconditioner_size(rank), settings.min_preconditioning_size(100), settings.max_cholesky_size(0), \
+                settings.cg_tolerance(1e-3), settings.max_cg_iterations(2000), settings.preconditioner_tolerance(1e-9):
+            sol = A.solve(rhs)
+            counts[rank] = K.cg_last_executed()["streaming_iterations"]
+            closure, precond_lt, logdet_p = A._preconditioner()
+        assert ((sol.double() - want).norm() / want.norm()).item() < 5e-3
+        if rank == 150:
+            assert closure.woodbury is None and A._q_cache.shape[-1] > 128
+            L = A._piv_chol_self.double()
+            ld_ref = torch.linalg.slogdet(L @ L.mT + torch.diag(d.double()))[1]
+            assert abs(float(logdet_p) - float(ld_ref)) < 1e-2 * abs(float(ld_ref)) + 1e-2
+    assert counts[150] < counts[15], counts
