@@ -326,4 +326,10 @@ size_t pc_onchip_workspace_bytes(const lo_op_desc* op, int max_rank);
 int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float* L_rows, long long* perm,
                   int32_t* rank_out, void* ws, size_t ws_bytes, hipStream_t st);
 
+// the same for operators whose rows are fetched (dense, Kronecker of two dense factors): k_pc_onchip_rows
+bool pc_onchip_rows_eligible(const lo_op_desc* op, int max_rank);
+size_t pc_onchip_rows_workspace_bytes(const lo_op_desc* op, int max_rank);
+int pc_onchip_rows_run(const lo_op_desc* op, int rank, int max_rank, float tol, float* L_rows, long long* perm,
+                       int32_t* rank_out, void* ws, size_t ws_bytes, hipStream_t st);
+
 }  // namespace lo

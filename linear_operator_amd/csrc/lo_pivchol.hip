@@ -543,8 +543,10 @@ extern "C" {
 
 size_t lo_pivoted_cholesky_workspace_bytes(const lo_op_desc* op, int32_t max_rank) {
   if (!op) return 0;
-  return std::max(pc_ws_bytes<float>(op, max_rank, false),
-                  (pc_onchip_eligible(op, max_rank) ? pc_onchip_workspace_bytes(op, max_rank) : (size_t)0));
+  size_t need = std::max(pc_ws_bytes<float>(op, max_rank, false),
+                         (pc_onchip_eligible(op, max_rank) ? pc_onchip_workspace_bytes(op, max_rank) : (size_t)0));
+  if (pc_onchip_rows_eligible(op, max_rank)) need = std::max(need, pc_onchip_rows_workspace_bytes(op, max_rank));
+  return need;
 }
 
 int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_tol, float* L_rows, int64_t* perm,
@@ -557,6 +559,10 @@ int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_
     const int rc = pc_onchip_run(op, rank, max_rank, error_tol, L_rows, (long long*)perm, rank_out, ws, ws_bytes, st);
     if (rc != LO_ERR_LAUNCH) return rc;
     (void)hipGetLastError();  // exchange timed out (co-residency lost): redo with the streaming engine
+  } else if (pc_onchip_rows_eligible(op, max_rank)) {  // dense / Kronecker rows, same results (k_pc_onchip_rows)
+    const int rc = pc_onchip_rows_run(op, rank, max_rank, error_tol, L_rows, (long long*)perm, rank_out, ws, ws_bytes, st);
+    if (rc != LO_ERR_LAUNCH) return rc;
+    (void)hipGetLastError();
   }
   return pc_stream(op, nullptr, nullptr, nullptr, max_rank, error_tol, L_rows, perm, rank_out, ws, ws_bytes, st);
 }

@@ -710,6 +710,297 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
   }
 }
 
+// ---- the same resident factorisation for operators whose ROWS are fetched instead of formed from a resident root
+// (round 4): DenseLinearOperator (row = K[pi, :], dense_linear_operator.py:47-50) and KroneckerProductLinearOperator of
+// two dense factors (row[i] = K1[p1, i1] K2[p2, i2], kronecker_product_linear_operator.py:198-216).  The streaming engine
+// re-read the m finished rows of L for every pivot and took two launches per pivot: 2.0 ms for the cfg4 shard (128 x
+// 65536 rows, 15 pivots at 3.3 - 3.8 TB/s), 0.65 ms for the cfg5 shard, 0.4 ms for ONE dense operator of 4000 rows -- a
+// chain of 30 launches in front of every solve.  Here, as in k_pc_onchip4, a member is a group of GW workgroups of 1024
+// rows (GW up to 64: 65536 rows), a thread owns four rows with their running diagonal and permutation position in
+// registers and their L entries in LDS; per pivot ONE exchange carries every workgroup's candidate (value, position,
+// row index, error partial, its L entries 0 .. m-1); the winner's row of the operator is then fetched from memory
+// (coalesced: consecutive threads = consecutive columns) and the Schur update runs in the streaming engine's operation
+// order (-ffp-contract=off), so L and the permutation are bit-identical to it and to the CPU path.
+constexpr int PR_SLOT = 40;  // granules per workgroup and parity: header + up to 32 L entries (+ pad)
+constexpr int PR_SRC_DENSE = 1, PR_SRC_KRON = 2;
+
+struct PrArgs {
+  const float* A0;  // dense: K [B, N, N]; Kronecker: K1 [B, n1, n1]
+  const float* A1;  // Kronecker: K2 [B, n2, n2]
+  int n1, n2;
+  int64_t B;
+  int N, RW, rank, max_rank;
+  float* L;        // [B, max_rank, N]
+  float* err_rec;  // [rank, B]
+  float* orig;     // [B]
+  int* swaps;      // [B, max_rank]
+  unsigned long long* gbuf;  // [ngroups][2][GW][PR_SLOT]
+  int* err;
+};
+
+template <int GW>
+struct alignas(16) PrShared {
+  float wv[P4_WAVES];
+  int wj[P4_WAVES];
+  float we[P4_WAVES];
+  int wi[P4_WAVES];
+  unsigned part[PR_SLOT];
+  unsigned gath[GW][PR_SLOT];
+};
+
+// One granule per polling thread (a thread that polls all GW workgroups' granules of its component issues GW loads per
+// attempt: 7.3 us per pivot at GW = 64).  Phase 1: every workgroup publishes its whole payload, then thread (w, f) =
+// (t / 4, t % 4) fetches header field f (value | position | row index | error partial) of workgroup w -- 4 GW <= 256
+// threads, one load each.  Phase 2, after the winner is known: threads 0 .. m-1 fetch the WINNER's L entries only (the
+// loads of the winner's row of the operator are issued first: their latency hides behind this poll).
+__device__ __forceinline__ unsigned pr_poll(const unsigned long long* src, unsigned tag, int* err) {
+  unsigned long long g = 0;
+  unsigned spin = 0;
+  for (;;) {
+    g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(g >> 32) == tag) break;
+    if (++spin > PO_MAXSPIN ||
+        ((spin & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      atomicExch(err, 1);  // timed out, or another workgroup already did: give up at once
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return (unsigned)(g & 0xffffffffull);
+}
+
+template <int GW>
+__device__ __forceinline__ void pr_headers(PrShared<GW>& sh, int cnt, unsigned long long* slot, int wig, unsigned tag,
+                                           int* err) {
+  const int t = threadIdx.x;
+  __syncthreads();  // sh.part complete
+  if constexpr (GW == 1) {
+    if (t < cnt) sh.gath[0][t] = sh.part[t];
+  } else {
+    if (t < cnt)
+      __hip_atomic_store(slot + (size_t)wig * PR_SLOT + t, ((unsigned long long)tag << 32) | (unsigned long long)sh.part[t],
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < 4 * GW) {
+      const int w = t >> 2, fld = t & 3;
+      sh.gath[w][fld] = pr_poll(slot + (size_t)w * PR_SLOT + fld, tag, err);
+    }
+  }
+  __syncthreads();
+}
+
+// L entries 0 .. m-1 (components PO_HDR ..) of workgroup wb -> sh.gath[wb]
+template <int GW>
+__device__ __forceinline__ void pr_winner(PrShared<GW>& sh, int m, unsigned long long* slot, int wb, unsigned tag, int* err) {
+  const int t = threadIdx.x;
+  if constexpr (GW > 1) {
+    if (t < m) sh.gath[wb][PO_HDR + t] = pr_poll(slot + (size_t)wb * PR_SLOT + PO_HDR + t, tag, err);
+  }
+  __syncthreads();
+}
+
+template <int SRC, int GW, int LQ>
+__global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip_rows(PrArgs a) {
+  __shared__ PrShared<GW> sh;
+  __shared__ float4 l_static[LQ == 4 ? P4_ROWS * 4 : 1];
+  extern __shared__ float4 l_dynamic[];
+  float4* const l_s = (LQ == 4) ? l_static : l_dynamic;
+  const int wg = blockIdx.x;
+  const int xcd = wg % 8, jx = wg / 8;
+  const int groups_per_xcd = (gridDim.x / 8) / GW;
+  const int grp = xcd * groups_per_xcd + jx / GW;
+  const int wig = jx % GW;
+  const int ngroups = groups_per_xcd * 8;
+  if (jx / GW >= groups_per_xcd) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned long long* gslot = a.gbuf + (size_t)grp * 2 * GW * PR_SLOT;
+  unsigned tag = 0;
+  const int row0 = wig * a.RW;
+  const int nv = max(0, min(a.RW, a.N - row0));
+  const int N = a.N;
+
+  for (int64_t b = grp; b < a.B; b += ngroups) {
+    float dg[P4_NR];
+    int pos[P4_NR];
+    const float* K0 = a.A0 + (size_t)b * (SRC == PR_SRC_DENSE ? (size_t)N * N : (size_t)a.n1 * a.n1);
+    const float* K2 = (SRC == PR_SRC_KRON) ? a.A1 + (size_t)b * a.n2 * a.n2 : nullptr;
+    // ---- initial diagonal (dense_linear_operator.py:37-40 / the product of the factors' diagonals), positions ----
+#pragma unroll
+    for (int q = 0; q < P4_NR; ++q) {
+      const int lr = t + P4_TPB * q;
+      const bool valid = lr < nv;
+      const int i = row0 + lr;
+      float v = 0.f;
+      if (valid) {
+        if (SRC == PR_SRC_DENSE) {
+          v = K0[(size_t)i * N + i];
+        } else {
+          const int i1 = i / a.n2, i2 = i - i1 * a.n2;
+          v = K0[(size_t)i1 * a.n1 + i1] * K2[(size_t)i2 * a.n2 + i2];
+        }
+      }
+      dg[q] = v;
+      pos[q] = valid ? i : PO_INVALID;
+#pragma unroll
+      for (int s4 = 0; s4 < LQ; ++s4) l_s[l_slot<LQ>(lr, s4)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int m = 0; m < a.rank; ++m) {
+      // ---- workgroup candidate: argmax of the running diagonal over the positions >= m, error 1-norm partial ----
+      float bv = -INFINITY, es = 0.f;
+      int bj = PO_INVALID;
+#pragma unroll
+      for (int q = 0; q < P4_NR; ++q) {
+        const bool cand = pos[q] != PO_INVALID && pos[q] >= m;
+        if (cand) {
+          es += fabsf(dg[q]);
+          if (po_better(dg[q], pos[q], bv, bj)) {
+            bv = dg[q];
+            bj = pos[q];
+          }
+        }
+      }
+      po_amax_step<1>(bv, bj); po_amax_step<2>(bv, bj); po_amax_step<4>(bv, bj);
+      po_amax_step<8>(bv, bj); po_amax_step<16>(bv, bj); po_amax_step<32>(bv, bj);
+      es = wave_sum_fast(es);
+      if (lane == 0) {
+        sh.wv[wave] = bv;
+        sh.wj[wave] = bj;
+        sh.we[wave] = es;
+      }
+      __syncthreads();
+      float gv = sh.wv[lane & 3];
+      int gj = sh.wj[lane & 3];
+      float ge = sh.we[lane & 3];
+      ge = bfly_add<1>(ge); ge = bfly_add<2>(ge);
+      po_amax_step<1>(gv, gj); po_amax_step<2>(gv, gj);
+      gv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gv)));
+      gj = __builtin_amdgcn_readfirstlane(gj);
+      ge = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ge)));
+      // the owner of the candidate publishes it: header (value, position, row index, error) and its L entries 0..m-1
+#pragma unroll
+      for (int q = 0; q < P4_NR; ++q) {
+        if (pos[q] != PO_INVALID && pos[q] >= m && pos[q] == gj) {
+          const int lr = t + P4_TPB * q;
+          sh.part[0] = __float_as_uint(gv);
+          sh.part[1] = (unsigned)gj;
+          sh.part[2] = (unsigned)(row0 + lr);
+          float4* dst = reinterpret_cast<float4*>(&sh.part[PO_HDR]);
+          for (int j4 = 0; 4 * j4 < m; ++j4) dst[j4] = l_s[l_slot<LQ>(lr, j4)];
+        }
+      }
+      if (t == 0) {
+        if (gj == PO_INVALID) {
+          sh.part[0] = __float_as_uint(-INFINITY);
+          sh.part[1] = (unsigned)PO_INVALID;
+          sh.part[2] = 0u;
+        }
+        sh.part[3] = __float_as_uint(ge);
+      }
+      ++tag;
+      unsigned long long* slot = gslot + (size_t)(tag & 1u) * GW * PR_SLOT;
+      pr_headers<GW>(sh, PO_HDR + m, slot, wig, tag, a.err);
+
+      // ---- group winner (identical in all workgroups): lane l holds candidate l % GW ----
+      float vb = __uint_as_float(sh.gath[lane % GW][0]);
+      const int myj = (int)sh.gath[lane % GW][1];
+      int jb = myj;
+      float etot = __uint_as_float(sh.gath[lane % GW][3]);
+      if constexpr (GW >= 2) { etot = bfly_add<1>(etot); po_amax_step<1>(vb, jb); }
+      if constexpr (GW >= 4) { etot = bfly_add<2>(etot); po_amax_step<2>(vb, jb); }
+      if constexpr (GW >= 8) { etot = bfly_add<4>(etot); po_amax_step<4>(vb, jb); }
+      if constexpr (GW >= 16) { etot = bfly_add<8>(etot); po_amax_step<8>(vb, jb); }
+      if constexpr (GW >= 32) { etot = bfly_add<16>(etot); po_amax_step<16>(vb, jb); }
+      if constexpr (GW >= 64) { etot = bfly_add<32>(etot); po_amax_step<32>(vb, jb); }
+      vb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vb)));
+      jb = __builtin_amdgcn_readfirstlane(jb);
+      etot = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(etot)));
+      const unsigned long long wbal = __ballot(lane < GW && myj == jb);
+      const int wb = wbal ? __ffsll((long long)wbal) - 1 : 0;
+      const int pim = __builtin_amdgcn_readfirstlane((int)sh.gath[wb][2]);  // the winner's row of the operator
+      if (wig == 0 && t == 0) {
+        a.err_rec[(size_t)m * a.B + b] = etot;
+        if (m == 0) a.orig[b] = vb;
+        a.swaps[(size_t)b * a.max_rank + m] = jb;
+      }
+      const float piv = sqrtf(vb);  // :73-74
+      const float* g = reinterpret_cast<const float*>(sh.gath[wb]) + PO_HDR;
+      // ---- row pi_m of the operator at this thread's four columns ----
+      float rowv[P4_NR], accs[P4_NR];
+      if (SRC == PR_SRC_DENSE) {
+        const float* kr = K0 + (size_t)pim * N + row0;
+#pragma unroll
+        for (int q = 0; q < P4_NR; ++q) rowv[q] = (t + P4_TPB * q < nv) ? kr[t + P4_TPB * q] : 0.f;
+      } else {
+        const int p1 = pim / a.n2, p2 = pim - p1 * a.n2;
+        const float* k1r = K0 + (size_t)p1 * a.n1;
+        const float* k2r = K2 + (size_t)p2 * a.n2;
+#pragma unroll
+        for (int q = 0; q < P4_NR; ++q) {
+          const int i = min(row0 + t + P4_TPB * q, N - 1);
+          const int i1 = i / a.n2, i2 = i - i1 * a.n2;
+          rowv[q] = k1r[i1] * k2r[i2];
+        }
+      }
+      pr_winner<GW>(sh, m, slot, wb, tag, a.err);  // (the row loads above are in flight)
+      // ---- Schur update, :83-89: products and sums sequential in j (the four rows in lockstep) ----
+#pragma unroll
+      for (int q = 0; q < P4_NR; ++q) accs[q] = 0.f;
+      for (int j4 = 0; 4 * j4 < m; ++j4) {
+        const float4 u4 = *reinterpret_cast<const float4*>(g + 4 * j4);
+        const int j = 4 * j4;
+        float4 l4[P4_NR];
+#pragma unroll
+        for (int q = 0; q < P4_NR; ++q) l4[q] = l_s[l_slot<LQ>(t + P4_TPB * q, j4)];
+#pragma unroll
+        for (int q = 0; q < P4_NR; ++q) accs[q] = (j == 0) ? u4.x * l4[q].x : accs[q] + u4.x * l4[q].x;
+        if (j + 1 < m) {
+#pragma unroll
+          for (int q = 0; q < P4_NR; ++q) accs[q] = accs[q] + u4.y * l4[q].y;
+        }
+        if (j + 2 < m) {
+#pragma unroll
+          for (int q = 0; q < P4_NR; ++q) accs[q] = accs[q] + u4.z * l4[q].z;
+        }
+        if (j + 3 < m) {
+#pragma unroll
+          for (int q = 0; q < P4_NR; ++q) accs[q] = accs[q] + u4.w * l4[q].w;
+        }
+      }
+      const int ms = m >> 2, me = m & 3;
+      float vq[P4_NR];
+#pragma unroll
+      for (int q = 0; q < P4_NR; ++q) vq[q] = ((m > 0) ? rowv[q] - accs[q] : rowv[q]) / piv;  // :91
+#pragma unroll
+      for (int q = 0; q < P4_NR; ++q) {
+        const int pq = pos[q];
+        const bool live = pq != PO_INVALID;
+        const int np = (pq == jb) ? m : ((pq == m) ? jb : pq);  // permutation swap of positions m and jb (:67-70)
+        if (live) pos[q] = np;
+        const float val = (np == m) ? piv : vq[q];  // the pivot row gets sqrt(max) (:73-74)
+        if (live && np >= m) reinterpret_cast<float*>(&l_s[l_slot<LQ>(t + P4_TPB * q, ms)])[me] = val;
+        if (live && np > m) dg[q] = dg[q] - vq[q] * vq[q];  // :94-95
+      }
+    }
+    // ---- L rows -> global, [max_rank, N] layout, consecutive threads = consecutive rows ----
+#pragma unroll
+    for (int q = 0; q < P4_NR; ++q) {
+      const int lr = t + P4_TPB * q;
+      if (lr < nv) {
+        float* Lb = a.L + (size_t)b * a.max_rank * N + row0 + lr;
+#pragma unroll
+        for (int j4 = 0; j4 < LQ; ++j4) {
+          const float4 l4 = l_s[l_slot<LQ>(lr, j4)];
+          const int m0 = 4 * j4;
+          if (m0 < a.max_rank) Lb[(size_t)m0 * N] = (m0 < a.rank) ? l4.x : 0.f;
+          if (m0 + 1 < a.max_rank) Lb[(size_t)(m0 + 1) * N] = (m0 + 1 < a.rank) ? l4.y : 0.f;
+          if (m0 + 2 < a.max_rank) Lb[(size_t)(m0 + 2) * N] = (m0 + 2 < a.rank) ? l4.z : 0.f;
+          if (m0 + 3 < a.max_rank) Lb[(size_t)(m0 + 3) * N] = (m0 + 3 < a.rank) ? l4.w : 0.f;
+        }
+      }
+    }
+    __syncthreads();  // l_s / sh reuse by the next member
+  }
+}
+
 // m* = number of pivots the reference takes: pivot 0 always, pivot m >= 1 while max_b error_{m-1} > tol (:57, :99).
 // Wave w evaluates the pivots m = w + 1, w + 5, ... (max over the members with wave butterflies, no barriers inside);
 // thread 0 then takes the first failing m.
@@ -928,6 +1219,138 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
     fprintf(stderr, "pc_onchip member0 (100 MHz ticks): load %lld pivots %lld store %lld | reduce+publish %lld gather %lld update %lld\n",
             ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4], ts[5], ts[6]);
     fprintf(stderr, "  update split: winner+row fetch %lld, C.C chain %lld, L.L chain %lld\n", ts[7], ts[8], ts[9]);
+  }
+  if (h[0]) {
+    onchip_note_timeout();
+    return LO_ERR_LAUNCH;
+  }
+  *rank_out = h[1];
+  return LO_OK;
+}
+
+// ---- host side of k_pc_onchip_rows ----------------------------------------------------------------------------------
+bool pc_onchip_rows_eligible(const lo_op_desc* op, int max_rank) {
+  if (g_onchip_disabled || getenv("LO_PC_NO_RESIDENT_ROWS")) return false;
+  if (op->kind == LO_OP_DENSE_DIAG) {
+    if (!op->A0) return false;
+  } else if (op->kind == LO_OP_KRON_DIAG) {
+    if (!op->A0 || !op->A1 || op->R < 1 || op->n2 < 1 || op->R * op->n2 != op->N) return false;
+  } else {
+    return false;
+  }
+  return max_rank <= P4_MAXR && op->N >= 64 && op->N <= (int64_t)64 * P4_ROWS && onchip_num_workgroups() >= 64;
+}
+
+struct PrLayout {
+  float* err_rec;
+  float* orig;
+  int* swaps;
+  unsigned long long* gbuf;
+  int* err;
+  int* m_out;
+};
+
+static void pr_layout(const lo_op_desc* op, int max_rank, Arena& ar, PrLayout* l) {
+  const int64_t B = op->B;
+  l->err = ar.take<int>(4);
+  l->m_out = l->err + 1;
+  l->err_rec = ar.take<float>((size_t)max_rank * B);
+  l->orig = ar.take<float>(B);
+  l->swaps = ar.take<int>((size_t)B * max_rank);
+  l->gbuf = ar.take<unsigned long long>((size_t)512 * 2 * PR_SLOT);
+}
+
+size_t pc_onchip_rows_workspace_bytes(const lo_op_desc* op, int max_rank) {
+  Arena ar(nullptr, 0);
+  PrLayout l;
+  pr_layout(op, max_rank, ar, &l);
+  return ar.off + 1024;
+}
+
+template <int SRC, int GW>
+static int pr_go(const PrArgs& a, bool wide, int nwg, hipStream_t st) {
+  const int wpc = wide ? 1 : 2;
+  const size_t dyn_lds = wide ? sizeof(float4) * (size_t)P4_ROWS * 8 : 0;
+  int per_cu = 0;
+  hipError_t e;
+  if (wide) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pc_onchip_rows<SRC, GW, 8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+    if (e == hipSuccess) e = LO_OCCUPANCY_CACHED(per_cu, (k_pc_onchip_rows<SRC, GW, 8>), P4_TPB, dyn_lds);
+  } else {
+    e = LO_OCCUPANCY_CACHED(per_cu, (k_pc_onchip_rows<SRC, GW, 4>), P4_TPB, 0);
+  }
+  // every XCD must hold at least one whole group, all of its workgroups resident at once
+  if (e != hipSuccess || per_cu < wpc || (wpc * nwg / 8) / GW < 1) return LO_ERR_LAUNCH;
+  LO_PROF_BEGIN("pc_onchip_rows", st);
+  {
+    ResidentLaunch guard(st);
+    if (wide) hipLaunchKernelGGL((k_pc_onchip_rows<SRC, GW, 8>), dim3(wpc * nwg), dim3(P4_TPB), dyn_lds, st, a);
+    else hipLaunchKernelGGL((k_pc_onchip_rows<SRC, GW, 4>), dim3(wpc * nwg), dim3(P4_TPB), 0, st, a);
+  }
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+template <int SRC>
+static int pr_go_gw(int gw, const PrArgs& a, bool wide, int nwg, hipStream_t st) {
+  switch (gw) {
+    case 1: return pr_go<SRC, 1>(a, wide, nwg, st);
+    case 2: return pr_go<SRC, 2>(a, wide, nwg, st);
+    case 4: return pr_go<SRC, 4>(a, wide, nwg, st);
+    case 8: return pr_go<SRC, 8>(a, wide, nwg, st);
+    case 16: return pr_go<SRC, 16>(a, wide, nwg, st);
+    case 32: return pr_go<SRC, 32>(a, wide, nwg, st);
+    default: return pr_go<SRC, 64>(a, wide, nwg, st);
+  }
+}
+
+// returns LO_ERR_LAUNCH when the kernel does not fit or an exchange timed out (caller falls back to the streaming engine)
+int pc_onchip_rows_run(const lo_op_desc* op, int rank, int max_rank, float tol, float* L_rows, long long* perm,
+                       int32_t* rank_out, void* ws, size_t ws_bytes, hipStream_t st) {
+  Arena ar(ws, ws_bytes);
+  PrLayout l;
+  pr_layout(op, max_rank, ar, &l);
+  if (!ar.ok) return LO_ERR_WORKSPACE;
+  const int nwg = onchip_num_workgroups();
+  int gw = 64;
+  for (int gq = 1; gq < 64; gq *= 2)
+    if (op->N <= (int64_t)gq * P4_ROWS) {
+      gw = gq;
+      break;
+    }
+  const bool wide = max_rank > PO_MAXR;  // rank 17 .. 32: 128 KB of L rows per workgroup, one workgroup per CU
+  PrArgs a;
+  a.A0 = op->A0; a.A1 = op->A1;
+  a.n1 = (int)op->R; a.n2 = (int)op->n2;
+  a.B = op->B; a.N = (int)op->N;
+  a.RW = (int)((op->N + gw - 1) / gw);
+  a.rank = rank; a.max_rank = max_rank;
+  a.L = L_rows; a.err_rec = l.err_rec; a.orig = l.orig; a.swaps = l.swaps; a.gbuf = l.gbuf; a.err = l.err;
+  LO_HIP_CHECK(hipMemsetAsync(l.err, 0, 4 * sizeof(int), st));
+  if (getenv("LO_OC_TEST_FALLBACK")) LO_HIP_CHECK(hipMemsetAsync(l.err, 1, 1, st));  // as if an exchange had timed out
+  {
+    const int zrc = zero_span(l.gbuf, sizeof(unsigned long long) * (size_t)512 * 2 * PR_SLOT, st);
+    if (zrc) return zrc;
+  }
+  const int rc = (op->kind == LO_OP_DENSE_DIAG) ? pr_go_gw<PR_SRC_DENSE>(gw, a, wide, nwg, st)
+                                                : pr_go_gw<PR_SRC_KRON>(gw, a, wide, nwg, st);
+  if (rc) return rc;
+  PoArgs pa;  // (k_po_perm reads the recorded errors / swaps and the factor)
+  memset(&pa, 0, sizeof(pa));
+  pa.B = op->B; pa.N = (int)op->N; pa.rank = rank; pa.max_rank = max_rank;
+  pa.L = L_rows; pa.err_rec = l.err_rec; pa.orig = l.orig; pa.swaps = l.swaps;
+  LO_PROF_BEGIN("pc_onchip_perm", st);
+  hipLaunchKernelGGL(k_po_perm, dim3((unsigned)op->B), dim3(kThreads), 0, st, pa, tol, l.m_out, perm);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  int h[2];
+  {
+    void* hp = pinned_status_block();
+    LO_HIP_CHECK(hipMemcpyAsync(hp ? hp : h, l.err, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    LO_HIP_CHECK(hipStreamSynchronize(st));
+    if (hp) memcpy(h, hp, sizeof(h));
   }
   if (h[0]) {
     onchip_note_timeout();
