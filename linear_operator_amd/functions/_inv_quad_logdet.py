@@ -110,8 +110,11 @@ def _fused_probe_block(precond_lt, num_samples, inv_quad_rhs, batch_shape):
     if L is None or diag is None or not (L.is_cuda and L.dtype == torch.float32):
         return None
     batch, n = tuple(batch_shape), precond_lt.size(-1)
-    if L.size(-1) > 32 or num_samples > 64 or tuple(precond_lt.batch_shape) != batch:
-        return None
+    nb = 1
+    for sz in batch:
+        nb *= int(sz)
+    if L.size(-1) > 32 or num_samples > 64 or tuple(precond_lt.batch_shape) != batch or nb > 65535 or nb < 1:
+        return None  # (shapes lo_probe_vectors_f32 does not take: the torch expressions below)
     if inv_quad_rhs is not None and not (inv_quad_rhs.is_cuda and inv_quad_rhs.dtype == torch.float32 and
                                         inv_quad_rhs.size(-1) <= 64 and tuple(inv_quad_rhs.shape[:-2]) == batch):
         return None
@@ -248,7 +251,7 @@ class InvQuadLogdet(Function):
         n_p, n_q = ctx.num_random_probes, (ctx.num_inv_quad_solves if ctx.inv_quad else 0)
         pre_left = pre_right = None
         if (solves.is_cuda and solves.dtype == torch.float32 and ctx.preconditioner is not None and n_p <= 64 and n_q <= 64
-                and g_ld0.dim() == solves.dim() - 2
+                and g_ld0.dim() == solves.dim() - 2 and 1 <= solves.shape[:-2].numel() <= 65535
                 and (not ctx.inv_quad or tuple(g_iq0.shape) == (*solves.shape[:-2], n_q))):
             # one pass (csrc/lo_probes.hip): the preconditioner is applied to the NORMALISED right-hand-side block of the
             # forward (linear: P^-1 (z / |z|) |z| = P^-1 z, the draws from N(0, P^-1) of :188-193), then the factors of
