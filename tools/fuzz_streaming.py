@@ -17,11 +17,11 @@ dev = torch.device("cuda")
 n_k = n_d = 0
 while time.time() < t_end:
     g = torch.Generator(device=dev); g.manual_seed(rnd.randrange(1 << 30))
-    c = rnd.choice([1, 1, 1, 3, 17])
-    k = rnd.choice([0, 7, 15])
+    c = rnd.choice([1, 1, 3, 11, 17, 32])
+    k = rnd.choice([0, 7, 15, 32])
     if rnd.random() < 0.6:
-        n1, n2 = rnd.choice([(64, 64), (72, 68), (96, 96), (128, 64), (100, 100), (33, 40), (64, 132)])
-        B = rnd.choice([1, 2, 5])
+        n1, n2 = rnd.choice([(64, 64), (72, 68), (96, 96), (128, 64), (100, 100), (33, 40), (64, 132), (200, 200)])
+        B = rnd.choice([1, 2, 5]) if n1 * n2 <= 16384 else 1
         X1 = torch.randn(B, n1, n1, generator=g, device=dev) / n1 ** 0.5
         X2 = torch.randn(B, n2, n2, generator=g, device=dev) / n2 ** 0.5
         K1 = X1 @ X1.mT + 0.1 * torch.eye(n1, device=dev); K2 = X2 @ X2.mT + 0.1 * torch.eye(n2, device=dev)
@@ -34,7 +34,7 @@ while time.time() < t_end:
         darg, const = sig, True
         n_k += 1
     else:
-        N = rnd.choice([300, 1025, 2050, 4096, 8192])
+        N = rnd.choice([65, 300, 777, 1025, 1500, 2050, 4096, 5001, 8192, 20000])
         B = rnd.choice([1, 2, 3]) if N <= 4096 else 1
         X = torch.randn(B, N, N, generator=g, device=dev) / N ** 0.5
         Kd = X @ X.mT
