@@ -279,7 +279,9 @@ class AddedDiagLinearOperator(SumLinearOperator):
                     break
         if self._q_cache is None:
             self._piv_chol_self = self._pivoted_cholesky_factor(max_iter)  # :125
-            if torch.any(torch.isnan(self._piv_chol_self)).item():  # :126-131
+            # :126-131 `torch.any(torch.isnan(L))` as one reduction pass: amax propagates NaN, so the maximum is NaN
+            # exactly when some entry is (no boolean tensor of L's size in between)
+            if self._piv_chol_self.numel() and torch.isnan(self._piv_chol_self.amax()).item():
                 warnings.warn(
                     "NaNs encountered in preconditioner computation. Attempting to continue without preconditioning.",
                     NumericalWarning,

@@ -1089,3 +1089,32 @@ def test_preconditioner_rank_above_128_takes_the_reference_qr_route():
             ld_ref = torch.linalg.slogdet(L @ L.mT + torch.diag(d.double()))[1]
             assert abs(float(logdet_p) - float(ld_ref)) < 1e-2 * abs(float(ld_ref)) + 1e-2
     assert counts[150] < counts[15], counts
+
+
+def test_nan_in_the_preconditioner_factor_warns_and_continues_without_it():
+    """added_diag_linear_operator.py:126-131: NaNs in the pivoted-Cholesky factor (here: an operator with a negative
+    diagonal, sqrt of the pivot) -> NumericalWarning and (None, None, None); a clean factor of the same shape does not
+    warn.  (The test is one reduction pass here: amax propagates NaN.)"""
+    from linear_operator_amd.operators.added_diag_linear_operator import clear_preconditioner_memo
+
+    N = 300
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = torch.randn(2, N, 20, generator=g, device="cuda")
+    good = X @ X.mT
+    bad = good.clone()
+    bad[1] = -bad[1]  # second member: every diagonal entry negative
+    d = torch.full((2, N), 0.5, device="cuda")
+    with settings.min_preconditioning_size(10), settings.max_preconditioner_size(8):
+        clear_preconditioner_memo()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            out = AddedDiagLinearOperator(DenseLinearOperator(bad), DiagLinearOperator(d))._preconditioner()
+        assert out == (None, None, None)
+        assert any(issubclass(x.category, NumericalWarning) and "NaNs encountered in preconditioner" in str(x.message)
+                   for x in w)
+        clear_preconditioner_memo()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            closure, lt, logdet = AddedDiagLinearOperator(DenseLinearOperator(good), DiagLinearOperator(d))._preconditioner()
+        assert closure is not None and torch.isfinite(logdet).all()
+        assert not any("NaNs encountered in preconditioner" in str(x.message) for x in w)
