@@ -742,6 +742,35 @@ def main():
     solve_rel_err = woodbury_fp64_rel_err(Cm, d, rhs, res_check.x)
     x_check = res_check.x.clone()
     res = None
+    # soak FIRST: the same step again and again for >= --min-seconds, every step timed on its own (host clock around a
+    # synchronous solve).  It doubles as the ramp: the first ~40 solves after ANY pause of the device (the validation
+    # above reads results back on the host) are 3 - 7 % slower than the steady state (tools/mb_step_ramp.py), and a W + K
+    # window of 10 ms right after such a pause measured the ramp, not the engine (0.404 vs 0.376 ms on the same box,
+    # profiles/r04/README.md).  The step count comes from a fenced pilot of five steps, maximum over the ranks, so that
+    # every rank runs the same number of steps (and all-gathers).
+    soak = None
+    if args.min_seconds > 0:
+        for _ in range(3):
+            res = step()
+        fence()
+        tp = time.perf_counter()
+        for _ in range(5):
+            res = step()
+        fence()
+        pilot = (time.perf_counter() - tp) / 5
+        if use_dist:
+            pilot = max(_gather_rank_ms(dist, pilot * 1e3, device)) * 1e-3
+        n_soak = max(1, min(200000, int(args.min_seconds / pilot)))
+        laps = [0.0] * n_soak
+        for i in range(n_soak):
+            ta = time.perf_counter()
+            res = step()
+            laps[i] = time.perf_counter() - ta
+        fence()
+        soak = _step_stats(laps)
+        soak["seconds"] = round(sum(laps), 3)
+        soak["position"] = "before the warm-up and the timed steps"
+    # ---- the contract's region: W untimed warm-up steps, then EXACTLY K steps between two fences (barrier + synchronize)
     for _ in range(args.warmup):
         res = step()
     fence()
@@ -766,19 +795,6 @@ def main():
             dist.all_gather_into_tensor(gather_bufs[i % 2], res.x)
         torch.cuda.synchronize(device)
         allgather_ms = (time.perf_counter() - tg) / 5 * 1e3
-    # soak: the same step again and again, every step timed on its own (host clock around a synchronous solve); the
-    # count follows from the job's measured step time, so every rank runs the same number of steps (and gathers)
-    soak = None
-    if args.min_seconds > 0:
-        n_soak = max(1, min(200000, int(args.min_seconds / (elapsed / args.steps))))
-        laps = [0.0] * n_soak
-        for i in range(n_soak):
-            ta = time.perf_counter()
-            res = step()
-            laps[i] = time.perf_counter() - ta
-        fence()
-        soak = _step_stats(laps)
-        soak["seconds"] = round(sum(laps), 3)
     matvecs_per_solve = res.matvecs
     total_members = world * B_PER_GPU
     value = total_members * matvecs_per_solve * args.steps / elapsed
