@@ -192,14 +192,26 @@ def _gc_off():
     gc.disable()
 
 
-def _time(fn, reps):
-    fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        out = fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps, out
+def _time(fn, reps, warm_seconds=0.02, min_seconds=0.05):
+    """Seconds per call of fn.  At least one untimed call and >= 20 ms of them (the first calls after a pause of the
+    device run 3 - 7 % slow, see the soak of the headline), then `reps` calls -- more if those take less than 50 ms."""
+    t_end = time.perf_counter() + warm_seconds
+    while True:
+        fn()
+        torch.cuda.synchronize()
+        if time.perf_counter() >= t_end:
+            break
+    while True:
+        out = None
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = None  # (a result of several GB must not be alive while the next call allocates its own)
+            out = fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds or reps >= 4096:
+            return dt / reps, out
+        reps = min(4096, max(reps + 1, int(reps * min_seconds / max(dt, 1e-6)) + 1))
 
 
 def _profiled(fn):
@@ -348,7 +360,9 @@ def other_configs(device):
         return iq
 
     with lo_settings.cg_tolerance(TOL), lo_settings.num_trace_samples(16):
-        t, _ = _time(train_step, 2)
+        # (one untimed + two timed steps, as before: the cyclic collector is off in this process and every step's autograd
+        # graph holds several GB until it is collected -- more repetitions would time the allocator, not the step)
+        t, _ = _time(train_step, 2, warm_seconds=0.0, min_seconds=0.0)
     res["cfg3_B512_inv_quad_logdet_forward_backward_host_api"] = {"ms": t * 1e3, "member_steps_per_s": B_PER_GPU / t,
                                                                   "preconditioner": "rebuilt every step"}
     del Cm, d, full, desc, V, q_mat, Cg, dg, y
