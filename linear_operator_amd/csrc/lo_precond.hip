@@ -275,6 +275,7 @@ __global__ __launch_bounds__(kThreads) void k_pb_q_mfma(const float* __restrict_
                                                          const float* __restrict__ sc, const float* __restrict__ dd,
                                                          int diag_mode, int N, int k, int ldq, int rows_per,
                                                          const double* __restrict__ Minv, float* __restrict__ Q) {
+  __shared__ __attribute__((aligned(16))) float q_tile[kThreads / 64][64 * 20];
   const int s = blockIdx.x;
   const int64_t b = blockIdx.y;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -322,7 +323,29 @@ __global__ __launch_bounds__(kThreads) void k_pb_q_mfma(const float* __restrict_
       acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)(x.w * sv.w), mb[st], acc[3], 0, 0, 0);
     }
     // acc[t][r] = Qtile_t[4 r + kk][j = i] -> row cb + 4 (4 r + kk) + t, column j
-    if (i < ldq) {
+    if (full && ldq == 16) {
+      // the wave's 64 rows x 16 columns are 4 KB contiguous in Q: through the wave's LDS tile (row stride 20 floats: the
+      // four row groups kk of a store land in different banks, rows stay 16-byte aligned) and out as four 16-byte stores
+      // per lane -- the direct stores below write 64-byte pieces of four rows per instruction (2.6 TB/s for the kernel)
+      float* tile = q_tile[wave];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lrow = 16 * r + 4 * kk;
+        const float4 s4 = scb ? *reinterpret_cast<const float4*>(scb + cb + lrow) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const double rs4[4] = {scb ? (double)s4.x : cs, scb ? (double)s4.y : cs, scb ? (double)s4.z : cs,
+                               scb ? (double)s4.w : cs};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) tile[(lrow + t) * 20 + i] = (float)(acc[t][r] * rs4[t]);
+      }
+      __builtin_amdgcn_wave_barrier();  // (LDS operations of a wave execute in order; this pins the compiler's order)
+      float4* dst = reinterpret_cast<float4*>(Qb + (size_t)cb * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = l + 64 * q;  // float4 index inside the 64 x 16 tile: row f / 4, columns 4 (f % 4) ..
+        dst[f] = *reinterpret_cast<const float4*>(tile + (f >> 2) * 20 + 4 * (f & 3));
+      }
+      __builtin_amdgcn_wave_barrier();  // the next chunk reuses the tile
+    } else if (i < ldq) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rowb = cb + 16 * r + 4 * kk;

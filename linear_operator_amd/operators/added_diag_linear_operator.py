@@ -337,7 +337,12 @@ class AddedDiagLinearOperator(SumLinearOperator):
         noise = self._diag_tensor._diagonal().expand(*batch_shape, n)
         # constant-diagonal test on VALUES, as the reference does (:146-150), not on the operator type
         first = noise[..., :1]
-        self._constant_diag = bool(torch.equal(noise, first.expand_as(noise)))
+        if noise.stride(-1) == 0 or n == 1:
+            # a ConstantDiagLinearOperator (homoskedastic noise): the diagonal is an expanded [*batch, 1] tensor, constant
+            # by construction -- no comparison kernel and no read-back
+            self._constant_diag = True
+        else:
+            self._constant_diag = bool(torch.equal(noise, first.expand_as(noise)))
         self._noise = first if self._constant_diag else noise
         if L.is_cuda and (L.dtype == torch.float64 or (L.dtype == torch.float32 and L.shape[-1] > 128)):
             # float32 preconditioners of rank > 128 (settings.max_preconditioner_size is unbounded in the reference; the
