@@ -20,6 +20,7 @@ from torch import Tensor
 
 from .. import settings, utils
 from ..utils.broadcasting import _matmul_broadcast_shape
+from ..utils.cholesky import cholesky_solve
 from .linear_operator_representation_tree import LinearOperatorRepresentationTree
 
 _HANDLED_FUNCTIONS = {}
@@ -779,7 +780,7 @@ class _TriangularFactor:
         is_vec = rhs.dim() == 1
         if is_vec:
             rhs = rhs.unsqueeze(-1)
-        res = torch.cholesky_solve(rhs, self.factor, upper=self.upper)
+        res = cholesky_solve(rhs, self.factor, upper=self.upper)
         return res.squeeze(-1) if is_vec else res
 
     def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):

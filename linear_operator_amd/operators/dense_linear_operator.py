@@ -7,6 +7,7 @@ import torch
 from torch import Tensor
 
 from .. import kernels as K
+from ..utils.cholesky import cholesky_solve
 from ._linear_operator import LinearOperator, to_dense
 
 
@@ -36,7 +37,7 @@ class DenseLinearOperator(LinearOperator):
         return K.dense_diag_descriptor(t, None)
 
     def _cholesky_solve(self, rhs, upper: bool = False):
-        return torch.cholesky_solve(rhs, self.to_dense(), upper=upper)
+        return cholesky_solve(rhs, self.to_dense(), upper=upper)
 
     def _bilinear_derivative(self, left_vecs: Tensor, right_vecs: Tensor):  # reference :69-71
         res = K.bilinear_dense(left_vecs, right_vecs, self.batch_shape)

@@ -16,7 +16,7 @@ import torch
 from torch import Tensor
 
 from .. import kernels as K
-from ..utils.cholesky import psd_safe_cholesky
+from ..utils.cholesky import cholesky_solve, psd_safe_cholesky
 from .added_diag_linear_operator import AddedDiagLinearOperator
 from .diag_linear_operator import DiagLinearOperator
 from .root_linear_operator import LowRankRootLinearOperator
@@ -91,7 +91,7 @@ class LowRankRootAddedDiagLinearOperator(AddedDiagLinearOperator):
         if self._wide_root():  # D^-1 r - D^-1 C cap^-1 C^T D^-1 r with library GEMMs
             C, d = self._root_and_diag()
             Cd = C / d.unsqueeze(-1)
-            small = torch.cholesky_solve(Cd.mT @ rhs, self.chol_cap_mat)
+            small = cholesky_solve(Cd.mT @ rhs, self.chol_cap_mat)
             return rhs / d.unsqueeze(-1) - Cd @ small
         pre = self._woodbury_factor()
         batch = torch.broadcast_shapes(self.batch_shape, rhs.shape[:-2])

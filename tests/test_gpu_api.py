@@ -1118,3 +1118,39 @@ def test_nan_in_the_preconditioner_factor_warns_and_continues_without_it():
             closure, lt, logdet = AddedDiagLinearOperator(DenseLinearOperator(good), DiagLinearOperator(d))._preconditioner()
         assert closure is not None and torch.isfinite(logdet).all()
         assert not any("NaNs encountered in preconditioner" in str(x.message) for x in w)
+
+
+@pytest.mark.parametrize("batch,n", [((3,), 300), ((2, 2), 257), ((2,), 383)])
+def test_batched_cholesky_of_257_to_383_rows_goes_through_the_padded_factorisation(batch, n):
+    """utils/cholesky.py:_cholesky_ex: the batched float32 factorisation of these sizes kills the HIP context on this stack;
+    psd_safe_cholesky (the N <= max_cholesky_size branch of solve / inv_quad_logdet, reference utils/cholesky.py:13-74)
+    factorises blockdiag(A, I) instead.  Values against float64, and the small-operator solve through the API."""
+    from linear_operator_amd.utils.cholesky import psd_safe_cholesky
+
+    g = torch.Generator(device="cuda").manual_seed(n)
+    X = torch.randn(*batch, n, 24, generator=g, device="cuda")
+    A = X @ X.mT + 0.5 * torch.eye(n, device="cuda")
+    L = psd_safe_cholesky(A)
+    L64 = torch.linalg.cholesky(A.double())
+    assert L.shape == A.shape and (L.double() - L64).abs().max().item() < 1e-4 * L64.abs().max().item()
+    rhs = torch.randn(*batch, n, 3, generator=g, device="cuda")
+    d = torch.full((*batch, n), 0.25, device="cuda")
+    x = AddedDiagLinearOperator(DenseLinearOperator(A), DiagLinearOperator(d)).solve(rhs)
+    exact = torch.linalg.solve(A.double() + torch.diag_embed(d.double()), rhs.double())
+    assert ((x.double() - exact).norm(dim=-2) / exact.norm(dim=-2)).max().item() < 1e-4
+
+
+@pytest.mark.parametrize("batch,n", [((3,), 600), ((2, 2), 513)])
+def test_batched_cholesky_solve_of_one_column_above_512_rows(batch, n):
+    """utils/cholesky.py:cholesky_solve: the batched single-column solve against factors of more than 512 rows kills the
+    HIP context on this stack; small batched operators (N <= max_cholesky_size) with ONE right-hand-side column go through
+    it on every `solve` (reference _linear_operator.py:2324-2379 -> cholesky()._cholesky_solve)."""
+    g = torch.Generator(device="cuda").manual_seed(n)
+    X = torch.randn(*batch, n, 24, generator=g, device="cuda")
+    A = X @ X.mT
+    d = torch.full((*batch, n), 0.5, device="cuda")
+    rhs = torch.randn(*batch, n, 1, generator=g, device="cuda")
+    x = AddedDiagLinearOperator(DenseLinearOperator(A), DiagLinearOperator(d)).solve(rhs)
+    exact = torch.linalg.solve(A.double() + torch.diag_embed(d.double()), rhs.double())
+    assert x.shape == rhs.shape
+    assert ((x.double() - exact).norm(dim=-2) / exact.norm(dim=-2)).max().item() < 1e-4
