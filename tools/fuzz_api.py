@@ -32,10 +32,12 @@ while time.time() < t_end:
     bs = rnd.choice([(), (3,), (2, 2)])
     leaves = []
     if kind == "lowrank":
-        N, R = rnd.choice([300, 1000, 2500, 4100]), rnd.choice([8, 20, 32])
+        N, R = rnd.choice([300, 1000, 2500, 4100, 8192, 9000]), rnd.choice([8, 20, 32, 40])
         Cm = (torch.randn(*bs, N, R, generator=g, device=dev) / R ** 0.5).requires_grad_(True)
         d = (torch.rand(*bs, N, generator=g, device=dev) + 0.3).requires_grad_(True)
-        build = lambda: AddedDiagLinearOperator(LowRankRootLinearOperator(Cm), DiagLinearOperator(d))  # noqa: E731
+        plus = rnd.random() < 0.4  # the reference's own `+` routing: LowRankRootAddedDiagLinearOperator (Woodbury closed form)
+        build = (lambda: LowRankRootLinearOperator(Cm) + DiagLinearOperator(d)) if plus else \
+            (lambda: AddedDiagLinearOperator(LowRankRootLinearOperator(Cm), DiagLinearOperator(d)))  # noqa: E731
         dense = lambda: Cm.double() @ Cm.double().mT + torch.diag_embed(d.double())  # noqa: E731
         leaves = [Cm, d]
     elif kind in ("dense", "dense_const"):
@@ -56,21 +58,29 @@ while time.time() < t_end:
         K1 = (spd(g, bs, n1, n1) + 0.2 * torch.eye(n1, device=dev)).requires_grad_(True)
         K2 = (spd(g, bs, n2, n2) + 0.2 * torch.eye(n2, device=dev)).requires_grad_(True)
         d = (torch.rand(*bs, 1, generator=g, device=dev) * 0.2 + 0.1).requires_grad_(True)
-        build = lambda: AddedDiagLinearOperator(  # noqa: E731
-            KroneckerProductLinearOperator(DenseLinearOperator(K1), DenseLinearOperator(K2)), ConstantDiagLinearOperator(d, N))
+        plus = rnd.random() < 0.4  # `+` routing: KroneckerProductAddedDiagLinearOperator (per-factor eigendecompositions)
+        build = (lambda: KroneckerProductLinearOperator(DenseLinearOperator(K1), DenseLinearOperator(K2))  # noqa: E731
+                 + ConstantDiagLinearOperator(d, N)) if plus else (lambda: AddedDiagLinearOperator(  # noqa: E731
+                     KroneckerProductLinearOperator(DenseLinearOperator(K1), DenseLinearOperator(K2)),
+                     ConstantDiagLinearOperator(d, N)))
 
         def dense():
             a, b = K1.double(), K2.double()
             kr = (a[..., :, None, :, None] * b[..., None, :, None, :]).reshape(*bs, N, N)
             return kr + d.double().unsqueeze(-1) * torch.eye(N, device=dev, dtype=torch.float64)
         leaves = [K1, K2, d]
-    c = rnd.choice([0, 1, 3, 11] if bs == () else [1, 3, 11])  # 0: vector right-hand side (unbatched operators only, as in the reference)
+    c = rnd.choice([0, 1, 3, 11, 17, 40] if bs == () else [1, 3, 11, 17, 40])  # 0: vector right-hand side (unbatched operators only, as in the reference)
     rhs = torch.randn(*bs, N, generator=g, device=dev) if c == 0 else torch.randn(*bs, N, c, generator=g, device=dev)
     chol = rnd.choice([0, 800])
     tag = (kind, bs, N, c, chol)
     if os.environ.get("FUZZ_VERBOSE"):
         print(tag, flush=True)
+    psize, nprobe = rnd.choice([0, 5, 15, 15, 40, 150]), rnd.choice([1, 10, 10, 16, 33])
+    tag = tag + (psize, nprobe)
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("   preconditioner size", psize, "probes", nprobe, flush=True)
     with settings.max_cholesky_size(chol), settings.min_preconditioning_size(rnd.choice([100, 2000])), \
+            settings.max_preconditioner_size(psize), settings.num_trace_samples(nprobe), \
             settings.cg_tolerance(1e-3), settings.max_cg_iterations(2000):
         A64 = dense()
         r64 = rhs.double() if c else rhs.double().unsqueeze(-1)
@@ -88,7 +98,7 @@ while time.time() < t_end:
         ld64 = lam.sum(-1)
         # noise of the stochastic estimate with 10 Gaussian probes: std <= sqrt(2 / P) ||log A||_F (less with a
         # preconditioner); the Cholesky branch is exact
-        noise = 5.0 * (0.2 * (lam * lam).sum(-1)).sqrt() if chol < N else torch.zeros_like(ld64)
+        noise = 5.0 * (2.0 / nprobe * (lam * lam).sum(-1)).sqrt() if chol < N else torch.zeros_like(ld64)
         e_ld = ((ld.double() - ld64).abs() / (noise + 0.02 * ld64.abs() + 1e-3) * 0.3).max().item()
         assert iq.shape == tuple(bs) and e_iq < 2e-2, ("inv_quad", tag, e_iq)
         assert ld.shape == tuple(bs) and e_ld < 0.3, ("logdet", tag, e_ld)  # (a stochastic estimate above max_cholesky_size)
