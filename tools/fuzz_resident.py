@@ -1,13 +1,10 @@
-"""Randomised shapes through the operator-resident kernels (pivoted Cholesky ranks 1 .. 32 bit-exact against the oracle,
-root-form / lockstep CG against the exact fp64 Woodbury solution) for a given number of minutes.  Not part of the test
-suite: run on the GPU box after kernel changes (`python tools/fuzz_resident.py --minutes 5 --seed 1`)."""
+"""Low-rank-root + diagonal operators through lo_cg_solve_f32 on random shapes -- the operator-resident engines (serial
+columns, column lockstep, groups of 1 .. 64 workgroups), their continuation passes (tight tolerances) and iteration caps,
+with and without the pivoted-Cholesky preconditioner, with tridiagonals -- against the float64 Woodbury solution; every
+solve is repeated and must return the same bits.  `python tools/fuzz_resident.py --minutes 4 --seed 1` on the GPU box."""
 import argparse, os, random, sys, time
-import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-import cases  # noqa: E402
-from oracle import lo_oracle as orc  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from linear_operator_amd import kernels as K  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -15,42 +12,62 @@ ap.add_argument("--minutes", type=float, default=3.0)
 ap.add_argument("--seed", type=int, default=0)
 args = ap.parse_args()
 rnd = random.Random(args.seed)
+dev = torch.device("cuda")
 t_end = time.time() + 60 * args.minutes
-n_pc = n_cg = 0
+engines = {}
 while time.time() < t_end:
-    B = rnd.choice([1, 2, 3, 9, 40, 130])
-    N = rnd.choice([256, 300, 777, 1024, 1025, 2048, 3000, 4096, 5000, 8192, 9001, 16384, 20000, 32768])
-    R = rnd.choice([1, 2, 5, 8, 11, 16, 24, 32])
-    rank = rnd.randint(1, 32)
-    if B * N * R > 6e7:
-        continue
-    C = cases.lowrank_diag(rnd.randrange(1 << 30), B, N, R, 1)[0]
-    Cd = torch.from_numpy(C).cuda()
-    L, piv = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cd, None), rank)
-    Lo, pivo = orc.pivoted_cholesky(orc.LowRankRowSource(C), rank)
-    # (equal_nan: a rank-deficient member whose remaining diagonal went negative gets a NaN column from sqrt(max) in
-    #  the reference, the oracle and the kernel alike -- seen at B=130 N=32768 R=11 rank=32)
-    assert np.array_equal(piv.cpu().numpy(), pivo) and np.array_equal(L.cpu().numpy(), Lo, equal_nan=True), \
-        ("pc", B, N, R, rank)
-    n_pc += 1
-    c = rnd.choice([1, 1, 2, 5, 16, 17, 33])
-    k = rnd.choice([0, 1, 7, 15, 16])
-    ntri = rnd.choice([0, min(c, 16)])
-    g = torch.Generator(device="cuda"); g.manual_seed(rnd.randrange(1 << 30))
-    d = torch.rand(B, N, generator=g, device="cuda") + 0.5
-    rhs = torch.randn(B, N, c, generator=g, device="cuda")
+    g = torch.Generator(device=dev); g.manual_seed(rnd.randrange(1 << 30))
+    N = rnd.choice([500, 1024, 1500, 2048, 3000, 4096, 8192, 12000, 16384, 33000, 65536])
+    R = rnd.choice([8, 16, 32, 32, 20])
+    B = rnd.choice([1, 3, 31, 64, 200]) if N <= 16384 else rnd.choice([1, 3, 9])
+    c = rnd.choice([1, 1, 2, 4, 5, 16, 17])
+    k = min(rnd.choice([0, 7, 15, 15, 24, 32]), R)  # (beyond the rank of C C^T the factor is rounding noise and NaN: the host API drops it, added_diag...py:126-131)
+    nt = rnd.choice([0, min(c, 16)])
+    tol = rnd.choice([1e-2, 1e-4, 1e-6])
+    max_iter = rnd.choice([1000, 1000, 15])
+    Cm = torch.randn(B, N, R, generator=g, device=dev) / R ** 0.5
+    d = torch.rand(B, N, generator=g, device=dev) * rnd.choice([1.0, 0.1]) + rnd.choice([0.5, 0.05])
+    rhs = torch.randn(B, N, c, generator=g, device=dev)
+    desc = K.lowrank_diag_descriptor(Cm, d)
     pre = None
     if k:
-        Lr, perm = K.pivoted_cholesky(K.lowrank_diag_descriptor(Cd, None), k, contiguous=False)
-        pre = K.precond_build(Lr, d, False, root=Cd, perm=perm) if rnd.random() < 0.6 else K.precond_build(Lr, d, False)
-    res = K.cg_solve(K.lowrank_diag_descriptor(Cd, d), rhs, precond=pre, n_tridiag=ntri, tolerance=1e-5, max_iter=400)
-    C64, d64, r64 = Cd.double(), d.double(), rhs.double()
-    Cs = C64 / d64.unsqueeze(-1)
-    cap = torch.eye(R, device="cuda", dtype=torch.float64) + C64.mT @ Cs
-    exact = r64 / d64.unsqueeze(-1) - Cs @ torch.linalg.solve(cap, Cs.mT @ r64)
+        L, perm = K.pivoted_cholesky(desc, k, contiguous=False)
+        pre = K.precond_build(L, d, False, root=Cm if R <= 32 else None, perm=perm)
+    tag = (B, N, R, c, k, nt, tol, max_iter)
+    if os.environ.get("FUZZ_VERBOSE"):
+        print(tag, flush=True)
+    res = K.cg_solve(desc, rhs, precond=pre, n_tridiag=nt, tolerance=tol, max_iter=max_iter)
+    plan = K.cg_last_executed()
+    again = K.cg_solve(desc, rhs, precond=pre, n_tridiag=nt, tolerance=tol, max_iter=max_iter)
+    if not (torch.equal(res.x, again.x) and res.iterations == again.iterations):
+        print("NOT REPRODUCIBLE", tag, plan, flush=True)
+        print("  second run's plan", K.cg_last_executed(), flush=True)
+        runs = [res, again] + [K.cg_solve(desc, rhs, precond=pre, n_tridiag=nt, tolerance=tol, max_iter=max_iter) for _ in range(4)]
+        for i, r in enumerate(runs):
+            dx = (r.x - runs[-1].x).abs().max().item()
+            print(f"  run {i}: iterations {r.iterations} reached {r.tolerance_reached} mean residual {r.mean_residual:.3e} "
+                  f"max |x - x_last| {dx:.3e}", flush=True)
+        for env in ("LO_OC_NO_WREC", "LO_OC_KEEP_STATE", "LO_OC_NO_LEAN_MEMO", "LO_OC_NO_INKERNEL_CLOSE", "LO_OC_NO_PREFETCH"):
+            os.environ[env] = "1"
+            a = K.cg_solve(desc, rhs, precond=pre, n_tridiag=nt, tolerance=tol, max_iter=max_iter)
+            b = K.cg_solve(desc, rhs, precond=pre, n_tridiag=nt, tolerance=tol, max_iter=max_iter)
+            print(f"  {env}=1: equal {torch.equal(a.x, b.x)} iterations {a.iterations}/{b.iterations}", flush=True)
+            del os.environ[env]
+        raise SystemExit(1)
+    if nt:
+        assert torch.equal(res.t_mat, again.t_mat) and torch.isfinite(res.t_mat).all(), ("t_mat", tag, plan)
+    # float64 Woodbury: x = D^-1 b - D^-1 C (I + C^T D^-1 C)^-1 C^T D^-1 b
+    C64, d64, b64 = Cm.double(), d.double().unsqueeze(-1), rhs.double()
+    cap = torch.eye(R, device=dev, dtype=torch.float64) + C64.mT @ (C64 / d64)
+    exact = b64 / d64 - (C64 / d64) @ torch.linalg.solve(cap, C64.mT @ (b64 / d64))
     err = ((res.x.double() - exact).norm(dim=-2) / exact.norm(dim=-2)).max().item()
-    # (unpreconditioned / rank-1 preconditioned solves stop on the residual: the error bound carries the condition number)
-    assert err < (1e-4 if k >= 7 else 5e-3) and not res.nan_detected, ("cg", B, N, R, c, k, ntri, res.iterations, err)
-    assert ntri == 0 or bool(torch.isfinite(res.t_mat).all()), ("tri", B, N, R, c, k)
-    n_cg += 1
-print(f"fuzz ok: {n_pc} factorisations, {n_cg} solves, seed {args.seed}")
+    # the stopping rule is on the mean residual of the normalised system: a solve that reports the tolerance as reached
+    # is within a condition-number multiple of it; one that hit the iteration cap only has to be finite and sane
+    cond = ((Cm.double() ** 2).sum(-1).max() + d.max().double()) / d.min().double()
+    # (fp32: the recurrence residual drifts from the true one by about eps per iteration -- long unpreconditioned runs
+    # stop on the former)
+    bound = max(20 * tol * cond.item() ** 0.5, 3e-7 * res.iterations * cond.item() ** 0.5, 5e-5) if res.tolerance_reached else 1.0
+    assert torch.isfinite(res.x).all() and err < bound, ("error", tag, err, bound, res.iterations, plan)
+    key = (plan["resident"], plan.get("serial_engine"), plan.get("lockstep_cols", 0) > 0, plan.get("streaming_precond"))
+    engines[key] = engines.get(key, 0) + 1
+print("fuzz ok:", sum(engines.values()), "cases; engines", engines, "seed", args.seed)
