@@ -159,6 +159,7 @@ __global__ __launch_bounds__(kThreads) void k_skinny_nn_mfma(const float* __rest
   if (stop && *stop) return;
   extern __shared__ float t_s[];  // [R4][32]  (columns >= c zero)
   __shared__ float dot_s[4][32];
+  __shared__ __attribute__((aligned(16))) float io_s[4][32 * 32 + 32];  // per wave: the v / y tile and its 32 diagonal values
   const int s = blockIdx.x, b = blockIdx.y, S = gridDim.x;
   for (int idx = threadIdx.x; idx < R4 * 32; idx += kThreads) {
     const int k = idx >> 5, j = idx & 31;
@@ -194,12 +195,35 @@ __global__ __launch_bounds__(kThreads) void k_skinny_nn_mfma(const float* __rest
 #pragma unroll
     for (int q = 0; q < KQ; ++q) a4[q] = av ? *reinterpret_cast<const float4*>(ap + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     float vin[16], dvv[16];
+    // a full tile of a packed block (ldv == c, c a multiple of 4): its 32 rows x c columns are 128 c contiguous bytes --
+    // in (and, below, out) through the wave's LDS tile with 16-byte accesses; the direct path touches two 4 c-byte pieces
+    // per instruction with the lanes li >= c idle (16 such loads + 16 stores per tile)
+    const bool staged = ((c & 3) == 0) && ldv == c && base + 32 <= r1;
+    float* tile = io_s[wave];
+    if (staged) {
+      const float4* src = reinterpret_cast<const float4*>(v + vbase + (size_t)base * c);
+      const int n4 = 8 * c;  // float4 of the tile
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = base + d_row(e, lane);
-      const bool ok = (li < c) && (row < r1);
-      vin[e] = ok ? v[vbase + (size_t)row * ldv + li] : 0.f;
-      dvv[e] = (dd_mode == LO_DIAG_FULL) ? (ok ? ddb[row] : 0.f) : ddc;
+      for (int q = 0; q < 4; ++q) {
+        const int f = lane + 64 * q;
+        if (f < n4) *reinterpret_cast<float4*>(tile + 4 * f) = src[f];
+      }
+      if (dd_mode == LO_DIAG_FULL && lane < 32) tile[32 * 32 + lane] = ddb[base + lane];
+      __builtin_amdgcn_wave_barrier();  // (LDS operations of a wave execute in order; this pins the compiler's order)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int lr = d_row(e, lane);
+        vin[e] = (li < c) ? tile[lr * c + li] : 0.f;
+        dvv[e] = (dd_mode == LO_DIAG_FULL) ? ((li < c) ? tile[32 * 32 + lr] : 0.f) : ddc;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = base + d_row(e, lane);
+        const bool ok = (li < c) && (row < r1);
+        vin[e] = ok ? v[vbase + (size_t)row * ldv + li] : 0.f;
+        dvv[e] = (dd_mode == LO_DIAG_FULL) ? (ok ? ddb[row] : 0.f) : ddc;
+      }
     }
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
@@ -209,7 +233,26 @@ __global__ __launch_bounds__(kThreads) void k_skinny_nn_mfma(const float* __rest
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].z, tb[64], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].w, tb[96], acc, 0, 0, 0);
     }
-    if (li < c) {
+    if (staged) {
+      __builtin_amdgcn_wave_barrier();  // every lane holds its vin / dvv: the tile now takes the output
+      if (li < c) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float yv = fmaf(dvv[e], vin[e], sgn * acc[e]);
+          tile[d_row(e, lane) * c + li] = yv;
+          if (DOT) dacc = fmaf(vin[e], yv, dacc);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      float4* dst = reinterpret_cast<float4*>(y + vbase + (size_t)base * c);
+      const int n4 = 8 * c;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = lane + 64 * q;
+        if (f < n4) dst[f] = *reinterpret_cast<const float4*>(tile + 4 * f);
+      }
+      __builtin_amdgcn_wave_barrier();  // the next tile reuses it
+    } else if (li < c) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = base + d_row(e, lane);
