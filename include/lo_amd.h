@@ -110,6 +110,13 @@ typedef struct lo_precond_desc {
   const float* kron_a;   /* [B, n1, 16]: kron_a[i1][m] = K1[pi_m / n2, i1], columns >= k zero       */
   const float* kron_b;   /* [B, n2, 16]: kron_b[i2][m] = K2[pi_m % n2, i2]                          */
   const float* kron_F;   /* [B, 16, 16], symmetric, zero padded                                     */
+  /* Optional R-SPACE FORM next to the root form (lo_precond_root_form_rs_f32; round 5, ABI 11): the fp64 matrices
+   * E = C^T D^-1 C | F E | E F E | G2 = C^T C | F | E F, [B, 6, rf_ld, rf_ld], zero padded.  With A P^-1 = I + C (I - F - E F) C^T D^-1
+   * every vector of linear_cg (linear_cg.py:245-332) is a combination of the right-hand side and the columns of C, so
+   * the iterations of a single-column, result-only solve run on R + 1 coordinates (csrc/lo_rspace.hip): the rows of C
+   * are touched twice per solve and a member costs one group all-reduce.  The Gram matrices have to be fp64-accurate
+   * (tests/proto/proto_rspace.py); D^-1 is `dinv` as stored (FULL) / 1.0 / (double)sigma (CONST).  NULL = not available. */
+  const double* RS;
 } lo_precond_desc;
 
 /* Batch-sharded solves (one process per GPU, SURVEY.md section 8(e) "option A"): the reference's stopping rule is the
@@ -333,6 +340,15 @@ int lo_precond_root_form_f32(const float* C, int32_t R, const float* d, int32_t 
                              int64_t ld_member, int64_t ld_row, int64_t ld_col, const int64_t* perm, int64_t B,
                              int64_t N, int32_t k, int32_t rf_ld, float* F, float* EF, float* E, float* dinv,
                              float* logdet_p, void* ws, size_t ws_bytes, void* stream);
+/* The same with the R-SPACE FORM (lo_precond_desc.RS) as a fifth output: RS fp64 [B, 6, rf_ld, rf_ld] = E | F E | E F E | C^T C | F | E F.
+ * E and C^T C are accumulated on the fp64 matrix cores from exact fp32 x fp32 products (the fp32 F / EF / E written next
+ * to them are the roundings of the same fp64 matrices).  Needs R % 4 == 0 and a 16-byte aligned C: LO_ERR_UNSUPPORTED
+ * otherwise (the caller uses lo_precond_root_form_f32).  Workspace: lo_precond_root_form_rs_workspace_bytes.          */
+size_t lo_precond_root_form_rs_workspace_bytes(int64_t B, int64_t N, int32_t R);
+int lo_precond_root_form_rs_f32(const float* C, int32_t R, const float* d, int32_t diag_mode, const float* L,
+                                int64_t ld_member, int64_t ld_row, int64_t ld_col, const int64_t* perm, int64_t B,
+                                int64_t N, int32_t k, int32_t rf_ld, float* F, float* EF, float* E, float* dinv,
+                                float* logdet_p, double* RS, void* ws, size_t ws_bytes, void* stream);
 /* Kronecker root form of the pivoted-Cholesky preconditioner (see lo_precond_desc.kron_*): op = LO_OP_KRON_DIAG with
  * LO_DIAG_CONST, L / perm as lo_precond_root_form_f32 (k <= 16 pivots).  Gathers the pivot rows of the two factors
  * (kron_a [B, n1, 16], kron_b [B, n2, 16]), forms E = KP^T KP / sigma as the Hadamard product of the two small Gram

@@ -673,7 +673,7 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   dd.B = B; dd.N = N; dd.c = (int)c; dd.S = sp.S;
   dd.ctrl = ar.take<CgCtrl>(1);
   // (granule buffer of the serial resident kernels right behind the control block: ONE memset clears both)
-  dd.oc_gbuf = ar.take<unsigned long long>(onchip_gbuf_bytes(66) / sizeof(unsigned long long));
+  dd.oc_gbuf = ar.take<unsigned long long>(std::max(onchip_gbuf_bytes(66), rspace_gbuf_bytes(66 * 8)) / sizeof(unsigned long long));
   dd.oc_close = ar.take<unsigned long long>((size_t)B + 2);
   dd.x = ar.take<float>(nv);
   dd.r = ar.take<float>(nv);
@@ -915,7 +915,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.rhs = rhs; a.B = B; a.N = (int)N;
     a.c = c; a.ab_rec = prm->n_tridiag ? d.oc_ab : nullptr;
     a.col0 = 0; a.ncols = c; a.RK = pre ? preR4 : 0; a.RCg = pl.R4;
-    a.F = nullptr; a.EF = nullptr; a.E = nullptr;
+    a.F = nullptr; a.EF = nullptr; a.E = nullptr; a.RS = nullptr;
     a.close_gran = nullptr; a.close_count = nullptr; a.close_ctrl = nullptr; a.close_mirror = nullptr;
     a.close_ticket = 0; a.close_tol = 0.f; a.close_floor_ok = 0;
     bool close_in_kernel = false;
@@ -977,6 +977,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       a.F = oc_nopre ? nullptr : pre->F;
       a.EF = oc_nopre ? nullptr : pre->EF;
       a.E = oc_nopre ? nullptr : pre->E;
+      a.RS = oc_nopre ? nullptr : pre->RS;
       a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
       a.dbg = oc_dbg ? d.oc_dbg : nullptr;
       // one column, no tridiagonals, no lockstep launch in front: the kernel closes the solve itself (stop rule, NaN /

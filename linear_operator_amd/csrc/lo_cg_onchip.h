@@ -22,6 +22,7 @@ struct OnchipArgs {
   const float* F;     // root-form preconditioner (lo_precond_desc.F / EF), [B, RC, RC] each, or nullptr
   const float* EF;
   const float* E;     // C^T D^-1 C [B, RC, RC] (lo_precond_desc.E) or nullptr: enables the w-recurrence mode of k_cg_onchip5
+  const double* RS;   // fp64 [B, 6, RC, RC]: E | F E | E F E | G2 = C^T C | F | E F (lo_precond_desc.RS) or nullptr: enables k_cg_rspace
   float* ab_rec;      // [iters, B, c, 2] masked alpha / beta per iteration (second generation, n_tridiag > 0) or nullptr
   int64_t B;
   int N, RW;          // rows per workgroup
@@ -60,6 +61,10 @@ int onchip4_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st)
 // root-form serial-column kernel (k_cg_onchip5, lo_cg_onchip4.hip): one all-reduce per iteration
 int onchip5_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st);
 bool onchip5_eligible(int RC, int64_t N, int64_t c);
+// the whole iteration on R + 1 coordinates (k_cg_rspace, lo_rspace.hip): one column, result only, one all-reduce per member
+int rspace_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st);
+bool rspace_eligible(int RC, int64_t N, int64_t c);
+size_t rspace_gbuf_bytes(int nworkgroups);
 // third generation (lo_cg_lockstep.hip): 16 columns of a member advance together on the matrix cores
 int lockstep_launch(int RC, bool pre, const OnchipArgs& a, int nwg, hipStream_t st);
 bool lockstep_eligible(int RC, int RK, bool pre, int64_t N, int64_t ncols);

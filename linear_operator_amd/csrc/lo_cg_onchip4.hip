@@ -27,6 +27,7 @@
 #include "lo_internal.h"
 #include "lo_cg_onchip.h"
 #include "lo_group_reduce.h"
+#include "lo_cg_close.h"
 
 namespace lo {
 
@@ -820,64 +821,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_onchip5(OnchipA
     b = b_next;
   }
   // ---- closing step: the first workgroup of the group that finishes LAST does what k_cg_ctrl_onchip does ----
-  if (!MC && a.close_gran && wig == 0) {
-    __shared__ int closer_s;
-    __shared__ float red_s[R4_TPB];
-    if (t == 0) closer_s = (atomicAdd(a.close_count, 1) == ngroups - 1) ? 1 : 0;
-    __syncthreads();
-    if (closer_s) {
-      // (the other groups' granules were stored before their counter increments, but nothing orders the two for us:
-      //  every granule is polled until its tag is there -- no fence anywhere)
-      float lsum = 0.f, lnan = 0.f, lnotconv = 0.f;
-      unsigned spin = 0;
-      bool lost = false;
-      for (int64_t i = t; i < a.B && !lost; i += R4_TPB) {
-        unsigned long long gr;
-        for (;;) {
-          gr = __hip_atomic_load(a.close_gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((unsigned)(gr >> 32) & 0x80000000u) break;
-          if (++spin > R4_MAXSPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            lost = true;  // a group gave up (hand-off timeout): its members never arrive -- the host redoes the solve
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (lost) break;
-        const float rn = __uint_as_float((unsigned)(gr & 0xffffffffull));
-        const unsigned fl = (unsigned)(gr >> 32);
-        lsum += rn;
-        if (rn != rn || (fl & 2u)) lnan = 1.f;
-        if (!(fl & 1u)) lnotconv = 1.f;
-      }
-      if (lost) atomicExch(a.err, 1);
-      const float mean = block_sum256(lsum, red_s) / (float)a.B;   // (the summation order of k_cg_ctrl_onchip)
-      const float anynan = block_sum256(lnan, red_s);
-      const float notconv = block_sum256(lnotconv, red_s);
-      if (t == 0) {
-        CgCtrl* c = a.close_ctrl;
-        c->iterations = a.iters;
-        c->mean_resid = mean;
-        if (anynan > 0.f) {
-          c->nan_detected = 1;
-          c->stop = 1;
-        } else if (notconv == 0.f) {                 // every column converged before the first iteration (:207-208)
-          c->skipped = 1;
-          c->iterations = 0;
-          c->stop = 1;
-        } else if (a.close_floor_ok && mean < a.close_tol) {
-          c->tol_reached = 1;
-          c->stop = 1;
-        }
-        c->oc_err = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a.close_mirror) {
-          *a.close_mirror = *c;
-          __threadfence_system();
-          __hip_atomic_store(reinterpret_cast<unsigned*>(a.close_mirror) + 63, a.close_ticket, __ATOMIC_RELEASE,
-                             __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-      }
-    }
-  }
+  if (!MC && a.close_gran && wig == 0) cg_close_solve(a, ngroups, t);
 }
 
 bool onchip5_eligible(int RC, int64_t N, int64_t c) {
@@ -908,6 +852,12 @@ int onchip5_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st) {
   // such solves miss the stop rule at the floor (evaluated on sum r^2 of the ACTUAL rows), and their repeat with the
   // continuation state runs the three-pass iteration.
   const bool wr = !mc && a.F && a.EF && a.E && !a.x && !getenv("LO_OC_NO_WREC");
+  // the same result-only pass with the fp64 Gram matrices of the operator at hand: the iterations run on R + 1
+  // coordinates (lo_rspace.hip), one all-reduce per member (LO_OC_NO_RSPACE restores the w-recurrence kernel)
+  if (wr && a.RS && a.xout && rspace_eligible(RC, a.N, a.c) && !getenv("LO_OC_NO_RSPACE")) {
+    const int rc = rspace_launch(RC, a, nwg, st);
+    if (rc != LO_ERR_UNSUPPORTED) return rc;
+  }
 #define LO_O5_G(C_, G_)                                \
   (mc ? onchip5_go<C_, G_, 1>(a, nwg, st)              \
       : (wr ? onchip5_go<C_, G_, 2>(a, nwg, st) : onchip5_go<C_, G_, 0>(a, nwg, st)))

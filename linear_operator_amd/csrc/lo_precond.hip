@@ -631,7 +631,9 @@ __global__ __launch_bounds__(kThreads) void k_pb_rootform(const double* __restri
                                                      float* __restrict__ Eo, float* __restrict__ logdet,
                                                      float* __restrict__ dinv_const,
                                                      const float* __restrict__ Cpiv = nullptr,
-                                                     float* __restrict__ kappa = nullptr) {
+                                                     float* __restrict__ kappa = nullptr,
+                                                     const double* __restrict__ gpart2 = nullptr,
+                                                     double* __restrict__ RS = nullptr) {
   __shared__ double E[kPbMaxK][kPbMaxK + 1];
   __shared__ double M[kPbMaxK][kPbMaxK + 1];   // [R][k]
   __shared__ double T[kPbMaxK][kPbMaxK + 1];   // scratch: E M, then Y = M Lg^-T
@@ -727,6 +729,37 @@ __global__ __launch_bounds__(kThreads) void k_pb_rootform(const double* __restri
     Fb[pr] = (float)f;
     EFb[pr] = (float)ef;
     Eb[pr] = (float)e;
+  }
+  if (RS) {  // R-space form (lo_precond_desc.RS): E | F E | E F E | G2 = C^T C | F | E F in fp64, [6][ld][ld], zero padded
+    // (gpart2: partials of C^T C; a constant diagonal has one set of partials -- E = C^T C / sigma was formed above)
+    __syncthreads();
+    for (int pr = lane; pr < R * R; pr += NT) {  // T <- E F (Y is no longer needed)
+      const int a = pr / R, c2 = pr % R;
+      double ef = 0.0;
+      for (int q = 0; q < R; ++q) ef += E[a][q] * Fm[q][c2];
+      T[a][c2] = ef;
+    }
+    __syncthreads();
+    double* Rb = RS + (size_t)b * 6 * ld * ld;
+    for (int pr = lane; pr < ld * ld; pr += NT) {
+      const int a = pr / ld, c2 = pr % ld;
+      double f = 0.0, ef = 0.0, fe = 0.0, efe = 0.0, e = 0.0, g2 = 0.0;
+      if (a < R && c2 < R) {
+        f = Fm[a][c2];
+        e = E[a][c2];
+        ef = T[a][c2];
+        fe = T[c2][a];  // F E = (E F)^T
+        for (int q = 0; q < R; ++q) efe += T[a][q] * E[q][c2];
+        for (int s = 0; s < S; ++s) g2 += gpart2[((size_t)b * S + s) * R * R + a * R + c2];
+      }
+      Rb[pr] = e;
+      Rb[ld * ld + pr] = fe;
+      Rb[2 * ld * ld + pr] = efe;
+      Rb[3 * ld * ld + pr] = g2;
+      Rb[4 * ld * ld + pr] = f;
+      Rb[5 * ld * ld + pr] = ef;
+    }
+    __syncthreads();
   }
   if (kappa) {  // sqrt(sum_m (F E F)_mm E_mm): amplification of the fp32 rounding of C^T (r/d) in P^-1 r (lo_amd.h)
     if (lane < R) {
@@ -1172,6 +1205,53 @@ int lo_precond_root_form_f32(const float* C, int32_t R, const float* d, int32_t 
   LO_PROF_BEGIN("pb_rootform", st);
   hipLaunchKernelGGL(k_pb_rootform, dim3((unsigned)B), dim3(kThreads), 0, st, gpart, logd, C, (int)R, d, diag_mode, L, ls,
                      (const long long*)perm, (int)N, (int)k, sp.S, (int)rf_ld, F, EF, E, logdet_p, dinv);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+size_t lo_precond_root_form_rs_workspace_bytes(int64_t B, int64_t N, int32_t R) {
+  Split sp = choose_split(B, N, 256);
+  Arena ar(nullptr, 0);
+  ar.take<double>((size_t)B * sp.S * R * R);
+  ar.take<double>((size_t)B * sp.S * R * R);
+  ar.take<double>((size_t)B * sp.S);
+  ar.take<float>((size_t)B * N);
+  return ar.off + 1024;
+}
+
+int lo_precond_root_form_rs_f32(const float* C, int32_t R, const float* d, int32_t diag_mode, const float* L,
+                                int64_t ld_member, int64_t ld_row, int64_t ld_col, const int64_t* perm, int64_t B,
+                                int64_t N, int32_t k, int32_t rf_ld, float* F, float* EF, float* E, float* dinv,
+                                float* logdet_p, double* RS, void* ws, size_t ws_bytes, void* stream) {
+  if (!C || !d || !L || !perm || !F || !EF || !E || !dinv || !logdet_p || !RS || !ws) return LO_ERR_BADARG;
+  if (diag_mode != LO_DIAG_FULL && diag_mode != LO_DIAG_CONST) return LO_ERR_BADARG;
+  if (R < 1 || R > kPbMaxK || k < 1 || k > kPbMaxK || rf_ld < R || rf_ld > kPbMaxK) return LO_ERR_UNSUPPORTED;
+  if ((R % 4) != 0 || ((uintptr_t)C % 16) != 0) return LO_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  Split sp = choose_split(B, N, 256);
+  Arena ar(ws, ws_bytes);
+  double* gpartE = ar.take<double>((size_t)B * sp.S * R * R);
+  double* gpart2 = ar.take<double>((size_t)B * sp.S * R * R);
+  double* logd = ar.take<double>((size_t)B * sp.S);
+  float* scale = ar.take<float>((size_t)B * N);
+  if (!ar.ok) return LO_ERR_WORKSPACE;
+  dim3 grid(sp.S, (unsigned)B), block(kThreads);
+  if (diag_mode == LO_DIAG_FULL) {  // dinv = fp32(1 / d): THE D^-1 of the R-space iteration (and log d partials)
+    LO_PROF_BEGIN("pb_scale", st);
+    hipLaunchKernelGGL(k_pb_scale, grid, block, 0, st, d, (int)N, sp.rows, scale, dinv, logd);
+    LO_PROF_END(st);
+  }
+  LO_PROF_BEGIN("rs_gram64", st);  // E = C^T diag(dinv) C and C^T C on the fp64 matrix cores (exact products)
+  rs_gram64_launch(C, diag_mode == LO_DIAG_FULL ? dinv : nullptr, B, N, (int)R, sp, gpartE, gpart2, st);
+  LO_PROF_END(st);
+  const LStride ls{ld_member, ld_row, ld_col};
+  LO_PROF_BEGIN("pb_rootform", st);
+  // FULL: the partials of E already carry dinv (k_pb_rootform divides by sigma = 1); CONST: E = C^T C / sigma
+  hipLaunchKernelGGL(k_pb_rootform, dim3((unsigned)B), dim3(kThreads), 0, st,
+                     diag_mode == LO_DIAG_FULL ? gpartE : gpart2, logd, C, (int)R, d, diag_mode, L, ls,
+                     (const long long*)perm, (int)N, (int)k, sp.S, (int)rf_ld, F, EF, E, logdet_p, dinv,
+                     (const float*)nullptr, (float*)nullptr, (const double*)gpart2, RS);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;

@@ -1,0 +1,733 @@
+// lo_rspace.hip -- the preconditioned CG of a low-rank + diagonal member in the coordinates of its own Krylov space.
+//
+// For A = C C^T + D (C [N, R], R <= 32) and the pivoted-Cholesky preconditioner in root form (lo_amd.h: lo_precond_desc.F),
+//     P^-1 = D^-1 - D^-1 C F C^T D^-1,        A P^-1 = I + C G C^T D^-1,   G = I - F - E F,   E = C^T D^-1 C,
+// every vector linear_cg (linear_operator/utils/linear_cg.py:245-332) ever forms is a combination of the right-hand side
+// r0 and the R columns of C:
+//     r_k = rho r0 + C g,        p_k = D^-1 (pi r0 + C h),        x_k = D^-1 (xi r0 + C y)          (g, h, y in R^R)
+// and every inner product of the iteration follows from ONE reduction over the rows per solve
+//     w0 = C^T D^-1 r0,   u0 = C^T r0,   s = r0^T D^-1 r0,   a0 = r0^T r0
+// and two Gram matrices of the OPERATOR, E and G2 = C^T C (built once with the preconditioner: lo_precond_desc.RS):
+//     w  = C^T D^-1 r = rho w0 + E g          r^T D^-1 r = rho (rho s + g.w0) + g.w        r^T r = rho (rho a0 + 2 g.u0) + g.G2 g
+//     z  = P^-1 r = D^-1 (rho r0 + C (g - F w))                     r.z = r^T D^-1 r - w.F w        (:215, :35-36)
+//     t  = C^T p = pi w0 + E h,   A p = pi r0 + C (h + t)            p.A p = |t|^2 + (pi^2 s + 2 pi h.w0 + h.E h)   (:247-257)
+// The iterations of the reference's floor run on R + 1 coordinates in fp64 inside ONE wave per workgroup (the same
+// recurrences as k_cg_onchip5, lo_cg_onchip4.hip: beta, the p-recurrences, alpha -- identical in exact arithmetic);
+// the rows of C are touched twice per solve: for the reduction above and for x = D^-1 (xi r0 + C y).  A member costs one
+// group all-reduce instead of twelve.  Numerics first: tests/proto/proto_rspace.py (solutions 1e-7 from the fp64 iteration
+// where the fp32 iteration of the reference is at 3e-6; needs the Gram matrices in fp64 -- with fp32-level noise in E the
+// iteration stalls when r0 lies almost inside span(C)).  The mode serves the result-only first pass of a single-column
+// solve (as the w-recurrence mode did): a solve whose residual misses the stop rule at the floor is repeated by the
+// three-pass kernel with the continuation state.
+#include <algorithm>
+#include <stdlib.h>
+
+#include "lo_device.h"
+#include "lo_internal.h"
+#include "lo_cg_onchip.h"
+#include "lo_group_reduce.h"
+#include "lo_cg_close.h"
+
+namespace lo {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp64 Gram matrices of a root on the fp64 matrix cores: E = C^T diag(dinv) C and G2 = C^T C, partials per row slice.
+// Products of two fp32 values are exact in fp64, so the only rounding is the fp64 accumulation (and c * dinv, 2^-53).
+// Layout of v_mfma_f64_16x16x4_f64 (tools/probe/mfma_f64_layout.hip): lane (a = l % 16, kk = l / 16) supplies
+// A[a][kk] and B[kk][a], acc[r] = D[4 r + kk][a].
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NA>
+__global__ __launch_bounds__(kThreads) void k_rs_gram64(const float* __restrict__ C, const float* __restrict__ dinv,
+                                                         int N, int R, int rows_per, double* __restrict__ gpartE,
+                                                         double* __restrict__ gpart2) {
+  constexpr int NB = (NA == 2) ? 3 : 1;
+  constexpr int TR = 128;  // rows per tile: 32 per wave
+  constexpr int LD = 33;   // tile row stride (conflict-free column reads)
+  __shared__ float tile[2][TR * LD];
+  __shared__ float dtile[2][TR];
+  __shared__ double red[4][64][4 * NB];
+  const int s = blockIdx.x, S = gridDim.x;
+  const int64_t b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int a = l & 15, kk = l >> 4;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  const float* Cb = C + (size_t)b * N * R;
+  const float* db = dinv ? dinv + (size_t)b * N : nullptr;
+  const int RQ = R >> 2;
+  constexpr int PPT = TR * 8 / kThreads;
+  float4 pv[PPT];
+  float pd = 0.f;
+  auto issue = [&](int base) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int e = i * kThreads + threadIdx.x;
+      const int row = e / RQ, q = e % RQ;
+      pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < TR * RQ && base + row < r1) pv[i] = *reinterpret_cast<const float4*>(Cb + (size_t)(base + row) * R + 4 * q);
+    }
+    pd = 0.f;
+    if (db && threadIdx.x < TR && base + (int)threadIdx.x < r1) pd = db[base + threadIdx.x];
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int e = i * kThreads + threadIdx.x;
+      if (e < TR * RQ) {
+        const int row = e / RQ, q = e % RQ;
+        float* t = &tile[buf][row * LD + 4 * q];
+        t[0] = pv[i].x; t[1] = pv[i].y; t[2] = pv[i].z; t[3] = pv[i].w;
+      }
+    }
+    if (threadIdx.x < TR) dtile[buf][threadIdx.x] = pd;
+  };
+  f64x4 e00 = {0.0, 0.0, 0.0, 0.0}, e01 = e00, e11 = e00, g00 = e00, g01 = e00, g11 = e00;
+  int buf = 0;
+  issue(r0);
+  commit(0);
+  __syncthreads();
+  for (int base = r0; base < r1; base += TR) {
+    const bool more = base + TR < r1;
+    if (more) issue(base + TR);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = 32 * wave + 4 * e + kk;
+      const double w0 = (a < R) ? (double)tile[buf][row * LD + a] : 0.0;
+      g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, w0, g00, 0, 0, 0);
+      double w1 = 0.0;
+      if (NA == 2) {
+        w1 = (a + 16 < R) ? (double)tile[buf][row * LD + a + 16] : 0.0;
+        g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, w1, g01, 0, 0, 0);
+        g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, w1, g11, 0, 0, 0);
+      }
+      if (db) {
+        const double dv = (double)dtile[buf][row];
+        const double v0 = w0 * dv;
+        e00 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, w0, e00, 0, 0, 0);
+        if (NA == 2) {
+          const double v1 = w1 * dv;
+          e01 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, w1, e01, 0, 0, 0);
+          e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, w1, e11, 0, 0, 0);
+        }
+      }
+    }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  for (int which = 0; which < (db ? 2 : 1); ++which) {
+    const f64x4& q00 = which ? e00 : g00;
+    const f64x4& q01 = which ? e01 : g01;
+    const f64x4& q11 = which ? e11 : g11;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[wave][l][r] = q00[r];
+      if (NA == 2) {
+        red[wave][l][4 + r] = q01[r];
+        red[wave][l][8 + r] = q11[r];
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      double* gp = (which ? gpartE : gpart2) + ((size_t)b * S + s) * R * R;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = 4 * r + kk, gj = a;  // D[4 r + l / 16][l % 16]
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+          const double v = (red[0][l][4 * blk + r] + red[1][l][4 * blk + r]) + (red[2][l][4 * blk + r] + red[3][l][4 * blk + r]);
+          const int i = gi + (blk == 2 ? 16 : 0), j = gj + (blk >= 1 ? 16 : 0);
+          if (i < R && j < R) {
+            gp[i * R + j] = v;
+            if (blk == 1) gp[j * R + i] = v;  // the (1, 0) block is the transpose of (0, 1)
+          }
+        }
+      }
+    }
+  }
+}
+
+void rs_gram64_launch(const float* C, const float* dinv_full, int64_t B, int64_t N, int R, Split sp, double* gpartE,
+                      double* gpart2, hipStream_t st) {
+  dim3 grid(sp.S, (unsigned)B), block(kThreads);
+  if (R <= 16) hipLaunchKernelGGL((k_rs_gram64<1>), grid, block, 0, st, C, dinv_full, (int)N, R, sp.rows, gpartE, gpart2);
+  else hipLaunchKernelGGL((k_rs_gram64<2>), grid, block, 0, st, C, dinv_full, (int)N, R, sp.rows, gpartE, gpart2);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp64 cross-lane helpers (two 32-bit moves per value on the same hardware paths as lo_device.h)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double mk_d(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
+__device__ __forceinline__ unsigned lo_w(double x) { return (unsigned)__double2loint(x); }
+__device__ __forceinline__ unsigned hi_w(double x) { return (unsigned)__double2hiint(x); }
+
+template <int M>
+__device__ __forceinline__ double xor_lane_d(double v) {
+  return mk_d((unsigned)xor_lane_i<M>((int)lo_w(v)), (unsigned)xor_lane_i<M>((int)hi_w(v)));
+}
+template <int M>
+__device__ __forceinline__ double bfly_add_d(double x) {
+  if constexpr (M == 32) {
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo_w(x), lo_w(x), false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hi_w(x), hi_w(x), false, false);
+    return mk_d(r0[0], r1[0]) + mk_d(r0[1], r1[1]);
+  } else if constexpr (M == 16) {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(lo_w(x), lo_w(x), false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(hi_w(x), hi_w(x), false, false);
+    return mk_d(r0[0], r1[0]) + mk_d(r0[1], r1[1]);
+  } else {
+    return x + xor_lane_d<M>(x);
+  }
+}
+__device__ __forceinline__ double lanes32_sum_d(double v) {
+  v = bfly_add_d<1>(v); v = bfly_add_d<2>(v); v = bfly_add_d<4>(v); v = bfly_add_d<8>(v); v = bfly_add_d<16>(v);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_fast_d(double v) { return bfly_add_d<32>(lanes32_sum_d(v)); }
+// {value of the lower half-wave's lane, value of the upper half-wave's lane} for every lane pair (l, l + 32)
+__device__ __forceinline__ void halves_d(double x, double& lower, double& upper) {
+  const auto r0 = __builtin_amdgcn_permlane32_swap(lo_w(x), lo_w(x), false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(hi_w(x), hi_w(x), false, false);
+  lower = mk_d(r0[0], r1[0]);
+  upper = mk_d(r0[1], r1[1]);
+}
+template <int M>
+__device__ __forceinline__ double halve_pair_d(double lo, double hi, int lane) {
+  if constexpr (M == 32) {
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo_w(lo), lo_w(hi), false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hi_w(lo), hi_w(hi), false, false);
+    return mk_d(r0[0], r1[0]) + mk_d(r0[1], r1[1]);
+  } else if constexpr (M == 16) {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(lo_w(lo), lo_w(hi), false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(hi_w(lo), hi_w(hi), false, false);
+    return mk_d(r0[0], r1[0]) + mk_d(r0[1], r1[1]);
+  } else {
+    const bool up = (lane & M) != 0;
+    const double keep = up ? hi : lo;
+    const double send = up ? lo : hi;
+    return keep + xor_lane_d<M>(send);
+  }
+}
+template <int CNT, int M, int NV>
+__device__ __forceinline__ void halving_steps_d(double (&v)[NV], int lane) {
+  if constexpr (M >= 1) {
+    if constexpr (CNT > 1) {
+      constexpr int half = CNT / 2;
+#pragma unroll
+      for (int j = 0; j < half; ++j) v[j] = halve_pair_d<M>(v[j], v[j + half], lane);
+      halving_steps_d<half, M / 2, NV>(v, lane);
+    } else {
+      v[0] = halve_pair_d<M>(v[0], v[0], lane);
+      halving_steps_d<1, M / 2, NV>(v, lane);
+    }
+  }
+}
+// wave reduce-scatter of n (<= 32, power of two) fp64 register values: lane l ends with the wave sum of component
+// l >> (6 - log2 n)
+template <int n>
+__device__ __forceinline__ double wave_rs_d(double (&v)[n], int lane) {
+  constexpr int h0 = n / 2;
+  double w[h0];
+#pragma unroll
+  for (int j = 0; j < h0; ++j) w[j] = halve_pair_d<32>(v[j], v[j + h0], lane);
+  halving_steps_d<h0, 16, h0>(w, lane);
+  return w[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The kernel.  Same launch geometry, member hand-out and granule hand-off as k_cg_onchip5 (lo_cg_onchip4.hip): 256
+// threads x 4 rows, the rows of C in VGPRs, groups of GW workgroups per member, two workgroups per CU.
+//   payload of the member's ONE all-reduce (fp64, two tagged 8-byte granules per value):
+//     [per 16-column block: w0 | u0]  s  a0  next-member
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int RS_SLOT = 136;  // granules per workgroup and parity: 2 x (2 * 32 + 3), padded
+__host__ __device__ constexpr int rs_np(int RC) { return 2 * RC + 3; }
+__host__ __device__ constexpr size_t rs_group_granules(int GW) { return (size_t)2 * (GW + 1) * R4_SLOT + (size_t)2 * GW * RS_SLOT; }
+
+template <int RC>
+struct alignas(16) RsShared {
+  double red[R4_WAVES][2 * RC + 4];
+  double res[2 * RC + 4];
+  double gv[R4_WAVES][32];      // every wave's own broadcast copy of the vector it multiplies (g, w0, at the end nrm * y)
+  double out[2][R4_WAVES][32];  // the four products of an iteration, double-buffered by the iteration's parity
+};
+
+template <int RC, int GW>
+__global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipArgs a) {
+  constexpr int NP = rs_np(RC);
+  constexpr int MLD = RC + 2;            // row stride of the fp64 matrices in LDS (16-byte aligned, conflict-free b128 reads)
+  constexpr int H = 8;                   // columns per accumulation round (2 H fp64 accumulators per thread)
+  constexpr int NH = RC / 2;             // columns per half-wave in the R x R products
+  __shared__ R4Shared sh;
+  __shared__ RsShared<RC> rs;
+  __shared__ __attribute__((aligned(16))) double mat_s[4 * RC * MLD];  // E | F E | E F E | G2
+  __shared__ float4 stage_s[R4_WAVES * 64 * (RC / 4)];                 // per-wave transposition window of the member load
+  const int wg = blockIdx.x;
+  const int xcd = wg % 8, jx = wg / 8;
+  const int groups_per_xcd = (gridDim.x / 8) / GW;
+  const int grp = xcd * groups_per_xcd + jx / GW;
+  const int wig = jx % GW;
+  const int ngroups = groups_per_xcd * 8;
+  if (jx / GW >= groups_per_xcd) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  R4Group g;
+  // granules of the group: [placement check: 2 x (GW + 1) x R4_SLOT] [the members' all-reduces: 2 x GW x RS_SLOT]
+  g.gslot = a.gbuf + (size_t)grp * rs_group_granules(GW);
+  unsigned long long* const rs_slot = g.gslot + 2 * (GW + 1) * R4_SLOT;
+  g.wig = wig;
+  g.dbg = nullptr;
+  g.tag = 0;
+  g.err = a.err;
+  g.same_xcd = false;
+  {  // placement check (see k_cg_onchip4): plain-store hand-off only when the whole group shares an XCD
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
+    if (t < 64) {
+      sh.red[0][0] = (float)xcc;
+      sh.red[0][1] = (float)(xcc * xcc);
+    }
+    if (t < 2 * (R4_WAVES - 1)) sh.red[1 + t / 2][t % 2] = 0.f;
+    r4_group_sum<GW>(sh, 2, g);
+    const float fx = (float)xcc;
+    g.same_xcd = (sh.res[0] == GW * fx) && (sh.res[1] == GW * fx * fx) && (a.allow_l2_handoff != 0);
+    __syncthreads();
+  }
+  const int row0 = wig * a.RW;
+  const int nv = max(0, min(a.RW, a.N - row0));
+  const bool di_full = a.dinv_mode == LO_DIAG_FULL;
+  int64_t b = grp;
+  while (b < a.B) {
+    const bool stamp = a.dbg && b == a.dbg_member && wig == 0 && t == 0;
+    if (stamp) a.dbg[0] = wall_clock64();
+    int drawn = 0;
+    if (wig == 0 && t == 0) drawn = atomicAdd(a.next_member, 1);  // (its round trip hides behind the member load)
+    f32x2 Cr[R4_NR][RC / 2];
+    int tl = t;
+    asm volatile("" : "+v"(tl));
+    // ---- every load of the member is issued before anything waits (vmcnt counts in order) ----
+    constexpr int CH = RC / 4;
+    const int wv_ = tl >> 6, ln = tl & 63;
+#pragma unroll
+    for (int q = 0; q < R4_NR; ++q) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int gch = 64 * i + ln;  // chunk of the wave's block
+        const int rw = gch / CH, ck = gch % CH;
+        const size_t grow_c = (size_t)b * a.N + min(row0 + R4_TPB * q + 64 * wv_ + rw, a.N - 1);
+        const float4 c4 = *reinterpret_cast<const float4*>(a.C + grow_c * RC + 4 * ck);
+        Cr[q][2 * i] = f32x2{c4.x, c4.y}; Cr[q][2 * i + 1] = f32x2{c4.z, c4.w};
+      }
+    }
+    float bq[R4_NR], diq[R4_NR];
+#pragma unroll
+    for (int q = 0; q < R4_NR; ++q) {
+      const size_t grow = (size_t)b * a.N + min(row0 + tl + R4_TPB * q, a.N - 1);
+      bq[q] = a.rhs[grow];
+      diq[q] = di_full ? a.dinv[grow] : a.dinv[b];
+    }
+    constexpr int NM = (4 * RC * RC / 2 + R4_TPB - 1) / R4_TPB;  // 16-byte pieces of the four matrices per thread
+    f32x4 mv[NM];
+    {
+      const f32x4* src = reinterpret_cast<const f32x4*>(a.RS + (size_t)b * 6 * RC * RC);  // E | F E | E F E | G2 (| F | E F)
+#pragma unroll
+      for (int u = 0; u < NM; ++u) mv[u] = src[min(tl + R4_TPB * u, 4 * RC * RC / 2 - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < R4_NR; ++q) {
+      const bool valid = tl + R4_TPB * q < nv;
+      float4* win = stage_s + wv_ * (64 * CH);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int gch = 64 * i + ln;
+        const int rw = gch / CH, ck = gch % CH;
+        win[rw * CH + (ck ^ ((rw ^ (rw >> 3)) & (CH - 1)))] =
+            make_float4(Cr[q][2 * i].x, Cr[q][2 * i].y, Cr[q][2 * i + 1].x, Cr[q][2 * i + 1].y);
+      }
+      __builtin_amdgcn_wave_barrier();  // (LDS operations of a wave execute in order; this pins the compiler's order)
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const float4 c4 = win[ln * CH + (i ^ ((ln ^ (ln >> 3)) & (CH - 1)))];
+        Cr[q][2 * i] = f32x2{c4.x, c4.y}; Cr[q][2 * i + 1] = f32x2{c4.z, c4.w};
+      }
+#pragma unroll
+      for (int i = 0; i < RC / 2; ++i) Cr[q][i] = valid ? Cr[q][i] : f32x2{0.f, 0.f};
+      __builtin_amdgcn_wave_barrier();  // the next row set reuses the window
+      bq[q] = valid ? bq[q] : 0.f;
+      diq[q] = valid ? diq[q] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NM; ++u) {
+      const int e = tl + R4_TPB * u;  // piece e = (matrix m, row i, column pair jj)
+      if (e < 4 * RC * RC / 2) {
+        const int mi = e / (RC / 2), jj = e % (RC / 2);
+        *reinterpret_cast<f32x4*>(&mat_s[mi * MLD + 2 * jj]) = mv[u];
+      }
+    }
+    if (stamp) a.dbg[1] = wall_clock64();
+
+    // ---- the member's one reduction over the rows, fp64: w0 = C^T (dinv o b), u0 = C^T b per 16-column block, s, a0 ----
+    {
+      double bd[R4_NR], bb[R4_NR];
+      double s_acc = 0.0, a_acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < R4_NR; ++q) {
+        bb[q] = (double)bq[q];
+        bd[q] = bb[q] * (double)diq[q];
+        s_acc = fma(bb[q], bd[q], s_acc);
+        a_acc = fma(bb[q], bb[q], a_acc);
+      }
+#pragma unroll
+      for (int blk = 0; blk < RC / H; ++blk) {
+        double acc[2 * H];
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+          double aw = 0.0, au = 0.0;
+#pragma unroll
+          for (int q = 0; q < R4_NR; ++q) {
+            const int col = H * blk + j;
+            const double cj = (double)((col & 1) ? Cr[q][col >> 1].y : Cr[q][col >> 1].x);
+            aw = fma(cj, bd[q], aw);
+            au = fma(cj, bb[q], au);
+          }
+          acc[j] = aw;
+          acc[H + j] = au;
+        }
+        const double mine = wave_rs_d<2 * H>(acc, lane);
+        constexpr int per = 64 / (2 * H);  // lanes per component
+        if ((lane & (per - 1)) == 0) rs.red[wave][2 * H * blk + lane / per] = mine;
+        __builtin_amdgcn_sched_barrier(0);  // (one block of columns at a time: 2 H fp64 accumulators live)
+      }
+      const double ssum = wave_sum_fast_d(s_acc), asum = wave_sum_fast_d(a_acc);
+      if (lane == 0) {
+        rs.red[wave][2 * RC] = ssum;
+        rs.red[wave][2 * RC + 1] = asum;
+        rs.red[wave][2 * RC + 2] = (wig == 0 && wave == 0) ? (double)(ngroups + drawn) : 0.0;
+      }
+    }
+    // (opaque to value numbering: otherwise the fp64 conversions of the rows are kept -- and spilled -- for the last pass)
+#pragma unroll
+    for (int q = 0; q < R4_NR; ++q)
+#pragma unroll
+      for (int i = 0; i < RC / 2; ++i) asm volatile("" : "+v"(Cr[q][i]));
+    // rows of F (wave 1) and E F (wave 2) for the two products with w0 behind the all-reduce: in flight during the exchange
+    f32x4 frow[NH / 2];
+    __builtin_amdgcn_sched_barrier(0);  // (not earlier: the fp64 accumulators of the reduction need the registers)
+    {
+      const int jj = min(lane & 31, RC - 1), hh = lane >> 5;
+      const int wsel = (wave == 2) ? 5 : 4;
+      const f32x4* fsrc = reinterpret_cast<const f32x4*>(a.RS + ((size_t)b * 6 + wsel) * RC * RC + (size_t)jj * RC + hh * NH);
+#pragma unroll
+      for (int q = 0; q < NH / 2; ++q) frow[q] = (wave == 1 || wave == 2) ? fsrc[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- group all-reduce of NP doubles: thread tt < NP owns component tt (two granules: low | high word) ----
+    {
+      const unsigned tag = ++g.tag;
+      __syncthreads();
+      if (t < NP) {
+        const double v = (rs.red[0][t] + rs.red[1][t]) + (rs.red[2][t] + rs.red[3][t]);
+        double tot = v;
+        if constexpr (GW > 1) {
+          unsigned long long* slot = rs_slot + (size_t)(tag & 1u) * GW * RS_SLOT;
+          unsigned long long* mine = slot + (size_t)wig * RS_SLOT + 2 * t;
+          const unsigned long long g0 = ((unsigned long long)tag << 32) | (unsigned long long)lo_w(v);
+          const unsigned long long g1 = ((unsigned long long)tag << 32) | (unsigned long long)hi_w(v);
+          if (g.same_xcd) {
+            __hip_atomic_store(mine, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(mine + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            __hip_atomic_store(mine, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          tot = 0.0;
+          unsigned spin = 0;
+          constexpr int CK = (GW < 8) ? GW : 8;  // workgroups polled together (2 CK loads in flight)
+          bool lost = false;
+          for (int w0_ = 0; w0_ < GW && !lost; w0_ += CK) {
+            unsigned long long x0[CK], x1[CK];
+            for (;;) {
+              bool ok = true;
+#pragma unroll
+              for (int w = 0; w < CK; ++w) {
+                const unsigned long long* src = slot + (size_t)(w0_ + w) * RS_SLOT + 2 * t;
+                x0[w] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x1[w] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && ((unsigned)(x0[w] >> 32) == tag) && ((unsigned)(x1[w] >> 32) == tag);
+              }
+              if (ok) break;
+              if (++spin > R4_MAXSPIN ||
+                  ((spin & 1023u) == 0 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                atomicExch(g.err, 1);  // timed out, or another workgroup already did: give up at once
+                lost = true;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int w = 0; w < CK; ++w) tot += mk_d((unsigned)(x0[w] & 0xffffffffull), (unsigned)(x1[w] & 0xffffffffull));
+          }
+        }
+        rs.res[t] = tot;
+      }
+      __syncthreads();
+    }
+    if (stamp) a.dbg[2] = wall_clock64();
+    const int64_t b_next = (int64_t)rs.res[2 * RC + 2];
+
+    // ---- the iterations, on R + 1 coordinates.  All four waves carry the (replicated) state; wave m owns matrix m of
+    // E | F E | E F E | G2 and contributes its product with g, one barrier per iteration joins them:
+    //     w = rho w0 + E g,    v = F w = rho (F w0) + (F E) g,    E v = rho (E F w0) + (E F E) g
+    // (F w0 and E F w0 once per member, by the waves 1 and 2 from rows of F / E F they fetched before the all-reduce) ----
+    const int j = lane & 31, hf = lane >> 5;
+    const bool live = j < RC;
+    const int jr = live ? j : RC - 1;
+    double yj = 0.0, xi = 0.0;
+    float nrm;
+    // (register budget: every wave parks its last row set of C in its own transposition window while it iterates)
+    {
+      float4* win = stage_s + wave * (64 * (RC / 4));
+#pragma unroll
+      for (int i = 0; i < RC / 4; ++i)
+        win[i * 64 + lane] = make_float4(Cr[R4_NR - 1][2 * i].x, Cr[R4_NR - 1][2 * i].y, Cr[R4_NR - 1][2 * i + 1].x,
+                                         Cr[R4_NR - 1][2 * i + 1].y);
+    }
+    {
+      const int iw = (jr / H) * 2 * H + (jr % H);
+      double a0 = rs.res[2 * RC + 1], s = rs.res[2 * RC];
+      nrm = sqrtf((float)a0);                             // rhs.norm(2, dim=-2)          :177
+      const bool rhs_zero = nrm < a.eps;                  // :178
+      if (rhs_zero) nrm = 1.0f;                           // :179
+      const double inv = 1.0 / (double)nrm;
+      const double w0 = live ? rs.res[iw] * inv : 0.0, u0 = live ? rs.res[iw + H] * inv : 0.0;
+      s *= inv * inv;
+      a0 *= inv * inv;
+      // this wave's matrix row (half of it per half-wave) against a vector the wave has just written to its own LDS copy
+      auto own_row_dot = [&](const double* mrow, const double* vec) {
+        double a0_ = 0.0, a1_ = 0.0;
+#pragma unroll
+        for (int q = 0; q < NH; q += 2) {
+          const double2 xa = *reinterpret_cast<const double2*>(mrow + q);
+          const double2 xx = *reinterpret_cast<const double2*>(vec + q);
+          a0_ = fma(xa.x, xx.x, a0_);
+          a1_ = fma(xa.y, xx.y, a1_);
+        }
+        double lo_, up_;
+        halves_d(a0_ + a1_, lo_, up_);
+        return lo_ + up_;
+      };
+      double* myv = rs.gv[wave];
+      double Fw0 = 0.0, EFw0 = 0.0;
+      {  // F w0, E F w0
+        if (hf == 0) myv[j] = w0;
+        __builtin_amdgcn_wave_barrier();
+        if (wave == 1 || wave == 2) {
+          double a0_ = 0.0, a1_ = 0.0;
+#pragma unroll
+          for (int q = 0; q < NH; q += 2) {
+            const double2 xx = *reinterpret_cast<const double2*>(myv + hf * NH + q);
+            const double fx = mk_d(__float_as_uint(frow[q / 2].x), __float_as_uint(frow[q / 2].y));
+            const double fy = mk_d(__float_as_uint(frow[q / 2].z), __float_as_uint(frow[q / 2].w));
+            a0_ = fma(fx, xx.x, a0_);
+            a1_ = fma(fy, xx.y, a1_);
+          }
+          double lo_, up_;
+          halves_d(a0_ + a1_, lo_, up_);
+          if (hf == 0) rs.out[1][wave][j] = lo_ + up_;
+        }
+        __syncthreads();
+        Fw0 = live ? rs.out[1][1][j] : 0.0;
+        EFw0 = live ? rs.out[1][2][j] : 0.0;
+      }
+      double gj = 0.0, hj = 0.0, Ehj = 0.0, tj = 0.0;
+      double rho = 1.0, pi = 0.0, rz = 0.0, dpp = 0.0, tt = 0.0, hw0 = 0.0;
+      double alpha = 0.0, beta = 0.0;
+      float rn = 0.f, last_alpha = 0.f;
+      bool conv = false;
+      unsigned close_flags = 0u;
+      const size_t bc = (size_t)b;
+      const double* mrow = mat_s + (size_t)(wave * RC + jr) * MLD + hf * NH;
+      for (int k = -1; k < a.iters; ++k) {
+        double Eg = 0.0, FEg = 0.0, EFEg = 0.0, G2g = 0.0;
+        if (k >= 0) {  // x += alpha p (:31);  r -= alpha A p (:264), A p = pi r0 + C (h + t)
+          last_alpha = (float)alpha;
+          xi = fma(alpha, pi, xi);
+          yj = fma(alpha, hj, yj);
+          rho = fma(-alpha, pi, rho);
+          gj = fma(-alpha, hj + tj, gj);
+          if (hf == 0) myv[j] = gj;
+          __builtin_amdgcn_wave_barrier();
+          const double mine = own_row_dot(mrow, myv + hf * NH);
+          const int par = k & 1;
+          if (hf == 0) rs.out[par][wave][j] = mine;
+          __syncthreads();
+          if (live) {
+            Eg = rs.out[par][0][j];
+            FEg = rs.out[par][1][j];
+            EFEg = rs.out[par][2][j];
+            G2g = rs.out[par][3][j];
+          }
+        }
+        const double wj = fma(rho, w0, Eg);
+        const double vj = fma(rho, Fw0, FEg);
+        const double Evj = fma(rho, EFw0, EFEg);
+        const double tz = wj - Evj;                        // (C^T z)_j
+        // eleven inner products over the components: the lower half-wave forms six, the upper five; ONE reduce-scatter of
+        // eight values per half, the totals come back as wave-uniform scalars (v_readlane)
+        const bool lo_h = hf == 0;
+        double pr[8];
+        pr[0] = lo_h ? gj * w0 : vj * Evj;
+        pr[1] = lo_h ? gj * wj : vj * tj;
+        pr[2] = lo_h ? gj * u0 : tz * tz;
+        pr[3] = lo_h ? gj * G2g : tz * tj;
+        pr[4] = lo_h ? wj * vj : vj * w0;
+        pr[5] = lo_h ? gj * Ehj : 0.0;
+        pr[6] = 0.0;
+        pr[7] = 0.0;
+        double red8;
+        {
+          double v4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v4[q] = halve_pair_d<16>(pr[q], pr[q + 4], lane);
+          halving_steps_d<4, 8, 4>(v4, lane);             // bit 8, then bit 4: lane l holds component (l >> 2) & 7
+          red8 = bfly_add_d<2>(v4[0]);
+          red8 = bfly_add_d<1>(red8);
+        }
+        const auto pick = [&](int ln) {
+          return mk_d((unsigned)__builtin_amdgcn_readlane((int)lo_w(red8), ln),
+                      (unsigned)__builtin_amdgcn_readlane((int)hi_w(red8), ln));
+        };
+        const double gw0 = pick(0), gw = pick(4), gu0 = pick(8), gG2g = pick(12), wv = pick(16), gEh = pick(20);
+        const double vEv = pick(32), vt = pick(36), tztz = pick(40), tzt = pick(44), vw0 = pick(48);
+        const double s2 = fma(rho, fma(rho, s, gw0), gw);            // r^T D^-1 r
+        const double s1 = fma(rho, fma(rho, a0, 2.0 * gu0), gG2g);   // r^T r
+        const double rzn = s2 - wv;                                  // residual_inner_prod :215 / :35-36
+        const float s1f = (float)s1;                                 // (tiny negative by rounding -> 0; NaN stays NaN)
+        float rnn = __builtin_amdgcn_sqrtf(s1f < 0.f ? 0.f : s1f);   // :298 / :204
+        if (k >= 0) {                                                // closes iteration k: beta, residual norm, records
+          beta = ((float)rz < a.eps) ? 0.0 : (double)((float)rzn * __builtin_amdgcn_rcpf((float)rz));  // :39-42
+          if (rhs_zero) rnn = 0.f;                                   // :299
+          rn = rnn;
+          if (wig == 0 && t == 0) a.resid_rec[(size_t)k * a.B + bc] = rn;
+        } else {
+          beta = 0.0;
+          rn = rnn;
+          if (wig == 0 && t == 0) a.init_conv[bc] = (rn < a.stop_after) ? 1 : 0;  // :204-205
+          close_flags = (rn < a.stop_after) ? 1u : 0u;
+        }
+        if (k == 0 && rnn != rnn) close_flags |= 2u;  // (NaN after the first product, linear_cg.py:199-200)
+        conv = rn < a.stop_after;                                    // :300
+        rz = rzn;
+        const double dzz = fma(-2.0, wv, s2) + vEv;                  // sum d z^2
+        const double rp = fma(rho, fma(pi, s, hw0), fma(pi, gw0, gEh));  // r^T p_old
+        const double dzp = rp - vt;
+        dpp = fma(beta, fma(beta, dpp, 2.0 * dzp), dzz);             // sum d p_new^2
+        tt = fma(beta, fma(beta, tt, 2.0 * tzt), tztz);              // |C^T p_new|^2
+        tj = fma(beta, tj, tz);                                      // C^T p_new
+        pi = fma(beta, pi, rho);                                     // p = z + beta p (:268, :46)
+        hj = fma(beta, hj, gj - vj);
+        Ehj = fma(beta, Ehj, Eg - Evj);
+        hw0 = fma(beta, hw0, gw0 - vw0);
+        const double pAp = tt + dpp;
+        alpha = ((float)pAp < a.eps) ? 0.0 : (double)((float)rz * __builtin_amdgcn_rcpf((float)pAp));  // :254-257
+        if (conv) alpha = 0.0;                                       // :260
+      }
+      if (wig == 0 && t == 0) {
+        a.rhs_norm[bc] = nrm;
+        a.rhs_is_zero[bc] = rhs_zero ? 1 : 0;
+        a.rz[bc] = (float)rz;
+        a.alpha[bc] = last_alpha;
+        a.beta[bc] = (float)beta;
+        a.resid_norm[bc] = rn;
+        a.has_conv[bc] = conv ? 1 : 0;
+        if (a.close_gran) {  // this member's line of the closing step: one never-torn 8-byte store
+          const unsigned long long gr =
+              ((unsigned long long)(0x80000000u | close_flags) << 32) | (unsigned long long)__float_as_uint(rn);
+          __hip_atomic_store(a.close_gran + b, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (stamp) a.dbg[3] = wall_clock64();
+    // ---- x = nrm D^-1 (xi r0 + C y) = D^-1 (xi b + C (nrm y)), in fp64 (for small diagonals the two terms cancel); every
+    // wave reads its own copy of y ----
+    {
+      const float4* win = stage_s + wave * (64 * (RC / 4));
+#pragma unroll
+      for (int i = 0; i < RC / 4; ++i) {
+        const float4 c4 = win[i * 64 + lane];
+        Cr[R4_NR - 1][2 * i] = f32x2{c4.x, c4.y}; Cr[R4_NR - 1][2 * i + 1] = f32x2{c4.z, c4.w};
+      }
+      double* myv = rs.gv[wave];
+      if (hf == 0) myv[j] = yj * (double)nrm;
+      __builtin_amdgcn_wave_barrier();
+      double acc[R4_NR];
+#pragma unroll
+      for (int q = 0; q < R4_NR; ++q) acc[q] = xi * (double)bq[q];
+#pragma unroll
+      for (int i = 0; i < RC; i += 2) {
+        const double2 y2 = *reinterpret_cast<const double2*>(&myv[i]);
+#pragma unroll
+        for (int q = 0; q < R4_NR; ++q) {
+          acc[q] = fma((double)Cr[q][i >> 1].x, y2.x, acc[q]);
+          acc[q] = fma((double)Cr[q][i >> 1].y, y2.y, acc[q]);
+        }
+      }
+      int tw = t;
+      asm volatile("" : "+v"(tw));
+#pragma unroll
+      for (int q = 0; q < R4_NR; ++q)
+        if (tw + R4_TPB * q < nv) a.xout[(size_t)b * a.N + row0 + tw + R4_TPB * q] = (float)(acc[q] * (double)diq[q]);  // :335
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (stamp) a.dbg[4] = wall_clock64();
+    b = b_next;
+  }
+  if (a.close_gran && wig == 0) cg_close_solve(a, ngroups, t);
+}
+
+// (worst case over the group sizes: groups of one)
+size_t rspace_gbuf_bytes(int nworkgroups) { return (size_t)nworkgroups * rs_group_granules(1) * sizeof(unsigned long long); }
+
+bool rspace_eligible(int RC, int64_t N, int64_t c) {
+  return (RC == 8 || RC == 16 || RC == 32) && c == 1 && N >= 256 && N <= (int64_t)64 * R4_ROWS;
+}
+
+template <int RC, int GW>
+static int rspace_go(const OnchipArgs& a, int nwg, hipStream_t st) {
+  int per_cu = 0;
+  if (LO_OCCUPANCY_CACHED(per_cu, (k_cg_rspace<RC, GW>), R4_TPB, 0) != hipSuccess || per_cu < 2)
+    return LO_ERR_UNSUPPORTED;
+  LO_PROF_BEGIN("cg_onchip", st);
+  ResidentLaunch guard(st);
+  hipLaunchKernelGGL((k_cg_rspace<RC, GW>), dim3(2 * nwg), dim3(R4_TPB), 0, st, a);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+// One column, result only (a.x == nullptr), a.F / a.RS present.  Same launch geometry as onchip5_launch.
+int rspace_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st) {
+  if (!a.RS || a.x || a.c != 1 || a.ab_rec || !a.xout) return LO_ERR_UNSUPPORTED;
+#define LO_RS(C_)                                                                                    \
+  switch (a.GW) {                                                                                    \
+    case 1: return rspace_go<C_, 1>(a, nwg, st);                                                     \
+    case 2: return rspace_go<C_, 2>(a, nwg, st);                                                     \
+    case 4: return rspace_go<C_, 4>(a, nwg, st);                                                     \
+    case 8: return rspace_go<C_, 8>(a, nwg, st);                                                     \
+    case 16: return rspace_go<C_, 16>(a, nwg, st);                                                   \
+    case 32: return rspace_go<C_, 32>(a, nwg, st);                                                   \
+    default: return rspace_go<C_, 64>(a, nwg, st);                                                   \
+  }
+  if (RC == 32) {
+    LO_RS(32);
+  } else if (RC == 16) {
+    LO_RS(16);
+  } else if (RC == 8) {
+    LO_RS(8);
+  }
+#undef LO_RS
+  return LO_ERR_UNSUPPORTED;
+}
+
+}  // namespace lo

@@ -6,6 +6,7 @@ current stream; there is no other implementation behind these functions.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Callable, Optional
 
@@ -151,6 +152,9 @@ class WoodburyPreconditioner:
     F: Optional[torch.Tensor] = None
     EF: Optional[torch.Tensor] = None
     E: Optional[torch.Tensor] = None
+    # R-space form (lo_precond_desc.RS): fp64 [B, 6, rf_ld, rf_ld] = E | F E | E F E | C^T C | F | E F -- single-column result-only solves
+    # run their iterations on R + 1 coordinates (csrc/lo_rspace.hip)
+    RS: Optional[torch.Tensor] = None
     source: Optional[tuple] = None  # (L, d) the preconditioner was built from (to build Q later)
     # Kronecker root form (lo_precond_desc.kron_*): (kron_a [B, n1, 16], kron_b [B, n2, 16], kron_F [B, 16, 16]) of a
     # Kronecker operator with a constant diagonal -- the single-column CG of large N forms the rows of the tall matrix
@@ -185,6 +189,7 @@ class WoodburyPreconditioner:
         if self.F is not None:
             s.F, s.EF, s.rf_ld = self.F.data_ptr(), self.EF.data_ptr(), self.rf_ld
             s.E = None if self.E is None else self.E.data_ptr()
+            s.RS = None if self.RS is None else self.RS.data_ptr()
         if self.kron is not None:
             s.kron_a, s.kron_b, s.kron_F = (t.data_ptr() for t in self.kron)
         return s
@@ -780,10 +785,19 @@ def _root_form(lib, root, perm, L3, d, constant_diag, B, N, k, dev) -> WoodburyP
         dinv = torch.empty(B, N, dtype=torch.float32, device=dev)
         mode = _hip.LO_DIAG_FULL
     logdet = torch.empty(B, dtype=torch.float32, device=dev)
-    ws = _hip.workspace(lib.lo_precond_root_form_workspace_bytes(B, N, R), dev)
     sm, sr, sc = L3.stride()
     if B == 1:
         sm = 0
+    if R % 4 == 0 and C3.data_ptr() % 16 == 0 and not os.environ.get("LO_NO_RSPACE_FORM"):
+        # with the R-space form: E and C^T C on the fp64 matrix cores (the fp32 F / EF / E are roundings of the same)
+        RS = torch.empty(B, 6, ld, ld, dtype=torch.float64, device=dev)
+        ws = _hip.workspace(lib.lo_precond_root_form_rs_workspace_bytes(B, N, R), dev)
+        _hip.check(lib.lo_precond_root_form_rs_f32(_hip.ptr(C3), R, _hip.ptr(d2), mode, _hip.ptr(L3), sm, sr, sc,
+                                                   _hip.ptr(p2), B, N, k, ld, _hip.ptr(F), _hip.ptr(EF), _hip.ptr(E),
+                                                   _hip.ptr(dinv), _hip.ptr(logdet), _hip.ptr(RS), _hip.ptr(ws),
+                                                   ws.numel(), _hip.stream_ptr(dev)), "lo_precond_root_form_rs_f32")
+        return WoodburyPreconditioner(None, dinv, k, constant_diag, logdet, F, EF, E, RS)
+    ws = _hip.workspace(lib.lo_precond_root_form_workspace_bytes(B, N, R), dev)
     _hip.check(lib.lo_precond_root_form_f32(_hip.ptr(C3), R, _hip.ptr(d2), mode, _hip.ptr(L3), sm, sr, sc, _hip.ptr(p2),
                                             B, N, k, ld, _hip.ptr(F), _hip.ptr(EF), _hip.ptr(E), _hip.ptr(dinv),
                                             _hip.ptr(logdet), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)),
@@ -851,7 +865,7 @@ def precond_build(L: torch.Tensor, d: torch.Tensor, constant_diag: bool, root: O
         if not need_q:
             return rf
         full = precond_build(L, d, constant_diag)
-        full.F, full.EF, full.E, full.source = rf.F, rf.EF, rf.E, rf.source
+        full.F, full.EF, full.E, full.RS, full.source = rf.F, rf.EF, rf.E, rf.RS, rf.source
         return full
     ldq = padded_rank(k)
     Q = torch.empty(B, N, ldq, dtype=torch.float32, device=dev)

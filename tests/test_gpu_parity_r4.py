@@ -274,9 +274,10 @@ def _woodbury_exact(C, d, rhs):
 ])
 def test_w_recurrence_mode_against_three_pass_oracle_and_exact_solution(N, R, B, dscale, doff, cscale, monkeypatch):
     """Single-column solves without tridiagonals carry w = C^T D^-1 r by recurrence (k_cg_onchip5 MODE 2; numerics
-    prototype tests/proto/proto_w_recurrence.py).  Same iteration count as the three-pass iteration (LO_OC_NO_WREC) and the
-    oracle; solution within 1e-4 per column of the oracle's (north_star's bar) and as close to the EXACT solution (fp64
-    Woodbury) as the three-pass iteration is, within a factor of 3."""
+    prototype tests/proto/proto_w_recurrence.py; selected with LO_OC_NO_RSPACE since round 5).  Same iteration count as
+    the three-pass iteration (LO_OC_NO_WREC) and the oracle; solution within 1e-4 per column of the oracle's
+    (north_star's bar) and as close to the EXACT solution (fp64 Woodbury) as the three-pass iteration is, within a
+    factor of 3."""
     C, d, rhs = cases.lowrank_diag(8800 + R, B, N, R, 1)
     C = (C * cscale).astype(np.float32)
     d = ((d - 0.5) * dscale + doff).astype(np.float32)
@@ -284,6 +285,7 @@ def test_w_recurrence_mode_against_three_pass_oracle_and_exact_solution(N, R, B,
     L, perm = K.pivoted_cholesky(desc, 15)
     pre = K.precond_build(L, dev(d), constant_diag=False, root=desc.A0, perm=perm)
     assert pre.E is not None
+    monkeypatch.setenv("LO_OC_NO_RSPACE", "1")
     K._hip.prof_enable(True)
     res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
     torch.cuda.synchronize()
@@ -312,6 +314,26 @@ def test_w_recurrence_mode_against_three_pass_oracle_and_exact_solution(N, R, B,
     assert max_rel_err_cols(host(res.x)[sub], xo) < (1e-4 if e_3p < 1e-5 else 2e-3)
     res2 = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
     assert torch.equal(res.x, res2.x)  # bitwise reproducible
+    monkeypatch.delenv("LO_OC_NO_RSPACE")
+
+    # ---- round 5: the default result-only pass runs the iterations on R + 1 coordinates in fp64 (k_cg_rspace, numerics
+    # prototype tests/proto/proto_rspace.py): the same CG in exact arithmetic.  Where the fp32 iterations stop at the floor
+    # it reports the same iteration count; where their rounding makes them go on (ill-conditioned members) it stops at
+    # the floor with a solution that is CLOSER to the exact one.
+    assert pre.RS is not None
+    rs = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+    ran = K.cg_last_executed()
+    assert ran["serial_engine"] == "root" and ran["lean"] and rs.tolerance_reached
+    if ran_lean:
+        assert rs.iterations == ref.iterations
+        assert not torch.equal(rs.x, res.x), "the R-space kernel did not run"
+    else:
+        assert rs.iterations <= ref.iterations
+    e_rs = max_rel_err_cols(host(rs.x), exact)
+    assert e_rs < 2e-6 and e_rs < 3 * e_3p + 1e-6, (e_rs, e_3p)
+    assert max_rel_err_cols(host(rs.x)[sub], xo) < (1e-4 if e_3p < 1e-5 else 2e-3)
+    rs2 = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+    assert torch.equal(rs.x, rs2.x)  # bitwise reproducible
 
 
 def test_w_recurrence_mode_continues_on_the_streaming_engine_when_the_floor_is_not_enough():
