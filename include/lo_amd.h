@@ -224,6 +224,12 @@ typedef struct lo_cg_plan {
   int32_t first_stop_iteration; /* min(10, max_iter-1), raised to min(max_tridiag_iter, max_iter-1) with tridiagonals
                                  * (linear_cg.py:302-308)                                                            */
   int32_t reserved;
+  int32_t rspace;               /* round 5 (needs lo_precond_desc.RS): the result-only first pass runs the iterations on
+                                 * R + 1 coordinates (csrc/lo_rspace.hip): 2 = the single column inside the resident
+                                 * launch of `serial_engine` (one all-reduce per member), 1 = ALL columns in three
+                                 * streaming launches (k_rs_part / k_rs_iter / k_rs_apply) -- lockstep_cols /
+                                 * serial_engine then name the engines of the repeat with the state                  */
+  int32_t reserved2;
 } lo_cg_plan;
 int lo_cg_plan_f32(const lo_op_desc* op, const lo_precond_desc* pre, int has_precond_cb, int has_x0,
                    const lo_cg_params* prm, int cus, lo_cg_plan* plan);

@@ -92,7 +92,7 @@ class CgPlan(C.Structure):
     """lo_cg_plan (include/lo_amd.h): the engine selection of lo_cg_solve_f32."""
     _fields_ = [(n, C.c_int32) for n in (
         "resident", "resident_iterations", "lockstep_cols", "lockstep_group", "serial_engine", "serial_group", "lean",
-        "needs_q", "streaming_precond", "poll_chunk", "first_stop_iteration", "reserved")]
+        "needs_q", "streaming_precond", "poll_chunk", "first_stop_iteration", "reserved", "rspace", "reserved2")]
 
 
 ENGINE_NAMES = {0: "none", 1: "gen1", 2: "gen2", 3: "root"}

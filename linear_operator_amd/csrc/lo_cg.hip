@@ -183,6 +183,7 @@ struct CgDev {
   float* oc_ab;      // [iters, B, c, 2] alpha / beta record of the resident kernel (n_tridiag > 0)
   int* oc_maxoff;    // [T + 1] per-iteration max off-diagonal (fp32 bit patterns, non-negative values)
   long long* oc_dbg;
+  double* rs_ws;      // partials / coefficients of the three-launch R-space form (lo_rspace.hip) or nullptr
 };
 
 // ---- init ----------------------------------------------------------------------------------------
@@ -565,7 +566,7 @@ static int padded_rank_c(int64_t R) {  // floats per row of the root as the skin
 }
 
 struct CgShape {  // what cg_layout allocates for the resident paths (it sizes the workspace from the same predicates)
-  bool oc_shape, has_ab, has_ls_gbuf, has_zero_q, pf_shape, sc_shape, sc_alloc;
+  bool oc_shape, has_ab, has_ls_gbuf, has_zero_q, pf_shape, sc_shape, sc_alloc, rs_cols;
 };
 
 static CgShape cg_shape(const lo_op_desc* op, const lo_precond_desc* pre, bool pre_cb, const lo_cg_params* prm) {
@@ -575,6 +576,7 @@ static CgShape cg_shape(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   s.has_ab = s.oc_shape && prm->n_tridiag > 0;
   s.has_ls_gbuf = s.oc_shape && c >= kLockstepMinCols && N <= 8192;
   s.has_zero_q = !pre && !pre_cb && s.oc_shape;
+  s.rs_cols = s.oc_shape && pre && pre->RS && rspace_cols_eligible(padded_rank_c(op->R), N, c);
   const Split sp = choose_split(B, N, 256);
   s.pf_shape = pre && precond_fused_eligible(B, N, c, padded_rank_k(pre->k), sp.S);
   // every other streaming shape of up to 32 columns and 16384 rows: the whole step behind the product in one launch
@@ -658,6 +660,16 @@ static void cg_plan(const lo_op_desc* op, const lo_precond_desc* pre, bool pre_c
   // (deterministic kernels: the continuation starts from the very numbers the first pass computed).
   out->lean = (!global_rule && !getenv("LO_OC_KEEP_STATE") && (ls_cols == c || out->serial_engine == LO_ENGINE_RESIDENT_ROOT))
                   ? 1 : 0;
+  // R-space forms of the result-only pass (lo_rspace.hip), with the fp64 Gram matrices of the root at hand
+  const bool rs_base = pre && pre->RS && pre_root && pre->rf_ld == RC && !global_rule && !getenv("LO_OC_KEEP_STATE");
+  if (rs_base && sh.rs_cols && (c >= 2 || prm->n_tridiag > 0) && !getenv("LO_NO_RSPACE_COLS")) {
+    out->rspace = 1;  // all columns, three streaming launches; the engines above are the repeat with the state
+    out->lean = 1;
+  } else if (rs_base && out->lean && ls_cols == 0 && c == 1 && prm->n_tridiag == 0 && pre->E &&
+             out->serial_engine == LO_ENGINE_RESIDENT_ROOT && rspace_eligible(RC, N, c) && !getenv("LO_OC_NO_RSPACE") &&
+             !getenv("LO_OC_NO_WREC")) {
+    out->rspace = 2;  // the single column inside the resident launch
+  }
 }
 
 
@@ -717,6 +729,7 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   dd.oc_ab = shp.has_ab ? ar.take<float>(2 * oc_n * oc_iters) : nullptr;
   dd.oc_maxoff = ar.take<int>((size_t)std::max(1, (int)prm->max_tridiag_iter) + 1);
   dd.oc_dbg = ar.take<long long>(16);
+  dd.rs_ws = shp.rs_cols ? ar.take<double>(rspace_cols_ws_doubles(B, N, padded_rank_c(op->R), (int)c)) : nullptr;
   dd.ls_gbuf = shp.has_ls_gbuf
                    ? ar.take<unsigned long long>(lockstep_gbuf_bytes(32, 16) / sizeof(unsigned long long))
                    : nullptr;
@@ -897,6 +910,8 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   lo_cg_plan exec = plan;  // the plan as executed: run-time fall-backs are recorded here (lo_cg_last_executed)
   exec.resident = 0;
   exec.serial_engine = LO_ENGINE_NONE;
+  exec.rspace = 0;
+  tls_rspace_resident_ran = false;
   for (int oc_pass = 0; oc_pass < 2; ++oc_pass) {
   bool oc_redo = false;
   if (oc_ok) {
@@ -942,6 +957,22 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     if (oc_dbg || ls_dbg) LO_HIP_CHECK(hipMemsetAsync(d.oc_dbg, 0, 16 * sizeof(long long), st));
     rc = LO_OK;
     bool xout_ok = true;  // every launched kernel wrote result * rhs_norm itself
+    bool serial_done = false;
+    bool rs_cols_ran = false;
+    if (plan.rspace == 1 && lean && d.rs_ws) {  // all columns on R + 1 coordinates: three streaming launches
+      a.xout = x;
+      lean_state(true);
+      a.F = pre->F; a.EF = pre->EF; a.E = pre->E; a.RS = pre->RS;
+      rc = rspace_cols_launch(pl.R4, a, d.rs_ws, st);
+      if (rc == LO_OK) {
+        serial_done = true;
+        rs_cols_ran = true;
+      } else if (rc == LO_ERR_UNSUPPORTED) {
+        rc = LO_OK;
+      }
+    }
+    const int ls_plan = ls_cols;
+    if (rs_cols_ran) ls_cols = 0;
     if (ls_cols) {  // third generation: columns [0, ls_cols)
       a.ncols = ls_cols;
       a.xout = x;
@@ -963,10 +994,9 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
         rc = (oc_gen1_ok || onchip4_eligible(pl.R4, ocR4, N, c)) ? LO_OK : LO_ERR_UNSUPPORTED;
       }
     }
-    bool serial_done = false;
     // (the plan chose the root-form kernel for the serial columns -- or the lockstep kernel did not fit this device and
     // its columns come here as well)
-    if (rc == LO_OK && ls_cols < c && !getenv("LO_OC_GEN2") && onchip5_eligible(pl.R4, N, c - ls_cols) &&
+    if (rc == LO_OK && !serial_done && ls_cols < c && !getenv("LO_OC_GEN2") && onchip5_eligible(pl.R4, N, c - ls_cols) &&
         (oc_nopre || (pre_root && pre->rf_ld == pl.R4))) {
       // root-form serial-column kernel (one all-reduce per iteration): columns [ls_cols, c)
       a.GW = (getenv("LO_OC_GW8") && N <= 32768) ? onchip4_group_size(N) : onchip5_group_size(N);
@@ -977,7 +1007,8 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       a.F = oc_nopre ? nullptr : pre->F;
       a.EF = oc_nopre ? nullptr : pre->EF;
       a.E = oc_nopre ? nullptr : pre->E;
-      a.RS = oc_nopre ? nullptr : pre->RS;
+      a.RS = (oc_nopre || plan.rspace != 2) ? nullptr : pre->RS;
+      tls_rspace_resident_ran = false;
       a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
       a.dbg = oc_dbg ? d.oc_dbg : nullptr;
       // one column, no tridiagonals, no lockstep launch in front: the kernel closes the solve itself (stop rule, NaN /
@@ -1092,12 +1123,14 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
         if (pre && !pre->Q) return LO_ERR_UNSUPPORTED;
         lean = false;
         oc_redo = true;
+        if (rs_cols_ran) ls_cols = ls_plan;  // (the repeat runs the engines of the plan)
       } else if (oc_err == 0) {
         k_start = a.iters;
         if (lean_skipped && h.stop) tls_lean_miss[miss_slot].valid = 0;  // (it stops at the floor now: speculate again)
         exec.resident = 1;
         exec.lockstep_cols = ls_cols;
         exec.lean = lean ? 1 : 0;
+        exec.rspace = rs_cols_ran ? 1 : ((lean && tls_rspace_resident_ran) ? 2 : 0);
         x_written = xout_ok;
       } else {  // a group hand-off timed out: redo everything with the streaming engine
         fprintf(stderr, "liblo_amd: operator-resident CG timed out, falling back to the streaming engine\n");

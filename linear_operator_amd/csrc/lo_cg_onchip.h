@@ -65,6 +65,11 @@ bool onchip5_eligible(int RC, int64_t N, int64_t c);
 int rspace_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st);
 bool rspace_eligible(int RC, int64_t N, int64_t c);
 size_t rspace_gbuf_bytes(int nworkgroups);
+extern thread_local bool tls_rspace_resident_ran;  // set by rspace_launch when k_cg_rspace was launched (lo_cg_last_executed)
+// all columns of a result-only solve in three streaming launches (k_rs_part / k_rs_iter / k_rs_apply, lo_rspace.hip)
+int rspace_cols_launch(int RC, const OnchipArgs& a, double* ws, hipStream_t st);
+bool rspace_cols_eligible(int RC, int64_t N, int64_t c);
+size_t rspace_cols_ws_doubles(int64_t B, int64_t N, int RC, int c);
 // third generation (lo_cg_lockstep.hip): 16 columns of a member advance together on the matrix cores
 int lockstep_launch(int RC, bool pre, const OnchipArgs& a, int nwg, hipStream_t st);
 bool lockstep_eligible(int RC, int RK, bool pre, int64_t N, int64_t ncols);

@@ -590,9 +590,8 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
           double v4[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) v4[q] = halve_pair_d<16>(pr[q], pr[q + 4], lane);
-          halving_steps_d<4, 8, 4>(v4, lane);             // bit 8, then bit 4: lane l holds component (l >> 2) & 7
-          red8 = bfly_add_d<2>(v4[0]);
-          red8 = bfly_add_d<1>(red8);
+          halving_steps_d<4, 8, 4>(v4, lane);  // bits 8, 4 (halving), 2, 1 (sums): lane l holds component (l >> 2) & 7
+          red8 = v4[0];
         }
         const auto pick = [&](int ln) {
           return mk_d((unsigned)__builtin_amdgcn_readlane((int)lo_w(red8), ln),
@@ -686,12 +685,480 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
   if (a.close_gran && wig == 0) cg_close_solve(a, ngroups, t);
 }
 
+// =====================================================================================================================
+// Several columns (inv_quad_logdet: 16 probes + the right-hand side, with the alpha / beta records of the Lanczos
+// tridiagonals, linear_cg.py:311-332): the same iteration per column, in THREE streaming launches instead of a resident one
+//   k_rs_part   w0 | u0 = C^T [D^-1 B | B] for all columns on the fp64 matrix cores (no cross-lane reduction: the matrix
+//               cores sum over the rows), s = sum b^2 / d, a0 = sum b^2 on the vector ALU; partials per row slice
+//   k_rs_iter   one wave per (member, column): the iterations on R + 1 coordinates (the single-wave form of the algebra
+//               above: four R x R products with g per iteration from LDS), alpha / beta / residual records, (xi, nrm y)
+//   k_rs_apply  x = D^-1 (xi b + C (nrm y)) for all columns, fp64
+// C is read twice, the right-hand sides twice, x written once; nothing has to be co-resident.
+// =====================================================================================================================
+constexpr int RSP_TR = 64;   // rows per tile of k_rs_part (16 per wave)
+constexpr int RSP_CMAX = 32; // columns per launch
+
+template <int RC, int NT>
+__global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ C, const float* __restrict__ rhs,
+                                                       const float* __restrict__ dinv, int dinv_mode, int N, int c,
+                                                       int rows_per, double* __restrict__ part, double* __restrict__ sq) {
+  constexpr int MT = RC > 16 ? 2 : 1;
+  constexpr int TR = RSP_TR;
+  constexpr int LD = RC + 1;
+  __shared__ float ctile[2][TR * LD];
+  __shared__ float btile[2][TR * RSP_CMAX];
+  __shared__ float dtile[2][TR];
+  __shared__ double red[4][64][4];
+  __shared__ double sqred[4][RSP_CMAX][2];
+  const int s = blockIdx.x, S = gridDim.x;
+  const int64_t b = blockIdx.y;
+  const int t = threadIdx.x, wave = t >> 6, l = t & 63;
+  const int a = l & 15, kk = l >> 4;
+  const int r0 = s * rows_per, r1 = min(N, r0 + rows_per);
+  const float* Cb = C + (size_t)b * N * RC;
+  const float* Bb = rhs + (size_t)b * N * c;
+  const bool dfull = dinv_mode == LO_DIAG_FULL;
+  const float dconst = dfull ? 0.f : dinv[b];
+  const float* db = dfull ? dinv + (size_t)b * N : nullptr;
+  constexpr int RQ = RC / 4;
+  constexpr int CP = (TR * RQ + kThreads - 1) / kThreads;  // 16-byte pieces of C per thread and tile
+  constexpr int BP = TR * RSP_CMAX / kThreads;             // floats of the right-hand sides per thread and tile (at c = 32)
+  float4 pc[CP];
+  float pb[BP];
+  float pd = 0.f;
+  auto issue = [&](int base) {
+#pragma unroll
+    for (int i = 0; i < CP; ++i) {
+      const int e = i * kThreads + t;
+      const int row = e / RQ, q = e % RQ;
+      pc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < TR * RQ && base + row < r1) pc[i] = *reinterpret_cast<const float4*>(Cb + (size_t)(base + row) * RC + 4 * q);
+    }
+    const int nb = min(TR, r1 - base) * c;  // the tile's right-hand sides are contiguous: rows x c
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const int e = i * kThreads + t;
+      pb[i] = (e < nb) ? Bb[(size_t)base * c + e] : 0.f;
+    }
+    pd = 0.f;
+    if (t < TR && base + t < r1) pd = dfull ? db[base + t] : dconst;
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < CP; ++i) {
+      const int e = i * kThreads + t;
+      if (e < TR * RQ) {
+        const int row = e / RQ, q = e % RQ;
+        float* dst = &ctile[buf][row * LD + 4 * q];
+        dst[0] = pc[i].x; dst[1] = pc[i].y; dst[2] = pc[i].z; dst[3] = pc[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const int e = i * kThreads + t;
+      if (e < TR * c) btile[buf][e] = pb[i];
+    }
+    if (t < TR) dtile[buf][t] = pd;
+  };
+  f64x4 acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NT; ++nj) acc[mi][nj] = f64x4{0.0, 0.0, 0.0, 0.0};
+  // s = sum b^2 dinv, a0 = sum b^2: thread (col = t % c, rsub = t / c < 4) walks 16 rows of its column per tile
+  const int scol = t % c, rsub = t / c;
+  double s_acc = 0.0, a_acc = 0.0;
+  int buf = 0;
+  issue(r0);
+  commit(0);
+  __syncthreads();
+  for (int base = r0; base < r1; base += TR) {
+    const bool more = base + TR < r1;
+    if (more) issue(base + TR);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 16 * wave + 4 * e + kk;
+      const double dv = (double)dtile[buf][row];
+      double av[MT], bv[NT];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) av[mi] = (16 * mi + a < RC) ? (double)ctile[buf][row * LD + 16 * mi + a] : 0.0;
+#pragma unroll
+      for (int nj = 0; nj < NT; ++nj) {
+        const int jc = 16 * nj + a;  // [0, c): b dinv   [c, 2 c): b
+        double v = 0.0;
+        if (jc < c) v = (double)btile[buf][row * c + jc] * dv;
+        else if (jc < 2 * c) v = (double)btile[buf][row * c + jc - c];
+        bv[nj] = v;
+      }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NT; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mi], bv[nj], acc[mi][nj], 0, 0, 0);
+    }
+    if (rsub < 4) {
+#pragma unroll 4
+      for (int i = 0; i < TR / 4; ++i) {
+        const int row = rsub + 4 * i;
+        const double v = (double)btile[buf][row * c + scol];
+        const double vv = v * v;
+        a_acc += vv;
+        s_acc = fma(vv, (double)dtile[buf][row], s_acc);
+      }
+    }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  double* pp = part + ((size_t)b * S + s) * RC * 2 * c;
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NT; ++nj) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][l][r] = acc[mi][nj][r];
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double v = (red[0][l][r] + red[1][l][r]) + (red[2][l][r] + red[3][l][r]);
+          const int i = 16 * mi + 4 * r + kk, jc = 16 * nj + a;  // D[4 r + l / 16][l % 16]
+          if (i < RC && jc < 2 * c) pp[(size_t)i * 2 * c + jc] = v;
+        }
+      }
+    }
+  if (rsub < 4) {
+    sqred[rsub][scol][0] = s_acc;
+    sqred[rsub][scol][1] = a_acc;
+  }
+  __syncthreads();
+  if (t < c) {
+    double* sp = sq + ((size_t)b * S + s) * 2 * c;
+    sp[t] = (sqred[0][t][0] + sqred[1][t][0]) + (sqred[2][t][0] + sqred[3][t][0]);
+    sp[c + t] = (sqred[0][t][1] + sqred[1][t][1]) + (sqred[2][t][1] + sqred[3][t][1]);
+  }
+}
+
+struct RsColsArgs {
+  const float* C; const float* rhs; const float* dinv; int dinv_mode;
+  const double* RS;
+  int64_t B; int N; int c; int S; int rows_per;
+  int iters; float eps, stop_after;
+  double* part; double* sq; double* coef;  // [B,S,RC,2c] | [B,S,2c] | [B,c,RC+1]
+  float* xout;
+  float* ab_rec; float* resid_rec; int* init_conv;
+  float *rhs_norm, *rz, *alpha, *beta, *resid_norm;
+  int *rhs_is_zero, *has_conv;
+};
+
+template <int RC>
+__global__ __launch_bounds__(kThreads) void k_rs_iter(RsColsArgs a) {
+  constexpr int MLD = RC + 2;
+  constexpr int NH = RC / 2;
+  __shared__ __attribute__((aligned(16))) double mat_s[4 * RC * MLD];  // E | F E | E F E | G2
+  __shared__ __attribute__((aligned(16))) double gv_s[4][32];
+  const int64_t b = blockIdx.y;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int col = 4 * blockIdx.x + wave;
+  const int c = a.c;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.RS + (size_t)b * 6 * RC * RC);
+    for (int e = t; e < 4 * RC * RC / 2; e += kThreads) {
+      const int mi = e / (RC / 2), jj = e % (RC / 2);
+      *reinterpret_cast<f32x4*>(&mat_s[mi * MLD + 2 * jj]) = src[e];
+    }
+  }
+  __syncthreads();
+  if (col >= c) return;
+  const int j = lane & 31, hf = lane >> 5;
+  const bool live = j < RC;
+  const int jr = live ? j : RC - 1;
+  // the column's reduction: partials of the row slices in fixed order
+  double w0 = 0.0, u0 = 0.0, s = 0.0, a0 = 0.0;
+  for (int sl = 0; sl < a.S; ++sl) {
+    const double* pp = a.part + (((size_t)b * a.S + sl) * RC + jr) * 2 * c;
+    w0 += pp[col];
+    u0 += pp[c + col];
+    const double* sp = a.sq + ((size_t)b * a.S + sl) * 2 * c;
+    s += sp[col];
+    a0 += sp[c + col];
+  }
+  float nrm = sqrtf((float)a0);                       // rhs.norm(2, dim=-2)          :177
+  const bool rhs_zero = nrm < a.eps;                  // :178
+  if (rhs_zero) nrm = 1.0f;                           // :179
+  const double inv = 1.0 / (double)nrm;
+  w0 = live ? w0 * inv : 0.0;
+  u0 = live ? u0 * inv : 0.0;
+  s *= inv * inv;
+  a0 *= inv * inv;
+  double* myv = gv_s[wave];
+  auto row_dot = [&](const double* mrow, const double* vec) {
+    double a0_ = 0.0, a1_ = 0.0;
+#pragma unroll
+    for (int q = 0; q < NH; q += 2) {
+      const double2 xa = *reinterpret_cast<const double2*>(mrow + q);
+      const double2 xx = *reinterpret_cast<const double2*>(vec + q);
+      a0_ = fma(xa.x, xx.x, a0_);
+      a1_ = fma(xa.y, xx.y, a1_);
+    }
+    double lo_, up_;
+    halves_d(a0_ + a1_, lo_, up_);
+    return lo_ + up_;
+  };
+  double Fw0, EFw0;
+  {  // F w0, E F w0: rows of F / E F straight from memory (once per column)
+    if (hf == 0) myv[j] = w0;
+    __builtin_amdgcn_wave_barrier();
+    const double* Frow = a.RS + ((size_t)b * 6 + 4) * RC * RC + (size_t)jr * RC + hf * NH;
+    const double* EFrow = a.RS + ((size_t)b * 6 + 5) * RC * RC + (size_t)jr * RC + hf * NH;
+    Fw0 = row_dot(Frow, myv + hf * NH);
+    EFw0 = row_dot(EFrow, myv + hf * NH);
+    if (!live) { Fw0 = 0.0; EFw0 = 0.0; }
+  }
+  double gj = 0.0, hj = 0.0, Ehj = 0.0, tj = 0.0, yj = 0.0;
+  double rho = 1.0, pi = 0.0, xi = 0.0, rz = 0.0, dpp = 0.0, tt = 0.0, hw0 = 0.0;
+  double alpha = 0.0, beta = 0.0;
+  float rn = 0.f, last_alpha = 0.f;
+  bool conv = false;
+  const size_t bc = (size_t)b * c + col;
+  const size_t nbc = (size_t)a.B * c;
+  const double* m0 = mat_s + (size_t)(0 * RC + jr) * MLD + hf * NH;
+  const double* m1 = mat_s + (size_t)(1 * RC + jr) * MLD + hf * NH;
+  const double* m2 = mat_s + (size_t)(2 * RC + jr) * MLD + hf * NH;
+  const double* m3 = mat_s + (size_t)(3 * RC + jr) * MLD + hf * NH;
+  for (int k = -1; k < a.iters; ++k) {
+    double Eg = 0.0, FEg = 0.0, EFEg = 0.0, G2g = 0.0;
+    if (k >= 0) {  // x += alpha p (:31);  r -= alpha A p (:264), A p = pi r0 + C (h + t)
+      last_alpha = (float)alpha;
+      xi = fma(alpha, pi, xi);
+      yj = fma(alpha, hj, yj);
+      rho = fma(-alpha, pi, rho);
+      gj = fma(-alpha, hj + tj, gj);
+      __builtin_amdgcn_wave_barrier();
+      if (hf == 0) myv[j] = gj;
+      __builtin_amdgcn_wave_barrier();
+      const double* xv = myv + hf * NH;
+      double e0 = 0.0, e1 = 0.0, f0 = 0.0, f1 = 0.0, h0 = 0.0, h1 = 0.0, g0 = 0.0, g1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < NH; q += 2) {
+        const double2 xx = *reinterpret_cast<const double2*>(xv + q);
+        const double2 x0 = *reinterpret_cast<const double2*>(m0 + q);
+        const double2 x1 = *reinterpret_cast<const double2*>(m1 + q);
+        const double2 x2 = *reinterpret_cast<const double2*>(m2 + q);
+        const double2 x3 = *reinterpret_cast<const double2*>(m3 + q);
+        e0 = fma(x0.x, xx.x, e0); e1 = fma(x0.y, xx.y, e1);
+        f0 = fma(x1.x, xx.x, f0); f1 = fma(x1.y, xx.y, f1);
+        h0 = fma(x2.x, xx.x, h0); h1 = fma(x2.y, xx.y, h1);
+        g0 = fma(x3.x, xx.x, g0); g1 = fma(x3.y, xx.y, g1);
+      }
+      double lo_, up_;
+      halves_d(e0 + e1, lo_, up_); Eg = lo_ + up_;
+      halves_d(f0 + f1, lo_, up_); FEg = lo_ + up_;
+      halves_d(h0 + h1, lo_, up_); EFEg = lo_ + up_;
+      halves_d(g0 + g1, lo_, up_); G2g = lo_ + up_;
+      if (!live) { Eg = 0.0; FEg = 0.0; EFEg = 0.0; G2g = 0.0; }
+    }
+    const double wj = fma(rho, w0, Eg);
+    const double vj = fma(rho, Fw0, FEg);
+    const double Evj = fma(rho, EFw0, EFEg);
+    const double tz = wj - Evj;                        // (C^T z)_j
+    const bool lo_h = hf == 0;
+    double pr[8];
+    pr[0] = lo_h ? gj * w0 : vj * Evj;
+    pr[1] = lo_h ? gj * wj : vj * tj;
+    pr[2] = lo_h ? gj * u0 : tz * tz;
+    pr[3] = lo_h ? gj * G2g : tz * tj;
+    pr[4] = lo_h ? wj * vj : vj * w0;
+    pr[5] = lo_h ? gj * Ehj : 0.0;
+    pr[6] = 0.0;
+    pr[7] = 0.0;
+    double red8;
+    {
+      double v4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v4[q] = halve_pair_d<16>(pr[q], pr[q + 4], lane);
+      halving_steps_d<4, 8, 4>(v4, lane);  // bits 8, 4 (halving), 2, 1 (sums): lane l holds component (l >> 2) & 7
+      red8 = v4[0];
+    }
+    const auto pick = [&](int ln) {
+      return mk_d((unsigned)__builtin_amdgcn_readlane((int)lo_w(red8), ln),
+                  (unsigned)__builtin_amdgcn_readlane((int)hi_w(red8), ln));
+    };
+    const double gw0 = pick(0), gw = pick(4), gu0 = pick(8), gG2g = pick(12), wv = pick(16), gEh = pick(20);
+    const double vEv = pick(32), vt = pick(36), tztz = pick(40), tzt = pick(44), vw0 = pick(48);
+    const double s2 = fma(rho, fma(rho, s, gw0), gw);            // r^T D^-1 r
+    const double s1 = fma(rho, fma(rho, a0, 2.0 * gu0), gG2g);   // r^T r
+    const double rzn = s2 - wv;                                  // residual_inner_prod :215 / :35-36
+    const float s1f = (float)s1;
+    float rnn = __builtin_amdgcn_sqrtf(s1f < 0.f ? 0.f : s1f);   // :298 / :204
+    if (k >= 0) {
+      beta = ((float)rz < a.eps) ? 0.0 : (double)((float)rzn * __builtin_amdgcn_rcpf((float)rz));  // :39-42
+      if (rhs_zero) rnn = 0.f;                                   // :299
+      rn = rnn;
+      if (lane == 0) {
+        a.resid_rec[(size_t)k * nbc + bc] = rn;
+        if (a.ab_rec) {
+          a.ab_rec[2 * ((size_t)k * nbc + bc)] = (float)alpha;
+          a.ab_rec[2 * ((size_t)k * nbc + bc) + 1] = (float)beta;
+        }
+      }
+    } else {
+      beta = 0.0;
+      rn = rnn;
+      if (lane == 0) a.init_conv[bc] = (rn < a.stop_after) ? 1 : 0;  // :204-205
+    }
+    conv = rn < a.stop_after;                                    // :300
+    rz = rzn;
+    const double dzz = fma(-2.0, wv, s2) + vEv;
+    const double rp = fma(rho, fma(pi, s, hw0), fma(pi, gw0, gEh));
+    const double dzp = rp - vt;
+    dpp = fma(beta, fma(beta, dpp, 2.0 * dzp), dzz);
+    tt = fma(beta, fma(beta, tt, 2.0 * tzt), tztz);
+    tj = fma(beta, tj, tz);
+    pi = fma(beta, pi, rho);
+    hj = fma(beta, hj, gj - vj);
+    Ehj = fma(beta, Ehj, Eg - Evj);
+    hw0 = fma(beta, hw0, gw0 - vw0);
+    const double pAp = tt + dpp;
+    alpha = ((float)pAp < a.eps) ? 0.0 : (double)((float)rz * __builtin_amdgcn_rcpf((float)pAp));  // :254-257
+    if (conv) alpha = 0.0;                                       // :260
+  }
+  double* cf = a.coef + bc * (RC + 1);
+  if (lane == 0) cf[0] = xi;
+  if (hf == 0 && live) cf[1 + j] = yj * (double)nrm;
+  if (lane == 0) {
+    a.rhs_norm[bc] = nrm;
+    a.rhs_is_zero[bc] = rhs_zero ? 1 : 0;
+    a.rz[bc] = (float)rz;
+    a.alpha[bc] = last_alpha;
+    a.beta[bc] = (float)beta;
+    a.resid_norm[bc] = rn;
+    a.has_conv[bc] = conv ? 1 : 0;
+  }
+}
+
+// x[b, row, col] = dinv[row] (xi_col b[row, col] + sum_j C[row, j] yn[col][j]); 512 rows per pass and workgroup (two per
+// thread), the right-hand sides / results of a pass travel through LDS (rows x c floats contiguous in memory)
+constexpr int RSA_ROWS = 2 * kThreads;
+template <int RC>
+__global__ __launch_bounds__(kThreads) void k_rs_apply(RsColsArgs a) {
+  __shared__ float bt[RSA_ROWS * (RSP_CMAX + 1)];
+  __shared__ __attribute__((aligned(16))) double yv[RSP_CMAX][RC + 2];  // [col][xi | yn_0 .. yn_RC-1 | pad]
+  const int s = blockIdx.x;
+  const int64_t b = blockIdx.y;
+  const int t = threadIdx.x;
+  const int c = a.c, N = a.N;
+  const int ldb = c | 1;  // odd row stride: the per-row reads below are conflict-free
+  const int r0 = s * a.rows_per, r1 = min(N, r0 + a.rows_per);
+  for (int e = t; e < c * (RC + 1); e += kThreads) {
+    const int col = e / (RC + 1), q = e % (RC + 1);
+    yv[col][q == 0 ? RC : q - 1] = a.coef[((size_t)b * c + col) * (RC + 1) + q];  // yn at [0, RC), xi at [RC]
+  }
+  const bool dfull = a.dinv_mode == LO_DIAG_FULL;
+  const float* Cb = a.C + (size_t)b * N * RC;
+  for (int base = r0; base < r1; base += RSA_ROWS) {
+    const int nr = min(RSA_ROWS, r1 - base);
+    __syncthreads();
+    for (int e = t; e < nr * c; e += kThreads) bt[(e / c) * ldb + e % c] = a.rhs[((size_t)b * N + base) * c + e];
+    double cr[2][RC];
+    double dv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = base + t + kThreads * q;
+      const bool ok = row < r1;
+      const float4* cp = reinterpret_cast<const float4*>(Cb + (size_t)min(row, N - 1) * RC);
+#pragma unroll
+      for (int i = 0; i < RC / 4; ++i) {
+        const float4 c4 = cp[i];
+        cr[q][4 * i] = (double)c4.x; cr[q][4 * i + 1] = (double)c4.y;
+        cr[q][4 * i + 2] = (double)c4.z; cr[q][4 * i + 3] = (double)c4.w;
+      }
+      dv[q] = ok ? (double)(dfull ? a.dinv[(size_t)b * N + row] : a.dinv[b]) : 0.0;
+    }
+    __syncthreads();
+    for (int col = 0; col < c; ++col) {
+      const double xi = yv[col][RC];
+      double acc0 = xi * (double)bt[t * ldb + col], acc1 = xi * (double)bt[(t + kThreads) * ldb + col];
+#pragma unroll
+      for (int i = 0; i < RC; i += 2) {
+        const double2 y2 = *reinterpret_cast<const double2*>(&yv[col][i]);
+        acc0 = fma(cr[0][i], y2.x, acc0); acc0 = fma(cr[0][i + 1], y2.y, acc0);
+        acc1 = fma(cr[1][i], y2.x, acc1); acc1 = fma(cr[1][i + 1], y2.y, acc1);
+      }
+      bt[t * ldb + col] = (float)(acc0 * dv[0]);                 // :335 (each thread rewrites its own rows)
+      bt[(t + kThreads) * ldb + col] = (float)(acc1 * dv[1]);
+    }
+    __syncthreads();
+    for (int e = t; e < nr * c; e += kThreads) a.xout[((size_t)b * N + base) * c + e] = bt[(e / c) * ldb + e % c];
+  }
+}
+
+Split rspace_cols_split(int64_t B, int64_t N) {
+  // row slices per member: at least ~1024 workgroups, slices of a multiple of 512 rows
+  int S = 1;
+  while ((int64_t)B * S < 1024 && (N + S - 1) / S > 1024) S *= 2;
+  int rows = (int)(((N + S - 1) / S + 511) / 512 * 512);
+  S = (int)((N + rows - 1) / rows);
+  return Split{S, rows};
+}
+
+size_t rspace_cols_ws_doubles(int64_t B, int64_t N, int RC, int c) {
+  const Split sp = rspace_cols_split(B, N);
+  return (size_t)B * sp.S * RC * 2 * c + (size_t)B * sp.S * 2 * c + (size_t)B * c * (RC + 1) + 64;
+}
+
+bool rspace_cols_eligible(int RC, int64_t N, int64_t c) {
+  return (RC == 8 || RC == 16 || RC == 32) && c >= 1 && c <= RSP_CMAX && N >= 256;
+}
+
+template <int RC>
+static int rspace_cols_go(const OnchipArgs& a, double* ws, hipStream_t st) {
+  const Split sp = rspace_cols_split(a.B, a.N);
+  RsColsArgs r;
+  r.C = a.C; r.rhs = a.rhs; r.dinv = a.dinv; r.dinv_mode = a.dinv_mode; r.RS = a.RS;
+  r.B = a.B; r.N = a.N; r.c = a.c; r.S = sp.S; r.rows_per = sp.rows;
+  r.iters = a.iters; r.eps = a.eps; r.stop_after = a.stop_after;
+  r.part = ws;
+  r.sq = r.part + (size_t)a.B * sp.S * RC * 2 * a.c;
+  r.coef = r.sq + (size_t)a.B * sp.S * 2 * a.c;
+  r.xout = a.xout; r.ab_rec = a.ab_rec; r.resid_rec = a.resid_rec; r.init_conv = a.init_conv;
+  r.rhs_norm = a.rhs_norm; r.rz = a.rz; r.alpha = a.alpha; r.beta = a.beta; r.resid_norm = a.resid_norm;
+  r.rhs_is_zero = a.rhs_is_zero; r.has_conv = a.has_conv;
+  dim3 block(kThreads);
+  const int nt = (2 * a.c + 15) / 16;
+  LO_PROF_BEGIN("rs_part", st);
+  dim3 gp(sp.S, (unsigned)a.B);
+  if (nt == 1) hipLaunchKernelGGL((k_rs_part<RC, 1>), gp, block, 0, st, r.C, r.rhs, r.dinv, r.dinv_mode, r.N, r.c, r.rows_per, r.part, r.sq);
+  else if (nt == 2) hipLaunchKernelGGL((k_rs_part<RC, 2>), gp, block, 0, st, r.C, r.rhs, r.dinv, r.dinv_mode, r.N, r.c, r.rows_per, r.part, r.sq);
+  else if (nt == 3) hipLaunchKernelGGL((k_rs_part<RC, 3>), gp, block, 0, st, r.C, r.rhs, r.dinv, r.dinv_mode, r.N, r.c, r.rows_per, r.part, r.sq);
+  else hipLaunchKernelGGL((k_rs_part<RC, 4>), gp, block, 0, st, r.C, r.rhs, r.dinv, r.dinv_mode, r.N, r.c, r.rows_per, r.part, r.sq);
+  LO_PROF_END(st);
+  LO_PROF_BEGIN("rs_iter", st);
+  hipLaunchKernelGGL((k_rs_iter<RC>), dim3((unsigned)((a.c + 3) / 4), (unsigned)a.B), block, 0, st, r);
+  LO_PROF_END(st);
+  LO_PROF_BEGIN("rs_apply", st);
+  hipLaunchKernelGGL((k_rs_apply<RC>), gp, block, 0, st, r);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+// All c columns of a result-only solve (a.x == nullptr) with the R-space form at hand; ws: rspace_cols_ws_doubles.
+int rspace_cols_launch(int RC, const OnchipArgs& a, double* ws, hipStream_t st) {
+  if (!a.RS || a.x || !a.xout || !ws || !rspace_cols_eligible(RC, a.N, a.c)) return LO_ERR_UNSUPPORTED;
+  if (RC == 32) return rspace_cols_go<32>(a, ws, st);
+  if (RC == 16) return rspace_cols_go<16>(a, ws, st);
+  return rspace_cols_go<8>(a, ws, st);
+}
+
 // (worst case over the group sizes: groups of one)
 size_t rspace_gbuf_bytes(int nworkgroups) { return (size_t)nworkgroups * rs_group_granules(1) * sizeof(unsigned long long); }
 
 bool rspace_eligible(int RC, int64_t N, int64_t c) {
   return (RC == 8 || RC == 16 || RC == 32) && c == 1 && N >= 256 && N <= (int64_t)64 * R4_ROWS;
 }
+
+thread_local bool tls_rspace_resident_ran = false;
 
 template <int RC, int GW>
 static int rspace_go(const OnchipArgs& a, int nwg, hipStream_t st) {
@@ -703,6 +1170,7 @@ static int rspace_go(const OnchipArgs& a, int nwg, hipStream_t st) {
   hipLaunchKernelGGL((k_cg_rspace<RC, GW>), dim3(2 * nwg), dim3(R4_TPB), 0, st, a);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
+  tls_rspace_resident_ran = true;
   return LO_OK;
 }
 

@@ -25,12 +25,14 @@ def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, U, 
                                  the preconditioner arguments of the Function and receives `precond_arg_grads`)
     Applies to the Woodbury closure of an AddedDiagLinearOperator; the pull-back through the pivoted Cholesky works
     for any operator (pivoted_cholesky_vjp reaches the pivot columns through the differentiable Matmul)."""
-    from ..operators.added_diag_linear_operator import AddedDiagLinearOperator, WoodburyPreconditionClosure
+    from ..operators.added_diag_linear_operator import (AddedDiagLinearOperator, DensePreconditionClosure,
+                                                        WoodburyPreconditionClosure)
     from ..operators.diag_linear_operator import ConstantDiagLinearOperator
     from ._pivoted_cholesky import pivoted_cholesky_vjp
 
     pre = ctx.preconditioner
-    if not isinstance(pre, WoodburyPreconditionClosure) or not isinstance(linear_op, AddedDiagLinearOperator):
+    dense = isinstance(pre, DensePreconditionClosure)  # (float64, or float32 of rank > 128: Q and the noise as tensors)
+    if not (isinstance(pre, WoodburyPreconditionClosure) or dense) or not isinstance(linear_op, AddedDiagLinearOperator):
         return matrix_arg_grads
     L, perm = getattr(pre, "piv_chol", None), getattr(pre, "piv_perm", None)
     if not any(t.requires_grad for t in matrix_args):
@@ -46,8 +48,12 @@ def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, U, 
     diag_leaf = matrix_args[diag_idx]
     if diag_leaf.requires_grad:
         const = isinstance(linear_op._diag_tensor, ConstantDiagLinearOperator)
-        q = wb.Q[..., : wb.k]
-        dinv = wb.dinv.unsqueeze(-1) if wb.constant_diag else wb.dinv
+        if dense:
+            q = pre.q
+            dinv = (1.0 / pre.noise).squeeze(-1)  # [*batch, N | 1]
+        else:
+            q = wb.Q[..., : wb.k]
+            dinv = wb.dinv.unsqueeze(-1) if wb.constant_diag else wb.dinv
         # diag(P^-1) = 1/d - rowsum(Q^2): the row sums as ONE reduction pass (norm, squared) instead of a product
         # tensor and its sum (250 -> 60 us at 512 x 8192 x 16)
         pinv_diag = (dinv - torch.linalg.vector_norm(q, dim=-1).square()).reshape(*linear_op.batch_shape, -1)
@@ -60,7 +66,10 @@ def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, U, 
     #      needs the Woodbury cache, so it is added even when they are not available)
     if L is not None and perm is not None and any(t.requires_grad for t in matrix_args[op_slice]):
         Lc = L.contiguous()
-        GL = torch.addcmul(K.bilinear_root(Lc, U, V), pre(Lc), 2.0 * g)  # one pass: 2 g P^-1 L + U (V^T L) + V (U^T L)
+        if dense:  # (library GEMMs: the float32 kernel of bilinear_root does not take these tensors)
+            GL = U @ (V.mT @ Lc) + V @ (U.mT @ Lc) + 2.0 * g * pre(Lc)
+        else:
+            GL = torch.addcmul(K.bilinear_root(Lc, U, V), pre(Lc), 2.0 * g)  # one pass: 2 g P^-1 L + U (V^T L) + V (U^T L)
         extra = pivoted_cholesky_vjp(linear_op._linear_op, perm, GL, factor=Lc)
         if extra is not None:
             idxs = range(*op_slice.indices(len(matrix_arg_grads)))

@@ -439,7 +439,8 @@ def _plan_dict(pl) -> dict:
                 lockstep_group=pl.lockstep_group, serial_engine=_hip.ENGINE_NAMES[pl.serial_engine],
                 serial_group=pl.serial_group, lean=bool(pl.lean), needs_q=bool(pl.needs_q),
                 streaming_precond=_hip.STREAM_PRE_NAMES[pl.streaming_precond], poll_chunk=pl.poll_chunk,
-                first_stop_iteration=pl.first_stop_iteration, streaming_iterations=pl.reserved)
+                first_stop_iteration=pl.first_stop_iteration, streaming_iterations=pl.reserved,
+                rspace={0: "none", 1: "cols", 2: "resident"}[pl.rspace])
 
 
 def cg_plan(desc: OperatorDescriptor, c: int, *, precond: Optional[WoodburyPreconditioner] = None, has_x0: bool = False,

@@ -352,19 +352,26 @@ class AddedDiagLinearOperator(SumLinearOperator):
             # kernels; the thin QR of _init_cache* is the LAPACK call the reference itself makes (:161-184), on the
             # device, and the apply is two library GEMMs -- not a performance path (no Woodbury descriptor: linear_cg in
             # float64 takes the closure)
+            # Built OUTSIDE autograd from the detached noise, like the float32 cache the kernels build: the derivatives of
+            # logdet P and of the probes' term are chained by hand (functions/_inv_quad_logdet._add_preconditioner_terms).
+            # A graph-carrying logdet in the memo below would be shared by later calls on the same tensors -- missing when
+            # a solve filled the memo under no_grad, freed after the first backward otherwise.
             self._woodbury = None
             k = L.shape[-1]
-            eye = torch.eye(k, dtype=L.dtype, device=L.device).expand(*batch_shape, k, k)
-            if self._constant_diag:
-                sig = first.unsqueeze(-1)  # [*batch, 1, 1]
-                Q, Rm = torch.linalg.qr(torch.cat((L, sig.sqrt() * eye), dim=-2))
-                self._q_cache = Q[..., :n, :]
-                logdet = Rm.diagonal(dim1=-1, dim2=-2).abs().log().sum(-1).mul(2) + (n - k) * sig[..., 0, 0].log()
-            else:
-                sq = noise.unsqueeze(-1).sqrt()
-                Q, Rm = torch.linalg.qr(torch.cat((L / sq, eye), dim=-2))
-                self._q_cache = Q[..., :n, :] / sq
-                logdet = Rm.diagonal(dim1=-1, dim2=-2).abs().log().sum(-1).mul(2) + noise.log().sum(-1)
+            with torch.no_grad():
+                L, noise, first = L.detach(), noise.detach(), first.detach()
+                self._noise = first if self._constant_diag else noise
+                eye = torch.eye(k, dtype=L.dtype, device=L.device).expand(*batch_shape, k, k)
+                if self._constant_diag:
+                    sig = first.unsqueeze(-1)  # [*batch, 1, 1]
+                    Q, Rm = torch.linalg.qr(torch.cat((L, sig.sqrt() * eye), dim=-2))
+                    self._q_cache = Q[..., :n, :]
+                    logdet = Rm.diagonal(dim1=-1, dim2=-2).abs().log().sum(-1).mul(2) + (n - k) * sig[..., 0, 0].log()
+                else:
+                    sq = noise.unsqueeze(-1).sqrt()
+                    Q, Rm = torch.linalg.qr(torch.cat((L / sq, eye), dim=-2))
+                    self._q_cache = Q[..., :n, :] / sq
+                    logdet = Rm.diagonal(dim1=-1, dim2=-2).abs().log().sum(-1).mul(2) + noise.log().sum(-1)
             self._precond_logdet_cache = logdet.view(*batch_shape) if len(batch_shape) else logdet.squeeze()
             self._precond_lt = PsdSumLinearOperator(RootLinearOperator(L), self._diag_tensor)  # :159
             return

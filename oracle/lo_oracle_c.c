@@ -639,3 +639,253 @@ done:
   free(r); free(z); free(p); free(Ap); free(sc); free(flags);
   return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * lanczos_tridiag (utils/lanczos.py:9-164): Lanczos with full re-orthogonalisation, P probe columns per member.
+ *   init_vecs [B, N, P] (the reference's randn default is not reproducible: the caller supplies them, :59-66)
+ *   q_mat [max_iter, B, N, P], t_mat [max_iter, max_iter, B, P]: the reference's WORKING layouts (:69-77); the host
+ *   wrapper crops to num_iter (:151) and permutes as :154-157.  Every batch-global decision (:133-147: the
+ *   re-orthogonalisation loop runs while ANY inner product of ANY member exceeds tol, the iteration ends when NO
+ *   beta of any member exceeds 1e-6) is taken from all members together, as the reference's torch.sum(...) does.
+ * ------------------------------------------------------------------------------------------------------------------ */
+static void lz_col_dots(const float* a, const float* bb, float* out, int64_t B, int64_t N, int64_t P) {
+  col_dots(a, bb, out, B, N, P);
+}
+
+int lo_cpu_lanczos_tridiag_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user, const float* init_vecs,
+                               int64_t P, int32_t max_iter, float tol, float* q_mat, float* t_mat, int32_t* num_iter_out) {
+  if (!op || !init_vecs || !q_mat || !t_mat || !num_iter_out || P < 1 || max_iter < 1) return LO_ERR_BADARG;
+  if (op->kind == LO_OP_CALLBACK ? !matvec : !op_ok(op)) return LO_ERR_BADARG;
+  const int64_t B = op->B, N = op->N;
+  const int num_iter = (int)(max_iter < N ? max_iter : N); /* :57 */
+  const size_t nv = (size_t)B * N * P, ns = (size_t)B * P;
+  cg_ctx cx = {op, matvec, matvec_user, NULL, NULL, NULL, B, N, P, 0};
+  float* r = (float*)malloc(sizeof(float) * nv);
+  float* dots = (float*)malloc(sizeof(float) * ns * (size_t)(num_iter + 1));
+  float* sc = (float*)malloc(sizeof(float) * ns * 2);
+  if (!r || !dots || !sc) {
+    free(r); free(dots); free(sc);
+    return LO_ERR_WORKSPACE;
+  }
+  float *alpha = sc, *beta = sc + ns;
+  memset(q_mat, 0, sizeof(float) * (size_t)num_iter * nv);
+  memset(t_mat, 0, sizeof(float) * (size_t)num_iter * num_iter * ns);
+#define QK(k) (q_mat + (size_t)(k) * nv)
+#define TM(i, j) (t_mat + ((size_t)(i) * num_iter + (j)) * ns)
+  int rc = LO_OK;
+  /* q_0 = init / ||init|| :81 */
+  lz_col_dots(init_vecs, init_vecs, dots, B, N, P);
+#pragma omp parallel for schedule(static) num_threads(nthr(B))
+  for (int64_t b = 0; b < B; ++b)
+    for (int64_t i = 0; i < N; ++i)
+      for (int64_t j = 0; j < P; ++j) {
+        const size_t e = ((size_t)b * N + i) * P + j;
+        QK(0)[e] = init_vecs[e] / sqrtf(dots[b * P + j]);
+      }
+  rc = cg_matvec(&cx, QK(0), r); /* :85 */
+  if (rc) goto done;
+  lz_col_dots(QK(0), r, alpha, B, N, P); /* :88 */
+#pragma omp parallel for schedule(static) num_threads(nthr(B))
+  for (int64_t b = 0; b < B; ++b)
+    for (int64_t i = 0; i < N; ++i)
+      for (int64_t j = 0; j < P; ++j) {
+        const size_t e = ((size_t)b * N + i) * P + j;
+        r[e] = r[e] - alpha[b * P + j] * QK(0)[e]; /* :89 */
+      }
+  lz_col_dots(r, r, beta, B, N, P);
+  for (size_t i = 0; i < ns; ++i) {
+    beta[i] = sqrtf(beta[i]); /* :90 */
+    TM(0, 0)[i] = alpha[i];   /* :93 */
+    if (num_iter > 1) {
+      TM(0, 1)[i] = beta[i];
+      TM(1, 0)[i] = beta[i]; /* :94-95 */
+    }
+  }
+  if (num_iter > 1) {
+#pragma omp parallel for schedule(static) num_threads(nthr(B))
+    for (int64_t b = 0; b < B; ++b)
+      for (int64_t i = 0; i < N; ++i)
+        for (int64_t j = 0; j < P; ++j) {
+          const size_t e = ((size_t)b * N + i) * P + j;
+          QK(1)[e] = r[e] / beta[b * P + j]; /* :98 */
+        }
+  }
+  int k = 0;
+  for (k = 1; k < num_iter; ++k) { /* :101 */
+    const float* q_prev = QK(k - 1);
+    const float* q_curr = QK(k);
+    const float* beta_prev = TM(k, k - 1);
+    rc = cg_matvec(&cx, q_curr, r);
+    if (rc) goto done;
+#pragma omp parallel for schedule(static) num_threads(nthr(B))
+    for (int64_t b = 0; b < B; ++b)
+      for (int64_t i = 0; i < N; ++i)
+        for (int64_t j = 0; j < P; ++j) {
+          const size_t e = ((size_t)b * N + i) * P + j;
+          r[e] = r[e] - q_prev[e] * beta_prev[b * P + j]; /* :108 */
+        }
+    lz_col_dots(q_curr, r, alpha, B, N, P); /* :109 */
+    for (size_t i = 0; i < ns; ++i) TM(k, k)[i] = alpha[i]; /* :111 */
+    if (k + 1 < num_iter) { /* :114 */
+#pragma omp parallel for schedule(static) num_threads(nthr(B))
+      for (int64_t b = 0; b < B; ++b)
+        for (int64_t i = 0; i < N; ++i)
+          for (int64_t j = 0; j < P; ++j) {
+            const size_t e = ((size_t)b * N + i) * P + j;
+            r[e] = r[e] - alpha[b * P + j] * q_curr[e]; /* :115 */
+          }
+      int could = 0;
+      for (int pass = 0; pass <= 10; ++pass) { /* pass 0 = :117-124, passes 1..10 = the loop :133-142 */
+        /* correction = sum_m Q_m (Q_m^T r) over the k + 1 vectors so far (:118-119), subtracted (:120) */
+        for (int m = 0; m <= k; ++m) lz_col_dots(r, QK(m), dots + (size_t)m * ns, B, N, P);
+#pragma omp parallel for schedule(static) num_threads(nthr(B))
+        for (int64_t b = 0; b < B; ++b)
+          for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < P; ++j) {
+              const size_t e = ((size_t)b * N + i) * P + j;
+              float corr = 0.f;
+              for (int m = 0; m <= k; ++m) corr += QK(m)[e] * dots[(size_t)m * ns + b * P + j];
+              r[e] = r[e] - corr;
+            }
+        lz_col_dots(r, r, beta, B, N, P);
+#pragma omp parallel for schedule(static) num_threads(nthr(B))
+        for (int64_t b = 0; b < B; ++b)
+          for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < P; ++j) {
+              const size_t e = ((size_t)b * N + i) * P + j;
+              r[e] = r[e] / sqrtf(beta[b * P + j]); /* :121-122 / :138-139 */
+            }
+        if (pass == 0) { /* :125-128: beta of THIS step is the norm before any extra pass */
+          for (size_t i = 0; i < ns; ++i) {
+            const float bv = sqrtf(beta[i]);
+            TM(k, k + 1)[i] = bv;
+            TM(k + 1, k)[i] = bv;
+            sc[ns + i] = bv; /* (kept for the test below) */
+          }
+        }
+        if (pass == 10) break; /* the tenth extra pass is not checked again (:133-142): could_reorthogonalize stays False */
+        /* inner products with all previous vectors (:131 / :140): signed compare against tol */
+        int over = 0;
+        for (int m = 0; m <= k; ++m) {
+          lz_col_dots(QK(m), r, dots + (size_t)m * ns, B, N, P);
+          for (size_t i = 0; i < ns; ++i) over += dots[(size_t)m * ns + i] > tol;
+        }
+        if (!over) { /* :134-136 */
+          could = 1;
+          break;
+        }
+      }
+      memcpy(QK(k + 1), r, sizeof(float) * nv); /* :145 */
+      int big = 0;
+      for (size_t i = 0; i < ns; ++i) big += fabsf(sc[ns + i]) > 1e-6f;
+      if (big == 0 || !could) break; /* :147 */
+    }
+  }
+  *num_iter_out = (k < num_iter ? k : num_iter - 1) + 1; /* :151 */
+done:
+#undef QK
+#undef TM
+  free(r); free(dots); free(sc);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * lanczos_tridiag_to_diag (utils/lanczos.py:167-189) + StochasticLQ.to_dense with funcs = [log]
+ * (utils/stochastic_lq.py:45-82): eigendecomposition of every k x k tridiagonal, negative eigenvalues clamped (their
+ * eigenvector columns zeroed, the eigenvalue set to 1: :186-187), logdet[b] = (n / P) sum_p sum_i V_p[0, i]^2 log(lambda_p,i).
+ * The reference calls LAPACK's symmetric eigensolver in the input precision; this restatement runs the implicit QL
+ * iteration with Wilkinson shifts (EISPACK tql2) in DOUBLE on the fp32 entries -- the eigenvalues of the same matrix
+ * without the fp32 solver's own rounding.  Only the FIRST ROW of the eigenvector matrix is needed and accumulated.
+ *   t_mat [P, B, ld, ld] (k x k leading blocks used), evals_out [P, B, k] or NULL, first_out [P, B, k] or NULL.
+ * ------------------------------------------------------------------------------------------------------------------ */
+static int tridiag_ql(int n, double* d, double* e, double* z0) {
+  /* d[0..n): diagonal, e[0..n): e[i] = T[i][i-1] (e[0] unused); z0: first row of the accumulated rotations (starts e_1) */
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.0;
+  double f = 0.0, tst1 = 0.0;
+  const double eps = 2.220446049250313e-16;
+  for (int l = 0; l < n; ++l) {
+    const double t = fabs(d[l]) + fabs(e[l]);
+    if (t > tst1) tst1 = t;
+    int m = l;
+    while (m < n) {
+      if (fabs(e[m]) <= eps * tst1) break;
+      ++m;
+    }
+    if (m > l) {
+      int iter = 0;
+      do {
+        if (++iter > 60) return 1;
+        double g = d[l];
+        double p = (d[l + 1] - g) / (2.0 * e[l]);
+        double r = hypot(p, 1.0);
+        if (p < 0) r = -r;
+        d[l] = e[l] / (p + r);
+        d[l + 1] = e[l] * (p + r);
+        const double dl1 = d[l + 1];
+        double h = g - d[l];
+        for (int i = l + 2; i < n; ++i) d[i] -= h;
+        f += h;
+        p = d[m];
+        double c = 1.0, c2 = c, c3 = c, s = 0.0, s2 = 0.0;
+        const double el1 = e[l + 1];
+        for (int i = m - 1; i >= l; --i) {
+          c3 = c2;
+          c2 = c;
+          s2 = s;
+          g = c * e[i];
+          h = c * p;
+          r = hypot(p, e[i]);
+          e[i + 1] = s * r;
+          s = e[i] / r;
+          c = p / r;
+          p = c * d[i] - s * g;
+          d[i + 1] = h + s * (c * g + s * d[i]);
+          h = z0[i + 1];
+          z0[i + 1] = s * z0[i] + c * h;
+          z0[i] = c * z0[i] - s * h;
+        }
+        p = -s * s2 * c3 * el1 * e[l] / dl1;
+        e[l] = s * p;
+        d[l] = c * p;
+      } while (fabs(e[l]) > eps * tst1);
+    }
+    d[l] = d[l] + f;
+    e[l] = 0.0;
+  }
+  return 0;
+}
+
+int lo_cpu_tridiag_eigh_slq_f32(const float* t_mat, int64_t P, int64_t B, int32_t k, int32_t ld, int64_t n, float* logdet,
+                                double* evals_out, double* first_out) {
+  if (!t_mat || !logdet || P < 1 || B < 1 || k < 1 || k > ld || k > 512) return LO_ERR_BADARG;
+  int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(nthr(B)) reduction(+ : bad)
+  for (int64_t b = 0; b < B; ++b) {
+    double d[512], e[512], z0[512];
+    double acc = 0.0;
+    for (int64_t p = 0; p < P; ++p) {
+      const float* T = t_mat + ((size_t)p * B + b) * ld * ld;
+      for (int i = 0; i < k; ++i) {
+        d[i] = (double)T[(size_t)i * ld + i];
+        e[i] = i ? (double)T[(size_t)i * ld + i - 1] : 0.0;
+        z0[i] = i ? 0.0 : 1.0;
+      }
+      bad += tridiag_ql(k, d, e, z0);
+      double dots = 0.0;
+      for (int i = 0; i < k; ++i) {
+        double ev = d[i], v0 = z0[i];
+        if (!(ev >= 0.0)) { /* mask = evals.ge(0): zero the eigenvector COLUMN, eigenvalue := 1 (:185-187) */
+          v0 = 0.0;
+          ev = 1.0;
+        }
+        if (evals_out) evals_out[((size_t)p * B + b) * k + i] = ev;
+        if (first_out) first_out[((size_t)p * B + b) * k + i] = v0;
+        dots += v0 * v0 * log(ev); /* stochastic_lq.py:72-78 */
+      }
+      acc += ((double)n / (double)P) * dots; /* :80 */
+    }
+    logdet[b] = (float)acc;
+  }
+  return bad ? LO_ERR_LAUNCH : LO_OK;
+}

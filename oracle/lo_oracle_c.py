@@ -108,6 +108,12 @@ def load():
         lib.lo_cpu_cg_solve_f32.restype = C.c_int
         lib.lo_cpu_cg_solve_f32.argtypes = [P(OpDesc), MATVEC_CB, C.c_void_p, P(PrecondDesc), MATVEC_CB, C.c_void_p,
                                             P(CgParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(CgInfo)]
+        lib.lo_cpu_lanczos_tridiag_f32.restype = C.c_int
+        lib.lo_cpu_lanczos_tridiag_f32.argtypes = [P(OpDesc), MATVEC_CB, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
+                                                   C.c_void_p, C.c_void_p, P(C.c_int32)]
+        lib.lo_cpu_tridiag_eigh_slq_f32.restype = C.c_int
+        lib.lo_cpu_tridiag_eigh_slq_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -230,3 +236,53 @@ def linear_cg(op: Operator, rhs, pre: Preconditioner = None, x0=None, n_tridiag=
 
 def num_threads() -> int:
     return int(load().lo_cpu_num_threads())
+
+
+def lanczos_tridiag(op: Operator, init_vecs, max_iter, tol=1e-5):
+    """(q_mat [P, B, N, k'], t_mat [P, B, k', k']) as the reference returns them (utils/lanczos.py:151-161; the leading
+    dimension is squeezed iff P == 1)."""
+    V = _f32(init_vecs)
+    B, N, Pn = V.shape
+    max_iter = int(max_iter)
+    num = min(max_iter, N)
+    q = np.empty((num, B, N, Pn), dtype=np.float32)
+    t = np.empty((num, num, B, Pn), dtype=np.float32)
+    m = C.c_int32(0)
+    _check(load().lo_cpu_lanczos_tridiag_f32(C.byref(op.s), MATVEC_CB(), None, _ptr(V), Pn, max_iter, float(tol), _ptr(q),
+                                             _ptr(t), C.byref(m)), "lo_cpu_lanczos_tridiag_f32")
+    k = m.value
+    q_out = np.ascontiguousarray(np.transpose(q[:k], (3, 1, 2, 0)))
+    t_out = np.ascontiguousarray(np.transpose(t[:k, :k], (3, 2, 0, 1)))
+    if Pn == 1:
+        q_out, t_out = q_out[0], t_out[0]
+    return q_out, t_out
+
+
+def tridiag_eigh_slq(t_mat, n, want_spectrum=False):
+    """logdet [B] = (n / P) sum_p e1^T log(T_p) e1 over the tridiagonals t_mat [P, B, k, k] (lanczos_tridiag_to_diag +
+    StochasticLQ.to_dense, utils/lanczos.py:167-189, stochastic_lq.py:45-82); eigenvalues by implicit QL in double.
+    want_spectrum: also (clamped eigenvalues [P, B, k], first eigenvector components [P, B, k])."""
+    t = _f32(t_mat)
+    Pn, B, k, ld = t.shape
+    out = np.empty(B, dtype=np.float32)
+    ev = np.empty((Pn, B, k), dtype=np.float64) if want_spectrum else None
+    v0 = np.empty((Pn, B, k), dtype=np.float64) if want_spectrum else None
+    _check(load().lo_cpu_tridiag_eigh_slq_f32(_ptr(t), Pn, B, k, ld, int(n), _ptr(out), _ptr(ev), _ptr(v0)),
+           "lo_cpu_tridiag_eigh_slq_f32")
+    return (out, ev, v0) if want_spectrum else out
+
+
+def inv_quad_logdet(op: Operator, row_op: Operator, d, inv_quad_rhs, probes, tolerance=1.0, max_iter=1000,
+                    max_tridiag_iter=20, rank=15, precond_tol=1e-3, const_diag=False):
+    """InvQuadLogdet.forward with injected (normalised) probes (functions/_inv_quad_logdet.py:112-153), all in C:
+    pivoted Cholesky of `row_op` (the operator without its diagonal) -> preconditioner -> linear_cg with the probe
+    tridiagonals -> eigh + SLQ.  Returns (inv_quad [B, c_rhs], logdet [B], solves, t_mat, CgInfo, pivots)."""
+    L, piv = pivoted_cholesky(row_op, rank, precond_tol)
+    pre = Preconditioner(L, d, const_diag)
+    Pn = probes.shape[-1]
+    rhs = np.concatenate([_f32(probes), _f32(inv_quad_rhs)], axis=-1)
+    x, t_mat, info = linear_cg(op, rhs, pre=pre, n_tridiag=Pn, tolerance=tolerance, max_iter=max_iter,
+                               max_tridiag_iter=max_tridiag_iter)
+    logdet = tridiag_eigh_slq(t_mat, probes.shape[-2]) + pre.logdet
+    inv_quad = np.sum(x[..., Pn:] * _f32(inv_quad_rhs), axis=-2)
+    return inv_quad, logdet, x, t_mat, info, piv

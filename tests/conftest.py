@@ -56,3 +56,13 @@ def tridiag_block_err(t, t64, valid, back_off=0):
             blk = t64[i, b, :k, :k]
             worst = max(worst, float((np.abs(t[i, b, :k, :k] - blk) / (np.abs(blk) + 1e-2 * np.abs(blk).max())).max()))
     return worst, smallest
+
+
+@pytest.fixture
+def legacy_resident_engines(monkeypatch):
+    """Tests of the operator-resident kernels that iterate on the ROWS (lockstep, serial root / Q form, w recurrence):
+    since round 5 the result-only first pass of an operator with the R-space form (lo_precond_desc.RS) runs on R + 1
+    coordinates instead (csrc/lo_rspace.hip); these kernels remain the repeat with the state, the engines under the
+    batch-global stop rule and the path of roots without the fp64 Gram matrices.  This switches the R-space forms off."""
+    monkeypatch.setenv("LO_NO_RSPACE_COLS", "1")
+    monkeypatch.setenv("LO_OC_NO_RSPACE", "1")

@@ -284,3 +284,41 @@ def test_float64_preconditioned_path_against_the_reference_golden():
     dense = (Cg.detach() @ Cg.detach().mT + torch.diag_embed(dg.detach())).requires_grad_(True)
     torch.linalg.solve(dense, dev(rhs)).sum().backward()
     assert torch.allclose(dg.grad, dense.grad.diagonal(dim1=-1, dim2=-2), rtol=1e-6, atol=1e-9)
+
+
+def test_float64_preconditioned_logdet_gradients_after_a_solve_on_the_same_tensors():
+    """the dense (QR) preconditioner cache of float64 operators is built outside autograd and memoised under
+    the operator's tensors; the derivative of logdet P and of the probes' term is chained by hand
+    (functions/_inv_quad_logdet._add_preconditioner_terms).  With max_preconditioner_size = rank of the root the
+    preconditioner IS the operator (P = A): logdet = logdet P and its gradient consists of the hand-chained terms only, no
+    probe noise.  A solve fills the memo under no_grad FIRST; the gradients of inv_quad + logdet taken afterwards on the
+    same tensors -- twice, the second time reusing the memo -- match dense autograd."""
+    import cases
+    import linear_operator_amd as lo
+    from linear_operator_amd.operators import AddedDiagLinearOperator, DiagLinearOperator, LowRankRootLinearOperator
+    from linear_operator_amd.operators.added_diag_linear_operator import clear_preconditioner_memo
+
+    clear_preconditioner_memo()
+    C, d, rhs = cases.lowrank_diag(2601, 2, 2048, 16, 1, dtype=np.float64)
+    Cg, dg = dev(C).requires_grad_(True), dev(d).requires_grad_(True)
+    y = dev(rhs)
+    dense = (Cg.detach() @ Cg.detach().mT + torch.diag_embed(dg.detach())).requires_grad_(True)
+    (torch.linalg.solve(dense, y).mul(y).sum() + torch.logdet(dense).sum()).backward()
+    want_d = dense.grad.diagonal(dim1=-1, dim2=-2)
+    want_C = (dense.grad + dense.grad.mT) @ Cg.detach()
+    with lo.settings.cg_tolerance(1e-10), lo.settings.num_trace_samples(8), lo.settings.max_cg_iterations(200), \
+            lo.settings.max_preconditioner_size(16), lo.settings.preconditioner_tolerance(1e-12):
+        A0 = AddedDiagLinearOperator(LowRankRootLinearOperator(Cg), DiagLinearOperator(dg))
+        with torch.no_grad():
+            A0.solve(y)  # fills the preconditioner memo outside autograd
+        for rep in range(2):
+            torch.manual_seed(11 + rep)
+            Cg.grad = dg.grad = None
+            A = AddedDiagLinearOperator(LowRankRootLinearOperator(Cg), DiagLinearOperator(dg))
+            iq, ld = A.inv_quad_logdet(y, logdet=True)
+            assert torch.allclose(ld, torch.logdet(dense.detach()), rtol=1e-8)
+            (iq.sum() + ld.sum()).backward()  # (a graph kept in the memo would raise on the second pass)
+            err_d = float((dg.grad - want_d).norm() / want_d.norm())
+            err_C = float((Cg.grad - want_C).norm() / want_C.norm())
+            assert err_d < 1e-6 and err_C < 1e-6, (rep, err_d, err_C)
+    clear_preconditioner_memo()

@@ -525,6 +525,7 @@ def _assert_tridiag_close(t_a, t_b, N, lead=2, same_size=True):
     assert np.abs(host(ld_a) - host(ld_b)).max() / N < 1e-4
 
 
+@pytest.mark.usefixtures("legacy_resident_engines")
 @pytest.mark.parametrize("N,R,c,nt", [(4096, 32, 5, 0), (8192, 32, 7, 6), (2048, 16, 3, 3), (5000, 8, 17, 16)])
 def test_onchip_cg_many_columns_and_tridiagonals(N, R, c, nt):
     """Several right-hand-side columns (the inv_quad_logdet call: probes + rhs) run one after the other against the
@@ -574,6 +575,7 @@ def test_onchip_cg_many_columns_and_tridiagonals(N, R, c, nt):
     assert torch.equal(res.x, res2.x) and (not nt or torch.equal(res.t_mat, res2.t_mat))
 
 
+@pytest.mark.usefixtures("legacy_resident_engines")
 @pytest.mark.parametrize("N,R,c,nt,mode", [
     (8192, 32, 16, 16, "full"),     # BASELINE cfg3 probes: one chunk of 16
     (8192, 32, 17, 16, "full"),     # cfg3 as written: 16 columns in lockstep + the 17th on the serial kernel
@@ -650,6 +652,7 @@ def test_lockstep_cg_matches_serial_resident_streaming_and_oracle(N, R, c, nt, m
     assert torch.equal(res.x, res2.x) and (not nt or torch.equal(res.t_mat, res2.t_mat))
 
 
+@pytest.mark.usefixtures("legacy_resident_engines")
 def test_lockstep_two_workgroups_per_cu_variant_matches_default(monkeypatch):
     """LO_LS_V2: 512-row workgroups, two per CU, groups of 16 with the reduce-scatter all-reduce -- same results as the
     default variant (different summation order across workgroups: compared to rounding noise) and reproducible."""
@@ -672,6 +675,7 @@ def test_lockstep_two_workgroups_per_cu_variant_matches_default(monkeypatch):
     assert torch.equal(res.x, res2.x) and torch.equal(res.t_mat, res2.t_mat)
 
 
+@pytest.mark.usefixtures("legacy_resident_engines")
 @pytest.mark.parametrize("N,R,c,nt,const", [(8192, 32, 1, 0, False), (4096, 16, 3, 2, False), (5000, 20, 2, 0, True),
                                             (20000, 32, 1, 0, False), (2048, 8, 1, 1, True)])
 def test_root_form_preconditioner_and_serial_kernel(N, R, c, nt, const, monkeypatch):
@@ -886,6 +890,7 @@ def test_onchip_cg_hands_over_to_streaming_loop_beyond_the_floor():
     assert max_rel_err_cols(host(res.x), xo) < 5e-2
 
 
+@pytest.mark.usefixtures("legacy_resident_engines")
 def test_onchip_timeout_falls_back_to_streaming_engines(monkeypatch):
     """A timed-out group hand-off (error word set) makes the host redo the work with the streaming engines: same
     pivots / L bit for bit, same iteration count, solutions equal to summation-order noise."""
@@ -1029,6 +1034,7 @@ def test_wide_preconditioner_rank_above_32(k):
         assert res.iterations <= res0.iterations
 
 
+@pytest.mark.usefixtures("legacy_resident_engines")
 @pytest.mark.parametrize("c,nt", [(1, 0), (17, 16), (3, 0)])
 def test_result_only_first_pass_and_its_repeat_with_state(c, nt, monkeypatch):
     """The resident CG kernels first run result-only (no x / r / p / z of a possible continuation).  (i) At the floor

@@ -241,8 +241,16 @@ def test_the_plan_is_what_the_solver_executes(kind, N, R, c, nt, form):
     ran = K.cg_last_executed()
     assert res.tolerance_reached
     assert not plan["needs_q"]
-    for key in ("resident", "lockstep_cols", "lockstep_group", "serial_engine", "serial_group", "streaming_precond",
-                "poll_chunk", "first_stop_iteration"):
+    keys = ("resident", "lockstep_cols", "lockstep_group", "serial_engine", "serial_group", "streaming_precond",
+            "poll_chunk", "first_stop_iteration")
+    if plan["rspace"] == "cols" and ran["streaming_iterations"] == 0:
+        # (round 5) all columns on R + 1 coordinates in three streaming launches, and the stop rule held at the floor:
+        # lockstep_cols / serial_engine of the PLAN name the engines of a repeat with the state, which did not happen
+        assert ran["rspace"] == "cols" and ran["lockstep_cols"] == 0 and ran["serial_engine"] == "none" and ran["lean"]
+        keys = ("resident", "streaming_precond", "poll_chunk", "first_stop_iteration")
+    else:
+        assert ran["rspace"] == (plan["rspace"] if ran["streaming_iterations"] == 0 else "none"), (plan, ran)
+    for key in keys:
         assert plan[key] == ran[key], (key, plan, ran)
     if plan["resident"]:
         assert ran["resident_iterations"] == plan["resident_iterations"]
@@ -321,6 +329,7 @@ def test_w_recurrence_mode_against_three_pass_oracle_and_exact_solution(N, R, B,
     # it reports the same iteration count; where their rounding makes them go on (ill-conditioned members) it stops at
     # the floor with a solution that is CLOSER to the exact one.
     assert pre.RS is not None
+    K.set_onchip_cg(True)  # (forgets the miss of the w-recurrence pass above: speculate afresh)
     rs = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
     ran = K.cg_last_executed()
     assert ran["serial_engine"] == "root" and ran["lean"] and rs.tolerance_reached
@@ -336,6 +345,36 @@ def test_w_recurrence_mode_against_three_pass_oracle_and_exact_solution(N, R, B,
     assert torch.equal(rs.x, rs2.x)  # bitwise reproducible
 
 
+def test_rspace_pass_is_repeated_with_the_state_when_the_floor_is_not_enough():
+    """Round 5.  Columns of C with geometrically decaying norms (32 well separated eigenvalue clusters), a rank-2
+    preconditioner and a tolerance the 11 iterations of the floor cannot meet even in exact arithmetic: the result-only
+    R-space pass (one column: k_cg_rspace; three columns: k_rs_part / k_rs_iter / k_rs_apply) misses the stop rule, the
+    three-pass resident kernel repeats the iterations WITH the state and the streaming engine continues from it."""
+    B, N, R = 12, 8192, 32
+    for c in (1, 3):
+        C, d, rhs = cases.lowrank_diag(8890 + c, B, N, R, c)
+        C = (C * (0.8 ** np.arange(R))[None, None, :]).astype(np.float32)
+        desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+        L, perm = K.pivoted_cholesky(desc, 2)
+        pre = K.precond_build(L, dev(d), constant_diag=False, root=desc.A0, perm=perm)
+        assert pre.RS is not None
+        K.set_onchip_cg(True)
+        plan = K.cg_plan(desc, c, precond=pre, max_iter=200)
+        assert plan["rspace"] == ("resident" if c == 1 else "cols") and plan["lean"]
+        K._hip.prof_enable(True)
+        res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-5, max_iter=200)
+        torch.cuda.synchronize()
+        prof = K._hip.prof_report()
+        K._hip.prof_enable(False)
+        ran = K.cg_last_executed()
+        assert ("rs_iter" in prof) == (c > 1) and "cg_onchip" in prof  # the R-space pass ran, then the repeat
+        assert ran["resident"] and ran["streaming_iterations"] > 0 and not ran["lean"] and ran["rspace"] == "none"
+        assert res.tolerance_reached and res.iterations > 11
+        exact = np.concatenate([_woodbury_exact(C, d, rhs[..., j:j + 1]) for j in range(c)], -1)
+        assert max_rel_err_cols(host(res.x), exact) < 1e-4
+
+
+@pytest.mark.usefixtures("legacy_resident_engines")
 def test_w_recurrence_mode_continues_on_the_streaming_engine_when_the_floor_is_not_enough():
     """Tolerance far below what 11 iterations reach with a weak (rank-2) preconditioner: the result-only first pass (w by
     recurrence) misses the stop rule, is repeated by the three-pass kernel WITH the state, and the streaming engine
@@ -382,6 +421,7 @@ def test_lanczos_basis_view_and_native_root_epilogue(B, N, P, k):
     assert float((a[0].double() - ref).abs().max()) < 1e-5
 
 
+@pytest.mark.usefixtures("legacy_resident_engines")
 def test_speculation_misses_are_remembered(monkeypatch):
     """(i) a solve whose result-only first pass misses the stop rule at the floor starts its NEXT solve with
     the state-writing pass (one resident launch instead of two); a solve that stops at the floor again clears the entry.

@@ -236,6 +236,7 @@ def test_pivoted_cholesky_nan_column_of_an_exhausted_member():
     assert np.array_equal(np.isnan(host(L)), np.isnan(Lo)) and np.array_equal(host(L), Lo, equal_nan=True)
 
 
+@pytest.mark.usefixtures("legacy_resident_engines")
 @pytest.mark.parametrize("N,c", [(40000, 1), (65536, 1), (50000, 3)])
 def test_large_members_take_groups_of_64(N, c):
     """32768 < N <= 65536: the root-form resident CG runs a member on 64 workgroups (lane-parallel two-hop all-reduce)

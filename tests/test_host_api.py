@@ -316,7 +316,7 @@ def test_diag_and_triangular_inv_quad_logdet_follow_the_reference():
 
 # ---------------------------------------------------------------- engine selection of lo_cg_solve_f32
 def _plan(kind, N, R=32, c=1, k=15, pre="root+q", nt=0, B=512, x0=False, closure=False, max_iter=1000, cus=256, n2=0,
-          kron_root=False, global_rule=False, diag_mode=_hip.LO_DIAG_FULL, const_pre=False):
+          kron_root=False, global_rule=False, diag_mode=_hip.LO_DIAG_FULL, const_pre=False, rs=False):
     """lo_cg_plan_f32 on a descriptor with placeholder (non-null) pointers: the plan reads shapes and null-ness only."""
     lib = _hip.load()
     FAKE = 0x1000
@@ -331,6 +331,8 @@ def _plan(kind, N, R=32, c=1, k=15, pre="root+q", nt=0, B=512, x0=False, closure
         if "root" in pre:
             rf = 8 if R <= 8 else (16 if R <= 16 else 32)
             pd.F, pd.EF, pd.E, pd.rf_ld = FAKE, FAKE, FAKE, rf
+            if rs:
+                pd.RS = FAKE
         if kron_root:
             pd.kron_a, pd.kron_b, pd.kron_F = FAKE, FAKE, FAKE
     prm = _hip.CgParams()
@@ -344,13 +346,27 @@ def _plan(kind, N, R=32, c=1, k=15, pre="root+q", nt=0, B=512, x0=False, closure
     assert rc == 0, rc
     return dict(resident=out.resident, iters=out.resident_iterations, ls=out.lockstep_cols, ls_gw=out.lockstep_group,
                 serial=_hip.ENGINE_NAMES[out.serial_engine], gw=out.serial_group, lean=out.lean, needs_q=out.needs_q,
-                stream=_hip.STREAM_PRE_NAMES[out.streaming_precond], chunk=out.poll_chunk, first_stop=out.first_stop_iteration)
+                stream=_hip.STREAM_PRE_NAMES[out.streaming_precond], chunk=out.poll_chunk, first_stop=out.first_stop_iteration,
+                rspace=out.rspace)
 
 
 LOW, DENSE, KRON, CB = _hip.LO_OP_LOWRANK_DIAG, _hip.LO_OP_DENSE_DIAG, _hip.LO_OP_KRON_DIAG, _hip.LO_OP_CALLBACK
 ENGINE_TABLE = [
     # (label, arguments of _plan, expected subset of the plan)
     ("headline: cfg3 operator, one column", dict(kind=LOW, N=8192), dict(resident=1, iters=11, ls=0, serial="root", gw=8, lean=1, needs_q=0)),
+    ("headline with the R-space form: iterations on R + 1 coordinates inside the resident launch", dict(kind=LOW, N=8192, rs=True),
+     dict(resident=1, iters=11, ls=0, serial="root", gw=8, lean=1, rspace=2)),
+    ("cfg3 with the R-space form: all columns in three streaming launches, lockstep + root as the repeat",
+     dict(kind=LOW, N=8192, c=17, nt=16, rs=True), dict(resident=1, iters=21, ls=16, serial="root", lean=1, rspace=1)),
+    ("R-space form, root form only, 17 columns", dict(kind=LOW, N=8192, c=17, nt=16, pre="root", rs=True),
+     dict(resident=1, ls=0, serial="root", lean=1, rspace=1)),
+    ("R-space form, one column WITH its tridiagonal: the streaming form records alpha / beta", dict(kind=LOW, N=8192, c=1, nt=1, rs=True),
+     dict(resident=1, rspace=1, lean=1)),
+    ("R-space form under the batch-global stop rule: state needed, not taken", dict(kind=LOW, N=8192, c=17, nt=16, rs=True, global_rule=True),
+     dict(resident=1, rspace=0, lean=0)),
+    ("R-space form, more than 32 columns", dict(kind=LOW, N=8192, c=40, rs=True), dict(resident=1, rspace=0)),
+    ("R-space form, N = 16384, 17 columns", dict(kind=LOW, N=16384, c=17, nt=16, rs=True), dict(resident=1, rspace=1, ls=0, serial="root")),
+    ("headline without the R-space form", dict(kind=LOW, N=8192), dict(rspace=0)),
     ("cfg2", dict(kind=LOW, N=8192, B=64), dict(resident=1, serial="root", gw=8, lean=1)),
     ("cfg3: 16 probes + rhs", dict(kind=LOW, N=8192, c=17, nt=16), dict(resident=1, iters=21, ls=16, ls_gw=8, serial="root", lean=1)),
     ("16 probes only", dict(kind=LOW, N=8192, c=16, nt=16), dict(resident=1, ls=16, serial="none", lean=1)),

@@ -133,3 +133,85 @@ def test_inv_quad_logdet_pipeline_against_golden_g4_and_numpy():
     pk = occ.Preconditioner(Lk, sig[:, 0], const_diag=True)
     xk, _, ik = occ.linear_cg(occ.kron_diag(K1, K2, sig[:, 0], const_diag=True), rk, pre=pk, tolerance=1e-3)
     assert abs(ik.matvecs - int(gk["matvecs"])) <= 3 and max_rel_err_cols(xk, gk["x"]) < 5e-3
+
+
+def test_lanczos_against_golden_g5_and_numpy():
+    """lo_cpu_lanczos_tridiag_f32 (utils/lanczos.py:9-164) against the real reference's golden g5 and the numpy oracle:
+    same shapes (the batch-global early exit included), tridiagonals to 1e-5 of the numpy restatement (same arithmetic,
+    other summation order), the reference's own acceptance Q T Q^T = M (test/utils/test_lanczos.py:35-36)."""
+    g = load_golden("g5_lanczos")
+    M = cases.spd_test_matrix(501, 100, dtype=np.float32, jitter=1e-6)
+    v0 = cases.randn(502, 100, 1, dtype=np.float32)
+    q, t = occ.lanczos_tridiag(occ.dense_diag(M[None]), v0[None], 100)
+    q, t = q[0], t[0]  # (one member)
+    assert q.shape == g["q_near"].shape and t.shape == g["t_near"].shape
+    assert np.allclose(t[:10, :10], g["t_near"][:10, :10], rtol=1e-3, atol=1e-5)
+    assert np.allclose(q @ t @ q.T, M, atol=1e-4)
+    C, d, _ = cases.lowrank_diag(511, 2, 256, 8, 1)
+    V = cases.randn(512, 2, 256, 3, dtype=np.float32)
+    q3, t3 = occ.lanczos_tridiag(occ.lowrank_diag(C, d), V, 10)
+    qo, to = orc.lanczos_tridiag(lambda v: orc.matvec_lowrank_diag(C, d, v), 10, V)
+    assert q3.shape == g["q_batch"].shape == qo.shape and t3.shape == g["t_batch"].shape == to.shape
+    assert np.allclose(t3, to, rtol=1e-4, atol=1e-5) and np.allclose(q3, qo, atol=2e-4)
+    assert np.allclose(t3, g["t_batch"], rtol=1e-3, atol=1e-4) and np.allclose(q3, g["q_batch"], atol=2e-3)
+    # early exit: an operator of rank 3 + identity exhausts its Krylov space after four steps in every member
+    C4 = cases.lowrank_diag(513, 2, 200, 3, 1)[0]
+    ones = np.ones((2, 200), dtype=np.float32)
+    V4 = cases.randn(514, 2, 200, 2, dtype=np.float32)
+    q4, t4 = occ.lanczos_tridiag(occ.lowrank_diag(C4, ones), V4, 20)
+    qo4, to4 = orc.lanczos_tridiag(lambda v: orc.matvec_lowrank_diag(C4, ones, v), 20, V4)
+    assert t4.shape == to4.shape and t4.shape[-1] < 20
+
+
+def test_tridiag_eigh_slq_against_numpy_and_golden_g4():
+    """lo_cpu_tridiag_eigh_slq_f32 (implicit QL in double; utils/lanczos.py:167-189 + stochastic_lq.py:45-82): eigenvalues
+    and first eigenvector components against numpy's eigh in float64 on random tridiagonals (clamping of negative
+    eigenvalues included), and the SLQ value of the REFERENCE's own t_mat (golden g4) against the reference's number --
+    within the fp32 eigensolver's noise floor the reference's value carries (test_oracle_vs_golden.py: `floor`)."""
+    rng = np.random.default_rng(77)
+    P, B, k = 3, 4, 12
+    t = np.zeros((P, B, k, k), dtype=np.float32)
+    dg = rng.uniform(0.5, 3.0, (P, B, k)).astype(np.float32)
+    off = rng.uniform(-1.0, 1.0, (P, B, k - 1)).astype(np.float32)
+    dg[0, 0, 3] = -2.0  # an indefinite block: negative eigenvalues are clamped
+    for i in range(k):
+        t[..., i, i] = dg[..., i]
+    for i in range(k - 1):
+        t[..., i, i + 1] = t[..., i + 1, i] = off[..., i]
+    ld, ev, v0 = occ.tridiag_eigh_slq(t, 500, want_spectrum=True)
+    w, v = np.linalg.eigh(t.astype(np.float64))
+    mask = w >= 0
+    first = v[..., 0, :] * mask
+    wc = np.where(mask, w, 1.0)
+    order = np.argsort(ev, axis=-1)
+    ev_s, v0_s = np.take_along_axis(ev, order, -1), np.take_along_axis(v0, order, -1)
+    wo = np.argsort(wc, axis=-1)
+    assert np.allclose(ev_s, np.take_along_axis(wc, wo, -1), rtol=1e-12, atol=1e-12)
+    want = (500.0 / P) * np.sum(first ** 2 * np.log(wc), axis=(0, -1))
+    assert np.allclose(ld, want, rtol=1e-6)
+    assert np.allclose(np.sort(v0_s ** 2, -1), np.sort(np.take_along_axis(first, wo, -1) ** 2, -1), atol=1e-10)
+    g = load_golden("g4_iql_lowrank")
+    got = occ.tridiag_eigh_slq(g["t_mat"], 2048)
+    floor = 2048 * 1.2e-7 * 137.0
+    assert np.allclose(got, g["pinvk_logdet"], rtol=1e-4, atol=floor)
+    # ... and EXACTLY (1e-6) the float64 eigendecomposition of the same matrices
+    ev64, evec64 = orc.lanczos_tridiag_to_diag(g["t_mat"].astype(np.float64))
+    assert np.allclose(got, orc.slq_logdet(2048, ev64, evec64), rtol=2e-6)
+
+
+def test_inv_quad_logdet_in_c_against_golden_g4_and_numpy():
+    """The whole forward of InvQuadLogdet with injected probes in C (pivoted Cholesky -> preconditioner -> linear_cg with
+    tridiagonals -> eigh + SLQ) against the real reference's golden g4_iql_lowrank and the numpy oracle."""
+    g = load_golden("g4_iql_lowrank")
+    C, d, rhs = cases.lowrank_diag(411, 3, 2048, 16, 1)
+    Z, _ = cases.probes(412, 3, 2048, 8)
+    iq, ld, solves, t_mat, info, piv = occ.inv_quad_logdet(occ.lowrank_diag(C, d), occ.lowrank_diag(C), d, rhs, Z, tolerance=1e-4)
+    assert info.matvecs == int(g["matvecs"])
+    assert max_rel_err_cols(solves, g["solves"]) < 1e-5
+    assert np.allclose(iq[..., 0], g["inv_quad"], rtol=1e-5)
+    floor = 2048 * 1.2e-7 * 137.0
+    assert np.allclose(ld, g["logdet"], rtol=1e-4, atol=floor)
+    iqo, ldo, so, to, infoo, _ = orc.inv_quad_logdet(lambda v: orc.matvec_lowrank_diag(C, d, v), orc.LowRankRowSource(C), d, rhs, Z,
+                                                     tolerance=1e-4)
+    assert infoo.matvecs == info.matvecs and np.allclose(iq, iqo, rtol=1e-5)
+    assert np.allclose(ld, ldo, rtol=1e-4, atol=floor)
