@@ -704,12 +704,18 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
                                                        int rows_per, double* __restrict__ part, double* __restrict__ sq) {
   constexpr int MT = RC > 16 ? 2 : 1;
   constexpr int TR = RSP_TR;
-  constexpr int LD = RC + 1;
-  __shared__ float ctile[2][TR * LD];
-  __shared__ float btile[2][TR * RSP_CMAX];
+  constexpr int LD = 16 * MT + 1;  // C tile row stride (columns beyond RC stay zero)
+  constexpr int WB = 16 * NT;      // B tile row stride: [b (c columns) | b again (c columns) | zeros]
+  __shared__ __attribute__((aligned(16))) float ctile[2][TR * LD];
+  __shared__ __attribute__((aligned(16))) float btile[2][TR * WB];
   __shared__ float dtile[2][TR];
-  __shared__ double red[4][64][4];
   __shared__ double sqred[4][RSP_CMAX][2];
+  // (the cross-wave reduction at the end reuses the tiles)
+  static_assert(sizeof(float) * 2 * TR * WB >= sizeof(double) * 4 * 64 * 4 || sizeof(float) * 2 * TR * LD >= sizeof(double) * 4 * 64 * 4,
+                "reduction buffer inside a tile");
+  double (*red)[64][4] = (sizeof(float) * 2 * TR * LD >= sizeof(double) * 4 * 64 * 4)
+                             ? reinterpret_cast<double (*)[64][4]>(&ctile[0][0])
+                             : reinterpret_cast<double (*)[64][4]>(&btile[0][0]);
   const int s = blockIdx.x, S = gridDim.x;
   const int64_t b = blockIdx.y;
   const int t = threadIdx.x, wave = t >> 6, l = t & 63;
@@ -723,6 +729,17 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
   constexpr int RQ = RC / 4;
   constexpr int CP = (TR * RQ + kThreads - 1) / kThreads;  // 16-byte pieces of C per thread and tile
   constexpr int BP = TR * RSP_CMAX / kThreads;             // floats of the right-hand sides per thread and tile (at c = 32)
+  // element e = i * 256 + t of a tile's right-hand sides (rows x c, contiguous) lands at row e / c, column e % c: the
+  // same for every tile -- one division per element for the whole kernel
+  int bdst[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int e = i * kThreads + t;
+    bdst[i] = (e / c) * WB + (e % c);
+  }
+  for (int e = t; e < 2 * TR * WB; e += kThreads) (&btile[0][0])[e] = 0.f;  // (the zero columns are never written again)
+  for (int e = t; e < 2 * TR * LD; e += kThreads) (&ctile[0][0])[e] = 0.f;
+  __syncthreads();
   float4 pc[CP];
   float pb[BP];
   float pd = 0.f;
@@ -756,7 +773,10 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
       const int e = i * kThreads + t;
-      if (e < TR * c) btile[buf][e] = pb[i];
+      if (e < TR * c) {
+        btile[buf][bdst[i]] = pb[i];
+        btile[buf][bdst[i] + c] = pb[i];
+      }
     }
     if (t < TR) dtile[buf][t] = pd;
   };
@@ -765,6 +785,10 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
   for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
     for (int nj = 0; nj < NT; ++nj) acc[mi][nj] = f64x4{0.0, 0.0, 0.0, 0.0};
+  // lane (a, kk) feeds column jc = 16 nj + a of the B operand: columns [0, c) carry b dinv, [c, 2 c) carry b
+  bool scaled[NT];
+#pragma unroll
+  for (int nj = 0; nj < NT; ++nj) scaled[nj] = 16 * nj + a < c;
   // s = sum b^2 dinv, a0 = sum b^2: thread (col = t % c, rsub = t / c < 4) walks 16 rows of its column per tile
   const int scol = t % c, rsub = t / c;
   double s_acc = 0.0, a_acc = 0.0;
@@ -775,21 +799,24 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
   for (int base = r0; base < r1; base += TR) {
     const bool more = base + TR < r1;
     if (more) issue(base + TR);
+    float avf[4][MT], bvf[4][NT], dvf[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // all operands of the wave's 16 rows first (branch-free), then the products
+      const int row = 16 * wave + 4 * e + kk;
+      dvf[e] = dtile[buf][row];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) avf[e][mi] = ctile[buf][row * LD + 16 * mi + a];
+#pragma unroll
+      for (int nj = 0; nj < NT; ++nj) bvf[e][nj] = btile[buf][row * WB + 16 * nj + a];
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int row = 16 * wave + 4 * e + kk;
-      const double dv = (double)dtile[buf][row];
+      const double dv = (double)dvf[e];
       double av[MT], bv[NT];
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) av[mi] = (16 * mi + a < RC) ? (double)ctile[buf][row * LD + 16 * mi + a] : 0.0;
+      for (int mi = 0; mi < MT; ++mi) av[mi] = (double)avf[e][mi];
 #pragma unroll
-      for (int nj = 0; nj < NT; ++nj) {
-        const int jc = 16 * nj + a;  // [0, c): b dinv   [c, 2 c): b
-        double v = 0.0;
-        if (jc < c) v = (double)btile[buf][row * c + jc] * dv;
-        else if (jc < 2 * c) v = (double)btile[buf][row * c + jc - c];
-        bv[nj] = v;
-      }
+      for (int nj = 0; nj < NT; ++nj) bv[nj] = (double)bvf[e][nj] * (scaled[nj] ? dv : 1.0);
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -799,7 +826,7 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
 #pragma unroll 4
       for (int i = 0; i < TR / 4; ++i) {
         const int row = rsub + 4 * i;
-        const double v = (double)btile[buf][row * c + scol];
+        const double v = (double)btile[buf][row * WB + scol];
         const double vv = v * v;
         a_acc += vv;
         s_acc = fma(vv, (double)dtile[buf][row], s_acc);
@@ -1037,59 +1064,84 @@ __global__ __launch_bounds__(kThreads) void k_rs_iter(RsColsArgs a) {
   }
 }
 
-// x[b, row, col] = dinv[row] (xi_col b[row, col] + sum_j C[row, j] yn[col][j]); 512 rows per pass and workgroup (two per
-// thread), the right-hand sides / results of a pass travel through LDS (rows x c floats contiguous in memory)
-constexpr int RSA_ROWS = 2 * kThreads;
-template <int RC>
+// x[b, row, col] = dinv[row] (xi_col b[row, col] + sum_j C[row, j] yn[col][j]).  A pass of a workgroup covers NQ row sets
+// of 256 rows (NQ = 2 up to 17 columns: the broadcast reads of yn serve two rows per thread); a wave fetches its 64 rows
+// of C as consecutive 16-byte pieces (whole cache lines per instruction) and turns them into one row per lane through
+// its own LDS window; the right-hand sides / results of a pass travel through LDS as well (rows x c floats contiguous).
+constexpr int RSA_BT = 512 * 17;  // floats of the right-hand-side tile
+template <int RC, int NQ>
 __global__ __launch_bounds__(kThreads) void k_rs_apply(RsColsArgs a) {
-  __shared__ float bt[RSA_ROWS * (RSP_CMAX + 1)];
-  __shared__ __attribute__((aligned(16))) double yv[RSP_CMAX][RC + 2];  // [col][xi | yn_0 .. yn_RC-1 | pad]
+  constexpr int CH = RC / 4;
+  __shared__ float bt[RSA_BT];
+  __shared__ float4 win_s[4 * 64 * CH];
+  __shared__ __attribute__((aligned(16))) double yv[RSP_CMAX][RC + 2];  // [col][yn_0 .. yn_RC-1 | xi | pad]
   const int s = blockIdx.x;
   const int64_t b = blockIdx.y;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int c = a.c, N = a.N;
-  const int ldb = c | 1;  // odd row stride: the per-row reads below are conflict-free
+  const int ldb = c;  // (row stride of the staged tile = c: conflict-free for odd c, 2-way .. 16-way for even c)
   const int r0 = s * a.rows_per, r1 = min(N, r0 + a.rows_per);
   for (int e = t; e < c * (RC + 1); e += kThreads) {
     const int col = e / (RC + 1), q = e % (RC + 1);
-    yv[col][q == 0 ? RC : q - 1] = a.coef[((size_t)b * c + col) * (RC + 1) + q];  // yn at [0, RC), xi at [RC]
+    yv[col][q == 0 ? RC : q - 1] = a.coef[((size_t)b * c + col) * (RC + 1) + q];
   }
   const bool dfull = a.dinv_mode == LO_DIAG_FULL;
   const float* Cb = a.C + (size_t)b * N * RC;
-  for (int base = r0; base < r1; base += RSA_ROWS) {
-    const int nr = min(RSA_ROWS, r1 - base);
+  float4* win = win_s + wave * (64 * CH);
+  constexpr int ROWS = NQ * kThreads;
+  for (int base = r0; base < r1; base += ROWS) {
+    const int nr = min(ROWS, r1 - base);
     __syncthreads();
-    for (int e = t; e < nr * c; e += kThreads) bt[(e / c) * ldb + e % c] = a.rhs[((size_t)b * N + base) * c + e];
-    double cr[2][RC];
-    double dv[2];
+    for (int e = t; e < nr * c; e += kThreads) bt[e] = a.rhs[((size_t)b * N + base) * c + e];  // (row stride c: no division)
+    double cr[NQ][RC];
+    double dv[NQ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int row = base + t + kThreads * q;
-      const bool ok = row < r1;
-      const float4* cp = reinterpret_cast<const float4*>(Cb + (size_t)min(row, N - 1) * RC);
+    for (int q = 0; q < NQ; ++q) {
+      const int wrow = base + kThreads * q + 64 * wave;  // first row of this wave's block
+      float4 pc[CH];
 #pragma unroll
-      for (int i = 0; i < RC / 4; ++i) {
-        const float4 c4 = cp[i];
+      for (int i = 0; i < CH; ++i) {
+        const int gch = 64 * i + lane;  // 16-byte piece of the wave's 64 x RC block
+        const int rw = gch / CH, ck = gch % CH;
+        pc[i] = *reinterpret_cast<const float4*>(Cb + (size_t)min(wrow + rw, N - 1) * RC + 4 * ck);
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int gch = 64 * i + lane;
+        const int rw = gch / CH, ck = gch % CH;
+        win[rw * CH + (ck ^ ((rw ^ (rw >> 3)) & (CH - 1)))] = pc[i];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const float4 c4 = win[lane * CH + (i ^ ((lane ^ (lane >> 3)) & (CH - 1)))];
         cr[q][4 * i] = (double)c4.x; cr[q][4 * i + 1] = (double)c4.y;
         cr[q][4 * i + 2] = (double)c4.z; cr[q][4 * i + 3] = (double)c4.w;
       }
-      dv[q] = ok ? (double)(dfull ? a.dinv[(size_t)b * N + row] : a.dinv[b]) : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      const int row = wrow + lane;
+      dv[q] = (row < r1) ? (double)(dfull ? a.dinv[(size_t)b * N + row] : a.dinv[b]) : 0.0;
     }
     __syncthreads();
     for (int col = 0; col < c; ++col) {
       const double xi = yv[col][RC];
-      double acc0 = xi * (double)bt[t * ldb + col], acc1 = xi * (double)bt[(t + kThreads) * ldb + col];
+      double acc[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[q] = xi * (double)bt[(t + kThreads * q) * ldb + col];
 #pragma unroll
       for (int i = 0; i < RC; i += 2) {
         const double2 y2 = *reinterpret_cast<const double2*>(&yv[col][i]);
-        acc0 = fma(cr[0][i], y2.x, acc0); acc0 = fma(cr[0][i + 1], y2.y, acc0);
-        acc1 = fma(cr[1][i], y2.x, acc1); acc1 = fma(cr[1][i + 1], y2.y, acc1);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          acc[q] = fma(cr[q][i], y2.x, acc[q]);
+          acc[q] = fma(cr[q][i + 1], y2.y, acc[q]);
+        }
       }
-      bt[t * ldb + col] = (float)(acc0 * dv[0]);                 // :335 (each thread rewrites its own rows)
-      bt[(t + kThreads) * ldb + col] = (float)(acc1 * dv[1]);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) bt[(t + kThreads * q) * ldb + col] = (float)(acc[q] * dv[q]);  // :335 (own rows only)
     }
     __syncthreads();
-    for (int e = t; e < nr * c; e += kThreads) a.xout[((size_t)b * N + base) * c + e] = bt[(e / c) * ldb + e % c];
+    for (int e = t; e < nr * c; e += kThreads) a.xout[((size_t)b * N + base) * c + e] = bt[e];
   }
 }
 
@@ -1137,7 +1189,8 @@ static int rspace_cols_go(const OnchipArgs& a, double* ws, hipStream_t st) {
   hipLaunchKernelGGL((k_rs_iter<RC>), dim3((unsigned)((a.c + 3) / 4), (unsigned)a.B), block, 0, st, r);
   LO_PROF_END(st);
   LO_PROF_BEGIN("rs_apply", st);
-  hipLaunchKernelGGL((k_rs_apply<RC>), gp, block, 0, st, r);
+  if (a.c <= 17) hipLaunchKernelGGL((k_rs_apply<RC, 2>), gp, block, 0, st, r);
+  else hipLaunchKernelGGL((k_rs_apply<RC, 1>), gp, block, 0, st, r);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
