@@ -36,7 +36,7 @@ from linear_operator_amd import kernels as K  # noqa: E402
 B_PER_GPU, N, R, C_COLS, RANK_K = 512, 8192, 32, 1, 15
 TOL = 1e-4
 ITERS_FLOOR = 11  # linear_cg.py:303 -- the iterations the operator-resident kernel runs in one launch
-PROFILE_DIR = "r04"  # profiles/<dir>/ holds the rocprofv3 summaries of this command (tools/profile_round.sh)
+PROFILE_DIR = "r05"  # profiles/<dir>/ holds the rocprofv3 summaries of this command (tools/profile_round.sh)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0  # the guide's measured float4-copy rate: the ceiling a streaming kernel can reach
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (v_mfma_f32_16x16x4_f32 / 32x32x2, MI355X_MICROARCH.md)
@@ -177,6 +177,123 @@ def cpu_baseline(seconds_budget=10.0, device=None):
                     "identical rank-15 preconditioner (pivots compared exactly); logdet = SLQ on the CG tridiagonals "
                     "+ logdet P.  The last figure is the estimator's own error against the fp64 closed form "
                     "(16 probes), not a parity figure"}
+    return out
+
+
+def config_baselines(device):
+    """SURVEY 8(d) for the other BASELINE configs: for cfg3, the cfg4 shard and the cfg5 shard a `cpu_baseline` (the C
+    oracle, oracle/lo_oracle_c.c, OpenMP over the members, timed on this box's host cores at the SAME per-member shape on
+    a host-sized batch) and a `parity` block (the HIP path on the oracle's very inputs: pivots compared exactly, solve /
+    inv_quad / logdet relative errors).  The oracle is the checker and the baseline here, never the thing measured."""
+    import cases
+    import numpy as np
+    from oracle import lo_oracle_c as occ
+
+    cores = occ.num_threads()
+    out = {}
+
+    def rel_cols(x, ref):
+        num = np.sqrt(((x.astype(np.float64) - ref) ** 2).sum(-2))
+        return float((num / np.maximum(np.sqrt((ref.astype(np.float64) ** 2).sum(-2)), 1e-300)).max())
+
+    def timed(fn, budget):
+        fn()  # warm (page faults, OpenMP team)
+        t0, reps = time.perf_counter(), 0
+        while True:
+            r = fn()
+            reps += 1
+            if time.perf_counter() - t0 >= budget or reps >= 50:
+                return (time.perf_counter() - t0) / reps, reps, r
+
+    # ---- cfg3: 16 probes + 1 right-hand side, rank-15 preconditioner, tridiagonals + SLQ (inv_quad_logdet) ----
+    Bc = max(8, min(32, cores))
+    C3, d3, r3 = cases.lowrank_diag(4301, Bc, N, R, 1)
+    Z3, _ = cases.probes(4302, Bc, N, 16)
+    t_c, reps, (iq_o, ld_o, x_o, t_o, info_o, piv_o) = timed(
+        lambda: occ.inv_quad_logdet(occ.lowrank_diag(C3, d3), occ.lowrank_diag(C3), d3, r3, Z3, tolerance=TOL), 3.0)
+    Ct, dt_ = torch.from_numpy(C3).to(device), torch.from_numpy(d3).to(device)
+    desc = K.lowrank_diag_descriptor(Ct, dt_)
+    pre = build_precond(desc, dt_)
+    full = torch.from_numpy(np.concatenate([Z3, r3], -1)).to(device)
+    rh = K.cg_solve(desc, full, precond=pre, n_tridiag=16, tolerance=TOL)
+    _, _, slq = K.tridiag_eigh_slq(rh.t_mat, N)
+    ld_h = (slq + pre.logdet.reshape(-1)).cpu().numpy()
+    xh = rh.x.cpu().numpy()
+    iq_h = (xh[..., 16:] * r3).sum(-2)
+    L3, p3 = K.pivoted_cholesky(desc, RANK_K)
+    out["cfg3"] = {
+        "cpu_baseline": {"value": Bc / t_c, "unit": "member-solve-logdets/s", "cores": cores, "kind": "port",
+                         "sample": f"{reps} x C oracle inv_quad_logdet (pivoted Cholesky + preconditioner + linear_cg with "
+                                   f"16 tridiagonals + eigh / SLQ) on {Bc} members of the cfg3 shape in {t_c * reps:.1f} s"},
+        "parity": {"members": Bc, "pivots_equal": bool(np.array_equal(p3.cpu().numpy()[:, :RANK_K], piv_o[:, :RANK_K])),
+                   "iterations": [int(rh.iterations), int(info_o.iterations)],
+                   "solve_rel_err_vs_oracle": rel_cols(xh, x_o),
+                   "inv_quad_rel_err_vs_oracle": float(np.max(np.abs(iq_h - iq_o) / np.abs(iq_o))),
+                   "logdet_rel_err_vs_oracle": float(np.max(np.abs(ld_h - ld_o) / np.abs(ld_o))),
+                   "note": "identical right-hand side, identical 16 probes; HIP path = rank-15 pivoted Cholesky, root-form "
+                           "preconditioner, CG with tridiagonals (R-space columns), fp64 QL + SLQ on the device"}}
+    del Ct, dt_, desc, pre, full, rh
+    # ---- cfg4 shard: Kronecker 256 (x) 256 + 1e-2 I, one column, tolerance 1e-3 ----
+    B4 = max(4, min(16, cores))
+    K1, K2, sig, r4 = cases.kron_factors(4401, B4, 256, 256, 1)
+
+    def cfg4_cpu():
+        L, piv = occ.pivoted_cholesky(occ.kron_diag(K1, K2), RANK_K)
+        pre_c = occ.Preconditioner(L, sig, const_diag=True)
+        x, _, info = occ.linear_cg(occ.kron_diag(K1, K2, sig, const_diag=True), r4, pre=pre_c, tolerance=1e-3)
+        return x, info, piv
+
+    t0 = time.perf_counter()
+    x4o, info4, piv4 = cfg4_cpu()
+    t_c4 = time.perf_counter() - t0
+    K1t, K2t, sigt = (torch.from_numpy(a).to(device) for a in (K1, K2, sig.reshape(-1)))
+    desc4 = K.kron_diag_descriptor(K1t, K2t, sigt, const_diag=True)
+    L4, p4 = K.pivoted_cholesky(desc4.without_diag(), RANK_K, contiguous=False)
+    r4h = K.cg_solve(desc4, torch.from_numpy(r4).to(device), precond=K.precond_build(L4, sigt, True, perm=p4, kron=desc4),
+                     tolerance=1e-3)
+    out["cfg4_shard"] = {
+        "cpu_baseline": {"value": B4 / t_c4, "unit": "member-solves/s", "cores": cores, "kind": "port",
+                         "sample": f"1 x C oracle (pivoted Cholesky of the Kronecker part + preconditioner + linear_cg to "
+                                   f"tolerance 1e-3, {info4.iterations} iterations) on {B4} members of the cfg4 shape "
+                                   f"(256 (x) 256 + 1e-2 I) in {t_c4:.1f} s"},
+        "parity": {"members": B4, "pivots_equal": bool(np.array_equal(p4.cpu().numpy()[:, :RANK_K], piv4[:, :RANK_K])),
+                   "iterations": [int(r4h.iterations), int(info4.iterations)],
+                   "solve_rel_err_vs_oracle": rel_cols(r4h.x.cpu().numpy(), x4o),
+                   "note": "both stop on the batch-global rule mean ||r|| < 1e-3 (linear_cg.py:302-308); with different "
+                           "summation orders the crossing can fall one iteration apart, the solutions then differ at the "
+                           "level of the tolerance -- the iteration-pinned golden g24 carries the 1e-4 bar"}}
+    del K1t, K2t, desc4, L4, r4h
+    # ---- cfg5 shard: dense 16384^2 + diag, 16 probes + 1 right-hand side ----
+    B5, N5 = 2, 16384
+    rng = np.random.Generator(np.random.PCG64(4501))
+    Y = (rng.standard_normal((B5, N5, 256)) / 16).astype(np.float32)
+    K5 = Y @ np.swapaxes(Y, -1, -2)
+    del Y
+    d5 = (rng.random((B5, N5)) + 0.5).astype(np.float32)
+    r5 = rng.standard_normal((B5, N5, 1)).astype(np.float32)
+    Z5, _ = cases.probes(4502, B5, N5, 16)
+    t0 = time.perf_counter()
+    iq5, ld5, x5, _, info5, piv5 = occ.inv_quad_logdet(occ.dense_diag(K5, d5), occ.dense_diag(K5), d5, r5, Z5, tolerance=TOL)
+    t_c5 = time.perf_counter() - t0
+    K5t, d5t = torch.from_numpy(K5).to(device), torch.from_numpy(d5).to(device)
+    desc5 = K.dense_diag_descriptor(K5t, d5t)
+    L5, p5 = K.pivoted_cholesky(desc5, RANK_K, contiguous=False)
+    pre5 = K.precond_build(L5, d5t, False)
+    r5h = K.cg_solve(desc5, torch.from_numpy(np.concatenate([Z5, r5], -1)).to(device), precond=pre5, n_tridiag=16,
+                     tolerance=TOL)
+    _, _, slq5 = K.tridiag_eigh_slq(r5h.t_mat, N5)
+    ld5h = (slq5 + pre5.logdet.reshape(-1)).cpu().numpy()
+    x5h = r5h.x.cpu().numpy()
+    out["cfg5_shard"] = {
+        "cpu_baseline": {"value": B5 / t_c5, "unit": "member-solve-logdets/s", "cores": min(cores, B5), "kind": "port",
+                         "sample": f"1 x C oracle inv_quad_logdet on {B5} members of 16384^2 (K = Y Y^T, Y [16384, 256], + "
+                                   f"diag; the oracle parallelises over members: {min(cores, B5)} cores busy) in "
+                                   f"{t_c5:.1f} s, {info5.iterations} iterations; per member, not scaled"},
+        "parity": {"members": B5, "pivots_equal": bool(np.array_equal(p5.cpu().numpy()[:, :RANK_K], piv5[:, :RANK_K])),
+                   "iterations": [int(r5h.iterations), int(info5.iterations)],
+                   "solve_rel_err_vs_oracle": rel_cols(x5h, x5),
+                   "inv_quad_rel_err_vs_oracle": float(np.max(np.abs((x5h[..., 16:] * r5).sum(-2) - iq5) / np.abs(iq5))),
+                   "logdet_rel_err_vs_oracle": float(np.max(np.abs(ld5h - ld5) / np.abs(ld5)))}}
     return out
 
 
@@ -641,6 +758,14 @@ def main():
                     help="after the timed K steps: keep stepping (each step timed on its own) for about this much wall "
                          "time -- per-step min / median / max for the JSON line, and a GPU that an external "
                          "utilisation sampler sees busy.  0 = off.  `value` / `ms_per_step` come from the K steps only")
+    ap.add_argument("--gather", choices=["step", "end"], default="step",
+                    help="N > 1: `step` = one all-gather of the solutions per solve, overlapped with the next solve "
+                         "(default: the demanding reading); `end` = ONE all-gather after the K steps, inside the timed "
+                         "region (north_star's literal `at the end`).  The other mode is timed as well and reported "
+                         "under `gather_modes`")
+    ap.add_argument("--inject-timeouts", type=int, default=0,
+                    help="treat the first n resident CG launches of the soak as timed out (exercises the cool-down / "
+                         "re-arm gate of the resident kernels; the JSON line reports what the gate did)")
     ap.add_argument("--chunk-members", type=int, default=128,
                     help="cfg5: members resident at a time per rank (1 GiB each)")
     args = ap.parse_args()
@@ -723,9 +848,12 @@ def main():
     pending = []  # [(work handle, tensor being gathered)]
     nstep = [0]
 
+    gather_mode = [args.gather]
+    engines_seen = {}
+
     def step():
         res = K.cg_solve(desc, rhs, precond=pre, tolerance=TOL)
-        if use_dist:
+        if use_dist and gather_mode[0] == "step":
             while pending:  # the previous gather has had a whole solve to finish
                 pending.pop(0)[0].wait()
             buf = gather_bufs[nstep[0] % 2]
@@ -733,12 +861,24 @@ def main():
             pending.append((dist.all_gather_into_tensor(buf, res.x, async_op=True), res.x))
         return res
 
-    def fence():
+    def fence(last=None):
+        """Both ends of a timed region.  `last` (gather mode `end`): the solution of the region's final solve -- its
+        ONE all-gather belongs to the region."""
         if use_dist:
             while pending:
                 pending.pop(0)[0].wait()
+            if last is not None and gather_mode[0] == "end":
+                dist.all_gather_into_tensor(gather_bufs[0], last.x)
             dist.barrier()
         torch.cuda.synchronize(device)
+
+    def engine_now():
+        """Which engine the last solve of this rank ran (lo_cg_last_executed)."""
+        e = K.cg_last_executed()
+        if not e["resident"]:
+            return "streaming"
+        return {"resident": "resident R-space (k_cg_rspace)", "cols": "R-space columns (k_rs_part/iter/apply)",
+                "none": "resident three-pass (k_cg_onchip5)"}[e["rspace"]]
 
     # ---- this box's HBM ceilings (SURVEY 8(d): reported beside the spec peak), measured first: 1 GiB arrays ----
     triad_gbs = copy_gbs = None
@@ -776,10 +916,15 @@ def main():
             pilot = max(_gather_rank_ms(dist, pilot * 1e3, device)) * 1e-3
         n_soak = max(1, min(200000, int(args.min_seconds / pilot)))
         laps = [0.0] * n_soak
+        if args.inject_timeouts > 0:
+            K.inject_resident_timeouts(args.inject_timeouts)
         for i in range(n_soak):
             ta = time.perf_counter()
             res = step()
             laps[i] = time.perf_counter() - ta
+            if args.inject_timeouts > 0:
+                en = engine_now()
+                engines_seen[en] = engines_seen.get(en, 0) + 1
         fence()
         soak = _step_stats(laps)
         soak["seconds"] = round(sum(laps), 3)
@@ -793,8 +938,10 @@ def main():
     for i in range(args.steps):
         res = step()
         stamps[i + 1] = time.perf_counter()  # (linear_cg returns when the solve's status block has arrived)
-    fence()
+    fence(res)
     elapsed = time.perf_counter() - t0
+    engine_timed = engine_now()
+    gate = K.resident_status()
     step_stats = _step_stats([stamps[i + 1] - stamps[i] for i in range(args.steps)])
     per_rank_ms = [elapsed / args.steps * 1e3]
     allgather_ms = None
@@ -812,6 +959,51 @@ def main():
     matvecs_per_solve = res.matvecs
     total_members = world * B_PER_GPU
     value = total_members * matvecs_per_solve * args.steps / elapsed
+
+    def timed_region(n_steps):
+        """W warm-up + n_steps timed steps between two fences, maximum over the ranks (ms per step)."""
+        r_ = None
+        for _ in range(args.warmup):
+            r_ = step()
+        fence()
+        ta = time.perf_counter()
+        for _ in range(n_steps):
+            r_ = step()
+        fence(r_)
+        ms = (time.perf_counter() - ta) / n_steps * 1e3
+        return max(_gather_rank_ms(dist, ms, device)) if use_dist else ms
+
+    # ---- the other gather mode over the same K steps (N > 1): both readings of north_star's "all-gather at the end" ----
+    gather_modes = None
+    if use_dist:
+        other = "end" if args.gather == "step" else "step"
+        gather_mode[0] = other
+        other_ms = timed_region(args.steps)
+        gather_mode[0] = args.gather
+        gather_modes = {args.gather: elapsed / args.steps * 1e3, other: other_ms, "timed_as_value": args.gather,
+                        "note": "`step`: one all-gather of the solutions per solve, overlapped with the next solve; "
+                                "`end`: ONE all-gather after the K steps, inside the timed region"}
+    # ---- the same K steps on the resident kernel that performs the 11 products on the rows (k_cg_onchip5, the engine
+    # of rounds 2 - 4 and still the repeat-with-state / global-stop-rule engine): the R-space pass switched off ----
+    matvec_engine = None
+    if engine_timed.startswith("resident R-space"):
+        os.environ["LO_OC_NO_RSPACE"] = "1"
+        try:
+            ms3 = timed_region(args.steps)
+            eng3 = engine_now()
+        finally:
+            del os.environ["LO_OC_NO_RSPACE"]
+        matvec_engine = {"engine": eng3, "ms_per_step": ms3, "value": total_members * matvecs_per_solve / (ms3 * 1e-3),
+                         "note": "LO_OC_NO_RSPACE=1: the 11 operator applications carried out on the rows of C in VGPRs "
+                                 "(three passes over the registers per iteration); same systems, same stop rule"}
+    # ---- per-rank engine and gate of the resident kernels: a line measured on the streaming engine says so ----
+    engines = [engine_timed]
+    gates = [gate]
+    if use_dist:
+        engines = [None] * world
+        gates = [None] * world
+        dist.all_gather_object(engines, engine_timed)
+        dist.all_gather_object(gates, gate)
 
     # ---- end-to-end solves/s (pivoted Cholesky + preconditioner build + CG), local rank ----
     # Through the PUBLIC path: A.solve(rhs) of AddedDiagLinearOperator(LowRankRootLinearOperator(C), DiagLinearOperator(d))
@@ -885,7 +1077,15 @@ def main():
         dom = max(prof, key=lambda k: prof[k][1])
         cnt, ms = prof[dom]
         avg_s = ms / cnt * 1e-3
-        alg = algorithmic_bytes(dom, RANK_K)
+        rs_engine = dom == "cg_onchip" and K.cg_last_executed()["rspace"] == "resident"
+        if rs_engine:
+            # k_cg_rspace: C, 1/d, the right-hand side in, x out, and the member's six fp64 R x R matrices of the
+            # R-space form (E | F E | E F E | G2 | F | E F: lo_precond_desc.RS)
+            alg = B_PER_GPU * (4 * N * (R + 3) + 6 * R * R * 8)
+            dom_kernel = "k_cg_rspace<32,8>"
+        else:
+            alg = algorithmic_bytes(dom, RANK_K)
+            dom_kernel = "k_cg_onchip5<32,8,2>" if dom == "cg_onchip" else dom
         achieved = alg / avg_s / 1e9
         tn, nn = prof.get("skinny_tn_R32"), prof.get("skinny_nn_R32")
         mv_alg = 4 * B_PER_GPU * (N * R + N + 2 * N * C_COLS)  # 1,146,880 B per member
@@ -914,7 +1114,7 @@ def main():
         traffic, traffic_source = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_DIR, "traffic.json")))
-            if tj.get("prof_name") == dom:
+            if tj.get("prof_name") == dom and tj.get("kernel", "").startswith(dom_kernel.split("<")[0]):
                 traffic = tj["traffic_bytes_per_launch"]
                 traffic_source = (f"profiles/{PROFILE_DIR}/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                   f"`bench.py --no-extras`, kernel {tj['kernel']}, FETCH x2 (gfx950 correction) + WRITE")
@@ -946,7 +1146,7 @@ def main():
                              f"{os.environ.get('LO_OC_RESERVE_CUS', '0')} CUs' worth of slots to RCCL")
                 if world > 1 else "single GPU",
             },
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom_kernel, "prof_scope": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "achievable_peak": copy_gbs or HBM_ACHIEVABLE_GBS,
@@ -955,7 +1155,15 @@ def main():
                          "achievable_peak_source": "copy_this_box when measured (1 GiB float4 copy of this run), else "
                                                    "the MI355X guide's 6.29 TB/s",
                          "algorithmic_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6, "launches_timed": cnt,
-                         "note": ("per-launch compulsory bytes (C, d, 1/d, rhs in, x out, root-form preconditioner "
+                         "note": ("per-launch compulsory bytes (C, 1/d, rhs in, x out, the six fp64 R x R matrices of the "
+                                  "R-space form) / launch time.  The kernel holds a member's rows of C in VGPRs between "
+                                  "its one reduction over the rows and x = D^-1 (xi b + C y); the 11 iterations of the "
+                                  "floor run on R + 1 coordinates in fp64.  64 members are on chip at a time and a "
+                                  "member takes ~27 us from its first load to its last store (load 5, reduction + group "
+                                  "all-reduce 5 - 9, iterations 8 - 16, x 1.5: LO_OC_DEBUG stamps, profiles/r05), so "
+                                  "64 MB / 27 us = 2.4 TB/s: bound by that latency chain at the on-chip capacity, not by "
+                                  "HBM") if rs_engine else
+                                 ("per-launch compulsory bytes (C, d, 1/d, rhs in, x out, root-form preconditioner "
                                   "matrices; the kernel keeps the operator on chip for all 11 iterations) / launch time.  "
                                   "The kernel is bound by VALU issue and the latency of its per-iteration group "
                                   "all-reduce, not by HBM") if dom == "cg_onchip" else ""},
@@ -979,7 +1187,17 @@ def main():
             "rccl_ranks": world if use_dist else 0,
             "per_rank_ms": per_rank_ms,
             "allgather_ms": allgather_ms,
+            "gather_modes": gather_modes,
+            "engine": engine_timed,
+            "engine_per_rank": engines,
+            "resident_timeouts": sum(g_["timeouts"] for g_ in gates),
+            "resident_gate_per_rank": gates,
+            "matvec_engine": matvec_engine,
         }
+        if args.inject_timeouts > 0:
+            out["inject_timeouts"] = {"injected": args.inject_timeouts, "soak_engines": engines_seen,
+                                      "note": "engines of the soak's solves after the injected hand-off timeouts: "
+                                              "cool-down on the streaming engine, then the resident kernel again"}
         # the one-launch end-to-end kernel at the headline shape: live HIP-event time, compulsory bytes per launch
         with lo_settings.cg_tolerance(TOL):
             prof_e = _profiled(e2e_api)
@@ -1006,6 +1224,12 @@ def main():
             out["other_configs"] = strong
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(device=device)
+            if not args.no_extras:
+                torch.cuda.empty_cache()
+                try:  # (the headline line must not be lost to an extra)
+                    out["config_baselines"] = config_baselines(device)
+                except Exception as e:  # noqa: BLE001
+                    out["config_baselines_error"] = repr(e)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

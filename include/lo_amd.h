@@ -288,6 +288,24 @@ int lo_solve_fused_perm(const int32_t* swaps, int64_t B, int64_t N, int32_t rank
  * up to summation order. */
 int lo_cg_set_onchip(int enable);
 
+/* ---- the gate of the resident kernels (round 5, ABI 12) ------------------------------------------ */
+/* The resident kernels need every workgroup of a group co-resident.  When a group exchange times out (another
+ * kernel -- RCCL's, another process' -- holds part of the CUs) the call is redone on the streaming engines and the
+ * next `backoff` entry-point calls (lo_cg_solve_f32 / lo_pivoted_cholesky_f32) skip the resident kernels; then they
+ * are tried again.  Timeouts right after a re-arm double the cool-down (16 .. 4096 calls), a clean resident solve
+ * resets it.  (Rounds 2 - 4 latched the resident kernels off for the life of the process.)
+ * lo_resident_inject_timeouts(n): the next n resident CG launches are treated as timed out (tests, bench --inject). */
+typedef struct lo_resident_status {
+  int32_t user_disabled;  /* lo_cg_set_onchip(0)                                                   */
+  int32_t timeouts;       /* hand-off timeouts since the library was loaded                        */
+  int32_t cooldown;       /* entry-point calls still to be served by the streaming engines         */
+  int32_t backoff;        /* length of the next cool-down                                          */
+  int32_t rearms;         /* cool-downs that ended (resident kernels tried again)                  */
+  int32_t fused_timeouts; /* of `timeouts`: inside lo_solve_fused_f32                              */
+} lo_resident_status;
+int lo_resident_status_get(lo_resident_status* out);
+int lo_resident_inject_timeouts(int32_t n);
+
 /* ---- PivotedCholesky.forward (linear_operator/functions/_pivoted_cholesky.py:14-105) ---------- */
 /* Greedy partial pivoted Cholesky of the NON-diagonal part of `op` (op->d is ignored, as
  * added_diag_linear_operator.py:125 calls self._linear_op.pivoted_cholesky).

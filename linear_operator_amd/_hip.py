@@ -19,7 +19,7 @@ _lib = None
 LO_OP_LOWRANK_DIAG, LO_OP_DENSE_DIAG, LO_OP_KRON_DIAG, LO_OP_CALLBACK, LO_OP_SUM = 0, 1, 2, 3, 4
 LO_MAX_TERMS = 4
 LO_DIAG_NONE, LO_DIAG_FULL, LO_DIAG_CONST = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 LO_ERR_UNSUPPORTED = -4
 LO_FUSED_OK, LO_FUSED_EARLY_STOP, LO_FUSED_CONTINUE, LO_FUSED_TIMEOUT = 0, 1, 2, 3
@@ -29,6 +29,7 @@ EXPORTS = [
     "lo_abi_version", "lo_target_arch",
     "lo_matvec_workspace_bytes", "lo_matvec_f32",
     "lo_cg_workspace_bytes", "lo_cg_solve_f32", "lo_cg_set_onchip", "lo_cg_plan_f32", "lo_cg_last_executed",
+    "lo_resident_status_get", "lo_resident_inject_timeouts",
     "lo_solve_fused_supported", "lo_solve_fused_workspace_bytes", "lo_solve_fused_f32", "lo_solve_fused_perm",
     "lo_cg_f64_workspace_bytes", "lo_cg_solve_f64", "lo_minres_f64_workspace_bytes", "lo_minres_f64",
     "lo_pivoted_cholesky_workspace_bytes", "lo_pivoted_cholesky_f32",
@@ -93,6 +94,11 @@ class CgPlan(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "resident", "resident_iterations", "lockstep_cols", "lockstep_group", "serial_engine", "serial_group", "lean",
         "needs_q", "streaming_precond", "poll_chunk", "first_stop_iteration", "reserved", "rspace", "reserved2")]
+
+
+class ResidentStatus(C.Structure):
+    """lo_resident_status (include/lo_amd.h): the gate of the resident kernels."""
+    _fields_ = [(n, C.c_int32) for n in ("user_disabled", "timeouts", "cooldown", "backoff", "rearms", "fused_timeouts")]
 
 
 ENGINE_NAMES = {0: "none", 1: "gen1", 2: "gen2", 3: "root"}
@@ -291,6 +297,10 @@ def load():
                                             C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p]
     lib.lo_cg_set_onchip.restype = C.c_int
     lib.lo_cg_set_onchip.argtypes = [C.c_int]
+    lib.lo_resident_status_get.restype = C.c_int
+    lib.lo_resident_status_get.argtypes = [P(ResidentStatus)]
+    lib.lo_resident_inject_timeouts.restype = C.c_int
+    lib.lo_resident_inject_timeouts.argtypes = [C.c_int32]
     lib.lo_prof_enable.restype = C.c_int
     lib.lo_prof_enable.argtypes = [C.c_int]
     lib.lo_prof_report.restype = C.c_int

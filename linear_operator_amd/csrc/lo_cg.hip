@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cstddef>
 #include <cmath>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -28,6 +29,31 @@ namespace lo {
 
 bool g_onchip_disabled = false;
 int g_onchip_fused_timeouts = 0;
+// ---- the gate of the resident kernels (round 5; replaces the process-wide latch of rounds 2 - 4) ----
+// A hand-off timeout (co-residency lost: another kernel -- RCCL's, another process' -- holds part of the CUs) sends the
+// next `backoff` entry-point calls to the streaming engines, then the resident kernels are tried again ("re-armed").
+// A timeout right after a re-arm doubles the cool-down (16, 32, ... 4096 calls: a persistent loss costs one ~0.5 s spin
+// per cool-down, amortised to nothing); a clean resident solve resets it.  Everything is reported (lo_resident_status).
+constexpr int kResidentBackoff0 = 16, kResidentBackoffMax = 4096;
+static std::atomic<int> g_res_timeouts{0}, g_res_cooldown{0}, g_res_backoff{kResidentBackoff0}, g_res_rearms{0},
+    g_res_inject{0};
+bool resident_off() { return g_onchip_disabled || g_res_cooldown.load(std::memory_order_relaxed) > 0; }
+void resident_tick() {  // once per entry-point call that could use a resident kernel
+  int c = g_res_cooldown.load(std::memory_order_relaxed);
+  while (c > 0 && !g_res_cooldown.compare_exchange_weak(c, c - 1, std::memory_order_relaxed)) {
+  }
+  if (c == 1) {
+    g_res_rearms.fetch_add(1, std::memory_order_relaxed);
+    fprintf(stderr, "liblo_amd: resident kernels re-armed after their cool-down\n");
+  }
+}
+void resident_note_ok() { g_res_backoff.store(kResidentBackoff0, std::memory_order_relaxed); }
+bool resident_take_injection() {
+  int n = g_res_inject.load(std::memory_order_relaxed);
+  while (n > 0 && !g_res_inject.compare_exchange_weak(n, n - 1, std::memory_order_relaxed)) {
+  }
+  return n > 0;
+}
 void* pinned_status_block() {
   static thread_local void* p = nullptr;
   if (!p) {
@@ -60,10 +86,12 @@ static int wait_ticket(volatile unsigned* word, unsigned ticket, hipStream_t st)
 }
 void onchip_note_timeout() {
   if (getenv("LO_OC_TEST_FALLBACK")) return;
-  if (!g_onchip_disabled)
-    fprintf(stderr, "liblo_amd: a resident kernel lost its co-residency (hand-off timeout): resident kernels are switched "
-                    "off for this process (lo_cg_set_onchip(1) re-arms them)\n");
-  g_onchip_disabled = true;
+  g_res_timeouts.fetch_add(1, std::memory_order_relaxed);
+  const int bo = g_res_backoff.load(std::memory_order_relaxed);
+  g_res_cooldown.store(bo, std::memory_order_relaxed);
+  g_res_backoff.store(std::min(2 * bo, kResidentBackoffMax), std::memory_order_relaxed);
+  fprintf(stderr, "liblo_amd: a resident kernel lost its co-residency (hand-off timeout): the next %d calls run on the "
+                  "streaming engines, then the resident kernels are tried again (lo_resident_status)\n", bo);
 }
 // The result-only ("lean") first pass is speculative: when the stop rule does not hold at the floor the launches are
 // repeated with the continuation state.  An operator that missed is likely to miss again on its next solve (same tensors,
@@ -608,7 +636,7 @@ static void cg_plan(const lo_op_desc* op, const lo_precond_desc* pre, bool pre_c
   // advances 16 columns together on the matrix cores; the root-form kernel needs F / EF of the operator's own root)
   const bool oc_gen1_ok = !oc_nopre && prm->n_tridiag == 0 && c == 1 && onchip_eligible(RC, preR4, N, c);
   const bool oc_base = (op->kind == LO_OP_LOWRANK_DIAG) && RC <= kMaxRank && (pre || oc_nopre) && !pre_cb && !has_x0 &&
-                       prm->max_iter >= 11 && prm->max_iter > kfloor0 && oc_nwg >= 64 && !g_onchip_disabled &&
+                       prm->max_iter >= 11 && prm->max_iter > kfloor0 && oc_nwg >= 64 && !resident_off() &&
                        (prm->n_tridiag == 0 || sh.has_ab) && B < (1 << 24) - 1024;
   // column split: full chunks of 16 (and a last chunk of at least kLockstepMinCols) -> lockstep kernel, the rest serial
   int ls_cols = 0;
@@ -817,6 +845,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   hipStream_t st = (hipStream_t)stream;
   const int64_t B = op->B, N = op->N;
   const int c = (int)prm->c;
+  resident_tick();
 
   CgDev d;
   MatvecPlan pl;
@@ -846,7 +875,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   dim3 gridv(sp.S, (unsigned)B), block(kThreads);
 
   {  // control block (+ the granule buffer behind it when a resident kernel may run)
-    const bool oc_possible = op->kind == LO_OP_LOWRANK_DIAG && !g_onchip_disabled;
+    const bool oc_possible = op->kind == LO_OP_LOWRANK_DIAG && !resident_off();
     const size_t span = oc_possible ? (size_t)(reinterpret_cast<char*>(d.oc_close + B + 2) - reinterpret_cast<char*>(d.ctrl))
                                     : sizeof(CgCtrl);
     rc = zero_span(d.ctrl, span, st);
@@ -953,7 +982,9 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.dbg_member = oc_dbg ? atoi(getenv("LO_OC_DEBUG")) : (ls_dbg ? atoi(getenv("LO_LS_DEBUG")) : 0);
     // LO_OC_TEST_FALLBACK: start with the error word set, as if a hand-off had timed out (exercises the host fallback)
     // (error word and member counters live in the control block: cleared with it, copied back with it)
-    if (getenv("LO_OC_TEST_FALLBACK")) LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 1, 1, st));
+    // lo_resident_inject_timeouts(n): the same through the real bookkeeping (cool-down, re-arm) -- the multi-rank tests
+    if (getenv("LO_OC_TEST_FALLBACK") || (oc_pass == 0 && resident_take_injection()))
+      LO_HIP_CHECK(hipMemsetAsync(d.oc_err, 1, 1, st));
     if (oc_dbg || ls_dbg) LO_HIP_CHECK(hipMemsetAsync(d.oc_dbg, 0, 16 * sizeof(long long), st));
     rc = LO_OK;
     bool xout_ok = true;  // every launched kernel wrote result * rhs_norm itself
@@ -1126,6 +1157,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
         if (rs_cols_ran) ls_cols = ls_plan;  // (the repeat runs the engines of the plan)
       } else if (oc_err == 0) {
         k_start = a.iters;
+        resident_note_ok();
         if (lean_skipped && h.stop) tls_lean_miss[miss_slot].valid = 0;  // (it stops at the floor now: speculate again)
         exec.resident = 1;
         exec.lockstep_cols = ls_cols;
@@ -1448,7 +1480,27 @@ int lo_cg_last_executed(lo_cg_plan* out) {
 // development / test switch: force the streaming engine (0) or allow the operator-resident fast path (1)
 int lo_cg_set_onchip(int enable) {
   g_onchip_disabled = (enable == 0);
+  if (enable) {  // (also ends a cool-down)
+    g_res_cooldown.store(0, std::memory_order_relaxed);
+    g_res_backoff.store(kResidentBackoff0, std::memory_order_relaxed);
+  }
   for (int i = 0; i < 16; ++i) tls_lean_miss[i].valid = 0;  // (also forgets which operators missed their result-only pass)
+  return LO_OK;
+}
+
+// The gate of the resident kernels (see the top of this file).
+int lo_resident_status_get(lo_resident_status* out) {
+  if (!out) return LO_ERR_BADARG;
+  out->user_disabled = g_onchip_disabled ? 1 : 0;
+  out->timeouts = g_res_timeouts.load(std::memory_order_relaxed);
+  out->cooldown = g_res_cooldown.load(std::memory_order_relaxed);
+  out->backoff = g_res_backoff.load(std::memory_order_relaxed);
+  out->rearms = g_res_rearms.load(std::memory_order_relaxed);
+  out->fused_timeouts = g_onchip_fused_timeouts;
+  return LO_OK;
+}
+int lo_resident_inject_timeouts(int32_t n) {
+  g_res_inject.store(n < 0 ? 0 : n, std::memory_order_relaxed);
   return LO_OK;
 }
 

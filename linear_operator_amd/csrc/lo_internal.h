@@ -230,10 +230,15 @@ struct ResidentLaunch {
 extern thread_local bool tls_graph_capture;  // a CG iteration is being captured: no cross-stream event traffic
 extern bool g_onchip_disabled;  // lo_cg_set_onchip(0): streaming engines only (tests compare the two)
 extern int g_onchip_fused_timeouts;  // group exchanges of the fused solve that timed out in this process
-// A REAL hand-off timeout (co-residency lost: another process / kernel holds part of the CUs) latches the resident
-// kernels off for the rest of the process -- every later solve would pay the ~0.5 s spin again before falling back.
-// lo_cg_set_onchip(1) re-arms them.  The injected timeout of the tests (LO_OC_TEST_FALLBACK) does not latch.
+// A REAL hand-off timeout (co-residency lost: another process / kernel holds part of the CUs) sends the next calls to
+// the streaming engines for a cool-down (16 calls, doubling up to 4096 while the timeouts repeat), after which the
+// resident kernels are tried again; lo_cg_set_onchip(1) ends a cool-down at once (lo_cg.hip, lo_resident_status).
+// The injected timeout of LO_OC_TEST_FALLBACK does not start a cool-down; lo_resident_inject_timeouts does.
 void onchip_note_timeout();
+bool resident_off();            // user switch or cool-down: no resident kernel for this call
+void resident_tick();           // entry points: one call of the cool-down served
+void resident_note_ok();        // a resident solve completed: the next cool-down is short again
+bool resident_take_injection(); // lo_resident_inject_timeouts: treat this resident launch as timed out
 // Pinned host landing zone for the small status read-backs of the synchronous entry points (a device-to-host copy into
 // pageable memory is staged through an internal buffer and costs tens of microseconds more): one 256-byte block per
 // host thread, allocated on first use; nullptr if pinned memory is unavailable (callers then copy to their stack).

@@ -555,6 +555,7 @@ int lo_pivoted_cholesky_f32(const lo_op_desc* op, int32_t max_rank, float error_
   if (const int rc = pc_check_desc(op)) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int rank = (int)std::min<int64_t>(max_rank, op->N);  // :33
+  resident_tick();
   if (pc_onchip_eligible(op, max_rank)) {  // operator-resident fast path (lo_pivchol_onchip.hip), same results
     const int rc = pc_onchip_run(op, rank, max_rank, error_tol, L_rows, (long long*)perm, rank_out, ws, ws_bytes, st);
     if (rc != LO_ERR_LAUNCH) return rc;

@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(kThreads) void k_po_perm(PoArgs a, float tol, int* 
 }
 
 bool pc_onchip_eligible(const lo_op_desc* op, int max_rank) {
-  if (g_onchip_disabled || op->kind != LO_OP_LOWRANK_DIAG) return false;
+  if (resident_off() || op->kind != LO_OP_LOWRANK_DIAG) return false;
   const int64_t R = op->R;  // (any rank up to 32: zero-padded to 8 / 16 / 32 columns in the workspace)
   // (rank 17 .. 32: second generation only, one workgroup per CU -- needs a full group of the member's size)
   return R >= 1 && R <= 32 && max_rank <= P4_MAXR && op->N >= 256 &&
@@ -1230,7 +1230,7 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
 
 // ---- host side of k_pc_onchip_rows ----------------------------------------------------------------------------------
 bool pc_onchip_rows_eligible(const lo_op_desc* op, int max_rank) {
-  if (g_onchip_disabled || getenv("LO_PC_NO_RESIDENT_ROWS")) return false;
+  if (resident_off() || getenv("LO_PC_NO_RESIDENT_ROWS")) return false;
   if (op->kind == LO_OP_DENSE_DIAG) {
     if (!op->A0) return false;
   } else if (op->kind == LO_OP_KRON_DIAG) {

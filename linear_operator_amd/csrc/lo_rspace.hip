@@ -663,14 +663,22 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
       double acc[R4_NR];
 #pragma unroll
       for (int q = 0; q < R4_NR; ++q) acc[q] = xi * (double)bq[q];
+      // (eight coordinates of y at a time: with all 32 in registers at once the compiler spills four doubles here)
 #pragma unroll
-      for (int i = 0; i < RC; i += 2) {
-        const double2 y2 = *reinterpret_cast<const double2*>(&myv[i]);
+      for (int i0 = 0; i0 < RC; i0 += 8) {
 #pragma unroll
-        for (int q = 0; q < R4_NR; ++q) {
-          acc[q] = fma((double)Cr[q][i >> 1].x, y2.x, acc[q]);
-          acc[q] = fma((double)Cr[q][i >> 1].y, y2.y, acc[q]);
+        for (int i = i0; i < i0 + 8; i += 2) {
+          const double2 y2 = *reinterpret_cast<const double2*>(&myv[i]);
+#pragma unroll
+          for (int q = 0; q < R4_NR; ++q) {
+            acc[q] = fma((double)Cr[q][i >> 1].x, y2.x, acc[q]);
+            acc[q] = fma((double)Cr[q][i >> 1].y, y2.y, acc[q]);
+          }
         }
+        // (pins the partial sums here: otherwise the products sink into the four guarded stores below, each of which
+        //  then wants all of y in registers)
+#pragma unroll
+        for (int q = 0; q < R4_NR; ++q) asm volatile("" : "+v"(acc[q]));
       }
       int tw = t;
       asm volatile("" : "+v"(tw));
@@ -1218,7 +1226,7 @@ static int rspace_go(const OnchipArgs& a, int nwg, hipStream_t st) {
   int per_cu = 0;
   if (LO_OCCUPANCY_CACHED(per_cu, (k_cg_rspace<RC, GW>), R4_TPB, 0) != hipSuccess || per_cu < 2)
     return LO_ERR_UNSUPPORTED;
-  LO_PROF_BEGIN("cg_onchip", st);
+  LO_PROF_BEGIN("cg_onchip", st);  // (one scope for the resident single-column kernels: lo_cg_last_executed().rspace tells them apart)
   ResidentLaunch guard(st);
   hipLaunchKernelGGL((k_cg_rspace<RC, GW>), dim3(2 * nwg), dim3(R4_TPB), 0, st, a);
   LO_PROF_END(st);

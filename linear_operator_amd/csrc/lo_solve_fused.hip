@@ -128,7 +128,7 @@ using namespace lo;
 extern "C" {
 
 int lo_solve_fused_supported(const lo_op_desc* op, int32_t rank, const lo_cg_params* prm) {
-  if (!op || !prm || g_onchip_disabled || getenv("LO_NO_FUSED_SOLVE")) return 0;
+  if (!op || !prm || resident_off() || getenv("LO_NO_FUSED_SOLVE")) return 0;
   if (op->kind != LO_OP_LOWRANK_DIAG || (op->diag_mode != LO_DIAG_FULL && op->diag_mode != LO_DIAG_CONST)) return 0;
   if (!(op->R == 8 || op->R == 16 || op->R == 32)) return 0;
   if (rank < 1 || rank > FU_MAXRANK || rank > op->N) return 0;

@@ -1203,5 +1203,20 @@ def bilinear_kron(K1: torch.Tensor, K2: torch.Tensor, left_vecs: torch.Tensor, r
 
 
 def set_onchip_cg(enable: bool):
-    """Allow (default) or forbid the operator-resident CG fast path (csrc/lo_cg_onchip.hip); test / A-B switch."""
+    """Allow (default) or forbid the operator-resident CG fast path (csrc/lo_cg_onchip.hip); test / A-B switch.
+    Enabling also ends a cool-down of the resident kernels (`resident_status`)."""
     _hip.load().lo_cg_set_onchip(1 if enable else 0)
+
+
+def resident_status() -> dict:
+    """lo_resident_status_get: the gate of the resident kernels -- hand-off timeouts seen by this process, calls still
+    to be served by the streaming engines (cool-down), length of the next cool-down, re-arms so far."""
+    out = _hip.ResidentStatus()
+    _hip.check(_hip.load().lo_resident_status_get(C.byref(out)), "lo_resident_status_get")
+    return {n: int(getattr(out, n)) for n, _ in _hip.ResidentStatus._fields_}
+
+
+def inject_resident_timeouts(n: int):
+    """lo_resident_inject_timeouts: the next n resident CG launches are treated as timed out (the solve is redone on
+    the streaming engine and a cool-down starts) -- tests and `bench.py --inject-timeouts`."""
+    _hip.check(_hip.load().lo_resident_inject_timeouts(int(n)), "lo_resident_inject_timeouts")
