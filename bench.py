@@ -758,11 +758,11 @@ def main():
                     help="after the timed K steps: keep stepping (each step timed on its own) for about this much wall "
                          "time -- per-step min / median / max for the JSON line, and a GPU that an external "
                          "utilisation sampler sees busy.  0 = off.  `value` / `ms_per_step` come from the K steps only")
-    ap.add_argument("--gather", choices=["step", "end"], default="step",
-                    help="N > 1: `step` = one all-gather of the solutions per solve, overlapped with the next solve "
-                         "(default: the demanding reading); `end` = ONE all-gather after the K steps, inside the timed "
-                         "region (north_star's literal `at the end`).  The other mode is timed as well and reported "
-                         "under `gather_modes`")
+    ap.add_argument("--gather", choices=["step", "end"], default="end",
+                    help="N > 1: `end` (default) = ONE all-gather of the solutions after the K steps, inside the timed "
+                         "region (north_star: `an RCCL all-gather over xGMI at the end`); `step` = one all-gather per "
+                         "solve, overlapped with the next solve (the demanding reading: 16 MB per rank every 0.25 ms).  "
+                         "The other mode is timed over the same K steps as well and reported under `gather_modes`")
     ap.add_argument("--inject-timeouts", type=int, default=0,
                     help="treat the first n resident CG launches of the soak as timed out (exercises the cool-down / "
                          "re-arm gate of the resident kernels; the JSON line reports what the gate did)")
@@ -822,11 +822,12 @@ def main():
         os.close(real_stdout)
         return
 
+    reserve_default = None
     if use_dist:
-        # The all-gather of solve k runs on RCCL's stream while solve k + 1 computes.  The resident CG kernel fills every
+        # (--gather step) The all-gather of solve k runs on RCCL's stream while solve k + 1 computes.  The resident CG kernel fills every
         # CU with two workgroups; a workgroup RCCL's kernel displaces stalls its whole group until the gather ends.
         # Leaving 32 CUs' worth of slots unused (liblo_amd reads the variable at every launch) gives RCCL room.
-        os.environ.setdefault("LO_OC_RESERVE_CUS", "32")
+        reserve_default = os.environ.get("LO_OC_RESERVE_CUS")  # (an explicit setting of the caller wins in both modes)
     # The quick numbers of the other BASELINE configs run FIRST (single GPU): several seconds of the library's own
     # kernels, after which the device sits at its steady clocks -- right after start-up the same solve is ~7 % slower
     # and speeds up over its first ~40 launches (tools/mb_step_ramp.py: 0.400 -> 0.372 ms per step), a ramp that would
@@ -848,7 +849,15 @@ def main():
     pending = []  # [(work handle, tensor being gathered)]
     nstep = [0]
 
-    gather_mode = [args.gather]
+    gather_mode = [None]
+
+    def set_gather_mode(m):
+        """`step`: RCCL's all-gather kernel runs beside the solves -- leave it 32 CUs' worth of workgroup slots."""
+        gather_mode[0] = m
+        if use_dist and reserve_default is None:
+            os.environ["LO_OC_RESERVE_CUS"] = "32" if m == "step" else "0"
+
+    set_gather_mode(args.gather)
     engines_seen = {}
 
     def step():
@@ -977,9 +986,9 @@ def main():
     gather_modes = None
     if use_dist:
         other = "end" if args.gather == "step" else "step"
-        gather_mode[0] = other
+        set_gather_mode(other)
         other_ms = timed_region(args.steps)
-        gather_mode[0] = args.gather
+        set_gather_mode(args.gather)
         gather_modes = {args.gather: elapsed / args.steps * 1e3, other: other_ms, "timed_as_value": args.gather,
                         "note": "`step`: one all-gather of the solutions per solve, overlapped with the next solve; "
                                 "`end`: ONE all-gather after the K steps, inside the timed region"}
@@ -1141,9 +1150,12 @@ def main():
                             "cg_tolerance 1e-4 -> 11 iterations (floor)",
                 "batch_per_gpu": B_PER_GPU, "N": N, "R": R, "rhs_columns": C_COLS, "precond_rank": RANK_K,
                 "iterations": res.iterations, "matvecs_per_solve": matvecs_per_solve,
-                "sharding": (f"batch x{world}, one all_gather of the solutions per solve, issued asynchronously and overlapped "
-                             "with the next solve; resident kernels leave "
-                             f"{os.environ.get('LO_OC_RESERVE_CUS', '0')} CUs' worth of slots to RCCL")
+                "sharding": ((f"batch x{world}, no collective inside the solve; ONE all_gather of the solutions after the K "
+                              "steps, inside the timed region (--gather end; the per-solve overlapped gather is timed "
+                              "beside it: gather_modes)") if args.gather == "end" else
+                             (f"batch x{world}, one all_gather of the solutions per solve, issued asynchronously and "
+                              "overlapped with the next solve; resident kernels leave "
+                              f"{os.environ.get('LO_OC_RESERVE_CUS', '0')} CUs' worth of slots to RCCL (--gather step)"))
                 if world > 1 else "single GPU",
             },
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "prof_scope": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -966,7 +966,10 @@ def lanczos_tridiag(desc: Optional[OperatorDescriptor], init_vecs: torch.Tensor,
         # the reference's q_mat [P, *batch, N, k] (lanczos.py:154) as a VIEW of the basis in the layout the step kernels
         # write it ([k, B, N, P]): same shape, same values, no 5 GB copy at the cfg3 shape.  The consumers on the path
         # (root_from_lanczos below) read this layout directly; anything else sees an ordinary strided tensor.
-        q_out = q[:k].reshape(k, *batch, N, P).permute(-1, *range(1, 1 + nb), -2, 0)
+        # (an early stop -- k well below the allocated steps -- must not keep the whole basis buffer alive behind the view:
+        #  ADVICE r4)
+        qk = q[:k] if k == q.shape[0] else q[:k].clone()
+        q_out = qk.reshape(k, *batch, N, P).permute(-1, *range(1, 1 + nb), -2, 0)
     t_out = t.permute(-1, *range(2, 2 + nb), 0, 1).contiguous()  # :156
     if P == 1:  # squeeze_(0) (:159-161) only acts on a size-1 leading dim
         q_out, t_out = q_out[0], t_out[0]
@@ -1018,7 +1021,7 @@ def lanczos_tridiag_f64(A: Optional[torch.Tensor], diag: Optional[torch.Tensor],
     _hip.check(rc, "lo_lanczos_tridiag_f64")
     k = iters.value
     nb = len(batch)
-    q_out = q[:k].reshape(k, *batch, N, P).permute(-1, *range(1, 1 + nb), -2, 0)
+    q_out = (q[:k] if k == q.shape[0] else q[:k].clone()).reshape(k, *batch, N, P).permute(-1, *range(1, 1 + nb), -2, 0)
     t_out = t[:k, :k].reshape(k, k, *batch, P).permute(-1, *range(2, 2 + nb), 0, 1).contiguous()
     if P == 1:
         q_out, t_out = q_out[0], t_out[0]

@@ -87,18 +87,18 @@ class DiagLinearOperator(TriangularLinearOperator):
         return rhs / self._diag.unsqueeze(-1).pow(2)
 
     def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
-        """Elementwise: sum_n rhs^2 / d and sum_n log d; vector right-hand sides are one column; terms that were not
-        asked for are EMPTY tensors (reference :161-191)."""
+        """Elementwise: sum_n rhs^2 / d and sum_n log d; terms that were not asked for are EMPTY tensors (reference
+        :161-191).  The trailing dimensions of the right-hand side beyond [*batch, N] are its columns; as in the reference
+        (:174-184) the final `.sum(-1)` of reduce_inv_quad is applied whatever is left -- for a [*batch, N] right-hand
+        side of a batched operator that is the last BATCH dimension (a quirk of the reference, kept: drop-in)."""
         empty = torch.empty(0, dtype=self.dtype, device=self.device)
         inv_quad_term = empty
         if inv_quad_rhs is not None:
-            if inv_quad_rhs.dim() == 1 or inv_quad_rhs.dim() == self._diag.dim():
-                # [*batch, N]: one column, already reduced
-                inv_quad_term = (inv_quad_rhs * inv_quad_rhs / self._diag).sum(-1)
-            else:
-                inv_quad_term = (inv_quad_rhs * inv_quad_rhs / self._diag.unsqueeze(-1)).sum(-2)
-                if reduce_inv_quad:
-                    inv_quad_term = inv_quad_term.sum(-1)
+            n_cols = inv_quad_rhs.dim() - self._diag.dim()  # len(rhs.shape[1 + batch_dim:])
+            diag = self._diag.reshape(*self._diag.shape, *([1] * max(n_cols, 0)))
+            inv_quad_term = (inv_quad_rhs / diag * inv_quad_rhs).sum(-(1 + max(n_cols, 0)))
+            if reduce_inv_quad:
+                inv_quad_term = inv_quad_term.sum(-1)
         logdet_term = self._diag.log().sum(-1) if logdet else empty
         return inv_quad_term, logdet_term
 

@@ -34,7 +34,7 @@ def cholesky_solve(rhs, factor, upper=False):
     more than 512 rows (float32 and float64; two or more columns, one matrix, and n <= 512 are fine --
     tools/probe/chol_solve_batched.py) ends in `unspecified launch failure`.  Such a column is solved twice side by side
     and the first copy returned."""
-    if (rhs.is_cuda and rhs.dim() > 2 and rhs.shape[-1] == 1 and factor.shape[-1] > 512
+    if (rhs.is_cuda and rhs.dim() >= 2 and rhs.shape[-1] == 1 and factor.shape[-1] > 512
             and torch.broadcast_shapes(rhs.shape[:-2], factor.shape[:-2]).numel() > 1):
         return torch.cholesky_solve(rhs.expand(*rhs.shape[:-1], 2).contiguous(), factor, upper=upper)[..., :1]
     return torch.cholesky_solve(rhs, factor, upper=upper)

@@ -16,6 +16,7 @@ tensors and closures, what the reference's own test/utils/test_linear_cg.py runs
 """
 from __future__ import annotations
 
+import threading
 import warnings
 
 import torch
@@ -43,33 +44,38 @@ def _default_preconditioner(x):
 # solve, the next step of a training loop): remember the miss and skip the speculation for the next few solves of the
 # same operator / settings, then try again.
 _FUSED_MISSES: dict = {}
+_FUSED_MISSES_LOCK = threading.Lock()
 _FUSED_SKIP_AFTER_MISS = 8
 
 
 def _fused_key(desc, rhs, rank, pc_tol, tolerance, n_iter):
+    """Signature of a solve whose one-launch attempt missed.  Address AND version counter of the leaves: a freed
+    operator's address reused by another operator, or the same tensor after an in-place update, is a new key."""
     d = getattr(desc, "d", None)
-    return (desc.A0.data_ptr(), 0 if d is None else d.data_ptr(), desc.B, desc.N, desc.R, int(rhs.shape[-1]), int(rank),
-            float(pc_tol), float(tolerance), int(n_iter))
+    return (desc.A0.data_ptr(), desc.A0._version, 0 if d is None else d.data_ptr(), 0 if d is None else d._version,
+            desc.B, desc.N, desc.R, int(rhs.shape[-1]), int(rank), float(pc_tol), float(tolerance), int(n_iter))
 
 
 def _fused_worth_trying(key) -> bool:
-    left = _FUSED_MISSES.get(key)
-    if left is None:
-        return True
-    if left <= 0:
-        del _FUSED_MISSES[key]  # (a retry: conditions may have changed)
-        return True
-    _FUSED_MISSES[key] = left - 1
-    return False
+    with _FUSED_MISSES_LOCK:
+        left = _FUSED_MISSES.get(key)
+        if left is None:
+            return True
+        if left <= 0:
+            del _FUSED_MISSES[key]  # (a retry: conditions may have changed)
+            return True
+        _FUSED_MISSES[key] = left - 1
+        return False
 
 
 def _fused_note(key, hit: bool):
-    if hit:
-        _FUSED_MISSES.pop(key, None)
-        return
-    if len(_FUSED_MISSES) >= 64:
-        _FUSED_MISSES.pop(next(iter(_FUSED_MISSES)))
-    _FUSED_MISSES[key] = _FUSED_SKIP_AFTER_MISS
+    with _FUSED_MISSES_LOCK:
+        if hit:
+            _FUSED_MISSES.pop(key, None)
+            return
+        if len(_FUSED_MISSES) >= 64:
+            _FUSED_MISSES.pop(next(iter(_FUSED_MISSES)))
+        _FUSED_MISSES[key] = _FUSED_SKIP_AFTER_MISS
 
 
 def _lower_matmul_closure(matmul_closure, batch_shape):

@@ -128,3 +128,43 @@ def test_golden_logdet_through_a_common_fp64_eigendecomposition():
     floor = 2048 * 1.2e-7 * 137.0
     np.testing.assert_allclose(ld_r, g["logdet"].reshape(-1), rtol=1e-4, atol=floor)
     np.testing.assert_allclose(ld_h, g["logdet"].reshape(-1), rtol=1e-4, atol=floor)
+
+
+# ------------------------------------------------ Lanczos at 1e-4 where the reference's fp32 and fp64 runs agree (g27)
+def _leading_agreement(a32, a64, tol):
+    """Largest k such that the reference's own float32 run is within tol of its float64 run on every leading index < k
+    (last axis), measured per index against the scale of the float64 values."""
+    a32, a64 = np.asarray(a32, dtype=np.float64), np.asarray(a64, dtype=np.float64)
+    k = 0
+    for j in range(min(a32.shape[-1], a64.shape[-1])):
+        if np.abs(a32[..., : j + 1] - a64[..., : j + 1]).max() > tol:
+            break
+        k = j + 1
+    return k
+
+
+@pytest.mark.parametrize("case", ["batch", "cfg3"])
+def test_lanczos_at_1e4_on_the_block_where_the_reference_agrees_with_itself(case):
+    g = load_golden("g27_lanczos_divergence")
+    if case == "batch":
+        C, d, _ = cases.lowrank_diag(511, 2, 256, 8, 1)
+        V, steps = cases.randn(512, 2, 256, 3, dtype=np.float32), 10
+    else:
+        C, d, _ = cases.lowrank_diag(2701, 2, 2048, 32, 1)
+        V, steps = cases.randn(2702, 2, 2048, 4, dtype=np.float32), 20
+    q, t = K.lanczos_tridiag(K.lowrank_diag_descriptor(dev(C), dev(d)), dev(V), steps)
+    q, t = host(q).astype(np.float64), host(t).astype(np.float64)
+    t32, t64, q32, q64 = g[f"t_{case}_f32"], g[f"t_{case}_f64"], g[f"q_{case}_f32"], g[f"q_{case}_f64"]
+    assert q.shape == q64.shape and t.shape == t64.shape
+    scale = np.abs(t64).max()
+    # tridiagonals: entries (i, j <= k) -- the reference's float32 run within 1e-5 of its float64 run there
+    colerr = np.abs(np.asarray(t32, np.float64) - t64).max(-2) / scale  # worst entry of every column
+    kt = _leading_agreement(colerr, np.zeros_like(colerr), 1e-5)
+    assert kt >= steps // 2, kt
+    assert np.abs(t[..., :kt, :kt] - t64[..., :kt, :kt]).max() <= 1e-4 * scale
+    # basis vectors (unit columns): column error in the 2-norm
+    e32 = np.sqrt(((np.asarray(q32, np.float64) - q64) ** 2).sum(-2))
+    kq = _leading_agreement(e32, np.zeros_like(e32), 3e-5)
+    assert kq >= steps // 2, kq
+    eh = np.sqrt(((q - q64) ** 2).sum(-2))
+    assert eh[..., :kq].max() <= 1e-4, eh[..., :kq].max()

@@ -10,6 +10,8 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 Cm, d, rhs = bench.make_problem(dev, 1234)
 desc = K.lowrank_diag_descriptor(Cm, d); pre = bench.build_precond(desc, d)
 bufs = [torch.empty(512, 8192, 1, device=dev) for _ in range(2)]
+big_src = torch.empty(7 * 512, 8192, 1, device=dev)   # what 7 peers would write into this rank per step at 8 ranks
+big_dst = [torch.empty(7 * 512, 8192, 1, device=dev) for _ in range(2)]
 def run(mode, steps=40):
     pend = []
     def solve(): return K.cg_solve(desc, rhs, precond=pre, tolerance=1e-4)
@@ -23,10 +25,13 @@ def run(mode, steps=40):
         elif mode == "copy":  # same bytes moved by a plain device copy on a side stream
             with torch.cuda.stream(side):
                 side.wait_stream(torch.cuda.current_stream()); bufs[k % 2].copy_(r.x)
+        elif mode == "copy8":  # the HBM side of an 8-rank gather: 112 MB written per step (here also read) on a side stream
+            with torch.cuda.stream(side):
+                side.wait_stream(torch.cuda.current_stream()); big_dst[k % 2].copy_(big_src)
     for w, _ in pend: w.wait()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / steps * 1e3
 side = torch.cuda.Stream()
 for reserve in ("0", "32"):
     os.environ["LO_OC_RESERVE_CUS"] = reserve
-    print(f"reserve {reserve}: solve only {run('none'):.3f} ms | + inline gather {run('inline'):.3f} ms | + side-stream copy {run('copy'):.3f} ms")
+    print(f"reserve {reserve}: solve only {run('none'):.3f} ms | + inline gather {run('inline'):.3f} ms | + side-stream copy {run('copy'):.3f} ms | + 112 MB side-stream copy per step (8-rank inbound volume) {run('copy8'):.3f} ms")
 dist.destroy_process_group()
