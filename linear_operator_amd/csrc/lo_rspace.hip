@@ -423,6 +423,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
       for (int q = 0; q < NH / 2; ++q) frow[q] = (wave == 1 || wave == 2) ? fsrc[q] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // ---- group all-reduce of NP doubles: thread tt < NP owns component tt (two granules: low | high word) ----
+    if (a.prefetch & 4) __builtin_amdgcn_s_setprio(3);
     {
       const unsigned tag = ++g.tag;
       __syncthreads();
@@ -475,6 +476,11 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
     }
     if (stamp) a.dbg[2] = wall_clock64();
     const int64_t b_next = (int64_t)rs.res[2 * RC + 2];
+    // The iterations are ONE dependent chain per wave (~200 instructions each, 0.6 us when nothing competes) that shares
+    // its SIMD with a wave of the CU's other workgroup; when that one is in its instruction-dense reduction the chain ran
+    // up to twice as long (8.3 .. 15.8 us per member).  Raised priority lets the chain issue whenever it is ready, the
+    // dense phase of the other workgroup fills the gaps.
+    if (a.prefetch & 1) __builtin_amdgcn_s_setprio(3);
 
     // ---- the iterations, on R + 1 coordinates.  All four waves carry the (replicated) state; wave m owns matrix m of
     // E | F E | E F E | G2 and contributes its product with g, one barrier per iteration joins them:
@@ -647,6 +653,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
         }
       }
     }
+    if (!(a.prefetch & 2)) __builtin_amdgcn_s_setprio(0);
     if (stamp) a.dbg[3] = wall_clock64();
     // ---- x = nrm D^-1 (xi r0 + C y) = D^-1 (xi b + C (nrm y)), in fp64 (for small diagonals the two terms cancel); every
     // wave reads its own copy of y ----
@@ -687,6 +694,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
         if (tw + R4_TPB * q < nv) a.xout[(size_t)b * a.N + row0 + tw + R4_TPB * q] = (float)(acc[q] * (double)diq[q]);  // :335
       __builtin_amdgcn_wave_barrier();
     }
+    __builtin_amdgcn_s_setprio(0);
     if (stamp) a.dbg[4] = wall_clock64();
     b = b_next;
   }
@@ -1228,7 +1236,12 @@ static int rspace_go(const OnchipArgs& a, int nwg, hipStream_t st) {
     return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("cg_onchip", st);  // (one scope for the resident single-column kernels: lo_cg_last_executed().rspace tells them apart)
   ResidentLaunch guard(st);
-  hipLaunchKernelGGL((k_cg_rspace<RC, GW>), dim3(2 * nwg), dim3(R4_TPB), 0, st, a);
+  OnchipArgs a2 = a;
+  {  // wave-priority mask of the latency-critical phases (1: iterations, 2: x pass as well, 4: all-reduce as well)
+    const char* e = getenv("LO_RS_PRIO");
+    a2.prefetch = e ? atoi(e) : 1;
+  }
+  hipLaunchKernelGGL((k_cg_rspace<RC, GW>), dim3(2 * nwg), dim3(R4_TPB), 0, st, a2);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   tls_rspace_resident_ran = true;
