@@ -415,7 +415,9 @@ def other_configs(device):
     desc = K.lowrank_diag_descriptor(Cm, d)
 
     def iql():
-        pre = build_precond(desc, d)
+        # (root form + fp64 Gram matrices, no generic Q: what AddedDiagLinearOperator._init_cache builds since round 5 --
+        #  Q is built on demand by the engines that take it, never on this path)
+        pre = build_precond(desc, d, need_q=False)
         r = K.cg_solve(desc, full, precond=pre, n_tridiag=16, tolerance=TOL)
         _, _, ld = K.tridiag_eigh_slq(r.t_mat, N)
         return r, ld + pre.logdet

@@ -53,6 +53,8 @@ struct PoArgs {
   unsigned long long* gbuf;  // [ngroups][2][PO_GW][PO_SLOT]
   int* err;
   int allow_l2_handoff;
+  int prio;        // k_pc_onchip4: wave-priority mask (LO_PC_PRIO): 1 = the candidate reduction / exchange / winner part of
+                   // a pivot runs at raised priority, the instruction-dense Schur update at normal priority
   long long* dbg;  // optional phase timers (wall_clock64 ticks) of member 0 / workgroup 0, or nullptr
 };
 
@@ -522,6 +524,7 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
     if (stamp) a.dbg[1] = wall_clock64();
     for (int m = 0; m < a.rank; ++m) {
       if (stamp) c0 = wall_clock64();
+      if (a.prio & 1) __builtin_amdgcn_s_setprio(3);
       // ---- workgroup candidate: argmax of the running diagonal over the positions >= m, error 1-norm partial ----
       float bv = -INFINITY, es = 0.f;
       int bj = PO_INVALID;
@@ -628,6 +631,7 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
       // row, applied below only where the reference writes)
       long long d0 = 0, d1 = 0, d2 = 0;
       if (stamp) d0 = wall_clock64();
+      if (!(a.prio & 2)) __builtin_amdgcn_s_setprio(0);
       float rowv[P4_NR], accs[P4_NR];
 #pragma unroll
       for (int q = 0; q < P4_NR; ++q) rowv[q] = gc[0] * Cr[q][0];
@@ -686,6 +690,7 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
         a.dbg[6] += c3 - c2;
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     if (stamp) a.dbg[2] = wall_clock64();
 
     // ---- L rows -> global, [max_rank, N] layout, consecutive threads = consecutive rows ----
@@ -1162,6 +1167,10 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   a.RW = (int)((op->N + gw - 1) / gw);
   a.rank = rank;
   a.max_rank = max_rank;
+  {
+    const char* e = getenv("LO_PC_PRIO");
+    a.prio = e ? atoi(e) : 1;
+  }
   a.L = L_rows;
   a.err_rec = l.err_rec;
   a.orig = l.orig;

@@ -52,7 +52,7 @@ def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, U, 
             q = pre.q
             dinv = (1.0 / pre.noise).squeeze(-1)  # [*batch, N | 1]
         else:
-            q = wb.Q[..., : wb.k]
+            q = wb.ensure_q().Q[..., : wb.k]
             dinv = wb.dinv.unsqueeze(-1) if wb.constant_diag else wb.dinv
         # diag(P^-1) = 1/d - rowsum(Q^2): the row sums as ONE reduction pass (norm, squared) instead of a product
         # tensor and its sum (250 -> 60 us at 512 x 8192 x 16)

@@ -268,7 +268,7 @@ def minres_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, shifts: 
         pc_cb, pc_err = _wrap_closure(lambda v: precond_closure(v.reshape(*bshape_p, N, c)), dev)
     else:
         pc_cb, pc_err = _hip.MATVEC_CB(), []
-    pre_s = precond.c_struct() if precond is not None else None
+    pre_s = precond.ensure_q().c_struct() if precond is not None else None  # (MINRES applies the Q form)
     pre_p = C.byref(pre_s) if pre_s is not None else None
     prm = _hip.MinresParams()
     prm.c, prm.n_shifts, prm.max_iter = c, Q, max_iter

@@ -139,6 +139,7 @@ class LazyWoodburyPreconditionClosure:
 # solve inside Solve.backward, each factorise again; here those calls hit the memo.  The entry keeps the tensors alive
 # (so an address cannot be reused by other data) and any in-place update bumps the version counter.
 PRECONDITIONER_MEMO_SIZE = 2
+_LAZY_Q = object()  # AddedDiagLinearOperator._q_cache of a root-form preconditioner whose Q has not been asked for
 _precond_memo: "list[tuple]" = []
 # root-form-only preconditioners the fused end-to-end solve produced (no L, no Q): enough for later SOLVES with the
 # same tensors; `_preconditioner()` (probe sampling, logdet terms) ignores them and builds in full
@@ -384,7 +385,12 @@ class AddedDiagLinearOperator(SumLinearOperator):
         perm = getattr(self, "_piv_chol_perm", None)
         if root is not None and perm is not None and root.is_cuda and root.dtype == torch.float32 and root.shape[-1] <= 32:
             root = root.detach().expand(*batch_shape, *root.shape[-2:])
-            self._woodbury = K.precond_build(L, d_arg.to(torch.float32), self._constant_diag, root=root, perm=perm)
+            # (root form + fp64 Gram matrices only: everything a first solve / inv_quad_logdet launches -- the resident
+            #  kernels and the R-space passes -- works from them; the generic Q of the reference's cache, 0.2 ms at the cfg3
+            #  shape, is built when something asks for it: WoodburyPreconditioner.ensure_q -- the streaming engine, the
+            #  stand-alone preconditioner apply, MINRES, the diagonal's logdet gradient)
+            self._woodbury = K.precond_build(L, d_arg.to(torch.float32), self._constant_diag, root=root, perm=perm,
+                                             need_q=False)
         else:
             # a Kronecker operator (two dense groups) with a constant diagonal also gets the Kronecker root form: the
             # single-column CG of large N then forms the rows of the preconditioner's tall matrix on the fly
@@ -395,7 +401,10 @@ class AddedDiagLinearOperator(SumLinearOperator):
                         and tuple(base.batch_shape) == tuple(batch_shape)):
                     kron = K._with_diag(base, d_arg.to(torch.float32), True)
             self._woodbury = K.precond_build(L, d_arg.to(torch.float32), self._constant_diag, perm=perm, kron=kron)
-        self._q_cache = self._woodbury.Q[..., : self._woodbury.k].reshape(*batch_shape, n, self._woodbury.k)
+        # (`_q_cache is not None` = "the cache is built", as in the reference :63-70; the tensor itself is only read on the
+        #  dense float64 / wide-rank route above, a root-form preconditioner carries its Q lazily)
+        self._q_cache = (_LAZY_Q if self._woodbury.Q is None else
+                         self._woodbury.Q[..., : self._woodbury.k].reshape(*batch_shape, n, self._woodbury.k))
         logdet = self._woodbury.logdet
         self._precond_logdet_cache = logdet.view(*batch_shape) if len(batch_shape) else logdet.squeeze()  # :172,:184
         self._precond_lt = PsdSumLinearOperator(RootLinearOperator(L), self._diag_tensor)  # :159

@@ -63,7 +63,7 @@ def minres(matmul_closure, rhs, eps=1e-25, shifts=None, value=None, max_iter=Non
     woodbury, precond_closure = None, None
     if preconditioner is not None:
         woodbury = getattr(preconditioner, "woodbury", None)
-        if woodbury is not None and tuple(woodbury.Q.shape[:-2]) != (max(1, batch_shape.numel()),):
+        if woodbury is not None and int(woodbury.dinv.shape[0]) != max(1, batch_shape.numel()):
             woodbury = None
         if woodbury is None:
             precond_closure = preconditioner

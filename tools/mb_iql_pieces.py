@@ -11,7 +11,7 @@ d = torch.rand(B, N, generator=g, device=dev) + 0.5
 full = torch.randn(B, N, 17, generator=g, device=dev); full[..., :16] /= full[..., :16].norm(dim=-2, keepdim=True)
 desc = K.lowrank_diag_descriptor(Cm, d)
 def iql():
-    pre = bench.build_precond(desc, d)
+    pre = bench.build_precond(desc, d, need_q=False)
     r = K.cg_solve(desc, full, precond=pre, n_tridiag=16, tolerance=1e-4)
     _, _, ld = K.tridiag_eigh_slq(r.t_mat, N)
     return r, ld + pre.logdet
