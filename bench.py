@@ -888,6 +888,8 @@ def main():
         e = K.cg_last_executed()
         if not e["resident"]:
             return "streaming"
+        if e["rspace"] == "resident" and e.get("rspace_diag"):
+            return "resident R-space, diagonal form (k_cg_rspace<..,true>)"
         return {"resident": "resident R-space (k_cg_rspace)", "cols": "R-space columns (k_rs_part/iter/apply)",
                 "none": "resident three-pass (k_cg_onchip5)"}[e["rspace"]]
 
@@ -1007,6 +1009,30 @@ def main():
         matvec_engine = {"engine": eng3, "ms_per_step": ms3, "value": total_members * matvecs_per_solve / (ms3 * 1e-3),
                          "note": "LO_OC_NO_RSPACE=1: the 11 operator applications carried out on the rows of C in VGPRs "
                                  "(three passes over the registers per iteration); same systems, same stop rule"}
+    # ---- the same K steps on the DENSE R-space iteration (four R x R products per iteration; the form a fresh cache
+    # carries before its second solve) and the cost of the diagonal form this rank's cache was given ----
+    rspace_dense_engine = None
+    if engine_timed.startswith("resident R-space, diagonal"):
+        os.environ["LO_RS_NO_DIAG"] = "1"
+        try:
+            ms4 = timed_region(args.steps)
+            eng4 = engine_now()
+        finally:
+            del os.environ["LO_RS_NO_DIAG"]
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            pre.RSD = None
+            pre.ensure_eigform()
+        torch.cuda.synchronize(device)
+        rspace_dense_engine = {"engine": eng4, "ms_per_step": ms4,
+                               "value": total_members * matvecs_per_solve / (ms4 * 1e-3),
+                               "eigform_build_ms": (time.perf_counter() - t0) / 5 * 1e3,
+                               "note": "LO_RS_NO_DIAG=1: k_cg_rspace<..,false>, the iteration with the four R x R products; "
+                                       "eigform_build_ms = lo_precond_eigform_f32 for this rank's members (two Jacobi "
+                                       "eigendecompositions each), paid ONCE per preconditioner cache when it serves its "
+                                       "second single-column solve (kernels.EIGFORM_AFTER_USES) -- outside the timed "
+                                       "region, as the pivoted Cholesky and the root form are"}
     # ---- per-rank engine and gate of the resident kernels: a line measured on the streaming engine says so ----
     engines = [engine_timed]
     gates = [gate]
@@ -1089,11 +1115,17 @@ def main():
         cnt, ms = prof[dom]
         avg_s = ms / cnt * 1e-3
         rs_engine = dom == "cg_onchip" and K.cg_last_executed()["rspace"] == "resident"
-        if rs_engine:
+        rs_diag = rs_engine and K.cg_last_executed().get("rspace_diag", False)
+        if rs_diag:
+            # k_cg_rspace<..,true>: C, 1/d, the right-hand side in, x out, and four fp64 R x R matrices + R eigenvalues of
+            # the diagonal form (TinT | E^+ | TuT | Nn | lam: lo_precond_desc.RSD)
+            alg = B_PER_GPU * (4 * N * (R + 3) + 4 * R * R * 8 + 8 * R)
+            dom_kernel = "k_cg_rspace<32,8,true>"
+        elif rs_engine:
             # k_cg_rspace: C, 1/d, the right-hand side in, x out, and the member's six fp64 R x R matrices of the
             # R-space form (E | F E | E F E | G2 | F | E F: lo_precond_desc.RS)
             alg = B_PER_GPU * (4 * N * (R + 3) + 6 * R * R * 8)
-            dom_kernel = "k_cg_rspace<32,8>"
+            dom_kernel = "k_cg_rspace<32,8,false>"
         else:
             alg = algorithmic_bytes(dom, RANK_K)
             dom_kernel = "k_cg_onchip5<32,8,2>" if dom == "cg_onchip" else dom
@@ -1125,7 +1157,7 @@ def main():
         traffic, traffic_source = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_DIR, "traffic.json")))
-            if tj.get("prof_name") == dom and tj.get("kernel", "").startswith(dom_kernel.split("<")[0]):
+            if tj.get("prof_name") == dom and tj.get("kernel", "").replace(" ", "").startswith(dom_kernel.replace(" ", "").rstrip(">")):
                 traffic = tj["traffic_bytes_per_launch"]
                 traffic_source = (f"profiles/{PROFILE_DIR}/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                   f"`bench.py --no-extras`, kernel {tj['kernel']}, FETCH x2 (gfx950 correction) + WRITE")
@@ -1169,13 +1201,22 @@ def main():
                          "achievable_peak_source": "copy_this_box when measured (1 GiB float4 copy of this run), else "
                                                    "the MI355X guide's 6.29 TB/s",
                          "algorithmic_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6, "launches_timed": cnt,
-                         "note": ("per-launch compulsory bytes (C, 1/d, rhs in, x out, the six fp64 R x R matrices of the "
+                         "note": ("per-launch compulsory bytes (C, 1/d, rhs in, x out, the four fp64 R x R matrices and the "
+                                  "eigenvalues of the diagonal form) / launch time.  The kernel holds a member's rows of C "
+                                  "in VGPRs between its one reduction over the rows and x = D^-1 (xi b + C y); the 11 "
+                                  "iterations of the floor run as the CG of a DIAGONAL matrix on R + 1 coordinates in fp64 "
+                                  "(one reduction of three values per iteration).  64 members are on chip at a time and a "
+                                  "member takes ~20 us from its first load to its last store (load 6 - 9, reduction + "
+                                  "group all-reduce 5 - 6.5, iterations 5.7, x 1.2: LO_OC_DEBUG stamps, profiles/r05), "
+                                  "so 64 MB / 20 us = 3.2 TB/s: bound by that latency chain at the on-chip capacity, not "
+                                  "by HBM") if rs_diag else
+                                 ("per-launch compulsory bytes (C, 1/d, rhs in, x out, the six fp64 R x R matrices of the "
                                   "R-space form) / launch time.  The kernel holds a member's rows of C in VGPRs between "
                                   "its one reduction over the rows and x = D^-1 (xi b + C y); the 11 iterations of the "
                                   "floor run on R + 1 coordinates in fp64.  64 members are on chip at a time and a "
-                                  "member takes ~27 us from its first load to its last store (load 5, reduction + group "
-                                  "all-reduce 5 - 9, iterations 8 - 16, x 1.5: LO_OC_DEBUG stamps, profiles/r05), so "
-                                  "64 MB / 27 us = 2.4 TB/s: bound by that latency chain at the on-chip capacity, not by "
+                                  "member takes ~24 us from its first load to its last store (load 5, reduction + group "
+                                  "all-reduce 5 - 9, iterations 9, x 1.5: LO_OC_DEBUG stamps, profiles/r05), so "
+                                  "64 MB / 24 us = 2.7 TB/s: bound by that latency chain at the on-chip capacity, not by "
                                   "HBM") if rs_engine else
                                  ("per-launch compulsory bytes (C, d, 1/d, rhs in, x out, root-form preconditioner "
                                   "matrices; the kernel keeps the operator on chip for all 11 iterations) / launch time.  "
@@ -1207,6 +1248,7 @@ def main():
             "resident_timeouts": sum(g_["timeouts"] for g_ in gates),
             "resident_gate_per_rank": gates,
             "matvec_engine": matvec_engine,
+            "rspace_dense_engine": rspace_dense_engine,
         }
         if args.inject_timeouts > 0:
             out["inject_timeouts"] = {"injected": args.inject_timeouts, "soak_engines": engines_seen,

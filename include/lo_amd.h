@@ -117,6 +117,14 @@ typedef struct lo_precond_desc {
    * are touched twice per solve and a member costs one group all-reduce.  The Gram matrices have to be fp64-accurate
    * (tests/proto/proto_rspace.py); D^-1 is `dinv` as stored (FULL) / 1.0 / (double)sigma (CONST).  NULL = not available. */
   const double* RS;
+  /* Optional DIAGONAL FORM of the R-space iteration (lo_precond_eigform_f32; round 5, ABI 13): fp64 [B, 6, rf_ld, rf_ld] =
+   * TinT | E^+ | TuT | Nn | Tin | {row 0: lam, row 1: status, sweeps, sweeps, rank}.  In the basis that diagonalises the
+   * preconditioned member on span(C) (two Jacobi eigendecompositions per member, csrc/lo_eigform.hip) linear_cg is the
+   * CG of a diagonal matrix: one reduction of three values per iteration and no R x R product on the dependent chain
+   * (k_cg_rspace<.., true>).  Worth building when the cache serves more than one solve (it costs two R x R
+   * eigendecompositions per member); same iterates as the RS form to fp64 rounding (tests/proto/proto_eigform.py).
+   * NULL = not available (the RS form is used).  Needs RS. */
+  const double* RSD;
 } lo_precond_desc;
 
 /* Batch-sharded solves (one process per GPU, SURVEY.md section 8(e) "option A"): the reference's stopping rule is the
@@ -229,7 +237,7 @@ typedef struct lo_cg_plan {
                                  * launch of `serial_engine` (one all-reduce per member), 1 = ALL columns in three
                                  * streaming launches (k_rs_part / k_rs_iter / k_rs_apply) -- lockstep_cols /
                                  * serial_engine then name the engines of the repeat with the state                  */
-  int32_t reserved2;
+  int32_t reserved2;            /* lo_cg_last_executed: 1 = the rspace == 2 launch ran the diagonal form (RSD)           */
 } lo_cg_plan;
 int lo_cg_plan_f32(const lo_op_desc* op, const lo_precond_desc* pre, int has_precond_cb, int has_x0,
                    const lo_cg_params* prm, int cus, lo_cg_plan* plan);
@@ -373,6 +381,12 @@ int lo_precond_root_form_rs_f32(const float* C, int32_t R, const float* d, int32
                                 int64_t ld_member, int64_t ld_row, int64_t ld_col, const int64_t* perm, int64_t B,
                                 int64_t N, int32_t k, int32_t rf_ld, float* F, float* EF, float* E, float* dinv,
                                 float* logdet_p, double* RS, void* ws, size_t ws_bytes, void* stream);
+/* The DIAGONAL FORM (lo_precond_desc.RSD) from the R-space form RS [B, 6, rf_ld, rf_ld] of a root of rank R (even,
+ * <= rf_ld <= 32): RSD [B, 6, rf_ld, rf_ld].  One workgroup per member, fp64, two cyclic Jacobi eigendecompositions in LDS.
+ * RSD[b][5][1][0] = 1.0 when the form is usable (every eigenvalue of the preconditioned member positive), -1.0 otherwise
+ * (the caller keeps the RS form).  Replaces nothing in the reference: it is a cached re-expression of
+ * added_diag_linear_operator.py:119-137's closure for linear_cg.py:245-332. */
+int lo_precond_eigform_f32(const double* RS, int64_t B, int32_t R, int32_t rf_ld, double* RSD, void* stream);
 /* Kronecker root form of the pivoted-Cholesky preconditioner (see lo_precond_desc.kron_*): op = LO_OP_KRON_DIAG with
  * LO_DIAG_CONST, L / perm as lo_precond_root_form_f32 (k <= 16 pivots).  Gathers the pivot rows of the two factors
  * (kron_a [B, n1, 16], kron_b [B, n2, 16]), forms E = KP^T KP / sigma as the Hadamard product of the two small Gram

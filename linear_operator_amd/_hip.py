@@ -19,7 +19,7 @@ _lib = None
 LO_OP_LOWRANK_DIAG, LO_OP_DENSE_DIAG, LO_OP_KRON_DIAG, LO_OP_CALLBACK, LO_OP_SUM = 0, 1, 2, 3, 4
 LO_MAX_TERMS = 4
 LO_DIAG_NONE, LO_DIAG_FULL, LO_DIAG_CONST = 0, 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 LO_ERR_UNSUPPORTED = -4
 LO_FUSED_OK, LO_FUSED_EARLY_STOP, LO_FUSED_CONTINUE, LO_FUSED_TIMEOUT = 0, 1, 2, 3
@@ -39,7 +39,7 @@ EXPORTS = [
     "lo_precond_build_workspace_bytes", "lo_precond_build_f32", "lo_precond_build_strided_f32",
     "lo_precond_apply_workspace_bytes", "lo_precond_apply_f32",
     "lo_precond_root_form_workspace_bytes", "lo_precond_root_form_f32",
-    "lo_precond_root_form_rs_workspace_bytes", "lo_precond_root_form_rs_f32",
+    "lo_precond_root_form_rs_workspace_bytes", "lo_precond_root_form_rs_f32", "lo_precond_eigform_f32",
     "lo_precond_kron_root_workspace_bytes", "lo_precond_kron_root_f32",
     "lo_lanczos_workspace_bytes", "lo_lanczos_tridiag_f32", "lo_lanczos_permute_f32",
     "lo_root_from_lanczos_f32", "lo_root_from_lanczos_native_f32",
@@ -73,7 +73,8 @@ class PrecondDesc(C.Structure):
     _fields_ = [("k", C.c_int32), ("ldq", C.c_int32), ("constant_diag", C.c_int32), ("reserved", C.c_int32),
                 ("Q", C.c_void_p), ("dinv", C.c_void_p), ("F", C.c_void_p), ("EF", C.c_void_p), ("E", C.c_void_p),
                 ("rf_ld", C.c_int32), ("reserved2", C.c_int32),
-                ("kron_a", C.c_void_p), ("kron_b", C.c_void_p), ("kron_F", C.c_void_p), ("RS", C.c_void_p)]
+                ("kron_a", C.c_void_p), ("kron_b", C.c_void_p), ("kron_F", C.c_void_p), ("RS", C.c_void_p),
+                ("RSD", C.c_void_p)]
 
 
 class CgParams(C.Structure):
@@ -263,6 +264,8 @@ def load():
                                              C.c_void_p, sz, C.c_void_p]
     lib.lo_precond_root_form_rs_workspace_bytes.restype = sz
     lib.lo_precond_root_form_rs_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
+    lib.lo_precond_eigform_f32.restype = C.c_int
+    lib.lo_precond_eigform_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.lo_precond_root_form_rs_f32.restype = C.c_int
     lib.lo_precond_root_form_rs_f32.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
                                                 C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,

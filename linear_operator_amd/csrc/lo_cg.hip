@@ -959,7 +959,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     a.rhs = rhs; a.B = B; a.N = (int)N;
     a.c = c; a.ab_rec = prm->n_tridiag ? d.oc_ab : nullptr;
     a.col0 = 0; a.ncols = c; a.RK = pre ? preR4 : 0; a.RCg = pl.R4;
-    a.F = nullptr; a.EF = nullptr; a.E = nullptr; a.RS = nullptr;
+    a.F = nullptr; a.EF = nullptr; a.E = nullptr; a.RS = nullptr; a.RSD = nullptr;
     a.close_gran = nullptr; a.close_count = nullptr; a.close_ctrl = nullptr; a.close_mirror = nullptr;
     a.close_ticket = 0; a.close_tol = 0.f; a.close_floor_ok = 0;
     bool close_in_kernel = false;
@@ -993,7 +993,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     if (plan.rspace == 1 && lean && d.rs_ws) {  // all columns on R + 1 coordinates: three streaming launches
       a.xout = x;
       lean_state(true);
-      a.F = pre->F; a.EF = pre->EF; a.E = pre->E; a.RS = pre->RS;
+      a.F = pre->F; a.EF = pre->EF; a.E = pre->E; a.RS = pre->RS; a.RSD = pre->RSD;
       rc = rspace_cols_launch(pl.R4, a, d.rs_ws, st);
       if (rc == LO_OK) {
         serial_done = true;
@@ -1039,6 +1039,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       a.EF = oc_nopre ? nullptr : pre->EF;
       a.E = oc_nopre ? nullptr : pre->E;
       a.RS = (oc_nopre || plan.rspace != 2) ? nullptr : pre->RS;
+      a.RSD = a.RS ? pre->RSD : nullptr;
       tls_rspace_resident_ran = false;
       a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
       a.dbg = oc_dbg ? d.oc_dbg : nullptr;
@@ -1163,6 +1164,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
         exec.lockstep_cols = ls_cols;
         exec.lean = lean ? 1 : 0;
         exec.rspace = rs_cols_ran ? 1 : ((lean && tls_rspace_resident_ran) ? 2 : 0);
+        exec.reserved2 = (exec.rspace == 2 && tls_rspace_diag_ran) ? 1 : 0;  // 1: the diagonal form of the R-space iteration ran
         x_written = xout_ok;
       } else {  // a group hand-off timed out: redo everything with the streaming engine
         fprintf(stderr, "liblo_amd: operator-resident CG timed out, falling back to the streaming engine\n");

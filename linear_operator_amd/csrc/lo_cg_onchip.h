@@ -23,6 +23,7 @@ struct OnchipArgs {
   const float* EF;
   const float* E;     // C^T D^-1 C [B, RC, RC] (lo_precond_desc.E) or nullptr: enables the w-recurrence mode of k_cg_onchip5
   const double* RS;   // fp64 [B, 6, RC, RC]: E | F E | E F E | G2 = C^T C | F | E F (lo_precond_desc.RS) or nullptr: enables k_cg_rspace
+  const double* RSD;  // fp64 [B, 6, RC, RC]: TinT | Ep | TuT | Nn | Tin | lam (lo_precond_desc.RSD, lo_eigform.hip) or nullptr: the diagonal chain of k_cg_rspace
   float* ab_rec;      // [iters, B, c, 2] masked alpha / beta per iteration (second generation, n_tridiag > 0) or nullptr
   int64_t B;
   int N, RW;          // rows per workgroup
@@ -65,6 +66,7 @@ bool onchip5_eligible(int RC, int64_t N, int64_t c);
 int rspace_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st);
 bool rspace_eligible(int RC, int64_t N, int64_t c);
 size_t rspace_gbuf_bytes(int nworkgroups);
+extern thread_local bool tls_rspace_diag_ran;      // ... and it ran the diagonal form (lo_precond_desc.RSD)
 extern thread_local bool tls_rspace_resident_ran;  // set by rspace_launch when k_cg_rspace was launched (lo_cg_last_executed)
 // all columns of a result-only solve in three streaming launches (k_rs_part / k_rs_iter / k_rs_apply, lo_rspace.hip)
 int rspace_cols_launch(int RC, const OnchipArgs& a, double* ws, hipStream_t st);

@@ -188,6 +188,20 @@ __device__ __forceinline__ double lanes32_sum_d(double v) {
   return v;
 }
 __device__ __forceinline__ double wave_sum_fast_d(double v) { return bfly_add_d<32>(lanes32_sum_d(v)); }
+// sum over each row of 16 lanes, every lane ends with the total: rotations instead of the xor pattern (a plain sum needs no
+// pairing, and row_ror:4 stays on the DPP path where the xor-4 exchange is an LDS-crossbar ds_swizzle with its own wait)
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_d(double x) {
+  return x + mk_d((unsigned)__builtin_amdgcn_update_dpp(0, (int)lo_w(x), CTRL, 0xf, 0xf, false),
+                  (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi_w(x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double row16_sum_d(double x) {
+  x = dpp_add_d<0x128>(x);  // row_ror:8
+  x = dpp_add_d<0x124>(x);  // row_ror:4
+  x = dpp_add_d<0x4e>(x);   // quad_perm [2,3,0,1]
+  x = dpp_add_d<0xb1>(x);   // quad_perm [1,0,3,2]
+  return x;
+}
 // {value of the lower half-wave's lane, value of the upper half-wave's lane} for every lane pair (l, l + 32)
 __device__ __forceinline__ void halves_d(double x, double& lower, double& upper) {
   const auto r0 = __builtin_amdgcn_permlane32_swap(lo_w(x), lo_w(x), false, false);
@@ -253,12 +267,13 @@ struct alignas(16) RsShared {
   double red[R4_WAVES][2 * RC + 4];
   double res[2 * RC + 4];
   double gv[R4_WAVES][32];      // every wave's own broadcast copy of the vector it multiplies (g, w0, at the end nrm * y)
+  double gu[R4_WAVES][32];      // diagonal form: the wave's copy of u0
   double out[2][R4_WAVES][32];  // the four products of an iteration, double-buffered by the iteration's parity
 };
 
-template <int RC, int GW>
+template <int RC, int GW, bool DG>
 __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipArgs a) {
-  constexpr int NP = rs_np(RC);
+  constexpr int NP = rs_np(RC) + (DG ? 1 : 0);  // (diagonal form: + sum dinv^2, the lower bound of the residual norm)
   constexpr int MLD = RC + 2;            // row stride of the fp64 matrices in LDS (16-byte aligned, conflict-free b128 reads)
   constexpr int H = 8;                   // columns per accumulation round (2 H fp64 accumulators per thread)
   constexpr int NH = RC / 2;             // columns per half-wave in the R x R products
@@ -331,7 +346,8 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
     constexpr int NM = (4 * RC * RC / 2 + R4_TPB - 1) / R4_TPB;  // 16-byte pieces of the four matrices per thread
     f32x4 mv[NM];
     {
-      const f32x4* src = reinterpret_cast<const f32x4*>(a.RS + (size_t)b * 6 * RC * RC);  // E | F E | E F E | G2 (| F | E F)
+      // E | F E | E F E | G2 (| F | E F), or the diagonal form TinT | Ep | TuT | Nn (| Tin | lam)
+      const f32x4* src = reinterpret_cast<const f32x4*>((DG ? a.RSD : a.RS) + (size_t)b * 6 * RC * RC);
 #pragma unroll
       for (int u = 0; u < NM; ++u) mv[u] = src[min(tl + R4_TPB * u, 4 * RC * RC / 2 - 1)];
     }
@@ -371,13 +387,14 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
     // ---- the member's one reduction over the rows, fp64: w0 = C^T (dinv o b), u0 = C^T b per 16-column block, s, a0 ----
     {
       double bd[R4_NR], bb[R4_NR];
-      double s_acc = 0.0, a_acc = 0.0;
+      double s_acc = 0.0, a_acc = 0.0, d2_acc = 0.0;
 #pragma unroll
       for (int q = 0; q < R4_NR; ++q) {
         bb[q] = (double)bq[q];
         bd[q] = bb[q] * (double)diq[q];
         s_acc = fma(bb[q], bd[q], s_acc);
         a_acc = fma(bb[q], bb[q], a_acc);
+        if constexpr (DG) d2_acc = fma((double)diq[q], (double)diq[q], d2_acc);
       }
 #pragma unroll
       for (int blk = 0; blk < RC / H; ++blk) {
@@ -401,10 +418,13 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
         __builtin_amdgcn_sched_barrier(0);  // (one block of columns at a time: 2 H fp64 accumulators live)
       }
       const double ssum = wave_sum_fast_d(s_acc), asum = wave_sum_fast_d(a_acc);
+      double d2sum = 0.0;
+      if constexpr (DG) d2sum = wave_sum_fast_d(d2_acc);
       if (lane == 0) {
         rs.red[wave][2 * RC] = ssum;
         rs.red[wave][2 * RC + 1] = asum;
         rs.red[wave][2 * RC + 2] = (wig == 0 && wave == 0) ? (double)(ngroups + drawn) : 0.0;
+        if constexpr (DG) rs.red[wave][2 * RC + 3] = d2sum;
       }
     }
     // (opaque to value numbering: otherwise the fp64 conversions of the rows are kept -- and spilled -- for the last pass)
@@ -413,14 +433,20 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
 #pragma unroll
       for (int i = 0; i < RC / 2; ++i) asm volatile("" : "+v"(Cr[q][i]));
     // rows of F (wave 1) and E F (wave 2) for the two products with w0 behind the all-reduce: in flight during the exchange
-    f32x4 frow[NH / 2];
+    constexpr int NFR = DG ? 1 : NH / 2;
+    f32x4 frow[NFR];
+    double lamj = 1.0;
     __builtin_amdgcn_sched_barrier(0);  // (not earlier: the fp64 accumulators of the reduction need the registers)
-    {
+    if constexpr (!DG) {
       const int jj = min(lane & 31, RC - 1), hh = lane >> 5;
       const int wsel = (wave == 2) ? 5 : 4;
       const f32x4* fsrc = reinterpret_cast<const f32x4*>(a.RS + ((size_t)b * 6 + wsel) * RC * RC + (size_t)jj * RC + hh * NH);
 #pragma unroll
       for (int q = 0; q < NH / 2; ++q) frow[q] = (wave == 1 || wave == 2) ? fsrc[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      // this lane's eigenvalue: in flight during the exchange
+      lamj = a.RSD[((size_t)b * 6 + 5) * RC * RC + min(lane & 31, RC - 1)];
+      frow[0] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // ---- group all-reduce of NP doubles: thread tt < NP owns component tt (two granules: low | high word) ----
     if (a.prefetch & 4) __builtin_amdgcn_s_setprio(3);
@@ -499,6 +525,166 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
         win[i * 64 + lane] = make_float4(Cr[R4_NR - 1][2 * i].x, Cr[R4_NR - 1][2 * i].y, Cr[R4_NR - 1][2 * i + 1].x,
                                          Cr[R4_NR - 1][2 * i + 1].y);
     }
+    if constexpr (DG) {
+      // ---- diagonal form (lo_eigform.hip): every wave runs the whole chain on its own copy, no barrier inside ----
+      const int iw = (jr / H) * 2 * H + (jr % H);
+      double a0 = rs.res[2 * RC + 1], s = rs.res[2 * RC];
+      const double d2 = rs.res[2 * RC + 3];
+      nrm = sqrtf((float)a0);                             // rhs.norm(2, dim=-2)          :177
+      const bool rhs_zero = nrm < a.eps;                  // :178
+      if (rhs_zero) nrm = 1.0f;                           // :179
+      const double inv = 1.0 / (double)nrm;
+      const double w0 = live ? rs.res[iw] * inv : 0.0, u0 = live ? rs.res[iw + H] * inv : 0.0;
+      s *= inv * inv;
+      a0 *= inv * inv;
+      // r^T r >= r.z / max(dinv) >= r.z / sqrt(sum dinv^2): above this r.z the has_converged mask (:300, 1e-10) cannot hold
+      const double sure_rz = 2.0 * (double)a.stop_after * (double)a.stop_after * sqrt(d2);
+      auto own_row_dot = [&](const double* mrow, const double* vec) {
+        double a0_ = 0.0, a1_ = 0.0;
+#pragma unroll
+        for (int q = 0; q < NH; q += 2) {
+          const double2 xa = *reinterpret_cast<const double2*>(mrow + q);
+          const double2 xx = *reinterpret_cast<const double2*>(vec + q);
+          a0_ = fma(xa.x, xx.x, a0_);
+          a1_ = fma(xa.y, xx.y, a1_);
+        }
+        double lo_, up_;
+        halves_d(a0_ + a1_, lo_, up_);
+        return lo_ + up_;
+      };
+      double* myv = rs.gv[wave];
+      double* myu = rs.gu[wave];
+      if (hf == 0) {
+        myv[j] = w0;
+        myu[j] = u0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const double* row0 = mat_s + (size_t)jr * MLD + hf * NH;
+      double c0 = own_row_dot(row0, myv + hf * NH);                              // TinT w0
+      double e0 = own_row_dot(row0 + (size_t)RC * MLD, myv + hf * NH);           // E^+ w0
+      double m0 = own_row_dot(row0 + (size_t)2 * RC * MLD, myu + hf * NH);       // TuT u0
+      const double* nrow = row0 + (size_t)3 * RC * MLD;
+      c0 = live ? c0 : 0.0;
+      e0 = live ? e0 : 0.0;
+      m0 = live ? m0 : 0.0;
+      double tau2 = s - lanes32_sum_d(w0 * e0);            // |b_perp|^2
+      tau2 = tau2 > 0.0 ? tau2 : 0.0;
+      const double lam = live ? lamj : 1.0;
+      long long ts_a = 0, ts_b = 0;
+      if (stamp) ts_a = wall_clock64();
+      double cj = c0, qj = 0.0, etaj = 0.0;
+      double cp = 1.0, qp = 0.0, etap = 0.0;
+      double rz = 0.0, pApE = 0.0, alpha = 0.0, beta = 0.0;
+      float rn = 0.f, last_alpha = 0.f;
+      bool conv = false;
+      unsigned close_flags = 0u;
+      const size_t bc = (size_t)b;
+      const bool rec = wig == 0 && lane == 0;
+      const int last_owner = (a.iters - 1) & 3;  // the wave that forms the last residual norm writes the member's state
+      for (int k = -1; k < a.iters; ++k) {
+        if (k >= 0) {  // x += alpha p (:31);  r -= alpha A p (:264)
+          last_alpha = (float)alpha;
+          etaj = fma(alpha, qj, etaj);
+          etap = fma(alpha, qp, etap);
+          cj = fma(-alpha * lam, qj, cj);
+          cp = fma(-alpha, qp, cp);
+        }
+        const double lc = lam * cj;
+        // three sums over the components in one pass: the lower half-wave carries c.c and c.lam c, the upper c.lam q
+        const bool lo_h = hf == 0;
+        const float inv_rz = __builtin_amdgcn_rcpf((float)rz);       // (off the chain: rz is the previous iteration's)
+        const double red2 = row16_sum_d(halve_pair_d<16>(lo_h ? cj * cj : lc * qj, lo_h ? lc * cj : 0.0, lane));
+        const auto pick = [&](double v, int ln) {
+          return mk_d((unsigned)__builtin_amdgcn_readlane((int)lo_w(v), ln),
+                      (unsigned)__builtin_amdgcn_readlane((int)hi_w(v), ln));
+        };
+        const double cc = pick(red2, 0), clc = pick(red2, 16), clq = pick(red2, 32);
+        const double rzn = fma(cp * cp, tau2, cc);                     // residual_inner_prod :215 / :35-36
+        // residual norm (:298 / :204): needed by the stop rule's records and by the has_converged mask; wave w forms it
+        // for every fourth iteration (and the first, the last, and whenever the mask could hold)
+        const bool sure = rzn > sure_rz;
+        const bool own = ((k & 3) == wave) || !sure;
+        float rnn = 0.f;
+        if (k < 0) {
+          const float s1f = (float)a0;
+          rnn = __builtin_amdgcn_sqrtf(s1f < 0.f ? 0.f : s1f);
+        } else if (own) {
+          const double dl = fma(-cp, c0, cj);                          // del = c - c' c0
+          __builtin_amdgcn_wave_barrier();
+          if (hf == 0) myv[j] = dl;
+          __builtin_amdgcn_wave_barrier();
+          const double nd = own_row_dot(nrow, myv + hf * NH);
+          const double r2 = row16_sum_d(halve_pair_d<16>(dl * nd, dl * m0, lane));
+          const double dnd = pick(r2, 0), dm = pick(r2, 16);
+          const double s1 = fma(cp, fma(cp, a0, 2.0 * dm), dnd);       // r^T r
+          const float s1f = (float)s1;
+          rnn = __builtin_amdgcn_sqrtf(s1f < 0.f ? 0.f : s1f);
+        }
+        if (k >= 0) {                                                // closes iteration k: beta, residual norm, records
+          beta = ((float)rz < a.eps) ? 0.0 : (double)((float)rzn * inv_rz);  // :39-42
+          if (rhs_zero) rnn = 0.f;                                   // :299
+          rn = rnn;
+          if (rec && wave == (k & 3)) a.resid_rec[(size_t)k * a.B + bc] = rn;
+        } else {
+          beta = 0.0;
+          rn = rnn;
+          if (wig == 0 && t == 0) a.init_conv[bc] = (rn < a.stop_after) ? 1 : 0;  // :204-205
+          close_flags = (rn < a.stop_after) ? 1u : 0u;
+        }
+        // (NaN after the first product, linear_cg.py:199-200: the residual norm is NaN exactly when the coordinates are)
+        if (k == 0 && (rnn != rnn || rzn != rzn)) close_flags |= 2u;
+        conv = (own || rhs_zero) ? (rn < a.stop_after) : false;      // :300
+        rz = rzn;
+        // p = z + beta p (:268, :46);  p.Ap = sum lam (c + beta q)^2 + q'^2 tau2
+        pApE = fma(beta, fma(beta, pApE, 2.0 * clq), clc);
+        qj = fma(beta, qj, cj);
+        qp = fma(beta, qp, cp);
+        const double pAp = fma(qp * qp, tau2, pApE);
+        alpha = ((float)pAp < a.eps) ? 0.0 : (double)((float)rz * __builtin_amdgcn_rcpf((float)pAp));  // :254-257
+        if (conv) alpha = 0.0;                                       // :260
+      }
+      if (stamp) ts_b = wall_clock64();
+      if (rec && wave == last_owner) {
+        a.rhs_norm[bc] = nrm;
+        a.rhs_is_zero[bc] = rhs_zero ? 1 : 0;
+        a.rz[bc] = (float)rz;
+        a.alpha[bc] = last_alpha;
+        a.beta[bc] = (float)beta;
+        a.resid_norm[bc] = rn;
+        a.has_conv[bc] = conv ? 1 : 0;
+        if (a.close_gran) {
+          const unsigned long long gr =
+              ((unsigned long long)(0x80000000u | close_flags) << 32) | (unsigned long long)__float_as_uint(rn);
+          __hip_atomic_store(a.close_gran + b, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      // y = Tin eta - xi E^+ w0: lane i walks column i of TinT (its half of the eigen-indices; consecutive lanes read
+      // consecutive doubles, eta is a broadcast) -- Tin itself never has to be on chip
+      __builtin_amdgcn_wave_barrier();
+      if (hf == 0) myv[j] = etaj;
+      __builtin_amdgcn_wave_barrier();
+      xi = etap;
+      {
+        const double* col = mat_s + (size_t)(hf * NH) * MLD + jr;
+        double a0_ = 0.0, a1_ = 0.0;
+#pragma unroll
+        for (int q = 0; q < NH; q += 2) {
+          const double2 ee = *reinterpret_cast<const double2*>(myv + hf * NH + q);
+          a0_ = fma(col[(size_t)q * MLD], ee.x, a0_);
+          a1_ = fma(col[(size_t)(q + 1) * MLD], ee.y, a1_);
+        }
+        double lo_, up_;
+        halves_d(a0_ + a1_, lo_, up_);
+        yj = (lo_ + up_) - etap * e0;
+      }
+      yj = live ? yj : 0.0;
+      if (stamp) {  // (printed as wg-wait / publish / poll: start of the chain, the iterations, y)
+        a.dbg[5] = ts_a - a.dbg[2];
+        a.dbg[6] = ts_b - ts_a;
+        a.dbg[7] = wall_clock64() - ts_b;
+      }
+      __syncthreads();  // the only barrier of the phase: the next member's matrices may replace these from here on
+    } else
     {
       const int iw = (jr / H) * 2 * H + (jr % H);
       double a0 = rs.res[2 * RC + 1], s = rs.res[2 * RC];
@@ -1229,10 +1415,12 @@ bool rspace_eligible(int RC, int64_t N, int64_t c) {
 
 thread_local bool tls_rspace_resident_ran = false;
 
-template <int RC, int GW>
+thread_local bool tls_rspace_diag_ran = false;
+
+template <int RC, int GW, bool DG>
 static int rspace_go(const OnchipArgs& a, int nwg, hipStream_t st) {
   int per_cu = 0;
-  if (LO_OCCUPANCY_CACHED(per_cu, (k_cg_rspace<RC, GW>), R4_TPB, 0) != hipSuccess || per_cu < 2)
+  if (LO_OCCUPANCY_CACHED(per_cu, (k_cg_rspace<RC, GW, DG>), R4_TPB, 0) != hipSuccess || per_cu < 2)
     return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("cg_onchip", st);  // (one scope for the resident single-column kernels: lo_cg_last_executed().rspace tells them apart)
   ResidentLaunch guard(st);
@@ -1241,25 +1429,28 @@ static int rspace_go(const OnchipArgs& a, int nwg, hipStream_t st) {
     const char* e = getenv("LO_RS_PRIO");
     a2.prefetch = e ? atoi(e) : 1;
   }
-  hipLaunchKernelGGL((k_cg_rspace<RC, GW>), dim3(2 * nwg), dim3(R4_TPB), 0, st, a2);
+  hipLaunchKernelGGL((k_cg_rspace<RC, GW, DG>), dim3(2 * nwg), dim3(R4_TPB), 0, st, a2);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   tls_rspace_resident_ran = true;
+  tls_rspace_diag_ran = DG;
   return LO_OK;
 }
 
 // One column, result only (a.x == nullptr), a.F / a.RS present.  Same launch geometry as onchip5_launch.
 int rspace_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st) {
   if (!a.RS || a.x || a.c != 1 || a.ab_rec || !a.xout) return LO_ERR_UNSUPPORTED;
+  const bool dg = a.RSD != nullptr && !getenv("LO_RS_NO_DIAG");  // the diagonal form (lo_eigform.hip) when the cache carries it
+#define LO_RS1(C_, G_) return dg ? rspace_go<C_, G_, true>(a, nwg, st) : rspace_go<C_, G_, false>(a, nwg, st)
 #define LO_RS(C_)                                                                                    \
   switch (a.GW) {                                                                                    \
-    case 1: return rspace_go<C_, 1>(a, nwg, st);                                                     \
-    case 2: return rspace_go<C_, 2>(a, nwg, st);                                                     \
-    case 4: return rspace_go<C_, 4>(a, nwg, st);                                                     \
-    case 8: return rspace_go<C_, 8>(a, nwg, st);                                                     \
-    case 16: return rspace_go<C_, 16>(a, nwg, st);                                                   \
-    case 32: return rspace_go<C_, 32>(a, nwg, st);                                                   \
-    default: return rspace_go<C_, 64>(a, nwg, st);                                                   \
+    case 1: LO_RS1(C_, 1);                                                                           \
+    case 2: LO_RS1(C_, 2);                                                                           \
+    case 4: LO_RS1(C_, 4);                                                                           \
+    case 8: LO_RS1(C_, 8);                                                                           \
+    case 16: LO_RS1(C_, 16);                                                                         \
+    case 32: LO_RS1(C_, 32);                                                                         \
+    default: LO_RS1(C_, 64);                                                                         \
   }
   if (RC == 32) {
     LO_RS(32);
@@ -1269,6 +1460,7 @@ int rspace_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st) {
     LO_RS(8);
   }
 #undef LO_RS
+#undef LO_RS1
   return LO_ERR_UNSUPPORTED;
 }
 

@@ -155,6 +155,11 @@ class WoodburyPreconditioner:
     # R-space form (lo_precond_desc.RS): fp64 [B, 6, rf_ld, rf_ld] = E | F E | E F E | C^T C | F | E F -- single-column result-only solves
     # run their iterations on R + 1 coordinates (csrc/lo_rspace.hip)
     RS: Optional[torch.Tensor] = None
+    # diagonal form of the R-space iteration (lo_precond_desc.RSD, csrc/lo_eigform.hip): fp64 [B, 6, rf_ld, rf_ld], built by
+    # ensure_eigform() once the cache has served enough single-column solves to pay for it (_eigform_due)
+    RSD: Optional[torch.Tensor] = None
+    rs_rank: int = 0      # true rank of the root the RS form was built from
+    rs_uses: int = 0      # single-column result-only solves this cache has served
     source: Optional[tuple] = None  # (L, d) the preconditioner was built from (to build Q later)
     # Kronecker root form (lo_precond_desc.kron_*): (kron_a [B, n1, 16], kron_b [B, n2, 16], kron_F [B, 16, 16]) of a
     # Kronecker operator with a constant diagonal -- the single-column CG of large N forms the rows of the tall matrix
@@ -180,6 +185,18 @@ class WoodburyPreconditioner:
             self.Q, self.dinv, self.k = full.Q, full.dinv, full.k
         return self
 
+    def ensure_eigform(self) -> "WoodburyPreconditioner":
+        """Build the diagonal form (lo_precond_eigform_f32) next to the R-space form; keeps RS when a member's form is unusable."""
+        if self.RSD is None and self.RS is not None and self.rs_rank >= 2 and self.rs_rank % 2 == 0 and self.RSD is not False:
+            lib = _hip.load()
+            B, ld = self.RS.shape[0], self.RS.shape[-1]
+            RSD = torch.empty_like(self.RS)
+            _hip.check(lib.lo_precond_eigform_f32(_hip.ptr(self.RS), B, self.rs_rank, ld, _hip.ptr(RSD),
+                                                  _hip.stream_ptr(self.RS.device)), "lo_precond_eigform_f32")
+            ok = bool((RSD[:, 5, 1, 0] > 0).all().item())
+            self.RSD = RSD if ok else False
+        return self
+
     def c_struct(self) -> _hip.PrecondDesc:
         s = _hip.PrecondDesc()
         s.k, s.constant_diag, s.reserved = self.k, int(self.constant_diag), 0
@@ -190,6 +207,7 @@ class WoodburyPreconditioner:
             s.F, s.EF, s.rf_ld = self.F.data_ptr(), self.EF.data_ptr(), self.rf_ld
             s.E = None if self.E is None else self.E.data_ptr()
             s.RS = None if self.RS is None else self.RS.data_ptr()
+            s.RSD = self.RSD.data_ptr() if (self.RS is not None and torch.is_tensor(self.RSD)) else None
         if self.kron is not None:
             s.kron_a, s.kron_b, s.kron_F = (t.data_ptr() for t in self.kron)
         return s
@@ -343,6 +361,25 @@ def minres_solve_f64(A: Optional[torch.Tensor], rhs: torch.Tensor, shifts: torch
                         float(info.conv))
 
 
+# The diagonal form of the R-space iteration (csrc/lo_eigform.hip) is a cache-lifetime investment: two R x R Jacobi
+# eigendecompositions per member (measured 0.45 ms + 0.45 us per member on the MI355X) against ~3.5 us per solve and
+# round of 64 resident members (k_cg_rspace 200 -> 171 us at 512 members).  A cache gets the form when the solves it
+# has served would have paid for it (the ski-rental rule: never more than twice the optimal cost):
+#   512 members: on the 25th single-column solve, 4096 members: on the 11th, 40 members: on the 134th.
+# EIGFORM_AFTER_USES >= 0 (LO_EIGFORM_AFTER_USES) fixes the count instead (0: with the first solve), -1: never; None: the model.
+_e = os.environ.get("LO_EIGFORM_AFTER_USES")
+EIGFORM_AFTER_USES = None if _e is None else int(_e)
+del _e
+
+
+def _eigform_due(uses: int, B: int) -> bool:
+    if EIGFORM_AFTER_USES is not None:
+        return EIGFORM_AFTER_USES >= 0 and uses > EIGFORM_AFTER_USES
+    build_us = 450.0 + 0.45 * B
+    gain_us = 3.5 * ((B + 63) // 64)
+    return uses * gain_us >= build_us
+
+
 def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optional[torch.Tensor] = None,
              precond: Optional[WoodburyPreconditioner] = None, matvec_closure: Optional[Callable] = None,
              precond_closure: Optional[Callable] = None, closure_batch_shape=None, n_tridiag: int = 0,
@@ -388,6 +425,10 @@ def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optio
     else:
         pc_cb, pc_err = _hip.MATVEC_CB(), []
     keep += [mv_cb, pc_cb]
+    if precond is not None and precond.RS is not None and c == 1 and not n_tridiag and x0 is None:
+        precond.rs_uses += 1
+        if precond.RSD is None and _eigform_due(precond.rs_uses, B):
+            precond.ensure_eigform()
     pre_s = precond.c_struct() if precond is not None else None
     prm = _hip.CgParams()
     prm.c, prm.n_tridiag, prm.max_iter, prm.max_tridiag_iter = c, n_tridiag, max_iter, max_tridiag_iter
@@ -440,7 +481,7 @@ def _plan_dict(pl) -> dict:
                 serial_group=pl.serial_group, lean=bool(pl.lean), needs_q=bool(pl.needs_q),
                 streaming_precond=_hip.STREAM_PRE_NAMES[pl.streaming_precond], poll_chunk=pl.poll_chunk,
                 first_stop_iteration=pl.first_stop_iteration, streaming_iterations=pl.reserved,
-                rspace={0: "none", 1: "cols", 2: "resident"}[pl.rspace])
+                rspace={0: "none", 1: "cols", 2: "resident"}[pl.rspace], rspace_diag=bool(pl.reserved2))
 
 
 def cg_plan(desc: OperatorDescriptor, c: int, *, precond: Optional[WoodburyPreconditioner] = None, has_x0: bool = False,
@@ -797,7 +838,7 @@ def _root_form(lib, root, perm, L3, d, constant_diag, B, N, k, dev) -> WoodburyP
                                                    _hip.ptr(p2), B, N, k, ld, _hip.ptr(F), _hip.ptr(EF), _hip.ptr(E),
                                                    _hip.ptr(dinv), _hip.ptr(logdet), _hip.ptr(RS), _hip.ptr(ws),
                                                    ws.numel(), _hip.stream_ptr(dev)), "lo_precond_root_form_rs_f32")
-        return WoodburyPreconditioner(None, dinv, k, constant_diag, logdet, F, EF, E, RS)
+        return WoodburyPreconditioner(None, dinv, k, constant_diag, logdet, F, EF, E, RS, rs_rank=R)
     ws = _hip.workspace(lib.lo_precond_root_form_workspace_bytes(B, N, R), dev)
     _hip.check(lib.lo_precond_root_form_f32(_hip.ptr(C3), R, _hip.ptr(d2), mode, _hip.ptr(L3), sm, sr, sc, _hip.ptr(p2),
                                             B, N, k, ld, _hip.ptr(F), _hip.ptr(EF), _hip.ptr(E), _hip.ptr(dinv),
@@ -867,6 +908,7 @@ def precond_build(L: torch.Tensor, d: torch.Tensor, constant_diag: bool, root: O
             return rf
         full = precond_build(L, d, constant_diag)
         full.F, full.EF, full.E, full.RS, full.source = rf.F, rf.EF, rf.E, rf.RS, rf.source
+        full.rs_rank = rf.rs_rank
         return full
     ldq = padded_rank(k)
     Q = torch.empty(B, N, ldq, dtype=torch.float32, device=dev)
