@@ -1031,8 +1031,8 @@ def main():
                                "note": "LO_RS_NO_DIAG=1: k_cg_rspace<..,false>, the iteration with the four R x R products; "
                                        "eigform_build_ms = lo_precond_eigform_f32 for this rank's members (two Jacobi "
                                        "eigendecompositions each), paid ONCE per preconditioner cache when it serves its "
-                                       "second single-column solve (kernels.EIGFORM_AFTER_USES) -- outside the timed "
-                                       "region, as the pivoted Cholesky and the root form are"}
+                                       "25th single-column solve (kernels._eigform_due: when the solves served have paid for it) -- "
+                                       "outside the timed region, as the pivoted Cholesky and the root form are"}
     # ---- per-rank engine and gate of the resident kernels: a line measured on the streaming engine says so ----
     engines = [engine_timed]
     gates = [gate]

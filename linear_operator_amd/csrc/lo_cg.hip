@@ -1246,12 +1246,15 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
                             plan.streaming_precond == LO_STREAM_NOPRE_FUSED_COLS);
   const bool sc_dbg = sc_on && getenv("LO_SC_DEBUG") != nullptr;
   if (sc_dbg) LO_HIP_CHECK(hipMemsetAsync(d.oc_dbg, 0, 16 * sizeof(long long), st));
-  if (sc_on) {  // cleared once per solve (tags are unique per launch)
+  // (a solve the resident phase has already closed launches no streaming iteration: its three clears -- 3 hipMemsetAsync =
+  //  4 fill kernels, ~15 us of stream time behind every headline solve -- are skipped)
+  const bool will_stream = k_start < prm->max_iter && !h.stop;
+  if (sc_on && will_stream) {  // cleared once per solve (tags are unique per launch)
     LO_HIP_CHECK(hipMemsetAsync(d.sc_gbuf, 0, cg_step_cols_gbuf_bytes(), st));
     LO_HIP_CHECK(hipMemsetAsync(d.sc_ctr, 0, sizeof(int) * 2 * ((size_t)std::max(1, (int)prm->max_iter) + 1), st));
     LO_HIP_CHECK(hipMemsetAsync(d.sc_gran, 0, sizeof(unsigned long long) * 3 * (size_t)B, st));
   }
-  if (pf_on) {  // granules and hand-out counters of the fused apply: cleared once per solve (tags are unique per launch)
+  if (pf_on && will_stream) {  // granules and hand-out counters of the fused apply: cleared once per solve (tags are unique per launch)
     LO_HIP_CHECK(hipMemsetAsync(d.pf_gbuf, 0, precond_fused_gbuf_bytes(), st));
     LO_HIP_CHECK(hipMemsetAsync(d.pf_ctr, 0, sizeof(int) * 2 * ((size_t)std::max(1, (int)prm->max_iter) + 1), st));
     LO_HIP_CHECK(hipMemsetAsync(d.pf_gran, 0, sizeof(unsigned long long) * (size_t)B, st));

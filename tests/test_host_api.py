@@ -430,3 +430,22 @@ def test_cg_engine_selection_table(label, args, want):
     got = _plan(**args)
     bad = {k: (got[k], v) for k, v in want.items() if got[k] != v}
     assert not bad, f"{label}: (got, want) {bad}\nfull plan: {got}"
+
+
+def test_eigform_policy_builds_the_diagonal_form_when_the_solves_served_have_paid_for_it():
+    """kernels._eigform_due (pure host logic): the ski-rental rule over the measured costs."""
+    from linear_operator_amd import kernels as K
+
+    old = K.EIGFORM_AFTER_USES
+    try:
+        K.EIGFORM_AFTER_USES = None
+        first = {B: next(n for n in range(1, 10 ** 4) if K._eigform_due(n, B)) for B in (40, 64, 512, 4096)}
+        assert first == {40: 134, 64: 137, 512: 25, 4096: 11}, first
+        K.EIGFORM_AFTER_USES = 0
+        assert K._eigform_due(1, 8)
+        K.EIGFORM_AFTER_USES = 3
+        assert not K._eigform_due(3, 512) and K._eigform_due(4, 512)
+        K.EIGFORM_AFTER_USES = -1
+        assert not K._eigform_due(10 ** 6, 4096)
+    finally:
+        K.EIGFORM_AFTER_USES = old
