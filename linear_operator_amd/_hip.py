@@ -422,7 +422,17 @@ def ptr(t: Optional[torch.Tensor]):
 
 
 def stream_ptr(device=None):
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """The current HIP stream of `device` as a raw handle (torch._C._cuda_getCurrentRawStream: 0.3 us instead of the 4 us
+    of building a torch.cuda.Stream object -- this sits on every solve's critical path)."""
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is None:
+        return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    if device is None:
+        idx = torch.cuda.current_device()
+    else:
+        dev = torch.device(device) if not isinstance(device, torch.device) else device
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    return C.c_void_p(raw(idx))
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
