@@ -1126,7 +1126,7 @@ def main():
         rs_diag = rs_engine and K.cg_last_executed().get("rspace_diag", False)
         if rs_diag:
             # k_cg_rspace<..,true>: C, 1/d, the right-hand side in, x out, and four fp64 R x R matrices + R eigenvalues of
-            # the diagonal form (TinT | E^+ | TuT | Nn | lam: lo_precond_desc.RSD)
+            # the diagonal form (TinT | E^+ | TuT | G2 | lam: lo_precond_desc.RSD)
             alg = B_PER_GPU * (4 * N * (R + 3) + 4 * R * R * 8 + 8 * R)
             dom_kernel = "k_cg_rspace<32,8,true>"
         elif rs_engine:

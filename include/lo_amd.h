@@ -118,7 +118,7 @@ typedef struct lo_precond_desc {
    * (tests/proto/proto_rspace.py); D^-1 is `dinv` as stored (FULL) / 1.0 / (double)sigma (CONST).  NULL = not available. */
   const double* RS;
   /* Optional DIAGONAL FORM of the R-space iteration (lo_precond_eigform_f32; round 5, ABI 13): fp64 [B, 6, rf_ld, rf_ld] =
-   * TinT | E^+ | TuT | Nn | Tin | {row 0: lam, row 1: status, sweeps, sweeps, rank}.  In the basis that diagonalises the
+   * TinT | E^+ | TuT | G2 = C^T C | Tin | {row 0: lam, row 1: status, sweeps, sweeps, rank}.  In the basis that diagonalises the
    * preconditioned member on span(C) (two Jacobi eigendecompositions per member, csrc/lo_eigform.hip) linear_cg is the
    * CG of a diagonal matrix: one reduction of three values per iteration and no R x R product on the dependent chain
    * (k_cg_rspace<.., true>).  Worth building when the cache serves more than one solve (it costs two R x R
@@ -383,8 +383,10 @@ int lo_precond_root_form_rs_f32(const float* C, int32_t R, const float* d, int32
                                 float* logdet_p, double* RS, void* ws, size_t ws_bytes, void* stream);
 /* The DIAGONAL FORM (lo_precond_desc.RSD) from the R-space form RS [B, 6, rf_ld, rf_ld] of a root of rank R (even,
  * <= rf_ld <= 32): RSD [B, 6, rf_ld, rf_ld].  One workgroup per member, fp64, two cyclic Jacobi eigendecompositions in LDS.
- * RSD[b][5][1][0] = 1.0 when the form is usable (every eigenvalue of the preconditioned member positive), -1.0 otherwise
- * (the caller keeps the RS form).  Replaces nothing in the reference: it is a cached re-expression of
+ * RSD[b][5][1][0] = 1.0 when the form is usable; -1.0 (an eigenvalue of the preconditioned member is not positive) or -2.0
+ * ((s_max / s_min) (1 + s_max^2) of E's kept directions exceeds 1e9: the change of basis V S^-1 would cost more than 1e-7
+ * of a solution that is a difference of large terms) otherwise -- the caller keeps the RS form, which stays in the
+ * coordinates of C.  Replaces nothing in the reference: it is a cached re-expression of
  * added_diag_linear_operator.py:119-137's closure for linear_cg.py:245-332. */
 int lo_precond_eigform_f32(const double* RS, int64_t B, int32_t R, int32_t rf_ld, double* RSD, void* stream);
 /* Kronecker root form of the pivoted-Cholesky preconditioner (see lo_precond_desc.kron_*): op = LO_OP_KRON_DIAG with

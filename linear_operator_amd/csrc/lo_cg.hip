@@ -941,7 +941,8 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   exec.serial_engine = LO_ENGINE_NONE;
   exec.rspace = 0;
   tls_rspace_resident_ran = false;
-  for (int oc_pass = 0; oc_pass < 2; ++oc_pass) {
+  bool rs_force_dense = false;  // the diagonal form asked for the dense one (CgCtrl::rs_redo): one more result-only pass
+  for (int oc_pass = 0; oc_pass < 3; ++oc_pass) {
   bool oc_redo = false;
   if (oc_ok) {
     OnchipArgs a;
@@ -1039,7 +1040,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       a.EF = oc_nopre ? nullptr : pre->EF;
       a.E = oc_nopre ? nullptr : pre->E;
       a.RS = (oc_nopre || plan.rspace != 2) ? nullptr : pre->RS;
-      a.RSD = a.RS ? pre->RSD : nullptr;
+      a.RSD = (a.RS && !rs_force_dense) ? pre->RSD : nullptr;
       tls_rspace_resident_ran = false;
       a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
       a.dbg = oc_dbg ? d.oc_dbg : nullptr;
@@ -1148,7 +1149,10 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
         fprintf(stderr, "onchip member0 (100 MHz ticks): load %lld init %lld iters %lld store %lld | wg-wait %lld publish %lld poll %lld\n",
                 ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5], ts[6], ts[7]);
       }
-      if (oc_err == 0 && lean && !h.stop) {
+      if (oc_err == 0 && lean && h.rs_redo && tls_rspace_diag_ran && !rs_force_dense) {
+        rs_force_dense = true;  // (the result-only pass again, on the dense R-space form)
+        oc_redo = true;
+      } else if (oc_err == 0 && lean && !h.stop) {
         // the stop rule does not hold at the floor and the state was not written: the same launches once more, in full
         // (a root-form-only preconditioner cannot continue on the streaming engine anyway: the caller builds Q first)
         lean_miss_note(op, prm);

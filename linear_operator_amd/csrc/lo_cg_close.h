@@ -19,7 +19,7 @@ __device__ __forceinline__ void cg_close_solve(const OnchipArgs& a, const int ng
   if (closer_s) {
     // (the other groups' granules were stored before their counter increments, but nothing orders the two for us:
     //  every granule is polled until its tag is there -- no fence anywhere)
-    float lsum = 0.f, lnan = 0.f, lnotconv = 0.f;
+    float lsum = 0.f, lnan = 0.f, lnotconv = 0.f, lredo = 0.f;
     unsigned spin = 0;
     bool lost = false;
     for (int64_t i = t; i < a.B && !lost; i += R4_TPB) {
@@ -39,13 +39,16 @@ __device__ __forceinline__ void cg_close_solve(const OnchipArgs& a, const int ng
       lsum += rn;
       if (rn != rn || (fl & 2u)) lnan = 1.f;
       if (!(fl & 1u)) lnotconv = 1.f;
+      if (fl & 4u) lredo = 1.f;  // (diagonal form: this member wants the dense form)
     }
     if (lost) atomicExch(a.err, 1);
     const float mean = block_sum256(lsum, red_s) / (float)a.B;   // (the summation order of k_cg_ctrl_onchip)
     const float anynan = block_sum256(lnan, red_s);
     const float notconv = block_sum256(lnotconv, red_s);
+    const float redo = block_sum256(lredo, red_s);
     if (t == 0) {
       CgCtrl* c = a.close_ctrl;
+      c->rs_redo = redo > 0.f ? 1 : 0;
       c->iterations = a.iters;
       c->mean_resid = mean;
       if (anynan > 0.f) {

@@ -23,7 +23,7 @@ struct OnchipArgs {
   const float* EF;
   const float* E;     // C^T D^-1 C [B, RC, RC] (lo_precond_desc.E) or nullptr: enables the w-recurrence mode of k_cg_onchip5
   const double* RS;   // fp64 [B, 6, RC, RC]: E | F E | E F E | G2 = C^T C | F | E F (lo_precond_desc.RS) or nullptr: enables k_cg_rspace
-  const double* RSD;  // fp64 [B, 6, RC, RC]: TinT | Ep | TuT | Nn | Tin | lam (lo_precond_desc.RSD, lo_eigform.hip) or nullptr: the diagonal chain of k_cg_rspace
+  const double* RSD;  // fp64 [B, 6, RC, RC]: TinT | E^+ | TuT | G2 | Tin | lam (lo_precond_desc.RSD, lo_eigform.hip) or nullptr: the diagonal chain of k_cg_rspace
   float* ab_rec;      // [iters, B, c, 2] masked alpha / beta per iteration (second generation, n_tridiag > 0) or nullptr
   int64_t B;
   int N, RW;          // rows per workgroup

@@ -11,10 +11,11 @@
 //     r.z = |c|^2 + c'^2 tau2,   p.Ap = sum lam q^2 + q'^2 tau2,   c -= alpha lam q,   q = c + beta q,   eta += alpha q
 // -- one reduction of three values per iteration, no matrix product on the chain.  This file builds, per member and in fp64,
 //     TinT = (V S^-1 W)^T     c0 = TinT w0                       (w0 = C^T D^-1 r0)
-//     Ep   = V S^-2 V^T       e0 = Ep w0,  tau2 = s - w0.e0       (E^+: the projection of r0 on span(C))
-//     TuT  = (V S^-1 W^-T)^T  m0 = TuT u0                        (u0 = C^T r0; residual norms)
-//     Nn   = W^-1 (U^T D U) W^-T,  U^T D U = S^-1 V^T (C^T C) V S^-1      r^T r = del.Nn del + 2 c' del.m0 + c'^2 a0, del = c - c' c0
-//     Tin  = V S^-1 W         y = Tin eta - xi e0,  x = D^-1 (xi r0 + C y)
+//     Ep   = V S^-2 V^T       (E^+, kept for the tests' identities; the kernel does not use it: it squares cond(S))
+//     TuT  = (V S^-1 W^-T)^T  g0 = TuT w0 = W^-1 beta0:  tau2 = s - c0.g0,  y = Tin (eta - xi g0),  x = D^-1 (xi r0 + C y)
+//     G2   = C^T C            residual norms in the coordinates of C:  r = c' r0 + C g,  g = Tu (c - c' c0),
+//                             r^T r = c'^2 a0 + 2 c' g.u0 + g.G2 g     (u0 = C^T r0)
+//     Tin  = V S^-1 W         (kept for reference; the kernel walks the columns of TinT)
 //     lam
 // from the R-space form RS (E | . | . | G2 = C^T C | F | .) with two cyclic Jacobi eigendecompositions in LDS (E, then Hs).
 // Directions of E below 1e-13 of its largest eigenvalue are dropped (S^-1 := 0: they stay in the complement, where both
@@ -32,6 +33,7 @@ constexpr int EF_N = 32;       // largest padded root rank
 constexpr int EF_LD = EF_N + 1;
 constexpr int EF_MAX_SWEEPS = 24;
 constexpr double EF_RANK_TOL = 1e-13;
+constexpr double EF_AMP_MAX = 1e9;    // (s_max / s_min) (1 + s_max^2) of a member's kept directions: beyond it the dense form is kept (eps x this = 1e-7)
 constexpr double EF_ROT_TOL = 1e-15;  // |a_pq| <= tol sqrt(a_pp a_qq): converged (relative criterion: small eigenvalues of E keep their digits)
 
 // Parallel cyclic Jacobi on the symmetric n x n matrix A (LDS, n even, <= 32): n / 2 disjoint rotations per round in the
@@ -49,23 +51,30 @@ __device__ __forceinline__ void pair_of(int r, int k, int n, int& p, int& q) {
   if (p > q) { const int t = p; p = q; q = t; }
 }
 // The rotation that annihilates a_pq, J = [[c, s], [-s, c]], from the double angle: with z = a_qq - a_pp and
-// h = sqrt(z^2 + 4 a_pq^2), cos 2phi = |z| / h, c = sqrt((1 + cos 2phi) / 2), s = sign(z) a_pq / (h c).  Two raw
-// reciprocal-square-root instructions (about 27 bits each) and one first-order renormalisation so that c^2 + s^2 = 1 to
-// fp64 rounding: s keeps a RELATIVE error of 1e-8 (the entry drops by that factor instead of to zero -- one more sweep at
-// worst, and small angles stay small), the product of the rotations stays orthogonal.  The IEEE sequence (two divisions,
+// h = sqrt(z^2 + 4 a_pq^2), cos 2phi = |z| / h, c = sqrt((1 + cos 2phi) / 2), s = sign(z) a_pq / (h c).  Two
+// reciprocal-square-root instructions with one Newton step each and a renormalisation so that c^2 + s^2 = 1 to fp64
+// rounding: s keeps a RELATIVE error of ~1e-9 (the entry drops by that factor instead of to zero, and small angles stay
+// small), the product of the rotations stays orthogonal.  The IEEE sequence (two divisions,
 // two square roots: ~60 dependent instructions) was the longest part of a round.
 __device__ __forceinline__ bool rotation(double app, double aqq, double apq, double floor_abs, double& c, double& s) {
   c = 1.0;
   s = 0.0;
   const double lim = EF_ROT_TOL * __builtin_amdgcn_sqrt(fabs(app) * fabs(aqq));
   if (!(fabs(apq) > lim) || apq == 0.0 || (fabs(app) <= floor_abs && fabs(aqq) <= floor_abs)) return false;
+  // (v_rsq_f64 is good to ~1e-5 only -- measured: rotations from the raw value left Q orthogonal to 6e-9 -- so each
+  //  reciprocal square root gets one Newton step, and the final renormalisation two: c^2 + s^2 = 1 to fp64 rounding)
   const double z = aqq - app;
-  const double r = __builtin_amdgcn_rsq(fma(z, z, 4.0 * apq * apq));  // 1 / h
+  const double h2 = fma(z, z, 4.0 * apq * apq);
+  double r = __builtin_amdgcn_rsq(h2);                                  // 1 / h
+  r = r * fma(-0.5 * h2, r * r, 1.5);
   const double c2 = fma(0.5 * fabs(z), r, 0.5);                         // cos^2 phi in [0.5, 1]
-  const double rc = __builtin_amdgcn_rsq(c2);
+  double rc = __builtin_amdgcn_rsq(c2);
+  rc = rc * fma(-0.5 * c2, rc * rc, 1.5);
   const double ct = c2 * rc;
   const double st = (z >= 0.0 ? apq : -apq) * r * rc;
-  const double sc = fma(-0.5, fma(ct, ct, st * st), 1.5);               // (c~^2 + s~^2)^-1/2 to first order
+  const double nu = fma(ct, ct, st * st);
+  double sc = fma(-0.5, nu, 1.5);                                       // nu^-1/2: first order, then one Newton step
+  sc = sc * fma(-0.5 * nu, sc * sc, 1.5);
   if (!(sc == sc)) return false;                                       // (overflow of z^2: the entry is negligible)
   c = ct * sc;
   s = st * sc;
@@ -176,10 +185,20 @@ __global__ __launch_bounds__(kThreads) void k_rs_eigform(const double* __restric
       Sinv_s[j] = keep ? 1.0 / sqrt(s2) : 0.0;
       Gam_s[j] = sqrt(1.0 + (keep ? s2 : 0.0));
     }
-    flag_s = rank;
+    // The coordinates c0 = TinT w0 mix the components of w0 (rounded at eps |w0|max) with weights up to 1 / s_min: the
+    // right-hand side's component along a small direction is known to eps s_max / s_min only, and a solution that is the
+    // difference of large terms (x = D^-1 (xi b + C y) for b inside span(C): |x^| ~ |b^| / (1 + s_max^2)) inherits that
+    // error relative to its own size: eps (s_max / s_min) (1 + s_max^2).  Measured 8e-4 on such a right-hand side with
+    // one column of C scaled by 1e-6 and d ~ 1e-3 (the dense form, which stays in the coordinates of C, is at 1e-7).
+    // Members beyond EF_AMP_MAX keep the dense form.
+    double mn = mx;
+    for (int j = 0; j < n; ++j)
+      if (S_s[j] > 0.0) mn = fmin(mn, M0[j][j]);
+    flag_s = (sqrt(mx / fmax(mn, 1e-300)) * (1.0 + mx) > EF_AMP_MAX) ? -rank - 1 : rank;
   }
   __syncthreads();
-  const int rank = flag_s;
+  const bool illcond = flag_s < 0;
+  const int rank = illcond ? -flag_s - 1 : flag_s;
   __syncthreads();
   mm<false, false>(M3, M2, M1, n);  // F V
   __syncthreads();
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void k_rs_eigform(const double* __restric
   const int sweeps_h = jacobi_eigh(M0, M3, M4, M5, n, pairs_s, 0.0);  // Hs = Q Lam Q^T, Q in M3 (M2 = X1 is dead; M4 / M5 free)
   if (t < n) lam_s[t] = M0[t][t];
   __syncthreads();
-  bool bad = false;
+  bool bad = illcond;
   for (int j = 0; j < n; ++j) bad = bad || !(lam_s[j] > 0.0);
   for (int e = t; e < n * n; e += kThreads) {
     const int i = e / n, j = e % n;
@@ -216,23 +235,15 @@ __global__ __launch_bounds__(kThreads) void k_rs_eigform(const double* __restric
     Ob[4 * ld * ld + i * ld + j] = M0[i][j];      // slot 4: Tin
   }
   __syncthreads();
-  for (int e = t; e < n * n; e += kThreads) M2[e / n][e % n] = Rb[3 * ld * ld + (e / n) * ld + e % n];  // G2
-  __syncthreads();
-  mm<false, false>(M3, M2, M1, n);       // G2 V S^-1
-  __syncthreads();
-  mm<true, false>(M0, M1, M3, n);        // U^T D U
-  __syncthreads();
-  mm<false, false>(M3, M0, M5, n);       // (U^T D U) W^-T
-  __syncthreads();
-  mm<true, false>(M0, M5, M3, n);        // Nn
-  __syncthreads();
+  // slot 3: G2 = C^T C itself -- the residual norm is formed in the coordinates of C (g = Tu del, r^T r = rho^2 a0 +
+  // 2 rho g.u0 + g.G2 g as the dense form does): through U^T D U = S^-1 V^T G2 V S^-1 its rounding would be amplified by cond(E)
   for (int e = t; e < n * n; e += kThreads) {
-    const int i = e / n, j = e % n;
-    Ob[3 * ld * ld + i * ld + j] = 0.5 * (M0[i][j] + M0[j][i]);
+    const int i = e / n, jj = e % n;
+    Ob[3 * ld * ld + i * ld + jj] = 0.5 * (Rb[3 * ld * ld + i * ld + jj] + Rb[3 * ld * ld + jj * ld + i]);
   }
   if (t < ld) Ob[5 * ld * ld + t] = (t < n && !bad) ? lam_s[t] : 1.0;
   if (t == 0) {
-    Ob[5 * ld * ld + ld + 0] = bad ? -1.0 : 1.0;  // status: 1 = usable
+    Ob[5 * ld * ld + ld + 0] = bad ? (illcond ? -2.0 : -1.0) : 1.0;  // status: 1 = usable, -1 = Lam not positive, -2 = ill-conditioned basis
     Ob[5 * ld * ld + ld + 1] = (double)sweeps_e;
     Ob[5 * ld * ld + ld + 2] = (double)sweeps_h;
     Ob[5 * ld * ld + ld + 3] = (double)rank;

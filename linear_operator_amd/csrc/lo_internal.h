@@ -78,6 +78,8 @@ struct CgCtrl {
   int oc_next;            // operator-resident kernels: shared counter of the dynamic member hand-out
   int oc_next_ls;         // the same for the column-lockstep kernel (both may run in one solve)
   int pf_next;            // the same for the fused preconditioner apply of the streaming loop
+  int rs_redo;            // diagonal form of the R-space iteration: a member's right-hand side lies (almost) inside span(C) --
+                          // the host repeats the launch with the dense form (lo_rspace.hip)
 };
 
 // fused-update arguments of the skinny tn kernels (VMODE 1: p-update, VMODE 2: r/x-update; see lo_skinny.hip)

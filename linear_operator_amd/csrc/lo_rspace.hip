@@ -267,7 +267,6 @@ struct alignas(16) RsShared {
   double red[R4_WAVES][2 * RC + 4];
   double res[2 * RC + 4];
   double gv[R4_WAVES][32];      // every wave's own broadcast copy of the vector it multiplies (g, w0, at the end nrm * y)
-  double gu[R4_WAVES][32];      // diagonal form: the wave's copy of u0
   double out[2][R4_WAVES][32];  // the four products of an iteration, double-buffered by the iteration's parity
 };
 
@@ -346,7 +345,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
     constexpr int NM = (4 * RC * RC / 2 + R4_TPB - 1) / R4_TPB;  // 16-byte pieces of the four matrices per thread
     f32x4 mv[NM];
     {
-      // E | F E | E F E | G2 (| F | E F), or the diagonal form TinT | Ep | TuT | Nn (| Tin | lam)
+      // E | F E | E F E | G2 (| F | E F), or the diagonal form TinT | E^+ | TuT | G2 (| Tin | lam)
       const f32x4* src = reinterpret_cast<const f32x4*>((DG ? a.RSD : a.RS) + (size_t)b * 6 * RC * RC);
 #pragma unroll
       for (int u = 0; u < NM; ++u) mv[u] = src[min(tl + R4_TPB * u, 4 * RC * RC / 2 - 1)];
@@ -553,22 +552,25 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
         return lo_ + up_;
       };
       double* myv = rs.gv[wave];
-      double* myu = rs.gu[wave];
-      if (hf == 0) {
-        myv[j] = w0;
-        myu[j] = u0;
-      }
+      if (hf == 0) myv[j] = w0;
       __builtin_amdgcn_wave_barrier();
       const double* row0 = mat_s + (size_t)jr * MLD + hf * NH;
+      // c0 = TinT w0 = W^T beta0, g0 = TuT w0 = W^-1 beta0 (beta0 = U^T b^): |beta0|^2 = c0 . g0 and V S^-1 beta0 = Tin g0 --
+      // the projection on span(C) through the two well-conditioned transforms (E^+ = V S^-2 V^T would square cond(S))
       double c0 = own_row_dot(row0, myv + hf * NH);                              // TinT w0
-      double e0 = own_row_dot(row0 + (size_t)RC * MLD, myv + hf * NH);           // E^+ w0
-      double m0 = own_row_dot(row0 + (size_t)2 * RC * MLD, myu + hf * NH);       // TuT u0
-      const double* nrow = row0 + (size_t)3 * RC * MLD;
+      double e0 = own_row_dot(row0 + (size_t)2 * RC * MLD, myv + hf * NH);       // g0 = TuT w0
+      const double* nrow = row0 + (size_t)3 * RC * MLD;                          // row j of G2 = C^T C
+      const double* tucol = mat_s + (size_t)(2 * RC + hf * NH) * MLD + jr;       // column j of TuT (this half of its rows)
       c0 = live ? c0 : 0.0;
       e0 = live ? e0 : 0.0;
-      m0 = live ? m0 : 0.0;
-      double tau2 = s - lanes32_sum_d(w0 * e0);            // |b_perp|^2
+      double tau2 = s - lanes32_sum_d(c0 * e0);            // |b_perp|^2 = s - |beta0|^2
       tau2 = tau2 > 0.0 ? tau2 : 0.0;
+      // A right-hand side (almost) inside span(C): the complement's coordinate c' then carries a weight of tau2 / s in every
+      // inner product the iteration sees, yet stands for c' r0 in the solution -- the floor's 11 iterations can leave it
+      // unresolved without the recurrences noticing (tools/fuzz_eigform.py: one member in 10^4 with tau2 / s = 7.5e-9
+      // returned a solution whose true residual was 0.1 at a reported 1.2e-4, depending on the last bit of E).  The dense
+      // form keeps r0's coefficient as a coordinate of its own; such members ask for it (CgCtrl::rs_redo).
+      const bool delicate = !rhs_zero && tau2 < 1e-2 * s;
       const double lam = live ? lamj : 1.0;
       long long ts_a = 0, ts_b = 0;
       if (stamp) ts_a = wall_clock64();
@@ -609,12 +611,30 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
           const float s1f = (float)a0;
           rnn = __builtin_amdgcn_sqrtf(s1f < 0.f ? 0.f : s1f);
         } else if (own) {
+          // in the coordinates of C, as the dense form: r = c' r0 + C g with g = Tu (c - c' c0) (column walk of TuT), then
+          // r^T r = c'^2 a0 + 2 c' g.u0 + g.G2 g -- through the orthonormal basis the rounding of G2 would be amplified by cond(E)
           const double dl = fma(-cp, c0, cj);                          // del = c - c' c0
           __builtin_amdgcn_wave_barrier();
           if (hf == 0) myv[j] = dl;
           __builtin_amdgcn_wave_barrier();
-          const double nd = own_row_dot(nrow, myv + hf * NH);
-          const double r2 = row16_sum_d(halve_pair_d<16>(dl * nd, dl * m0, lane));
+          double gj_;
+          {
+            double a0_ = 0.0, a1_ = 0.0;
+#pragma unroll
+            for (int q = 0; q < NH; q += 2) {
+              const double2 dd = *reinterpret_cast<const double2*>(myv + hf * NH + q);
+              a0_ = fma(tucol[(size_t)q * MLD], dd.x, a0_);
+              a1_ = fma(tucol[(size_t)(q + 1) * MLD], dd.y, a1_);
+            }
+            double lo_, up_;
+            halves_d(a0_ + a1_, lo_, up_);
+            gj_ = live ? lo_ + up_ : 0.0;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (hf == 0) myv[j] = gj_;
+          __builtin_amdgcn_wave_barrier();
+          const double nd = own_row_dot(nrow, myv + hf * NH);          // (G2 g)_j
+          const double r2 = row16_sum_d(halve_pair_d<16>(gj_ * nd, gj_ * u0, lane));
           const double dnd = pick(r2, 0), dm = pick(r2, 16);
           const double s1 = fma(cp, fma(cp, a0, 2.0 * dm), dnd);       // r^T r
           const float s1f = (float)s1;
@@ -629,7 +649,8 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
           beta = 0.0;
           rn = rnn;
           if (wig == 0 && t == 0) a.init_conv[bc] = (rn < a.stop_after) ? 1 : 0;  // :204-205
-          close_flags = (rn < a.stop_after) ? 1u : 0u;
+          close_flags = ((rn < a.stop_after) ? 1u : 0u) | (delicate ? 4u : 0u);
+          if (delicate && rec && wave == 0) atomicOr(a.err + 4, 1);  // (CgCtrl::rs_redo, for the host-launched control step)
         }
         // (NaN after the first product, linear_cg.py:199-200: the residual norm is NaN exactly when the coordinates are)
         if (k == 0 && (rnn != rnn || rzn != rzn)) close_flags |= 2u;
@@ -658,10 +679,10 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
           __hip_atomic_store(a.close_gran + b, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      // y = Tin eta - xi E^+ w0: lane i walks column i of TinT (its half of the eigen-indices; consecutive lanes read
-      // consecutive doubles, eta is a broadcast) -- Tin itself never has to be on chip
+      // y = Tin (eta - xi g0): lane i walks column i of TinT (its half of the eigen-indices; consecutive lanes read
+      // consecutive doubles, the vector is a broadcast) -- Tin itself never has to be on chip
       __builtin_amdgcn_wave_barrier();
-      if (hf == 0) myv[j] = etaj;
+      if (hf == 0) myv[j] = fma(-etap, e0, etaj);
       __builtin_amdgcn_wave_barrier();
       xi = etap;
       {
@@ -675,7 +696,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
         }
         double lo_, up_;
         halves_d(a0_ + a1_, lo_, up_);
-        yj = (lo_ + up_) - etap * e0;
+        yj = lo_ + up_;
       }
       yj = live ? yj : 0.0;
       if (stamp) {  // (printed as wg-wait / publish / poll: start of the chain, the iterations, y)

@@ -7,10 +7,12 @@ symmetric matrix Hs = Gam P_U^-1 Gam = Q Lam Q^T gives W = Gam^-1 Q Lam^1/2 with
 coordinates c of r^ = P^ [U W c + c' b_perp] (b_perp = the part of the right-hand side outside span(U), coordinate c'
 starting at 1) linear_cg (linear_cg.py:245-332) is the CG of a DIAGONAL matrix:
     r.z = |c|^2 + c'^2 tau2      p.Ap = sum lam q^2 + q'^2 tau2      c -= alpha lam q     q = c + beta q     eta += alpha q
-with c0 = Tin^T w0 (Tin = V S^-1 W), tau2 = s - w0.E^+ w0, and at the end x = D^-1 (xi r0 + C y), xi = eta',
-y = Tin eta - xi E^+ w0.  The residual norm (stop rule, records) is the one quantity that is not diagonal:
-    r^T r = del^T Nn del + 2 c' del.m0 + c'^2 a0,   del = c - c' c0,   Nn = W^-1 (U^T D U) W^-T,   m0 = Tu^T u0, Tu = V S^-1 W^-T
-(off the dependent chain: only the has_converged mask at 1e-10 feeds back).
+with c0 = Tin^T w0 (Tin = V S^-1 W), g0 = Tu^T w0 (Tu = V S^-1 W^-T), tau2 = s - c0.g0, and at the end
+x = D^-1 (xi r0 + C y), xi = eta', y = Tin (eta - xi g0).  The residual norm (stop rule, records) is the one quantity that
+is not diagonal; this prototype forms it as
+    r^T r = del^T Nn del + 2 c' del.m0 + c'^2 a0,   del = c - c' c0,   Nn = W^-1 (U^T D U) W^-T,   m0 = Tu^T u0
+(off the dependent chain: only the has_converged mask at 1e-10 feeds back); the kernel forms it in the coordinates of C
+(g = Tu del, r^T r = c'^2 a0 + 2 c' g.u0 + g.G2 g): Nn amplifies the rounding of G2 by cond(E) (tools/fuzz_eigform.py).
 Measured here: alphas / betas / residual norms / solutions against proto_rspace.cg_rspace and the exact solution on the
 same cases, including rank-deficient C, r0 in span(C), small diagonals.
 """
@@ -26,6 +28,7 @@ from proto_w_recurrence import _root_form64  # noqa: E402
 from proto_rspace import cg_rspace, exact  # noqa: E402
 
 RANK_TOL = 1e-13
+USE_EP = False
 
 
 def eigform(E, F, G2):
@@ -71,9 +74,13 @@ def cg_eig(C, dinv32, form, rhs, iters, eps=1e-10, stop_after=1e-10):
     a0 = a0 / nrm ** 2
     dot = lambda a, bb: np.sum(a * bb, -2, keepdims=True)  # noqa: E731
     c0 = np.swapaxes(Tin, -1, -2) @ w0
-    e0 = Ep @ w0
     m0 = np.swapaxes(Tu, -1, -2) @ u0
-    tau2 = np.maximum(s - dot(w0, e0), 0.0)
+    if USE_EP:   # first version: E^+ = V S^-2 V^T squares the conditioning of the basis (1e-4 errors at cond(E) = 1e12)
+        e0 = Ep @ w0
+        tau2 = np.maximum(s - dot(w0, e0), 0.0)
+    else:        # g0 = Tu^T w0 = W^-1 beta0:  |beta0|^2 = c0.g0,  V S^-1 beta0 = Tin g0
+        g0 = np.swapaxes(Tu, -1, -2) @ w0
+        tau2 = np.maximum(s - dot(c0, g0), 0.0)
     lm = lam[..., None]
     c = c0.copy(); cp = np.ones_like(s)
     q = np.zeros_like(c); qp = np.zeros_like(s)
@@ -106,12 +113,12 @@ def cg_eig(C, dinv32, form, rhs, iters, eps=1e-10, stop_after=1e-10):
         c = c - alpha * lm * q
         cp = cp - alpha * qp
     xi = etap
-    y = Tin @ eta - xi * e0
+    y = (Tin @ eta - xi * e0) if USE_EP else Tin @ (eta - xi * g0)
     x = di * (xi * b + nrm * (C64 @ y))
     return x.astype(f32), np.stack(alphas), np.stack(betas), np.stack(rns)
 
 
-def run(B, N, R, c, k, dscale, doff, seed=5, cscale=1.0, decay=0.0, inspan=False, dup=False, zerocol=False):
+def run(B, N, R, c, k, dscale, doff, seed=5, cscale=1.0, decay=0.0, inspan=False, dup=False, zerocol=False, tiny=0.0):
     C, d, rhs = cases.lowrank_diag(seed, B, N, R, c)
     C = (C * cscale).astype(f32)
     if decay:
@@ -120,6 +127,8 @@ def run(B, N, R, c, k, dscale, doff, seed=5, cscale=1.0, decay=0.0, inspan=False
         C[..., R // 2:] = C[..., :R - R // 2]
     if zerocol:
         C[..., 3] = 0
+    if tiny:
+        C[..., 5] *= f32(tiny)
     d = ((d - 0.5) * dscale + doff).astype(f32)
     if inspan:
         rng0 = np.random.default_rng(seed + 1)
@@ -140,7 +149,7 @@ def run(B, N, R, c, k, dscale, doff, seed=5, cscale=1.0, decay=0.0, inspan=False
     xr, al, be, rn = cg_rspace(C, dinv32, F64, E64, G2, rhs, it)
     form = eigform(E64, F64, G2)
     xg, al2, be2, rn2 = cg_eig(C, dinv32, form, rhs, it)
-    print(f"N={N} R={R} k={k} Cx{cscale} decay={decay} d in [{doff:g},{doff + dscale:g}] inspan={inspan} dup={dup} zerocol={zerocol}: iters {it}\n"
+    print(f"N={N} R={R} k={k} Cx{cscale} decay={decay} d in [{doff:g},{doff + dscale:g}] inspan={inspan} dup={dup} zerocol={zerocol} tiny={tiny}: iters {it}\n"
           f"   x vs exact: oracle32 {rel(x32, xe):.1e} rspace {rel(xr, xe):.1e} eig {rel(xg, xe):.1e} | eig vs rspace {rel(xg, xr):.1e}"
           f" | alpha {rmax(al2, al):.1e} beta {rmax(be2, be):.1e} rn {rmax(rn2, rn):.1e} (last rn {rn[-1].max():.1e} / {rn2[-1].max():.1e})")
 
@@ -160,3 +169,9 @@ if __name__ == "__main__":
     run(3, 4096, 32, 3, 15, 1.0, 0.5, dup=True)
     run(3, 4096, 32, 3, 15, 1.0, 0.5, zerocol=True)
     run(3, 4096, 32, 3, 15, 0.01, 0.001, dup=True, inspan=True)
+    for use_ep in (True, False):   # one column of C scaled by 1e-6: cond(E) = 1e12, the direction is kept
+        globals()["USE_EP"] = use_ep
+        print("USE_EP", use_ep)
+        run(3, 8192, 12, 3, 12, 0.01, 0.001, tiny=1e-6)
+        run(3, 4096, 32, 3, 15, 0.01, 0.001, tiny=1e-6)
+        run(3, 4096, 32, 3, 15, 1.0, 0.5, tiny=1e-5)

@@ -160,3 +160,49 @@ def test_eigform_is_built_on_the_second_single_column_solve_only():
     assert K._eigform_due(11, 4096) and not K._eigform_due(10, 4096)
     K.EIGFORM_AFTER_USES = -1
     assert not K._eigform_due(10 ** 6, 512)
+
+
+def test_right_hand_side_inside_span_of_the_root_is_redone_on_the_dense_form():
+    """A right-hand side (almost) inside span(C) leaves the complement's coordinate with a weight of tau2 / s in every
+    inner product of the diagonal iteration (DESIGN 4.14): the kernel flags the member (CgCtrl::rs_redo) and
+    lo_cg_solve_f32 repeats the result-only pass on the dense form -- same bits as a dense-form solve."""
+    C, d, rhs, desc, pre, _L = _setup(7501, 40, 4096, 32)
+    rng = np.random.default_rng(3)
+    rhs_in = (C.astype(np.float64) @ rng.standard_normal((40, 32, 1)) + 1e-3 * rhs).astype(np.float32)
+    rhs_mixed = rhs.copy()
+    rhs_mixed[7] = rhs_in[7]                      # one member of the batch is enough
+    dense = K.cg_solve(desc, dev(rhs_mixed), precond=pre, tolerance=1e-4)
+    assert not K.cg_last_executed()["rspace_diag"]
+    pre.ensure_eigform()
+    assert torch.is_tensor(pre.RSD)
+    res = K.cg_solve(desc, dev(rhs_mixed), precond=pre, tolerance=1e-4)
+    e = K.cg_last_executed()
+    assert e["rspace"] == "resident" and not e["rspace_diag"] and e["lean"], e
+    assert torch.equal(res.x, dense.x) and res.iterations == dense.iterations
+    ex = _woodbury(C, d, rhs_mixed)
+    assert float(((res.x.double() - ex).norm(dim=-2) / ex.norm(dim=-2)).max()) < 1e-4
+    # the same cache keeps the diagonal form for right-hand sides in general position
+    ok = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+    assert K.cg_last_executed()["rspace_diag"]
+    exo = _woodbury(C, d, rhs)
+    assert float(((ok.x.double() - exo).norm(dim=-2) / exo.norm(dim=-2)).max()) < 1e-4
+
+
+def test_eigform_is_refused_where_the_change_of_basis_would_cost_accuracy():
+    """(s_max / s_min)(1 + s_max^2) > 1e9 over E's kept directions: status -2, the cache keeps the dense form."""
+    C, d, rhs = cases.lowrank_diag(7601, 6, 4096, 32, 1)
+    C[..., 5] *= np.float32(1e-6)
+    d = ((d - 0.5) * 0.01 + 0.001).astype(np.float32)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    L, perm = K.pivoted_cholesky(desc, 15)
+    pre = K.precond_build(L, dev(d), constant_diag=False, root=desc.A0, perm=perm)
+    pre.ensure_eigform()
+    assert pre.RSD is False
+    pre.ensure_eigform()                          # (not rebuilt)
+    assert pre.RSD is False
+    K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+    res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+    e = K.cg_last_executed()
+    assert e["rspace"] == "resident" and not e["rspace_diag"]
+    ex = _woodbury(C, d, rhs)
+    assert float(((res.x.double() - ex).norm(dim=-2) / ex.norm(dim=-2)).max()) < 1e-4
