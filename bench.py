@@ -481,8 +481,21 @@ def other_configs(device):
     with lo_settings.cg_tolerance(TOL), lo_settings.num_trace_samples(16):
         # (one untimed + two timed steps, as before: the cyclic collector is off in this process and every step's autograd
         # graph holds several GB until it is collected -- more repetitions would time the allocator, not the step)
-        t, _ = _time(train_step, 2, warm_seconds=0.0, min_seconds=0.0)
+        # Every step timed on its own, the median reported (with the per-step list): a mean over two steps right behind
+        # the Lanczos extra measured that extra's memory coming back through the caching allocator (7.9 / 22.8 ms for the
+        # same build in two runs; tools/mb_train_step.py: 7.3 - 7.5 ms per step in steady state).
+        train_step()
+        torch.cuda.synchronize()
+        laps = []
+        for _ in range(5):
+            ta = time.perf_counter()
+            out = train_step()
+            torch.cuda.synchronize()
+            laps.append(time.perf_counter() - ta)
+            del out
+        t = sorted(laps)[len(laps) // 2]
     res["cfg3_B512_inv_quad_logdet_forward_backward_host_api"] = {"ms": t * 1e3, "member_steps_per_s": B_PER_GPU / t,
+                                                                  "steps_ms": [round(x * 1e3, 3) for x in laps],
                                                                   "preconditioner": "rebuilt every step"}
     del Cm, d, full, desc, V, q_mat, Cg, dg, y
     # cfg4 shard: 128 of 1024 Kronecker members (256 (x) 256 + 1e-2 I), CG to tolerance 1e-3
