@@ -1011,8 +1011,13 @@ def main():
                                 "`end`: ONE all-gather after the K steps, inside the timed region"}
     # ---- the same K steps on the resident kernel that performs the 11 products on the rows (k_cg_onchip5, the engine
     # of rounds 2 - 4 and still the repeat-with-state / global-stop-rule engine): the R-space pass switched off ----
+    def all_ranks(flag):
+        """The comparison regions below contain barriers: every rank has to enter them or none (a rank whose timed solves
+        fell back to another engine would otherwise leave the others waiting)."""
+        return (min(_gather_rank_ms(dist, 1.0 if flag else 0.0, device)) > 0.5) if use_dist else bool(flag)
+
     matvec_engine = None
-    if engine_timed.startswith("resident R-space"):
+    if all_ranks(engine_timed.startswith("resident R-space")):
         os.environ["LO_OC_NO_RSPACE"] = "1"
         try:
             ms3 = timed_region(args.steps)
@@ -1025,7 +1030,7 @@ def main():
     # ---- the same K steps on the DENSE R-space iteration (four R x R products per iteration; the form a fresh cache
     # carries before its second solve) and the cost of the diagonal form this rank's cache was given ----
     rspace_dense_engine = None
-    if engine_timed.startswith("resident R-space, diagonal"):
+    if all_ranks(engine_timed.startswith("resident R-space, diagonal")):
         os.environ["LO_RS_NO_DIAG"] = "1"
         try:
             ms4 = timed_region(args.steps)
