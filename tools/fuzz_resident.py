@@ -34,6 +34,10 @@ while time.time() < t_end:
         L, perm = K.pivoted_cholesky(desc, k, contiguous=False)
         pre = K.precond_build(L, d, False, root=Cm if R <= 32 else None, perm=perm)
     tag = (B, N, R, c, k, nt, tol, max_iter)
+    # (forget which operators missed their result-only pass: the memo of lo_cg_solve_f32 is keyed on addresses and shapes,
+    #  the caching allocator hands a freed operator's address to the next case, and since round 5 the result-only pass --
+    #  fp64 R-space -- and the engine with the state -- fp32 -- differ in the last bits: seed 11, (9, 33000, 32, 1, 15))
+    K.set_onchip_cg(True)
     if os.environ.get("FUZZ_VERBOSE"):
         print(tag, flush=True)
     res = K.cg_solve(desc, rhs, precond=pre, n_tridiag=nt, tolerance=tol, max_iter=max_iter)
