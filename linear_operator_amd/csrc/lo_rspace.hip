@@ -920,6 +920,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
 // =====================================================================================================================
 constexpr int RSP_TR = 64;   // rows per tile of k_rs_part (16 per wave)
 constexpr int RSP_CMAX = 32; // columns per launch
+constexpr int RSP_SQ = 16;   // row classes of the s / a0 sums (threads per column)
 
 template <int RC, int NT>
 __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ C, const float* __restrict__ rhs,
@@ -932,7 +933,7 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
   __shared__ __attribute__((aligned(16))) float ctile[2][TR * LD];
   __shared__ __attribute__((aligned(16))) float btile[2][TR * WB];
   __shared__ float dtile[2][TR];
-  __shared__ double sqred[4][RSP_CMAX][2];
+  __shared__ double sqred[RSP_SQ][RSP_CMAX][2];
   // (the cross-wave reduction at the end reuses the tiles)
   static_assert(sizeof(float) * 2 * TR * WB >= sizeof(double) * 4 * 64 * 4 || sizeof(float) * 2 * TR * LD >= sizeof(double) * 4 * 64 * 4,
                 "reduction buffer inside a tile");
@@ -1012,7 +1013,10 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
   bool scaled[NT];
 #pragma unroll
   for (int nj = 0; nj < NT; ++nj) scaled[nj] = 16 * nj + a < c;
-  // s = sum b^2 dinv, a0 = sum b^2: thread (col = t % c, rsub = t / c < 4) walks 16 rows of its column per tile
+  // s = sum b^2 dinv, a0 = sum b^2: thread (col = t % c, rsub = t / c < nsq) walks the rows rsub, rsub + nsq, ... of its
+  // column -- ALL threads share the work (with four row classes the 4 c threads of the first wave did 16 rows each on the
+  // fp64 pipe the matrix instructions also run on, and every tile's barrier waited for that wave)
+  const int nsq = min(RSP_SQ, kThreads / c);
   const int scol = t % c, rsub = t / c;
   double s_acc = 0.0, a_acc = 0.0;
   int buf = 0;
@@ -1045,10 +1049,8 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
 #pragma unroll
         for (int nj = 0; nj < NT; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mi], bv[nj], acc[mi][nj], 0, 0, 0);
     }
-    if (rsub < 4) {
-#pragma unroll 4
-      for (int i = 0; i < TR / 4; ++i) {
-        const int row = rsub + 4 * i;
+    if (rsub < nsq) {
+      for (int row = rsub; row < TR; row += nsq) {
         const double v = (double)btile[buf][row * WB + scol];
         const double vv = v * v;
         a_acc += vv;
@@ -1077,15 +1079,20 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
         }
       }
     }
-  if (rsub < 4) {
+  if (rsub < nsq) {
     sqred[rsub][scol][0] = s_acc;
     sqred[rsub][scol][1] = a_acc;
   }
   __syncthreads();
   if (t < c) {
     double* sp = sq + ((size_t)b * S + s) * 2 * c;
-    sp[t] = (sqred[0][t][0] + sqred[1][t][0]) + (sqred[2][t][0] + sqred[3][t][0]);
-    sp[c + t] = (sqred[0][t][1] + sqred[1][t][1]) + (sqred[2][t][1] + sqred[3][t][1]);
+    double ss = 0.0, aa = 0.0;
+    for (int i = 0; i < nsq; ++i) {
+      ss += sqred[i][t][0];
+      aa += sqred[i][t][1];
+    }
+    sp[t] = ss;
+    sp[c + t] = aa;
   }
 }
 
