@@ -206,3 +206,22 @@ def test_eigform_is_refused_where_the_change_of_basis_would_cost_accuracy():
     assert e["rspace"] == "resident" and not e["rspace_diag"]
     ex = _woodbury(C, d, rhs)
     assert float(((res.x.double() - ex).norm(dim=-2) / ex.norm(dim=-2)).max()) < 1e-4
+
+
+def test_diagonal_form_against_the_real_references_solve_golden_g4():
+    """g4_solve_lowrank: the REAL reference's A.solve (linear_cg + rank-15 pivoted-Cholesky preconditioner, its own fp32
+    iteration) and the exact solution of the same systems; the diagonal form reproduces the reference's matvec count and
+    lands within 1e-4 of both (tests/golden/make_golden.py generated the fixture from /root/reference)."""
+    from conftest import load_golden
+
+    g = load_golden("g4_solve_lowrank")
+    C, d, rhs = cases.lowrank_diag(401, 4, 2048, 32, 1)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    L, perm = K.pivoted_cholesky(desc, 15, 1e-3)
+    pre = K.precond_build(L, dev(d), constant_diag=False, root=desc.A0, perm=perm)
+    K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+    res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
+    assert K.cg_last_executed()["rspace_diag"]
+    assert res.iterations == int(g["matvecs"]) - 1 == 11 and res.tolerance_reached
+    assert max_rel_err_cols(host(res.x), g["x"]) < 1e-4
+    assert max_rel_err_cols(host(res.x), g["x_exact"]) < 1e-4
