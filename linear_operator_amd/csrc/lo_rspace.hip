@@ -19,6 +19,11 @@
 // iteration stalls when r0 lies almost inside span(C)).  The mode serves the result-only first pass of a single-column
 // solve (as the w-recurrence mode did): a solve whose residual misses the stop rule at the floor is repeated by the
 // three-pass kernel with the continuation state.
+//
+// Second half of round 5 (template parameter DG of k_cg_rspace, lo_precond_desc.RSD, lo_eigform.hip): the same iteration in
+// the basis that diagonalises the preconditioned member on span(C) -- the CG of a diagonal matrix, one reduction of three
+// values per iteration, no R x R product and no barrier on the chain; residual norms (in the coordinates of C) off the
+// chain; right-hand sides (almost) inside span(C) ask for the dense form above (CgCtrl::rs_redo).  DESIGN.md 4.14.
 #include <algorithm>
 #include <stdlib.h>
 
