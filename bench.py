@@ -1041,6 +1041,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(5):
             pre.RSD = None
+            pre.rsd_refused = None
             pre.ensure_eigform()
         torch.cuda.synchronize(device)
         rspace_dense_engine = {"engine": eng4, "ms_per_step": ms4,

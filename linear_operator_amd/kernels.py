@@ -158,6 +158,7 @@ class WoodburyPreconditioner:
     # diagonal form of the R-space iteration (lo_precond_desc.RSD, csrc/lo_eigform.hip): fp64 [B, 6, rf_ld, rf_ld], built by
     # ensure_eigform() once the cache has served enough single-column solves to pay for it (_eigform_due)
     RSD: Optional[torch.Tensor] = None
+    rsd_refused: Optional[str] = None  # why lo_precond_eigform_f32's form is not used for this cache (None: not built yet / in use)
     rs_rank: int = 0      # true rank of the root the RS form was built from
     rs_uses: int = 0      # single-column result-only solves this cache has served
     source: Optional[tuple] = None  # (L, d) the preconditioner was built from (to build Q later)
@@ -186,15 +187,23 @@ class WoodburyPreconditioner:
         return self
 
     def ensure_eigform(self) -> "WoodburyPreconditioner":
-        """Build the diagonal form (lo_precond_eigform_f32) next to the R-space form; keeps RS when a member's form is unusable."""
-        if self.RSD is None and self.RS is not None and self.rs_rank >= 2 and self.rs_rank % 2 == 0 and self.RSD is not False:
+        """Build the diagonal form (lo_precond_eigform_f32) next to the R-space form.  The cache keeps the dense form when a
+        member refuses it (`rsd_refused`: an eigenvalue of the preconditioned member not positive, or a change of basis that
+        would cost accuracy -- DESIGN 4.14); one attempt per cache."""
+        if self.RSD is None and self.rsd_refused is None and self.RS is not None:
+            if self.rs_rank < 2 or self.rs_rank % 2:
+                self.rsd_refused = "root rank"
+                return self
             lib = _hip.load()
             B, ld = self.RS.shape[0], self.RS.shape[-1]
             RSD = torch.empty_like(self.RS)
             _hip.check(lib.lo_precond_eigform_f32(_hip.ptr(self.RS), B, self.rs_rank, ld, _hip.ptr(RSD),
                                                   _hip.stream_ptr(self.RS.device)), "lo_precond_eigform_f32")
-            ok = bool((RSD[:, 5, 1, 0] > 0).all().item())
-            self.RSD = RSD if ok else False
+            worst = float(RSD[:, 5, 1, 0].amin().item())
+            if worst > 0:
+                self.RSD = RSD
+            else:
+                self.rsd_refused = "ill-conditioned basis" if worst == -2.0 else "eigenvalue not positive"
         return self
 
     def c_struct(self) -> _hip.PrecondDesc:
@@ -207,7 +216,7 @@ class WoodburyPreconditioner:
             s.F, s.EF, s.rf_ld = self.F.data_ptr(), self.EF.data_ptr(), self.rf_ld
             s.E = None if self.E is None else self.E.data_ptr()
             s.RS = None if self.RS is None else self.RS.data_ptr()
-            s.RSD = self.RSD.data_ptr() if (self.RS is not None and torch.is_tensor(self.RSD)) else None
+            s.RSD = self.RSD.data_ptr() if (self.RS is not None and self.RSD is not None) else None
         if self.kron is not None:
             s.kron_a, s.kron_b, s.kron_F = (t.data_ptr() for t in self.kron)
         return s
@@ -427,7 +436,7 @@ def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optio
     keep += [mv_cb, pc_cb]
     if precond is not None and precond.RS is not None and c == 1 and not n_tridiag and x0 is None:
         precond.rs_uses += 1
-        if precond.RSD is None and _eigform_due(precond.rs_uses, B):
+        if precond.RSD is None and precond.rsd_refused is None and _eigform_due(precond.rs_uses, B):
             precond.ensure_eigform()
     pre_s = precond.c_struct() if precond is not None else None
     prm = _hip.CgParams()

@@ -197,9 +197,9 @@ def test_eigform_is_refused_where_the_change_of_basis_would_cost_accuracy():
     L, perm = K.pivoted_cholesky(desc, 15)
     pre = K.precond_build(L, dev(d), constant_diag=False, root=desc.A0, perm=perm)
     pre.ensure_eigform()
-    assert pre.RSD is False
-    pre.ensure_eigform()                          # (not rebuilt)
-    assert pre.RSD is False
+    assert pre.RSD is None and pre.rsd_refused == "ill-conditioned basis"
+    pre.ensure_eigform()                          # (one attempt per cache)
+    assert pre.RSD is None and pre.rsd_refused == "ill-conditioned basis"
     K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
     res = K.cg_solve(desc, dev(rhs), precond=pre, tolerance=1e-4)
     e = K.cg_last_executed()
