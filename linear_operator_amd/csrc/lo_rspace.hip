@@ -607,10 +607,14 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
         };
         const double cc = pick(red2, 0), clc = pick(red2, 16), clq = pick(red2, 32);
         const double rzn = fma(cp * cp, tau2, cc);                     // residual_inner_prod :215 / :35-36
-        // residual norm (:298 / :204): needed by the stop rule's records and by the has_converged mask; wave w forms it
-        // for every fourth iteration (and the first, the last, and whenever the mask could hold)
+        // residual norm (:298 / :204): needed by the stop rule's records and by the has_converged mask
+        // (neither closing step reads the records of the iterations in between -- cg_close_solve takes the last norm from the
+        //  member's granule, k_cg_ctrl_onchip reads the records of k = 0 and k = iters - 1 -- so the norm is formed for the
+        //  last iteration by one wave, for the first one when the host closes, and whenever the mask could hold)
         const bool sure = rzn > sure_rz;
-        const bool own = ((k & 3) == wave) || !sure;
+        const bool rec_first = k == 0 && a.close_gran == nullptr && wave == 0;
+        const bool rec_last = k == a.iters - 1 && wave == last_owner;
+        const bool own = rec_first || rec_last || !sure;
         float rnn = 0.f;
         if (k < 0) {
           const float s1f = (float)a0;
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(R4_TPB, 2 * R4_TPB / 256) void k_cg_rspace(OnchipAr
           beta = ((float)rz < a.eps) ? 0.0 : (double)((float)rzn * inv_rz);  // :39-42
           if (rhs_zero) rnn = 0.f;                                   // :299
           rn = rnn;
-          if (rec && wave == (k & 3)) a.resid_rec[(size_t)k * a.B + bc] = rn;
+          if (rec && (rec_first || rec_last)) a.resid_rec[(size_t)k * a.B + bc] = rn;
         } else {
           beta = 0.0;
           rn = rnn;
