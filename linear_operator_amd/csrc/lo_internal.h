@@ -145,6 +145,7 @@ struct MatvecPlan {
   const float* Apad;  // padded copy of C when R % 4 != 0 (else op.A0)
   int lda, R4;
   float* tpart;       // [B,S,R4,c]
+  bool mv_resident;   // shape the one-pass resident matvec takes (lo_lowrank_mv.hip); else the two-pass kernels
   float* kron_tmp;    // [B,N,c]
   float* dense_part;  // split-K partials of the dense matvec (small batches) or nullptr
   lo_matvec_cb cb;
@@ -205,6 +206,13 @@ int kron_matvec_mfma_cols(const float* K1, const float* K2, const float* diag, i
 int kron_S_dot(int n1, int n2, int64_t c, int S_default);
 int kron_matvec_mfma(const float* K1, const float* K2, const float* diag, int diag_mode, const float* v, float* tmp,
                      float* y, float* dot_part, int64_t B, int n1, int n2, const int* stop, hipStream_t st);
+
+// ---- one-pass operator-resident matvec of low-rank + diagonal members (lo_lowrank_mv.hip) ------------------------
+// y = C (C^T v) + d o v with C read from HBM once (rows wait in registers for the group all-reduce of t = C^T v).
+// R4 = padded rank 8 / 16 / 32, c <= 4 columns, N <= 32768.  LO_ERR_UNSUPPORTED: the caller runs the two-pass kernels.
+bool lowrank_mv_eligible(int R4, int64_t N, int64_t c);
+int lowrank_mv_run(const float* C, int R4, const float* d, int d_mode, const float* v, float* y, int64_t B, int64_t N,
+                   int64_t c, const int* stop, hipStream_t st);
 
 // ---- operator-resident CG (lo_cg_onchip.hip) -----------------------------------------------------
 struct OnchipArgs;

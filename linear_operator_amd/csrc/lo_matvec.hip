@@ -53,6 +53,7 @@ int matvec_plan_init(MatvecPlan* pl, const lo_op_desc* op, lo_matvec_cb cb, void
   pl->cb_user = cb_user;
   pl->Apad = nullptr;
   pl->tpart = nullptr;
+  pl->mv_resident = false;
   pl->kron_tmp = nullptr;
   pl->dense_part = nullptr;
   pl->lda = pl->R4 = 0;
@@ -79,6 +80,7 @@ int matvec_plan_init(MatvecPlan* pl, const lo_op_desc* op, lo_matvec_cb cb, void
         pl->Apad = op->A0;
       }
       pl->tpart = ar->take<float>((size_t)op->B * sp.S * R4 * c);
+      pl->mv_resident = lowrank_mv_eligible(R4, op->N, c);
       break;
     }
     case LO_OP_DENSE_DIAG: {
@@ -137,6 +139,12 @@ int matvec_run(const MatvecPlan* pl, const float* v, float* y, float* dot_part, 
   int rc = LO_OK;
   switch (op.kind) {
     case LO_OP_LOWRANK_DIAG:
+      // one pass over C with the rows resident between t = C^T v and y = C t + d o v (lo_lowrank_mv.hip); the fused dot
+      // partials of the CG iteration and shapes it does not take run the two streaming passes
+      if (pl->mv_resident && !dot_part) {
+        rc = lowrank_mv_run(pl->Apad, pl->R4, op.d, op.diag_mode, v, y, op.B, op.N, pl->c, stop, st);
+        if (rc != LO_ERR_UNSUPPORTED) return rc;
+      }
       rc = skinny_tn(pl->Apad, pl->lda, pl->R4, v, pl->c, pl->tpart, op.B, op.N, pl->sp, stop, st);
       if (rc) return rc;
       return skinny_nn(pl->Apad, pl->lda, pl->R4, pl->tpart, op.d, op.diag_mode, 1.0f, v, pl->c, y, dot_part, op.B,
