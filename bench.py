@@ -36,7 +36,7 @@ from linear_operator_amd import kernels as K  # noqa: E402
 B_PER_GPU, N, R, C_COLS, RANK_K = 512, 8192, 32, 1, 15
 TOL = 1e-4
 ITERS_FLOOR = 11  # linear_cg.py:303 -- the iterations the operator-resident kernel runs in one launch
-PROFILE_DIR = "r05"  # profiles/<dir>/ holds the rocprofv3 summaries of this command (tools/profile_round.sh)
+PROFILE_DIR = "r06"  # profiles/<dir>/ holds the rocprofv3 summaries of this command (tools/profile_round.sh)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0  # the guide's measured float4-copy rate: the ceiling a streaming kernel can reach
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (v_mfma_f32_16x16x4_f32 / 32x32x2, MI355X_MICROARCH.md)
@@ -1141,6 +1141,48 @@ def main():
         dom = max(prof, key=lambda k: prof[k][1])
         cnt, ms = prof[dom]
         avg_s = ms / cnt * 1e-3
+        # ---- the LITERAL batched CG matvec of north_star's 60 % target: one application of the operator to one column
+        # through lo_matvec_f32 (= torch.matmul(A, v) of the operator API).  k_lr_mv reads C from HBM ONCE: the rows wait
+        # in registers for the group all-reduce of C^T v (csrc/lo_lowrank_mv.hip); live HIP events on the launch stream ----
+        hbm_matvec = None
+        try:
+            def mv_call():
+                return K.matvec(desc, rhs)
+
+            t_mv, _ = _time(mv_call, 100)
+            prof_mv = _profiled(lambda: [mv_call() for _ in range(50)])
+            os.environ["LO_NO_RESIDENT_MV"] = "1"
+            try:
+                t_mv2, _ = _time(mv_call, 50)
+            finally:
+                del os.environ["LO_NO_RESIDENT_MV"]
+            if "lr_mv" in prof_mv:
+                hbm_matvec = _roof(
+                    "k_lr_mv<32,8,1>", "lo_matvec_f32 low-rank+diag 512x8192x32, c=1 (one batched CG matvec, C read once)",
+                    prof_mv["lr_mv"], "hbm", 4 * B_PER_GPU * (N * R + N + 2 * N * C_COLS),
+                    "SURVEY 8(d)'s algorithmic bytes of ONE batched matvec (C, d, v in; y out: 587.2 MB) / the kernel's "
+                    "launch time.  The rows of C are read from HBM once and wait in registers (128 per lane) for the "
+                    "group all-reduce of t = C^T v; y = C t + d o v comes from the same registers.  north_star's budget: "
+                    "<= 122 us (60 % of 8 TB/s)", _committed_traffic("traffic_mv.json"))
+                hbm_matvec["wall_us_per_call"] = t_mv * 1e6
+                hbm_matvec["member_matvecs_per_sec"] = B_PER_GPU / t_mv
+                hbm_matvec["frac_wall"] = 4 * B_PER_GPU * (N * R + N + 2 * N * C_COLS) / t_mv / 1e9 / HBM_PEAK_GBS
+                hbm_matvec["two_pass_wall_us_per_call"] = t_mv2 * 1e6
+                hbm_matvec["two_pass_note"] = ("LO_NO_RESIDENT_MV=1: k_skinny_tn + k_skinny_nn, C streamed twice (the "
+                                               "product of rounds 1 - 5)")
+        except Exception as e:  # noqa: BLE001 -- the headline line must not be lost to an extra
+            hbm_matvec = {"error": repr(e)}
+        # ---- what a solve costs when its preconditioner cache serves n single-column solves: the R-space engine reads
+        # E = C^T D^-1 C and C^T C (k_rs_gram64, part of the cache build) and, from the 25th solve on, the diagonal form
+        # (k_rs_eigform, built once); the timed region above runs on a cache that has paid both ----
+        cache_use = None
+        try:
+            prof_b = _profiled(lambda: build_precond(desc, d, need_q=False))
+            t_build, _ = _time(lambda: build_precond(desc, d, need_q=False), 3)
+            gram_ms = (prof_b["rs_gram64"][1] / prof_b["rs_gram64"][0]) if "rs_gram64" in prof_b else None
+            cache_use = {"cache_build_ms": t_build * 1e3, "rs_gram64_ms": gram_ms}
+        except Exception as e:  # noqa: BLE001
+            cache_use = {"error": repr(e)}
         rs_engine = dom == "cg_onchip" and K.cg_last_executed()["rspace"] == "resident"
         rs_diag = rs_engine and K.cg_last_executed().get("rspace_diag", False)
         if rs_diag:
@@ -1175,7 +1217,7 @@ def main():
             mv_s = avg_s / ITERS_FLOOR
             mv_note = ("operator-resident kernel: wall time of one full CG iteration (matvec + preconditioner + "
                        "updates) next to north_star's budget of 122 us for the streamed matvec alone; equivalent rate, "
-                       "not HBM traffic")
+                       "not HBM traffic -- the literal HBM matvec is `hbm_matvec`")
         kernels = {k: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2),
                        "alg_GBs": round(algorithmic_bytes(k, RANK_K) / (v[1] / v[0] * 1e-3) / 1e9, 1)}
                    for k, v in sorted(prof.items())}
@@ -1219,6 +1261,16 @@ def main():
                               f"{os.environ.get('LO_OC_RESERVE_CUS', '0')} CUs' worth of slots to RCCL (--gather step)"))
                 if world > 1 else "single GPU",
             },
+            "value_kind": ("cg-iteration-equivalents (operator read once per solve): members x the 11 operator "
+                           "applications the reference's linear_cg performs / wall time of the solve.  The timed engine "
+                           "(k_cg_rspace) reads C from HBM ONCE per solve and carries the 11 iterations on R + 1 Krylov "
+                           "coordinates in fp64: no product with C is executed per iteration.  The engine that applies "
+                           "the operator 11 times on the rows is `operator_applications_per_sec`; ONE application of the "
+                           "operator as an HBM pass (C read once) is `hbm_matvec`")
+                          if engine_timed.startswith("resident R-space") else "operator applications on the rows of C",
+            "operator_applications_per_sec": (matvec_engine or {}).get("value"),
+            "operator_applications_engine": (matvec_engine or {}).get("engine"),
+            "hbm_matvec": hbm_matvec,
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "prof_scope": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
@@ -1228,6 +1280,10 @@ def main():
                          "achievable_peak_source": "copy_this_box when measured (1 GiB float4 copy of this run), else "
                                                    "the MI355X guide's 6.29 TB/s",
                          "algorithmic_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6, "launches_timed": cnt,
+                         "algorithmic_bytes_survey": mv_alg,
+                         "algorithmic_bytes_survey_note": "SURVEY 8(d): 4 (N R + N + 2 N c) per member and matvec = 587.2 MB "
+                                                          "per batched matvec; the kernel needs these bytes ONCE per solve "
+                                                          "plus its fp64 R x R inputs (algorithmic_bytes_per_launch)",
                          "note": ("per-launch compulsory bytes (C, 1/d, rhs in, x out, the four fp64 R x R matrices and the "
                                   "eigenvalues of the diagonal form) / launch time.  The kernel holds a member's rows of C "
                                   "in VGPRs between its one reduction over the rows and x = D^-1 (xi b + C y); the 11 "
@@ -1282,6 +1338,32 @@ def main():
             "matvec_engine": matvec_engine,
             "rspace_dense_engine": rspace_dense_engine,
         }
+        if cache_use and "error" not in cache_use and rspace_dense_engine:
+            t_diag, t_dense = elapsed / args.steps * 1e3, rspace_dense_engine["ms_per_step"]
+            t_eig, due = rspace_dense_engine["eigform_build_ms"], 25
+
+            def per_solve(n, with_build):
+                tot = (cache_use["cache_build_ms"] if with_build else (cache_use["rs_gram64_ms"] or 0.0))
+                tot += t_dense * min(n, due - 1)
+                if n >= due:
+                    tot += t_eig + t_diag * (n - due + 1)
+                return tot / n
+
+            out["solve_ms_at_cache_use"] = {
+                str(n): {"ms_per_solve": per_solve(n, False), "ms_per_solve_incl_cache_build": per_solve(n, True)}
+                for n in (1, 25, 100)}
+            out["solve_ms_at_cache_use"]["pieces_ms"] = {
+                "solve_dense_form": t_dense, "solve_diagonal_form": t_diag, "rs_eigform_build": t_eig,
+                "rs_gram64": cache_use["rs_gram64_ms"], "cache_build": cache_use["cache_build_ms"],
+                "diagonal_form_from_solve": due}
+            out["solve_ms_at_cache_use"]["note"] = (
+                "wall ms per single-column solve when ONE preconditioner cache serves n solves.  ms_per_solve counts what the "
+                "R-space engine adds to a cache (k_rs_gram64 once; k_rs_eigform once at the 25th solve, the dense form before "
+                "it); ms_per_solve_incl_cache_build adds the whole cache build (pivoted Cholesky + root form + Gram matrices). "
+                "`ms_per_step` of this line is the diagonal-form solve alone; a training loop that rebuilds the operator every "
+                "step pays `end_to_end_ms`")
+        elif cache_use:
+            out["solve_ms_at_cache_use"] = cache_use
         if args.inject_timeouts > 0:
             out["inject_timeouts"] = {"injected": args.inject_timeouts, "soak_engines": engines_seen,
                                       "note": "engines of the soak's solves after the injected hand-off timeouts: "
@@ -1304,6 +1386,8 @@ def main():
             out["other_configs"], out["rooflines"] = extras
             if fused_roof is not None:
                 out["rooflines"].insert(0, fused_roof)
+            if hbm_matvec and "error" not in hbm_matvec:
+                out["rooflines"].insert(0, hbm_matvec)
             out["order"] = ("other_configs (cfg2 - cfg5 extras) -> HBM ceilings -> validation solve -> W warm-up steps -> "
                             "K timed steps -> soak -> end-to-end / roofline measurements -> cpu_baseline")
         elif extras_error is not None:
