@@ -713,7 +713,9 @@ static size_t cg_layout(const lo_op_desc* op, const lo_precond_desc* pre, bool p
   dd.B = B; dd.N = N; dd.c = (int)c; dd.S = sp.S;
   dd.ctrl = ar.take<CgCtrl>(1);
   // (granule buffer of the serial resident kernels right behind the control block: ONE memset clears both)
-  dd.oc_gbuf = ar.take<unsigned long long>(std::max(onchip_gbuf_bytes(66), rspace_gbuf_bytes(66 * 8)) / sizeof(unsigned long long));
+  // (k_cg_rspace launches 2 x onchip_num_workgroups() workgroups and indexes its granules by group: sized from that count,
+  //  not from the 256-CU part's 528 -- ADVICE r5)
+  dd.oc_gbuf = ar.take<unsigned long long>(std::max(onchip_gbuf_bytes(66), rspace_gbuf_bytes(std::max(66 * 8, 2 * onchip_num_workgroups()))) / sizeof(unsigned long long));
   dd.oc_close = ar.take<unsigned long long>((size_t)B + 2);
   dd.x = ar.take<float>(nv);
   dd.r = ar.take<float>(nv);

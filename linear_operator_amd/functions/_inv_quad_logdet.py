@@ -55,8 +55,14 @@ def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, U, 
             q = wb.ensure_q().Q[..., : wb.k]
             dinv = wb.dinv.unsqueeze(-1) if wb.constant_diag else wb.dinv
         # diag(P^-1) = 1/d - rowsum(Q^2): the row sums as ONE reduction pass (norm, squared) instead of a product
-        # tensor and its sum (250 -> 60 us at 512 x 8192 x 16)
-        pinv_diag = (dinv - torch.linalg.vector_norm(q, dim=-1).square()).reshape(*linear_op.batch_shape, -1)
+        # tensor and its sum (250 -> 60 us at 512 x 8192 x 16).  The dense closure of a CONSTANT diagonal applies
+        # (t - q q^T t) / sigma with the reference's unscaled q (added_diag_linear_operator.py:137-139) -- only the fp32
+        # kernel's Q carries the 1 / sqrt(sigma) factor -- so there diag(P^-1) = (1 - rowsum(q^2)) / sigma
+        qsq = torch.linalg.vector_norm(q, dim=-1).square()
+        if dense and pre.constant_diag:
+            pinv_diag = ((1.0 - qsq) * dinv).reshape(*linear_op.batch_shape, -1)
+        else:
+            pinv_diag = (dinv - qsq).reshape(*linear_op.batch_shape, -1)
         gd = pinv_diag * g.squeeze(-1)
         if const:
             gd = gd.sum(-1, keepdim=True)

@@ -394,7 +394,7 @@ def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optio
              precond_closure: Optional[Callable] = None, closure_batch_shape=None, n_tridiag: int = 0,
              max_iter: int = 1000, max_tridiag_iter: int = 20, tolerance: float = 1.0, eps: float = 1e-10,
              stop_updating_after: float = 1e-10, floor_max_iter: int = 0,
-             stop_reduce: Optional[Callable] = None) -> CGResult:
+             stop_reduce: Optional[Callable] = None, _retry: bool = False) -> CGResult:
     """lo_cg_solve_f32: the reference's linear_cg (utils/linear_cg.py:98-359) on the device.
 
     rhs [*batch, N, c].  Either `desc` (structured operator, fully native loop) or `matvec_closure`
@@ -434,10 +434,19 @@ def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optio
     else:
         pc_cb, pc_err = _hip.MATVEC_CB(), []
     keep += [mv_cb, pc_cb]
-    if precond is not None and precond.RS is not None and c == 1 and not n_tridiag and x0 is None:
-        precond.rs_uses += 1
-        if precond.RSD is None and precond.rsd_refused is None and _eigform_due(precond.rs_uses, B):
-            precond.ensure_eigform()
+    # The diagonal form (0.5 - 0.7 ms of Jacobi work, 25 MB at 512 x 32, one blocking read-back) is built once the cache has
+    # served enough solves ON THE RESIDENT R-SPACE KERNEL to pay for it: solves that kernel does not take (members beyond its
+    # range, the batch-global stop rule, a cool-down of the resident kernels, LO_OC_NO_RSPACE) are not counted -- they are
+    # counted AFTER the solve, from what lo_cg_last_executed says ran.
+    rs_candidate = (precond is not None and precond.RS is not None and c == 1 and not n_tridiag and x0 is None
+                    and stop_reduce is None and not _retry)
+    if rs_candidate and precond.RSD is None and precond.rsd_refused is None and _eigform_due(precond.rs_uses + 1, B) \
+            and (precond.rs_uses > 0 or EIGFORM_AFTER_USES is not None):
+        precond.ensure_eigform()
+    if stop_reduce is not None and precond is not None and precond.Q is None and precond_closure is None:
+        # batch-global stop rule over ranks: a root-form-only cache could send THIS rank through the "unsupported -> build Q
+        # -> start over" retry below while another rank continues -- the collective counts would diverge.  Q up front.
+        precond.ensure_q()
     pre_s = precond.c_struct() if precond is not None else None
     prm = _hip.CgParams()
     prm.c, prm.n_tridiag, prm.max_iter, prm.max_tridiag_iter = c, n_tridiag, max_iter, max_tridiag_iter
@@ -475,8 +484,13 @@ def cg_solve(desc: Optional[OperatorDescriptor], rhs: torch.Tensor, *, x0: Optio
         return cg_solve(desc, rhs, x0=x0, precond=precond, matvec_closure=matvec_closure,
                         precond_closure=precond_closure, closure_batch_shape=closure_batch_shape, n_tridiag=n_tridiag,
                         max_iter=max_iter, max_tridiag_iter=max_tridiag_iter, tolerance=tolerance, eps=eps,
-                        stop_updating_after=stop_updating_after, floor_max_iter=floor_max_iter, stop_reduce=stop_reduce)
+                        stop_updating_after=stop_updating_after, floor_max_iter=floor_max_iter, stop_reduce=stop_reduce,
+                        _retry=True)
     _hip.check(rc, "lo_cg_solve_f32")
+    if rs_candidate:
+        ex = _hip.CgPlan()
+        if lib.lo_cg_last_executed(C.byref(ex)) == 0 and ex.rspace == 2:
+            precond.rs_uses += 1
     if t_mat is not None:
         m = info.last_tridiag_iter + 1
         t_mat = t_mat[:, :, :m, :m].contiguous()

@@ -322,3 +322,44 @@ def test_float64_preconditioned_logdet_gradients_after_a_solve_on_the_same_tenso
             err_C = float((Cg.grad - want_C).norm() / want_C.norm())
             assert err_d < 1e-6 and err_C < 1e-6, (rep, err_d, err_C)
     clear_preconditioner_memo()
+
+
+@pytest.mark.parametrize("kind", ["constant_diag_operator", "diag_operator_with_equal_values"])
+def test_float64_preconditioned_logdet_gradients_with_a_constant_diagonal(kind):
+    """homoskedastic noise.  The dense closure of a constant diagonal is (t - q q^T t) / sigma with an
+    UNSCALED q (added_diag_linear_operator.py:137-139), so diag(P^-1) = (1 - rowsum(q^2)) / sigma; with sigma != 1 the
+    noise gradient of logdet P was wrong.  P = A here (preconditioner rank = root rank), so the gradient consists of the
+    hand-chained terms only and has to match dense autograd."""
+    import cases
+    import linear_operator_amd as lo
+    from linear_operator_amd.operators import (AddedDiagLinearOperator, ConstantDiagLinearOperator, DiagLinearOperator,
+                                               LowRankRootLinearOperator)
+    from linear_operator_amd.operators.added_diag_linear_operator import clear_preconditioner_memo
+
+    clear_preconditioner_memo()
+    B, N, R = 2, 2048, 16
+    C, _, rhs = cases.lowrank_diag(2701, B, N, R, 1, dtype=np.float64)
+    Cg = dev(C).requires_grad_(True)
+    y = dev(rhs)
+    sig = torch.tensor([[0.37], [2.5]], dtype=torch.float64, device="cuda", requires_grad=True)  # [B, 1], far from 1
+    dense = (Cg.detach() @ Cg.detach().mT + torch.diag_embed(sig.detach().expand(B, N))).requires_grad_(True)
+    (torch.linalg.solve(dense, y).mul(y).sum() + torch.logdet(dense).sum()).backward()
+    want_sig = dense.grad.diagonal(dim1=-1, dim2=-2).sum(-1, keepdim=True)
+    want_C = (dense.grad + dense.grad.mT) @ Cg.detach()
+    with lo.settings.cg_tolerance(1e-10), lo.settings.num_trace_samples(8), lo.settings.max_cg_iterations(200), \
+            lo.settings.max_preconditioner_size(R), lo.settings.preconditioner_tolerance(1e-12):
+        for rep in range(2):
+            torch.manual_seed(21 + rep)
+            Cg.grad = sig.grad = None
+            if kind == "constant_diag_operator":
+                D = ConstantDiagLinearOperator(sig, diag_shape=N)
+            else:
+                D = DiagLinearOperator(sig.expand(B, N))
+            A = AddedDiagLinearOperator(LowRankRootLinearOperator(Cg), D)
+            iq, ld = A.inv_quad_logdet(y, logdet=True)
+            assert torch.allclose(ld, torch.logdet(dense.detach()), rtol=1e-8)
+            (iq.sum() + ld.sum()).backward()
+            err_s = float((sig.grad - want_sig).norm() / want_sig.norm())
+            err_C = float((Cg.grad - want_C).norm() / want_C.norm())
+            assert err_s < 1e-6 and err_C < 1e-6, (kind, rep, err_s, err_C)
+    clear_preconditioner_memo()
