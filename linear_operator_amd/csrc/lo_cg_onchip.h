@@ -64,6 +64,8 @@ int onchip5_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st);
 bool onchip5_eligible(int RC, int64_t N, int64_t c);
 // the whole iteration on R + 1 coordinates (k_cg_rspace, lo_rspace.hip): one column, result only, one all-reduce per member
 int rspace_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st);
+// ... its diagonal form in the chunk-per-lane register layout (k_cg_rspace3, lo_rspace3.hip); called by rspace_launch
+int rspace3_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st);
 bool rspace_eligible(int RC, int64_t N, int64_t c);
 size_t rspace_gbuf_bytes(int nworkgroups);
 extern thread_local bool tls_rspace_diag_ran;      // ... and it ran the diagonal form (lo_precond_desc.RSD)
