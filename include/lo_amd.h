@@ -205,7 +205,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
  * (next engine down) or a group hand-off times out (streaming engine).
  *   cus  compute units to plan for; <= 0: the current device (LO_OC_RESERVE_CUS applied)                             */
 #define LO_ENGINE_NONE 0          /* no serial resident columns                                                 */
-#define LO_ENGINE_RESIDENT_GEN1 1 /* k_cg_onchip  (one row per thread, Q form, one column)                       */
+#define LO_ENGINE_RESIDENT_GEN1 1 /* (k_cg_onchip of rounds 1 - 5: removed in round 6, never reported any more)          */
 #define LO_ENGINE_RESIDENT_GEN2 2 /* k_cg_onchip4 (four rows per thread, Q form, columns one after the other)    */
 #define LO_ENGINE_RESIDENT_ROOT 3 /* k_cg_onchip5 (root-form preconditioner, one all-reduce per iteration)       */
 #define LO_STREAM_PRE_NONE 0       /* unpreconditioned update                                                    */

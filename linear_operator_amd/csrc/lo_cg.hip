@@ -632,9 +632,8 @@ static void cg_plan(const lo_op_desc* op, const lo_precond_desc* pre, bool pre_c
   // 1/d = 1, i.e. z = r and r.z = ||r||^2, which is the reference's unpreconditioned update (linear_cg.py:49-95)
   const bool oc_nopre = !pre && !pre_cb && sh.has_zero_q;
   const int ocR4 = oc_nopre ? 4 : preR4;
-  // (the first generation handles one column without tridiagonals; the second loops over the columns; the third
-  // advances 16 columns together on the matrix cores; the root-form kernel needs F / EF of the operator's own root)
-  const bool oc_gen1_ok = !oc_nopre && prm->n_tridiag == 0 && c == 1 && onchip_eligible(RC, preR4, N, c);
+  // (the second generation loops over the columns with the Q form; the third advances 16 columns together on the matrix
+  // cores; the root-form kernel needs F / EF of the operator's own root.  The first generation went in round 6.)
   const bool oc_base = (op->kind == LO_OP_LOWRANK_DIAG) && RC <= kMaxRank && (pre || oc_nopre) && !pre_cb && !has_x0 &&
                        prm->max_iter >= 11 && prm->max_iter > kfloor0 && oc_nwg >= 64 && !resident_off() &&
                        (prm->n_tridiag == 0 || sh.has_ab) && B < (1 << 24) - 1024;
@@ -648,8 +647,7 @@ static void cg_plan(const lo_op_desc* op, const lo_precond_desc* pre, bool pre_c
   const bool root_match = oc_nopre || (pre_root && pre->rf_ld == RC);
   const bool oc_root_ok = ls_cols < c && !getenv("LO_OC_GEN2") && onchip5_eligible(RC, N, c - ls_cols) && root_match;
   const bool gen2_ok = ls_cols < c && onchip4_eligible(RC, ocR4, N, c - ls_cols) && (!pre || pre->Q);
-  const bool gen1_ok = ls_cols < c && oc_gen1_ok && pre && pre->Q;
-  const bool oc_ok = oc_base && (ls_cols == c || oc_root_ok || gen2_ok || gen1_ok);
+  const bool oc_ok = oc_base && (ls_cols == c || oc_root_ok || gen2_ok);
   out->streaming_precond = pre_cb ? LO_STREAM_PRE_CLOSURE : (pre ? LO_STREAM_PRE_TWO_PASS : LO_STREAM_PRE_NONE);
   if (pre && pre->Q && sh.pf_shape && !tls_no_fused_precond && oc_nwg >= 64) {
     const bool kron = op->kind == LO_OP_KRON_DIAG && op->diag_mode == LO_DIAG_CONST && pre->constant_diag && pre->kron_a &&
@@ -674,12 +672,9 @@ static void cg_plan(const lo_op_desc* op, const lo_precond_desc* pre, bool pre_c
     if (oc_root_ok) {
       out->serial_engine = LO_ENGINE_RESIDENT_ROOT;
       out->serial_group = (getenv("LO_OC_GW8") && N <= 32768) ? onchip4_group_size(N) : onchip5_group_size(N);
-    } else if (gen2_ok && !(getenv("LO_OC_GEN1") && gen1_ok)) {
+    } else {
       out->serial_engine = LO_ENGINE_RESIDENT_GEN2;
       out->serial_group = onchip4_group_size(N);
-    } else {
-      out->serial_engine = LO_ENGINE_RESIDENT_GEN1;
-      out->serial_group = 8;
     }
   }
   // Result-only first pass ("lean"): the resident kernels that take it (root-form serial columns, lockstep) write the
@@ -931,7 +926,6 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   const int kfloor0 = plan.first_stop_iteration;
   const bool oc_nopre = !pre && !precond_cb && d.oc_zero_q != nullptr;
   const int ocR4 = oc_nopre ? 4 : preR4;
-  const bool oc_gen1_ok = !oc_nopre && prm->n_tridiag == 0 && c == 1 && onchip_eligible(pl.R4, preR4, N, c) && pre && pre->Q;
   const bool oc_ok = plan.resident != 0;
   int ls_cols = plan.lockstep_cols;
   bool lean = plan.lean != 0;
@@ -1025,7 +1019,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       if (rc == LO_OK) exec.lockstep_group = a.GW;
       if (rc == LO_ERR_UNSUPPORTED) {  // (does not fit this device: all columns go to the serial kernels)
         ls_cols = 0;
-        rc = (oc_gen1_ok || onchip4_eligible(pl.R4, ocR4, N, c)) ? LO_OK : LO_ERR_UNSUPPORTED;
+        rc = onchip4_eligible(pl.R4, ocR4, N, c) ? LO_OK : LO_ERR_UNSUPPORTED;
       }
     }
     // (the plan chose the root-form kernel for the serial columns -- or the lockstep kernel did not fit this device and
@@ -1080,14 +1074,14 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
     }
     if (rc == LO_OK && ls_cols < c && !serial_done && !oc_redo) {
       lean_state(false);
-      const bool gen2 = onchip4_eligible(pl.R4, ocR4, N, c - ls_cols) && !(getenv("LO_OC_GEN1") && oc_gen1_ok);
+      const bool gen2 = onchip4_eligible(pl.R4, ocR4, N, c - ls_cols);
       a.GW = gen2 ? onchip4_group_size(N) : 8;
       a.RW = (int)((N + a.GW - 1) / a.GW);
       a.col0 = ls_cols; a.ncols = c - ls_cols;
       a.xout = gen2 ? x : nullptr;
       a.gbuf = d.oc_gbuf; a.next_member = d.oc_err + 1;
       a.dbg = oc_dbg ? d.oc_dbg : nullptr;
-      LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(66), st));  // whole allocation (either generation)
+      LO_HIP_CHECK(hipMemsetAsync(d.oc_gbuf, 0, onchip_gbuf_bytes(66), st));  // whole allocation
       rc = LO_ERR_UNSUPPORTED;
       if (gen2) rc = onchip4_launch(pl.R4, ocR4, a, oc_nwg, st);
       if (gen2 && rc == LO_OK) {
@@ -1095,15 +1089,6 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
         exec.serial_group = a.GW;
       }
       xout_ok = gen2 && rc == LO_OK;
-      if (rc == LO_ERR_UNSUPPORTED && oc_gen1_ok) {
-        a.GW = 8;
-        a.RW = (int)((N + 7) / 8);
-        rc = onchip_launch(pl.R4, preR4, a, oc_nwg, st);
-        if (rc == LO_OK) {
-          exec.serial_engine = LO_ENGINE_RESIDENT_GEN1;
-          exec.serial_group = 8;
-        }
-      }
     }
     if (rc && rc != LO_ERR_UNSUPPORTED) return rc;
     if (rc == LO_OK && !oc_redo) {  // (LO_ERR_UNSUPPORTED: no resident kernel fits this device / shape -> streaming engine)

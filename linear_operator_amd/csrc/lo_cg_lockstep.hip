@@ -771,7 +771,9 @@ int lockstep_launch(int RC, bool pre, const OnchipArgs& a, int ncu, hipStream_t 
       : (a.GW == 8 ? lockstep_go<C_, P_, 8, 8>(a, ncu, st)                 \
                    : (a.GW == 4 ? lockstep_go<C_, P_, 4, 8>(a, ncu, st)    \
                                 : (a.GW == 2 ? lockstep_go<C_, P_, 2, 8>(a, ncu, st) : lockstep_go<C_, P_, 1, 8>(a, ncu, st)))))
+#ifdef LO_DEBUG_KERNELS  // (phase timers: two more instantiations that spill 46 registers; make CXXFLAGS+=-DLO_DEBUG_KERNELS)
   if (RC == 32 && pre && a.dbg) return v2 ? lockstep_go<32, true, 16, 4, true>(a, ncu, st) : lockstep_go<32, true, 8, 8, true>(a, ncu, st);
+#endif
   if (RC == 32) return pre ? LO_LS(32, true) : LO_LS(32, false);
   if (RC == 16 || RC == 8) return pre ? LO_LS(16, true) : LO_LS(16, false);
 #undef LO_LS

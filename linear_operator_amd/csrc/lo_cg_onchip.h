@@ -57,7 +57,6 @@ struct OnchipArgs {
   int dbg_member;
 };
 
-int onchip_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st);
 int onchip4_launch(int RC, int RK, const OnchipArgs& a, int nwg, hipStream_t st);
 // root-form serial-column kernel (k_cg_onchip5, lo_cg_onchip4.hip): one all-reduce per iteration
 int onchip5_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st);

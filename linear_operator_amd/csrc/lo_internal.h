@@ -220,7 +220,6 @@ size_t onchip_gbuf_bytes(int ngroups);
 // fp64 Gram partials of a root on the fp64 matrix cores (lo_rspace.hip): E = C^T diag(dinv) C (dinv_full != nullptr) and C^T C
 void rs_gram64_launch(const float* C, const float* dinv_full, int64_t B, int64_t N, int R, Split sp, double* gpartE,
                       double* gpart2, hipStream_t st);
-bool onchip_eligible(int RC, int RK, int64_t N, int64_t c);
 int onchip_num_workgroups();
 int onchip_l2_handoff_allowed();  // same-XCD plain-store hand-off: verified architectures only (lo_cg_onchip.hip)
 bool onchip4_eligible(int RC, int RK, int64_t N, int64_t c);  // lo_cg_onchip4.hip

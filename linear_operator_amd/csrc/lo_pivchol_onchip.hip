@@ -3,13 +3,20 @@
 // RootLinearOperator._get_indices root_linear_operator.py:37-50 / _diagonal :22-28).
 //
 // The streaming engine (lo_pivchol.hip) re-reads C (4NR bytes) and the m finished rows of L (4mN bytes) from HBM
-// for every pivot.  Here one group of 8 workgroups x 1024 threads owns one batch member for ALL pivots: thread =
-// one row i of the operator, its C row sits in LDS, its running diagonal, its position in the permutation and
-// its L entries L[0..m-1][i] sit in registers.  HBM traffic per member: C once (4NR) + L once (4 max_rank N).
-// Per pivot the group needs ONE exchange (8-byte {value, tag} granules, same mechanism as lo_cg_onchip.hip):
-// every workgroup publishes its best candidate (diagonal value, position, row), that row's C row and L entries,
-// and its partial of the error 1-norm; everybody then picks the same winner and has all it needs for the Schur
-// update of its own rows.
+// for every pivot.  Here a group of GW workgroups (256 threads x 4 rows; GW = smallest power of two that holds the member)
+// owns one batch member for ALL pivots: a thread keeps its four rows of C in registers, their running diagonal and position
+// in the permutation as well, and their L entries L[0..m-1][i] in LDS (swizzled 16-byte slots); two workgroups of different
+// members share a CU.  HBM traffic per member: C once (4NR) + L once (4 max_rank N).
+// Per pivot the group needs ONE exchange (8-byte {value, tag} granules, the hand-off of lo_group_reduce.h): every
+// workgroup publishes its best candidate (diagonal value, position, row), that row's C row and L entries, and its partial
+// of the error 1-norm; everybody then picks the same winner and has all it needs for the Schur update of its own rows.
+// (The first generation -- one row per thread, C in LDS, L in registers, 1.0 ms at the headline shape against 0.58 -- was
+// removed in round 6; nothing had selected it since round 2.)
+//
+// What a pivot costs (LO_OC_DEBUG stamps, 512 x 8192 x 32, rank 15, second round of members): 4.1 us =
+// candidate reduction + publication 1.06, exchange 0.62, winner + pivot row 0.38, C.C chain 0.51 (the mandated sequential
+// 32-term products and sums of four rows in lockstep), L.L chain 0.53, quotient / write-back 0.6.  The group exchange is
+// 15 % of a pivot: taking several pivots per exchange cannot shorten the chain by more than that.
 //
 // Every operation that feeds a pivot decision is the same individually rounded, fixed-order arithmetic as
 // lo_pivchol.hip / oracle.pivoted_cholesky (file compiled with -ffp-contract=off), so L and the permutation
@@ -31,13 +38,10 @@
 
 namespace lo {
 
-constexpr int PO_TPB = 1024;
 constexpr int PO_GW = 8;
-constexpr int PO_WAVES = PO_TPB / 64;
-constexpr int PO_CLD = 36;    // LDS row stride of C (floats)
 constexpr int PO_SLOT = 72;   // granules per workgroup and parity (header + 32 C entries + up to 32 L entries)
-constexpr int PO_MAXR = 16;   // pivots held in registers (first generation)
-constexpr int P4_MAXR = 32;   // pivots held in LDS (second generation, 8 slots of 16 bytes per row above 16)
+constexpr int PO_MAXR = 16;   // up to here: 4 slots of 16 bytes per row (64 KB of L rows, two workgroups per CU)
+constexpr int P4_MAXR = 32;   // above 16: 8 slots of 16 bytes per row (128 KB, one workgroup per CU)
 constexpr int PO_HDR = 4;     // value, position, (unused), error partial
 constexpr unsigned PO_MAXSPIN = 1u << 20;  // ~0.5 s of polling: co-residency was lost (never seen on a dedicated GPU)
 constexpr int PO_INVALID = 0x7fffffff;
@@ -58,61 +62,11 @@ struct PoArgs {
   long long* dbg;  // optional phase timers (wall_clock64 ticks) of member 0 / workgroup 0, or nullptr
 };
 
-struct PoShared {
-  float wv[PO_WAVES];
-  int wj[PO_WAVES];
-  float we[PO_WAVES];
-  unsigned part[PO_SLOT];
-  unsigned gath[PO_GW][PO_SLOT];
-};
-
 __device__ __forceinline__ bool po_better(float ov, int oj, float mv, int mj) {
   // FIRST maximal position wins (torch.max on CPU, :61-63)
   return oj != PO_INVALID && (mj == PO_INVALID || ov > mv || (ov == mv && oj < mj));
 }
 
-// All workgroups of the group publish sh.part[0..cnt) and receive everybody's in sh.gath[w][0..cnt).
-__device__ __forceinline__ void po_gather(PoShared& sh, int cnt, unsigned long long* gslot_base, int wig, unsigned tag,
-                                          int* err, bool same_xcd) {
-  const int t = threadIdx.x;
-  unsigned long long* slot = gslot_base + (size_t)(tag & 1u) * PO_GW * PO_SLOT;
-  if (t < cnt) {
-    const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)sh.part[t];
-    if (same_xcd)
-      __hip_atomic_store(slot + (size_t)wig * PO_SLOT + t, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else
-      __hip_atomic_store(slot + (size_t)wig * PO_SLOT + t, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  const int w = t >> 6, i = t & 63;  // wave w polls workgroup w's granules (at most 64 of the PO_SLOT are in use here)
-  if (w < PO_GW && i < cnt) {
-    const unsigned long long* src = slot + (size_t)w * PO_SLOT + i;
-    unsigned long long g = 0;
-    unsigned spin = 0;
-    for (;;) {
-      g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((unsigned)(g >> 32) == tag) break;
-      if (++spin > PO_MAXSPIN ||
-          ((spin & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        atomicExch(err, 1);  // timed out, or another workgroup already did: give up at once
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    sh.gath[w][i] = (unsigned)(g & 0xffffffffull);
-  }
-  __syncthreads();
-}
-
-// Per-row state of the factorisation (one thread = one row of the operator).
-struct PoRow {
-  float dg;   // running diagonal
-  int pos;    // position of this row in the permutation
-  int row;
-  bool valid;
-};
-
-// One pivot.  M is a template parameter so that every index into the register array Lr is a compile-time
-// constant (a runtime-indexed register array would be demoted to scratch memory).
 // argmax butterfly step over lane bit M on (value, position): FIRST maximal position wins; positions of valid
 // candidates are unique, so the unordered {own, partner} pair of bfly_i resolves identically in both lanes
 template <int M>
@@ -126,211 +80,7 @@ __device__ __forceinline__ void po_amax_step(float& v, int& j) {
   j = tb ? jb : ja;
 }
 
-template <int RC, int m>
-__device__ __forceinline__ void po_pivot(const PoArgs& a, PoShared& sh, const float* c_s, const float* crow,
-                                         float (&Lr)[PO_MAXR], PoRow& st, int64_t b, unsigned long long* gslot,
-                                         int wig, unsigned& tag, bool same_xcd) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const bool stamp = a.dbg && b == 0 && wig == 0 && t == 0;
-  long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-  if (stamp) c0 = wall_clock64();
-  const bool valid = st.valid;
-  float dg = st.dg;
-  int pos = st.pos;
-  // ---- workgroup candidate: argmax of the running diagonal over the positions >= m, error 1-norm partial ----
-  const bool cand = valid && pos >= m;
-  float bv = cand ? dg : -INFINITY;
-  int bj = cand ? pos : PO_INVALID;
-  po_amax_step<1>(bv, bj); po_amax_step<2>(bv, bj); po_amax_step<4>(bv, bj);
-  po_amax_step<8>(bv, bj); po_amax_step<16>(bv, bj); po_amax_step<32>(bv, bj);
-  const float es = wave_sum_fast(cand ? fabsf(dg) : 0.f);
-  if (lane == 0) {
-    sh.wv[wave] = bv;
-    sh.wj[wave] = bj;
-    sh.we[wave] = es;
-  }
-  __syncthreads();
-  // every wave finishes the reduction over the 16 wave partials itself (lane l holds partial l & 15)
-  float gv = sh.wv[lane & 15];
-  int gj = sh.wj[lane & 15];
-  float ge = lanes16_sum(sh.we[lane & 15]);
-  po_amax_step<1>(gv, gj); po_amax_step<2>(gv, gj); po_amax_step<4>(gv, gj); po_amax_step<8>(gv, gj);
-  gv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gv)));
-  gj = __builtin_amdgcn_readfirstlane(gj);
-  ge = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ge)));
-  // the wave holding the candidate publishes it: header, its C row (copied from LDS by RC lanes), its L entries
-  const bool mine = cand && pos == gj;
-  const unsigned long long bal = __ballot(mine);
-  if (bal != 0ull) {
-    const int src = __ffsll((long long)bal) - 1;
-    if (lane < RC) sh.part[PO_HDR + lane] = __float_as_uint(c_s[(wave * 64 + src) * PO_CLD + lane]);
-    if (mine) {
-      sh.part[0] = __float_as_uint(gv);
-      sh.part[1] = (unsigned)gj;
-#pragma unroll
-      for (int j = 0; j < m; ++j) sh.part[PO_HDR + RC + j] = __float_as_uint(Lr[j]);
-    }
-  }
-  if (t == 0) {
-    if (gj == PO_INVALID) {
-      sh.part[0] = __float_as_uint(-INFINITY);
-      sh.part[1] = (unsigned)PO_INVALID;
-    }
-    sh.part[3] = __float_as_uint(ge);
-  }
-  __syncthreads();
-  if (stamp) c1 = wall_clock64();
-  po_gather(sh, PO_HDR + RC + m, gslot, wig, ++tag, a.err, same_xcd);
-  if (stamp) c2 = wall_clock64();
-
-  // ---- group winner (identical in all 8 workgroups): lane l holds candidate l & 7 ----
-  float vb = __uint_as_float(sh.gath[lane & 7][0]);
-  const int myj = (int)sh.gath[lane & 7][1];
-  int jb = myj;
-  float etot = lanes8_sum(__uint_as_float(sh.gath[lane & 7][3]));
-  po_amax_step<1>(vb, jb); po_amax_step<2>(vb, jb); po_amax_step<4>(vb, jb);
-  vb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vb)));
-  jb = __builtin_amdgcn_readfirstlane(jb);
-  etot = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(etot)));
-  const unsigned long long wbal = __ballot(lane < PO_GW && myj == jb);
-  const int wb = wbal ? __ffsll((long long)wbal) - 1 : 0;
-  if (wig == 0 && t == 0) {
-    a.err_rec[(size_t)m * a.B + b] = etot;
-    if (m == 0) a.orig[b] = vb;
-    a.swaps[(size_t)b * a.max_rank + m] = jb;
-  }
-  // permutation swap of positions m and jb (:67-70), tracked per row
-  if (valid) {
-    if (pos == jb) pos = m;
-    else if (pos == m) pos = jb;
-  }
-  const float piv = sqrtf(vb);  // :73-74
-  if (valid) {
-    if (pos == m) {
-      Lr[m] = piv;
-    } else if (pos > m) {  // Schur update of row m at the not yet pivoted rows (:77-95)
-      const float* g = reinterpret_cast<const float*>(sh.gath[wb]) + PO_HDR;
-      float rowv = 0.f;
-#pragma unroll
-      for (int q = 0; q < RC / 4; ++q) {
-        const float4 g4 = *reinterpret_cast<const float4*>(g + 4 * q);
-        const float4 c4 = *reinterpret_cast<const float4*>(crow + 4 * q);
-        rowv = (q == 0) ? g4.x * c4.x : rowv + g4.x * c4.x;
-        rowv = rowv + g4.y * c4.y;
-        rowv = rowv + g4.z * c4.z;
-        rowv = rowv + g4.w * c4.w;
-      }
-      float v = rowv;
-      if constexpr (m > 0) {
-        float u[PO_MAXR];
-#pragma unroll
-        for (int q = 0; q < (m + 3) / 4; ++q) {
-          const float4 u4 = *reinterpret_cast<const float4*>(g + RC + 4 * q);
-          u[4 * q] = u4.x; u[4 * q + 1] = u4.y; u[4 * q + 2] = u4.z; u[4 * q + 3] = u4.w;
-        }
-        float acc = u[0] * Lr[0];
-#pragma unroll
-        for (int j = 1; j < m; ++j) acc = acc + u[j] * Lr[j];
-        v = rowv - acc;
-      }
-      v = v / piv;
-      Lr[m] = v;
-      dg = dg - v * v;
-    }
-  }
-  // sh.gath is next written two barriers from here (candidate reduction, publication): no extra barrier
-  st.dg = dg;
-  st.pos = pos;
-  if (stamp) {
-    c3 = wall_clock64();
-    a.dbg[4] += c1 - c0;
-    a.dbg[5] += c2 - c1;
-    a.dbg[6] += c3 - c2;
-  }
-}
-
-template <int RC, int m>
-__device__ __forceinline__ void po_pivots(const PoArgs& a, PoShared& sh, const float* c_s, const float* crow,
-                                          float (&Lr)[PO_MAXR], PoRow& st, int64_t b, unsigned long long* gslot,
-                                          int wig, unsigned& tag, bool same_xcd) {
-  if constexpr (m < PO_MAXR) {
-    if (m < a.rank) {
-      po_pivot<RC, m>(a, sh, c_s, crow, Lr, st, b, gslot, wig, tag, same_xcd);
-      po_pivots<RC, m + 1>(a, sh, c_s, crow, Lr, st, b, gslot, wig, tag, same_xcd);
-    }
-  }
-}
-
-template <int RC>
-__global__ __launch_bounds__(PO_TPB) void k_pc_onchip(PoArgs a) {
-  __shared__ PoShared sh;
-  __shared__ float c_s[PO_TPB * PO_CLD];
-  const int wg = blockIdx.x;
-  const int xcd = wg % 8, jx = wg / 8;  // block b runs on XCD b % 8: keep a group behind one L2 (speed only)
-  const int groups_per_xcd = (gridDim.x / 8) / PO_GW;
-  const int grp = xcd * groups_per_xcd + jx / PO_GW;
-  const int wig = jx % PO_GW;
-  const int ngroups = groups_per_xcd * 8;
-  if (jx / PO_GW >= groups_per_xcd) return;
-  const int t = threadIdx.x;
-  unsigned long long* gslot = a.gbuf + (size_t)grp * 2 * PO_GW * PO_SLOT;
-  unsigned tag = 0;
-  bool same_xcd = false;
-  {  // placement check through the agent-scope path: plain-store hand-off only when all 8 share an XCD
-    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
-    if (t == 0) sh.part[0] = xcc;
-    __syncthreads();
-    po_gather(sh, 1, gslot, wig, ++tag, a.err, false);
-    bool same = true;
-#pragma unroll
-    for (int w = 1; w < PO_GW; ++w) same = same && (sh.gath[w][0] == sh.gath[0][0]);
-    same_xcd = same && (a.allow_l2_handoff != 0);
-    __syncthreads();
-  }
-
-  for (int64_t b = grp; b < a.B; b += ngroups) {
-    const bool stamp = a.dbg && b == 0 && wig == 0 && t == 0;
-    if (stamp) a.dbg[0] = wall_clock64();
-    const int row = wig * a.RW + t;
-    const bool valid = (t < a.RW) && (row < a.N);
-    float* crow = c_s + t * PO_CLD;
-    {
-      const int row0 = wig * a.RW;
-      const int nv = max(0, min(a.RW, a.N - row0));
-      float4 cq[RC / 4];
-      rows_issue<RC, PO_TPB>(a.C + ((size_t)b * a.N + row0) * RC, nv, cq);  // coalesced: 1 KiB per wave instruction
-      rows_commit<RC, PO_CLD, PO_TPB>(c_s, cq);
-    }
-    __syncthreads();
-    float dg = 0.f;
-    {
-      float acc = crow[0] * crow[0];  // (root ** 2).sum(-1), sequential in r
-#pragma unroll
-      for (int r = 1; r < RC; ++r) acc = acc + crow[r] * crow[r];
-      dg = valid ? acc : 0.f;
-    }
-    int pos = valid ? row : PO_INVALID;
-    float Lr[PO_MAXR];
-#pragma unroll
-    for (int m = 0; m < PO_MAXR; ++m) Lr[m] = 0.f;
-
-    if (stamp) a.dbg[1] = wall_clock64();
-    PoRow st{dg, pos, row, valid};
-    po_pivots<RC, 0>(a, sh, c_s, crow, Lr, st, b, gslot, wig, tag, same_xcd);
-
-    if (stamp) a.dbg[2] = wall_clock64();
-    if (valid) {
-      float* Lb = a.L + (size_t)b * a.max_rank * a.N + row;
-#pragma unroll
-      for (int m = 0; m < PO_MAXR; ++m)
-        if (m < a.max_rank) Lb[(size_t)m * a.N] = (m < a.rank) ? Lr[m] : 0.f;
-    }
-    __syncthreads();  // c_s / sh reuse by the next member
-    if (stamp) a.dbg[3] = wall_clock64();
-  }
-}
-
-// ---- second generation: 4 rows per thread, two workgroups per CU (same idea as lo_cg_onchip4.hip) -------------
+// ---- 4 rows per thread, two workgroups per CU (same idea as lo_cg_onchip4.hip) ---------------------------------
 // Workgroup = 256 threads x 4 rows; the 4 C rows of a thread live in VGPRs, the L rows of the workgroup in LDS
 // (1024 x 16 floats, 16-byte slots XOR-swizzled), so the pivot index is a run-time value and the pivot loop is a
 // plain loop.  A member is a group of GW = 8 (N <= 8192), 16 (N <= 16384) or 32 (N <= 32768) workgroups; two workgroups of
@@ -1130,8 +880,8 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   const bool wide = max_rank > PO_MAXR;  // rank 17 .. 32: 128 KB of L rows per workgroup, one workgroup per CU
   const int wpc = wide ? 1 : 2;          // workgroups per CU the launch relies on
   const size_t dyn_lds = wide ? sizeof(float4) * (size_t)P4_ROWS * 8 : 0;
-  bool gen2 = wide || !(getenv("LO_OC_GEN1") && op->N <= (int64_t)PO_GW * PO_TPB);
-  if (gen2) {
+  bool gen2 = true;
+  {
     int per_cu = 0;
     hipError_t e = hipErrorUnknown;
 #define LO_OCC(R_, G_)                                                                                               \
@@ -1158,8 +908,8 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
     // every XCD must hold at least one whole group, all of its workgroups resident at once
     gen2 = (e == hipSuccess) && per_cu >= wpc && (wpc * nwg / 8) / gw2 >= 1;
   }
-  if (!gen2 && (wide || op->N > (int64_t)PO_GW * PO_TPB)) return LO_ERR_LAUNCH;  // caller runs the streaming engine
-  const int gw = gen2 ? gw2 : PO_GW;
+  if (!gen2) return LO_ERR_LAUNCH;  // two workgroups per CU do not fit this device: the caller runs the streaming engine
+  const int gw = gw2;
   PoArgs a;
   a.C = Csrc;
   a.B = op->B;
@@ -1184,11 +934,10 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
   LO_HIP_CHECK(hipMemsetAsync(l.err, 0, 4 * sizeof(int), st));
   if (getenv("LO_OC_TEST_FALLBACK")) LO_HIP_CHECK(hipMemsetAsync(l.err, 1, 1, st));  // as if an exchange had timed out
   LO_HIP_CHECK(hipMemsetAsync(l.gbuf, 0, sizeof(unsigned long long) * (size_t)64 * 2 * PO_GW * PO_SLOT, st));
-  dim3 grid(nwg), block(PO_TPB);
   LO_PROF_BEGIN("pc_onchip", st);
   {
   ResidentLaunch guard(st);
-  if (gen2) {
+  {
     dim3 grid2(wpc * nwg), block2(P4_TPB);
 #define LO_GO(R_, G_)                                                                      \
   if (wide) hipLaunchKernelGGL((k_pc_onchip4<R_, G_, 8>), grid2, block2, dyn_lds, st, a);  \
@@ -1205,9 +954,7 @@ int pc_onchip_run(const lo_op_desc* op, int rank, int max_rank, float tol, float
     if (RP == 32) { LO_GO_R(32) } else if (RP == 16) { LO_GO_R(16) } else { LO_GO_R(8) }
 #undef LO_GO_R
 #undef LO_GO
-  } else if (RP == 32) hipLaunchKernelGGL((k_pc_onchip<32>), grid, block, 0, st, a);
-  else if (RP == 16) hipLaunchKernelGGL((k_pc_onchip<16>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((k_pc_onchip<8>), grid, block, 0, st, a);
+  }
   }
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();

@@ -1395,15 +1395,18 @@ int rspace_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st) {
       return rc3;
     }
   }
+  // (the diagonal form of groups of up to 32 workgroups is k_cg_rspace3's: k_cg_rspace<.., true> is instantiated for the
+  //  groups of 64 only -- members of 32768 < N <= 65536 rows)
+#define LO_RS0(C_, G_) return rspace_go<C_, G_, false>(a, nwg, st)
 #define LO_RS1(C_, G_) return dg ? rspace_go<C_, G_, true>(a, nwg, st) : rspace_go<C_, G_, false>(a, nwg, st)
 #define LO_RS(C_)                                                                                    \
   switch (a.GW) {                                                                                    \
-    case 1: LO_RS1(C_, 1);                                                                           \
-    case 2: LO_RS1(C_, 2);                                                                           \
-    case 4: LO_RS1(C_, 4);                                                                           \
-    case 8: LO_RS1(C_, 8);                                                                           \
-    case 16: LO_RS1(C_, 16);                                                                         \
-    case 32: LO_RS1(C_, 32);                                                                         \
+    case 1: LO_RS0(C_, 1);                                                                           \
+    case 2: LO_RS0(C_, 2);                                                                           \
+    case 4: LO_RS0(C_, 4);                                                                           \
+    case 8: LO_RS0(C_, 8);                                                                           \
+    case 16: LO_RS0(C_, 16);                                                                         \
+    case 32: LO_RS0(C_, 32);                                                                         \
     default: LO_RS1(C_, 64);                                                                         \
   }
   if (RC == 32) {
@@ -1415,6 +1418,7 @@ int rspace_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st) {
   }
 #undef LO_RS
 #undef LO_RS1
+#undef LO_RS0
   return LO_ERR_UNSUPPORTED;
 }
 

@@ -49,12 +49,25 @@ constexpr int R3_ROWS = 1024;
 
 __host__ __device__ constexpr int r3_np(int RC) { return 2 * RC + 6; }  // w0 | u0 | s | a0 | next member | sum dinv^2 | xcc | xcc^2
 
+// xor-4 exchange of a double on the DPP path (two row shifts under complementary bank masks per word) instead of the
+// LDS-crossbar ds_swizzle with its own wait
+__device__ __forceinline__ unsigned xor4_dpp_u(unsigned x) {
+  const int a = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0x5, false);  // row_shl:4 -> banks 0, 2 read lane + 4
+  return (unsigned)__builtin_amdgcn_update_dpp(a, (int)x, 0x114, 0xf, 0xa, false);  // row_shr:4 -> banks 1, 3 read lane - 4
+}
+__device__ __forceinline__ double halve4_d(double lo, double hi, int lane) {
+  const bool up = (lane & 4) != 0;
+  const double keep = up ? hi : lo;
+  const double send = up ? lo : hi;
+  return keep + mk_d(xor4_dpp_u(lo_w(send)), xor4_dpp_u(hi_w(send)));
+}
+
 // sum of one row's CH lane partials for CH rows at once (fp64): lane k ends with the total of p[k]
 template <int CH>
 __device__ __forceinline__ double rows_reduce_d(double (&p)[CH], int lane) {
   if constexpr (CH == 8) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) p[m] = halve_pair_d<4>(p[m], p[m + 4], lane);
+    for (int m = 0; m < 4; ++m) p[m] = halve4_d(p[m], p[m + 4], lane);
     p[0] = halve_pair_d<2>(p[0], p[2], lane);
     p[1] = halve_pair_d<2>(p[1], p[3], lane);
     return halve_pair_d<1>(p[0], p[1], lane);
@@ -524,7 +537,7 @@ int rspace3_go(const OnchipArgs& a, int nwg, hipStream_t st) {
   OnchipArgs a2 = a;
   {
     const char* e = getenv("LO_RS_PRIO");
-    a2.prefetch = e ? atoi(e) : 1;
+    a2.prefetch = e ? atoi(e) : 3;  // iterations AND the x pass at raised priority (0.1935 -> 0.1894 ms per headline solve)
   }
   hipLaunchKernelGGL((k_cg_rspace3<RC, GW>), dim3(2 * nwg), dim3(R3_TPB), 0, st, a2);
   LO_PROF_END(st);
@@ -550,8 +563,7 @@ int rspace3_gw(const OnchipArgs& a, int nwg, hipStream_t st) {
 // The diagonal form in the chunk-per-lane layout: groups of up to 32 workgroups (N <= 32768), members of at least 256 rows,
 // rows per workgroup = 1024 (a.RW).  LO_ERR_UNSUPPORTED: rspace_launch runs k_cg_rspace<.., true>.
 int rspace3_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st) {
-  if (!a.RSD || a.x || a.c != 1 || a.ab_rec || !a.xout || a.GW > 32 || a.N < 256 || (int64_t)a.GW * R3_ROWS < a.N ||
-      getenv("LO_RS_OLD_LAYOUT"))
+  if (!a.RSD || a.x || a.c != 1 || a.ab_rec || !a.xout || a.GW > 32 || a.N < 256 || (int64_t)a.GW * R3_ROWS < a.N)
     return LO_ERR_UNSUPPORTED;
   // granules of a group: 2 x GW x NP x 2 -- inside what rspace_gbuf_bytes reserves per workgroup (432)
   if (RC == 32) return rspace3_gw<32>(a, nwg, st);
