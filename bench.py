@@ -902,7 +902,7 @@ def main():
         if not e["resident"]:
             return "streaming"
         if e["rspace"] == "resident" and e.get("rspace_diag"):
-            return "resident R-space, diagonal form (k_cg_rspace<..,true>)"
+            return "resident R-space, diagonal form (k_cg_rspace3)"
         return {"resident": "resident R-space (k_cg_rspace)", "cols": "R-space columns (k_rs_part/iter/apply)",
                 "none": "resident three-pass (k_cg_onchip5)"}[e["rspace"]]
 
@@ -1188,8 +1188,9 @@ def main():
         if rs_diag:
             # k_cg_rspace<..,true>: C, 1/d, the right-hand side in, x out, and four fp64 R x R matrices + R eigenvalues of
             # the diagonal form (TinT | E^+ | TuT | G2 | lam: lo_precond_desc.RSD)
-            alg = B_PER_GPU * (4 * N * (R + 3) + 4 * R * R * 8 + 8 * R)
-            dom_kernel = "k_cg_rspace<32,8,true>"
+            # (k_cg_rspace3 keeps three of them in LDS -- TinT | TuT | G2 -- and reads the eigenvalues: 3 R^2 + R doubles)
+            alg = B_PER_GPU * (4 * N * (R + 3) + 3 * R * R * 8 + 8 * R)
+            dom_kernel = "k_cg_rspace3<32,8>"
         elif rs_engine:
             # k_cg_rspace: C, 1/d, the right-hand side in, x out, and the member's six fp64 R x R matrices of the
             # R-space form (E | F E | E F E | G2 | F | E F: lo_precond_desc.RS)
@@ -1284,15 +1285,15 @@ def main():
                          "algorithmic_bytes_survey_note": "SURVEY 8(d): 4 (N R + N + 2 N c) per member and matvec = 587.2 MB "
                                                           "per batched matvec; the kernel needs these bytes ONCE per solve "
                                                           "plus its fp64 R x R inputs (algorithmic_bytes_per_launch)",
-                         "note": ("per-launch compulsory bytes (C, 1/d, rhs in, x out, the four fp64 R x R matrices and the "
+                         "note": ("per-launch compulsory bytes (C, 1/d, rhs in, x out, three fp64 R x R matrices and the "
                                   "eigenvalues of the diagonal form) / launch time.  The kernel holds a member's rows of C "
-                                  "in VGPRs between its one reduction over the rows and x = D^-1 (xi b + C y); the 11 "
-                                  "iterations of the floor run as the CG of a DIAGONAL matrix on R + 1 coordinates in fp64 "
-                                  "(one reduction of three values per iteration).  64 members are on chip at a time and a "
-                                  "member takes ~20 us from its first load to its last store (load 6 - 9, reduction + "
-                                  "group all-reduce 5 - 6.5, iterations 5.7, x 1.2: LO_OC_DEBUG stamps, profiles/r05), "
-                                  "so 64 MB / 20 us = 3.2 TB/s: bound by that latency chain at the on-chip capacity, not "
-                                  "by HBM") if rs_diag else
+                                  "in VGPRs (16-byte chunk per lane, no transposition) between its one reduction over the "
+                                  "rows and x = D^-1 (xi b + C y); the 11 iterations of the floor run as the CG of a DIAGONAL "
+                                  "matrix on R + 1 coordinates in fp64 (one reduction of three values per iteration).  64 "
+                                  "members are on chip at a time (235 VGPRs: C 128 + the fp64 chain) and a member takes "
+                                  "~19 us from its first load to its last store (load 4 - 10, reduction + group all-reduce "
+                                  "5 - 6, iterations 5.3, x 1.4 - 2: LO_OC_DEBUG stamps, profiles/r06), so 64 MB / 19 us = "
+                                  "3.4 TB/s: bound by that latency chain at the on-chip capacity, not by HBM") if rs_diag else
                                  ("per-launch compulsory bytes (C, 1/d, rhs in, x out, the six fp64 R x R matrices of the "
                                   "R-space form) / launch time.  The kernel holds a member's rows of C in VGPRs between "
                                   "its one reduction over the rows and x = D^-1 (xi b + C y); the 11 iterations of the "

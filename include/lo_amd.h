@@ -197,6 +197,15 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
                     const float* x0, float* x, float* t_mat, void* ws, size_t ws_bytes, lo_cg_info* info,
                     void* stream);
 
+/* ---- prototype: the gather of SURVEY 8(e) as peer writes (round 6) ------------------------------------------------ */
+/* north_star: "independent batch elements shard across the 8 GPUs of one node with an RCCL all-gather over xGMI at the
+ * end".  Instead of a collective kernel that has to share the CUs with the spin-waiting resident groups, the x pass of the
+ * resident single-column solve (k_cg_rspace3) can store every solution value into up to seven more buffers: the IPC-mapped
+ * gather buffers of the peers, bufs[p] [B_total, N] fp32, this rank's members starting at `member_offset`.  The pointers
+ * are process-wide and stay installed until replaced (n = 0 removes them); only the diagonal-form resident solve honours
+ * them.  Emulated on one GPU with local buffers by tools/mb_peer_gather.py; no reference counterpart.                 */
+int lo_peer_gather_set(float* const* bufs, int n, long long member_offset);
+
 /* ---- engine selection of lo_cg_solve_f32 as a PURE function ------------------------------------------------------ */
 /* Which kernels lo_cg_solve_f32 will run for these arguments: decided from the shapes, the null-ness of the pointers in
  * `pre`, the parameters and the number of compute units -- no device memory is read and nothing is launched, so the

@@ -19,7 +19,7 @@ _lib = None
 LO_OP_LOWRANK_DIAG, LO_OP_DENSE_DIAG, LO_OP_KRON_DIAG, LO_OP_CALLBACK, LO_OP_SUM = 0, 1, 2, 3, 4
 LO_MAX_TERMS = 4
 LO_DIAG_NONE, LO_DIAG_FULL, LO_DIAG_CONST = 0, 1, 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 LO_ERR_UNSUPPORTED = -4
 LO_FUSED_OK, LO_FUSED_EARLY_STOP, LO_FUSED_CONTINUE, LO_FUSED_TIMEOUT = 0, 1, 2, 3
@@ -49,7 +49,7 @@ EXPORTS = [
     "lo_bilinear_kron_workspace_bytes", "lo_bilinear_kron_f32",
     "lo_minres_workspace_bytes", "lo_minres_f32",
     "lo_probe_vectors_workspace_bytes", "lo_probe_vectors_f32", "lo_iql_backward_factors_f32",
-    "lo_prof_enable", "lo_prof_report", "lo_hbm_triad_f32", "lo_hbm_copy_f32", "lo_hbm_stream_dev",
+    "lo_prof_enable", "lo_prof_report", "lo_hbm_triad_f32", "lo_hbm_copy_f32", "lo_hbm_stream_dev", "lo_peer_gather_set",
 ]
 
 
@@ -337,6 +337,8 @@ def load():
     lib.lo_hbm_triad_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, sz, C.c_void_p]
     lib.lo_hbm_copy_f32.restype = C.c_int
     lib.lo_hbm_copy_f32.argtypes = [C.c_void_p, C.c_void_p, sz, C.c_void_p]
+    lib.lo_peer_gather_set.restype = C.c_int
+    lib.lo_peer_gather_set.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_longlong]
     lib.lo_hbm_stream_dev.restype = C.c_int
     lib.lo_hbm_stream_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, sz,
                                       C.c_void_p]

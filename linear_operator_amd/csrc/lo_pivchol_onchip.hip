@@ -93,13 +93,49 @@ constexpr int P4_ROWS = P4_TPB * P4_NR;
 
 template <int GW>
 struct alignas(16) P4Shared {
-  float wv[P4_WAVES];
-  int wj[P4_WAVES];
-  float we[P4_WAVES];
-  int pad[4];
-  unsigned part[PO_SLOT];
+  unsigned part[PO_SLOT];            // (placement check only)
+  unsigned part4[P4_WAVES][PO_SLOT]; // every wave's candidate: header, its C row, its L entries
   unsigned gath[GW][PO_SLOT];
 };
+
+// (value, position) of the wave's best candidate in every lane: FIRST maximal position wins (torch.max on CPU, :61-63).
+// The value maximum runs as six cross-lane maxima; the position comes from the winner's lane (v_readlane) -- a tie of
+// the maximum (exact float equality, rare) takes the smallest position among the tied lanes through a second reduction.
+// The returned value is the winner's own bits (a maximum of +0 and -0 would not say which).
+__device__ __forceinline__ void p4_wave_argmax(float& v, int& j) {
+  float mx = (j == PO_INVALID) ? -INFINITY : v;
+  mx = fmaxf(mx, xor_lane<1>(mx)); mx = fmaxf(mx, xor_lane<2>(mx)); mx = fmaxf(mx, xor_lane<4>(mx));
+  mx = fmaxf(mx, xor_lane<8>(mx));
+  {
+    int a_, b_;
+    bfly_i<16>(__float_as_int(mx), a_, b_);
+    mx = fmaxf(__int_as_float(a_), __int_as_float(b_));
+    bfly_i<32>(__float_as_int(mx), a_, b_);
+    mx = fmaxf(__int_as_float(a_), __int_as_float(b_));
+  }
+  const bool eq = j != PO_INVALID && v == mx;
+  const unsigned long long bal = __ballot(eq);
+  if (bal == 0ull) {  // no candidate (or only NaNs): nothing to offer
+    v = -INFINITY;
+    j = PO_INVALID;
+    return;
+  }
+  int lane_w = __ffsll((long long)bal) - 1;
+  if (__popcll(bal) > 1) {  // tie: smallest position among the tied lanes
+    int jm = eq ? j : PO_INVALID;
+    jm = min(jm, xor_lane_i<1>(jm)); jm = min(jm, xor_lane_i<2>(jm)); jm = min(jm, xor_lane_i<4>(jm));
+    jm = min(jm, xor_lane_i<8>(jm));
+    int a_, b_;
+    bfly_i<16>(jm, a_, b_);
+    jm = min(a_, b_);
+    bfly_i<32>(jm, a_, b_);
+    jm = min(a_, b_);
+    const unsigned long long bw = __ballot(eq && j == jm);
+    lane_w = __ffsll((long long)bw) - 1;
+  }
+  v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_w));
+  j = __builtin_amdgcn_readlane(j, lane_w);
+}
 
 // LQ = 16-byte slots per row: 4 (rank <= 16, rows 64 bytes apart, XOR over groups of 4 rows) or 8 (rank <= 32, rows 128
 // bytes apart: two consecutive rows cover the 64 banks, XOR over pairs of rows)
@@ -110,14 +146,32 @@ __device__ __forceinline__ int l_slot(int r, int q) {
 }
 
 // thread t < cnt publishes sh.part[t] and fetches component t of every workgroup of the group into sh.gath
-template <int GW>
+// (WIN: the value comes from the four wave candidates in sh.part4 -- every publishing thread picks the workgroup's winner
+//  itself from the four headers, in the order of the butterfly the workgroup-level reduction used to run, so the
+//  candidate phase needs ONE barrier instead of two and the four owner lanes write their payloads side by side)
+template <int GW, bool WIN = false>
 __device__ __forceinline__ void p4_gather(P4Shared<GW>& sh, int cnt, unsigned long long* gslot_base, int wig,
                                           unsigned tag, int* err, bool same_xcd) {
   const int t = threadIdx.x;
-  __syncthreads();  // sh.part complete
+  __syncthreads();  // sh.part / sh.part4 complete
   if (t < cnt) {
     unsigned long long* slot = gslot_base + (size_t)(tag & 1u) * GW * PO_SLOT;
-    const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned long long)sh.part[t];
+    unsigned myval;
+    if constexpr (WIN) {
+      float v0 = __uint_as_float(sh.part4[0][0]), v1 = __uint_as_float(sh.part4[1][0]);
+      float v2 = __uint_as_float(sh.part4[2][0]), v3 = __uint_as_float(sh.part4[3][0]);
+      int j0 = (int)sh.part4[0][1], j1 = (int)sh.part4[1][1], j2 = (int)sh.part4[2][1], j3 = (int)sh.part4[3][1];
+      int w01 = 0, w23 = 2;
+      if (po_better(v1, j1, v0, j0)) { v0 = v1; j0 = j1; w01 = 1; }
+      if (po_better(v3, j3, v2, j2)) { v2 = v3; j2 = j3; w23 = 3; }
+      const int wsel = po_better(v2, j2, v0, j0) ? w23 : w01;
+      const float ge = (__uint_as_float(sh.part4[0][3]) + __uint_as_float(sh.part4[1][3])) +
+                       (__uint_as_float(sh.part4[2][3]) + __uint_as_float(sh.part4[3][3]));  // (the butterfly's order)
+      myval = (t == 3) ? __float_as_uint(ge) : sh.part4[wsel][t];
+    } else {
+      myval = sh.part[t];
+    }
+    const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned long long)myval;
     if (same_xcd)
       __hip_atomic_store(slot + (size_t)wig * PO_SLOT + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else
@@ -289,31 +343,21 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
           }
         }
       }
-      po_amax_step<1>(bv, bj); po_amax_step<2>(bv, bj); po_amax_step<4>(bv, bj);
-      po_amax_step<8>(bv, bj); po_amax_step<16>(bv, bj); po_amax_step<32>(bv, bj);
+      p4_wave_argmax(bv, bj);
       es = wave_sum_fast(es);
+      // every WAVE's candidate goes to LDS with its payload (header, C row, L entries 0..m-1): the four owner lanes write
+      // side by side, and the workgroup's winner is picked by the publishing threads after ONE barrier (p4_gather<.., true>)
+      unsigned* const mine4 = sh.part4[wave];
       if (lane == 0) {
-        sh.wv[wave] = bv;
-        sh.wj[wave] = bj;
-        sh.we[wave] = es;
+        mine4[0] = __float_as_uint(bv);   // (-inf, PO_INVALID when the wave has no candidate left)
+        mine4[1] = (unsigned)bj;
+        mine4[3] = __float_as_uint(es);
       }
-      __syncthreads();
-      float gv = sh.wv[lane & 3];
-      int gj = sh.wj[lane & 3];
-      float ge = sh.we[lane & 3];
-      ge = bfly_add<1>(ge); ge = bfly_add<2>(ge);
-      po_amax_step<1>(gv, gj); po_amax_step<2>(gv, gj);
-      gv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gv)));
-      gj = __builtin_amdgcn_readfirstlane(gj);
-      ge = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ge)));
-      // the owner of the candidate publishes it: header, its C row, its L entries 0..m-1
 #pragma unroll
       for (int q = 0; q < P4_NR; ++q) {
-        if (pos[q] != PO_INVALID && pos[q] >= m && pos[q] == gj) {
-          sh.part[0] = __float_as_uint(gv);
-          sh.part[1] = (unsigned)gj;
+        if (pos[q] != PO_INVALID && pos[q] >= m && pos[q] == bj) {
           // (one thread writes the whole payload: 16-byte LDS stores -- PO_HDR and RC are multiples of 4)
-          float4* dst = reinterpret_cast<float4*>(&sh.part[PO_HDR]);
+          float4* dst = reinterpret_cast<float4*>(&mine4[PO_HDR]);
 #pragma unroll
           for (int r = 0; r < RC / 4; ++r)
             dst[r] = make_float4(Cr[q][4 * r], Cr[q][4 * r + 1], Cr[q][4 * r + 2], Cr[q][4 * r + 3]);
@@ -321,15 +365,8 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
           for (int j4 = 0; 4 * j4 < m; ++j4) dst[RC / 4 + j4] = l_s[l_slot<LQ>(lr, j4)];
         }
       }
-      if (t == 0) {
-        if (gj == PO_INVALID) {
-          sh.part[0] = __float_as_uint(-INFINITY);
-          sh.part[1] = (unsigned)PO_INVALID;
-        }
-        sh.part[3] = __float_as_uint(ge);
-      }
       if (stamp) c1 = wall_clock64();
-      p4_gather<GW>(sh, PO_HDR + RC + m, gslot, wig, ++tag, a.err, same_xcd);
+      p4_gather<GW, true>(sh, PO_HDR + RC + m, gslot, wig, ++tag, a.err, same_xcd);
       if (stamp) c2 = wall_clock64();
 
       // ---- group winner (identical in all workgroups): lane l holds candidate l % GW ----

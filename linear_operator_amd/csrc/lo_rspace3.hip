@@ -47,6 +47,18 @@ __device__ __forceinline__ T* opaque_uniform(T* p) {
 constexpr int R3_TPB = 256;
 constexpr int R3_ROWS = 1024;
 
+// Gather by peer writes (prototype, SURVEY 8(e): "one RCCL all-gather over xGMI at the end"): the x pass can store every
+// solution value into up to seven more buffers next to the caller's -- on a node these would be the IPC-mapped gather
+// buffers of the seven peers (each rank writes its slice straight over its own xGMI link while the solve runs; no RCCL
+// kernel competes for CUs with the spin-waiting groups).  lo_peer_gather_set installs the pointers for the calling
+// process; tools/mb_peer_gather.py emulates the peers with local buffers and times the solve with and without them.
+struct PeerOut {
+  float* buf[7];
+  int n;
+  long long member_off;  // this rank's first member inside a peer's gather buffer
+};
+PeerOut g_peer_out = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, 0, 0};
+
 __host__ __device__ constexpr int r3_np(int RC) { return 2 * RC + 6; }  // w0 | u0 | s | a0 | next member | sum dinv^2 | xcc | xcc^2
 
 // xor-4 exchange of a double on the DPP path (two row shifts under complementary bank masks per word) instead of the
@@ -81,7 +93,7 @@ __device__ __forceinline__ double rows_reduce_d(double (&p)[CH], int lane) {
 }
 
 template <int RC, int GW>
-__global__ __launch_bounds__(R3_TPB, 2) void k_cg_rspace3(OnchipArgs a) {
+__global__ __launch_bounds__(R3_TPB, 2) void k_cg_rspace3(OnchipArgs a, PeerOut po) {
   constexpr int CH = RC / 4;     // 16-byte chunks per row
   constexpr int RPI = 64 / CH;   // rows per wave load instruction
   constexpr int NI = 256 / RPI;  // load instructions per wave
@@ -516,7 +528,12 @@ __global__ __launch_bounds__(R3_TPB, 2) void k_cg_rspace3(OnchipArgs a) {
         const int rw = 64 * jj + RPI * k2 + g2;
         const int row = row0c + rw;
         const double acc = fma(xi, (double)bw[rw], xv);
-        if (row >= row0 && row < a.N) xb[rw] = (float)(acc * (double)dw[rw]);  // :335
+        if (row >= row0 && row < a.N) {
+          const float xval = (float)(acc * (double)dw[rw]);  // :335
+          xb[rw] = xval;
+          for (int pp = 0; pp < po.n; ++pp)  // (prototype: the gather as peer writes)
+            ((g_f*)po.buf[pp])[((size_t)(b + po.member_off)) * a.N + row] = xval;
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -539,7 +556,7 @@ int rspace3_go(const OnchipArgs& a, int nwg, hipStream_t st) {
     const char* e = getenv("LO_RS_PRIO");
     a2.prefetch = e ? atoi(e) : 3;  // iterations AND the x pass at raised priority (0.1935 -> 0.1894 ms per headline solve)
   }
-  hipLaunchKernelGGL((k_cg_rspace3<RC, GW>), dim3(2 * nwg), dim3(R3_TPB), 0, st, a2);
+  hipLaunchKernelGGL((k_cg_rspace3<RC, GW>), dim3(2 * nwg), dim3(R3_TPB), 0, st, a2, g_peer_out);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
@@ -573,3 +590,11 @@ int rspace3_launch(int RC, const OnchipArgs& a, int nwg, hipStream_t st) {
 }
 
 }  // namespace lo
+
+extern "C" int lo_peer_gather_set(float* const* bufs, int n, long long member_offset) {
+  if (n < 0 || n > 7 || (n > 0 && !bufs)) return LO_ERR_BADARG;
+  for (int i = 0; i < 7; ++i) lo::g_peer_out.buf[i] = i < n ? bufs[i] : nullptr;
+  lo::g_peer_out.n = n;
+  lo::g_peer_out.member_off = member_offset;
+  return LO_OK;
+}

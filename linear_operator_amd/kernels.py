@@ -1288,3 +1288,12 @@ def inject_resident_timeouts(n: int):
     """lo_resident_inject_timeouts: the next n resident CG launches are treated as timed out (the solve is redone on
     the streaming engine and a cool-down starts) -- tests and `bench.py --inject-timeouts`."""
     _hip.check(_hip.load().lo_resident_inject_timeouts(int(n)), "lo_resident_inject_timeouts")
+
+
+def peer_gather_set(bufs=(), member_offset: int = 0) -> None:
+    """lo_peer_gather_set (prototype): up to seven [B_total, N] fp32 buffers the resident single-column solve writes its
+    solutions into next to its own output -- the gather of SURVEY 8(e) as peer writes.  () removes them."""
+    lib = _hip.load()
+    n = len(bufs)
+    arr = (C.c_void_p * max(n, 1))(*[b.data_ptr() for b in bufs])
+    _hip.check(lib.lo_peer_gather_set(arr, n, int(member_offset)), "lo_peer_gather_set")
