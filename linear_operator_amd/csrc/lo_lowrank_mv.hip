@@ -129,7 +129,9 @@ __global__ __launch_bounds__(MV_TPB, WPS) void k_lr_mv(LrMvArgs a) {
   __shared__ __attribute__((aligned(16))) float res[NPS];
   __shared__ float pol[GW > 1 ? GW * NPS : 1];
   __shared__ int lost_s;
-  if (a.stop && *a.stop) return;
+  // (the sticky stop word of a CG solve and the launch's error word are REQUESTED here and looked at behind the first
+  //  member's loads: two dependent round trips less in front of the first byte from HBM)
+  const int stop0 = a.stop ? *a.stop : 0;
   const int wg = blockIdx.x;
   const int xcd = wg % 8, jx = wg / 8;  // (workgroups go round-robin to the XCDs: checked below, not assumed)
   const int per_xcd = (int)gridDim.x / 8;
@@ -145,7 +147,8 @@ __global__ __launch_bounds__(MV_TPB, WPS) void k_lr_mv(LrMvArgs a) {
   // every tag an earlier launch left behind (lowrank_mv_run hands out tag ranges), so a stale granule never matches.
   unsigned tag = a.tag_base;
   bool same_xcd = false;
-  if (t == 0) lost_s = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.tag_base ? 1 : 0;
+  unsigned err0 = 0;
+  if (t == 0) err0 = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   // Sum over the group of red[0..3][0 .. cnt) -> res[0 .. cnt); false when the hand-off was lost.  The first cnt threads
   // publish the workgroup's partials; ALL threads poll (granule idx = workgroup w * cnt + entry e, one or a few per thread:
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(MV_TPB, WPS) void k_lr_mv(LrMvArgs a) {
     int t = (int)threadIdx.x;
     asm volatile("" : "+v"(t));  // (LDS / granule addresses are formed here, not at kernel entry)
     __syncthreads();
+    if (lost_s != 0) return false;  // (another launch-wide loss, or the test switch: decided behind a barrier, uniformly)
     if constexpr (GW == 1) {
       if (t < cnt) res[t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
     } else {
@@ -197,11 +201,10 @@ __global__ __launch_bounds__(MV_TPB, WPS) void k_lr_mv(LrMvArgs a) {
     __syncthreads();
     return lost_s == 0;
   };
-  __syncthreads();
   // placement check (see k_cg_onchip4): the group's FIRST exchange goes through agent-scope stores and carries the XCC id;
   // plain same-XCD stores (hand-off at L2 latency) only from the second member on, and only if the whole group shares an XCD
   const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
-  bool first = true;
+  bool first = true, lost = false;
   if (a.dbg && wig == 0 && t == 0) a.dbg[8 + 2 * grp] = wall_clock64();  // (LO_MV_DEBUG: when each group starts / ends)
 
   // A wave owns the rows [row0, row0 + 256) of the member; it LOADS the 256 rows from row0c = min(row0, N - 256) on, so that
@@ -276,10 +279,13 @@ __global__ __launch_bounds__(MV_TPB, WPS) void k_lr_mv(LrMvArgs a) {
         if (e < 256 * c) vw[(e / c) * CT + (e % c)] = vq[m];
       }
     }
+    if (mseq == 0) {  // (behind the loads: the words requested at kernel entry)
+      if (stop0) return;
+      if (t == 0) lost_s = (err0 == a.tag_base) ? 1 : 0;
+    }
     __builtin_amdgcn_wave_barrier();
     if (stamp) s1 = wall_clock64();
 
-    const bool lost = lost_s != 0;  // (written before a barrier every thread has passed)
     if (!lost) {
       // ---- pass 1: partials of t = C^T v for this lane's chunk ----
       float tacc[CT][4];
@@ -321,6 +327,7 @@ __global__ __launch_bounds__(MV_TPB, WPS) void k_lr_mv(LrMvArgs a) {
       }
     }
     if (stamp) s3 = wall_clock64();
+    lost = !have_t;  // (uniform: read behind a barrier; once lost, always lost for this launch)
     if (!have_t) {
       // ---- the hand-off is lost: t of the WHOLE member from HBM, by this workgroup alone (every workgroup of the group
       // computes the same bits) ----
