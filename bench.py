@@ -10,11 +10,17 @@ side column, solved by `linear_cg` with the reference's rank-15 pivoted-Cholesky
 cg_tolerance 1e-4 (stops at the 11-iteration floor).  A "step" is one full linear_cg call
 over the whole batch (init, 11 iterations, un-normalise; preconditioner already built, as the reference's
 `_solve` receives it).  Inputs are resident in HBM before the timed region.
-  metric  = member-matvecs per second inside CG = batch members x operator applications / CG wall time
+  metric  = member-matvecs per second inside CG = batch members x the operator applications linear_cg performs (11) / CG
+            wall time -- CG-ITERATION EQUIVALENTS: the timed engine (k_cg_rspace3) reads the operator once per solve and
+            runs the iterations on R + 1 Krylov coordinates (`value_kind` says so in the line).  Beside it, first level:
+            `operator_applications_per_sec` (the engine that performs the 11 products on the resident rows) and
+            `hbm_matvec` (ONE application of the operator as an HBM pass, lo_matvec_f32 -> k_lr_mv: north_star's "batched
+            CG matvec" with its roofline fraction by SURVEY 8(d)'s bytes)
   value   = whole-job aggregate over all ranks (weak scaling: every rank owns 512 members; the solutions are
-            all-gathered over RCCL at the end of each step when N > 1, as north_star prescribes)
-Also reported: end-to-end solves/s (preconditioner build included), the roofline line of the dominant
-kernel (live HIP-event timing on the launch stream), and the CPU oracle timed on the host cores.
+            all-gathered over RCCL when N > 1, as north_star prescribes: --gather end | step)
+Also reported: end-to-end solves/s (preconditioner build included), what a solve costs when its preconditioner cache
+serves 1 / 25 / 100 solves, the roofline line of the dominant kernel (live HIP-event timing on the launch stream), and
+the CPU oracle timed on the host cores.
 """
 from __future__ import annotations
 
