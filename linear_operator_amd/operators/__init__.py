@@ -8,6 +8,7 @@ from .kronecker_product_linear_operator import KroneckerProductDiagLinearOperato
 from .kronecker_product_added_diag_linear_operator import KroneckerProductAddedDiagLinearOperator
 from .linear_operator_representation_tree import LinearOperatorRepresentationTree
 from .low_rank_root_added_diag_linear_operator import LowRankRootAddedDiagLinearOperator
+from .matmul_linear_operator import MatmulLinearOperator
 from .root_linear_operator import LowRankRootLinearOperator, RootLinearOperator
 from .sum_linear_operator import PsdSumLinearOperator, SumLinearOperator
 from .triangular_linear_operator import TriangularLinearOperator
@@ -17,5 +18,5 @@ __all__ = [
     "LinearOperator", "to_dense", "to_linear_operator", "AddedDiagLinearOperator", "DenseLinearOperator",
     "DiagLinearOperator", "ConstantDiagLinearOperator", "IdentityLinearOperator", "KroneckerProductLinearOperator", "KroneckerProductDiagLinearOperator",
     "LinearOperatorRepresentationTree", "RootLinearOperator", "LowRankRootLinearOperator", "SumLinearOperator",
-    "PsdSumLinearOperator", "TriangularLinearOperator",
+    "PsdSumLinearOperator", "TriangularLinearOperator", "MatmulLinearOperator",
 ]

@@ -13,7 +13,9 @@ noise model): K + D = D^1/2 (S + I) D^1/2 with S = (x)_i D_i^-1/2 K_i D_i^-1/2 =
 -- ONE formulation for the reference's two branches (factors with constant diagonals are the case where Q_i are the
 eigenvectors of K_i themselves, :189-193).
 Other diagonals follow the reference's last branch: the AddedDiag CG path, WITHOUT a preconditioner (:132-134).
-The lazy Matmul roots (:224-294) are not on this path."""
+`_root_decomposition` / `_root_inv_decomposition` (:224-294; round 6) return the lazy roots
+`Q diag((lambda + sigma^2)^{+-1/2})` and `D^{+-1/2} Q diag((lambda + 1)^{+-1/2})` as `MatmulLinearOperator`s whose products
+run on the Kronecker matvec kernels -- the N x N factor is never formed."""
 from __future__ import annotations
 
 import torch
@@ -133,6 +135,39 @@ class KroneckerProductAddedDiagLinearOperator(AddedDiagLinearOperator):
                                                        reduce_inv_quad=reduce_inv_quad)
         logdet_term = self._logdet() if logdet else None
         return inv_quad_term, logdet_term
+
+    # ------------------------------------------------------------------ lazy roots (:224-294)
+    def _eig_root(self, power: float):
+        """R with R R^T = (K + D)^(2 power) for the two closed forms above, as a lazy product; None: no closed form."""
+        from .matmul_linear_operator import MatmulLinearOperator
+
+        if self._diag_is_constant:  # :227-230 / :263-266: Q diag((lambda + sigma^2)^power), Q = Q_1 (x) ... (x) Q_P
+            evals, _, q = self._factor_eig()
+            sig = self.diag_tensor._diagonal().to(evals.dtype)
+            return MatmulLinearOperator(q, DiagLinearOperator((evals + sig).pow(power).to(self.dtype)))
+        if self._structured():  # :234-256 / :270-292: ONE formulation for both branches, D^(+-1/2) Q diag((lambda + 1)^power)
+            with torch.no_grad():
+                ir, evals, evecs = self._symmetrized_eig(detach=True)
+            q = KroneckerProductLinearOperator(*[e.to(self.dtype) for e in evecs])
+            scale = ir.reciprocal() if power > 0 else ir  # D^(1/2) for the root, D^(-1/2) for the inverse root
+            return MatmulLinearOperator(DiagLinearOperator(scale.to(self.dtype)),
+                                        MatmulLinearOperator(q, DiagLinearOperator((evals + 1.0).pow(power).to(self.dtype))))
+        return None
+
+    def _root_decomposition(self):  # :224-258
+        root = self._eig_root(0.5)
+        return root if root is not None else super()._root_decomposition()
+
+    def _root_inv_decomposition(self, initial_vectors=None, test_vectors=None):  # :260-294
+        root = self._eig_root(-0.5)
+        return root if root is not None else super()._root_inv_decomposition(initial_vectors=initial_vectors,
+                                                                             test_vectors=test_vectors)
+
+    def _choose_root_method(self) -> str:
+        # the closed forms hold at every size: the exact branch of small operators (dense Cholesky of N x N) is not needed
+        if self._diag_is_constant or self._structured():
+            return "lanczos"  # (the name of the branch that calls `_root_decomposition`, reference :2190-2199)
+        return super()._choose_root_method()
 
     def _symeig(self, eigenvectors: bool = False, return_evals_as_lazy: bool = False):  # :296-308
         if self._diag_is_constant:

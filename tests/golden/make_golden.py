@@ -1145,8 +1145,47 @@ def g27_lanczos_fp32_fp64_divergence():
         print(f"  {k}: shapes {a.shape} / {b.shape}, max |t32 - t64| on the common block {np.abs(a[..., :n, :n] - b[..., :n, :n]).max():.3e}")
 
 
+def g28_kronecker_roots():
+    """KroneckerProductAddedDiagLinearOperator._root_decomposition / _root_inv_decomposition
+    (kronecker_product_added_diag_linear_operator.py:224-294): the lazy Matmul roots of the constant-diagonal form and of
+    the two Kronecker-structured-diagonal branches.  The roots themselves are unique only up to the signs of the
+    eigenvectors, so the vectors hold R R^T, R_inv R_inv^T and the products R^T w / R_inv^T w squared (sign-free)."""
+    import linear_operator
+    from linear_operator.operators import KroneckerProductAddedDiagLinearOperator, KroneckerProductDiagLinearOperator
+
+    print("G28 Kronecker roots")
+    K1, K2, sig, _ = cases.kron_factors(2801, 2, 6, 8, 3)
+    w = cases.randn(2802, 2, 48, 3, dtype=np.float32)
+    d1 = (np.abs(cases.randn(2804, 2, 6, dtype=np.float32)) * 0.3 + 0.4).astype(np.float32)
+    d2 = (np.abs(cases.randn(2805, 2, 8, dtype=np.float32)) * 0.3 + 0.4).astype(np.float32)
+    c1 = np.array([[0.6], [0.9]], dtype=np.float32)
+    c2 = np.array([[0.5], [0.3]], dtype=np.float32)
+    out = {}
+    with linear_operator.settings.max_cholesky_size(0):
+        for tag in ("sigma", "full", "const"):
+            Kp = KroneckerProductLinearOperator(DenseLinearOperator(T(K1)), DenseLinearOperator(T(K2)))
+            if tag == "sigma":
+                A = Kp + ConstantDiagLinearOperator(T(sig), 48)
+            elif tag == "full":
+                A = Kp + KroneckerProductDiagLinearOperator(DiagLinearOperator(T(d1)), DiagLinearOperator(T(d2)))
+            else:
+                # (the reference's constant-factor branch scales `evec_ * diag_values.sqrt()`, :247, and raises for batched
+                #  constant factors -- [2, 6, 6] by [2, 1] -- so this branch is recorded for the first member, unbatched)
+                Kp = KroneckerProductLinearOperator(DenseLinearOperator(T(K1[0])), DenseLinearOperator(T(K2[0])))
+                A = Kp + KroneckerProductDiagLinearOperator(ConstantDiagLinearOperator(T(c1[0]), 6), ConstantDiagLinearOperator(T(c2[0]), 8))
+            assert isinstance(A, KroneckerProductAddedDiagLinearOperator)
+            wt = T(w[0]) if tag == "const" else T(w)
+            R = A.root_decomposition().root
+            Ri = A.root_inv_decomposition().root
+            assert "Matmul" in type(R).__name__ and "Matmul" in type(Ri).__name__, (type(R), type(Ri))
+            Rd, Rid = R.to_dense(), Ri.to_dense()
+            out.update({f"{tag}_dense": A.to_dense(), f"{tag}_rrt": Rd @ Rd.mT, f"{tag}_riri": Rid @ Rid.mT,
+                        f"{tag}_rtw_sq": (R._t_matmul(wt) ** 2).sum(-2), f"{tag}_ritw_sq": (Ri._t_matmul(wt) ** 2).sum(-2)})
+    save("g28_kron_roots", checksum=cases.checksum(K1, K2, sig, w, d1, d2, c1, c2), **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g27", "g26", "g25", "g24", "g23", "g22", "g21", "g20", "g19", "g18", "g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g28", "g27", "g26", "g25", "g24", "g23", "g22", "g21", "g20", "g19", "g18", "g17", "g16", "g15", "g14", "g13", "g12", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name, fn in (("g1", g1_linear_cg), ("g2", g2_pivoted_cholesky), ("g3", g3_preconditioner),
                      ("g4", g4_solve_and_inv_quad_logdet), ("g5", g5_lanczos), ("g6", g6_matmuls),
                      ("g7", g7_low_rank_root_added_diag), ("g8", g8_root_decomposition),
@@ -1158,7 +1197,8 @@ if __name__ == "__main__":
                      ("g20", g20_kronecker_structured_diag), ("g21", g21_minres_fp64),
                      ("g22", g22_kronecker_iteration_pinned), ("g23", g23_tridiag_divergence_and_tight_logdet),
                      ("g24", g24_kronecker_256_iteration_pinned), ("g25", g25_fp64_preconditioned_path),
-                     ("g26", g26_lanczos_fp64), ("g27", g27_lanczos_fp32_fp64_divergence)):
+                     ("g26", g26_lanczos_fp64), ("g27", g27_lanczos_fp32_fp64_divergence),
+                     ("g28", g28_kronecker_roots)):
         if name in todo:
             fn()
     print("done")
