@@ -26,6 +26,7 @@
 // to summation order) and the sticky error word sends every later member of the launch down the same path.
 #include <algorithm>
 #include <stdlib.h>
+#include <string.h>
 
 #include "lo_device.h"
 #include "lo_internal.h"
@@ -49,7 +50,9 @@ struct LrMvArgs {
   int64_t B;
   int N;
   unsigned long long* gran;  // [ngroups][2][GW][RC * CT + 2]
-  unsigned* err;             // == tag_base while a hand-off of THIS launch is lost
+  unsigned* err;             // == tag_base while a hand-off of THIS launch is lost (pinned host memory the device maps:
+                             // the host sees a loss at its next call without a copy or a synchronisation)
+  const float* zero;         // a word of device memory that is never written (the "diagonal" of an operator without one)
   unsigned tag_base;         // tags of this launch: tag_base + 1 + (member of the group); larger than any earlier launch's
   int allow_l2_handoff;
   int prio_mode;             // wave priority against the oldest-first arbitration of a CU's two workgroups (LO_MV_PRIO)
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(MV_TPB, WPS) void k_lr_mv(LrMvArgs a) {
       // (branch-free: stride 1 for a full diagonal, 0 for a constant one, and a zeroed word of the workspace for none)
       const int dstride = a.d_mode == LO_DIAG_FULL ? 1 : 0;
       g_cf* db = opaque_uniform((g_cf*)(a.d_mode == LO_DIAG_FULL ? a.d + (size_t)b * a.N + row0c
-                                        : a.d_mode == LO_DIAG_CONST ? a.d + b : reinterpret_cast<const float*>(a.err + 8)));  // (never written)
+                                        : a.d_mode == LO_DIAG_CONST ? a.d + b : a.zero));
 #pragma unroll
       for (int j = 0; j < 4; ++j) dq[j] = db[(64 * j + RPI * k + g) * dstride];  // (row0c + 255 < N)
     }
@@ -461,6 +464,9 @@ struct MvCtl {
   size_t bytes = 0;
   unsigned next_tag = 1;
   bool failed = false;
+  unsigned* err_host = nullptr;  // the launch error word: pinned, mapped
+  unsigned* err_dev = nullptr;   // ... as the device addresses it
+  unsigned last_tag = 0;         // tag range of the previous launch (0: none / already looked at)
 };
 MvCtl g_mv_ctl[16];
 constexpr size_t MV_MAX_WGS = 3 * 320;  // up to three workgroups per CU, up to 320 CUs
@@ -471,10 +477,17 @@ MvCtl* mv_ctl() {  // (called with the ResidentLaunch lock held)
   MvCtl& m = g_mv_ctl[dev];
   if (!m.buf && !m.failed) {
     m.bytes = MV_ERR_BYTES + MV_MAX_WGS * 2 * (size_t)(32 * 4 + 2) * sizeof(unsigned long long);
-    if (hipMalloc(&m.buf, m.bytes) != hipSuccess || hipMemset(m.buf, 0, m.bytes) != hipSuccess) {
+    void* eh = nullptr;
+    void* ed = nullptr;
+    if (hipMalloc(&m.buf, m.bytes) != hipSuccess || hipMemset(m.buf, 0, m.bytes) != hipSuccess ||
+        hipHostMalloc(&eh, 256, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&ed, eh, 0) != hipSuccess) {
       (void)hipGetLastError();
       m.buf = nullptr;
       m.failed = true;
+    } else {
+      memset(eh, 0, 256);
+      m.err_host = static_cast<unsigned*>(eh);
+      m.err_dev = static_cast<unsigned*>(ed);
     }
   }
   return m.buf ? &m : nullptr;
@@ -498,6 +511,14 @@ int lowrank_mv_run(const float* C, int R4, const float* d, int d_mode, const flo
   ResidentLaunch guard(st);
   MvCtl* m = mv_ctl();
   if (!m) return LO_ERR_UNSUPPORTED;
+  // a launch of this process that lost its co-residency (another process' resident kernel held part of the CUs) repaired
+  // itself inside the kernel, at the price of a 0.5 s spin: it left its tag in the pinned error word, and the gate of
+  // the resident kernels starts its cool-down here -- the next calls run the two streaming passes (lo_resident_status)
+  if (m->last_tag && *static_cast<volatile unsigned*>(m->err_host) == m->last_tag) {
+    m->last_tag = 0;
+    onchip_note_timeout();
+    return LO_ERR_UNSUPPORTED;
+  }
   // tags of this launch: tag_base + 1 .. tag_base + (members per group) <= tag_base + B / 8 + 1
   const unsigned need = (unsigned)std::min<int64_t>(B / 8 + 2, 1 << 28);
   if (m->next_tag + need >= 0x7ff00000u) {
@@ -506,15 +527,21 @@ int lowrank_mv_run(const float* C, int R4, const float* d, int d_mode, const flo
   }
   LrMvArgs a;
   a.C = C; a.d = d; a.d_mode = d ? d_mode : LO_DIAG_NONE; a.v = v; a.y = y; a.c = (int)c; a.B = B; a.N = (int)N;
-  a.err = reinterpret_cast<unsigned*>(m->buf);
+  a.err = m->err_dev;
+  a.zero = reinterpret_cast<const float*>(m->buf);  // (the first MV_ERR_BYTES of the buffer stay zero for good)
   a.gran = reinterpret_cast<unsigned long long*>(m->buf + MV_ERR_BYTES);
   a.tag_base = m->next_tag;
   m->next_tag += need;
+  m->last_tag = a.tag_base;
   a.allow_l2_handoff = onchip_l2_handoff_allowed();
   a.stop = stop;
   a.dbg = nullptr;
-  if (getenv("LO_MV_TEST_FALLBACK"))  // every workgroup starts "lost"
+  if (getenv("LO_MV_TEST_FALLBACK")) {  // every workgroup starts "lost" (tests of the in-kernel repair; not a real loss)
     LO_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)a.err, (int)a.tag_base, 1, st));
+    m->last_tag = 0;
+  } else if (resident_take_injection()) {  // lo_resident_inject_timeouts: the same THROUGH the gate's bookkeeping
+    LO_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)a.err, (int)a.tag_base, 1, st));
+  }
   static long long* dbg_buf = nullptr;
   const bool dbg = getenv("LO_MV_DEBUG") != nullptr;
   if (dbg) {

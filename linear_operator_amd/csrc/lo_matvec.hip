@@ -219,6 +219,7 @@ int lo_matvec_f32(const lo_op_desc* op, const float* v, float* y, int64_t c, voi
   hipStream_t st = (hipStream_t)stream;
   Split sp = choose_split(op->B, op->N, 256);
   Arena ar(ws, ws_bytes);
+  if (op->kind == LO_OP_LOWRANK_DIAG) resident_tick();  // (an entry point that may run a resident kernel: serves the cool-down)
   if (matvec_plan_bytes(op, c, sp) > 256 && !ws) return LO_ERR_WORKSPACE;
   MatvecPlan pl;
   int rc = matvec_plan_init(&pl, op, nullptr, nullptr, c, sp, &ar, st);

@@ -71,3 +71,45 @@ def test_resident_gate_cools_down_and_rearms():
     finally:
         K.inject_resident_timeouts(0)
         K.set_onchip_cg(True)
+
+
+def test_resident_matvec_obeys_the_gate():
+    """lo_matvec_f32 is asynchronous: a launch of k_lr_mv that loses its co-residency repairs itself INSIDE the kernel (the
+    workgroups recompute C^T v of their member from HBM) and leaves its tag in a pinned error word; the NEXT call sees it,
+    starts the cool-down of the resident kernels and runs the two streaming passes until the gate re-arms."""
+    C, d, v = cases.lowrank_diag(5601, 40, 8192, 32, 1)
+    desc = K.lowrank_diag_descriptor(dev(C), dev(d))
+    vd = dev(v)
+
+    def mv():
+        torch.cuda.synchronize()
+        K._hip.prof_enable(True)
+        try:
+            y = K.matvec(desc, vd)
+            torch.cuda.synchronize()
+            return y, K._hip.prof_report()
+        finally:
+            K._hip.prof_enable(False)
+
+    K.set_onchip_cg(True)
+    y0, p0 = mv()
+    assert "lr_mv" in p0
+    s0 = K.resident_status()
+    try:
+        K.inject_resident_timeouts(1)
+        y1, p1 = mv()                       # every workgroup "lost": repaired in the kernel, result to summation order
+        assert "lr_mv" in p1 and max_rel_err_cols(host(y1), host(y0)) < 2e-6
+        assert K.resident_status()["timeouts"] == s0["timeouts"]  # nobody has looked at the error word yet
+        y2, p2 = mv()                       # ... this call does: cool-down, two streaming passes
+        s2 = K.resident_status()
+        assert "lr_mv" not in p2 and s2["timeouts"] == s0["timeouts"] + 1 and s2["cooldown"] > 0
+        assert max_rel_err_cols(host(y2), host(y0)) < 2e-6
+        seen = []
+        for _ in range(s2["cooldown"] + 1):
+            _, p = mv()
+            seen.append("lr_mv" in p)
+        assert seen[-1] and not any(seen[:-2]), seen  # back on the resident kernel once the cool-down is served
+        assert torch.equal(K.matvec(desc, vd), y0)
+    finally:
+        K.inject_resident_timeouts(0)
+        K.set_onchip_cg(True)
