@@ -99,7 +99,10 @@ typedef struct lo_precond_desc {
   const float* EF;       /* [B, rf_ld, rf_ld] = E F                                                 */
   const float* E;        /* [B, rf_ld, rf_ld] = C^T D^-1 C                                          */
   int32_t rf_ld;         /* row stride of F / EF / E = padded root rank (8, 16 or 32); 0 = absent   */
-  int32_t reserved2;
+  int32_t generation;    /* (was reserved2) optional: a number the host changes whenever it rebuilds this cache; part of
+                          * the key under which lo_cg_solve_f32 remembers that a solve missed the stop rule in its
+                          * result-only pass, so that an ADDRESS the allocator recycles does not inherit the memo.  0 = none.
+                          * Results are bit-reproducible per cache state (form of the cache x memo), not across them.      */
   /* Optional KRONECKER ROOT FORM of the same preconditioner (lo_precond_kron_root_f32), valid when the operator is
    * LO_OP_KRON_DIAG with a constant diagonal and L is the pivoted Cholesky factor of K1 (x) K2 with k <= 16 pivots.
    * Row pi of K1 (x) K2 is the Kronecker product of row pi / n2 of K1 and row pi % n2 of K2, and every column of L

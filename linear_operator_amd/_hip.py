@@ -72,7 +72,7 @@ OpDesc._fields_ = [("kind", C.c_int32), ("diag_mode", C.c_int32), ("B", C.c_int6
 class PrecondDesc(C.Structure):
     _fields_ = [("k", C.c_int32), ("ldq", C.c_int32), ("constant_diag", C.c_int32), ("reserved", C.c_int32),
                 ("Q", C.c_void_p), ("dinv", C.c_void_p), ("F", C.c_void_p), ("EF", C.c_void_p), ("E", C.c_void_p),
-                ("rf_ld", C.c_int32), ("reserved2", C.c_int32),
+                ("rf_ld", C.c_int32), ("generation", C.c_int32),
                 ("kron_a", C.c_void_p), ("kron_b", C.c_void_p), ("kron_F", C.c_void_p), ("RS", C.c_void_p),
                 ("RSD", C.c_void_p)]
 

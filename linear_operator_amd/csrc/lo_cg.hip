@@ -102,22 +102,24 @@ struct LeanMiss {
   const void* d;
   int64_t B, N, c;
   float tol;
+  int gen;  // lo_precond_desc.generation of the cache the miss was seen with (0: none given): an address the allocator
+            // hands out again for OTHER tensors does not inherit the entry
   int valid;
 };
 static thread_local LeanMiss tls_lean_miss[16] = {};
 static thread_local int tls_lean_miss_next = 0;
-static int lean_miss_find(const lo_op_desc* op, const lo_cg_params* prm) {
+static int lean_miss_find(const lo_op_desc* op, const lo_cg_params* prm, int gen) {
   for (int i = 0; i < 16; ++i) {
     const LeanMiss& m = tls_lean_miss[i];
     if (m.valid && m.a0 == op->A0 && m.d == op->d && m.B == op->B && m.N == op->N && m.c == prm->c &&
-        m.tol == prm->tolerance)
+        m.tol == prm->tolerance && m.gen == gen)
       return i;
   }
   return -1;
 }
-static void lean_miss_note(const lo_op_desc* op, const lo_cg_params* prm) {
-  if (lean_miss_find(op, prm) >= 0) return;
-  tls_lean_miss[tls_lean_miss_next] = LeanMiss{op->A0, op->d, op->B, op->N, prm->c, prm->tolerance, 1};
+static void lean_miss_note(const lo_op_desc* op, const lo_cg_params* prm, int gen) {
+  if (lean_miss_find(op, prm, gen) >= 0) return;
+  tls_lean_miss[tls_lean_miss_next] = LeanMiss{op->A0, op->d, op->B, op->N, prm->c, prm->tolerance, gen, 1};
   tls_lean_miss_next = (tls_lean_miss_next + 1) % 16;
 }
 static thread_local lo_cg_plan tls_last_exec = {};    // what the last lo_cg_solve_f32 of this thread actually launched
@@ -929,7 +931,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
   const bool oc_ok = plan.resident != 0;
   int ls_cols = plan.lockstep_cols;
   bool lean = plan.lean != 0;
-  const int miss_slot = lean ? lean_miss_find(op, prm) : -1;
+  const int miss_slot = lean ? lean_miss_find(op, prm, pre ? pre->generation : 0) : -1;
   const bool lean_skipped = miss_slot >= 0 && pre && pre->Q && !getenv("LO_OC_NO_LEAN_MEMO");
   if (lean_skipped) lean = false;  // this operator missed the floor last time: write the state in the first pass
   lo_cg_plan exec = plan;  // the plan as executed: run-time fall-backs are recorded here (lo_cg_last_executed)
@@ -1142,7 +1144,7 @@ int lo_cg_solve_f32(const lo_op_desc* op, lo_matvec_cb matvec, void* matvec_user
       } else if (oc_err == 0 && lean && !h.stop) {
         // the stop rule does not hold at the floor and the state was not written: the same launches once more, in full
         // (a root-form-only preconditioner cannot continue on the streaming engine anyway: the caller builds Q first)
-        lean_miss_note(op, prm);
+        lean_miss_note(op, prm, pre ? pre->generation : 0);
         if (pre && !pre->Q) return LO_ERR_UNSUPPORTED;
         lean = false;
         oc_redo = true;

@@ -6,8 +6,9 @@ current stream; there is no other implementation behind these functions.
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import os
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import Callable, Optional
 
 import torch
@@ -138,6 +139,9 @@ def matvec(desc: OperatorDescriptor, v: torch.Tensor) -> torch.Tensor:
     return y.reshape(v.shape)
 
 
+_CACHE_GENERATIONS = itertools.count(1)
+
+
 @dataclass
 class WoodburyPreconditioner:
     """Device form of the reference's cached (Q, noise) pair, added_diag_linear_operator.py:63-70."""
@@ -168,6 +172,9 @@ class WoodburyPreconditioner:
     kron: Optional[tuple] = None
     kron_kappa: Optional[float] = None  # worst rounding amplification of the Kronecker root form over the batch
     rebuild: Optional[Callable] = None  # root form from the fused solve (no L exists): () -> the full preconditioner
+    # lo_precond_desc.generation: one number per cache OBJECT (never 0), part of the key of the library's "this solve missed
+    # the stop rule in its result-only pass" memo -- a tensor address the allocator hands out again does not inherit it
+    generation: int = field(default_factory=lambda: next(_CACHE_GENERATIONS))
 
     @property
     def rf_ld(self) -> int:
@@ -209,6 +216,7 @@ class WoodburyPreconditioner:
     def c_struct(self) -> _hip.PrecondDesc:
         s = _hip.PrecondDesc()
         s.k, s.constant_diag, s.reserved = self.k, int(self.constant_diag), 0
+        s.generation = (self.generation & 0x7FFFFFFF) or 1
         s.ldq = padded_rank(self.k) if self.Q is None else self.Q.shape[-1]
         s.Q = None if self.Q is None else self.Q.data_ptr()
         s.dinv = self.dinv.data_ptr()
