@@ -50,8 +50,10 @@ struct LrMvArgs {
   int64_t B;
   int N;
   unsigned long long* gran;  // [ngroups][2][GW][RC * CT + 2]
-  unsigned* err;             // == tag_base while a hand-off of THIS launch is lost (pinned host memory the device maps:
-                             // the host sees a loss at its next call without a copy or a synchronisation)
+  unsigned* err;             // == tag_base while a hand-off of THIS launch is lost (device memory: every workgroup reads it)
+  unsigned* err_host;        // the same word in pinned host memory the device maps, written ONLY by a workgroup that loses
+                             // its hand-off: the host sees a loss at its next call without a copy or a synchronisation
+                             // (all 512 workgroups READING a host word at kernel entry cost 70 us: 113 -> 184 us)
   const float* zero;         // a word of device memory that is never written (the "diagonal" of an operator without one)
   unsigned tag_base;         // tags of this launch: tag_base + 1 + (member of the group); larger than any earlier launch's
   int allow_l2_handoff;
@@ -184,7 +186,8 @@ __global__ __launch_bounds__(MV_TPB, WPS) void k_lr_mv(LrMvArgs a) {
           if ((unsigned)(x >> 32) == tag) break;
           if (++spin > R4_MAXSPIN ||
               ((spin & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.tag_base)) {
-            atomicExch(a.err, a.tag_base);
+            if (atomicExch(a.err, a.tag_base) != a.tag_base)
+              __hip_atomic_store(a.err_host, a.tag_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             lost = true;
             break;
           }
@@ -527,8 +530,9 @@ int lowrank_mv_run(const float* C, int R4, const float* d, int d_mode, const flo
   }
   LrMvArgs a;
   a.C = C; a.d = d; a.d_mode = d ? d_mode : LO_DIAG_NONE; a.v = v; a.y = y; a.c = (int)c; a.B = B; a.N = (int)N;
-  a.err = m->err_dev;
-  a.zero = reinterpret_cast<const float*>(m->buf);  // (the first MV_ERR_BYTES of the buffer stay zero for good)
+  a.err = reinterpret_cast<unsigned*>(m->buf + 128);
+  a.err_host = m->err_dev;
+  a.zero = reinterpret_cast<const float*>(m->buf);  // (the first 128 bytes of the buffer stay zero for good)
   a.gran = reinterpret_cast<unsigned long long*>(m->buf + MV_ERR_BYTES);
   a.tag_base = m->next_tag;
   m->next_tag += need;
@@ -541,6 +545,7 @@ int lowrank_mv_run(const float* C, int R4, const float* d, int d_mode, const flo
     m->last_tag = 0;
   } else if (resident_take_injection()) {  // lo_resident_inject_timeouts: the same THROUGH the gate's bookkeeping
     LO_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)a.err, (int)a.tag_base, 1, st));
+    *static_cast<volatile unsigned*>(m->err_host) = a.tag_base;  // (what a losing workgroup would have stored)
   }
   static long long* dbg_buf = nullptr;
   const bool dbg = getenv("LO_MV_DEBUG") != nullptr;
