@@ -294,29 +294,40 @@ __global__ __launch_bounds__(MV_TPB, WPS) void k_lr_mv(LrMvArgs a) {
 
     if (!lost) {
       // ---- pass 1: partials of t = C^T v for this lane's chunk ----
-      float tacc[CT][4];
-#pragma unroll
-      for (int cc = 0; cc < CT; ++cc) tacc[cc][0] = tacc[cc][1] = tacc[cc][2] = tacc[cc][3] = 0.f;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int r = RPI * i + g;
-#pragma unroll
-        for (int cc = 0; cc < CT; ++cc) {
-          const float vv = vw[r * CT + cc];
-          tacc[cc][0] = fmaf(Cr[i].x, vv, tacc[cc][0]);
-          tacc[cc][1] = fmaf(Cr[i].y, vv, tacc[cc][1]);
-          tacc[cc][2] = fmaf(Cr[i].z, vv, tacc[cc][2]);
-          tacc[cc][3] = fmaf(Cr[i].w, vv, tacc[cc][3]);
-        }
-      }
       int l1 = lane;
       asm volatile("" : "+v"(l1));
       const int comp = ((l1 >> 5) << 1) | ((l1 >> 4) & 1);
       const bool writer = (l1 & 15 & ~(CH - 1)) == 0;
+      // (two columns at a time, eight rows at a time: the scheduler otherwise hoists every stage read of the pass over the
+      //  loop -- 53 spilled registers at four columns beside the 128 of C)
+      constexpr int CB = CT < 2 ? CT : 2;
 #pragma unroll
-      for (int cc = 0; cc < CT; ++cc) {
-        const float s = chunk_reduce<CH>(tacc[cc], l1);
-        if (writer) red[wave_u][cc * RC + 4 * (l1 & (CH - 1)) + comp] = s;
+      for (int c0 = 0; c0 < CT; c0 += CB) {
+        float tacc[CB][4];
+#pragma unroll
+        for (int cc = 0; cc < CB; ++cc) tacc[cc][0] = tacc[cc][1] = tacc[cc][2] = tacc[cc][3] = 0.f;
+#pragma unroll
+        for (int i0 = 0; i0 < NI; i0 += 8) {
+#pragma unroll
+          for (int i = i0; i < i0 + 8; ++i) {
+            const int r = RPI * i + g;
+#pragma unroll
+            for (int cc = 0; cc < CB; ++cc) {
+              const float vv = vw[r * CT + c0 + cc];
+              tacc[cc][0] = fmaf(Cr[i].x, vv, tacc[cc][0]);
+              tacc[cc][1] = fmaf(Cr[i].y, vv, tacc[cc][1]);
+              tacc[cc][2] = fmaf(Cr[i].z, vv, tacc[cc][2]);
+              tacc[cc][3] = fmaf(Cr[i].w, vv, tacc[cc][3]);
+            }
+          }
+          if constexpr (CT > 2) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int cc = 0; cc < CB; ++cc) {
+          const float s = chunk_reduce<CH>(tacc[cc], l1);
+          if (writer) red[wave_u][(c0 + cc) * RC + 4 * (l1 & (CH - 1)) + comp] = s;
+        }
+        if constexpr (CT > 2) __builtin_amdgcn_sched_barrier(0);
       }
     }
     bool have_t = !lost;
@@ -448,8 +459,7 @@ template <int RC>
 int lr_mv_ct(int CT, int GW, const LrMvArgs& a, int ncu, hipStream_t st) {
   if (CT == 1) return lr_mv_gw<RC, 1>(GW, a, ncu, st);
   if (CT == 2) return lr_mv_gw<RC, 2>(GW, a, ncu, st);
-  if constexpr (RC < 32) return lr_mv_gw<RC, 4>(GW, a, ncu, st);
-  return LO_ERR_UNSUPPORTED;
+  return lr_mv_gw<RC, 4>(GW, a, ncu, st);
 }
 
 int group_size(int64_t N) {
@@ -500,9 +510,8 @@ MvCtl* mv_ctl() {  // (called with the ResidentLaunch lock held)
 
 bool lowrank_mv_eligible(int R4, int64_t N, int64_t c) {
   if (getenv("LO_NO_RESIDENT_MV")) return false;
-  // (four columns next to 128 registers of C spill: the 32-wide root takes up to two columns, the narrower ones four)
   const int ncu = onchip_num_workgroups();
-  return (R4 == 8 || R4 == 16 || R4 == 32) && c >= 1 && c <= (R4 == 32 ? 2 : 4) && N >= 256 &&
+  return (R4 == 8 || R4 == 16 || R4 == 32) && c >= 1 && c <= 4 && N >= 256 &&
          N <= (int64_t)32 * MV_ROWS && ncu >= 64 && (size_t)3 * ncu <= MV_MAX_WGS;
 }
 

@@ -60,13 +60,13 @@ def env():
             os.environ[name] = value
 
 
-# every group size (1, 2, 4, 8, 16, 32 workgroups per member), ragged members, all three padded ranks, the column counts
-# the kernel takes (two beside a 32-wide root, four beside the narrower ones) and the three diagonal modes
+# every group size (1, 2, 4, 8, 16, 32 workgroups per member), ragged members, all three padded ranks, one to four columns
+# and the three diagonal modes
 SHAPES = [
     (5, 300, 32, 1, "full"), (5, 1024, 32, 2, "const"), (5, 1025, 32, 1, "full"), (4, 2049, 20, 1, "none"),
     (3, 5000, 32, 2, "full"), (6, 8192, 32, 1, "full"), (2, 20000, 32, 1, "const"), (2, 32768, 17, 2, "full"),
     (7, 4097, 16, 4, "full"), (7, 3000, 9, 3, "const"), (9, 2500, 8, 4, "full"), (9, 8192, 5, 2, "none"),
-    (70, 2048, 32, 1, "full"),
+    (70, 2048, 32, 1, "full"), (6, 8192, 32, 4, "full"), (5, 3001, 27, 3, "const"), (3, 16384, 32, 4, "none"),
 ]
 
 
@@ -104,7 +104,7 @@ def test_resident_matvec_against_the_oracle_and_the_two_pass_kernels(B, N, R, c,
 
 
 def test_shapes_the_resident_kernel_does_not_take_run_the_two_pass_kernels():
-    for (B, N, R, c) in [(3, 1000, 32, 3), (3, 1000, 8, 5), (3, 200, 32, 1), (2, 1000, 40, 1)]:
+    for (B, N, R, c) in [(3, 1000, 32, 5), (3, 1000, 8, 5), (3, 200, 32, 1), (2, 1000, 40, 1)]:
         C, d, v = cases.lowrank_diag(4100 + c + R, B, N, R, c)
         desc = K.lowrank_diag_descriptor(dev(C), dev(d))
         y, prof = _prof(lambda: K.matvec(desc, dev(v)))
