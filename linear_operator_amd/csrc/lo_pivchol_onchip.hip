@@ -94,17 +94,69 @@ constexpr int P4_ROWS = P4_TPB * P4_NR;
 template <int GW>
 struct alignas(16) P4Shared {
   unsigned part[PO_SLOT];            // (placement check only)
-  unsigned part4[P4_WAVES][PO_SLOT]; // every wave's candidate: header, its C row, its L entries
+  unsigned part4[P4_WAVES][PO_SLOT]; // every wave's candidate: header, the register pairs of its C row (2 x 32 words)
   unsigned gath[GW][PO_SLOT];
 };
+
+// LQ = 16-byte slots per row: 4 (rank <= 16, rows 64 bytes apart, XOR over groups of 4 rows) or 8 (rank <= 32, rows 128
+// bytes apart: two consecutive rows cover the 64 banks, XOR over pairs of rows)  [k_pc_onchip_rows]
+template <int LQ>
+__device__ __forceinline__ int l_slot(int r, int q) {
+  if constexpr (LQ == 4) return r * 4 + (q ^ ((r >> 2) & 3));
+  else return r * 8 + (q ^ ((r >> 1) & 7));
+}
+
+// k_pc_onchip4 keeps the L entries of a PAIR of a thread's rows side by side (rows t + 256 (2 p) and t + 256 (2 p + 1),
+// p = 0, 1: the "pair row" pr = t + 256 p): slot jb of a pair row = {L[r0][2 jb], L[r1][2 jb], L[r0][2 jb + 1],
+// L[r1][2 jb + 1]}, so one ds_read_b128 feeds two packed products.  NS = 16-byte slots per pair row: 8 (rank <= 16, pair
+// rows 128 bytes apart) or 16 (rank <= 32, 256 bytes apart), XOR-swizzled so that 8 consecutive lanes cover the 64 banks.
+template <int NS>
+__device__ __forceinline__ int l_pslot(int pr, int jb) {
+  if constexpr (NS == 8) return pr * 8 + (jb ^ ((pr >> 1) & 7));
+  else return pr * 16 + (jb ^ (pr & 15));
+}
+// entry j of the workgroup's row lr (0 .. 1023)
+template <int NS>
+__device__ __forceinline__ float l_entry(const float4* l_s, int lr, int j) {
+  const int q = lr >> 8, pr = (lr & 255) + 256 * (q >> 1);
+  return reinterpret_cast<const float*>(&l_s[l_pslot<NS>(pr, j >> 1)])[2 * (j & 1) + (q & 1)];
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+// packed products of a pair with ONE factor taken from the low / high half of a register pair (v_pk_mul_f32 with op_sel
+// rounds each half like v_mul_f32: the mandated individually rounded product, two rows per instruction; the file is
+// compiled with -ffp-contract=off, so the sums stay separate v_pk_add_f32)
+template <int HI>
+__device__ __forceinline__ f2 pk_mul_bcast(f2 a, f2 b) {
+  const float s = HI ? b.y : b.x;
+  return a * (f2){s, s};
+}
+__device__ __forceinline__ f2 pk_add(f2 a, f2 b) { return a + b; }
+__device__ __forceinline__ f2 pk_mul(f2 a, f2 b) { return a * b; }
+
+// xor-4 partner on the DPP path (two row shifts under complementary bank masks) instead of the LDS-crossbar ds_swizzle
+__device__ __forceinline__ int p4_xor4(int x) {
+  const int a = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0x5, false);  // row_shl:4 -> banks 0, 2 read lane + 4
+  return __builtin_amdgcn_update_dpp(a, x, 0x114, 0xf, 0xa, false);          // row_shr:4 -> banks 1, 3 read lane - 4
+}
+// wave_sum_fast (lo_device.h) with the xor-4 step on the DPP path: same operands, same order, same bits
+__device__ __forceinline__ float p4_wave_sum(float v) {
+  v = bfly_add<1>(v); v = bfly_add<2>(v);
+  v = v + __int_as_float(p4_xor4(__float_as_int(v)));
+  v = bfly_add<8>(v); v = bfly_add<16>(v); v = bfly_add<32>(v);
+  return v;
+}
 
 // (value, position) of the wave's best candidate in every lane: FIRST maximal position wins (torch.max on CPU, :61-63).
 // The value maximum runs as six cross-lane maxima; the position comes from the winner's lane (v_readlane) -- a tie of
 // the maximum (exact float equality, rare) takes the smallest position among the tied lanes through a second reduction.
-// The returned value is the winner's own bits (a maximum of +0 and -0 would not say which).
-__device__ __forceinline__ void p4_wave_argmax(float& v, int& j) {
+// The returned value is the winner's own bits (a maximum of +0 and -0 would not say which); returns the winner's lane
+// (or -1: no candidate).
+__device__ __forceinline__ int p4_wave_argmax(float& v, int& j) {
   float mx = (j == PO_INVALID) ? -INFINITY : v;
-  mx = fmaxf(mx, xor_lane<1>(mx)); mx = fmaxf(mx, xor_lane<2>(mx)); mx = fmaxf(mx, xor_lane<4>(mx));
+  mx = fmaxf(mx, xor_lane<1>(mx)); mx = fmaxf(mx, xor_lane<2>(mx));
+  mx = fmaxf(mx, __int_as_float(p4_xor4(__float_as_int(mx))));
   mx = fmaxf(mx, xor_lane<8>(mx));
   {
     int a_, b_;
@@ -118,12 +170,12 @@ __device__ __forceinline__ void p4_wave_argmax(float& v, int& j) {
   if (bal == 0ull) {  // no candidate (or only NaNs): nothing to offer
     v = -INFINITY;
     j = PO_INVALID;
-    return;
+    return -1;
   }
   int lane_w = __ffsll((long long)bal) - 1;
   if (__popcll(bal) > 1) {  // tie: smallest position among the tied lanes
     int jm = eq ? j : PO_INVALID;
-    jm = min(jm, xor_lane_i<1>(jm)); jm = min(jm, xor_lane_i<2>(jm)); jm = min(jm, xor_lane_i<4>(jm));
+    jm = min(jm, xor_lane_i<1>(jm)); jm = min(jm, xor_lane_i<2>(jm)); jm = min(jm, p4_xor4(jm));
     jm = min(jm, xor_lane_i<8>(jm));
     int a_, b_;
     bfly_i<16>(jm, a_, b_);
@@ -135,25 +187,20 @@ __device__ __forceinline__ void p4_wave_argmax(float& v, int& j) {
   }
   v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_w));
   j = __builtin_amdgcn_readlane(j, lane_w);
+  return lane_w;
 }
 
-// LQ = 16-byte slots per row: 4 (rank <= 16, rows 64 bytes apart, XOR over groups of 4 rows) or 8 (rank <= 32, rows 128
-// bytes apart: two consecutive rows cover the 64 banks, XOR over pairs of rows)
-template <int LQ>
-__device__ __forceinline__ int l_slot(int r, int q) {
-  if constexpr (LQ == 4) return r * 4 + (q ^ ((r >> 2) & 3));
-  else return r * 8 + (q ^ ((r >> 1) & 7));
-}
-
-// thread t < cnt publishes sh.part[t] and fetches component t of every workgroup of the group into sh.gath
-// (WIN: the value comes from the four wave candidates in sh.part4 -- every publishing thread picks the workgroup's winner
-//  itself from the four headers, in the order of the butterfly the workgroup-level reduction used to run, so the
-//  candidate phase needs ONE barrier instead of two and the four owner lanes write their payloads side by side)
-template <int GW, bool WIN = false>
-__device__ __forceinline__ void p4_gather(P4Shared<GW>& sh, int cnt, unsigned long long* gslot_base, int wig,
-                                          unsigned tag, int* err, bool same_xcd) {
+// thread t < cnt publishes component t of the workgroup's candidate and fetches component t of every workgroup of the
+// group into sh.gath.  WIN = false (placement check): the component is sh.part[t].  WIN = true (a pivot): the value comes
+// from the four wave candidates in sh.part4 -- every publishing thread picks the workgroup's winner itself from the four
+// headers, in the order of the butterfly the workgroup-level reduction used to run, so the candidate phase needs ONE
+// barrier; the winner's C row comes from its wave's sh.part4, its L entries 0 .. m-1 straight from the L rows in LDS
+// (header word 2 = the candidate's row inside the workgroup): no owner lane copies them first.
+template <int GW, int NS, int RC, bool WIN>
+__device__ __forceinline__ void p4_gather(P4Shared<GW>& sh, const float4* l_s, int cnt, unsigned long long* gslot_base,
+                                          int wig, unsigned tag, int* err, bool same_xcd) {
   const int t = threadIdx.x;
-  __syncthreads();  // sh.part / sh.part4 complete
+  __syncthreads();  // sh.part / sh.part4 and the L entries of the last pivot complete
   if (t < cnt) {
     unsigned long long* slot = gslot_base + (size_t)(tag & 1u) * GW * PO_SLOT;
     unsigned myval;
@@ -167,7 +214,14 @@ __device__ __forceinline__ void p4_gather(P4Shared<GW>& sh, int cnt, unsigned lo
       const int wsel = po_better(v2, j2, v0, j0) ? w23 : w01;
       const float ge = (__uint_as_float(sh.part4[0][3]) + __uint_as_float(sh.part4[1][3])) +
                        (__uint_as_float(sh.part4[2][3]) + __uint_as_float(sh.part4[3][3]));  // (the butterfly's order)
-      myval = (t == 3) ? __float_as_uint(ge) : sh.part4[wsel][t];
+      const int lr = (int)sh.part4[wsel][2] & (P4_ROWS - 1);  // (no candidate at all: any row, nobody reads it)
+      if (t >= PO_HDR + RC) {
+        myval = __float_as_uint(l_entry<NS>(l_s, lr, t - (PO_HDR + RC)));
+      } else if (t >= PO_HDR) {
+        myval = sh.part4[wsel][PO_HDR + 2 * (t - PO_HDR) + ((lr >> 8) & 1)];  // (pairs {row 2 p, row 2 p + 1} per column)
+      } else {
+        myval = (t == 3) ? __float_as_uint(ge) : sh.part4[wsel][t];
+      }
     } else {
       myval = sh.part[t];
     }
@@ -231,11 +285,42 @@ __device__ __forceinline__ void p4_gather(P4Shared<GW>& sh, int cnt, unsigned lo
   __syncthreads();
 }
 
+// the member's rows of C: every request in flight before anything waits (vmcnt counts in order).  A wave fetches its 64
+// consecutive rows as 64 * RC / 4 CONSECUTIVE 16-byte chunks (whole cache lines per instruction instead of 16 bytes out
+// of 64 lines); padding rows read a clamped valid row and are zeroed after the transposition.
+template <int RC>
+__device__ __forceinline__ void p4_issue_loads(const float* C, int64_t b, int N, int row0, int tl,
+                                               float4 (&raw)[P4_NR][RC / 4]) {
+  constexpr int CH = RC / 4;
+  const int wv = tl >> 6, ln = tl & 63;
+#pragma unroll
+  for (int q = 0; q < P4_NR; ++q) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int g = 64 * i + ln;
+      const int rw = g / CH, ck = g % CH;
+      const size_t grow = (size_t)b * N + min(row0 + P4_TPB * q + 64 * wv + rw, N - 1);
+      raw[q][i] = *reinterpret_cast<const float4*>(C + grow * RC + 4 * ck);
+    }
+  }
+}
+
+// phase timers without registers carried between the stamps: a stamp adds the clock to the phase that ends here and
+// subtracts it from the phase(s) that begin (the phase's sum of end - start builds up in memory)
+__device__ __forceinline__ void p4_stamp(long long* dbg, int ends, int begins, int begins2 = -1) {
+  const unsigned long long n = (unsigned long long)wall_clock64();
+  unsigned long long* d = reinterpret_cast<unsigned long long*>(dbg);
+  if (ends >= 0) atomicAdd(d + ends, n);
+  if (begins >= 0) atomicAdd(d + begins, 0ull - n);
+  if (begins2 >= 0) atomicAdd(d + begins2, 0ull - n);
+}
+
 template <int RC, int GW, int LQ>
 __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
+  constexpr int NS = 2 * LQ;  // 16-byte slots per pair row
   __shared__ P4Shared<GW> sh;
-  // L rows (4 * LQ floats) of this workgroup, swizzled 16-byte slots: 64 KB static (two workgroups per CU) for rank
-  // <= 16, 128 KB dynamic (one workgroup per CU) for rank <= 32
+  // L entries of this workgroup's rows (pair rows, swizzled 16-byte slots): 64 KB static (two workgroups per CU) for
+  // rank <= 16, 128 KB dynamic (one workgroup per CU) for rank <= 32
   __shared__ float4 l_static[LQ == 4 ? P4_ROWS * 4 : 1];
   extern __shared__ float4 l_dynamic[];
   float4* const l_s = (LQ == 4) ? l_static : l_dynamic;
@@ -253,7 +338,7 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
   {
     const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
     if (t == 0) sh.part[0] = xcc;
-    p4_gather<GW>(sh, 1, gslot, wig, ++tag, a.err, false);
+    p4_gather<GW, NS, RC, false>(sh, l_s, 1, gslot, wig, ++tag, a.err, false);
     bool same = true;
 #pragma unroll
     for (int w = 1; w < GW; ++w) same = same && (sh.gath[w][0] == sh.gath[0][0]);
@@ -262,34 +347,28 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
   }
   const int row0 = wig * a.RW;
   const int nv = max(0, min(a.RW, a.N - row0));
+  constexpr int CH = RC / 4;
 
+  float4 raw[P4_NR][CH];
+  {
+    int tl = t;
+    asm volatile("" : "+v"(tl));
+    if (grp < a.B) p4_issue_loads<RC>(a.C, grp, a.N, row0, tl, raw);
+  }
   for (int64_t b = grp; b < a.B; b += ngroups) {
     const bool stamp = a.dbg && b == 64 && wig == 0 && t == 0;  // a member of the second round
-    long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     if (stamp) a.dbg[0] = wall_clock64();
     int tl = t;
-    asm volatile("" : "+v"(tl));  // keeps the load-phase address arithmetic inside the member loop (VGPR budget)
-    float Cr[P4_NR][RC];
-    float dg[P4_NR];
+    asm volatile("" : "+v"(tl));  // keeps the address arithmetic of a phase inside the member loop (VGPR budget)
+    // Cq[p][k] = {C[r0][2 k], C[r1][2 k], C[r0][2 k + 1], C[r1][2 k + 1]}, r0 = row t + 256 (2 p), r1 = r0 + 256: the two
+    // rows of a pair share a register pair per column, the chains of a pivot run as packed products and sums (two rows
+    // per instruction); two columns share a 16-byte register group (the owner lane's LDS stores of a pivot row)
+    f4 Cq[2][RC / 2];
+    f2 dg2[2];
     int pos[P4_NR];
-    // All loads of the member are in flight before anything waits (vmcnt counts in order: a use inside the loop would
-    // serialise the four row sets).  A wave fetches its 64 consecutive rows as 64 * RC / 4 CONSECUTIVE 16-byte chunks
-    // (whole cache lines per instruction instead of 16 bytes out of 64 lines), parks them in its own window of the
-    // (not yet used) L rows, chunk slot XOR-swizzled by the row, and reads its row back; padding rows read a clamped
-    // valid row and are zeroed.
-    constexpr int CH = RC / 4;
+    // A wave parks the 64 x CH chunks of a row set in its own window of the (not yet used) L rows, chunk slot
+    // XOR-swizzled by the row, and reads its row back
     const int wv = tl >> 6, ln = tl & 63;
-#pragma unroll
-    for (int q = 0; q < P4_NR; ++q) {
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const int g = 64 * i + ln;
-        const int rw = g / CH, ck = g % CH;
-        const size_t grow = (size_t)b * a.N + min(row0 + P4_TPB * q + 64 * wv + rw, a.N - 1);
-        const float4 c4 = *reinterpret_cast<const float4*>(a.C + grow * RC + 4 * ck);
-        Cr[q][4 * i] = c4.x; Cr[q][4 * i + 1] = c4.y; Cr[q][4 * i + 2] = c4.z; Cr[q][4 * i + 3] = c4.w;
-      }
-    }
 #pragma unroll
     for (int q = 0; q < P4_NR; ++q) {
       const int lr = tl + P4_TPB * q;
@@ -299,39 +378,51 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
       for (int i = 0; i < CH; ++i) {
         const int g = 64 * i + ln;
         const int rw = g / CH, ck = g % CH;
-        win[rw * CH + (ck ^ ((rw ^ (rw >> 3)) & (CH - 1)))] =
-            make_float4(Cr[q][4 * i], Cr[q][4 * i + 1], Cr[q][4 * i + 2], Cr[q][4 * i + 3]);
+        win[rw * CH + (ck ^ ((rw ^ (rw >> 3)) & (CH - 1)))] = raw[q][i];
       }
       __builtin_amdgcn_wave_barrier();  // (LDS operations of a wave execute in order; this pins the compiler's order)
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        const float4 c4 = win[ln * CH + (i ^ ((ln ^ (ln >> 3)) & (CH - 1)))];
-        Cr[q][4 * i] = c4.x; Cr[q][4 * i + 1] = c4.y; Cr[q][4 * i + 2] = c4.z; Cr[q][4 * i + 3] = c4.w;
+        float4 c4 = win[ln * CH + (i ^ ((ln ^ (ln >> 3)) & (CH - 1)))];
+        c4.x = valid ? c4.x : 0.f; c4.y = valid ? c4.y : 0.f; c4.z = valid ? c4.z : 0.f; c4.w = valid ? c4.w : 0.f;
+        if (q & 1) {
+          Cq[q >> 1][2 * i].y = c4.x; Cq[q >> 1][2 * i].w = c4.y; Cq[q >> 1][2 * i + 1].y = c4.z; Cq[q >> 1][2 * i + 1].w = c4.w;
+        } else {
+          Cq[q >> 1][2 * i].x = c4.x; Cq[q >> 1][2 * i].z = c4.y; Cq[q >> 1][2 * i + 1].x = c4.z; Cq[q >> 1][2 * i + 1].z = c4.w;
+        }
       }
-#pragma unroll
-      for (int i = 0; i < RC; ++i) Cr[q][i] = valid ? Cr[q][i] : 0.f;
       __builtin_amdgcn_wave_barrier();  // the next row set reuses the window
-      float acc = Cr[q][0] * Cr[q][0];  // (root ** 2).sum(-1), sequential in r
-#pragma unroll
-      for (int r = 1; r < RC; ++r) acc = acc + Cr[q][r] * Cr[q][r];
-      dg[q] = valid ? acc : 0.f;
       pos[q] = valid ? row0 + lr : PO_INVALID;
     }
+    // (opaque: otherwise the 16-byte values read from the window are kept alive -- in scratch -- for the owner lane's
+    //  16-byte LDS stores of a pivot row, which are rebuilt from the pairs instead)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int k = 0; k < RC / 2; ++k) asm volatile("" : "+v"(Cq[p][k]));
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      f2 acc = Cq[p][0].lo * Cq[p][0].lo;  // (root ** 2).sum(-1), sequential in r (zero rows give 0)
+      acc = acc + Cq[p][0].hi * Cq[p][0].hi;
+#pragma unroll
+      for (int k = 1; k < RC / 2; ++k) {
+        acc = acc + Cq[p][k].lo * Cq[p][k].lo;
+        acc = acc + Cq[p][k].hi * Cq[p][k].hi;
+      }
+      dg2[p] = acc;
+    }
+    float dg[P4_NR] = {dg2[0].x, dg2[0].y, dg2[1].x, dg2[1].y};
     __syncthreads();  // the windows are done: the L rows can be cleared
 #pragma unroll
-    for (int q = 0; q < P4_NR; ++q) {
-      const int lr = tl + P4_TPB * q;
-#pragma unroll
-      for (int i = 0; i < LQ; ++i) l_s[l_slot<LQ>(lr, i)] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int i = 0; i < 4 * LQ; ++i) l_s[tl + P4_TPB * i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     if (stamp) a.dbg[1] = wall_clock64();
     for (int m = 0; m < a.rank; ++m) {
-      if (stamp) c0 = wall_clock64();
+      if (stamp) p4_stamp(a.dbg, -1, 4);
       if (a.prio & 1) __builtin_amdgcn_s_setprio(3);
       // ---- workgroup candidate: argmax of the running diagonal over the positions >= m, error 1-norm partial ----
       float bv = -INFINITY, es = 0.f;
-      int bj = PO_INVALID;
+      int bj = PO_INVALID, bq = 0;
 #pragma unroll
       for (int q = 0; q < P4_NR; ++q) {
         const bool cand = pos[q] != PO_INVALID && pos[q] >= m;
@@ -340,34 +431,38 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
           if (po_better(dg[q], pos[q], bv, bj)) {
             bv = dg[q];
             bj = pos[q];
+            bq = q;
           }
         }
       }
-      p4_wave_argmax(bv, bj);
-      es = wave_sum_fast(es);
-      // every WAVE's candidate goes to LDS with its payload (header, C row, L entries 0..m-1): the four owner lanes write
-      // side by side, and the workgroup's winner is picked by the publishing threads after ONE barrier (p4_gather<.., true>)
+      const int lane_w = p4_wave_argmax(bv, bj);
+      es = p4_wave_sum(es);
+      // every WAVE's candidate goes to LDS with its header and C row: the four owner lanes write side by side, and the
+      // workgroup's winner is picked by the publishing threads after ONE barrier (p4_gather<.., true>)
       unsigned* const mine4 = sh.part4[wave];
       if (lane == 0) {
         mine4[0] = __float_as_uint(bv);   // (-inf, PO_INVALID when the wave has no candidate left)
         mine4[1] = (unsigned)bj;
         mine4[3] = __float_as_uint(es);
       }
+      if (lane_w >= 0) {
+        // (the owner lane writes the register PAIRS that hold the row -- both rows of the pair, 8-byte LDS stores straight
+        //  from the registers; the publishing threads pick the row's half.  Which pair is a wave-uniform value, so exactly
+        //  one of the two compile-time variants runs)
+        const int bq_u = __builtin_amdgcn_readlane(bq, lane_w);
+        f4* dst = reinterpret_cast<f4*>(&mine4[PO_HDR]);
 #pragma unroll
-      for (int q = 0; q < P4_NR; ++q) {
-        if (pos[q] != PO_INVALID && pos[q] >= m && pos[q] == bj) {
-          // (one thread writes the whole payload: 16-byte LDS stores -- PO_HDR and RC are multiples of 4)
-          float4* dst = reinterpret_cast<float4*>(&mine4[PO_HDR]);
+        for (int p = 0; p < 2; ++p) {
+          if ((bq_u >> 1) == p && lane == lane_w) {
+            mine4[2] = (unsigned)(t + P4_TPB * bq);
 #pragma unroll
-          for (int r = 0; r < RC / 4; ++r)
-            dst[r] = make_float4(Cr[q][4 * r], Cr[q][4 * r + 1], Cr[q][4 * r + 2], Cr[q][4 * r + 3]);
-          const int lr = t + P4_TPB * q;
-          for (int j4 = 0; 4 * j4 < m; ++j4) dst[RC / 4 + j4] = l_s[l_slot<LQ>(lr, j4)];
+            for (int k = 0; k < RC / 2; ++k) dst[k] = Cq[p][k];
+          }
         }
       }
-      if (stamp) c1 = wall_clock64();
-      p4_gather<GW, true>(sh, PO_HDR + RC + m, gslot, wig, ++tag, a.err, same_xcd);
-      if (stamp) c2 = wall_clock64();
+      if (stamp) p4_stamp(a.dbg, 4, 5);
+      p4_gather<GW, NS, RC, true>(sh, l_s, PO_HDR + RC + m, gslot, wig, ++tag, a.err, same_xcd);
+      if (stamp) p4_stamp(a.dbg, 5, 6, 7);
 
       // ---- group winner (identical in all workgroups): lane l holds candidate l % GW ----
       float vb = __uint_as_float(sh.gath[lane % GW][0]);
@@ -406,57 +501,107 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
       }
       const float piv = sqrtf(vb);  // :73-74
       const float* g = reinterpret_cast<const float*>(sh.gath[wb]) + PO_HDR;
-      // pivot row of C and its L entries, shared by the 4 rows of this thread
-      float gc[RC];
+      // the pivot row of C as register pairs {g[2 k], g[2 k + 1]}
+      f2 g2[RC / 2];
 #pragma unroll
       for (int i = 0; i < RC / 4; ++i) {
         const float4 g4 = *reinterpret_cast<const float4*>(g + 4 * i);
-        gc[4 * i] = g4.x; gc[4 * i + 1] = g4.y; gc[4 * i + 2] = g4.z; gc[4 * i + 3] = g4.w;
+        g2[2 * i] = (f2){g4.x, g4.y};
+        g2[2 * i + 1] = (f2){g4.z, g4.w};
       }
-      // Schur update of row m for the 4 rows of this thread IN LOCKSTEP: the products and sums of a row are a
-      // dependent chain in the mandated order, the 4 rows give the instruction-level parallelism (computed for every
-      // row, applied below only where the reference writes)
-      long long d0 = 0, d1 = 0, d2 = 0;
-      if (stamp) d0 = wall_clock64();
+      // Schur update of row m for the 4 rows of this thread: the products and sums of a row are a dependent chain in the
+      // mandated order; the two rows of a pair share an instruction, the two pairs run in lockstep (computed for every
+      // row, applied below only where the reference writes).  The L entries (of the pivot row: u; of this thread's rows:
+      // sl) are requested two slots (four entries) at a time, a stage ahead of their use: the chains hide the LDS latency
+      // and at most 72 registers hold operands in flight (VGPR budget: 128 of the 256 hold C).
+      if (stamp) p4_stamp(a.dbg, 7, 8);
       if (!(a.prio & 2)) __builtin_amdgcn_s_setprio(0);
-      float rowv[P4_NR], accs[P4_NR];
+      f2 rowv[2], accs[2];
+      int tp = t;
+      asm volatile("" : "+v"(tp));  // (the 16 slot addresses are formed per pivot, not kept in registers across the loop)
+      f2 u2[4];         // {u[2 k], u[2 k + 1]}, entries 0 .. 7
+      float4 sl[2][4];  // slots 0 .. 3 of the two pair rows
+#define LO_P4_FETCH(K0)                                                                      \
+  if (2 * (K0) < m) {                                                                        \
+    const float4 u4 = *reinterpret_cast<const float4*>(g + RC + 2 * (K0));                   \
+    u2[K0] = (f2){u4.x, u4.y};                                                               \
+    u2[(K0) + 1] = (f2){u4.z, u4.w};                                                         \
+    sl[0][K0] = l_s[l_pslot<NS>(tp, K0)];                                                     \
+    sl[1][K0] = l_s[l_pslot<NS>(tp + P4_TPB, K0)];                                            \
+    if (2 * ((K0) + 1) < m) {                                                                \
+      sl[0][(K0) + 1] = l_s[l_pslot<NS>(tp, (K0) + 1)];                                       \
+      sl[1][(K0) + 1] = l_s[l_pslot<NS>(tp + P4_TPB, (K0) + 1)];                              \
+    }                                                                                        \
+  }
+#define LO_P4_CHAIN(K)                                                                       \
+  if (2 * (K) < m) {                                                                         \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                          \
+      const f2 pr0 = pk_mul_bcast<0>((f2){sl[p][K].x, sl[p][K].y}, u2[K]);                   \
+      accs[p] = ((K) == 0) ? pr0 : pk_add(accs[p], pr0);                                     \
+    }                                                                                        \
+    if (2 * (K) + 1 < m) {                                                                   \
+      _Pragma("unroll") for (int p = 0; p < 2; ++p)                                          \
+        accs[p] = pk_add(accs[p], pk_mul_bcast<1>((f2){sl[p][K].z, sl[p][K].w}, u2[K]));     \
+    }                                                                                        \
+  }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < P4_NR; ++q) rowv[q] = gc[0] * Cr[q][0];
+      for (int p = 0; p < 2; ++p) rowv[p] = pk_mul_bcast<0>(Cq[p][0].lo, g2[0]);
 #pragma unroll
-      for (int r = 1; r < RC; ++r)
+      for (int r = 1; r < RC / 2; ++r)
 #pragma unroll
-        for (int q = 0; q < P4_NR; ++q) rowv[q] = rowv[q] + gc[r] * Cr[q][r];
-      if (stamp) { asm volatile("" :: "v"(rowv[0]), "v"(rowv[1]), "v"(rowv[2]), "v"(rowv[3])); d1 = wall_clock64(); }
+        for (int p = 0; p < 2; ++p)
+          rowv[p] = pk_add(rowv[p], (r & 1) ? pk_mul_bcast<1>(Cq[p][r >> 1].hi, g2[r >> 1]) : pk_mul_bcast<0>(Cq[p][r >> 1].lo, g2[r >> 1]));
+      __builtin_amdgcn_sched_barrier(0);
+      LO_P4_FETCH(0)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < P4_NR; ++q) accs[q] = 0.f;
-      for (int j4 = 0; 4 * j4 < m; ++j4) {  // :83-89, sequential in j
-        const float4 u4 = *reinterpret_cast<const float4*>(g + RC + 4 * j4);
-        const int j = 4 * j4;
-        float4 l4[P4_NR];
+      for (int r = RC / 2; r < RC; ++r)
 #pragma unroll
-        for (int q = 0; q < P4_NR; ++q) l4[q] = l_s[l_slot<LQ>(t + P4_TPB * q, j4)];
+        for (int p = 0; p < 2; ++p)
+          rowv[p] = pk_add(rowv[p], (r & 1) ? pk_mul_bcast<1>(Cq[p][r >> 1].hi, g2[r >> 1]) : pk_mul_bcast<0>(Cq[p][r >> 1].lo, g2[r >> 1]));
+      if (stamp) { asm volatile("" :: "v"(rowv[0]), "v"(rowv[1])); p4_stamp(a.dbg, 8, 9); }
 #pragma unroll
-        for (int q = 0; q < P4_NR; ++q) accs[q] = (j == 0) ? u4.x * l4[q].x : accs[q] + u4.x * l4[q].x;
-        if (j + 1 < m) {
-#pragma unroll
-          for (int q = 0; q < P4_NR; ++q) accs[q] = accs[q] + u4.y * l4[q].y;
-        }
-        if (j + 2 < m) {
-#pragma unroll
-          for (int q = 0; q < P4_NR; ++q) accs[q] = accs[q] + u4.z * l4[q].z;
-        }
-        if (j + 3 < m) {
-#pragma unroll
-          for (int q = 0; q < P4_NR; ++q) accs[q] = accs[q] + u4.w * l4[q].w;
+      for (int p = 0; p < 2; ++p) accs[p] = (f2){0.f, 0.f};
+      // :83-89, sequential in j
+      __builtin_amdgcn_sched_barrier(0);
+      LO_P4_FETCH(2)
+      __builtin_amdgcn_sched_barrier(0);
+      LO_P4_CHAIN(0)
+      LO_P4_CHAIN(1)
+      LO_P4_CHAIN(2)
+      LO_P4_CHAIN(3)
+#undef LO_P4_FETCH
+#undef LO_P4_CHAIN
+      // entries 8 ..: one slot (two entries) of the pivot row and of the two pair rows per step, requested a step ahead
+      if (m > 8) {
+        const int nk = (m + 1) >> 1;
+        float2 un = *reinterpret_cast<const float2*>(g + RC + 8);
+        float4 ln0 = l_s[l_pslot<NS>(tp, 4)], ln1 = l_s[l_pslot<NS>(tp + P4_TPB, 4)];
+        for (int k = 4; k < nk; ++k) {
+          const f2 uk = (f2){un.x, un.y};
+          const float4 lq0 = ln0, lq1 = ln1;
+          if (k + 1 < nk) {
+            un = *reinterpret_cast<const float2*>(g + RC + 2 * (k + 1));
+            ln0 = l_s[l_pslot<NS>(tp, k + 1)];
+            ln1 = l_s[l_pslot<NS>(tp + P4_TPB, k + 1)];
+          }
+          accs[0] = pk_add(accs[0], pk_mul_bcast<0>((f2){lq0.x, lq0.y}, uk));
+          accs[1] = pk_add(accs[1], pk_mul_bcast<0>((f2){lq1.x, lq1.y}, uk));
+          if (2 * k + 1 < m) {
+            accs[0] = pk_add(accs[0], pk_mul_bcast<1>((f2){lq0.z, lq0.w}, uk));
+            accs[1] = pk_add(accs[1], pk_mul_bcast<1>((f2){lq1.z, lq1.w}, uk));
+          }
         }
       }
-      if (stamp) { asm volatile("" :: "v"(accs[0]), "v"(accs[1]), "v"(accs[2]), "v"(accs[3])); d2 = wall_clock64(); a.dbg[7] += d0 - c2; a.dbg[8] += d1 - d0; a.dbg[9] += d2 - d1; }
+      if (stamp) { asm volatile("" :: "v"(accs[0]), "v"(accs[1])); p4_stamp(a.dbg, 9, -1); }
       // write-back without divergent control flow: the four quotients are formed in lockstep (independent divisions),
       // the new L entry is ONE 4-byte LDS store into its 16-byte slot (no read-modify-write of the float4)
-      const int ms = m >> 2, me = m & 3;
+      const float rw4[P4_NR] = {rowv[0].x, rowv[0].y, rowv[1].x, rowv[1].y};
+      const float ac4[P4_NR] = {accs[0].x, accs[0].y, accs[1].x, accs[1].y};
       float vq[P4_NR];
 #pragma unroll
-      for (int q = 0; q < P4_NR; ++q) vq[q] = ((m > 0) ? rowv[q] - accs[q] : rowv[q]) / piv;  // :91
+      for (int q = 0; q < P4_NR; ++q) vq[q] = ((m > 0) ? rw4[q] - ac4[q] : rw4[q]) / piv;  // :91
 #pragma unroll
       for (int q = 0; q < P4_NR; ++q) {
         const int pq = pos[q];
@@ -466,34 +611,59 @@ __global__ __launch_bounds__(P4_TPB, 2) void k_pc_onchip4(PoArgs a) {
         if (live) pos[q] = np;
         const float val = (np == m) ? piv : vq[q];  // the pivot row gets sqrt(max) (:73-74)
         if (live && np >= m)                         // already pivoted rows keep L[m] = 0
-          reinterpret_cast<float*>(&l_s[l_slot<LQ>(t + P4_TPB * q, ms)])[me] = val;
+          reinterpret_cast<float*>(&l_s[l_pslot<NS>(tp + P4_TPB * (q >> 1), m >> 1)])[2 * (m & 1) + (q & 1)] = val;
         if (live && np > m) dg[q] = dg[q] - vq[q] * vq[q];  // :94-95
       }
-      // sh.gath / sh.part are next written after the barrier that follows the candidate reduction
-      if (stamp) {
-        c3 = wall_clock64();
-        a.dbg[4] += c1 - c0;
-        a.dbg[5] += c2 - c1;
-        a.dbg[6] += c3 - c2;
-      }
+      // sh.gath / sh.part4 are next written after the barrier that follows the candidate reduction
+      if (stamp) p4_stamp(a.dbg, 6, -1);
     }
     __builtin_amdgcn_s_setprio(0);
     if (stamp) a.dbg[2] = wall_clock64();
 
+    // the next member's rows are requested BEFORE this member's L rows leave (the registers of C are free from here on)
+    int tn = t;
+    asm volatile("" : "+v"(tn));
+    {
+      if (b + ngroups < a.B) {
+        p4_issue_loads<RC>(a.C, b + ngroups, a.N, row0, tn, raw);
+      } else {  // (defined on both paths: the old values must not stay live through the pivot loop)
+#pragma unroll
+        for (int q = 0; q < P4_NR; ++q)
+#pragma unroll
+          for (int i = 0; i < CH; ++i) raw[q][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     // ---- L rows -> global, [max_rank, N] layout, consecutive threads = consecutive rows ----
 #pragma unroll
-    for (int q = 0; q < P4_NR; ++q) {
-      const int lr = t + P4_TPB * q;
-      if (lr < nv) {
-        float* Lb = a.L + (size_t)b * a.max_rank * a.N + row0 + lr;
+    for (int p = 0; p < 2; ++p) {
+      const int lr0 = tn + P4_TPB * (2 * p), lr1 = lr0 + P4_TPB;
+      float* Lb = a.L + (size_t)b * a.max_rank * a.N + row0 + lr0;
 #pragma unroll
-        for (int j4 = 0; j4 < LQ; ++j4) {
-          const float4 l4 = l_s[l_slot<LQ>(lr, j4)];
-          const int m0 = 4 * j4;
-          if (m0 < a.max_rank) Lb[(size_t)m0 * a.N] = (m0 < a.rank) ? l4.x : 0.f;
-          if (m0 + 1 < a.max_rank) Lb[(size_t)(m0 + 1) * a.N] = (m0 + 1 < a.rank) ? l4.y : 0.f;
-          if (m0 + 2 < a.max_rank) Lb[(size_t)(m0 + 2) * a.N] = (m0 + 2 < a.rank) ? l4.z : 0.f;
-          if (m0 + 3 < a.max_rank) Lb[(size_t)(m0 + 3) * a.N] = (m0 + 3 < a.rank) ? l4.w : 0.f;
+      for (int h = 0; h < NS; h += 4) {
+        float4 l4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) l4[k] = l_s[l_pslot<NS>(tn + P4_TPB * p, h + k)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int m0 = 2 * (h + k);
+          l4[k].x = (m0 < a.rank) ? l4[k].x : 0.f; l4[k].y = (m0 < a.rank) ? l4[k].y : 0.f;
+          l4[k].z = (m0 + 1 < a.rank) ? l4[k].z : 0.f; l4[k].w = (m0 + 1 < a.rank) ? l4[k].w : 0.f;
+        }
+        if (lr0 < nv) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int m0 = 2 * (h + k);
+            if (m0 < a.max_rank) Lb[(size_t)m0 * a.N] = l4[k].x;
+            if (m0 + 1 < a.max_rank) Lb[(size_t)(m0 + 1) * a.N] = l4[k].z;
+          }
+        }
+        if (lr1 < nv) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int m0 = 2 * (h + k);
+            if (m0 < a.max_rank) Lb[(size_t)m0 * a.N + P4_TPB] = l4[k].y;
+            if (m0 + 1 < a.max_rank) Lb[(size_t)(m0 + 1) * a.N + P4_TPB] = l4[k].w;
+          }
         }
       }
     }
