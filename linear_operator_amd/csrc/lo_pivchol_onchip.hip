@@ -4,19 +4,21 @@
 //
 // The streaming engine (lo_pivchol.hip) re-reads C (4NR bytes) and the m finished rows of L (4mN bytes) from HBM
 // for every pivot.  Here a group of GW workgroups (256 threads x 4 rows; GW = smallest power of two that holds the member)
-// owns one batch member for ALL pivots: a thread keeps its four rows of C in registers, their running diagonal and position
-// in the permutation as well, and their L entries L[0..m-1][i] in LDS (swizzled 16-byte slots); two workgroups of different
-// members share a CU.  HBM traffic per member: C once (4NR) + L once (4 max_rank N).
+// owns one batch member for ALL pivots: a thread keeps its four rows of C in registers (as two PAIRS of rows: a register
+// pair per column, so the chains of a pivot run as packed products and sums), their running diagonal and position in the
+// permutation as well, and their L entries L[0..m-1][i] in LDS (pair rows, swizzled 16-byte slots); two workgroups of
+// different members share a CU.  HBM traffic per member: C once (4NR) + L once (4 max_rank N).
 // Per pivot the group needs ONE exchange (8-byte {value, tag} granules, the hand-off of lo_group_reduce.h): every
 // workgroup publishes its best candidate (diagonal value, position, row), that row's C row and L entries, and its partial
 // of the error 1-norm; everybody then picks the same winner and has all it needs for the Schur update of its own rows.
 // (The first generation -- one row per thread, C in LDS, L in registers, 1.0 ms at the headline shape against 0.58 -- was
 // removed in round 6; nothing had selected it since round 2.)
 //
-// What a pivot costs (LO_OC_DEBUG stamps, 512 x 8192 x 32, rank 15, second round of members): 4.1 us =
-// candidate reduction + publication 1.06, exchange 0.62, winner + pivot row 0.38, C.C chain 0.51 (the mandated sequential
-// 32-term products and sums of four rows in lockstep), L.L chain 0.53, quotient / write-back 0.6.  The group exchange is
-// 15 % of a pivot: taking several pivots per exchange cannot shorten the chain by more than that.
+// What a pivot costs (variants of this file with one piece removed, timed on one box; 512 x 8192 x 32, rank
+// 15: 566 us = 100 us of HBM time + 120 pivots of 3.9 us per workgroup): C.C chain 0.43, L.L chain 0.52, the group
+// exchange 0.62 (0.52 of it the wait for the slowest workgroup), the owner lanes' LDS stores of their C rows 0.52, wave
+// argmax 0.17, winner 0.20, division 0.08 -- and 1.3 us are left when all of these are gone.  No piece dominates; a
+// member alone on its CUs takes 59 us, two members per CU 71 us each.
 //
 // Every operation that feeds a pivot decision is the same individually rounded, fixed-order arithmetic as
 // lo_pivchol.hip / oracle.pivoted_cholesky (file compiled with -ffp-contract=off), so L and the permutation
