@@ -838,7 +838,10 @@ constexpr int RSP_TR = 64;   // rows per tile of k_rs_part (16 per wave)
 constexpr int RSP_CMAX = 32; // columns per launch
 constexpr int RSP_SQ = 16;   // row classes of the s / a0 sums (threads per column)
 
-template <int RC, int NT>
+// VL: the LAST column (inv_quad_logdet: the right-hand side behind 16 probes) runs on the vector ALU -- 2 c = 34 operand
+// columns would open a third 16-column tile for two columns (24 instead of 16 matrix instructions per wave and tile:
+// 330 -> 265 us at the cfg3 shape); the matrix cores then see cm = c - 1 columns, twice.
+template <int RC, int NT, bool VL>
 __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ C, const float* __restrict__ rhs,
                                                        const float* __restrict__ dinv, int dinv_mode, int N, int c,
                                                        int rows_per, double* __restrict__ part, double* __restrict__ sq) {
@@ -849,6 +852,7 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
   __shared__ __attribute__((aligned(16))) float ctile[2][TR * LD];
   __shared__ __attribute__((aligned(16))) float btile[2][TR * WB];
   __shared__ float dtile[2][TR];
+  __shared__ float ltile[2][VL ? TR : 1];  // the last column (VL)
   __shared__ double sqred[RSP_SQ][RSP_CMAX][2];
   // (the cross-wave reduction at the end reuses the tiles)
   static_assert(sizeof(float) * 2 * TR * WB >= sizeof(double) * 4 * 64 * 4 || sizeof(float) * 2 * TR * LD >= sizeof(double) * 4 * 64 * 4,
@@ -871,11 +875,12 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
   constexpr int BP = TR * RSP_CMAX / kThreads;             // floats of the right-hand sides per thread and tile (at c = 32)
   // element e = i * 256 + t of a tile's right-hand sides (rows x c, contiguous) lands at row e / c, column e % c: the
   // same for every tile -- one division per element for the whole kernel
+  const int cm = VL ? c - 1 : c;  // columns on the matrix cores
   int bdst[BP];
 #pragma unroll
   for (int i = 0; i < BP; ++i) {
     const int e = i * kThreads + t;
-    bdst[i] = (e / c) * WB + (e % c);
+    bdst[i] = (VL && e % c == cm) ? -1 - e / c : (e / c) * WB + (e % c);  // (VL: the last column goes to ltile[row])
   }
   for (int e = t; e < 2 * TR * WB; e += kThreads) (&btile[0][0])[e] = 0.f;  // (the zero columns are never written again)
   for (int e = t; e < 2 * TR * LD; e += kThreads) (&ctile[0][0])[e] = 0.f;
@@ -914,8 +919,12 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
     for (int i = 0; i < BP; ++i) {
       const int e = i * kThreads + t;
       if (e < TR * c) {
-        btile[buf][bdst[i]] = pb[i];
-        btile[buf][bdst[i] + c] = pb[i];
+        if (VL && bdst[i] < 0) {
+          ltile[buf][-1 - bdst[i]] = pb[i];
+        } else {
+          btile[buf][bdst[i]] = pb[i];
+          btile[buf][bdst[i] + cm] = pb[i];
+        }
       }
     }
     if (t < TR) dtile[buf][t] = pd;
@@ -925,10 +934,13 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
   for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
     for (int nj = 0; nj < NT; ++nj) acc[mi][nj] = f64x4{0.0, 0.0, 0.0, 0.0};
-  // lane (a, kk) feeds column jc = 16 nj + a of the B operand: columns [0, c) carry b dinv, [c, 2 c) carry b
+  // lane (a, kk) feeds column jc = 16 nj + a of the B operand: columns [0, cm) carry b dinv, [cm, 2 cm) carry b
   bool scaled[NT];
 #pragma unroll
-  for (int nj = 0; nj < NT; ++nj) scaled[nj] = 16 * nj + a < c;
+  for (int nj = 0; nj < NT; ++nj) scaled[nj] = 16 * nj + a < cm;
+  double lw[MT], lu[MT];  // VL: C^T (dinv o b_last) and C^T b_last of the lane's rows (kk + 4 e) and components 16 mi + a
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) lw[mi] = lu[mi] = 0.0;
   // s = sum b^2 dinv, a0 = sum b^2: thread (col = t % c, rsub = t / c < nsq) walks the rows rsub, rsub + nsq, ... of its
   // column -- ALL threads share the work (with four row classes the 4 c threads of the first wave did 16 rows each on the
   // fp64 pipe the matrix instructions also run on, and every tile's barrier waited for that wave)
@@ -942,11 +954,12 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
   for (int base = r0; base < r1; base += TR) {
     const bool more = base + TR < r1;
     if (more) issue(base + TR);
-    float avf[4][MT], bvf[4][NT], dvf[4];
+    float avf[4][MT], bvf[4][NT], dvf[4], lvf[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {  // all operands of the wave's 16 rows first (branch-free), then the products
       const int row = 16 * wave + 4 * e + kk;
       dvf[e] = dtile[buf][row];
+      lvf[e] = VL ? ltile[buf][row] : 0.f;
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) avf[e][mi] = ctile[buf][row * LD + 16 * mi + a];
 #pragma unroll
@@ -964,10 +977,18 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int nj = 0; nj < NT; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mi], bv[nj], acc[mi][nj], 0, 0, 0);
+      if constexpr (VL) {
+        const double bl = (double)lvf[e], bld = bl * dv;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          lw[mi] = fma(av[mi], bld, lw[mi]);
+          lu[mi] = fma(av[mi], bl, lu[mi]);
+        }
+      }
     }
     if (rsub < nsq) {
       for (int row = rsub; row < TR; row += nsq) {
-        const double v = (double)btile[buf][row * WB + scol];
+        const double v = (double)((VL && scol == cm) ? ltile[buf][row] : btile[buf][row * WB + scol]);
         const double vv = v * v;
         a_acc += vv;
         s_acc = fma(vv, (double)dtile[buf][row], s_acc);
@@ -991,10 +1012,38 @@ __global__ __launch_bounds__(kThreads) void k_rs_part(const float* __restrict__ 
         for (int r = 0; r < 4; ++r) {
           const double v = (red[0][l][r] + red[1][l][r]) + (red[2][l][r] + red[3][l][r]);
           const int i = 16 * mi + 4 * r + kk, jc = 16 * nj + a;  // D[4 r + l / 16][l % 16]
-          if (i < RC && jc < 2 * c) pp[(size_t)i * 2 * c + jc] = v;
+          // operand column jc -> result column: [0, cm) stay, [cm, 2 cm) move behind the c scaled ones
+          if (i < RC && jc < 2 * cm) pp[(size_t)i * 2 * c + (jc < cm ? jc : jc - cm + c)] = v;
         }
       }
     }
+  if constexpr (VL) {  // the last column: sum over the four row classes kk (lane bits 4, 5), then over the waves
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      lw[mi] = bfly_add_d<32>(bfly_add_d<16>(lw[mi]));
+      lu[mi] = bfly_add_d<32>(bfly_add_d<16>(lu[mi]));
+    }
+    __syncthreads();
+    if (kk == 0) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        red[wave][a][2 * mi] = lw[mi];
+        red[wave][a][2 * mi + 1] = lu[mi];
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && kk == 0) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const int i = 16 * mi + a;
+        if (i < RC) {
+          pp[(size_t)i * 2 * c + cm] = (red[0][a][2 * mi] + red[1][a][2 * mi]) + (red[2][a][2 * mi] + red[3][a][2 * mi]);
+          pp[(size_t)i * 2 * c + c + cm] =
+              (red[0][a][2 * mi + 1] + red[1][a][2 * mi + 1]) + (red[2][a][2 * mi + 1] + red[3][a][2 * mi + 1]);
+        }
+      }
+    }
+  }
   if (rsub < nsq) {
     sqred[rsub][scol][0] = s_acc;
     sqred[rsub][scol][1] = a_acc;
@@ -1323,13 +1372,24 @@ static int rspace_cols_go(const OnchipArgs& a, double* ws, hipStream_t st) {
   r.rhs_norm = a.rhs_norm; r.rz = a.rz; r.alpha = a.alpha; r.beta = a.beta; r.resid_norm = a.resid_norm;
   r.rhs_is_zero = a.rhs_is_zero; r.has_conv = a.has_conv;
   dim3 block(kThreads);
-  const int nt = (2 * a.c + 15) / 16;
+  // the last column on the vector ALU when it alone would open another 16-column tile (c = 9, 17, 25: 2 c = 16 k + 2)
+  const bool vl = a.c > 1 && (2 * a.c - 2 + 15) / 16 < (2 * a.c + 15) / 16 && !getenv("LO_RS_NO_VL");
+  const int nt = vl ? (2 * a.c - 2 + 15) / 16 : (2 * a.c + 15) / 16;
   LO_PROF_BEGIN("rs_part", st);
   dim3 gp(sp.S, (unsigned)a.B);
-  if (nt == 1) hipLaunchKernelGGL((k_rs_part<RC, 1>), gp, block, 0, st, r.C, r.rhs, r.dinv, r.dinv_mode, r.N, r.c, r.rows_per, r.part, r.sq);
-  else if (nt == 2) hipLaunchKernelGGL((k_rs_part<RC, 2>), gp, block, 0, st, r.C, r.rhs, r.dinv, r.dinv_mode, r.N, r.c, r.rows_per, r.part, r.sq);
-  else if (nt == 3) hipLaunchKernelGGL((k_rs_part<RC, 3>), gp, block, 0, st, r.C, r.rhs, r.dinv, r.dinv_mode, r.N, r.c, r.rows_per, r.part, r.sq);
-  else hipLaunchKernelGGL((k_rs_part<RC, 4>), gp, block, 0, st, r.C, r.rhs, r.dinv, r.dinv_mode, r.N, r.c, r.rows_per, r.part, r.sq);
+#define LO_RSP(NT_, VL_) \
+  hipLaunchKernelGGL((k_rs_part<RC, NT_, VL_>), gp, block, 0, st, r.C, r.rhs, r.dinv, r.dinv_mode, r.N, r.c, r.rows_per, r.part, r.sq)
+  if (vl) {
+    if (nt == 1) LO_RSP(1, true);
+    else if (nt == 2) LO_RSP(2, true);
+    else LO_RSP(3, true);
+  } else {
+    if (nt == 1) LO_RSP(1, false);
+    else if (nt == 2) LO_RSP(2, false);
+    else if (nt == 3) LO_RSP(3, false);
+    else LO_RSP(4, false);
+  }
+#undef LO_RSP
   LO_PROF_END(st);
   LO_PROF_BEGIN("rs_iter", st);
   hipLaunchKernelGGL((k_rs_iter<RC>), dim3((unsigned)((a.c + 3) / 4), (unsigned)a.B), block, 0, st, r);

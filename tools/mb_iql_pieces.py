@@ -2,6 +2,8 @@
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from linear_operator_amd import _hip, kernels as K
+if os.environ.get("LO_LIB_VARIANT"):  # experiments: variants/liblo_amd_<name>.so (tools/build_variant.sh)
+    _hip._LIB_PATH = os.path.join(ROOT, "variants", "liblo_amd_%s.so" % os.environ["LO_LIB_VARIANT"])
 import bench
 dev = torch.device("cuda")
 g = torch.Generator(device=dev); g.manual_seed(77)
