@@ -20,6 +20,7 @@
 //
 // Numerics: fp64 sums in another order (the old kernel's results to ~1e-15 relative before the final rounding to fp32).
 #include <algorithm>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "lo_device.h"
@@ -129,7 +130,34 @@ __global__ __launch_bounds__(R3_TPB, 2) void k_cg_rspace3(OnchipArgs a, PeerOut 
   const bool di_full = a.dinv_mode == LO_DIAG_FULL;
   float* const bw = bst[wave_u];
   float* const dw = dst[wave_u];
+  // HALF of a member's rows (the load instructions 0 .. NI/2 - 1 of every wave) are requested while the PREVIOUS member's
+  // iterations run: the registers the chain leaves free hold them (C of the current member stays for its x pass), the
+  // requests travel while this workgroup would otherwise ask HBM for nothing, and the burst at the start of a member
+  // halves.  pre[] is carried around the member loop; the first member's half is requested here.
+  constexpr int NPF = 8;  // (a quarter of the rows at 32 columns, half at 16, all at 8)
+  f32x4 pre[NPF];
+  auto request = [&](int64_t bm, int tl_, int i_lo, auto cnt, f32x4* dst) {  // load instructions i_lo .. i_lo + cnt - 1 of member bm
+    const int ln_ = tl_ & 63, k_ = ln_ & (CH - 1), g_ = ln_ / CH;
+    const unsigned loff = (unsigned)((g_ * RC + 4 * k_) * sizeof(float));
+    g_cc* Cw = (g_cc*)(a.C + ((size_t)bm * a.N + row0c) * RC);
+#pragma unroll
+    for (int q = 0; q < decltype(cnt)::value / 8; ++q) {
+      g_cc* bq = opaque_uniform(Cw + (i_lo + 8 * q + 4) * 1024);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dst[8 * q + i] = *(g_cf4*)(bq + loff + (i - 4) * 1024);
+    }
+  };
   int64_t b = grp;
+  {
+    int tl0 = t;
+    asm volatile("" : "+v"(tl0));
+    if (b < a.B) {
+      request(b, tl0, 0, std::integral_constant<int, NPF>{}, pre);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) pre[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
   while (b < a.B) {
     const bool stamp = a.dbg && b == a.dbg_member && wig == 0 && t == 0;
     if (stamp) a.dbg[0] = wall_clock64();
@@ -140,16 +168,9 @@ __global__ __launch_bounds__(R3_TPB, 2) void k_cg_rspace3(OnchipArgs a, PeerOut 
     const int ln = tl & 63, k = ln & (CH - 1), g = ln / CH;
     // ---- every request of the member in flight before anything waits ----
     f32x4 Cr[NI];
-    {
-      const unsigned loff = (unsigned)((g * RC + 4 * k) * sizeof(float));
-      g_cc* Cw = (g_cc*)(a.C + ((size_t)b * a.N + row0c) * RC);
 #pragma unroll
-      for (int q = 0; q < NI / 8; ++q) {
-        g_cc* bq = opaque_uniform(Cw + (8 * q + 4) * 1024);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) Cr[8 * q + i] = *(g_cf4*)(bq + loff + (i - 4) * 1024);
-      }
-    }
+    for (int i = 0; i < NPF; ++i) Cr[i] = pre[i];   // (requested during the previous member's iterations)
+    request(b, tl, NPF, std::integral_constant<int, NI - NPF>{}, Cr + NPF);
     float bq4[4], dq4[4];
     {
       g_cf* bb_ = opaque_uniform((g_cf*)(a.rhs + (size_t)b * a.N + row0c));
@@ -242,8 +263,12 @@ __global__ __launch_bounds__(R3_TPB, 2) void k_cg_rspace3(OnchipArgs a, PeerOut 
         red[wave_u][2 * RC + 1] = asum;
         red[wave_u][2 * RC + 2] = (wig == 0 && wave_u == 0) ? (double)(ngroups + drawn) : 0.0;
         red[wave_u][2 * RC + 3] = d2sum;
-        red[wave_u][2 * RC + 4] = (first && wave_u == 0) ? (double)xcc : 0.0;
-        red[wave_u][2 * RC + 5] = (first && wave_u == 0) ? (double)(xcc * xcc) : 0.0;
+        // (loop invariants that are cheaper to form than to keep: opaque copies, or they are spilled around the loop and
+        //  their reload waits behind every request in flight)
+        unsigned xc = xcc;
+        asm volatile("" : "+s"(xc));
+        red[wave_u][2 * RC + 4] = (first && wave_u == 0) ? (double)xc : 0.0;
+        red[wave_u][2 * RC + 5] = (first && wave_u == 0) ? (double)(xc * xc) : 0.0;
       }
     }
     // (opaque to value numbering: otherwise the fp64 conversions of the rows are kept -- and spilled -- for the last pass)
@@ -315,12 +340,24 @@ __global__ __launch_bounds__(R3_TPB, 2) void k_cg_rspace3(OnchipArgs a, PeerOut 
       __syncthreads();
     }
     if (GW > 1 && first) {  // placement check (see k_cg_onchip4): plain-store hand-off only when the group shares an XCD
-      const double fx = (double)xcc;
+      unsigned xc = xcc;
+      asm volatile("" : "+s"(xc));
+      const double fx = (double)xc;
       same_xcd = (res[2 * RC + 4] == GW * fx) && (res[2 * RC + 5] == GW * fx * fx) && (a.allow_l2_handoff != 0);
     }
     first = false;
     if (stamp) a.dbg[2] = wall_clock64();
     const int64_t b_next = (int64_t)res[2 * RC + 2];
+    {
+      int tp = t;
+      asm volatile("" : "+v"(tp));
+      if (b_next < a.B) {
+        request(b_next, tp, 0, std::integral_constant<int, NPF>{}, pre);
+      } else {  // (defined on both paths: no value of the finished members stays live)
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) pre[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
     if (a.prefetch & 1) __builtin_amdgcn_s_setprio(3);
 
     // ---- the iterations: the chain of k_cg_rspace<.., true> (lo_rspace.hip), operation for operation ----
@@ -340,7 +377,9 @@ __global__ __launch_bounds__(R3_TPB, 2) void k_cg_rspace3(OnchipArgs a, PeerOut 
       s *= inv * inv;
       a0 *= inv * inv;
       // r^T r >= r.z / max(dinv) >= r.z / sqrt(sum dinv^2): above this r.z the has_converged mask (:300, 1e-10) cannot hold
-      const double sure_rz = 2.0 * (double)a.stop_after * (double)a.stop_after * sqrt(d2);
+      float sa = a.stop_after;
+      asm volatile("" : "+s"(sa));
+      const double sure_rz = 2.0 * (double)sa * (double)sa * sqrt(d2);
       auto own_row_dot = [&](const double* mrow, const double* vec) {
         double a0_ = 0.0, a1_ = 0.0;
 #pragma unroll
