@@ -136,6 +136,8 @@ __global__ __launch_bounds__(R3_TPB, 2) void k_cg_rspace3(OnchipArgs a, PeerOut 
   // halves.  pre[] is carried around the member loop; the first member's half is requested here.
   constexpr int NPF = 8;  // (a quarter of the rows at 32 columns, half at 16, all at 8)
   f32x4 pre[NPF];
+  constexpr int NXT = NI - NPF;          // the other load instructions: requested while the x pass frees their registers
+  f32x4 nxt[NXT > 0 ? NXT : 1];
   auto request = [&](int64_t bm, int tl_, int i_lo, auto cnt, f32x4* dst) {  // load instructions i_lo .. i_lo + cnt - 1 of member bm
     const int ln_ = tl_ & 63, k_ = ln_ & (CH - 1), g_ = ln_ / CH;
     const unsigned loff = (unsigned)((g_ * RC + 4 * k_) * sizeof(float));
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(R3_TPB, 2) void k_cg_rspace3(OnchipArgs a, PeerOut 
     asm volatile("" : "+v"(tl0));
     if (b < a.B) {
       request(b, tl0, 0, std::integral_constant<int, NPF>{}, pre);
+      request(b, tl0, NPF, std::integral_constant<int, NXT>{}, nxt);
     } else {
 #pragma unroll
       for (int i = 0; i < NPF; ++i) pre[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -170,7 +173,8 @@ __global__ __launch_bounds__(R3_TPB, 2) void k_cg_rspace3(OnchipArgs a, PeerOut 
     f32x4 Cr[NI];
 #pragma unroll
     for (int i = 0; i < NPF; ++i) Cr[i] = pre[i];   // (requested during the previous member's iterations)
-    request(b, tl, NPF, std::integral_constant<int, NI - NPF>{}, Cr + NPF);
+#pragma unroll
+    for (int i = 0; i < NXT; ++i) Cr[NPF + i] = nxt[i];
     float bq4[4], dq4[4];
     {
       g_cf* bb_ = opaque_uniform((g_cf*)(a.rhs + (size_t)b * a.N + row0c));
@@ -555,8 +559,13 @@ __global__ __launch_bounds__(R3_TPB, 2) void k_cg_rspace3(OnchipArgs a, PeerOut 
       const double2 ya = *reinterpret_cast<const double2*>(&myv[4 * k2]);
       const double2 yb = *reinterpret_cast<const double2*>(&myv[4 * k2 + 2]);
       g_f* const xb = opaque_uniform((g_f*)(a.xout + (size_t)b * a.N + row0c));
+      const bool more = b_next < a.B;
+      g_cc* const Cn = (g_cc*)(a.C + ((size_t)(more ? b_next : b) * a.N + row0c) * RC);
+      const unsigned loffn = (unsigned)((g2 * RC + 4 * k2) * sizeof(float));
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
+      for (int js = 0; js < 4; ++js) {
+        constexpr int J0 = NPF / CH;        // first group behind the prefetched instructions
+        const int jj = (js + J0) & 3;       // (compile-time after unrolling)
         double p[CH];
 #pragma unroll
         for (int m = 0; m < CH; ++m) {
@@ -572,6 +581,12 @@ __global__ __launch_bounds__(R3_TPB, 2) void k_cg_rspace3(OnchipArgs a, PeerOut 
           xb[rw] = xval;
           for (int pp = 0; pp < po.n; ++pp)  // (prototype: the gather as peer writes)
             ((g_f*)po.buf[pp])[((size_t)(b + po.member_off)) * a.N + row] = xval;
+        }
+        if (CH * jj >= NPF) {  // the registers of this group are free: the next member's rows of the same instructions
+          g_cc* bqn = opaque_uniform(Cn + (CH * jj + 4) * 1024);
+#pragma unroll
+          for (int m = 0; m < CH; ++m)
+            nxt[CH * jj - NPF + m] = more ? *(g_cf4*)(bqn + loffn + (m - 4) * 1024) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
       }
       __builtin_amdgcn_wave_barrier();
