@@ -89,5 +89,10 @@ cd $R
 timeout 200 python tools/mb_dist_overlap.py > $OUT/dist_overlap.txt 2>&1
 timeout 200 python tools/mb_peer_gather.py > $OUT/peer_gather.txt 2>&1
 timeout 200 python tools/check_lowrank_mv.py --time > $OUT/check_lowrank_mv.txt 2>&1
+# one training step (forward + backward through the operator API) as a kernel timeline with the idle gaps
+cd /tmp; rm -rf /tmp/tl; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python $R/tools/iql_timeline.py train > /dev/null 2>&1
+f=$(find /tmp/tl -name '*kernel_trace.csv' | head -1)
+if [ -n "$f" ]; then timeout 60 python $R/tools/iql_timeline.py parse $f > $OUT/iql_train_timeline.txt; fi
+cd $R
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 ls -la $OUT
