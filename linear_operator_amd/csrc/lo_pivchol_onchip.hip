@@ -41,10 +41,11 @@
 namespace lo {
 
 constexpr int PO_GW = 8;
-constexpr int PO_SLOT = 72;   // granules per workgroup and parity (header + 32 C entries + up to 32 L entries)
+constexpr int PO_SLOT = 72;   // granules per workgroup and parity (header + 32 C entries + up to 32 L entries); also the
+                              // words of a wave's candidate in LDS (header + the 2 x 32 words of its row PAIR)
 constexpr int PO_MAXR = 16;   // up to here: 4 slots of 16 bytes per row (64 KB of L rows, two workgroups per CU)
 constexpr int P4_MAXR = 32;   // above 16: 8 slots of 16 bytes per row (128 KB, one workgroup per CU)
-constexpr int PO_HDR = 4;     // value, position, (unused), error partial
+constexpr int PO_HDR = 4;     // value, position, (k_pc_onchip4, in LDS only: the candidate's row inside its workgroup), error partial
 constexpr unsigned PO_MAXSPIN = 1u << 20;  // ~0.5 s of polling: co-residency was lost (never seen on a dedicated GPU)
 constexpr int PO_INVALID = 0x7fffffff;
 
