@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../linear_operator_amd/csrc"
 name=$1
 mkdir -p build ../../variants
-objs=""
+objs=""  # (the replacement and its object live in build/_variant_*: remove them after an experiment)
 for f in *.hip; do
   o=build/${f%.hip}.o
   if [ "${2:-}" = "$f" ]; then
