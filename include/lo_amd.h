@@ -495,6 +495,12 @@ int lo_bilinear_root_f32(const float* C, const float* U, const float* V, int64_t
 size_t lo_bilinear_kron_workspace_bytes(int64_t B, int64_t n1, int64_t n2, int64_t D);
 int lo_bilinear_kron_f32(const float* K1, const float* K2, const float* U, const float* V, int64_t B, int64_t n1,
                          int64_t n2, int64_t D, float* dK1, float* dK2, void* ws, size_t ws_bytes, void* stream);
+/* out [B,N,R] += U [B,N,D] T [B,D,R] in one pass over `out` (ABI 15): the N-sized product of the pull-back through the
+ * pivoted Cholesky of a root, bar R = G2 (L11^-1 Rm) -- what PivotedCholesky.backward obtains by autograd
+ * (functions/_pivoted_cholesky.py:107-147) -- accumulated onto the gradient the operator's bilinear derivative left in
+ * `out`.  R in {8, 16, 32}, D <= 32; LO_ERR_UNSUPPORTED otherwise (the caller takes the library product).            */
+int lo_root_apply_add_f32(const float* U, const float* T, int64_t B, int64_t N, int64_t D, int64_t R, float* out,
+                          void* stream);
 
 /* ---- shifted MINRES: the reference's second iterative solver -------------------------- */
 /* Replaces linear_operator.utils.minres.minres (utils/minres.py:10-207; update block :210-282): solutions of

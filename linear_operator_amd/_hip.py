@@ -19,7 +19,7 @@ _lib = None
 LO_OP_LOWRANK_DIAG, LO_OP_DENSE_DIAG, LO_OP_KRON_DIAG, LO_OP_CALLBACK, LO_OP_SUM = 0, 1, 2, 3, 4
 LO_MAX_TERMS = 4
 LO_DIAG_NONE, LO_DIAG_FULL, LO_DIAG_CONST = 0, 1, 2
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 LO_ERR_UNSUPPORTED = -4
 LO_FUSED_OK, LO_FUSED_EARLY_STOP, LO_FUSED_CONTINUE, LO_FUSED_TIMEOUT = 0, 1, 2, 3
@@ -46,7 +46,7 @@ EXPORTS = [
     "lo_lanczos_f64_workspace_bytes", "lo_lanczos_tridiag_f64",
     "lo_tridiag_eigh_slq_workspace_bytes", "lo_tridiag_eigh_slq_f32",
     "lo_bilinear_dense_f32", "lo_bilinear_diag_f32", "lo_bilinear_root_workspace_bytes", "lo_bilinear_root_f32",
-    "lo_bilinear_kron_workspace_bytes", "lo_bilinear_kron_f32",
+    "lo_bilinear_kron_workspace_bytes", "lo_bilinear_kron_f32", "lo_root_apply_add_f32",
     "lo_minres_workspace_bytes", "lo_minres_f32",
     "lo_probe_vectors_workspace_bytes", "lo_probe_vectors_f32", "lo_iql_backward_factors_f32",
     "lo_prof_enable", "lo_prof_report", "lo_hbm_triad_f32", "lo_hbm_copy_f32", "lo_hbm_stream_dev", "lo_peer_gather_set",
@@ -323,6 +323,9 @@ def load():
     lib.lo_bilinear_kron_f32.restype = C.c_int
     lib.lo_bilinear_kron_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                          C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, sz, C.c_void_p]
+    lib.lo_root_apply_add_f32.restype = C.c_int
+    lib.lo_root_apply_add_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                          C.c_void_p]
     lib.lo_probe_vectors_workspace_bytes.restype = sz
     lib.lo_probe_vectors_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64]
     lib.lo_probe_vectors_f32.restype = C.c_int

@@ -306,6 +306,76 @@ __global__ __launch_bounds__(kThreads) void k_bil_root_out(const float* __restri
   }
 }
 
+// out[b, n, :] += U[b, n, :] T[b]   (U [B,N,D], T [B,D,R], out [B,N,R] read and written in place): the N-sized step of the
+// pull-back through the pivoted Cholesky of a root (functions/_pivoted_cholesky.py::_dense_root_vjp, bar R = G2 (L11^-1 Rm),
+// the reference's PivotedCholesky.backward :107-147 by autograd) ADDED to the gradient the operator's own bilinear
+// derivative has already left in `out` -- one pass (U once, out once in, once out) instead of a library GEMM with N x D x R
+// of work in a [N x D] [D x R] shape it runs at 1.3 TB/s plus an elementwise sum of two [B,N,R] tensors.
+// Layout: the chunk-per-lane layout of lo_lowrank_mv.hip -- lane (g = l / CH, k = l % CH) owns the 16-byte chunk k of the rows
+// RPI i + g of its wave's 256 rows: every load / store of `out` is 1 KiB of consecutive addresses; T's rows of chunk k wait in
+// registers (DP x 4 floats), the wave's rows of U (contiguous in memory) in its own LDS stage.
+template <int RC, int DP>
+__global__ __launch_bounds__(kThreads) void k_root_apply_add(const float* __restrict__ U, const float* __restrict__ T,
+                                                              int N, int D, float* __restrict__ out) {
+  constexpr int CH = RC / 4, RPI = 64 / CH;
+  constexpr int LD = DP + 4;  // row stride of the stage (16-byte rows, the 8 rows of an instruction on different banks)
+  constexpr int SR = DP <= 8 ? 256 : (DP <= 16 ? 128 : 64);  // rows of U staged at a time (<= 40 KB of LDS per workgroup)
+  __shared__ __attribute__((aligned(16))) float ust[4][SR * LD];
+  const int64_t b = blockIdx.y;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int k = lane & (CH - 1), g = lane / CH;
+  const int row0 = blockIdx.x * 1024 + 256 * wave;
+  if (row0 >= N) return;
+  const int nr = min(256, N - row0);
+  float* us = ust[wave];
+  // T's chunk k of every row d (zero beyond D)
+  float4 tw[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d)
+    tw[d] = d < D ? *reinterpret_cast<const float4*>(T + ((size_t)b * D + d) * RC + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float* ob = out + ((size_t)b * N + row0) * RC + 4 * k;
+  const int step_r = 64 / D, step_d = 64 % D;
+  for (int sb = 0; sb < nr; sb += SR) {
+    const int ns = min(SR, nr - sb);
+    // the block's ns x D floats of U are contiguous; (row, column) of element e advanced without divisions
+    {
+      const size_t base = ((size_t)b * N + row0 + sb) * D;
+      int r = lane / D, d = lane % D;
+      for (int e = lane; e < ns * D; e += 64) {
+        us[r * LD + d] = U[base + e];
+        r += step_r;
+        d += step_d;
+        if (d >= D) { d -= D; ++r; }
+      }
+      if (sb == 0)  // columns D .. DP-1 stay zero
+        for (int e = lane; e < SR * (DP - D); e += 64) us[(e / (DP - D)) * LD + D + e % (DP - D)] = 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+    for (int i = 0; i < SR / RPI; ++i) {
+      const int rl = RPI * i + g;  // row inside the staged block
+      if (rl < ns) {
+        float* orow = ob + (size_t)(sb + rl) * RC;
+        float4 acc = *reinterpret_cast<const float4*>(orow);
+#pragma unroll
+        for (int d4 = 0; d4 < DP; d4 += 4) {
+          const float4 u4 = *reinterpret_cast<const float4*>(&us[rl * LD + d4]);
+          const float uu[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc.x = fmaf(uu[j], tw[d4 + j].x, acc.x);
+            acc.y = fmaf(uu[j], tw[d4 + j].y, acc.y);
+            acc.z = fmaf(uu[j], tw[d4 + j].z, acc.z);
+            acc.w = fmaf(uu[j], tw[d4 + j].w, acc.w);
+          }
+        }
+        *reinterpret_cast<float4*>(orow) = acc;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the next block reuses the stage
+  }
+}
+
 }  // namespace lo
 
 using namespace lo;
@@ -384,6 +454,26 @@ int lo_bilinear_root_f32(const float* C, const float* U, const float* V, int64_t
   LO_PROF_BEGIN("bil_root_out", st);
   hipLaunchKernelGGL(k_bil_root_out, dim3((unsigned)((N + 32 * nw - 1) / (32 * nw)), (unsigned)B), dim3(kThreads), lds_o,
                      st, U, V, tpart, sp.S, (int)N, (int)R, (int)D, nw, out, rowdot);
+  LO_PROF_END(st);
+  LO_LAUNCH_CHECK();
+  return LO_OK;
+}
+
+int lo_root_apply_add_f32(const float* U, const float* T, int64_t B, int64_t N, int64_t D, int64_t R, float* out,
+                          void* stream) {
+  if (!U || !T || !out || B < 1 || N < 1 || D < 1 || R < 1 || B > 65535) return LO_ERR_BADARG;
+  if ((R != 8 && R != 16 && R != 32) || D > 32) return LO_ERR_UNSUPPORTED;  // (the caller runs the library product)
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((N + 1023) / 1024), (unsigned)B), block(kThreads);
+  LO_PROF_BEGIN("root_apply_add", st);
+#define LO_RAA(R_, D_) hipLaunchKernelGGL((k_root_apply_add<R_, D_>), grid, block, 0, st, U, T, (int)N, (int)D, out)
+#define LO_RAA_D(R_)                 \
+  if (D <= 8) LO_RAA(R_, 8);         \
+  else if (D <= 16) LO_RAA(R_, 16);  \
+  else LO_RAA(R_, 32)
+  if (R == 32) { LO_RAA_D(32); } else if (R == 16) { LO_RAA_D(16); } else { LO_RAA_D(8); }
+#undef LO_RAA_D
+#undef LO_RAA
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;

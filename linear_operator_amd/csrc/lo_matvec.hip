@@ -205,7 +205,7 @@ using namespace lo;
 
 extern "C" {
 
-int lo_abi_version(void) { return 14; }
+int lo_abi_version(void) { return 15; }
 const char* lo_target_arch(void) { return "gfx950"; }
 
 size_t lo_matvec_workspace_bytes(const lo_op_desc* op, int64_t c) {

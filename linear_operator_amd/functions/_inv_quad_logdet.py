@@ -76,11 +76,14 @@ def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, U, 
             GL = U @ (V.mT @ Lc) + V @ (U.mT @ Lc) + 2.0 * g * pre(Lc)
         else:
             GL = torch.addcmul(K.bilinear_root(Lc, U, V), pre(Lc), 2.0 * g)  # one pass: 2 g P^-1 L + U (V^T L) + V (U^T L)
-        extra = pivoted_cholesky_vjp(linear_op._linear_op, perm, GL, factor=Lc)
+        idxs = range(*op_slice.indices(len(matrix_arg_grads)))
+        # (the gradients of the operator's own bilinear derivative are tensors of this backward: the pull-back may add
+        #  its N-sized part to them in place -- one pass instead of a library GEMM and a sum of two [*, N, R] tensors)
+        extra = pivoted_cholesky_vjp(linear_op._linear_op, perm, GL, factor=Lc,
+                                     accumulate_into=[matrix_arg_grads[i] for i in idxs])
         if extra is not None:
-            idxs = range(*op_slice.indices(len(matrix_arg_grads)))
             for i, e in zip(idxs, extra):
-                if e is not None:
+                if e is not None and e is not matrix_arg_grads[i]:
                     matrix_arg_grads[i] = e if matrix_arg_grads[i] is None else matrix_arg_grads[i] + e
     return matrix_arg_grads
 

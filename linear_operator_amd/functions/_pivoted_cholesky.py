@@ -46,7 +46,7 @@ class PivotedCholesky(Function):
         return tuple([None, None, None] + list(grads))
 
 
-def _dense_root_vjp(r, perm, grad_L, m, factor=None):
+def _dense_root_vjp(r, perm, grad_L, m, factor=None, accumulate_into=None):
     """The same pull-back for K = R R^T written out by hand (a dozen passes over [*, N, m] / [*, N, R] data instead of
     the autograd tape of the generic re-expression); only the m x m Cholesky goes through autograd, so the
     triangular / symmetric conventions of its backward are the ones the generic path (and the reference) get.
@@ -55,7 +55,11 @@ def _dense_root_vjp(r, perm, grad_L, m, factor=None):
       bar Rp = bar Krows Rm,  bar Rm += bar Krows^T Rp   (Krows = Rp Rm^T, Rm = the m pivot rows).
     `factor`: the pivoted-Cholesky factor L [*, N, m] itself when the caller has it (the preconditioner cache does):
     Rest = K21 L11^-T IS its non-pivot rows and L11 its pivot rows, so the N x R x m and N x m x m products that
-    rebuild them are skipped."""
+    rebuild them are skipped.
+    `accumulate_into`: a gradient tensor [*, N, R] of the caller's own that the result is to be ADDED to -- the N-sized
+    product then runs as one in-place pass over it (kernels.root_apply_add) and the tensor itself is returned; when the
+    kernel does not take the operands the result comes back as a new tensor, as without the argument."""
+    from .. import kernels as K
     from ..utils.cholesky import psd_safe_cholesky
 
     R = r.size(-1)
@@ -87,18 +91,23 @@ def _dense_root_vjp(r, perm, grad_L, m, factor=None):
     # bar K[:, pivots] = G2 L11^-1 below the pivots (kb0) and bar K11 on the pivot rows (S); with Krows = R Rm^T
     #   bar R = kb0 Rm + [pivot rows] (S Rm + (kb0 + S)^T R):
     # the N-sized work is ONE product G2 (L11^-1 Rm) and ONE reduction G2^T R, the rest is m x m / m x R algebra
-    r_bar = g2 @ (l11_inv @ rm)
     piv_rows = k11bar @ rm + l11_inv.mT @ (g2.mT @ r) + k11bar.mT @ rm
+    w = l11_inv @ rm
+    if accumulate_into is not None and tuple(accumulate_into.shape) == tuple(r.shape) and K.root_apply_add(g2, w, accumulate_into):
+        return accumulate_into.scatter_add_(-2, idx_r.expand(*accumulate_into.shape[:-2], m, R), piv_rows.expand(*accumulate_into.shape[:-2], m, R))
+    r_bar = g2 @ w
     return r_bar.scatter_add_(-2, idx_r, piv_rows)
 
 
-def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False, factor=None):
+def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False, factor=None, accumulate_into=None):
     """Vector-Jacobian product of the pivoted-Cholesky factor L [*batch, N, m] with respect to the tensors that
     represent `linear_op`, the way PivotedCholesky.backward does it (reference :107-147): re-express the factor of
     the SAME pivots as  Pi^T [chol(K_pp); (chol(K_pp)^-1 K_pr)^T]  with differentiable ATen ops on the m pivot rows
     (m x N data, k x k Cholesky: plumbing, like the reference) and back-propagate grad_L through it.
     Returns one gradient (or None) per tensor of linear_op.representation().  Dense roots take the hand-written
-    pull-back (_dense_root_vjp) unless `generic` asks for the autograd tape (tests compare the two)."""
+    pull-back (_dense_root_vjp) unless `generic` asks for the autograd tape (tests compare the two).
+    `accumulate_into` (one entry per tensor of the representation, or None): gradients of the caller's own that the
+    results are to be added to; an entry that comes back as the SAME tensor has been updated in place."""
     from ..operators.dense_linear_operator import DenseLinearOperator
     from ..operators.root_linear_operator import RootLinearOperator
     from ..utils.cholesky import psd_safe_cholesky
@@ -108,7 +117,8 @@ def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False, fac
     perm = full_permutation
     reps = linear_op.representation()
     if not generic and isinstance(linear_op, RootLinearOperator) and len(reps) == 1 and linear_op._dense_root() is reps[0]:
-        return [_dense_root_vjp(reps[0].detach(), perm, grad_L, m, factor=factor)]
+        acc = accumulate_into[0] if accumulate_into else None
+        return [_dense_root_vjp(reps[0].detach(), perm, grad_L, m, factor=factor, accumulate_into=acc)]
     inv_perm = inverse_permutation(perm)
     leaves = []
     for t in linear_op.representation():

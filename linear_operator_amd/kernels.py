@@ -1257,6 +1257,34 @@ def bilinear_root(root: torch.Tensor, left_vecs: torch.Tensor, right_vecs: torch
     return out.reshape(*bs, N, R)
 
 
+def root_apply_add(U: torch.Tensor, T: torch.Tensor, out: torch.Tensor) -> bool:
+    """lo_root_apply_add_f32: out [*batch, N, R] += U [*batch, N, D] @ T [*batch, D, R] in place, one pass over `out`
+    (the N-sized product of the pull-back through the pivoted Cholesky of a root, functions/_pivoted_cholesky.py).
+    Returns False -- nothing touched -- when the kernel does not take the operands (the caller runs the library product):
+    not fp32 CUDA, `out` not contiguous or not the whole of its storage (a slice of somebody else's tensor), R not 8 / 16 /
+    32, D > 32, more than 65535 members."""
+    if not (out.is_cuda and out.dtype == torch.float32 and U.dtype == torch.float32 and T.dtype == torch.float32
+            and out.is_contiguous() and out.storage_offset() == 0
+            and out.untyped_storage().nbytes() == out.numel() * 4 and not out.requires_grad) \
+            or os.environ.get("LO_NO_ROOT_APPLY_ADD"):
+        return False
+    *bs, N, R = out.shape
+    D = U.shape[-1]
+    B = 1
+    for x in bs:
+        B *= int(x)
+    if R not in (8, 16, 32) or not 1 <= D <= 32 or not 1 <= B <= 65535 or tuple(U.shape) != (*bs, N, D) \
+            or tuple(T.shape[-2:]) != (D, R):
+        return False
+    lib = _hip.load()
+    _hip.require_hip(out)
+    Uc = U.contiguous()
+    Tc = T.expand(*bs, D, R).contiguous()
+    _hip.check(lib.lo_root_apply_add_f32(_hip.ptr(Uc), _hip.ptr(Tc), B, N, D, R, _hip.ptr(out),
+                                         _hip.stream_ptr(out.device)), "lo_root_apply_add_f32")
+    return True
+
+
 def bilinear_kron(K1: torch.Tensor, K2: torch.Tensor, left_vecs: torch.Tensor, right_vecs: torch.Tensor):
     """lo_bilinear_kron_f32: (dK1, dK2) of sum_d u_d^T (K1 (x) K2) v_d (autograd of the Kronecker matvec)."""
     lib = _hip.load()
