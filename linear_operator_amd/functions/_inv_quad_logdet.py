@@ -80,7 +80,7 @@ def _add_preconditioner_terms(ctx, linear_op, matrix_arg_grads, matrix_args, U, 
         # (the gradients of the operator's own bilinear derivative are tensors of this backward: the pull-back may add
         #  its N-sized part to them in place -- one pass instead of a library GEMM and a sum of two [*, N, R] tensors)
         extra = pivoted_cholesky_vjp(linear_op._linear_op, perm, GL, factor=Lc,
-                                     accumulate_into=[matrix_arg_grads[i] for i in idxs])
+                                     accumulate_into=[matrix_arg_grads[i] for i in idxs], consume_grad=True)
         if extra is not None:
             for i, e in zip(idxs, extra):
                 if e is not None and e is not matrix_arg_grads[i]:

@@ -46,7 +46,7 @@ class PivotedCholesky(Function):
         return tuple([None, None, None] + list(grads))
 
 
-def _dense_root_vjp(r, perm, grad_L, m, factor=None, accumulate_into=None):
+def _dense_root_vjp(r, perm, grad_L, m, factor=None, accumulate_into=None, consume_grad=False):
     """The same pull-back for K = R R^T written out by hand (a dozen passes over [*, N, m] / [*, N, R] data instead of
     the autograd tape of the generic re-expression); only the m x m Cholesky goes through autograd, so the
     triangular / symmetric conventions of its backward are the ones the generic path (and the reference) get.
@@ -58,7 +58,9 @@ def _dense_root_vjp(r, perm, grad_L, m, factor=None, accumulate_into=None):
     rebuild them are skipped.
     `accumulate_into`: a gradient tensor [*, N, R] of the caller's own that the result is to be ADDED to -- the N-sized
     product then runs as one in-place pass over it (kernels.root_apply_add) and the tensor itself is returned; when the
-    kernel does not take the operands the result comes back as a new tensor, as without the argument."""
+    kernel does not take the operands the result comes back as a new tensor, as without the argument.
+    `consume_grad`: grad_L is a temporary of the caller's that may be overwritten (its pivot rows are zeroed in place
+    instead of in a copy: one pass over [*, N, m] less)."""
     from .. import kernels as K
     from ..utils.cholesky import psd_safe_cholesky
 
@@ -83,7 +85,8 @@ def _dense_root_vjp(r, perm, grad_L, m, factor=None, accumulate_into=None):
     eye = torch.eye(m, dtype=l11d.dtype, device=l11d.device).expand(*l11d.shape[:-2], m, m)
     l11_inv = torch.linalg.solve_triangular(l11d, eye, upper=False)
     g11 = torch.gather(grad_L, -2, idx_m)
-    g2 = grad_L.scatter(-2, idx_m, 0.0)  # gradient of the non-pivot rows (pivot rows zeroed)
+    # gradient of the non-pivot rows (pivot rows zeroed; g11 above holds them)
+    g2 = grad_L.scatter_(-2, idx_m, 0.0) if consume_grad else grad_L.scatter(-2, idx_m, 0.0)
     if factor is None:
         rest = krows @ l11_inv.mT  # K21 L11^-T (its pivot rows meet zeros of g2 only)
     lbar = g11 - l11_inv.mT @ (g2.mT @ rest)
@@ -99,7 +102,8 @@ def _dense_root_vjp(r, perm, grad_L, m, factor=None, accumulate_into=None):
     return r_bar.scatter_add_(-2, idx_r, piv_rows)
 
 
-def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False, factor=None, accumulate_into=None):
+def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False, factor=None, accumulate_into=None,
+                         consume_grad=False):
     """Vector-Jacobian product of the pivoted-Cholesky factor L [*batch, N, m] with respect to the tensors that
     represent `linear_op`, the way PivotedCholesky.backward does it (reference :107-147): re-express the factor of
     the SAME pivots as  Pi^T [chol(K_pp); (chol(K_pp)^-1 K_pr)^T]  with differentiable ATen ops on the m pivot rows
@@ -107,7 +111,8 @@ def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False, fac
     Returns one gradient (or None) per tensor of linear_op.representation().  Dense roots take the hand-written
     pull-back (_dense_root_vjp) unless `generic` asks for the autograd tape (tests compare the two).
     `accumulate_into` (one entry per tensor of the representation, or None): gradients of the caller's own that the
-    results are to be added to; an entry that comes back as the SAME tensor has been updated in place."""
+    results are to be added to; an entry that comes back as the SAME tensor has been updated in place.
+    `consume_grad`: grad_L is a temporary that may be overwritten."""
     from ..operators.dense_linear_operator import DenseLinearOperator
     from ..operators.root_linear_operator import RootLinearOperator
     from ..utils.cholesky import psd_safe_cholesky
@@ -118,7 +123,8 @@ def pivoted_cholesky_vjp(linear_op, full_permutation, grad_L, generic=False, fac
     reps = linear_op.representation()
     if not generic and isinstance(linear_op, RootLinearOperator) and len(reps) == 1 and linear_op._dense_root() is reps[0]:
         acc = accumulate_into[0] if accumulate_into else None
-        return [_dense_root_vjp(reps[0].detach(), perm, grad_L, m, factor=factor, accumulate_into=acc)]
+        return [_dense_root_vjp(reps[0].detach(), perm, grad_L, m, factor=factor, accumulate_into=acc,
+                                consume_grad=consume_grad)]
     inv_perm = inverse_permutation(perm)
     leaves = []
     for t in linear_op.representation():
