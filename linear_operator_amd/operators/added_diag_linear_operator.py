@@ -281,14 +281,27 @@ class AddedDiagLinearOperator(SumLinearOperator):
         if self._q_cache is None:
             self._piv_chol_self = self._pivoted_cholesky_factor(max_iter)  # :125
             # :126-131 `torch.any(torch.isnan(L))` as one reduction pass: amax propagates NaN, so the maximum is NaN
-            # exactly when some entry is (no boolean tensor of L's size in between)
-            if self._piv_chol_self.numel() and torch.isnan(self._piv_chol_self.amax()).item():
+            # exactly when some entry is (no boolean tensor of L's size in between).  The constant-diagonal test of
+            # _init_cache (:146-150) is evaluated with it: ONE read-back for the two flags instead of two drains of the
+            # stream in a row
+            L = self._piv_chol_self
+            has_nan, constant = False, None
+            if L.numel():
+                nan_t = torch.isnan(L.amax())
+                n = L.shape[-2]
+                noise = self._diag_tensor._diagonal().expand(*L.shape[:-2], n)
+                if L.is_cuda and not (noise.stride(-1) == 0 or n == 1):
+                    both = torch.stack((nan_t, (noise == noise[..., :1]).all())).tolist()
+                    has_nan, constant = bool(both[0]), bool(both[1])
+                else:
+                    has_nan = bool(nan_t.item())
+            if has_nan:
                 warnings.warn(
                     "NaNs encountered in preconditioner computation. Attempting to continue without preconditioning.",
                     NumericalWarning,
                 )
                 return None, None, None
-            self._init_cache()
+            self._init_cache(constant)
             if PRECONDITIONER_MEMO_SIZE > 0 and key is not None:
                 _precond_memo.insert(0, (key, tensors, (self._piv_chol_self, self._piv_chol_perm, self._woodbury,
                                                         self._q_cache, self._precond_logdet_cache, self._constant_diag,
@@ -331,7 +344,8 @@ class AddedDiagLinearOperator(SumLinearOperator):
         self._piv_chol_perm = perm  # needed by the backward pass of the preconditioner terms
         return L
 
-    def _init_cache(self):
+    def _init_cache(self, constant_diag=None):
+        """`constant_diag`: the value of the constant-diagonal test when the caller has already evaluated it."""
         L = self._piv_chol_self
         batch_shape = L.shape[:-2]
         n = L.shape[-2]
@@ -342,6 +356,8 @@ class AddedDiagLinearOperator(SumLinearOperator):
             # a ConstantDiagLinearOperator (homoskedastic noise): the diagonal is an expanded [*batch, 1] tensor, constant
             # by construction -- no comparison kernel and no read-back
             self._constant_diag = True
+        elif constant_diag is not None:
+            self._constant_diag = bool(constant_diag)
         else:
             self._constant_diag = bool(torch.equal(noise, first.expand_as(noise)))
         self._noise = first if self._constant_diag else noise
