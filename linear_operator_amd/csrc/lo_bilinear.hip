@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void k_bil_root_t_mfma(const float* __res
 typedef float bo_f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(kThreads) void k_bil_root_out(const float* __restrict__ U, const float* __restrict__ V,
                                                             const float* __restrict__ tpart, int S, int N, int R,
-                                                            int D, int nw, float* __restrict__ out,
+                                                            int D, int nw, int tiles, float* __restrict__ out,
                                                             float* __restrict__ rowdot) {
   extern __shared__ float sh[];  // t1 [DE][RP] | t2 [DE][RP] | u_s [rows][DP] | v_s [rows][DP]
   const int DE = (D + 1) & ~1;     // k extent, even (the instruction takes two k per step)
@@ -243,8 +243,6 @@ __global__ __launch_bounds__(kThreads) void k_bil_root_out(const float* __restri
   float* u_s = t2 + DE * RP;
   float* v_s = u_s + rows * DP;
   const int64_t b = blockIdx.y;
-  const int row0 = blockIdx.x * rows;
-  const int nr = min(rows, N - row0);
   const int npair = D * R;
   for (int e = threadIdx.x; e < 2 * DE * RP; e += kThreads) {
     const int which = e / (DE * RP), rem = e % (DE * RP), d = rem / RP, rho = rem % RP;
@@ -253,6 +251,14 @@ __global__ __launch_bounds__(kThreads) void k_bil_root_out(const float* __restri
       for (int s = 0; s < S; ++s) acc += tpart[((size_t)b * S + s) * 2 * npair + (size_t)which * npair + d * R + rho];
     sh[e] = acc;
   }
+  // a workgroup forms `tiles` consecutive blocks of `rows` rows with ONE reduction of T1 | T2 (the prologue used to be paid
+  // per 128 rows: 32 768 workgroups of 16 KB of output each at the cfg3 shape)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  for (int tile = 0; tile < tiles; ++tile) {
+  const int row0 = (blockIdx.x * tiles + tile) * rows;
+  if (row0 >= N) break;
+  const int nr = min(rows, N - row0);
+  if (tile) __syncthreads();  // (the last block's products have read the staged rows)
   const size_t base = ((size_t)b * N + row0) * D;
   {  // the nr * D staged floats are contiguous in U / V; (row, column) of element e advanced without divisions
     const int step_r = kThreads / D, step_d = kThreads % D;
@@ -276,13 +282,12 @@ __global__ __launch_bounds__(kThreads) void k_bil_root_out(const float* __restri
     }
   }
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
   if (rowdot && threadIdx.x < nr) {
     float dot = 0.f;
     for (int d = 0; d < D; ++d) dot = fmaf(u_s[threadIdx.x * DP + d], v_s[threadIdx.x * DP + d], dot);
     rowdot[(size_t)b * N + row0 + threadIdx.x] = dot;
   }
-  if (wave >= nw) return;
+  if (wave < nw) {
   const float* ua = u_s + (32 * wave + li) * DP + h;
   const float* va = v_s + (32 * wave + li) * DP + h;
   for (int cb = 0; cb < RP; cb += 32) {
@@ -303,6 +308,8 @@ __global__ __launch_bounds__(kThreads) void k_bil_root_out(const float* __restri
         if (r < nr) out[((size_t)b * N + row0 + r) * R + col] = acc[e];
       }
     }
+  }
+  }
   }
 }
 
@@ -452,8 +459,12 @@ int lo_bilinear_root_f32(const float* C, const float* U, const float* V, int64_t
   }
   if (nw < 1) return LO_ERR_UNSUPPORTED;
   LO_PROF_BEGIN("bil_root_out", st);
-  hipLaunchKernelGGL(k_bil_root_out, dim3((unsigned)((N + 32 * nw - 1) / (32 * nw)), (unsigned)B), dim3(kThreads), lds_o,
-                     st, U, V, tpart, sp.S, (int)N, (int)R, (int)D, nw, out, rowdot);
+  // blocks of 32 nw rows per workgroup: as many as leave ~4 workgroups per CU
+  const int nblk = (int)((N + 32 * nw - 1) / (32 * nw));
+  int tiles = 1;
+  while (tiles < 8 && (int64_t)B * ((nblk + 2 * tiles - 1) / (2 * tiles)) >= 1024) tiles *= 2;
+  hipLaunchKernelGGL(k_bil_root_out, dim3((unsigned)((nblk + tiles - 1) / tiles), (unsigned)B), dim3(kThreads), lds_o,
+                     st, U, V, tpart, sp.S, (int)N, (int)R, (int)D, nw, tiles, out, rowdot);
   LO_PROF_END(st);
   LO_LAUNCH_CHECK();
   return LO_OK;
